@@ -1,0 +1,242 @@
+/*
+ * taseg_hip.h — C ABI of libtaseg_hip.so, the MI355X (gfx950) backend for the
+ * TASeg / OpenPCSeg sparse-convolution hot path.
+ *
+ * Every entry point below replaces one function of the reference's native
+ * backend (the pybind module `torchsparse.backend`, mit-han-lab/torchsparse
+ * v1.4.0 vendored at /root/reference/package/torchsparse.zip; paths below are
+ * relative to the zip member `torchsparse/`) or one tensor-op sequence of its
+ * Python rulebook construction.  The reference interface each one replaces is
+ * cited as file:line.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch / ATen types;
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     nothing here synchronises the host, allocates or frees device memory:
+ *     scratch comes in through (`ws`, `ws_bytes`), sized by the matching
+ *     `*_workspace_bytes()` query;
+ *   - return value: TS_OK (0) or a negative TS_ERR_* code; ts_last_error()
+ *     returns a thread-local message for the last failure (the reference
+ *     throws std::invalid_argument, e.g. convolution_cuda.cu:57-59);
+ *   - coordinates are int32 [N,4] rows (x, y, z, batch)  (utils/collate.py:26-31);
+ *   - features are row-major float32 [N, C].
+ */
+#ifndef TASEG_HIP_H_
+#define TASEG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_OK 0
+#define TS_ERR_INVALID_ARGUMENT (-1)
+#define TS_ERR_WORKSPACE_TOO_SMALL (-2)
+#define TS_ERR_LAUNCH_FAILED (-3)
+#define TS_ERR_UNSUPPORTED (-4)
+
+typedef void *ts_stream_t;
+
+/* Library identity: "taseg_hip <version> gfx950". */
+const char *ts_version(void);
+/* Thread-local message describing the last non-TS_OK return. */
+const char *ts_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* 1. The ten entry points of torchsparse.backend                           */
+/*    (backend/pybind_cuda.cpp:18-39)                                       */
+/* ------------------------------------------------------------------------ */
+
+/* hash_cuda (backend/hash/hash_cuda.cu:10-23,67-73):
+ * out[i] = fold60(FNV-1a-64 over (uint32)x,y,z,b).  coords [n,4], out [n]. */
+int ts_hash(const int32_t *coords, int64_t n, int64_t *out, ts_stream_t stream);
+
+/* kernel_hash_cuda (backend/hash/hash_cuda.cu:27-55,75-84):
+ * out[k*n + i] = hash(x+ox[k], y+oy[k], z+oz[k], b).  offsets [K,3], out [K,n].
+ * The row's own batch index is used (CUDA semantics, hash_cuda.cu:46), not
+ * row 0's as in the CPU twin (hash_cpu.cpp:29). */
+int ts_kernel_hash(const int32_t *coords, int64_t n, const int32_t *offsets,
+                   int32_t n_offsets, int64_t *out, ts_stream_t stream);
+
+/* hash_query_cuda (backend/others/query_cuda.cu:9-56):
+ * out[q] = ref_idx[j] + 1 where ref_hash[j] == query[q], else 0.
+ * ref_idx == NULL means arange(n_ref) (nn/functional/query.py:18-20).
+ * Duplicate reference keys resolve to the smallest j (the CPU twin's
+ * dense_hash_map::insert keeps the first, others/query_cpu.cpp:20-24).
+ * Keys must not be -1 (reserved as the empty slot). */
+size_t ts_hash_query_workspace_bytes(int64_t n_ref);
+int ts_hash_query(const int64_t *query, int64_t n_query, const int64_t *ref_hash,
+                  const int64_t *ref_idx, int64_t n_ref, int64_t *out, void *ws,
+                  size_t ws_bytes, ts_stream_t stream);
+
+/* count_cuda (backend/others/count_cuda.cu:10-31):
+ * out[idx[i]]++ for idx[i] >= 0; out [n_out] is zeroed here first. */
+int ts_count(const int32_t *idx, int64_t n, int32_t *out, int64_t n_out,
+             ts_stream_t stream);
+
+/* voxelize_forward_cuda (backend/voxelize/voxelize_cuda.cu:12-25,43-60):
+ * out[idx[i], :] += feat[i, :] / counts[idx[i]]; out [m,c] is zeroed here. */
+int ts_voxelize_forward(const float *feat, const int32_t *idx, const int32_t *counts,
+                        int64_t n, int32_t c, int64_t m, float *out,
+                        ts_stream_t stream);
+/* voxelize_backward_cuda (voxelize_cuda.cu:28-41,62-80):
+ * grad_feat[i, :] = grad_out[idx[i], :] / counts[idx[i]] (0 for skipped rows). */
+int ts_voxelize_backward(const float *grad_out, const int32_t *idx,
+                         const int32_t *counts, int64_t n, int32_t c, int64_t m,
+                         float *grad_feat, ts_stream_t stream);
+
+/* devoxelize_forward_cuda (backend/devoxelize/devoxelize_cuda.cu:11-33,61-78):
+ * out[i,:] = sum_{k<8} w[i,k] * feat[idx[i,k],:]  (idx<0 contributes 0). */
+int ts_devoxelize_forward(const float *feat, const int32_t *idx, const float *weight,
+                          int64_t n, int32_t c, int64_t m, float *out,
+                          ts_stream_t stream);
+/* devoxelize_backward_cuda (devoxelize_cuda.cu:37-57,82-98): the exact adjoint,
+ * grad_feat[idx[i,k],:] += w[i,k] * grad_out[i,:]; grad_feat [m,c] zeroed here. */
+int ts_devoxelize_backward(const float *grad_out, const int32_t *idx,
+                           const float *weight, int64_t n, int32_t c, int64_t m,
+                           float *grad_feat, ts_stream_t stream);
+
+/* convolution_forward_cuda (backend/convolution/convolution_cuda.cu:53-165):
+ * out[o,:] = sum_k sum_{(i,o) in map_k} in[i,:] @ kernel[k]   (out is overwritten).
+ * nbmap [P,2] int32 rows (in_idx, out_idx) grouped by offset k in order;
+ * nbsizes_host [K] int32 on the HOST, exactly as the reference passes it
+ * (nn/functional/conv.py:56).  transpose swaps the two map columns
+ * (convolution_cuda.cu:21,34).  kernel is [K, c_in, c_out]. */
+size_t ts_convolution_workspace_bytes(int64_t n_in, int64_t n_out, int32_t c_in,
+                                      int32_t c_out, int32_t kernel_volume);
+int ts_convolution_forward(const float *in_feat, int64_t n_in, int32_t c_in,
+                           float *out_feat, int64_t n_out, int32_t c_out,
+                           const float *kernel, int32_t kernel_volume,
+                           const int32_t *nbmap, const int32_t *nbsizes_host,
+                           int32_t transpose, void *ws, size_t ws_bytes,
+                           ts_stream_t stream);
+/* convolution_backward_cuda (convolution_cuda.cu:167-278):
+ * grad_in = adjoint wrt in_feat, grad_kernel[k] = gather(in)^T @ gather(grad_out);
+ * both outputs are overwritten.  grad_in may be NULL (input needs no grad). */
+int ts_convolution_backward(const float *in_feat, int64_t n_in, int32_t c_in,
+                            float *grad_in, const float *grad_out, int64_t n_out,
+                            int32_t c_out, const float *kernel, float *grad_kernel,
+                            int32_t kernel_volume, const int32_t *nbmap,
+                            const int32_t *nbsizes_host, int32_t transpose, void *ws,
+                            size_t ws_bytes, ts_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Rulebook construction (replaces the Python tensor-op sequences)        */
+/* ------------------------------------------------------------------------ */
+
+/* spdownsample (nn/functional/downsample.py:25-51), the branch taken when
+ * stride[k] in {1, kernel_size[k]}:  c' = trunc(c / s) * s per axis, then the
+ * unique rows in lexicographic (b, x, y, z) order (torch.unique(dim=0) of the
+ * [b,x,y,z] permutation), returned as (x, y, z, b).
+ * out_coords has room for n rows; *out_count (device int32) gets the number
+ * of unique rows.  Supported range: 0 <= b < 1024, -2^17 <= x,y,z < 2^17
+ * (checked on device; *out_count = -1 on violation). */
+size_t ts_downsample_workspace_bytes(int64_t n);
+int ts_downsample(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz,
+                  int32_t *out_coords, int32_t *out_count, void *ws, size_t ws_bytes,
+                  ts_stream_t stream);
+
+/* torch.unique(int64) + position lookup as used by initial_voxelize
+ * (pcseg/model/segmentor/voxel/minkunet/utils.py:16-18):
+ * uniq = ascending unique values of keys (non-negative, < 2^62),
+ * inverse[i] = position of keys[i] in uniq (either output may be NULL),
+ * *out_count (device int32) = number of unique values. */
+size_t ts_unique_workspace_bytes(int64_t n);
+int ts_unique_i64(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *inverse,
+                  int32_t *out_count, void *ws, size_t ws_bytes, ts_stream_t stream);
+
+/* Kernel map construction: F.sphash(in) + F.sphash(out, offsets) +
+ * F.sphashquery + the nonzero()/sum() compaction
+ * (nn/functional/conv.py:156-176).
+ *   nbr      [K, n_out] int32 : index of the input voxel at out_coords[j]+offsets[k], or -1
+ *                               (== `results` of conv.py:166);
+ *   nbr_t    [K, n_in]  int32 : the inverse table (output index j per (k, input i), or -1);
+ *                               may be NULL;
+ *   nbmaps   [K*n_out, 2] int32 capacity: rows (in_idx, out_idx) ordered by (k, out_idx)
+ *                               (== conv.py:169-173); may be NULL together with nboffs;
+ *   nbsizes  [K] int32        : hits per offset (== conv.py:168);
+ *   nboffs   [K+1] int32      : exclusive prefix of nbsizes (nboffs[K] = P). */
+size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int32_t n_offsets);
+int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords,
+                  int64_t n_out, const int32_t *offsets, int32_t n_offsets, int32_t *nbr,
+                  int32_t *nbr_t, int32_t *nbmaps, int32_t *nbsizes, int32_t *nboffs,
+                  void *ws, size_t ws_bytes, ts_stream_t stream);
+
+/* Neighbour table from an explicit rulebook (the reference-form entry points
+ * above go through this): nbr[k, col_out] = col_in for every pair of offset k.
+ * nboffs [K+1] device prefix of the pair counts. */
+int ts_nbr_from_nbmaps(const int32_t *nbmaps, const int32_t *nboffs, int32_t n_offsets,
+                       int32_t col_in, int64_t n_rows, int32_t *nbr, ts_stream_t stream);
+
+/* calc_ti_weights + the 8-corner lookup of voxel_to_point
+ * (pcseg/.../minkunet/utils.py:72-82, nn/functional/devoxelize.py:10-48):
+ * for point p (float [n,4] = x,y,z,b) and voxel grid `vox_coords` at stride s,
+ * idx[i,k] = voxel at floor(p/s)*s + off_k (off = get_kernel_offsets(2, s), x
+ * outermost) or -1, weight[i,k] = trilinear weight, masked and renormalised. */
+size_t ts_trilinear_workspace_bytes(int64_t n_vox);
+int ts_trilinear_map(const float *points, int64_t n_points, const int32_t *vox_coords,
+                     int64_t n_vox, int32_t stride, int32_t *idx, float *weight, void *ws,
+                     size_t ws_bytes, ts_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Sparse convolution on the neighbour table (the production kernels)     */
+/* ------------------------------------------------------------------------ */
+
+/* Output-stationary gather -> MFMA -> write-once convolution.
+ *   out[j, :] = sum_k  in[nbr[k, j], :] @ W_k          (rows with nbr<0 skipped)
+ * weight_transposed == 0: W_k = kernel[k]      ([c_in, c_out], forward);
+ * weight_transposed == 1: W_k = kernel[k]^T    (kernel is [K, c_out, c_in]; this
+ *                         is dgrad: in = grad_out, nbr = the inverse table).
+ * out is overwritten; every row j < n_out is written exactly once. */
+int ts_conv_nbr(const float *in_feat, int64_t n_in, int32_t c_in, const float *kernel,
+                int32_t kernel_volume, int32_t weight_transposed, const int32_t *nbr,
+                float *out_feat, int64_t n_out, int32_t c_out, ts_stream_t stream);
+
+/* Weight gradient:  grad_kernel[k] = sum_{pairs p of k} a[pa_p, :]^T b[pb_p, :]
+ * with (pa, pb) = nbmaps columns (col_a, 1-col_a); a is [*, c_a], b is [*, c_b],
+ * grad_kernel [K, c_a, c_b] is overwritten (zeroed then accumulated). */
+int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
+                  const int32_t *nbmaps, const int32_t *nboffs, int32_t kernel_volume,
+                  int32_t col_a, int64_t max_pairs_per_offset, float *grad_kernel,
+                  ts_stream_t stream);
+
+/* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
+ * 1 = scalar reference kernels (one thread per output element, atomics). */
+void ts_set_conv_impl(int32_t impl);
+
+/* ------------------------------------------------------------------------ */
+/* 4. Host-side data stage moved on device                                   */
+/* ------------------------------------------------------------------------ */
+
+/* Dataset voxelisation, first half (pcseg/data/dataset/semantickitti/semantickitti_voxel.py:119-120,
+ * semantickitti_voxel_ms.py:127-130,151): c = int32(round_half_even(p / voxel_size)) in float32, then
+ * c -= shift.  points [n, point_stride] float32 (x, y, z first); batch_idx [n] int32 or NULL (= 0).
+ * shift_in [n_batch,3] given: subtract it.  shift_in NULL: the per-batch minimum is computed into
+ * mins_out [n_batch,3] and subtracted (pc_ -= pc_.min(0)).  out_coords [n,4] = (x, y, z, b). */
+int ts_voxel_coords(const float *points, int64_t n, int32_t point_stride, float voxel_size,
+                    const int32_t *batch_idx, int32_t n_batch, const int32_t *shift_in,
+                    int32_t *mins_out, int32_t *out_coords, ts_stream_t stream);
+
+/* Dataset voxelisation, second half: sparse_quantize(coords, return_index, return_inverse)
+ * (torchsparse utils/quantize.py:9-46 == np.unique of the ravel key).  coords [n,4] int32 (x,y,z,b):
+ *   out_index   [<=n] : for voxel v (ascending (b,x,y,z)) the index of its FIRST point in input order;
+ *   out_inverse [n]   : voxel id of every point (global over the batch);
+ *   *out_count        : number of voxels (-1 if a coordinate is outside [-2^17, 2^17) or b >= 1024). */
+size_t ts_quantize_workspace_bytes(int64_t n);
+int ts_sparse_quantize(const int32_t *coords, int64_t n, int32_t *out_index, int32_t *out_inverse,
+                       int32_t *out_count, void *ws, size_t ws_bytes, ts_stream_t stream);
+
+/* fuse_multi_scan (pcseg/data/dataset/semantickitti/semantickitti_ms.py:403-417):
+ * p' = ((p . R_t^T + t_t) - t_0) . R_0 for one history scan, in float32 with the
+ * reference's summation order; points [n,4] (x,y,z,intensity), pose/pose0 are
+ * 4x4 row-major float32 on the device; out [n,4]. */
+int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose,
+                 float *out, ts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TASEG_HIP_H_ */

@@ -1,0 +1,120 @@
+"""ctypes binding of libtaseg_hip.so (the C ABI declared in include/taseg_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a tensor is
+not on a ROCm device every op raises.  PyTorch is used for device memory and streams
+only; all arithmetic of the hot path happens inside the library's HIP kernels.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtaseg_hip.so")
+
+TS_OK = 0
+_c = ctypes
+_vp, _i64, _i32, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/taseg_hip.h one to one
+SIGNATURES = {
+    "ts_version": (_c.c_char_p, []),
+    "ts_last_error": (_c.c_char_p, []),
+    "ts_hash": (_i32, [_vp, _i64, _vp, _vp]),
+    "ts_kernel_hash": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    "ts_hash_query_workspace_bytes": (_sz, [_i64]),
+    "ts_hash_query": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "ts_count": (_i32, [_vp, _i64, _vp, _i64, _vp]),
+    "ts_voxelize_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ts_voxelize_backward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ts_devoxelize_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ts_devoxelize_backward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ts_convolution_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
+    "ts_convolution_forward": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "ts_convolution_backward": (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32,
+                                       _vp, _sz, _vp]),
+    "ts_downsample_workspace_bytes": (_sz, [_i64]),
+    "ts_downsample": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ts_unique_workspace_bytes": (_sz, [_i64]),
+    "ts_unique_i64": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_build_kmap_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "ts_build_kmap": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_nbr_from_nbmaps": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "ts_trilinear_workspace_bytes": (_sz, [_i64]),
+    "ts_trilinear_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ts_conv_nbr": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
+    "ts_conv_wgrad": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "ts_set_conv_impl": (None, [_i32]),
+    "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "ts_quantize_workspace_bytes": (_sz, [_i64]),
+    "ts_sparse_quantize": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_voxel_coords": (_i32, [_vp, _i64, _i32, _c.c_float, _vp, _i32, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class BackendError(RuntimeError):
+    """A libtaseg_hip entry point returned a TS_ERR_* code."""
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build it with `python -m taseg_amd.csrc.build` "
+                    "(or __graft_entry__.build()).  taseg_amd has no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the .so lags behind the header
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != TS_OK:
+        msg = load().ts_last_error().decode("utf-8", "replace")
+        raise BackendError(f"{what or 'taseg_hip'} failed (code {rc}): {msg}")
+
+
+def require_device(*tensors):
+    """Every tensor handed to the backend must live on a ROCm device."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "taseg_amd: tensor is on '%s'; the HIP backend only accepts ROCm device tensors "
+                "(there is no CPU fallback in the product path)" % t.device)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- per-device scratch buffer handed to the library as (ws, ws_bytes) -------------------
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch: one growing buffer per (device, stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        cap = max(int(nbytes * 1.5), 1 << 20)
+        buf = torch.empty(cap, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

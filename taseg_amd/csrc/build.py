@@ -1,0 +1,61 @@
+"""Build libtaseg_hip.so (gfx950) in-tree with hipcc.  No torch / cmake involved.
+
+    python -m taseg_amd.csrc.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting shared library sits
+next to the package (taseg_amd/libtaseg_hip.so) so it travels with the tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "quantize.hip"]
+LIB = os.path.join(PKG, "libtaseg_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(ROOT, "include")]
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def _deps():
+    return [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "taseg_hip.h"), os.path.abspath(__file__)]
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    jobs = []
+    objs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in _deps()):
+            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr, flush=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,113 @@
+// Shared helpers for libtaseg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "../../include/taseg_hip.h"
+
+#define TS_WAVE 64
+
+void ts_set_error(const char *fmt, ...);
+
+#define TS_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      ts_set_error(__VA_ARGS__);     \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+#define TS_CHECK_LAUNCH(what)                                            \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      ts_set_error("%s: launch failed: %s", what, hipGetErrorString(e_)); \
+      return TS_ERR_LAUNCH_FAILED;                                       \
+    }                                                                    \
+  } while (0)
+
+#define TS_CHECK_HIP(expr, what)                                      \
+  do {                                                                \
+    hipError_t e_ = (expr);                                           \
+    if (e_ != hipSuccess) {                                           \
+      ts_set_error("%s: %s", what, hipGetErrorString(e_));            \
+      return TS_ERR_LAUNCH_FAILED;                                    \
+    }                                                                 \
+  } while (0)
+
+static inline size_t ts_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline int64_t ts_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// FNV-1a-64 over the four coordinates, folded to 60 bits
+// (reference: backend/hash/hash_cuda.cu:15-20).
+__device__ __forceinline__ uint64_t ts_fnv60(int x, int y, int z, int b) {
+  uint64_t h = 14695981039346656037ULL;
+  h ^= (uint32_t)x;
+  h *= 1099511628211ULL;
+  h ^= (uint32_t)y;
+  h *= 1099511628211ULL;
+  h ^= (uint32_t)z;
+  h *= 1099511628211ULL;
+  h ^= (uint32_t)b;
+  h *= 1099511628211ULL;
+  return (h >> 60) ^ (h & 0x0FFFFFFFFFFFFFFFULL);
+}
+
+// ---- open-addressing hash table {uint64 key -> int32 value} -------------------
+// keys[cap] (empty = ~0), vals[cap] (init INT_MAX-ish so atomicMin keeps the
+// smallest position for duplicate keys).  cap is a power of two >= 2*n.
+#define TS_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
+
+struct TsTable {
+  unsigned long long *keys;
+  int *vals;
+  uint32_t mask;
+};
+
+static inline uint32_t ts_table_capacity(int64_t n) {
+  uint64_t cap = 1024;
+  while (cap < (uint64_t)(2 * n + 2)) cap <<= 1;
+  return (uint32_t)cap;
+}
+static inline size_t ts_table_bytes(int64_t n) {
+  size_t cap = ts_table_capacity(n);
+  return ts_align_up(cap * 8, 256) + ts_align_up(cap * 4, 256);
+}
+
+__device__ __forceinline__ uint32_t ts_slot0(uint64_t h, uint32_t mask) {
+  // fold the high half in: the low FNV bits alone are fine, this is cheap insurance
+  uint64_t m = h * 0x9E3779B97F4A7C15ULL;
+  return (uint32_t)(m >> 32) & mask;
+}
+
+__device__ __forceinline__ void ts_table_insert(const TsTable &t, uint64_t key, int val) {
+  uint32_t s = ts_slot0(key, t.mask);
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    unsigned long long prev = atomicCAS(&t.keys[s], (unsigned long long)TS_EMPTY_KEY,
+                                        (unsigned long long)key);
+    if (prev == TS_EMPTY_KEY || prev == key) {
+      atomicMin(&t.vals[s], val);
+      return;
+    }
+    s = (s + 1) & t.mask;
+  }
+}
+
+__device__ __forceinline__ int ts_table_find(const TsTable &t, uint64_t key) {
+  uint32_t s = ts_slot0(key, t.mask);
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    unsigned long long k = t.keys[s];
+    if (k == key) return t.vals[s];
+    if (k == TS_EMPTY_KEY) return -1;
+    s = (s + 1) & t.mask;
+  }
+  return -1;
+}
+
+// Carve a table out of a workspace and reset it on `stream`.
+int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream,
+                  size_t *used);

@@ -1,0 +1,460 @@
+// Rulebook construction on device: strided down-sampling (sort + unique),
+// int64 unique/inverse, kernel-map (neighbour table + reference-order pair list),
+// trilinear point<->voxel maps.
+//
+// Reference semantics restated here:
+//   torchsparse nn/functional/downsample.py:25-51, nn/functional/conv.py:156-176,
+//   nn/functional/devoxelize.py:10-48, pcseg/model/segmentor/voxel/minkunet/utils.py:11-36,69-82.
+// Sorting / scanning use rocPRIM device primitives (the AMD-native ones torch itself
+// uses on ROCm); everything coordinate-specific is hand-written below.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ packing
+// (b, x, y, z) -> one uint64 whose unsigned order == lexicographic signed order.
+#define TS_CBIAS (1 << 17)
+#define TS_CMASK ((1u << 18) - 1)
+
+__device__ __forceinline__ bool ts_pack_ok(int x, int y, int z, int b) {
+  return (unsigned)(x + TS_CBIAS) <= TS_CMASK && (unsigned)(y + TS_CBIAS) <= TS_CMASK &&
+         (unsigned)(z + TS_CBIAS) <= TS_CMASK && (unsigned)b < 1024u;
+}
+__device__ __forceinline__ uint64_t ts_pack(int x, int y, int z, int b) {
+  return ((uint64_t)(unsigned)b << 54) | ((uint64_t)(unsigned)(x + TS_CBIAS) << 36) |
+         ((uint64_t)(unsigned)(y + TS_CBIAS) << 18) | (uint64_t)(unsigned)(z + TS_CBIAS);
+}
+__device__ __forceinline__ int4 ts_unpack(uint64_t k) {
+  int4 c;
+  c.w = (int)(k >> 54);
+  c.x = (int)((k >> 36) & TS_CMASK) - TS_CBIAS;
+  c.y = (int)((k >> 18) & TS_CMASK) - TS_CBIAS;
+  c.z = (int)(k & TS_CMASK) - TS_CBIAS;
+  return c;
+}
+
+// ------------------------------------------------------------------ downsample
+__global__ __launch_bounds__(256) void ds_pack_kernel(const int4 *__restrict__ coords, int64_t n, int sx,
+                                                      int sy, int sz, uint64_t *__restrict__ keys,
+                                                      int *__restrict__ err) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    int4 c = coords[i];
+    // trunc(c / s) * s  (C integer division truncates toward zero, like
+    // torch.div(int, int).trunc() on exactly-representable values)
+    int x = (c.x / sx) * sx, y = (c.y / sy) * sy, z = (c.z / sz) * sz;
+    if (!ts_pack_ok(x, y, z, c.w)) *err = 1;
+    keys[i] = ts_pack(x, y, z, c.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void ds_unpack_kernel(const uint64_t *__restrict__ uniq,
+                                                        const unsigned *__restrict__ count,
+                                                        const int *__restrict__ err,
+                                                        int4 *__restrict__ out, int *__restrict__ out_count) {
+  int64_t m = *count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = (*err) ? -1 : (int)m;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < m; i += step) out[i] = ts_unpack(uniq[i]);
+}
+
+static size_t sort_unique_ws_bytes(int64_t n) {
+  // 3 key arrays + counters + generous rocPRIM scratch (verified at run time)
+  size_t nn = (size_t)(n < 1 ? 1 : n);
+  return 3 * ts_align_up(nn * 8, 256) + 256 + ts_align_up(nn * 16 + (4u << 20), 256);
+}
+
+struct SortUniqueWs {
+  uint64_t *a, *b, *u;
+  unsigned *count;
+  int *err;
+  void *tmp;
+  size_t tmp_bytes;
+};
+
+static int carve_sort_unique(SortUniqueWs *w, int64_t n, void *ws, size_t ws_bytes) {
+  TS_REQUIRE(ws && ws_bytes >= sort_unique_ws_bytes(n), TS_ERR_WORKSPACE_TOO_SMALL,
+             "sort/unique: workspace %zu < %zu bytes", ws_bytes, sort_unique_ws_bytes(n));
+  TS_REQUIRE(((uintptr_t)ws & 255) == 0, TS_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+  size_t nn = (size_t)(n < 1 ? 1 : n);
+  size_t kb = ts_align_up(nn * 8, 256);
+  char *p = (char *)ws;
+  w->a = (uint64_t *)p;
+  p += kb;
+  w->b = (uint64_t *)p;
+  p += kb;
+  w->u = (uint64_t *)p;
+  p += kb;
+  w->count = (unsigned *)p;
+  w->err = (int *)(p + 64);
+  p += 256;
+  w->tmp = p;
+  w->tmp_bytes = ws_bytes - (size_t)(p - (char *)ws);
+  return TS_OK;
+}
+
+// keys in w->a  ->  sorted unique keys in w->u, *w->count
+static int sort_unique(SortUniqueWs *w, int64_t n, unsigned end_bit, hipStream_t stream) {
+  size_t need = 0;
+  TS_CHECK_HIP(rocprim::radix_sort_keys(nullptr, need, w->a, w->b, (size_t)n, 0u, end_bit, stream),
+               "radix_sort size query");
+  TS_REQUIRE(need <= w->tmp_bytes, TS_ERR_WORKSPACE_TOO_SMALL, "radix sort scratch %zu > %zu", need, w->tmp_bytes);
+  size_t tb = w->tmp_bytes;
+  TS_CHECK_HIP(rocprim::radix_sort_keys(w->tmp, tb, w->a, w->b, (size_t)n, 0u, end_bit, stream), "radix_sort");
+  need = 0;
+  TS_CHECK_HIP(rocprim::unique(nullptr, need, w->b, w->u, w->count, (size_t)n,
+                               rocprim::equal_to<uint64_t>(), stream),
+               "unique size query");
+  TS_REQUIRE(need <= w->tmp_bytes, TS_ERR_WORKSPACE_TOO_SMALL, "unique scratch %zu > %zu", need, w->tmp_bytes);
+  tb = w->tmp_bytes;
+  TS_CHECK_HIP(rocprim::unique(w->tmp, tb, w->b, w->u, w->count, (size_t)n, rocprim::equal_to<uint64_t>(), stream),
+               "unique");
+  return TS_OK;
+}
+
+extern "C" size_t ts_downsample_workspace_bytes(int64_t n) { return sort_unique_ws_bytes(n); }
+
+extern "C" int ts_downsample(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz,
+                             int32_t *out_coords, int32_t *out_count, void *ws, size_t ws_bytes,
+                             ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && n < (1LL << 31), TS_ERR_INVALID_ARGUMENT, "ts_downsample: bad n");
+  TS_REQUIRE(sx > 0 && sy > 0 && sz > 0, TS_ERR_INVALID_ARGUMENT, "ts_downsample: strides must be positive");
+  TS_REQUIRE(out_count, TS_ERR_INVALID_ARGUMENT, "ts_downsample: null out_count");
+  if (n == 0) {
+    TS_CHECK_HIP(hipMemsetAsync(out_count, 0, 4, stream), "ts_downsample memset");
+    return TS_OK;
+  }
+  TS_REQUIRE(coords && out_coords, TS_ERR_INVALID_ARGUMENT, "ts_downsample: null pointer");
+  TS_REQUIRE(((uintptr_t)coords & 15) == 0 && ((uintptr_t)out_coords & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_downsample: coords must be 16-byte aligned");
+  SortUniqueWs w;
+  int rc = carve_sort_unique(&w, n, ws, ws_bytes);
+  if (rc != TS_OK) return rc;
+  TS_CHECK_HIP(hipMemsetAsync(w.count, 0, 256, stream), "ts_downsample memset");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 2048);
+  ds_pack_kernel<<<grid, 256, 0, stream>>>((const int4 *)coords, n, sx, sy, sz, w.a, w.err);
+  TS_CHECK_LAUNCH("ts_downsample/pack");
+  rc = sort_unique(&w, n, 64, stream);
+  if (rc != TS_OK) return rc;
+  ds_unpack_kernel<<<grid, 256, 0, stream>>>(w.u, w.count, w.err, (int4 *)out_coords, out_count);
+  TS_CHECK_LAUNCH("ts_downsample/unpack");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ unique int64 (+ inverse)
+__global__ __launch_bounds__(256) void uq_copy_kernel(const int64_t *__restrict__ keys, int64_t n,
+                                                      uint64_t *__restrict__ out, int *__restrict__ err) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    int64_t k = keys[i];
+    if (k < 0 || k >= (1LL << 62)) *err = 1;
+    out[i] = (uint64_t)k;
+  }
+}
+
+__global__ __launch_bounds__(256) void uq_insert_kernel(TsTable t, const uint64_t *__restrict__ uniq,
+                                                        const unsigned *__restrict__ count,
+                                                        int64_t *__restrict__ uniq_out) {
+  int64_t m = *count;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < m; i += step) {
+    uint64_t k = uniq[i];
+    if (t.keys) ts_table_insert(t, k, (int)i);
+    if (uniq_out) uniq_out[i] = (int64_t)k;
+  }
+}
+
+__global__ __launch_bounds__(256) void uq_inverse_kernel(TsTable t, const int64_t *__restrict__ keys, int64_t n,
+                                                         const unsigned *__restrict__ count,
+                                                         const int *__restrict__ err, int *__restrict__ inverse,
+                                                         int *__restrict__ out_count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = (*err) ? -1 : (int)(*count);
+  if (!inverse) return;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) inverse[i] = ts_table_find(t, (uint64_t)keys[i]);
+}
+
+extern "C" size_t ts_unique_workspace_bytes(int64_t n) {
+  return sort_unique_ws_bytes(n) + ts_table_bytes(n < 0 ? 0 : n);
+}
+
+extern "C" int ts_unique_i64(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *inverse,
+                             int32_t *out_count, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && n < (1LL << 30), TS_ERR_INVALID_ARGUMENT, "ts_unique_i64: bad n");
+  TS_REQUIRE(out_count, TS_ERR_INVALID_ARGUMENT, "ts_unique_i64: null out_count");
+  if (n == 0) {
+    TS_CHECK_HIP(hipMemsetAsync(out_count, 0, 4, stream), "ts_unique memset");
+    return TS_OK;
+  }
+  TS_REQUIRE(keys, TS_ERR_INVALID_ARGUMENT, "ts_unique_i64: null keys");
+  TS_REQUIRE(ws_bytes >= ts_unique_workspace_bytes(n), TS_ERR_WORKSPACE_TOO_SMALL, "ts_unique_i64: workspace too small");
+  size_t su = sort_unique_ws_bytes(n);
+  SortUniqueWs w;
+  int rc = carve_sort_unique(&w, n, ws, su);
+  if (rc != TS_OK) return rc;
+  TS_CHECK_HIP(hipMemsetAsync(w.count, 0, 256, stream), "ts_unique memset");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 2048);
+  uq_copy_kernel<<<grid, 256, 0, stream>>>(keys, n, w.a, w.err);
+  TS_CHECK_LAUNCH("ts_unique/copy");
+  rc = sort_unique(&w, n, 62, stream);
+  if (rc != TS_OK) return rc;
+  TsTable t{nullptr, nullptr, 0};
+  if (inverse) {
+    rc = ts_table_init(&t, n, (char *)ws + su, ws_bytes - su, stream, nullptr);
+    if (rc != TS_OK) return rc;
+  }
+  uq_insert_kernel<<<grid, 256, 0, stream>>>(t, w.u, w.count, uniq);
+  TS_CHECK_LAUNCH("ts_unique/insert");
+  uq_inverse_kernel<<<grid, 256, 0, stream>>>(t, keys, n, w.count, w.err, inverse, out_count);
+  TS_CHECK_LAUNCH("ts_unique/inverse");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ kernel map
+__global__ __launch_bounds__(256) void table_insert_coords_kernel(TsTable t, const int4 *__restrict__ coords,
+                                                                  int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    int4 c = coords[i];
+    ts_table_insert(t, ts_fnv60(c.x, c.y, c.z, c.w), (int)i);
+  }
+}
+
+#define KM_BLOCK 256
+// One block = 256 consecutive output voxels; every thread keeps its coordinate in
+// registers and probes all K offsets.  nbr stores are coalesced across j for each
+// k; hit counts per (k, block) go through LDS counters.
+__global__ __launch_bounds__(KM_BLOCK) void kmap_probe_kernel(TsTable t, const int4 *__restrict__ out_coords,
+                                                             int64_t n_out, const int *__restrict__ offsets, int K,
+                                                             int *__restrict__ nbr, unsigned *__restrict__ blk_counts,
+                                                             int nblk) {
+  extern __shared__ unsigned lds_cnt[];
+  for (int k = threadIdx.x; k < K; k += KM_BLOCK) lds_cnt[k] = 0;
+  __syncthreads();
+  int64_t j = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+  bool valid = j < n_out;
+  int4 c = valid ? out_coords[j] : make_int4(0, 0, 0, 0);
+  for (int k = 0; k < K; ++k) {
+    int ox = offsets[3 * k], oy = offsets[3 * k + 1], oz = offsets[3 * k + 2];
+    int r = -1;
+    if (valid) {
+      r = ts_table_find(t, ts_fnv60(c.x + ox, c.y + oy, c.z + oz, c.w));
+      nbr[(int64_t)k * n_out + j] = r;
+    }
+    unsigned long long m = __ballot(r >= 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&lds_cnt[k], (unsigned)__popcll(m));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += KM_BLOCK) blk_counts[(int64_t)k * nblk + blockIdx.x] = lds_cnt[k];
+}
+
+__global__ void kmap_sizes_kernel(const unsigned *__restrict__ blk_offs, int K, int nblk, int *__restrict__ nbsizes,
+                                  int *__restrict__ nboffs) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= K) {
+    unsigned o = blk_offs[(int64_t)k * nblk];
+    if (nboffs) nboffs[k] = (int)o;
+    if (k < K && nbsizes) nbsizes[k] = (int)(blk_offs[(int64_t)(k + 1) * nblk] - o);
+  }
+}
+
+// grid (nblk, K): stable compaction of the hits of offset k inside one block of
+// 256 outputs -> pairs (in, out) at blk_offs[k][blk] + rank; also fills the
+// inverse table nbr_t[k][in] = out.
+__global__ __launch_bounds__(KM_BLOCK) void kmap_compact_kernel(const int *__restrict__ nbr, int64_t n_out,
+                                                               int64_t n_in, const unsigned *__restrict__ blk_offs,
+                                                               int nblk, int2 *__restrict__ nbmaps,
+                                                               int *__restrict__ nbr_t) {
+  __shared__ unsigned wave_cnt[KM_BLOCK / 64];
+  int k = blockIdx.y;
+  int64_t j = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+  int r = (j < n_out) ? nbr[(int64_t)k * n_out + j] : -1;
+  bool hit = r >= 0;
+  unsigned long long m = __ballot(hit);
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned rank = (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
+  if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+  __syncthreads();
+  unsigned base = blk_offs[(int64_t)k * nblk + blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+  if (hit) {
+    if (nbmaps) nbmaps[base + rank] = make_int2(r, (int)j);
+    if (nbr_t) nbr_t[(int64_t)k * n_in + r] = (int)j;
+  }
+}
+
+extern "C" size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int32_t K) {
+  int64_t nblk = ts_cdiv(n_out < 1 ? 1 : n_out, KM_BLOCK);
+  size_t cnt = ts_align_up(((size_t)K * nblk + 1) * 4, 256);
+  return ts_table_bytes(n_in < 0 ? 0 : n_in) + 2 * cnt + ts_align_up(cnt + (1u << 20), 256);
+}
+
+extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords, int64_t n_out,
+                             const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t, int32_t *nbmaps,
+                             int32_t *nbsizes, int32_t *nboffs, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n_in >= 0 && n_out >= 0 && K > 0 && K <= 4096, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: bad sizes");
+  TS_REQUIRE(n_in < (1LL << 30) && n_out < (1LL << 30) && (int64_t)K * n_out < (1LL << 31), TS_ERR_UNSUPPORTED,
+             "ts_build_kmap: problem too large for int32 indexing");
+  TS_REQUIRE(offsets && nbr, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: null pointer");
+  TS_REQUIRE(ws_bytes >= ts_build_kmap_workspace_bytes(n_in, n_out, K), TS_ERR_WORKSPACE_TOO_SMALL,
+             "ts_build_kmap: workspace %zu < %zu", ws_bytes, ts_build_kmap_workspace_bytes(n_in, n_out, K));
+  if (nbsizes) TS_CHECK_HIP(hipMemsetAsync(nbsizes, 0, (size_t)K * 4, stream), "kmap memset");
+  if (nboffs) TS_CHECK_HIP(hipMemsetAsync(nboffs, 0, (size_t)(K + 1) * 4, stream), "kmap memset");
+  if (nbr_t && n_in > 0) TS_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * n_in * 4, stream), "kmap memset");
+  if (n_out == 0) return TS_OK;
+  TS_REQUIRE(out_coords && (in_coords || n_in == 0), TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: null coords");
+  TS_REQUIRE(((uintptr_t)in_coords & 15) == 0 && ((uintptr_t)out_coords & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_build_kmap: coords must be 16-byte aligned");
+  TsTable t;
+  size_t used = 0;
+  int rc = ts_table_init(&t, n_in, ws, ws_bytes, stream, &used);
+  if (rc != TS_OK) return rc;
+  int nblk = (int)ts_cdiv(n_out, KM_BLOCK);
+  size_t n_cnt = (size_t)K * nblk + 1;
+  size_t cnt_bytes = ts_align_up(n_cnt * 4, 256);
+  unsigned *blk_counts = (unsigned *)((char *)ws + used);
+  unsigned *blk_offs = (unsigned *)((char *)ws + used + cnt_bytes);
+  void *tmp = (char *)ws + used + 2 * cnt_bytes;
+  size_t tmp_bytes = ws_bytes - used - 2 * cnt_bytes;
+
+  if (n_in > 0) {
+    int grid = (int)std::min<int64_t>(ts_cdiv(n_in, 256), 4096);
+    table_insert_coords_kernel<<<grid, 256, 0, stream>>>(t, (const int4 *)in_coords, n_in);
+    TS_CHECK_LAUNCH("ts_build_kmap/insert");
+  }
+  TS_CHECK_HIP(hipMemsetAsync(blk_counts + (n_cnt - 1), 0, 4, stream), "kmap memset");
+  kmap_probe_kernel<<<nblk, KM_BLOCK, (size_t)K * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
+                                                               blk_counts, nblk);
+  TS_CHECK_LAUNCH("ts_build_kmap/probe");
+  if (!nbmaps && !nbr_t && !nbsizes && !nboffs) return TS_OK;
+  size_t need = 0;
+  TS_CHECK_HIP(rocprim::exclusive_scan(nullptr, need, blk_counts, blk_offs, 0u, n_cnt, rocprim::plus<unsigned>(), stream),
+               "scan size query");
+  TS_REQUIRE(need <= tmp_bytes, TS_ERR_WORKSPACE_TOO_SMALL, "ts_build_kmap: scan scratch %zu > %zu", need, tmp_bytes);
+  TS_CHECK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, blk_counts, blk_offs, 0u, n_cnt, rocprim::plus<unsigned>(), stream),
+               "scan");
+  kmap_sizes_kernel<<<(int)ts_cdiv(K + 1, 256), 256, 0, stream>>>(blk_offs, K, nblk, nbsizes, nboffs);
+  TS_CHECK_LAUNCH("ts_build_kmap/sizes");
+  if (nbmaps || nbr_t) {
+    dim3 grid(nblk, K);
+    kmap_compact_kernel<<<grid, KM_BLOCK, 0, stream>>>(nbr, n_out, n_in, blk_offs, nblk, (int2 *)nbmaps, nbr_t);
+    TS_CHECK_LAUNCH("ts_build_kmap/compact");
+  }
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ nbr from an explicit rulebook
+__global__ __launch_bounds__(256) void nbr_from_nbmaps_kernel(const int2 *__restrict__ nbmaps,
+                                                              const int *__restrict__ nboffs, int K, int col_in,
+                                                              int64_t n_rows, int *__restrict__ nbr) {
+  int k = blockIdx.y;
+  int beg = nboffs[k], end = nboffs[k + 1];
+  for (int p = beg + blockIdx.x * blockDim.x + threadIdx.x; p < end; p += gridDim.x * blockDim.x) {
+    int2 pr = nbmaps[p];
+    int i = col_in ? pr.y : pr.x, o = col_in ? pr.x : pr.y;
+    if (o >= 0 && o < n_rows && i >= 0) nbr[(int64_t)k * n_rows + o] = i;
+  }
+}
+
+extern "C" int ts_nbr_from_nbmaps(const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_in,
+                                  int64_t n_rows, int32_t *nbr, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(K > 0 && n_rows >= 0 && (int64_t)K * n_rows < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
+             "ts_nbr_from_nbmaps: bad sizes");
+  if (n_rows == 0) return TS_OK;
+  TS_REQUIRE(nbmaps && nboffs && nbr, TS_ERR_INVALID_ARGUMENT, "ts_nbr_from_nbmaps: null pointer");
+  TS_CHECK_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)K * n_rows * 4, stream), "nbr memset");
+  dim3 grid((unsigned)std::min<int64_t>(ts_cdiv(n_rows, 256), 1024), K);
+  nbr_from_nbmaps_kernel<<<grid, 256, 0, stream>>>((const int2 *)nbmaps, nboffs, K, col_in ? 1 : 0, n_rows, nbr);
+  TS_CHECK_LAUNCH("ts_nbr_from_nbmaps");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ trilinear map
+__global__ __launch_bounds__(256) void trilinear_kernel(TsTable t, const float4 *__restrict__ pts, int64_t n, int s,
+                                                        int *__restrict__ idx, float *__restrict__ wout) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  const float fs = (float)s;
+  for (; i < n; i += step) {
+    float4 p = pts[i];
+    // utils.py:73-76: floor(z.C[:, :3] / s).int() * s ; batch = z.C[:, -1].int()
+    float fx = floorf(p.x / fs), fy = floorf(p.y / fs), fz = floorf(p.z / fs);
+    int bx = (int)fx * s, by = (int)fy * s, bz = (int)fz * s, b = (int)p.w;
+    // devoxelize.py:14-32 (pf = floor(p / s) * s in float, pc = pf + s)
+    float xf, yf, zf;
+    if (s != 1) {
+      xf = fx * fs;
+      yf = fy * fs;
+      zf = fz * fs;
+    } else {
+      xf = floorf(p.x);
+      yf = floorf(p.y);
+      zf = floorf(p.z);
+    }
+    float xc = xf + fs, yc = yf + fs, zc = zf + fs;
+    float wx[2] = {xc - p.x, p.x - xf}, wy[2] = {yc - p.y, p.y - yf}, wz[2] = {zc - p.z, p.z - zf};
+    int id[8];
+    float w[8];
+    float sum = 0.f;
+    const float s3 = (float)(s * s * s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int ix = (k >> 2) & 1, iy = (k >> 1) & 1, iz = k & 1;  // get_kernel_offsets(2): x outermost
+      id[k] = ts_table_find(t, ts_fnv60(bx + ix * s, by + iy * s, bz + iz * s, b));
+      float v = (wx[ix] * wy[iy]) * wz[iz];
+      if (s != 1) v /= s3;  // w /= scale**3
+      if (id[k] < 0) v = 0.f;
+      w[k] = v;
+      sum += v;
+    }
+    sum += 1e-8f;
+    int4 *ip = (int4 *)(idx + i * 8);
+    ip[0] = make_int4(id[0], id[1], id[2], id[3]);
+    ip[1] = make_int4(id[4], id[5], id[6], id[7]);
+    float4 *wp = (float4 *)(wout + i * 8);
+    wp[0] = make_float4(w[0] / sum, w[1] / sum, w[2] / sum, w[3] / sum);
+    wp[1] = make_float4(w[4] / sum, w[5] / sum, w[6] / sum, w[7] / sum);
+  }
+}
+
+extern "C" size_t ts_trilinear_workspace_bytes(int64_t n_vox) { return ts_table_bytes(n_vox < 0 ? 0 : n_vox); }
+
+extern "C" int ts_trilinear_map(const float *points, int64_t n_points, const int32_t *vox_coords, int64_t n_vox,
+                                int32_t stride, int32_t *idx, float *weight, void *ws, size_t ws_bytes,
+                                ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n_points >= 0 && n_vox >= 0 && stride > 0, TS_ERR_INVALID_ARGUMENT, "ts_trilinear_map: bad sizes");
+  TS_REQUIRE(n_vox < (1LL << 30), TS_ERR_UNSUPPORTED, "ts_trilinear_map: too many voxels");
+  if (n_points == 0) return TS_OK;
+  TS_REQUIRE(points && idx && weight && (vox_coords || n_vox == 0), TS_ERR_INVALID_ARGUMENT,
+             "ts_trilinear_map: null pointer");
+  TS_REQUIRE(((uintptr_t)points & 15) == 0 && ((uintptr_t)vox_coords & 15) == 0 && ((uintptr_t)idx & 15) == 0 &&
+                 ((uintptr_t)weight & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "ts_trilinear_map: pointers must be 16-byte aligned");
+  TsTable t;
+  int rc = ts_table_init(&t, n_vox, ws, ws_bytes, stream, nullptr);
+  if (rc != TS_OK) return rc;
+  if (n_vox > 0) {
+    int grid = (int)std::min<int64_t>(ts_cdiv(n_vox, 256), 4096);
+    table_insert_coords_kernel<<<grid, 256, 0, stream>>>(t, (const int4 *)vox_coords, n_vox);
+    TS_CHECK_LAUNCH("ts_trilinear_map/insert");
+  }
+  int grid = (int)std::min<int64_t>(ts_cdiv(n_points, 256), 4096);
+  trilinear_kernel<<<grid, 256, 0, stream>>>(t, (const float4 *)points, n_points, stride, idx, weight);
+  TS_CHECK_LAUNCH("ts_trilinear_map");
+  return TS_OK;
+}

@@ -1,0 +1,234 @@
+// Point <-> voxel feature transfer and the multi-scan pose fuse.
+// Reference semantics: torchsparse backend/voxelize/voxelize_cuda.cu,
+// backend/devoxelize/devoxelize_cuda.cu (the CUDA files are the authority: the CPU
+// devoxelize backward is buggy), and
+// pcseg/data/dataset/semantickitti/semantickitti_ms.py:403-417.
+//
+// All four feature kernels are HBM-bound row movers: a group of lanes owns one
+// row and walks its channels with 16-byte accesses where C % 4 == 0.
+#include "common.h"
+
+// ------------------------------------------------------------------ voxelize
+// forward: out[idx[i]] += feat[i] / counts[idx[i]]   (float atomics, like the reference)
+__global__ __launch_bounds__(256) void voxelize_fwd_kernel(const float *__restrict__ feat,
+                                                           const int *__restrict__ idx,
+                                                           const int *__restrict__ counts, int64_t n, int c,
+                                                           int64_t m, float *__restrict__ out) {
+  int64_t total = n * c;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    int64_t i = e / c;
+    int j = (int)(e - i * c);
+    int pos = idx[i];
+    if (pos < 0 || pos >= m) continue;
+    int cnt = counts[pos];
+    if (cnt == 0) continue;
+    atomicAdd(&out[(int64_t)pos * c + j], feat[e] / (float)cnt);
+  }
+}
+
+__global__ __launch_bounds__(256) void voxelize_bwd_kernel(const float *__restrict__ gout,
+                                                           const int *__restrict__ idx,
+                                                           const int *__restrict__ counts, int64_t n, int c,
+                                                           int64_t m, float *__restrict__ gfeat) {
+  int64_t total = n * c;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    int64_t i = e / c;
+    int j = (int)(e - i * c);
+    int pos = idx[i];
+    float v = 0.f;
+    if (pos >= 0 && pos < m) {
+      int cnt = counts[pos];
+      if (cnt != 0) v = gout[(int64_t)pos * c + j] / (float)cnt;
+    }
+    gfeat[e] = v;
+  }
+}
+
+extern "C" int ts_voxelize_forward(const float *feat, const int32_t *idx, const int32_t *counts, int64_t n,
+                                   int32_t c, int64_t m, float *out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_voxelize_forward: bad sizes");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(out && counts, TS_ERR_INVALID_ARGUMENT, "ts_voxelize_forward: null pointer");
+  TS_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)m * c * 4, stream), "voxelize memset");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(feat && idx, TS_ERR_INVALID_ARGUMENT, "ts_voxelize_forward: null pointer");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n * c, 256), 8192);
+  voxelize_fwd_kernel<<<grid, 256, 0, stream>>>(feat, idx, counts, n, c, m, out);
+  TS_CHECK_LAUNCH("ts_voxelize_forward");
+  return TS_OK;
+}
+
+extern "C" int ts_voxelize_backward(const float *grad_out, const int32_t *idx, const int32_t *counts, int64_t n,
+                                    int32_t c, int64_t m, float *grad_feat, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_voxelize_backward: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(grad_feat && idx && (m == 0 || (grad_out && counts)), TS_ERR_INVALID_ARGUMENT,
+             "ts_voxelize_backward: null pointer");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n * c, 256), 8192);
+  voxelize_bwd_kernel<<<grid, 256, 0, stream>>>(grad_out, idx, counts, n, c, m, grad_feat);
+  TS_CHECK_LAUNCH("ts_voxelize_backward");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ devoxelize
+// forward: out[i, :] = sum_k w[i,k] * feat[idx[i,k], :], accumulated in k order
+// like the reference's `out += w * f` loop (devoxelize_cuda.cu:26-31).
+// VEC = 4: lane group of (c/4) lanes per point, float4 loads; VEC = 1 generic.
+template <int VEC>
+__global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const float *__restrict__ feat,
+                                                             const int *__restrict__ idx,
+                                                             const float *__restrict__ w, int64_t n, int c,
+                                                             float *__restrict__ out) {
+  const int cv = c / VEC;
+  int64_t total = n * cv;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    int64_t i = e / cv;
+    int j = (int)(e - i * cv) * VEC;
+    const int *ip = idx + i * 8;
+    const float *wp = w + i * 8;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int id = ip[k];
+      float wk = wp[k];
+      if (VEC == 4) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0) f = *(const float4 *)(feat + (int64_t)id * c + j);
+        acc[0] += wk * f.x;
+        acc[1 % VEC] += wk * f.y;
+        acc[2 % VEC] += wk * f.z;
+        acc[3 % VEC] += wk * f.w;
+      } else {
+        float f = 0.f;
+        if (id >= 0) f = feat[(int64_t)id * c + j];
+        acc[0] += wk * f;
+      }
+    }
+    if (VEC == 4) {
+      *(float4 *)(out + i * c + j) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+    } else {
+      out[i * c + j] = acc[0];
+    }
+  }
+}
+
+// backward: gfeat[idx[i,k], :] += w[i,k] * gout[i, :]   (float atomics)
+__global__ __launch_bounds__(256) void devoxelize_bwd_kernel(const float *__restrict__ gout,
+                                                             const int *__restrict__ idx,
+                                                             const float *__restrict__ w, int64_t n, int c,
+                                                             int64_t m, float *__restrict__ gfeat) {
+  int64_t total = n * c;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    int64_t i = e / c;
+    int j = (int)(e - i * c);
+    float g = gout[e];
+    const int *ip = idx + i * 8;
+    const float *wp = w + i * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int id = ip[k];
+      if (id >= 0 && id < m) atomicAdd(&gfeat[(int64_t)id * c + j], wp[k] * g);
+    }
+  }
+}
+
+extern "C" int ts_devoxelize_forward(const float *feat, const int32_t *idx, const float *weight, int64_t n,
+                                     int32_t c, int64_t m, float *out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_forward: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(out && idx && weight && (feat || m == 0), TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_forward: null pointer");
+  bool vec = (c % 4 == 0) && (((uintptr_t)feat & 15) == 0) && (((uintptr_t)out & 15) == 0);
+  if (vec) {
+    int grid = (int)std::min<int64_t>(ts_cdiv(n * (c / 4), 256), 16384);
+    devoxelize_fwd_kernel<4><<<grid, 256, 0, stream>>>(feat, idx, weight, n, c, out);
+  } else {
+    int grid = (int)std::min<int64_t>(ts_cdiv(n * c, 256), 16384);
+    devoxelize_fwd_kernel<1><<<grid, 256, 0, stream>>>(feat, idx, weight, n, c, out);
+  }
+  TS_CHECK_LAUNCH("ts_devoxelize_forward");
+  return TS_OK;
+}
+
+extern "C" int ts_devoxelize_backward(const float *grad_out, const int32_t *idx, const float *weight, int64_t n,
+                                      int32_t c, int64_t m, float *grad_feat, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward: bad sizes");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(grad_feat, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward: null pointer");
+  TS_CHECK_HIP(hipMemsetAsync(grad_feat, 0, (size_t)m * c * 4, stream), "devoxelize memset");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(grad_out && idx && weight, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward: null pointer");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n * c, 256), 16384);
+  devoxelize_bwd_kernel<<<grid, 256, 0, stream>>>(grad_out, idx, weight, n, c, m, grad_feat);
+  TS_CHECK_LAUNCH("ts_devoxelize_backward");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ multi-scan pose fuse
+// new = sum_k hp[k] * pose^T[k][:]  (k = 0..3, summed in k order like np.sum(axis=1));
+// out = sum_k (new - t0)[k] * R0[k][:]  (k = 0..2).  float32 throughout.
+__global__ __launch_bounds__(256) void fuse_scan_kernel(const float4 *__restrict__ pts, int64_t n,
+                                                        const float *__restrict__ pose0,
+                                                        const float *__restrict__ pose, float4 *__restrict__ out) {
+  // 32 wave-uniform scalars
+  float P[16], Q[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    P[i] = pose[i];
+    Q[i] = pose0[i];
+  }
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    float4 p = pts[i];
+    float h[4] = {p.x, p.y, p.z, 1.0f};
+    float nw[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      // (hpoints[:, k, None] * pose.T[k, j]) summed over k;  pose.T[k][j] = pose[j][k]
+      float s = __fmul_rn(h[0], P[j * 4 + 0]);
+      s = __fadd_rn(s, __fmul_rn(h[1], P[j * 4 + 1]));
+      s = __fadd_rn(s, __fmul_rn(h[2], P[j * 4 + 2]));
+      s = __fadd_rn(s, __fmul_rn(h[3], P[j * 4 + 3]));
+      nw[j] = __fsub_rn(s, Q[j * 4 + 3]);  // - pose0[:3, 3]
+    }
+    float o[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      // sum_k new[k] * pose0[:3, :3][k][j]
+      float s = __fmul_rn(nw[0], Q[0 * 4 + j]);
+      s = __fadd_rn(s, __fmul_rn(nw[1], Q[1 * 4 + j]));
+      s = __fadd_rn(s, __fmul_rn(nw[2], Q[2 * 4 + j]));
+      o[j] = s;
+    }
+    out[i] = make_float4(o[0], o[1], o[2], p.w);
+  }
+}
+
+extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose, float *out,
+                            ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARGUMENT, "ts_fuse_scan: n < 0");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(points && pose0 && pose && out, TS_ERR_INVALID_ARGUMENT, "ts_fuse_scan: null pointer");
+  TS_REQUIRE(((uintptr_t)points & 15) == 0 && ((uintptr_t)out & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_fuse_scan: points/out must be 16-byte aligned");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
+  fuse_scan_kernel<<<grid, 256, 0, stream>>>((const float4 *)points, n, pose0, pose, (float4 *)out);
+  TS_CHECK_LAUNCH("ts_fuse_scan");
+  return TS_OK;
+}
