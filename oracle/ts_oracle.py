@@ -1,0 +1,303 @@
+"""CPU ORACLE - test infrastructure, not product code.
+
+A numpy restatement of the reference's algorithm for the TASeg hot path, used only as the
+checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
+taseg_amd/ imports it.  Every function cites the reference lines it follows
+(TS/ = /root/reference/package/torchsparse.zip member torchsparse/, R/ = /root/reference/).
+The CUDA sources are the semantic authority where the reference's CPU twin is buggy
+(SURVEY.md fact 4).
+
+Parity pin: tests/test_oracle_golden.py checks every function here against the golden vectors
+in tests/golden/*.npz, which tests/golden/make_golden.py captured from the real reference
+(its Python + its CPU extension) running in the build container.
+"""
+import numpy as np
+
+FNV_OFFSET = np.uint64(14695981039346656037)
+FNV_PRIME = np.uint64(1099511628211)
+MASK60 = np.uint64(0x0FFFFFFFFFFFFFFF)
+
+
+# --------------------------------------------------------------------------------- hashing
+def sphash(coords, offsets=None):
+    """TS/torchsparse/backend/hash/hash_cuda.cu:10-23 (K1) and :27-55 (K2, output [K, N], the
+    row's own batch index).  coords int32 [N,4] (x,y,z,b); returns int64."""
+    c = np.ascontiguousarray(coords, dtype=np.int32)
+    if offsets is not None:
+        off = np.asarray(offsets, dtype=np.int32)
+        out = np.empty((off.shape[0], c.shape[0]), dtype=np.int64)
+        for k in range(off.shape[0]):
+            ck = c.copy()
+            ck[:, :3] += off[k]
+            out[k] = sphash(ck)
+        return out
+    h = np.full(c.shape[0], FNV_OFFSET, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for j in range(4):
+            h ^= c[:, j].astype(np.uint32).astype(np.uint64)   # (unsigned int) cast of the int32
+            h *= FNV_PRIME                                       # mod 2^64
+    h = (h >> np.uint64(60)) ^ (h & MASK60)
+    return h.astype(np.int64)
+
+
+def sphashquery(queries, references, idx=None):
+    """TS/torchsparse/nn/functional/query.py:8-33 + backend/others/query_cuda.cu:9-56 /
+    query_cpu.cpp:12-37: position (or idx value) of each query hash among the references,
+    -1 on a miss; duplicate reference keys keep the first (dense_hash_map::insert)."""
+    q = np.asarray(queries, dtype=np.int64)
+    r = np.asarray(references, dtype=np.int64)
+    vals = np.arange(r.shape[0], dtype=np.int64) if idx is None else np.asarray(idx, dtype=np.int64)
+    out = np.full(q.size, -1, dtype=np.int64)
+    if r.size:
+        order = np.argsort(r, kind="stable")
+        rs = r[order]
+        pos = np.searchsorted(rs, q.reshape(-1), side="left")
+        pos_c = np.minimum(pos, rs.size - 1)
+        hit = rs[pos_c] == q.reshape(-1)
+        out[hit] = vals[order[pos_c[hit]]]
+    return out.reshape(q.shape)
+
+
+def spcount(idx, n):
+    """TS/torchsparse/backend/others/count_cuda.cu:10-16: histogram of idx >= 0."""
+    idx = np.asarray(idx)
+    return np.bincount(idx[idx >= 0], minlength=n).astype(np.int32)[:n]
+
+
+# --------------------------------------------------------------------------------- voxelize / devoxelize
+def voxelize_forward(feat, idx, counts):
+    """TS/.../voxelize/voxelize_cuda.cu:12-25: out[idx[i]] += feat[i] / counts[idx[i]]."""
+    feat = np.asarray(feat, dtype=np.float32)
+    idx = np.asarray(idx, dtype=np.int64)
+    counts = np.asarray(counts)
+    m = counts.shape[0]
+    out = np.zeros((m, feat.shape[1]), dtype=np.float32)
+    ok = (idx >= 0) & (idx < m)
+    ok[ok] &= counts[idx[ok]] != 0
+    np.add.at(out, idx[ok], feat[ok] / counts[idx[ok]].astype(np.float32)[:, None])
+    return out
+
+
+def voxelize_backward(gout, idx, counts, n):
+    """TS/.../voxelize/voxelize_cuda.cu:28-41: gfeat[i] = gout[idx[i]] / counts[idx[i]]."""
+    gout = np.asarray(gout, dtype=np.float32)
+    idx = np.asarray(idx, dtype=np.int64)
+    counts = np.asarray(counts)
+    out = np.zeros((n, gout.shape[1]), dtype=np.float32)
+    ok = (idx >= 0) & (idx < counts.shape[0])
+    ok[ok] &= counts[idx[ok]] != 0
+    out[ok] = gout[idx[ok]] / counts[idx[ok]].astype(np.float32)[:, None]
+    return out
+
+
+def devoxelize_forward(feat, idx, w):
+    """TS/.../devoxelize/devoxelize_cuda.cu:11-33: out[i] = sum_k w[i,k] * feat[idx[i,k]] in k order."""
+    feat = np.asarray(feat, dtype=np.float32)
+    idx = np.asarray(idx, dtype=np.int64)
+    w = np.asarray(w, dtype=np.float32)
+    out = np.zeros((idx.shape[0], feat.shape[1]), dtype=np.float32)
+    for k in range(8):
+        ok = idx[:, k] >= 0
+        out[ok] += w[ok, k, None] * feat[idx[ok, k]]
+    return out
+
+
+def devoxelize_backward(gout, idx, w, m):
+    """TS/.../devoxelize/devoxelize_cuda.cu:37-57 (the CUDA adjoint; the CPU twin at
+    devoxelize_cpu.cpp:35-59 is wrong): gfeat[idx[i,k]] += w[i,k] * gout[i]."""
+    gout = np.asarray(gout, dtype=np.float32)
+    idx = np.asarray(idx, dtype=np.int64)
+    w = np.asarray(w, dtype=np.float32)
+    out = np.zeros((m, gout.shape[1]), dtype=np.float32)
+    for k in range(8):
+        ok = idx[:, k] >= 0
+        np.add.at(out, idx[ok, k], w[ok, k, None] * gout[ok])
+    return out
+
+
+def calc_ti_weights(coords, idx_query, scale=1):
+    """TS/torchsparse/nn/functional/devoxelize.py:10-48.  coords float [N,>=3], idx_query [8,N];
+    returns float32 [8,N]."""
+    p = np.asarray(coords, dtype=np.float32)[:, :3]
+    s = np.float32(scale)
+    pf = np.floor(p / s) * s if scale != 1 else np.floor(p)
+    pc = pf + s
+    lo, hi = (p - pf).astype(np.float32), (pc - p).astype(np.float32)
+    rows = []
+    for k in range(8):
+        bx, by, bz = (k >> 2) & 1, (k >> 1) & 1, k & 1
+        fx = lo[:, 0] if bx else hi[:, 0]
+        fy = lo[:, 1] if by else hi[:, 1]
+        fz = lo[:, 2] if bz else hi[:, 2]
+        rows.append((fx * fy) * fz)
+    w = np.stack(rows, 0).astype(np.float32)
+    if scale != 1:
+        w = w / np.float32(scale ** 3)
+    w[np.asarray(idx_query) == -1] = 0
+    tot = np.zeros(w.shape[1], dtype=np.float32)
+    for k in range(8):
+        tot = tot + w[k]
+    return (w / (tot + np.float32(1e-8))).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------- rulebook
+def get_kernel_offsets(size, stride=1, dilation=1):
+    """TS/torchsparse/nn/utils/kernel.py:11-32."""
+    tup = lambda v: (v,) * 3 if isinstance(v, int) else tuple(v)  # noqa: E731
+    size, stride, dilation = tup(size), tup(stride), tup(dilation)
+    ax = [np.arange(-size[k] // 2 + 1, size[k] // 2 + 1) * stride[k] * dilation[k] for k in range(3)]
+    if np.prod(size) % 2 == 1:
+        rows = [[x, y, z] for z in ax[2] for y in ax[1] for x in ax[0]]
+    else:
+        rows = [[x, y, z] for x in ax[0] for y in ax[1] for z in ax[2]]
+    return np.array(rows, dtype=np.int32)
+
+
+def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
+    """TS/torchsparse/nn/functional/downsample.py:25-51 (stride in {1, kernel} branch):
+    trunc(c / s) * s, unique rows sorted by (b, x, y, z)."""
+    tup = lambda v: (v,) * 3 if isinstance(v, int) else tuple(v)  # noqa: E731
+    stride, tensor_stride = tup(stride), tup(tensor_stride)
+    step = np.array([stride[k] * tensor_stride[k] for k in range(3)], dtype=np.int64)
+    c = np.asarray(coords, dtype=np.int64).copy()
+    c[:, :3] = np.trunc(c[:, :3] / step).astype(np.int64) * step
+    u = np.unique(c[:, [3, 0, 1, 2]], axis=0)
+    return u[:, [1, 2, 3, 0]].astype(np.int32)
+
+
+def build_kmap(in_coords, out_coords, offsets):
+    """TS/torchsparse/nn/functional/conv.py:160-176: results [K, N_out] (index of the input voxel at
+    out + offset, -1 if none), nbsizes [K], nbmaps [P, 2] = (in, out) ordered by (k, out)."""
+    refs = sphash(in_coords)
+    queries = sphash(out_coords, offsets)
+    results = sphashquery(queries, refs)
+    nbsizes = (results != -1).sum(axis=1)
+    kk, jj = np.nonzero(results != -1)
+    nbmaps = np.stack([results[kk, jj], jj], axis=1).astype(np.int64)
+    return results, nbmaps, nbsizes.astype(np.int64)
+
+
+# --------------------------------------------------------------------------------- convolution
+def conv_forward(feats, weight, nbmaps, nbsizes, sizes, transposed=False):
+    """TS/.../convolution/convolution_cuda.cu:53-165 (per offset: gather, GEMM, scatter-add)."""
+    feats = np.asarray(feats, dtype=np.float32)
+    weight = np.asarray(weight, dtype=np.float32)
+    n_out = sizes[0] if transposed else sizes[1]
+    out = np.zeros((n_out, weight.shape[-1]), dtype=np.float32)
+    a = 0
+    for k in range(weight.shape[0]):
+        b = a + int(nbsizes[k])
+        if b > a:
+            i = nbmaps[a:b, 1 if transposed else 0]
+            o = nbmaps[a:b, 0 if transposed else 1]
+            np.add.at(out, o, feats[i] @ weight[k])
+        a = b
+    return out
+
+
+def conv_backward(feats, weight, gout, nbmaps, nbsizes, transposed=False):
+    """TS/.../convolution/convolution_cuda.cu:167-278: grad_in (scatter of gout W^T) and
+    grad_weight[k] = gather(in)^T gather(gout)."""
+    feats = np.asarray(feats, dtype=np.float32)
+    weight = np.asarray(weight, dtype=np.float32)
+    gout = np.asarray(gout, dtype=np.float32)
+    gin = np.zeros_like(feats)
+    gw = np.zeros_like(weight)
+    a = 0
+    for k in range(weight.shape[0]):
+        b = a + int(nbsizes[k])
+        if b > a:
+            i = nbmaps[a:b, 1 if transposed else 0]
+            o = nbmaps[a:b, 0 if transposed else 1]
+            np.add.at(gin, i, gout[o] @ weight[k].T)
+            gw[k] = feats[i].T @ gout[o]
+        a = b
+    return gin, gw
+
+
+# --------------------------------------------------------------------------------- dataset side
+def ravel_hash(x):
+    """TS/torchsparse/utils/quantize.py:9-21."""
+    x = np.asarray(x)
+    x = (x - x.min(axis=0)).astype(np.uint64)
+    xmax = x.max(axis=0).astype(np.uint64) + np.uint64(1)
+    h = np.zeros(x.shape[0], dtype=np.uint64)
+    for k in range(x.shape[1] - 1):
+        h += x[:, k]
+        h *= xmax[k + 1]
+    return h + x[:, -1]
+
+
+def sparse_quantize(coords):
+    """TS/torchsparse/utils/quantize.py:24-46 with voxel_size=1 on integer coords:
+    (indices of first occurrence per voxel in ascending key order, inverse map)."""
+    _, index, inverse = np.unique(ravel_hash(np.asarray(coords)), return_index=True, return_inverse=True)
+    return index, inverse
+
+
+def voxel_coords(points, voxel_size):
+    """R/pcseg/data/dataset/semantickitti/semantickitti_voxel.py:119: np.round(xyz / vs).astype(int32)
+    (float32 division, round-half-even); the min shift of :120 is left to the caller."""
+    return np.round(np.asarray(points, dtype=np.float32)[:, :3] / np.float32(voxel_size)).astype(np.int32)
+
+
+def fuse_scan(points, pose0, pose):
+    """R/pcseg/data/dataset/semantickitti/semantickitti_ms.py:403-417, float32 throughout,
+    products summed in index order like np.sum(axis=1) over a length-4 / length-3 axis."""
+    points = np.asarray(points, dtype=np.float32)
+    pose0 = np.asarray(pose0, dtype=np.float32)
+    pose = np.asarray(pose, dtype=np.float32)
+    h = np.concatenate([points[:, :3], np.ones_like(points[:, :1])], 1)
+    pt = pose.T
+    new = np.zeros((h.shape[0], 4), dtype=np.float32)
+    for k in range(4):
+        new = new + h[:, k:k + 1] * pt[k][None, :] if k else h[:, k:k + 1] * pt[k][None, :]
+    nc = new[:, :3] - pose0[:3, 3]
+    r0 = pose0[:3, :3]
+    out = nc[:, 0:1] * r0[0][None, :]
+    for k in (1, 2):
+        out = out + nc[:, k:k + 1] * r0[k][None, :]
+    return np.concatenate([out.astype(np.float32), points[:, 3:]], 1)
+
+
+def history_mask(labels_raw, delta, flexible_steps, learning_map_inv):
+    """R/.../semantickitti_ms.py:303-308: keep a history point when its (pseudo-)label's class has a
+    non-zero step that divides |delta|."""
+    mask = np.zeros(len(labels_raw), dtype=bool)
+    for cls, step in enumerate(flexible_steps):
+        if step and abs(delta) % step == 0:
+            mask |= np.asarray(labels_raw) == learning_map_inv[cls]
+    return mask
+
+
+def append_time_flag(n_current, raw_ms):
+    """R/.../semantickitti_ms.py:253-257: column 4 = 1 for the current scan's rows, 0 for history."""
+    flag = np.zeros((len(raw_ms), 1), dtype=raw_ms.dtype)
+    flag[:n_current, 0] = 1
+    return np.concatenate([raw_ms[:, :4], flag, raw_ms[:, 4:]], axis=1)
+
+
+# --------------------------------------------------------------------------------- model glue
+def initial_voxelize_maps(coords_float4, pres, vres):
+    """R/pcseg/model/segmentor/voxel/minkunet/utils.py:11-27: scaled float coords, ascending unique
+    hashes, point->voxel map, counts."""
+    c = np.asarray(coords_float4, dtype=np.float32)
+    scaled = np.concatenate([(c[:, :3] * np.float32(pres)) / np.float32(vres), c[:, 3:4]], 1).astype(np.float32)
+    cell = np.floor(scaled)
+    pc_hash = sphash(cell.astype(np.int32))
+    sparse_hash = np.unique(pc_hash)
+    idx_query = sphashquery(pc_hash, sparse_hash)
+    counts = spcount(idx_query, len(sparse_hash))
+    return scaled, cell, sparse_hash, idx_query, counts
+
+
+def trilinear_map(points_float4, vox_coords, stride):
+    """R/.../minkunet/utils.py:72-82: idx_query [N,8] (int64, -1 = absent) and weights [N,8]."""
+    p = np.asarray(points_float4, dtype=np.float32)
+    s = int(stride)
+    base = np.concatenate([np.floor(p[:, :3] / np.float32(s)).astype(np.int32) * s,
+                           p[:, 3:4].astype(np.int32)], 1)
+    off = get_kernel_offsets(2, s, 1)
+    idx = sphashquery(sphash(base, off), sphash(vox_coords))            # [8, N]
+    w = calc_ti_weights(p, idx, scale=s)
+    return idx.T.copy(), w.T.copy()

@@ -1,0 +1,339 @@
+"""Torch-facing wrappers over the C ABI (include/taseg_hip.h).
+
+Section 1 mirrors the ten functions of the reference's pybind module
+`torchsparse.backend` (TS/torchsparse/backend/pybind_cuda.cpp:18-39) name for name and
+argument for argument, so `torchsparse.nn.functional` code written against the reference
+binds unchanged.  Section 2 exposes the fused rulebook / convolution entry points the
+MI355X design adds.  Tensors must be contiguous ROCm tensors; outputs are allocated with
+torch (memory + stream plumbing only).
+"""
+import torch
+
+from . import _lib as L
+
+__all__ = [
+    "hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda",
+    "voxelize_forward_cuda", "voxelize_backward_cuda",
+    "devoxelize_forward_cuda", "devoxelize_backward_cuda",
+    "convolution_forward_cuda", "convolution_backward_cuda",
+    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
+    "fuse_scan", "voxel_coords", "sparse_quantize", "set_conv_impl",
+]
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype}); the HIP path computes in f32")
+    return t.contiguous()
+
+
+def _i32(t, name):
+    if t.dtype != torch.int32:
+        raise TypeError(f"{name} must be int32 (got {t.dtype})")
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- section 1
+def hash_cuda(idx):
+    """hash_cuda(idx[N,4] int32) -> int64[N]   (hash_cuda.cu:67-73)."""
+    L.require_device(idx)
+    idx = _i32(idx, "coords")
+    assert idx.ndim == 2 and idx.shape[1] == 4, idx.shape
+    out = torch.empty(idx.shape[0], dtype=torch.int64, device=idx.device)
+    L.check(L.load().ts_hash(L.ptr(idx), idx.shape[0], L.ptr(out), L.stream()), "ts_hash")
+    return out
+
+
+def kernel_hash_cuda(idx, kernel_offset):
+    """kernel_hash_cuda(idx[N,4], offsets[K,3]) -> int64[K,N]   (hash_cuda.cu:75-84)."""
+    L.require_device(idx, kernel_offset)
+    idx = _i32(idx, "coords")
+    kernel_offset = _i32(kernel_offset, "offsets")
+    n, k = idx.shape[0], kernel_offset.shape[0]
+    out = torch.empty((k, n), dtype=torch.int64, device=idx.device)
+    L.check(L.load().ts_kernel_hash(L.ptr(idx), n, L.ptr(kernel_offset), k, L.ptr(out), L.stream()),
+            "ts_kernel_hash")
+    return out
+
+
+def hash_query_cuda(hash_query, hash_target, idx_target):
+    """hash_query_cuda(queries, refs, ref_idx) -> int64, 0 = miss else idx+1 (query_cuda.cu:9-56)."""
+    L.require_device(hash_query, hash_target, idx_target)
+    q = hash_query.contiguous()
+    r = hash_target.contiguous()
+    if q.dtype != torch.int64 or r.dtype != torch.int64:
+        raise TypeError("hash_query: hashes must be int64")
+    it = None if idx_target is None else idx_target.contiguous()
+    if it is not None and it.dtype != torch.int64:
+        raise TypeError("hash_query: idx_target must be int64")
+    lib = L.load()
+    nb = lib.ts_hash_query_workspace_bytes(r.numel())
+    ws = L.workspace(nb, q.device)
+    out = torch.empty(q.numel(), dtype=torch.int64, device=q.device)
+    L.check(lib.ts_hash_query(L.ptr(q), q.numel(), L.ptr(r), L.ptr(it), r.numel(), L.ptr(out), L.ptr(ws),
+                              ws.numel(), L.stream()), "ts_hash_query")
+    return out
+
+
+def count_cuda(idx, s):
+    """count_cuda(idx int32[N], s) -> int32[s] histogram of idx >= 0 (count_cuda.cu:24-31)."""
+    L.require_device(idx)
+    idx = _i32(idx, "idx")
+    out = torch.empty(int(s), dtype=torch.int32, device=idx.device)
+    L.check(L.load().ts_count(L.ptr(idx), idx.numel(), L.ptr(out), int(s), L.stream()), "ts_count")
+    return out
+
+
+def voxelize_forward_cuda(inputs, idx, counts):
+    L.require_device(inputs, idx, counts)
+    inputs, idx, counts = _f32(inputs, "inputs"), _i32(idx, "idx"), _i32(counts, "counts")
+    n, c = inputs.shape
+    m = counts.shape[0]
+    out = torch.empty((m, c), dtype=torch.float32, device=inputs.device)
+    L.check(L.load().ts_voxelize_forward(L.ptr(inputs), L.ptr(idx), L.ptr(counts), n, c, m, L.ptr(out), L.stream()),
+            "ts_voxelize_forward")
+    return out
+
+
+def voxelize_backward_cuda(top_grad, idx, counts, n):
+    L.require_device(top_grad, idx, counts)
+    top_grad, idx, counts = _f32(top_grad, "top_grad"), _i32(idx, "idx"), _i32(counts, "counts")
+    m, c = top_grad.shape
+    out = torch.empty((int(n), c), dtype=torch.float32, device=top_grad.device)
+    L.check(L.load().ts_voxelize_backward(L.ptr(top_grad), L.ptr(idx), L.ptr(counts), int(n), c, m, L.ptr(out),
+                                          L.stream()), "ts_voxelize_backward")
+    return out
+
+
+def devoxelize_forward_cuda(feat, indices, weight):
+    L.require_device(feat, indices, weight)
+    feat, indices, weight = _f32(feat, "feat"), _i32(indices, "indices"), _f32(weight, "weight")
+    m, c = feat.shape
+    n = indices.shape[0]
+    assert indices.shape == (n, 8) and weight.shape == (n, 8), (indices.shape, weight.shape)
+    out = torch.empty((n, c), dtype=torch.float32, device=feat.device)
+    L.check(L.load().ts_devoxelize_forward(L.ptr(feat), L.ptr(indices), L.ptr(weight), n, c, m, L.ptr(out),
+                                           L.stream()), "ts_devoxelize_forward")
+    return out
+
+
+def devoxelize_backward_cuda(top_grad, indices, weight, n):
+    L.require_device(top_grad, indices, weight)
+    top_grad, indices, weight = _f32(top_grad, "top_grad"), _i32(indices, "indices"), _f32(weight, "weight")
+    npts, c = top_grad.shape
+    out = torch.empty((int(n), c), dtype=torch.float32, device=top_grad.device)
+    L.check(L.load().ts_devoxelize_backward(L.ptr(top_grad), L.ptr(indices), L.ptr(weight), npts, c, int(n),
+                                            L.ptr(out), L.stream()), "ts_devoxelize_backward")
+    return out
+
+
+def _host_sizes(neighbor_offset):
+    if neighbor_offset.is_cuda:
+        raise RuntimeError("neighbor_offset (nbsizes) must be a host tensor, as in the reference "
+                           "(nn/functional/conv.py:56 passes nbsizes.cpu())")
+    return neighbor_offset.to(torch.int32).contiguous()
+
+
+def convolution_forward_cuda(in_feat, out_feat, kernel, neighbor_map, neighbor_offset, transpose):
+    """Reference-form forward (convolution_cuda.cu:53-165): writes out_feat in place."""
+    L.require_device(in_feat, out_feat, kernel, neighbor_map)
+    if in_feat.shape[1] != kernel.shape[1]:
+        raise ValueError("Input feature size and kernel size mismatch")  # convolution_cuda.cu:57-59
+    in_feat, kernel = _f32(in_feat, "in_feat"), _f32(kernel, "kernel")
+    nbmap = _i32(neighbor_map, "neighbor_map")
+    sizes = _host_sizes(neighbor_offset)
+    assert out_feat.is_contiguous() and out_feat.dtype == torch.float32
+    lib = L.load()
+    k, ci, co = kernel.shape
+    nb = lib.ts_convolution_workspace_bytes(in_feat.shape[0], out_feat.shape[0], ci, co, k)
+    ws = L.workspace(nb, in_feat.device)
+    L.check(lib.ts_convolution_forward(L.ptr(in_feat), in_feat.shape[0], ci, L.ptr(out_feat), out_feat.shape[0], co,
+                                       L.ptr(kernel), k, L.ptr(nbmap), sizes.data_ptr(), int(bool(transpose)),
+                                       L.ptr(ws), ws.numel(), L.stream()), "ts_convolution_forward")
+    return out_feat
+
+
+def convolution_backward_cuda(in_feat, grad_in_feat, grad_out_feat, kernel, grad_kernel, neighbor_map,
+                              neighbor_offset, transpose):
+    """Reference-form backward (convolution_cuda.cu:167-278): fills grad_in_feat / grad_kernel."""
+    L.require_device(in_feat, grad_in_feat, grad_out_feat, kernel, grad_kernel, neighbor_map)
+    in_feat, kernel = _f32(in_feat, "in_feat"), _f32(kernel, "kernel")
+    grad_out_feat = _f32(grad_out_feat, "grad_out_feat")
+    nbmap = _i32(neighbor_map, "neighbor_map")
+    sizes = _host_sizes(neighbor_offset)
+    assert grad_in_feat.is_contiguous() and grad_kernel.is_contiguous()
+    lib = L.load()
+    k, ci, co = kernel.shape
+    nb = lib.ts_convolution_workspace_bytes(in_feat.shape[0], grad_out_feat.shape[0], ci, co, k)
+    ws = L.workspace(nb, in_feat.device)
+    L.check(lib.ts_convolution_backward(L.ptr(in_feat), in_feat.shape[0], ci, L.ptr(grad_in_feat),
+                                        L.ptr(grad_out_feat), grad_out_feat.shape[0], co, L.ptr(kernel),
+                                        L.ptr(grad_kernel), k, L.ptr(nbmap), sizes.data_ptr(),
+                                        int(bool(transpose)), L.ptr(ws), ws.numel(), L.stream()),
+            "ts_convolution_backward")
+
+
+# --------------------------------------------------------------------------- section 2
+def _count_to_host(cnt, what):
+    n = int(cnt.item())  # the one host sync of a rulebook level: the output shape
+    if n < 0:
+        raise ValueError(f"{what}: coordinate outside the supported range "
+                         "(0 <= batch < 1024, -2^17 <= x,y,z < 2^17)")
+    return n
+
+
+def downsample(coords, stride):
+    """spdownsample for stride in {1, kernel_size} (downsample.py:25-51): unique strided coords, (b,x,y,z)-sorted."""
+    L.require_device(coords)
+    coords = _i32(coords, "coords")
+    n = coords.shape[0]
+    lib = L.load()
+    ws = L.workspace(lib.ts_downsample_workspace_bytes(n), coords.device)
+    out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=coords.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=coords.device)
+    sx, sy, sz = (int(s) for s in stride)
+    L.check(lib.ts_downsample(L.ptr(coords), n, sx, sy, sz, L.ptr(out), L.ptr(cnt), L.ptr(ws), ws.numel(),
+                              L.stream()), "ts_downsample")
+    m = _count_to_host(cnt, "downsample")
+    return out[:m]
+
+
+def unique_i64(keys, return_inverse=True):
+    """torch.unique(int64) (+ inverse positions) as initial_voxelize uses it (minkunet/utils.py:16-18)."""
+    L.require_device(keys)
+    keys = keys.contiguous()
+    assert keys.dtype == torch.int64 and keys.ndim == 1
+    n = keys.numel()
+    lib = L.load()
+    ws = L.workspace(lib.ts_unique_workspace_bytes(n), keys.device)
+    uniq = torch.empty(max(n, 1), dtype=torch.int64, device=keys.device)
+    inv = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device) if return_inverse else None
+    cnt = torch.empty(1, dtype=torch.int32, device=keys.device)
+    L.check(lib.ts_unique_i64(L.ptr(keys), n, L.ptr(uniq), L.ptr(inv), L.ptr(cnt), L.ptr(ws), ws.numel(),
+                              L.stream()), "ts_unique_i64")
+    m = int(cnt.item())
+    if m < 0:
+        raise ValueError("unique_i64: keys must be in [0, 2^62)")
+    return (uniq[:m], inv[:n]) if return_inverse else uniq[:m]
+
+
+def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=True):
+    """Neighbour table + reference-order rulebook (conv.py:156-176) in one call, no host sync.
+
+    Returns dict(nbr [K,n_out], nbr_t [K,n_in] | None, nbmaps [K*n_out,2] capacity | None,
+                 nbsizes [K], nboffs [K+1]).
+    """
+    L.require_device(in_coords, out_coords, offsets)
+    in_coords, out_coords, offsets = _i32(in_coords, "in_coords"), _i32(out_coords, "out_coords"), _i32(offsets, "offsets")
+    n_in, n_out, k = in_coords.shape[0], out_coords.shape[0], offsets.shape[0]
+    dev = in_coords.device
+    lib = L.load()
+    ws = L.workspace(lib.ts_build_kmap_workspace_bytes(n_in, n_out, k), dev)
+    nbr = torch.empty((k, n_out), dtype=torch.int32, device=dev)
+    nbr_t = torch.empty((k, n_in), dtype=torch.int32, device=dev) if want_inverse else None
+    nbmaps = torch.empty((max(k * n_out, 1), 2), dtype=torch.int32, device=dev) if want_pairs else None
+    nbsizes = torch.empty(k, dtype=torch.int32, device=dev)
+    nboffs = torch.empty(k + 1, dtype=torch.int32, device=dev)
+    L.check(lib.ts_build_kmap(L.ptr(in_coords), n_in, L.ptr(out_coords), n_out, L.ptr(offsets), k, L.ptr(nbr),
+                              L.ptr(nbr_t), L.ptr(nbmaps), L.ptr(nbsizes), L.ptr(nboffs), L.ptr(ws), ws.numel(),
+                              L.stream()), "ts_build_kmap")
+    return dict(nbr=nbr, nbr_t=nbr_t, nbmaps=nbmaps, nbsizes=nbsizes, nboffs=nboffs)
+
+
+def trilinear_map(points, vox_coords, stride):
+    """8-corner voxel indices and trilinear weights of `voxel_to_point` (minkunet/utils.py:72-82)."""
+    L.require_device(points, vox_coords)
+    points = _f32(points, "points")
+    vox_coords = _i32(vox_coords, "vox_coords")
+    assert points.ndim == 2 and points.shape[1] == 4, points.shape
+    n, m = points.shape[0], vox_coords.shape[0]
+    lib = L.load()
+    ws = L.workspace(lib.ts_trilinear_workspace_bytes(m), points.device)
+    idx = torch.empty((n, 8), dtype=torch.int32, device=points.device)
+    w = torch.empty((n, 8), dtype=torch.float32, device=points.device)
+    L.check(lib.ts_trilinear_map(L.ptr(points), n, L.ptr(vox_coords), m, int(stride), L.ptr(idx), L.ptr(w),
+                                 L.ptr(ws), ws.numel(), L.stream()), "ts_trilinear_map")
+    return idx, w
+
+
+def conv_nbr(in_feat, kernel, nbr, n_out, weight_transposed=False):
+    """out[j] = sum_k in[nbr[k,j]] @ (kernel[k] or kernel[k]^T); every output row written once."""
+    L.require_device(in_feat, kernel, nbr)
+    in_feat, kernel, nbr = _f32(in_feat, "in_feat"), _f32(kernel, "kernel"), _i32(nbr, "nbr")
+    if kernel.ndim != 3:
+        raise ValueError("kernel must be [K, c_in, c_out]")
+    k = kernel.shape[0]
+    c_red, c_out = (kernel.shape[2], kernel.shape[1]) if weight_transposed else (kernel.shape[1], kernel.shape[2])
+    if in_feat.shape[1] != c_red:
+        raise ValueError("Input feature size and kernel size mismatch")
+    if nbr.shape != (k, n_out):
+        raise ValueError(f"neighbour table shape {tuple(nbr.shape)} != {(k, n_out)}")
+    out = torch.empty((n_out, c_out), dtype=torch.float32, device=in_feat.device)
+    L.check(L.load().ts_conv_nbr(L.ptr(in_feat), in_feat.shape[0], c_red, L.ptr(kernel), k,
+                                 1 if weight_transposed else 0, L.ptr(nbr), L.ptr(out), n_out, c_out, L.stream()),
+            "ts_conv_nbr")
+    return out
+
+
+def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
+    """grad_kernel[k] = sum_pairs a[pa]^T b[pb]  ->  [K, c_a, c_b]."""
+    L.require_device(a_feat, b_feat, nbmaps, nboffs)
+    a_feat, b_feat = _f32(a_feat, "a_feat"), _f32(b_feat, "b_feat")
+    nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
+    out = torch.empty((kernel_volume, a_feat.shape[1], b_feat.shape[1]), dtype=torch.float32, device=a_feat.device)
+    L.check(L.load().ts_conv_wgrad(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1], L.ptr(nbmaps),
+                                   L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs), L.ptr(out), L.stream()),
+            "ts_conv_wgrad")
+    return out
+
+
+def set_conv_impl(impl):
+    """0 = MFMA kernels (default), 1 = scalar cross-check kernels."""
+    L.load().ts_set_conv_impl(int(impl))
+
+
+def fuse_scan(points, pose0, pose):
+    """fuse_multi_scan for one history scan (semantickitti_ms.py:403-417); points [n,4] f32."""
+    L.require_device(points, pose0, pose)
+    points, pose0, pose = _f32(points, "points"), _f32(pose0, "pose0"), _f32(pose, "pose")
+    assert points.ndim == 2 and points.shape[1] == 4 and pose0.shape == (4, 4) and pose.shape == (4, 4)
+    out = torch.empty_like(points)
+    L.check(L.load().ts_fuse_scan(L.ptr(points), points.shape[0], L.ptr(pose0), L.ptr(pose), L.ptr(out), L.stream()),
+            "ts_fuse_scan")
+    return out
+
+
+def voxel_coords(points, voxel_size, batch_idx=None, n_batch=1, shift=None):
+    """int32(round(xyz / voxel_size)) minus the per-scan minimum (or a given shift).
+
+    Returns (coords [n,4] int32 = x,y,z,b ; mins [n_batch,3] int32 actually subtracted).
+    """
+    L.require_device(points, batch_idx, shift)
+    points = _f32(points, "points")
+    n = points.shape[0]
+    out = torch.empty((n, 4), dtype=torch.int32, device=points.device)
+    mins = torch.empty((n_batch, 3), dtype=torch.int32, device=points.device) if shift is None else None
+    if batch_idx is not None:
+        batch_idx = _i32(batch_idx, "batch_idx")
+    if shift is not None:
+        shift = _i32(shift, "shift")
+    L.check(L.load().ts_voxel_coords(L.ptr(points), n, points.shape[1], float(voxel_size), L.ptr(batch_idx),
+                                     int(n_batch), L.ptr(shift), L.ptr(mins), L.ptr(out), L.stream()),
+            "ts_voxel_coords")
+    return out, (mins if shift is None else shift)
+
+
+def sparse_quantize(coords):
+    """np.unique-style voxel grouping of int coords [n,4]: (index [m], inverse [n]) int32, m via one sync."""
+    L.require_device(coords)
+    coords = _i32(coords, "coords")
+    n = coords.shape[0]
+    lib = L.load()
+    ws = L.workspace(lib.ts_quantize_workspace_bytes(n), coords.device)
+    index = torch.empty(max(n, 1), dtype=torch.int32, device=coords.device)
+    inverse = torch.empty(max(n, 1), dtype=torch.int32, device=coords.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=coords.device)
+    L.check(lib.ts_sparse_quantize(L.ptr(coords), n, L.ptr(index), L.ptr(inverse), L.ptr(cnt), L.ptr(ws),
+                                   ws.numel(), L.stream()), "ts_sparse_quantize")
+    m = _count_to_host(cnt, "sparse_quantize")
+    return index[:m], inverse[:n]

@@ -1,0 +1,171 @@
+"""Seeded synthetic SemanticKITTI-shaped LiDAR scans + small helpers shared by
+bench.py, the tests and the golden generator.  Pure numpy / torch-CPU, no reference code.
+
+Scene (world frame, metres): ground plane z = -1.73 (road / sidewalk / terrain bands), a star-shaped
+ring of vertical facades at radius r_w(theta) = 14 + 6 sin 3 theta + 4 sin(7 theta + 1) (6 m high:
+building below 2.5 m, vegetation above), and 40 axis-aligned boxes (cars, poles, persons, trunks).
+Sensor: HDL-64E-like, `n_beams` elevations linspace(+2.0, -24.8 deg) x `n_az` azimuth steps, range
+noise N(0, 0.02 m), max range 80 m, then a random drop to exactly `n_points` returns.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+# learning-map class ids used as labels (SemanticKITTI 20-class map)
+CAR, PERSON, ROAD, SIDEWALK, BUILDING, VEGETATION, TRUNK, TERRAIN, POLE = 1, 6, 9, 11, 13, 15, 16, 17, 18
+# reference FSA schedule (tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10_fsa.yaml:17)
+FLEXIBLE_STEPS_KITTI = [0, 0, 2, 2, 2, 2, 2, 2, 2, 0, 4, 4, 4, 0, 4, 0, 2, 4, 2, 2]
+GROUND_Z = -1.73
+
+
+class AttrDict(dict):
+    """The ten-line stand-in for EasyDict the model needs (attribute access + .get)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def make_model_cfg(name="MinkUNet", in_dim=4, cr=1.0, num_layer=(2, 3, 4, 6, 2, 2, 2, 2), if_dist=False, **kw):
+    cfg = AttrDict(NAME=name, IGNORE_LABEL=0, IN_FEATURE_DIM=in_dim, BLOCK="ResBlock", NUM_LAYER=list(num_layer),
+                   PLANES=[32, 32, 64, 128, 256, 256, 128, 96, 96], cr=cr, pres=0.05, vres=0.05, DROPOUT_P=0.0,
+                   LABEL_SMOOTHING=0.1, IF_DIST=if_dist)
+    cfg.update(kw)
+    return cfg
+
+
+def fill_parameters(module, seed=0):
+    """Deterministic parameters that do not depend on construction order: every entry of the
+    state_dict is drawn from a generator seeded by crc32(name) (+ seed).  Scales keep activations O(1)."""
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name, t in sd.items():
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed) % (2 ** 31))
+            if name.endswith("num_batches_tracked"):
+                t.zero_()
+            elif name.endswith("running_var"):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            elif name.endswith("running_mean"):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+            elif name.endswith(".kernel"):
+                fan = t.shape[-2] * (t.shape[0] if t.ndim == 3 else 1)
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (3.0 / fan) ** 0.5)
+            elif t.ndim == 2:  # linear weight
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (3.0 / t.shape[1]) ** 0.5)
+            elif name.endswith("weight"):  # BN gamma
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            else:  # biases
+                t.copy_(torch.randn(t.shape, generator=g) * 0.05)
+    return module
+
+
+def synth_pose(t, step=1.1, yaw_deg=0.4):
+    """Sensor pose (4x4 float32, world <- sensor) `t` frames in the PAST: the ego vehicle drives +x,
+    so frame -t sits at x = -step * t with yaw -yaw_deg * t."""
+    a = np.deg2rad(-yaw_deg * t)
+    c, s = np.cos(a), np.sin(a)
+    pose = np.eye(4, dtype=np.float64)
+    pose[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    pose[0, 3] = -step * t
+    return pose.astype(np.float32)
+
+
+def _wall_radius(theta):
+    return 14.0 + 6.0 * np.sin(3.0 * theta) + 4.0 * np.sin(7.0 * theta + 1.0)
+
+
+def _scene_boxes(scene_seed):
+    rs = np.random.RandomState(scene_seed)
+    kinds = [(CAR, (4.0, 1.8, 1.5), 15), (POLE, (0.3, 0.3, 4.0), 10), (PERSON, (0.6, 0.6, 1.7), 8),
+             (TRUNK, (0.5, 0.5, 3.0), 7)]
+    lo, hi, lab = [], [], []
+    for label, (sx, sy, sz), count in kinds:
+        for _ in range(count):
+            th = rs.uniform(0, 2 * np.pi)
+            r = max(rs.uniform(0.45, 0.9) * _wall_radius(th), 8.0)
+            cx, cy = r * np.cos(th), r * np.sin(th)
+            if rs.rand() < 0.5:
+                sx, sy = sy, sx
+            lo.append([cx - sx / 2, cy - sy / 2, GROUND_Z])
+            hi.append([cx + sx / 2, cy + sy / 2, GROUND_Z + sz])
+            lab.append(label)
+    return np.array(lo), np.array(hi), np.array(lab)
+
+
+def synth_scan(seed, n_points=120000, n_beams=64, n_az=2083, pose=None, scene_seed=None):
+    """One scan in the SENSOR frame: (points [n,4] float32 x,y,z,intensity ; labels [n] uint8).
+
+    `pose` (4x4, world <- sensor) places the sensor in the shared scene so that history scans of
+    the same `scene_seed` see the same static world from a different ego pose."""
+    rs = np.random.RandomState(seed)
+    scene_seed = seed if scene_seed is None else scene_seed
+    pose = np.eye(4) if pose is None else np.asarray(pose, dtype=np.float64)
+    elev = np.deg2rad(np.linspace(2.0, -24.8, n_beams))
+    az = np.arange(n_az) * (2 * np.pi / n_az)
+    el, azg = np.meshgrid(elev, az, indexing="ij")
+    d_s = np.stack([np.cos(el) * np.cos(azg), np.cos(el) * np.sin(azg), np.sin(el)], -1).reshape(-1, 3)
+    d = d_s @ pose[:3, :3].T              # ray directions in the world frame
+    o = pose[:3, 3]
+    n = d.shape[0]
+    t_hit = np.full(n, np.inf)
+    label = np.zeros(n, dtype=np.uint8)
+
+    # ground bands
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = (GROUND_Z - o[2]) / d[:, 2]
+    ok = (d[:, 2] < 0) & (tg > 0)
+    gy = np.abs(o[1] + tg * d[:, 1])
+    glab = np.where(gy < 4.0, ROAD, np.where(gy < 7.0, SIDEWALK, TERRAIN)).astype(np.uint8)
+    t_hit = np.where(ok, tg, t_hit)
+    label = np.where(ok, glab, label)
+
+    # facade ring: march + bisection on f(t) = |p_xy| - r_w(atan2(p_y, p_x))
+    def f(t):
+        px, py = o[0] + t * d[:, 0], o[1] + t * d[:, 1]
+        return np.hypot(px, py) - _wall_radius(np.arctan2(py, px))
+
+    ts = np.linspace(0.0, 80.0, 81)
+    lo_t = np.zeros(n)
+    hi_t = np.full(n, np.nan)
+    prev = f(lo_t)
+    found = np.zeros(n, dtype=bool)
+    for t1 in ts[1:]:
+        cur = f(np.full(n, t1))
+        cross = (~found) & (prev < 0) & (cur >= 0)
+        lo_t = np.where(cross, t1 - 1.0, lo_t)
+        hi_t = np.where(cross, t1, hi_t)
+        found |= cross
+        prev = cur
+    hi_t = np.where(found, hi_t, 0.0)
+    for _ in range(14):
+        mid = 0.5 * (lo_t + hi_t)
+        inside = f(mid) < 0
+        lo_t = np.where(inside, mid, lo_t)
+        hi_t = np.where(inside, hi_t, mid)
+    tw = 0.5 * (lo_t + hi_t)
+    zw = o[2] + tw * d[:, 2]
+    okw = found & (zw >= GROUND_Z) & (zw <= GROUND_Z + 6.0) & (tw < t_hit)
+    t_hit = np.where(okw, tw, t_hit)
+    label = np.where(okw, np.where(zw < GROUND_Z + 4.23, BUILDING, VEGETATION).astype(np.uint8), label)
+
+    # boxes: slab test
+    blo, bhi, blab = _scene_boxes(scene_seed)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+    for b in range(len(blab)):
+        t0 = (blo[b] - o) * inv
+        t1 = (bhi[b] - o) * inv
+        tn = np.nanmax(np.minimum(t0, t1), axis=1)
+        tf = np.nanmin(np.maximum(t0, t1), axis=1)
+        okb = (tn <= tf) & (tn > 0.5) & (tn < t_hit)
+        t_hit = np.where(okb, tn, t_hit)
+        label = np.where(okb, blab[b], label)
+
+    rng = t_hit + rs.normal(0.0, 0.02, n)
+    keep = np.isfinite(t_hit) & (rng < 80.0) & (rng > 1.0)
+    idx = np.nonzero(keep)[0]
+    if len(idx) > n_points:
+        idx = np.sort(rs.choice(idx, n_points, replace=False))
+    pts = d_s[idx] * rng[idx, None]                      # sensor frame
+    inten = rs.uniform(0.0, 1.0, len(idx))
+    out = np.concatenate([pts, inten[:, None]], 1).astype(np.float32)
+    return out, label[idx].astype(np.uint8)

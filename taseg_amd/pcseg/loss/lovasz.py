@@ -1,0 +1,53 @@
+"""Lovasz-softmax loss (Berman et al., CVPR 2018; the reference vendors the authors' MIT-licensed
+PyTorch code at tools/utils/common/lovasz_losses.py:158-227).
+
+Same value as the reference's per-class loop with classes='present', computed for all classes at
+once: ONE batched descending sort of the [P, C] error matrix instead of C sorts, and no
+`fg.sum() == 0` host synchronisation per class.
+"""
+import torch
+
+__all__ = ["lovasz_softmax", "lovasz_softmax_flat"]
+
+
+def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, classes="present") -> torch.Tensor:
+    """probas [P, C] class probabilities, labels [P]; mean over classes of dot(sorted errors, Lovasz grad)."""
+    if probas.numel() == 0:
+        return probas * 0.0
+    num_classes = probas.size(1)
+    cls = torch.arange(num_classes, device=probas.device)
+    fg = (labels.view(-1, 1) == cls.view(1, -1)).to(probas.dtype)          # [P, C] one-hot foreground
+    errors = (fg - probas).abs()
+    errors_sorted, perm = torch.sort(errors, dim=0, descending=True)
+    fg_sorted = torch.gather(fg, 0, perm)
+    # gradient of the Lovasz extension of the Jaccard loss w.r.t. sorted errors (Alg. 1)
+    gts = fg_sorted.sum(dim=0, keepdim=True)
+    intersection = gts - fg_sorted.cumsum(dim=0)
+    union = gts + (1.0 - fg_sorted).cumsum(dim=0)
+    jaccard = 1.0 - intersection / union
+    grad = torch.cat([jaccard[:1], jaccard[1:] - jaccard[:-1]], dim=0)
+    per_class = (errors_sorted * grad).sum(dim=0)                          # [C]
+    if classes == "all":
+        return per_class.mean()
+    if classes == "present":
+        present = (gts.view(-1) > 0).to(per_class.dtype)
+    else:
+        present = torch.zeros_like(per_class)
+        present[list(classes)] = 1.0
+    # mean over the selected classes; 0 when none is selected (the reference's mean of an
+    # empty list with its default `empty=0`)
+    return (per_class * present).sum() / present.sum().clamp(min=1.0)
+
+
+def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=None):
+    """probas [P, C] (already flattened point-wise, as pcseg.loss passes them) and labels [P];
+    rows whose label equals `ignore` are dropped first (lovasz_losses.py:207-227)."""
+    if per_image:
+        raise NotImplementedError("per_image Lovasz is an image-segmentation mode, unused by pcseg")
+    if probas.dim() != 2:
+        raise ValueError("lovasz_softmax here expects point-wise [P, C] probabilities")
+    labels = labels.view(-1)
+    if ignore is not None:
+        valid = labels != ignore
+        probas, labels = probas[valid], labels[valid]
+    return lovasz_softmax_flat(probas, labels, classes=classes)

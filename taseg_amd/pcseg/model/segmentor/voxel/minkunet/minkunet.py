@@ -1,0 +1,284 @@
+"""MinkUNet segmentor (reference pcseg/model/segmentor/voxel/minkunet/minkunet.py:186-458).
+
+Module tree, attribute names and therefore every state_dict key / shape are identical to
+the reference (`stem.0.kernel`, `stage1.0.net.0.kernel`, `stage2.1.downsample.0.kernel`,
+`up1.1.0.net.0.kernel`, `classifier.0.weight`, BN `weight/bias/running_*` ...), so reference
+checkpoints load here and vice versa.  The sparse ops run on the HIP backend through
+`taseg_amd.torchsparse`.
+"""
+import torch
+from torch import nn
+
+from taseg_amd import torchsparse
+from taseg_amd.torchsparse import PointTensor, SparseTensor
+from taseg_amd.torchsparse import nn as spnn
+from taseg_amd.torchsparse.nn.utils import fapply
+from taseg_amd.pcseg.loss import Losses
+from ...base_segmentors import BaseSegmentor
+from .utils import initial_voxelize, voxel_to_point
+
+__all__ = ["MinkUNet"]
+
+
+class SyncBatchNorm(nn.SyncBatchNorm):
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return fapply(input, super().forward)
+
+
+class BatchNorm(nn.BatchNorm1d):
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return fapply(input, super().forward)
+
+
+def _norm(channels: int, if_dist: bool) -> nn.Module:
+    return SyncBatchNorm(channels) if if_dist else BatchNorm(channels)
+
+
+class BasicConvolutionBlock(nn.Module):
+    """conv -> BN -> ReLU (minkunet.py:31-54)."""
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, if_dist=False):
+        super().__init__()
+        self.net = nn.Sequential(
+            spnn.Conv3d(inc, outc, kernel_size=ks, dilation=dilation, stride=stride),
+            _norm(outc, if_dist),
+            spnn.ReLU(True),
+        )
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class BasicDeconvolutionBlock(nn.Module):
+    """transposed conv -> BN -> ReLU (minkunet.py:57-80)."""
+
+    def __init__(self, inc, outc, ks=3, stride=1, if_dist=False):
+        super().__init__()
+        self.net = nn.Sequential(
+            spnn.Conv3d(inc, outc, kernel_size=ks, stride=stride, transposed=True),
+            _norm(outc, if_dist),
+            spnn.ReLU(True),
+        )
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def _shortcut(inc, outc, stride, if_dist):
+    if inc == outc and stride == 1:
+        return nn.Identity()
+    return nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=1, dilation=1, stride=stride), _norm(outc, if_dist))
+
+
+class ResidualBlock(nn.Module):
+    """two 3x3x3 convs + identity / 1x1x1 shortcut (minkunet.py:83-129)."""
+    expansion = 1
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, if_dist=False):
+        super().__init__()
+        self.net = nn.Sequential(
+            spnn.Conv3d(inc, outc, kernel_size=ks, dilation=dilation, stride=stride),
+            _norm(outc, if_dist),
+            spnn.ReLU(True),
+            spnn.Conv3d(outc, outc, kernel_size=ks, dilation=dilation, stride=1),
+            _norm(outc, if_dist),
+        )
+        self.downsample = _shortcut(inc, outc * self.expansion, stride, if_dist)
+        self.relu = spnn.ReLU(True)
+
+    def forward(self, x):
+        return self.relu(self.net(x) + self.downsample(x))
+
+
+class Bottleneck(nn.Module):
+    """1x1x1 -> 3x3x3 -> 1x1x1 (x4) with shortcut (minkunet.py:132-183)."""
+    expansion = 4
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, if_dist=False):
+        super().__init__()
+        wide = outc * self.expansion
+        self.net = nn.Sequential(
+            spnn.Conv3d(inc, outc, kernel_size=1, bias=False),
+            _norm(outc, if_dist),
+            spnn.Conv3d(outc, outc, kernel_size=ks, stride=stride, bias=False, dilation=dilation),
+            _norm(outc, if_dist),
+            spnn.Conv3d(outc, wide, kernel_size=1, bias=False),
+            _norm(wide, if_dist),
+        )
+        self.downsample = _shortcut(inc, wide, stride, if_dist)
+        self.relu = spnn.ReLU(True)
+
+    def forward(self, x):
+        return self.relu(self.net(x) + self.downsample(x))
+
+
+class LazyScalar:
+    """float-like view of a device scalar: the host sync happens only if somebody formats or
+    converts it (the reference calls `loss.item()` inside forward, stalling the launch queue
+    before backward; TASeg's trainer only logs the value)."""
+
+    def __init__(self, t):
+        self._t = t.detach()
+        self._v = None
+
+    def item(self):
+        if self._v is None:
+            self._v = float(self._t.item())
+        return self._v
+
+    __float__ = item
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __repr__(self):
+        return repr(self.item())
+
+    def _num(self, other):
+        return float(other)
+
+    def __add__(self, o):
+        return self.item() + self._num(o)
+
+    __radd__ = __add__
+
+    def __mul__(self, o):
+        return self.item() * self._num(o)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self.item() / self._num(o)
+
+
+class MinkUNetBackbone(BaseSegmentor):
+    """Everything MinkUNet and MinkUNetMs share: construction (minkunet.py:187-356 ==
+    minkunet_ms.py:187-356) and the encoder / decoder / point-head pass (minkunet.py:393-422)."""
+
+    def __init__(self, model_cfgs, num_class: int):
+        super().__init__(model_cfgs, num_class)
+        self.in_feature_dim = model_cfgs.IN_FEATURE_DIM
+        self.num_layer = model_cfgs.get("NUM_LAYER", [2, 3, 4, 6, 2, 2, 2, 2])
+        self.block = {"ResBlock": ResidualBlock, "Bottleneck": Bottleneck}[model_cfgs.get("BLOCK", "Bottleneck")]
+        cr = model_cfgs.get("cr", 1.0)
+        cs = [int(cr * x) for x in model_cfgs.get("PLANES", [32, 32, 64, 128, 256, 256, 128, 96, 96])]
+        self.pres = model_cfgs.get("pres", 0.05)
+        self.vres = model_cfgs.get("vres", 0.05)
+        if_dist = model_cfgs.IF_DIST
+        exp = self.block.expansion
+
+        self.stem = nn.Sequential(
+            spnn.Conv3d(self.in_feature_dim, cs[0], kernel_size=3, stride=1), _norm(cs[0], if_dist), spnn.ReLU(True),
+            spnn.Conv3d(cs[0], cs[0], kernel_size=3, stride=1), _norm(cs[0], if_dist), spnn.ReLU(True),
+        )
+        self.in_channels = cs[0]
+
+        def encoder_stage(width, depth):
+            return nn.Sequential(
+                BasicConvolutionBlock(self.in_channels, self.in_channels, ks=2, stride=2, dilation=1, if_dist=if_dist),
+                *self._make_layer(self.block, width, depth, if_dist=if_dist))
+
+        self.stage1 = encoder_stage(cs[1], self.num_layer[0])
+        self.stage2 = encoder_stage(cs[2], self.num_layer[1])
+        self.stage3 = encoder_stage(cs[3], self.num_layer[2])
+        self.stage4 = encoder_stage(cs[4], self.num_layer[3])
+
+        def decoder_stage(width, skip_channels, depth):
+            up = BasicDeconvolutionBlock(self.in_channels, width, ks=2, stride=2, if_dist=if_dist)
+            self.in_channels = width + skip_channels
+            body = nn.Sequential(*self._make_layer(self.block, width, depth, if_dist=if_dist))
+            return nn.ModuleList([up, body])
+
+        self.up1 = decoder_stage(cs[5], cs[3] * exp, self.num_layer[4])
+        self.up2 = decoder_stage(cs[6], cs[2] * exp, self.num_layer[5])
+        self.up3 = decoder_stage(cs[7], cs[1] * exp, self.num_layer[6])
+        self.up4 = decoder_stage(cs[8], cs[0], self.num_layer[7])
+
+        self.classifier = nn.Sequential(nn.Linear((cs[4] + cs[6] + cs[8]) * exp, self.num_class))
+        self.weight_initialization()
+        self.dropout = nn.Dropout(model_cfgs.get("DROPOUT_P", 0.3), True)
+
+        default_loss = {"LOSS_TYPES": ["CELoss", "LovLoss"], "LOSS_WEIGHTS": [1.0, 1.0], "KNN": 10}
+        loss_cfg = self.model_cfgs.get("LOSS_CONFIG", default_loss)
+        loss_types = loss_cfg.get("LOSS_TYPES", default_loss["LOSS_TYPES"])
+        loss_weights = loss_cfg.get("LOSS_WEIGHTS", default_loss["LOSS_WEIGHTS"])
+        assert len(loss_types) == len(loss_weights)
+        self.criterion_losses = Losses(
+            loss_types=loss_types, loss_weights=loss_weights, ignore_index=model_cfgs.IGNORE_LABEL,
+            knn=loss_cfg.get("KNN", default_loss["KNN"]), label_smoothing=model_cfgs.get("LABEL_SMOOTHING", 0.0))
+
+    def _make_layer(self, block, out_channels, num_block, stride=1, if_dist=False):
+        layers = [block(self.in_channels, out_channels, stride=stride, if_dist=if_dist)]
+        self.in_channels = out_channels * block.expansion
+        layers += [block(self.in_channels, out_channels, if_dist=if_dist) for _ in range(1, num_block)]
+        return layers
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _unet(self, x0: SparseTensor, z: PointTensor) -> torch.Tensor:
+        """stem .. classifier on a stride-1 SparseTensor and its point view; returns logits [N, num_class]."""
+        x0 = self.stem(x0)
+        z0 = voxel_to_point(x0, z, nearest=False)
+
+        x1 = self.stage1(x0)
+        x2 = self.stage2(x1)
+        x3 = self.stage3(x2)
+        x4 = self.stage4(x3)
+        z1 = voxel_to_point(x4, z0)
+
+        x4.F = self.dropout(x4.F)
+        y1 = self.up1[1](torchsparse.cat([self.up1[0](x4), x3]))
+        y2 = self.up2[1](torchsparse.cat([self.up2[0](y1), x2]))
+        z2 = voxel_to_point(y2, z1)
+
+        y2.F = self.dropout(y2.F)
+        y3 = self.up3[1](torchsparse.cat([self.up3[0](y2), x1]))
+        y4 = self.up4[1](torchsparse.cat([self.up4[0](y3), x0]))
+        z3 = voxel_to_point(y4, z2)
+
+        return self.classifier(torch.cat([z1.F, z2.F, z3.F], dim=1))
+
+    def _train_outputs(self, logits, target, coords_xyz, offset):
+        loss = self.criterion_losses(logits, target, xyz=coords_xyz, offset=offset)
+        lazy = LazyScalar(loss)
+        return {"loss": loss}, {"loss": lazy}, {"loss": lazy}
+
+
+class MinkUNet(MinkUNetBackbone):
+    """Single-frame model: re-voxelises `batch_dict['lidar']` on device, then the U-Net
+    (minkunet.py:385-455)."""
+
+    def forward(self, batch_dict, return_logit=False, return_tta=False):
+        x = batch_dict["lidar"]
+        x.F = x.F[:, :self.in_feature_dim]
+        z = PointTensor(x.F, x.C.float())
+        x0 = initial_voxelize(z, self.pres, self.vres)
+        out = self._unet(x0, z)
+
+        if self.training:
+            target = batch_dict["targets"].F.long().cuda(non_blocking=True)
+            return self._train_outputs(out, target, batch_dict["lidar"].C[:, :3].float(), batch_dict["offset"])
+
+        invs = batch_dict["inverse_map"]
+        all_labels = batch_dict["targets_mapped"]
+        point_predict, point_labels, point_predict_logits = [], [], []
+        for idx in range(int(invs.C[:, -1].max()) + 1):
+            scene = x.C[:, -1] == idx
+            cur_inv = invs.F[invs.C[:, -1] == idx]
+            mapped = out[scene][cur_inv]
+            n_cur = int(batch_dict["num_points"][idx])
+            if return_logit or return_tta:
+                point_predict.append(mapped.softmax(1)[:n_cur].cpu().numpy())
+            else:
+                point_predict.append(mapped.argmax(1)[:n_cur].cpu().numpy())
+                point_predict_logits.append(mapped[:n_cur].cpu().numpy())
+            point_labels.append(all_labels.F[all_labels.C[:, -1] == idx][:n_cur].cpu().numpy())
+        return {"point_predict": point_predict, "point_labels": point_labels, "name": batch_dict["name"],
+                "point_predict_logits": point_predict_logits}
+
+    def forward_ensemble(self, batch_dict):
+        return self.forward(batch_dict, return_tta=True)

@@ -1,0 +1,267 @@
+"""`torchsparse.nn.functional` on the HIP backend.
+
+Operator names, argument meaning and results follow the reference
+(TS/torchsparse/nn/functional/{conv,hash,query,count,voxelize,devoxelize,downsample}.py);
+what differs is how the work is scheduled on the device:
+
+* the kernel map of a convolution is built by ONE backend call (`ts_build_kmap`) that
+  hashes, probes and compacts on device - no `torch.nonzero`, no `nbsizes.cpu()`;
+* the convolution itself runs on the [K, N_out] neighbour table (output-stationary,
+  every output row written once) instead of 3 x K gather / GEMM / scatter launches;
+* `nbmaps` / `nbsizes` with the reference's exact contents and order are still produced
+  (and are what the weight-gradient kernel walks), so rulebooks can be compared bit for bit.
+"""
+from typing import List, Optional, Tuple, Union
+
+import torch
+from torch.autograd import Function
+
+from ... import backend as B
+from ..tensor import SparseTensor
+from ..utils import make_ntuple
+from .utils import get_kernel_offsets
+
+__all__ = ["conv3d", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
+           "spdownsample", "KernelMap", "build_kernel_map"]
+
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+# ------------------------------------------------------------------------------ hashing
+def sphash(coords: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """hash.py:10-37: int64 FNV hash of [N,4] int coords, or the [K,N] table for K offsets."""
+    assert coords.dtype == torch.int, coords.dtype
+    assert coords.ndim == 2 and coords.shape[1] == 4, coords.shape
+    if offsets is None:
+        return B.hash_cuda(coords)
+    assert offsets.dtype == torch.int, offsets.dtype
+    assert offsets.ndim == 2 and offsets.shape[1] == 3, offsets.shape
+    return B.kernel_hash_cuda(coords, offsets)
+
+
+def sphashquery(queries: torch.Tensor, references: torch.Tensor) -> torch.Tensor:
+    """query.py:8-33: position of every query hash in `references`, -1 where absent."""
+    shape = queries.shape
+    out = B.hash_query_cuda(queries.reshape(-1), references, None)
+    return (out - 1).view(*shape)
+
+
+def spcount(coords: torch.Tensor, num) -> torch.Tensor:
+    """count.py:8-16."""
+    return B.count_cuda(coords, int(num))
+
+
+# ------------------------------------------------------------------------------ voxelize / devoxelize
+class _Voxelize(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, feats, idx, counts):
+        idx = idx.int().contiguous()
+        counts = counts.int().contiguous()
+        out = B.voxelize_forward_cuda(feats.contiguous(), idx, counts)
+        ctx.saved = (idx, counts, feats.shape[0])
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        idx, counts, n = ctx.saved
+        return B.voxelize_backward_cuda(grad_out.contiguous(), idx, counts, n), None, None
+
+
+def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    """voxelize.py:54-56: mean-pool point rows into voxel rows (`coords` = voxel index per point)."""
+    return _Voxelize.apply(feats, coords, counts)
+
+
+class _Devoxelize(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, feats, idx, weights):
+        idx = idx.int().contiguous()
+        weights = weights.contiguous()
+        out = B.devoxelize_forward_cuda(feats.contiguous(), idx, weights)
+        ctx.saved = (idx, weights, feats.shape[0])
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        idx, weights, m = ctx.saved
+        return B.devoxelize_backward_cuda(grad_out.contiguous(), idx, weights, m), None, None
+
+
+def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """devoxelize.py:96-98: out[i] = sum_k weights[i,k] * feats[coords[i,k]]."""
+    return _Devoxelize.apply(feats, coords, weights)
+
+
+def calc_ti_weights(coords: torch.Tensor, idx_query: torch.Tensor, scale: float = 1) -> torch.Tensor:
+    """devoxelize.py:10-48: trilinear weights [8, N] for float point coords and the [8, N] corner
+    lookup result, masked where the corner voxel is absent and renormalised by (sum + 1e-8).
+
+    Kept for API parity (elementwise torch ops); `voxel_to_point` uses the fused
+    `backend.trilinear_map` which produces indices and weights in one pass.
+    """
+    with torch.no_grad():
+        p = coords[:, :3]
+        lo = torch.floor(p / scale) * scale if scale != 1 else torch.floor(p)
+        hi = lo + scale
+        up, dn = (hi - p).float(), (p - lo).float()   # weight of the lower / upper corner per axis
+        sel = lambda bit, ax: (dn if bit else up)[:, ax]  # noqa: E731
+        rows = [sel(k >> 2 & 1, 0) * sel(k >> 1 & 1, 1) * sel(k & 1, 2) for k in range(8)]
+        w = torch.stack(rows, dim=0)
+        if scale != 1:
+            w /= scale ** 3
+        w[idx_query == -1] = 0
+        w /= torch.sum(w, dim=0) + 1e-8
+    return w
+
+
+# ------------------------------------------------------------------------------ downsample
+def spdownsample(coords: torch.Tensor, stride=2, kernel_size=2, tensor_stride=1) -> torch.Tensor:
+    """downsample.py:11-52: output coordinates of a strided convolution."""
+    stride = make_ntuple(stride, ndim=3)
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    tensor_stride = make_ntuple(tensor_stride, ndim=3)
+    if not all(stride[k] in (1, kernel_size[k]) for k in range(3)):
+        # the overlapping-window branch (downsample.py:32-48) is never reached by the
+        # MinkUNet family (kernel 2 / stride 2 and kernel 3 / stride 1 only)
+        raise NotImplementedError("spdownsample: stride must be 1 or equal to kernel_size on every axis")
+    step = [stride[k] * tensor_stride[k] for k in range(3)]
+    return B.downsample(coords, step)
+
+
+# ------------------------------------------------------------------------------ kernel map
+class KernelMap:
+    """What `input.kmaps[key]` holds.  Indexing / unpacking reproduces the reference's
+    `[nbmaps, nbsizes, (n_in, n_out)]` list (conv.py:175-177); the device-resident neighbour
+    tables are what the kernels consume.
+
+      nbr    [K, n_out] int32   input row feeding output j through offset k (or -1)
+      nbr_t  [K, n_in]  int32   output row fed by input i through offset k (or -1)
+      nbmaps_buf [K*n_out, 2]   (in, out) pairs ordered by (k, out); first nboffs[K] rows valid
+      nbsizes [K], nboffs [K+1] int32 on device
+    """
+
+    def __init__(self, tables, sizes):
+        self.nbr = tables["nbr"]
+        self.nbr_t = tables["nbr_t"]
+        self.nbmaps_buf = tables["nbmaps"]
+        self.nbsizes_dev = tables["nbsizes"]
+        self.nboffs = tables["nboffs"]
+        self.sizes = sizes
+        self._nbmaps = None
+
+    @property
+    def nbmaps(self) -> torch.Tensor:
+        """Exact [P, 2] int64 rulebook like the reference's (one host sync, cached)."""
+        if self._nbmaps is None:
+            total = int(self.nboffs[-1].item())
+            self._nbmaps = self.nbmaps_buf[:total].long()
+        return self._nbmaps
+
+    @property
+    def nbsizes(self) -> torch.Tensor:
+        return self.nbsizes_dev.long()
+
+    def __getitem__(self, i):
+        return (self.nbmaps, self.nbsizes, self.sizes)[i]
+
+    def __iter__(self):
+        return iter((self.nbmaps, self.nbsizes, self.sizes))
+
+    def __len__(self):
+        return 3
+
+
+def build_kernel_map(in_coords, out_coords, kernel_size, tensor_stride, dilation=1) -> KernelMap:
+    offsets = get_kernel_offsets(kernel_size, stride=tensor_stride, dilation=dilation, device=in_coords.device)
+    tables = B.build_kmap(in_coords, out_coords, offsets)
+    return KernelMap(tables, (in_coords.shape[0], out_coords.shape[0]))
+
+
+# ------------------------------------------------------------------------------ convolution
+class _SparseConv(Function):
+    """conv.py:16-119 on the neighbour tables.  `transposed` swaps the roles of the two
+    index columns exactly like convolution_cuda.cu:21,34."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool):
+        feats = feats.contiguous()
+        weight = weight.contiguous()
+        if feats.shape[1] != weight.shape[1]:
+            raise ValueError("Input feature size and kernel size mismatch")
+        n_in, n_out = kmap.sizes
+        if not transposed:
+            if feats.shape[0] != n_in:
+                raise ValueError(f"conv3d: {feats.shape[0]} input rows but the kernel map has {n_in}")
+            out = B.conv_nbr(feats, weight, kmap.nbr, n_out, weight_transposed=False)
+        else:
+            if feats.shape[0] != n_out:
+                raise ValueError(f"conv3d (transposed): {feats.shape[0]} input rows but the kernel map has {n_out}")
+            out = B.conv_nbr(feats, weight, kmap.nbr_t, n_in, weight_transposed=False)
+        ctx.kmap, ctx.transposed = kmap, transposed
+        ctx.save_for_backward(feats, weight)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        feats, weight = ctx.saved_tensors
+        kmap, transposed = ctx.kmap, ctx.transposed
+        grad_out = grad_out.contiguous()
+        n_in, n_out = kmap.sizes
+        k = weight.shape[0]
+        grad_feats = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T over the inverse table
+            table, rows = (kmap.nbr_t, n_in) if not transposed else (kmap.nbr, n_out)
+            grad_feats = B.conv_nbr(grad_out, weight, table, rows, weight_transposed=True)
+        if ctx.needs_input_grad[1]:
+            grad_weight = B.conv_wgrad(feats, grad_out, kmap.nbmaps_buf, kmap.nboffs, k,
+                                       col_a=1 if transposed else 0, max_pairs=n_out)
+        return grad_feats, grad_weight, None, None
+
+
+def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optional[torch.Tensor] = None,
+           stride: Union[int, List[int], Tuple[int, ...]] = 1, dilation: Union[int, Tuple[int, ...]] = 1,
+           transposed: bool = False) -> SparseTensor:
+    """conv.py:122-205 - same coordinate / kernel-map caching protocol as the reference:
+    `cmaps[stride]` holds coordinates, `kmaps[(in_stride, kernel, stride, dilation)]` the map,
+    a transposed convolution reuses the map of its mirror strided convolution."""
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    stride = make_ntuple(stride, ndim=3)
+    dilation = make_ntuple(dilation, ndim=3)
+    ones = (1, 1, 1)
+
+    if kernel_size == ones and stride == ones and dilation == ones:
+        out_stride, out_coords = input.stride, input.coords
+        out_feats = input.feats.matmul(weight)   # plain dense GEMM -> rocBLAS/hipBLASLt
+    elif not transposed:
+        out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
+        if out_stride in input.cmaps:
+            out_coords = input.cmaps[out_stride]
+        elif stride == ones:
+            out_coords = input.coords
+        else:
+            out_coords = spdownsample(input.coords, stride, kernel_size, input.stride)
+        key = (input.stride, kernel_size, stride, dilation)
+        if key not in input.kmaps:
+            input.kmaps[key] = build_kernel_map(input.coords, out_coords, kernel_size, input.stride, dilation)
+        out_feats = _SparseConv.apply(input.feats, weight, input.kmaps[key], False)
+    else:
+        out_stride = tuple(input.stride[k] // stride[k] for k in range(3))
+        out_coords = input.cmaps[out_stride]
+        out_feats = _SparseConv.apply(input.feats, weight, input.kmaps[(out_stride, kernel_size, stride, dilation)],
+                                      True)
+    if bias is not None:
+        out_feats = out_feats + bias
+
+    output = SparseTensor(coords=out_coords, feats=out_feats, stride=out_stride)
+    output.cmaps = input.cmaps
+    output.cmaps.setdefault(out_stride, out_coords)
+    output.kmaps = input.kmaps
+    return output

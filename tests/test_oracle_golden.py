@@ -1,0 +1,183 @@
+"""Pins the CPU oracle (oracle/ts_oracle.py, oracle/model.py) against the golden vectors captured
+from the REAL reference (tests/golden/make_golden.py).  Integer results bit-exact, fp32 <= 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from oracle import ts_oracle as O
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg
+
+torch.set_num_threads(2)
+
+
+def close(a, b, tol=1e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.abs(a - b).max()) <= tol * scale, float(np.abs(a - b).max())
+
+
+def test_hash_known_answers():
+    # values produced by the reference CPU build
+    got = O.sphash(np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [1, 0, 0, 1]], dtype=np.int32))
+    assert got.tolist() == [947293587111810033, 948793285165995886, 947292487600181830, 948794384677624093]
+
+
+def test_hash_and_kernel_hash(g_ops):
+    assert np.array_equal(O.sphash(g_ops["coords"]), g_ops["hash"])
+    assert np.array_equal(O.sphash(g_ops["coords_neg"]), g_ops["hash_neg"])
+    assert np.array_equal(O.sphash(g_ops["coords"], g_ops["offsets_k3s1"]), g_ops["khash_k3s1"])
+    assert np.array_equal(O.get_kernel_offsets(3, 1, 1), g_ops["offsets_k3s1"])
+
+
+def test_downsample_and_kmaps(g_ops):
+    cur, ts = g_ops["coords"], 1
+    for _ in range(3):
+        res, nbmaps, nbsizes = O.build_kmap(cur, cur, O.get_kernel_offsets(3, ts, 1))
+        assert np.array_equal(res, g_ops[f"k3_s{ts}_results"])
+        assert np.array_equal(nbmaps, g_ops[f"k3_s{ts}_nbmaps"])
+        assert np.array_equal(nbsizes, g_ops[f"k3_s{ts}_nbsizes"])
+        down = O.spdownsample(cur, 2, 2, ts)
+        assert np.array_equal(down, g_ops[f"down_s{ts}"])
+        res2, nbmaps2, nbsizes2 = O.build_kmap(cur, down, O.get_kernel_offsets(2, ts, 1))
+        assert np.array_equal(res2, g_ops[f"k2_s{ts}_results"])
+        assert np.array_equal(nbmaps2, g_ops[f"k2_s{ts}_nbmaps"])
+        assert np.array_equal(nbsizes2, g_ops[f"k2_s{ts}_nbsizes"])
+        assert nbsizes2.sum() == cur.shape[0]        # every fine voxel has exactly one parent
+        cur, ts = down, ts * 2
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_conv_fwd_bwd(g_ops, tag):
+    c = g_ops["coords"]
+    _, nbmaps, nbsizes = O.build_kmap(c, c, O.get_kernel_offsets(3, 1, 1))
+    sizes = (c.shape[0], c.shape[0])
+    y = O.conv_forward(g_ops[f"conv_{tag}_x"], g_ops[f"conv_{tag}_w"], nbmaps, nbsizes, sizes)
+    close(y, g_ops[f"conv_{tag}_y"])
+    gx, gw = O.conv_backward(g_ops[f"conv_{tag}_x"], g_ops[f"conv_{tag}_w"], g_ops[f"conv_{tag}_gy"], nbmaps, nbsizes)
+    close(gx, g_ops[f"conv_{tag}_gx"])
+    close(gw, g_ops[f"conv_{tag}_gw"])
+
+
+def test_conv_strided_and_transposed(g_ops):
+    c = g_ops["coords"]
+    down = O.spdownsample(c, 2, 2, 1)
+    assert np.array_equal(down, g_ops["convt_coords_d"])
+    _, nbmaps, nbsizes = O.build_kmap(c, down, O.get_kernel_offsets(2, 1, 1))
+    sizes = (c.shape[0], down.shape[0])
+    yd = O.conv_forward(g_ops["convt_x"], g_ops["convt_wd"], nbmaps, nbsizes, sizes)
+    close(yd, g_ops["convt_yd"])
+    yu = O.conv_forward(yd, g_ops["convt_wu"], nbmaps, nbsizes, sizes, transposed=True)
+    close(yu, g_ops["convt_yu"])
+    gyd, gwu = O.conv_backward(yd, g_ops["convt_wu"], g_ops["convt_gy"], nbmaps, nbsizes, transposed=True)
+    close(gwu, g_ops["convt_gwu"])
+    gx, gwd = O.conv_backward(g_ops["convt_x"], g_ops["convt_wd"], gyd, nbmaps, nbsizes)
+    close(gx, g_ops["convt_gx"])
+    close(gwd, g_ops["convt_gwd"])
+
+
+def test_initial_voxelize_pieces(g_ops):
+    pc = g_ops["iv_points_c"]
+    scaled, cell, sparse_hash, idx_query, counts = O.initial_voxelize_maps(pc, 0.05, 0.05)
+    assert np.array_equal(O.sphash(cell.astype(np.int32)), g_ops["iv_hash"])
+    assert np.array_equal(sparse_hash, g_ops["iv_sparse_hash"])
+    assert np.array_equal(idx_query, g_ops["iv_idx_query"])
+    assert np.array_equal(counts, g_ops["iv_counts"])
+    assert np.array_equal(np.round(O.voxelize_forward(cell, idx_query, counts)).astype(np.int32), g_ops["iv_vox_c"])
+    close(O.voxelize_forward(g_ops["iv_points_f"], idx_query, counts), g_ops["iv_vox_f"], 1e-6)
+    close(O.voxelize_backward(g_ops["iv_gv"], idx_query, counts, pc.shape[0]), g_ops["iv_gf"], 1e-6)
+
+
+@pytest.mark.parametrize("s", [1, 4])
+def test_trilinear_and_devoxelize(g_ops, s):
+    idx, w = O.trilinear_map(g_ops["tri_points"], g_ops[f"tri_s{s}_vox"], s)
+    assert np.array_equal(idx, g_ops[f"tri_s{s}_idx"])
+    close(w, g_ops[f"tri_s{s}_w"], 1e-6)
+    out = O.devoxelize_forward(g_ops[f"tri_s{s}_feat"], idx, w)
+    close(out, g_ops[f"tri_s{s}_out"], 1e-6)
+    gfeat = O.devoxelize_backward(g_ops[f"tri_s{s}_gout"], idx, w, g_ops[f"tri_s{s}_feat"].shape[0])
+    close(gfeat, g_ops[f"tri_s{s}_gfeat"], 1e-5)
+
+
+def test_multiscan_data_stage(g_multiscan):
+    g = g_multiscan
+    T = int(g["T"])
+    steps = g["steps"].tolist()
+    inv = g["learning_map_inv"]
+    lm = g["learning_map"]
+    fused_per_scan, coords_ms_all = [], []
+    for b in range(2):
+        pose0 = g[f"b{b}_pose_t{T}"]
+        hist, masks, labs = [], [], []
+        for delta in range(-T, 0):                                       # semantickitti_ms.py:271-276
+            t = T + delta
+            pts = g[f"b{b}_points_t{t}"]
+            raw = g[f"b{b}_rawlabels_t{t}"]
+            hist.append(O.fuse_scan(pts, pose0, g[f"b{b}_pose_t{t}"]))
+            masks.append(O.history_mask(raw, delta, steps, inv))
+            labs.append(lm[raw])
+        hist, masks, labs = np.concatenate(hist), np.concatenate(masks), np.concatenate(labs)
+        assert np.array_equal(hist.astype(np.float32), g[f"b{b}_fused_all"])      # bit-exact float32 pose fuse
+        assert np.array_equal(masks, g[f"b{b}_mask"])
+        cur = g[f"b{b}_points_t{T}"]
+        fused = O.append_time_flag(len(cur), np.concatenate([cur, hist[masks]]))
+        assert np.array_equal(fused.astype(np.float32), g[f"b{b}_raw_data_ms"])
+        labels_ms = np.concatenate([lm[g[f"b{b}_rawlabels_t{T}"]], labs[masks]])
+        assert np.array_equal(labels_ms, g[f"b{b}_labels_ms"])
+        fused_per_scan.append((cur, fused))
+
+    # voxelisation of both clouds (semantickitti_voxel_ms.py:121-170) + collate (:189-212)
+    lidar_c, lidar_ms_c, inv_ms, pmask = [], [], [], []
+    for b, (cur, fused) in enumerate(fused_per_scan):
+        keep = np.all(fused[:, :3] >= cur[:, :3].min(0), axis=1)         # clamp_mask :121
+        fused = fused[keep]
+        pc = O.voxel_coords(cur, 0.05)
+        pc_ms = O.voxel_coords(fused, 0.05)
+        pc = pc - pc_ms.min(0)
+        pc_ms = pc_ms - pc_ms.min(0)
+        idx, _ = O.sparse_quantize(pc)
+        idx_ms, inverse_ms = O.sparse_quantize(pc_ms)
+        lidar_c.append(np.concatenate([pc[idx], np.full((len(idx), 1), b)], 1))
+        lidar_ms_c.append(np.concatenate([pc_ms[idx_ms], np.full((len(idx_ms), 1), b)], 1))
+        inv_ms.append(inverse_ms)
+        m = np.zeros(len(fused), dtype=bool)
+        m[:len(cur)] = True
+        pmask.append(m)
+    assert np.array_equal(np.concatenate(lidar_c), g["batch_lidar_C"])
+    assert np.array_equal(np.concatenate(lidar_ms_c), g["batch_lidar_ms_C"])
+    assert np.array_equal(np.concatenate(inv_ms), g["batch_inverse_map_ms_F"])
+    assert np.array_equal(np.concatenate(pmask), g["batch_point_mask"])
+
+
+def _oracle_run(g, name, in_dim, training):
+    cfg = make_model_cfg(name, in_dim=in_dim, cr=0.5, num_layer=[1] * 8)
+    from taseg_amd.pcseg.model import build_network
+    model = fill_parameters(build_network(cfg, 20), seed=3)
+    learn = {k for k, _ in model.named_parameters()}
+    params = {k: v.clone().requires_grad_(k in learn) for k, v in model.state_dict().items()}
+    om = OM.OracleMinkUNet(params, cfg, training=training)
+    feats = torch.from_numpy(g["feats"])
+    fwd = om.forward_minkunet if name == "MinkUNet" else om.forward_minkunet_ms
+    logits = fwd(g["coords"], feats)
+    loss = OM.loss_ce_lovasz(logits, torch.from_numpy(g["labels"]))
+    loss.backward()
+    return params, logits, loss
+
+
+@pytest.mark.parametrize("name,in_dim,fix", [("MinkUNet", 4, "g_minkunet"), ("MinkUNetMs", 5, "g_minkunet_ms")])
+@pytest.mark.parametrize("training", [True, False])
+def test_model_oracle_vs_reference(request, name, in_dim, fix, training):
+    g = request.getfixturevalue(fix)
+    tag = "train" if training else "eval"
+    params, logits, loss = _oracle_run(g, name, in_dim, training)
+    close(logits.detach().numpy(), g[f"{tag}_logits"], 1e-4)
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 1e-4
+    # eval-mode BN: pure restatement error (~1e-7).  train-mode BN: batch statistics over the few
+    # voxels of the deep levels amplify fp32 summation-order noise, so gradients are compared by
+    # relative L2 norm with a looser bound.
+    tol = 1e-2 if training else 1e-5
+    for key in g:
+        if key.startswith(f"{tag}_grad/"):
+            a, b = params[key.split("/", 1)[1]].grad.numpy(), g[key]
+            assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b), key
