@@ -1,0 +1,247 @@
+"""bench.py - scans/sec of the TASeg hot path (train step: rulebook construction + MinkUNet forward +
+CE/Lovasz loss + backward + SGD step) on synthetic SemanticKITTI-shaped scans, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload minkunet|minkunet_ms]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); every rank
+trains on its own scans (weak scaling, DDP gradient all-reduce overlapped with backward, SyncBN as in
+the reference configs).  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
+VOXEL = 0.05
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms"])
+    ap.add_argument("--batch", type=int, default=2, help="scans per GPU per step")
+    ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sector-deg", type=float, default=180.0)
+    return ap.parse_args()
+
+
+def make_scans(rank, batch, points, workload):
+    """Seeded synthetic scans (seed = 1000 * seq + frame, seq = rank), dataset-voxelised on the host with
+    numpy exactly like the reference's CPU workers, returned as resident device tensors."""
+    from taseg_amd.data.synthetic import synth_pose, synth_scan, FLEXIBLE_STEPS_KITTI
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    coords, feats, labels, npts = [], [], [], 0
+    for b in range(batch):
+        seed = 1000 * rank + 10 * b
+        pts, lab = synth_scan(seed, n_points=points)
+        if workload == "minkunet_ms":
+            # "4-scan TFA": current scan + T = 4 pose-aligned history scans filtered by the reference
+            # FLEXIBLE_STEPS schedule, time flag in column 4
+            from taseg_amd.data.stage import fuse_history_host
+            pts, lab = fuse_history_host(seed, pts, lab, points, synth_scan, synth_pose, FLEXIBLE_STEPS_KITTI)
+        pc = np.round(pts[:, :3] / VOXEL).astype(np.int32)
+        pc -= pc.min(0, keepdims=True)
+        _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+        coords.append(np.concatenate([pc[idx], np.full((len(idx), 1), b, np.int32)], 1))
+        feats.append(pts[idx])
+        labels.append(lab[idx].astype(np.int64))
+        npts += len(pts)
+    dev = torch.device("cuda")
+    return (torch.from_numpy(np.concatenate(coords)).to(dev), torch.from_numpy(np.concatenate(feats)).to(dev),
+            torch.from_numpy(np.concatenate(labels)).to(dev), npts)
+
+
+def cpu_baseline(cfg, points, sector_deg):
+    """Reference CPU path on a bounded sample (one azimuth sector of scan seed 0), 1 thread: the oracle model
+    driven by the reference's own compiled CPU kernels (oracle/_ref) when present, else the numpy port."""
+    from oracle import model as OM
+    from taseg_amd.data.synthetic import fill_parameters, synth_scan
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    torch.set_num_threads(1)
+    kind = "reference"
+    try:
+        OM._load_ref()
+    except Exception:
+        kind = "port"
+    pts, lab = synth_scan(0, n_points=points)
+    az = np.degrees(np.arctan2(pts[:, 1], pts[:, 0]))
+    keep = np.abs(az) < sector_deg / 2
+    pts, lab = pts[keep], lab[keep]
+    pc = np.round(pts[:, :3] / VOXEL).astype(np.int32)
+    pc -= pc.min(0, keepdims=True)
+    _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+    coords = np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)
+    feats = torch.from_numpy(pts[idx])
+    labels = torch.from_numpy(lab[idx].astype(np.int64))
+    model = fill_parameters(build_network(cfg, 20), seed=0)
+    learn = {k for k, _ in model.named_parameters()}
+    params = {k: v.clone().requires_grad_(k in learn) for k, v in model.state_dict().items()}
+    om = OM.OracleMinkUNet(params, cfg, backend="ref" if kind == "reference" else "numpy", training=True)
+    t0 = time.time()
+    fwd = om.forward_minkunet if cfg.NAME == "MinkUNet" else om.forward_minkunet_ms
+    logits = fwd(coords, feats)
+    loss = OM.loss_ce_lovasz(logits, labels)
+    loss.backward()
+    dt = time.time() - t0
+    frac = float(keep.sum()) / float(points)
+    return {"value": frac / dt, "unit": "scans/s", "cores": 1, "kind": kind,
+            "sample": f"{sector_deg:g} deg azimuth sector of one scan: {int(keep.sum())} pts -> {len(idx)} voxels "
+                      f"({frac:.3f} scan), fwd+bwd {dt:.1f} s, fp32, 1 thread (the reference's fastest setting)"}
+
+
+def summarise_profile(records, steps):
+    """Per kernel instantiation: launches, mean duration, algorithmic flops / bytes (SURVEY.md section 8(d):
+    flops = 2 P Cin Cout per pass; bytes = P (Cin s + 2 Cout s + 8) + K Cin Cout s, s = 4)."""
+    pairs_cache = {}
+    groups = {}
+    for kind, e0, e1, m in records:
+        ms = e0.elapsed_time(e1)
+        if kind == "conv_nbr":
+            key = m["nbr"].data_ptr()
+            if key not in pairs_cache:
+                pairs_cache[key] = int((m["nbr"] >= 0).sum())
+            p = pairs_cache[key]
+        else:
+            key = m["nboffs"].data_ptr()
+            if key not in pairs_cache:
+                pairs_cache[key] = int(m["nboffs"][-1])
+            p = pairs_cache[key]
+        flops = 2.0 * p * m["c_red"] * m["c_out"]
+        byts = p * (m["c_red"] * 4 + 2 * m["c_out"] * 4 + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+        g = groups.setdefault(m["name"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        g["launches"] += 1
+        g["ms"] += ms
+        g["flops"] += flops
+        g["bytes"] += byts
+    out = []
+    for name, g in groups.items():
+        sec = g["ms"] / 1e3
+        out.append({"kernel": name, "launches_per_step": g["launches"] / steps, "avg_us": 1e3 * g["ms"] / g["launches"],
+                    "ms_per_step": g["ms"] / steps, "tflops": g["flops"] / sec / 1e12, "gbs": g["bytes"] / sec / 1e9,
+                    "flops_per_launch": g["flops"] / g["launches"], "bytes_per_launch": g["bytes"] / g["launches"]})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")      # RCCL on ROCm
+
+    from taseg_amd import backend as B
+    from taseg_amd.data.synthetic import make_model_cfg
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+
+    ms = args.workload == "minkunet_ms"
+    name = "MinkUNetMs" if ms else "MinkUNet"
+    cfg = make_model_cfg(name, in_dim=5 if ms else 4, cr=1.0, if_dist=world > 1)
+    torch.manual_seed(0)
+    model = build_network(cfg, 20).cuda().train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
+    opt = torch.optim.SGD(model.parameters(), lr=0.02 * args.batch * world, momentum=0.9, weight_decay=1e-4)
+
+    coords, feats, labels, npts = make_scans(rank, args.batch, args.points, args.workload)
+    key, sfx = ("lidar_ms", "_ms") if ms else ("lidar", "")
+    offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        bd = {key: SparseTensor(feats, coords), "targets" + sfx: SparseTensor(labels, coords), "offset" + sfx: offset}
+        ret, _, _ = net(bd)
+        ret["loss"].mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        return ret["loss"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    B.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    records = B.profile_end()
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = args.batch * world * args.steps / dt
+
+    if rank == 0:
+        prof = summarise_profile(records, args.steps)
+        dom = prof[0] if prof else None
+        roofline = None
+        if dom:
+            t_mfma = dom["flops_per_launch"] / (MFMA_F32_PEAK_TF * 1e12)
+            t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
+            if t_mfma >= t_hbm:
+                roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": dom["tflops"] / MFMA_F32_PEAK_TF}
+            else:
+                roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": dom["gbs"] / HBM_PEAK_GBS}
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom["kernel"])
+            roofline.update(traffic=traffic, kernel=dom["kernel"], avg_us=dom["avg_us"],
+                            launches_per_step=dom["launches_per_step"],
+                            algorithmic_bytes_per_launch=dom["bytes_per_launch"],
+                            algorithmic_flops_per_launch=dom["flops_per_launch"])
+        line = {
+            "metric": "scans/sec (train fwd+bwd) at ~120k pts/scan", "value": value, "unit": "scans/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name} mk34 cr1.0 ({'4-scan TFA multi-scan' if ms else 'single-frame'}), "
+                                   f"bs={args.batch}/GPU, voxel 0.05 m, fp32, rulebook+fwd+loss+bwd+SGD step",
+                       "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": int(coords.shape[0]),
+                       "parallelism": f"dp{world}"},
+            "loss": float(loss),
+            "roofline": roofline,
+            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in prof[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.points, args.cpu_sector_deg)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

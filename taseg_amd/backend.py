@@ -256,6 +256,52 @@ def trilinear_map(points, vox_coords, stride):
     return idx, w
 
 
+# Optional per-launch timing (bench.py): HIP events on the launch stream around the conv kernels.
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    global _prof
+    out, _prof = _prof, None
+    return out or []
+
+
+class _Timed:
+    def __init__(self, kind, **meta):
+        self.kind, self.meta = kind, meta
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.e1.record()
+            _prof.append((self.kind, self.e0, self.e1, self.meta))
+        return False
+
+
+def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None):
+    """The template instantiation ts_conv_nbr / ts_conv_wgrad picks (mirrors csrc/conv.hip)."""
+    if wgrad_cb is not None:
+        units = ((c_out_or_ca + 15) // 16) * ((min(64, wgrad_cb) + 15) // 16)
+        per_wave = (units + 3) // 4
+        maxu = next(m for m in (2, 4, 8, 16, 24) if per_wave <= m)
+        return f"conv_wgrad_kernel<{maxu}>"
+    nsplit = (c_out_or_ca + 255) // 256
+    o_tile = ((c_out_or_ca + nsplit - 1) // nsplit + 15) & ~15
+    bm, maxu = ((128, 4) if o_tile <= 32 else (128, 8) if o_tile <= 64 else (64, 8) if o_tile <= 128 else (64, 16))
+    return f"conv_nbr_kernel<{bm},{maxu},{'true' if weight_transposed else 'false'}>"
+
+
 def conv_nbr(in_feat, kernel, nbr, n_out, weight_transposed=False):
     """out[j] = sum_k in[nbr[k,j]] @ (kernel[k] or kernel[k]^T); every output row written once."""
     L.require_device(in_feat, kernel, nbr)
@@ -269,9 +315,11 @@ def conv_nbr(in_feat, kernel, nbr, n_out, weight_transposed=False):
     if nbr.shape != (k, n_out):
         raise ValueError(f"neighbour table shape {tuple(nbr.shape)} != {(k, n_out)}")
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=in_feat.device)
-    L.check(L.load().ts_conv_nbr(L.ptr(in_feat), in_feat.shape[0], c_red, L.ptr(kernel), k,
-                                 1 if weight_transposed else 0, L.ptr(nbr), L.ptr(out), n_out, c_out, L.stream()),
-            "ts_conv_nbr")
+    with _Timed("conv_nbr", name=conv_kernel_name(c_out, weight_transposed), nbr=nbr, c_red=c_red, c_out=c_out, k=k,
+                n_in=in_feat.shape[0], n_out=n_out):
+        L.check(L.load().ts_conv_nbr(L.ptr(in_feat), in_feat.shape[0], c_red, L.ptr(kernel), k,
+                                     1 if weight_transposed else 0, L.ptr(nbr), L.ptr(out), n_out, c_out,
+                                     L.stream()), "ts_conv_nbr")
     return out
 
 
@@ -281,9 +329,11 @@ def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
     a_feat, b_feat = _f32(a_feat, "a_feat"), _f32(b_feat, "b_feat")
     nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
     out = torch.empty((kernel_volume, a_feat.shape[1], b_feat.shape[1]), dtype=torch.float32, device=a_feat.device)
-    L.check(L.load().ts_conv_wgrad(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1], L.ptr(nbmaps),
-                                   L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs), L.ptr(out), L.stream()),
-            "ts_conv_wgrad")
+    with _Timed("conv_wgrad", name=conv_kernel_name(a_feat.shape[1], wgrad_cb=b_feat.shape[1]), nboffs=nboffs,
+                c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume):
+        L.check(L.load().ts_conv_wgrad(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
+                                       L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
+                                       L.ptr(out), L.stream()), "ts_conv_wgrad")
     return out
 
 

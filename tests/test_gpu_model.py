@@ -1,0 +1,134 @@
+"""Model-level parity on the GPU: taseg_amd.pcseg MinkUNet / MinkUNetMs (HIP kernels) against the
+logits / loss / gradients the REAL reference produced for the same inputs and parameters
+(tests/golden/model_*.npz), and against the CPU oracle on a second seeded input.
+
+north_star tolerance: per-point logits within 1e-3 absolute of the reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, synth_scan  # noqa: E402
+
+LOGIT_TOL = 1e-3
+
+
+def _build(name, in_dim):
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg(name, in_dim=in_dim, cr=0.5, num_layer=[1] * 8)
+    return cfg, fill_parameters(build_network(cfg, 20), seed=3).cuda()
+
+
+def _batch(g, key):
+    from taseg_amd.torchsparse import SparseTensor
+    coords = torch.from_numpy(g["coords"]).cuda()
+    bd = {key: SparseTensor(torch.from_numpy(g["feats"]).cuda(), coords)}
+    suffix = "" if key == "lidar" else "_ms"
+    bd["targets" + suffix] = SparseTensor(torch.from_numpy(g["labels"]).cuda(), coords)
+    bd["offset" + suffix] = torch.tensor([0], device="cuda")
+    return bd
+
+
+@pytest.mark.parametrize("name,in_dim,key,fix", [("MinkUNet", 4, "lidar", "g_minkunet"),
+                                                 ("MinkUNetMs", 5, "lidar_ms", "g_minkunet_ms")])
+@pytest.mark.parametrize("training", [True, False])
+def test_model_vs_reference_golden(request, name, in_dim, key, fix, training):
+    g = request.getfixturevalue(fix)
+    tag = "train" if training else "eval"
+    cfg, model = _build(name, in_dim)
+    model.train()
+    if not training:
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o))
+    ret, tb, _ = model(_batch(g, key))
+    h.remove()
+    logits = grabbed["logits"].detach().cpu().numpy()
+    assert np.abs(logits - g[f"{tag}_logits"]).max() <= LOGIT_TOL
+    assert abs(float(tb["loss"]) - float(g[f"{tag}_loss"])) <= 1e-3
+    model.zero_grad()
+    ret["loss"].backward()
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    tol = 2e-2 if training else 1e-4     # train-mode BN amplifies fp32 ordering noise (see test_oracle_golden)
+    for k in g:
+        if k.startswith(f"{tag}_grad/"):
+            a, b = grads[k.split("/", 1)[1]].cpu().numpy(), g[k]
+            assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b), k
+    norms = np.array([float(grads[n].norm()) for n, _ in model.named_parameters()])
+    assert np.allclose(norms, g[f"{tag}_gradnorms"], rtol=5e-2 if training else 1e-3, atol=1e-6)
+
+
+def test_state_dict_matches_reference(g_minkunet):
+    cfg, model = _build("MinkUNet", 4)
+    sd = model.state_dict()
+    assert list(sd.keys()) == g_minkunet["state_keys"].tolist()
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == g_minkunet["state_shapes"].tolist()
+
+
+def test_minkunet_vs_oracle_bigger_scan():
+    """a 20k-point scan, bs = 2: HIP logits vs the CPU oracle (eval-mode BN), kmaps bit-exact"""
+    from oracle import model as OM
+    from oracle import ts_oracle as O
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.collate import sparse_collate
+    cfg, model = _build("MinkUNet", 4)
+    model.eval()
+    samples = []
+    for seed in (41, 42):
+        pts, lab = synth_scan(seed, n_points=20000, n_beams=32, n_az=1000)
+        pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+        pc -= pc.min(0)
+        idx, _ = O.sparse_quantize(pc)
+        samples.append(SparseTensor(torch.from_numpy(pts[idx]), torch.from_numpy(pc[idx])))
+    batch = sparse_collate(samples)
+    coords, feats = batch.C.int().numpy(), batch.F.float()
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    om = OM.OracleMinkUNet(params, cfg, training=False)
+    with torch.no_grad():
+        want = om.forward_minkunet(coords, feats).numpy()
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o))
+    x = SparseTensor(feats.cuda(), torch.from_numpy(coords).cuda())
+    model.train()            # take the training branch (returns before the eval un-voxelisation) ...
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()         # ... with running statistics
+    with torch.no_grad():
+        model({"lidar": x, "targets": SparseTensor(torch.zeros(len(coords), dtype=torch.long).cuda(), x.C),
+               "offset": torch.tensor([0])})
+    h.remove()
+    got = grabbed["logits"].cpu().numpy()
+    assert np.abs(got - want).max() <= LOGIT_TOL
+    # rulebooks of the whole pyramid: bit-exact against the oracle's
+    for (stride, ks, st), (nbmaps, nbsizes, sizes) in om.debug["kmaps"].items():
+        key = ((stride,) * 3, (ks,) * 3, (st,) * 3, (1, 1, 1))
+        km = x.kmaps[key]
+        assert km.sizes == sizes
+        assert np.array_equal(km.nbmaps.cpu().numpy(), nbmaps)
+        assert np.array_equal(km.nbsizes.cpu().numpy(), nbsizes)
+
+
+def test_eval_branch_unvoxelises(g_minkunet):
+    """forward(eval) returns per-point predictions through inverse_map (minkunet.py:435-455)"""
+    from taseg_amd.torchsparse import SparseTensor
+    cfg, model = _build("MinkUNet", 4)
+    model.eval()
+    g = g_minkunet
+    coords = torch.from_numpy(g["coords"]).cuda()
+    n = len(coords)
+    rs = np.random.RandomState(0)
+    per_scan = [int((g["coords"][:, 3] == b).sum()) for b in range(2)]
+    inv = np.concatenate([rs.randint(0, m, size=m + 50) for m in per_scan])
+    invc = np.concatenate([np.full((m + 50, 4), b, dtype=np.int32) for b, m in enumerate(per_scan)])
+    bd = {"lidar": SparseTensor(torch.from_numpy(g["feats"]).cuda(), coords),
+          "inverse_map": SparseTensor(torch.from_numpy(inv).cuda(), torch.from_numpy(invc).cuda()),
+          "targets_mapped": SparseTensor(torch.zeros(len(inv), dtype=torch.uint8).cuda(), torch.from_numpy(invc).cuda()),
+          "num_points": torch.tensor([m + 50 for m in per_scan]), "name": ["a", "b"]}
+    with torch.no_grad():
+        out = model(bd)
+    assert [len(p) for p in out["point_predict"]] == [m + 50 for m in per_scan]
+    assert out["point_predict_logits"][0].shape == (per_scan[0] + 50, 20)
+    assert n == sum(per_scan)

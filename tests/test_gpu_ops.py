@@ -1,0 +1,328 @@
+"""Parity of every HIP entry point (through the C ABI, via taseg_amd.backend) against the golden
+vectors of the real reference and against the CPU oracle on seeded inputs.
+
+Bars: integer / index results bit-exact; fp32 results <= 1e-5 relative to the tensor's scale
+(MFMA f32 accumulates in a different order than the reference's BLAS GEMM + scatter-add)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ts_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def close(a, b, tol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+    assert err <= tol * scale, (err, scale)
+
+
+def same(a, b):
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == np.asarray(b).shape, (a.shape, np.asarray(b).shape)
+    assert np.array_equal(a, b)
+
+
+@pytest.fixture(scope="module")
+def B():
+    from taseg_amd import backend
+    return backend
+
+
+@pytest.fixture(scope="module")
+def F():
+    from taseg_amd.torchsparse.nn import functional
+    return functional
+
+
+# --------------------------------------------------------------------------- hashing / query / count
+def test_hash_golden(B, g_ops):
+    same(B.hash_cuda(T(g_ops["coords"])), g_ops["hash"])
+    same(B.hash_cuda(T(g_ops["coords_neg"])), g_ops["hash_neg"])
+    same(B.kernel_hash_cuda(T(g_ops["coords"]), T(g_ops["offsets_k3s1"])), g_ops["khash_k3s1"])
+
+
+def test_hash_known_answers(B):
+    c = torch.tensor([[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [1, 0, 0, 1]], dtype=torch.int32, device=DEV)
+    assert B.hash_cuda(c).tolist() == [947293587111810033, 948793285165995886, 947292487600181830,
+                                       948794384677624093]
+
+
+def test_hash_empty_and_large(B):
+    assert B.hash_cuda(torch.zeros((0, 4), dtype=torch.int32, device=DEV)).numel() == 0
+    rs = np.random.RandomState(0)
+    c = rs.randint(-2000, 2000, size=(300001, 4)).astype(np.int32)
+    same(B.hash_cuda(T(c)), O.sphash(c))
+
+
+def test_hash_query_semantics(B, F):
+    rs = np.random.RandomState(1)
+    refs = np.unique(rs.randint(0, 1 << 40, size=5000).astype(np.int64))
+    q = np.concatenate([refs[::3], rs.randint(0, 1 << 40, size=2000).astype(np.int64)])
+    want = O.sphashquery(q, refs)
+    got = F.sphashquery(T(q), T(refs))
+    same(got, want)
+    # explicit idx + duplicate reference keys keep the first (query_cpu.cpp:20-24)
+    refs2 = np.array([5, 9, 5, 7], dtype=np.int64)
+    idx2 = np.array([10, 11, 12, 13], dtype=np.int64)
+    got2 = B.hash_query_cuda(T(np.array([5, 7, 8, 9], dtype=np.int64)), T(refs2), T(idx2))
+    assert got2.tolist() == [11, 14, 0, 12]
+    # 2-D query keeps its shape; empty reference set -> all misses
+    q2 = T(q[:12].reshape(3, 4))
+    assert F.sphashquery(q2, T(refs)).shape == (3, 4)
+    assert (F.sphashquery(q2, torch.zeros(0, dtype=torch.int64, device=DEV)) == -1).all()
+
+
+def test_count(B):
+    rs = np.random.RandomState(2)
+    idx = rs.randint(-1, 50, size=10000).astype(np.int32)
+    same(B.count_cuda(T(idx), 50), O.spcount(idx, 50))
+
+
+# --------------------------------------------------------------------------- rulebook
+def test_downsample_and_kmaps_golden(B, F, g_ops):
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    cur, ts = T(g_ops["coords"]), 1
+    for _ in range(3):
+        km = B.build_kmap(cur, cur, get_kernel_offsets(3, ts, 1, device=DEV))
+        total = int(km["nboffs"][-1])
+        same(km["nbr"], g_ops[f"k3_s{ts}_results"])
+        same(km["nbmaps"][:total], g_ops[f"k3_s{ts}_nbmaps"])
+        same(km["nbsizes"], g_ops[f"k3_s{ts}_nbsizes"])
+        down = F.spdownsample(cur, 2, 2, ts)
+        same(down, g_ops[f"down_s{ts}"])
+        km2 = B.build_kmap(cur, down, get_kernel_offsets(2, ts, 1, device=DEV))
+        total2 = int(km2["nboffs"][-1])
+        assert total2 == cur.shape[0]
+        same(km2["nbr"], g_ops[f"k2_s{ts}_results"])
+        same(km2["nbmaps"][:total2], g_ops[f"k2_s{ts}_nbmaps"])
+        same(km2["nbsizes"], g_ops[f"k2_s{ts}_nbsizes"])
+        # inverse table is the exact inverse of the neighbour table
+        nbr, nbr_t = km2["nbr"].cpu().numpy(), km2["nbr_t"].cpu().numpy()
+        kk, jj = np.nonzero(nbr >= 0)
+        assert np.array_equal(nbr_t[kk, nbr[kk, jj]], jj)
+        assert (nbr_t >= 0).sum() == (nbr >= 0).sum()
+        cur, ts = down, ts * 2
+
+
+def _blob(seed, n=20000, extent=48, batch=2):
+    """dense random blob: many neighbours per voxel, unique rows, shuffled (unsorted) order"""
+    rs = np.random.RandomState(seed)
+    c = np.unique(np.concatenate([rs.randint(0, extent, size=(n, 3)), rs.randint(0, batch, size=(n, 1))], 1), axis=0)
+    return c[rs.permutation(len(c))].astype(np.int32)
+
+
+def test_kmap_dense_blob_vs_oracle(B, F):
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    c = _blob(3)
+    res, nbmaps, nbsizes = O.build_kmap(c, c, O.get_kernel_offsets(3, 1, 1))
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+    same(km["nbr"], res.astype(np.int32))
+    same(km["nbmaps"][:int(km["nboffs"][-1])], nbmaps.astype(np.int32))
+    same(km["nbsizes"], nbsizes.astype(np.int32))
+    # symmetry of a submanifold k3 map: pair (i, o, k) <-> (o, i, 26 - k); centre = identity
+    nbr = km["nbr"].cpu().numpy()
+    assert np.array_equal(nbr[13], np.arange(len(c)))
+    assert np.array_equal(km["nbr_t"].cpu().numpy(), nbr[::-1])
+    down = O.spdownsample(c, 2, 2, 1)
+    same(F.spdownsample(T(c), 2, 2, 1), down)
+
+
+def test_downsample_negative_and_range(B, F):
+    c = _blob(4, n=3000, extent=30)
+    c[:, :3] -= 15                       # negative coordinates: trunc toward zero, like the reference
+    same(F.spdownsample(T(c), 2, 2, 1), O.spdownsample(c, 2, 2, 1))
+    bad = c.copy()
+    bad[0, 0] = 1 << 20
+    with pytest.raises(ValueError):
+        F.spdownsample(T(bad), 2, 2, 1)
+
+
+def test_unique_i64(B):
+    rs = np.random.RandomState(5)
+    keys = rs.randint(0, 1 << 59, size=4000).astype(np.int64)
+    keys = np.concatenate([keys, keys[:1500]])
+    u, inv = B.unique_i64(T(keys))
+    wu, winv = np.unique(keys, return_inverse=True)
+    same(u, wu)
+    same(inv, winv.astype(np.int32))
+
+
+# --------------------------------------------------------------------------- voxelize / devoxelize / trilinear
+def test_initial_voxelize_pieces_golden(B, F, g_ops):
+    pc = T(g_ops["iv_points_c"])
+    h = F.sphash(torch.floor(pc).int())
+    same(h, g_ops["iv_hash"])
+    u, inv = B.unique_i64(h)
+    same(u, g_ops["iv_sparse_hash"])
+    same(inv, g_ops["iv_idx_query"])
+    counts = F.spcount(inv, len(u))
+    same(counts, g_ops["iv_counts"])
+    vc = torch.round(F.spvoxelize(torch.floor(pc), inv, counts)).int()
+    same(vc, g_ops["iv_vox_c"])
+    pf = T(g_ops["iv_points_f"]).requires_grad_()
+    vf = F.spvoxelize(pf, inv, counts)
+    close(vf, g_ops["iv_vox_f"], 1e-6)
+    vf.backward(T(g_ops["iv_gv"]))
+    close(pf.grad, g_ops["iv_gf"], 1e-6)
+
+
+@pytest.mark.parametrize("s", [1, 4])
+def test_trilinear_and_devoxelize_golden(B, F, g_ops, s):
+    idx, w = B.trilinear_map(T(g_ops["tri_points"]), T(g_ops[f"tri_s{s}_vox"]), s)
+    same(idx, g_ops[f"tri_s{s}_idx"])
+    close(w, g_ops[f"tri_s{s}_w"], 1e-6)
+    feat = T(g_ops[f"tri_s{s}_feat"]).requires_grad_()
+    out = F.spdevoxelize(feat, idx, w)
+    close(out, g_ops[f"tri_s{s}_out"], 1e-6)
+    out.backward(T(g_ops[f"tri_s{s}_gout"]))
+    close(feat.grad, g_ops[f"tri_s{s}_gfeat"], 1e-5)
+    # API-parity helper agrees with the fused kernel
+    w2 = F.calc_ti_weights(T(g_ops["tri_points"]), idx.t().contiguous(), scale=s).t()
+    close(w2, w, 1e-6)
+
+
+def test_devoxelize_adjoint_property(B, F):
+    """<A x, y> == <x, A^T y> for the voxel->point operator (SURVEY.md section 4 property test)."""
+    rs = np.random.RandomState(6)
+    m, n, c = 700, 1500, 20
+    idx = rs.randint(-1, m, size=(n, 8)).astype(np.int32)
+    w = rs.rand(n, 8).astype(np.float32)
+    x = rs.randn(m, c).astype(np.float32)
+    y = rs.randn(n, c).astype(np.float32)
+    ax = B.devoxelize_forward_cuda(T(x), T(idx), T(w))
+    aty = B.devoxelize_backward_cuda(T(y), T(idx), T(w), m)
+    lhs = float((ax.double() * T(y).double()).sum())
+    rhs = float((T(x).double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    close(ax, O.devoxelize_forward(x, idx, w), 1e-5)
+
+
+# --------------------------------------------------------------------------- convolution
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_conv_golden(B, F, g_ops, tag, impl):
+    from taseg_amd.torchsparse import SparseTensor
+    B.set_conv_impl(impl)
+    try:
+        x = T(g_ops[f"conv_{tag}_x"]).requires_grad_()
+        w = T(g_ops[f"conv_{tag}_w"]).requires_grad_()
+        y = F.conv3d(SparseTensor(x, T(g_ops["coords"]), 1), w, 3)
+        close(y.F, g_ops[f"conv_{tag}_y"])
+        y.F.backward(T(g_ops[f"conv_{tag}_gy"]))
+        close(x.grad, g_ops[f"conv_{tag}_gx"])
+        close(w.grad, g_ops[f"conv_{tag}_gw"])
+    finally:
+        B.set_conv_impl(0)
+
+
+def test_conv_strided_transposed_golden(B, F, g_ops):
+    from taseg_amd.torchsparse import SparseTensor
+    x = T(g_ops["convt_x"]).requires_grad_()
+    wd = T(g_ops["convt_wd"]).requires_grad_()
+    wu = T(g_ops["convt_wu"]).requires_grad_()
+    st = SparseTensor(x, T(g_ops["coords"]), 1)
+    st.cmaps[st.stride] = st.coords
+    yd = F.conv3d(st, wd, 2, stride=2)
+    same(yd.C, g_ops["convt_coords_d"])
+    close(yd.F, g_ops["convt_yd"])
+    yu = F.conv3d(yd, wu, 2, stride=2, transposed=True)
+    close(yu.F, g_ops["convt_yu"])
+    yu.F.backward(T(g_ops["convt_gy"]))
+    close(x.grad, g_ops["convt_gx"])
+    close(wd.grad, g_ops["convt_gwd"])
+    close(wu.grad, g_ops["convt_gwu"])
+
+
+@pytest.mark.parametrize("ci,co", [(4, 32), (32, 32), (64, 64), (96, 128), (128, 256), (384, 256), (48, 24)])
+def test_conv_dense_blob_vs_oracle(B, F, ci, co):
+    """every kernel template bucket (C_out <= 32 / 64 / 128 / 256, C_in 4 .. 384), many neighbours per voxel"""
+    from taseg_amd.torchsparse import SparseTensor
+    rs = np.random.RandomState(ci * 1000 + co)
+    c = _blob(7, n=3000, extent=20)
+    _, nbmaps, nbsizes = O.build_kmap(c, c, O.get_kernel_offsets(3, 1, 1))
+    xn = rs.randn(len(c), ci).astype(np.float32)
+    wn = (rs.randn(27, ci, co) / np.sqrt(27 * ci)).astype(np.float32)
+    gyn = rs.randn(len(c), co).astype(np.float32)
+    want_y = O.conv_forward(xn, wn, nbmaps, nbsizes, (len(c), len(c)))
+    want_gx, want_gw = O.conv_backward(xn, wn, gyn, nbmaps, nbsizes)
+    x, w = T(xn).requires_grad_(), T(wn).requires_grad_()
+    y = F.conv3d(SparseTensor(x, T(c), 1), w, 3)
+    close(y.F, want_y, 2e-5)
+    y.F.backward(T(gyn))
+    close(x.grad, want_gx, 2e-5)
+    close(w.grad, want_gw, 2e-5)
+
+
+def test_conv_reference_form_entry_points(B, g_ops):
+    """the ten-function lower boundary: explicit nbmaps + host nbsizes, plain and transposed"""
+    c = g_ops["coords"]
+    x, w, gy = g_ops["conv_b_x"], g_ops["conv_b_w"], g_ops["conv_b_gy"]
+    nbmaps, nbsizes = g_ops["k3_s1_nbmaps"], g_ops["k3_s1_nbsizes"]
+    out = torch.zeros(len(c), w.shape[2], device=DEV)
+    B.convolution_forward_cuda(T(x), out, T(w), T(nbmaps), torch.from_numpy(nbsizes), False)
+    close(out, g_ops["conv_b_y"])
+    gin, gw = torch.zeros(x.shape, device=DEV), torch.zeros(w.shape, device=DEV)
+    B.convolution_backward_cuda(T(x), gin, T(gy), T(w), gw, T(nbmaps), torch.from_numpy(nbsizes), False)
+    close(gin, g_ops["conv_b_gx"])
+    close(gw, g_ops["conv_b_gw"])
+    # transposed through the strided map
+    nb2, ns2 = g_ops["k2_s1_nbmaps"], g_ops["k2_s1_nbsizes"]
+    yu = torch.zeros(len(c), g_ops["convt_wu"].shape[2], device=DEV)
+    B.convolution_forward_cuda(T(g_ops["convt_yd"]), yu, T(g_ops["convt_wu"]), T(nb2), torch.from_numpy(ns2), True)
+    close(yu, g_ops["convt_yu"])
+    with pytest.raises(ValueError):
+        B.convolution_forward_cuda(T(x[:, :3].copy()), out, T(w), T(nbmaps), torch.from_numpy(nbsizes), False)
+
+
+def test_conv_empty_and_ragged(B, F):
+    from taseg_amd.torchsparse import SparseTensor
+    # a single voxel, and a row count that is not a multiple of any tile size
+    for n in (1, 129, 257):
+        c = _blob(8, n=4 * n, extent=12)[:n]
+        _, nbmaps, nbsizes = O.build_kmap(c, c, O.get_kernel_offsets(3, 1, 1))
+        rs = np.random.RandomState(n)
+        xn, wn = rs.randn(n, 16).astype(np.float32), rs.randn(27, 16, 48).astype(np.float32)
+        y = F.conv3d(SparseTensor(T(xn), T(c), 1), T(wn), 3)
+        close(y.F, O.conv_forward(xn, wn, nbmaps, nbsizes, (n, n)), 2e-5)
+    empty = B.conv_nbr(torch.zeros((0, 16), device=DEV), torch.zeros((27, 16, 32), device=DEV),
+                       torch.zeros((27, 0), dtype=torch.int32, device=DEV), 0)
+    assert empty.shape == (0, 32)
+
+
+def test_cpu_tensors_are_rejected(B):
+    with pytest.raises(RuntimeError):
+        B.hash_cuda(torch.zeros((4, 4), dtype=torch.int32))
+
+
+# --------------------------------------------------------------------------- data stage kernels
+def test_fuse_voxelise_quantize_golden(B, g_multiscan):
+    g = g_multiscan
+    Tn = int(g["T"])
+    for b in range(2):
+        pose0 = T(g[f"b{b}_pose_t{Tn}"])
+        fused = [B.fuse_scan(T(g[f"b{b}_points_t{t}"]), pose0, T(g[f"b{b}_pose_t{t}"])) for t in range(Tn)]
+        same(torch.cat(fused), g[f"b{b}_fused_all"])                       # bit-exact float32
+    # voxel coords + quantize on the fused cloud of scan 0 against the oracle
+    ms = g["b0_raw_data_ms"]
+    want_c = O.voxel_coords(ms, 0.05)
+    want_c = want_c - want_c.min(0)
+    c4, mins = B.voxel_coords(T(ms), 0.05)
+    same(c4[:, :3], want_c)
+    widx, winv = O.sparse_quantize(want_c)
+    idx, inv = B.sparse_quantize(c4)
+    same(idx, widx.astype(np.int32))
+    same(inv, winv.astype(np.int32))

@@ -1,0 +1,117 @@
+"""Host-side logic that needs no GPU: containers, kernel offsets, numpy quantize / collate against the
+oracle, state_dict layout against the reference's, the vectorised Lovasz loss against the per-class loop."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from oracle import ts_oracle as O
+from taseg_amd.data.synthetic import AttrDict, fill_parameters, make_model_cfg, synth_pose, synth_scan
+from taseg_amd.pcseg.loss import Losses, lovasz_softmax
+from taseg_amd.pcseg.model import build_network
+from taseg_amd.torchsparse import PointTensor, SparseTensor, cat
+from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+from taseg_amd.torchsparse.utils import make_ntuple, sparse_collate_fn, sparse_quantize
+
+
+def test_kernel_offsets_match_oracle():
+    for size, stride in ((3, 1), (3, 4), (2, 1), (2, 8), ((3, 1, 3), 2)):
+        assert np.array_equal(get_kernel_offsets(size, stride).numpy(), O.get_kernel_offsets(size, stride))
+    k3 = get_kernel_offsets(3, 1).tolist()
+    assert k3[13] == [0, 0, 0] and k3[0] == [-1, -1, -1] and k3[1] == [0, -1, -1]   # x innermost, centre = 13
+
+
+def test_sparse_quantize_numpy_matches_oracle():
+    pts, _ = synth_scan(3, n_points=5000, n_beams=16, n_az=500)
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    coords, idx, inv = sparse_quantize(pc, return_index=True, return_inverse=True)
+    widx, winv = O.sparse_quantize(pc)
+    assert np.array_equal(idx, widx) and np.array_equal(inv, winv)
+    assert np.array_equal(coords, pc[widx])
+    assert np.array_equal(coords[inv], pc)                       # inverse map reconstructs every point's voxel
+    assert np.all(np.diff(O.ravel_hash(coords).astype(np.int64)) > 0)   # strictly ascending ravel key
+
+
+def test_collate_appends_batch_column():
+    a = {"lidar": SparseTensor(np.ones((3, 4), np.float32), np.zeros((3, 3), np.int32)), "name": "a",
+         "num_points": np.array([3])}
+    b = {"lidar": SparseTensor(np.ones((2, 4), np.float32), np.ones((2, 3), np.int32)), "name": "b",
+         "num_points": np.array([2])}
+    out = sparse_collate_fn([a, b])
+    assert out["lidar"].C.shape == (5, 4) and out["lidar"].C[:, 3].tolist() == [0, 0, 0, 1, 1]
+    assert out["name"] == ["a", "b"] and out["num_points"].shape == (2, 1)
+
+
+def test_containers_share_caches():
+    x = SparseTensor(torch.ones(4, 2), torch.zeros(4, 4, dtype=torch.int32), 2)
+    assert x.s == (2, 2, 2) and x.F is x.feats and x.C is x.coords
+    y = x + x
+    z = cat([x, y])
+    assert y.kmaps is x.kmaps and z.cmaps is x.cmaps and z.F.shape == (4, 4) and float(y.F.sum()) == 16
+    x.F = x.F[:, :1]
+    assert x.feats.shape == (4, 1)
+    p = PointTensor(torch.ones(4, 2), torch.zeros(4, 4))
+    q = p + p
+    assert q.idx_query is p.idx_query and q.additional_features is p.additional_features
+    assert make_ntuple(3, 3) == (3, 3, 3) and make_ntuple([1, 2, 3], 3) == (1, 2, 3)
+
+
+def test_state_dict_layout_matches_reference(g_minkunet, g_minkunet_ms):
+    for name, in_dim, g in (("MinkUNet", 4, g_minkunet), ("MinkUNetMs", 5, g_minkunet_ms)):
+        cfg = make_model_cfg(name, in_dim=in_dim, cr=0.5, num_layer=[1] * 8)
+        sd = build_network(cfg, 20).state_dict()
+        assert list(sd.keys()) == g["state_keys"].tolist()
+        assert [",".join(map(str, v.shape)) for v in sd.values()] == g["state_shapes"].tolist()
+
+
+def test_mk34_parameter_count():
+    m = build_network(make_model_cfg("MinkUNet", in_dim=4, cr=1.0), 20)
+    assert sum(p.numel() for p in m.parameters()) == 37882900 and len(m.state_dict()) == 380
+    m5 = build_network(make_model_cfg("MinkUNetMs", in_dim=5, cr=1.0), 20)
+    assert sum(p.numel() for p in m5.parameters()) == 37883764
+
+
+def test_fill_parameters_is_order_independent(g_minkunet):
+    import zlib
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
+    sd = fill_parameters(build_network(cfg, 20), seed=3).state_dict()
+    crc = np.array([zlib.crc32(v.numpy().tobytes()) for v in sd.values()], dtype=np.int64)
+    assert np.array_equal(crc, g_minkunet["param_crc"])       # same parameters as the reference model got
+
+
+def test_registry_errors():
+    with pytest.raises(NotImplementedError):
+        build_network(AttrDict(NAME="SPVCNN"), 20)
+    with pytest.raises(NameError):
+        build_network(AttrDict(NAME="Nope"), 20)
+    with pytest.raises(KeyError):
+        build_network(make_model_cfg("MinkUNet", BLOCK="Wrong"), 20)
+
+
+def test_lovasz_vectorised_equals_per_class_loop():
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(4000, 20, generator=g, requires_grad=True)
+    labels = torch.randint(0, 12, (4000,), generator=g)          # classes 12..19 absent, 0 ignored
+    a = lovasz_softmax(logits.softmax(1), labels, ignore=0)
+    b = OM.lovasz_softmax_ref(logits.softmax(1), labels, ignore=0)
+    assert abs(float(a) - float(b)) < 1e-6
+    ga, = torch.autograd.grad(a, logits, retain_graph=True)
+    gb, = torch.autograd.grad(b, logits)
+    assert float((ga - gb).abs().max()) < 1e-7
+    crit = Losses(["CELoss", "LovLoss"], [1.0, 1.0], ignore_index=0, label_smoothing=0.1)
+    want = OM.loss_ce_lovasz(logits, labels)
+    assert abs(float(crit(logits, labels)) - float(want)) < 1e-6
+    all_ignored = lovasz_softmax(logits.softmax(1), torch.zeros(4000, dtype=torch.long), ignore=0)
+    assert float(all_ignored.sum()) == 0.0
+    with pytest.raises(NotImplementedError):
+        Losses(["FocalLoss"], [1.0])
+
+
+def test_synthetic_scan_is_deterministic_and_shaped():
+    a, la = synth_scan(1000, n_points=120000)
+    b, lb = synth_scan(1000, n_points=120000)
+    assert a.shape == (120000, 4) and a.dtype == np.float32 and np.array_equal(a, b) and np.array_equal(la, lb)
+    assert set(np.unique(la)) <= set(range(20)) and len(np.unique(la)) >= 6
+    h, _ = synth_scan(1001, n_points=4000, n_beams=16, n_az=400, pose=synth_pose(2), scene_seed=1000)
+    assert h.shape[1] == 4 and synth_pose(0).tolist() == np.eye(4).tolist()
