@@ -41,17 +41,12 @@ def parse():
 def make_scans(rank, batch, points, workload):
     """Seeded synthetic scans (seed = 1000 * seq + frame, seq = rank), dataset-voxelised on the host with
     numpy exactly like the reference's CPU workers, returned as resident device tensors."""
-    from taseg_amd.data.synthetic import synth_pose, synth_scan, FLEXIBLE_STEPS_KITTI
+    from taseg_amd.data.synthetic import synth_scan
     from taseg_amd.torchsparse.utils.quantize import sparse_quantize
     coords, feats, labels, npts = [], [], [], 0
     for b in range(batch):
         seed = 1000 * rank + 10 * b
         pts, lab = synth_scan(seed, n_points=points)
-        if workload == "minkunet_ms":
-            # "4-scan TFA": current scan + T = 4 pose-aligned history scans filtered by the reference
-            # FLEXIBLE_STEPS schedule, time flag in column 4 (SURVEY.md section 8(d) config 3)
-            from taseg_amd.data.stage import fuse_history_host
-            pts, lab = fuse_history_host(seed, pts, lab, points, synth_scan, synth_pose, FLEXIBLE_STEPS_KITTI)
         pc = np.round(pts[:, :3] / VOXEL).astype(np.int32)
         pc -= pc.min(0, keepdims=True)
         _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
@@ -62,6 +57,28 @@ def make_scans(rank, batch, points, workload):
     dev = torch.device("cuda")
     return (torch.from_numpy(np.concatenate(coords)).to(dev), torch.from_numpy(np.concatenate(feats)).to(dev),
             torch.from_numpy(np.concatenate(labels)).to(dev), npts)
+
+
+def make_multiscans(rank, batch, points, history=4):
+    """Raw resident scans for the "4-scan TFA" workload: per sample the
+    current scan plus `history` earlier scans of the same scene seen from the ego poses
+    synth_pose(t) (1.1 m and 0.4 deg per frame).  The temporal aggregation + voxelisation itself runs on the
+    device INSIDE the timed step (taseg_amd.data.stage.build_multiscan_batch)."""
+    from taseg_amd.data.synthetic import synth_pose, synth_scan
+    dev = torch.device("cuda")
+    scans, npts = [], 0
+    for b in range(batch):
+        seed = 1000 * rank + 10 * b
+        pts, labs, poses = [], [], []
+        for t in range(history + 1):               # frame t: current = history, oldest = 0
+            pose = synth_pose(history - t)
+            p, l = synth_scan(seed + t, n_points=points, pose=pose, scene_seed=seed)
+            pts.append(torch.from_numpy(p).to(dev))
+            labs.append(torch.from_numpy(l.astype(np.int64)).to(dev))
+            poses.append(torch.from_numpy(pose).to(dev))
+            npts += len(p)
+        scans.append({"points": pts, "labels": labs, "poses": poses, "name": f"{rank}/{b}"})
+    return scans, npts
 
 
 def cpu_baseline(cfg, points, sector_deg):
@@ -86,6 +103,8 @@ def cpu_baseline(cfg, points, sector_deg):
     _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
     coords = np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)
     feats = torch.from_numpy(pts[idx])
+    if cfg.IN_FEATURE_DIM == 5:
+        feats = torch.cat([feats, torch.ones(len(feats), 1)], 1)      # time flag of a current-frame point
     labels = torch.from_numpy(lab[idx].astype(np.int64))
     model = fill_parameters(build_network(cfg, 20), seed=0)
     learn = {k for k, _ in model.named_parameters()}
@@ -165,14 +184,27 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
     opt = torch.optim.SGD(model.parameters(), lr=0.02 * args.batch * world, momentum=0.9, weight_decay=1e-4)
 
-    coords, feats, labels, npts = make_scans(rank, args.batch, args.points, args.workload)
-    key, sfx = ("lidar_ms", "_ms") if ms else ("lidar", "")
-    offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
+    nvox = [0]
+    if ms:
+        from taseg_amd.data.stage import build_multiscan_batch
+        from taseg_amd.data.synthetic import FLEXIBLE_STEPS_KITTI
+        scans, npts = make_multiscans(rank, args.batch, args.points)
+
+        def make_batch():
+            bd = build_multiscan_batch(scans, VOXEL, FLEXIBLE_STEPS_KITTI)
+            nvox[0] = int(bd["lidar_ms"].C.shape[0])
+            return bd
+    else:
+        coords, feats, labels, npts = make_scans(rank, args.batch, args.points, args.workload)
+        offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
+        nvox[0] = int(coords.shape[0])
+
+        def make_batch():
+            return {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset}
 
     def step():
         opt.zero_grad(set_to_none=True)
-        bd = {key: SparseTensor(feats, coords), "targets" + sfx: SparseTensor(labels, coords), "offset" + sfx: offset}
-        ret, _, _ = net(bd)
+        ret, _, _ = net(make_batch())
         ret["loss"].mean().backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
@@ -228,7 +260,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name} mk34 cr1.0 ({'4-scan TFA multi-scan' if ms else 'single-frame'}), "
                                    f"bs={args.batch}/GPU, voxel 0.05 m, fp32, rulebook+fwd+loss+bwd+SGD step",
-                       "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": int(coords.shape[0]),
+                       "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}"},
             "loss": float(loss),
             "roofline": roofline,

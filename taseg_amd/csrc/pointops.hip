@@ -184,6 +184,7 @@ extern "C" int ts_devoxelize_backward(const float *grad_out, const int32_t *idx,
 __global__ __launch_bounds__(256) void fuse_scan_kernel(const float4 *__restrict__ pts, int64_t n,
                                                         const float *__restrict__ pose0,
                                                         const float *__restrict__ pose, float4 *__restrict__ out) {
+#pragma clang fp contract(off)  // numpy multiplies, then adds: no fused multiply-add anywhere below
   // 32 wave-uniform scalars
   float P[16], Q[16];
 #pragma unroll

@@ -1,0 +1,132 @@
+"""Device-resident data stage: TASeg's multi-scan temporal aggregation (FSA) + dataset voxelisation.
+
+The reference does this in numpy inside DataLoader workers
+(R/pcseg/data/dataset/semantickitti/semantickitti_ms.py:140-149,253-320,403-417 and
+semantickitti_voxel_ms.py:77-212); here the same steps run on the GPU on resident scans:
+
+  pose fuse            ts_fuse_scan        p' = ((p R_t^T + t_t) - t_0) R_0, float32, reference summation order
+  class-step filter    lookup table        keep a history point iff steps[class] != 0 and |delta| % steps[class] == 0
+  concat + time flag   torch.cat           current scan first (flag 1), kept history points after it (flag 0)
+  voxel coordinates    ts_voxel_coords     int32(round_half_even(xyz / voxel)) - min
+  voxel grouping       ts_sparse_quantize  radix sort + first-occurrence representative + inverse map
+
+Outputs have the reference's exact layout and ORDER (batch_dict schema of SURVEY.md appendix C), checked bit
+for bit against the reference dataset code in tests (tests/golden/multiscan.npz).
+"""
+from typing import Dict, List, Sequence
+
+import torch
+
+from .. import backend as B
+from ..torchsparse import SparseTensor
+
+__all__ = ["fuse_multiscan", "voxelize_sample_ms", "voxelize_sample", "collate_batch", "build_multiscan_batch"]
+
+
+def _keep_table(steps: Sequence[int], delta: int, device) -> torch.Tensor:
+    """bool[num_classes]: is class c aggregated from the scan `delta` frames away (semantickitti_ms.py:303-308)."""
+    return torch.tensor([bool(s) and abs(delta) % s == 0 for s in steps], dtype=torch.bool, device=device)
+
+
+def fuse_multiscan(cur_pts, cur_lab, hist_pts: List[torch.Tensor], hist_lab: List[torch.Tensor], pose0,
+                   hist_poses: List[torch.Tensor], deltas: Sequence[int], steps: Sequence[int]):
+    """Current scan + filtered, pose-aligned history scans -> (raw_data_ms [n, 5], labels_ms [n]).
+
+    cur_pts / hist_pts[i]: float32 [n, 4] (x, y, z, intensity) in their own sensor frames;
+    *_lab: class ids (learning-map ids, 0..C-1); poses: 4x4 float32 (world <- sensor);
+    deltas[i] < 0 is the frame offset of hist_pts[i].  History order is preserved (oldest first, as the
+    reference iterates delta = -MULTISCAN .. -1)."""
+    dev = cur_pts.device
+    parts, labs = [cur_pts[:, :4]], [cur_lab.long()]
+    for pts, lab, pose, delta in zip(hist_pts, hist_lab, hist_poses, deltas):
+        keep = _keep_table(steps, delta, dev)[lab.long()]
+        if not bool(keep.any()):
+            continue
+        sel = pts[keep].contiguous()            # filter first: fuse only what survives (same values, less work)
+        parts.append(B.fuse_scan(sel[:, :4].contiguous(), pose0, pose))
+        labs.append(lab[keep].long())
+    fused = torch.cat(parts, 0)
+    flag = torch.zeros((fused.shape[0], 1), dtype=fused.dtype, device=dev)
+    flag[:cur_pts.shape[0]] = 1                  # append_time_flag (semantickitti_ms.py:253-257)
+    return torch.cat([fused, flag], 1), torch.cat(labs, 0)
+
+
+def _quantize(points, voxel_size, shift=None):
+    coords4, mins = B.voxel_coords(points, voxel_size, shift=shift)
+    index, inverse = B.sparse_quantize(coords4)
+    return coords4[:, :3], mins, index.long(), inverse.long()
+
+
+def voxelize_sample(points, labels, voxel_size, name="") -> Dict:
+    """Single-frame sample (semantickitti_voxel.py:119-150)."""
+    pc, _, inds, inverse = _quantize(points, voxel_size)
+    return {"name": name, "lidar": SparseTensor(points[inds], pc[inds]), "targets": SparseTensor(labels[inds], pc[inds]),
+            "targets_mapped": SparseTensor(labels, pc), "inverse_map": SparseTensor(inverse, pc),
+            "num_points": torch.tensor([points.shape[0]])}
+
+
+def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name="") -> Dict:
+    """Multi-scan sample (semantickitti_voxel_ms.py:121-187): both clouds voxelised, the single-frame one
+    shifted by the fused cloud's minimum."""
+    lo = points[:, :3].min(0).values
+    clamp = (points_ms[:, :3] >= lo).all(1)                               # :121-124
+    points_ms, labels_ms = points_ms[clamp].contiguous(), labels_ms[clamp]
+    pc_ms, mins_ms, inds_ms, inverse_ms = _quantize(points_ms, voxel_size)
+    pc, _, inds, inverse = _quantize(points, voxel_size, shift=mins_ms)   # pc_ -= pc_ms_.min(0)  (:130)
+    return {
+        "name": name,
+        "lidar": SparseTensor(points[inds], pc[inds]), "targets": SparseTensor(labels[inds], pc[inds]),
+        "targets_mapped": SparseTensor(labels, pc), "inverse_map": SparseTensor(inverse, pc),
+        "num_points": torch.tensor([points.shape[0]]),
+        "lidar_ms": SparseTensor(points_ms[inds_ms], pc_ms[inds_ms]),
+        "targets_ms": SparseTensor(labels_ms[inds_ms], pc_ms[inds_ms]),
+        "targets_mapped_ms": SparseTensor(labels_ms, pc_ms), "inverse_map_ms": SparseTensor(inverse_ms, pc_ms),
+        "num_points_ms": torch.tensor([points_ms.shape[0]]),
+    }
+
+
+def _stack_sparse(items: List[SparseTensor]) -> SparseTensor:
+    coords = [torch.cat([t.coords, torch.full((t.coords.shape[0], 1), b, dtype=torch.int32, device=t.coords.device)], 1)
+              for b, t in enumerate(items)]
+    return SparseTensor(torch.cat([t.feats for t in items], 0), torch.cat(coords, 0).contiguous(), items[0].stride)
+
+
+def collate_batch(samples: List[Dict]) -> Dict:
+    """sparse_collate_fn + offsets + point_mask (semantickitti_voxel_ms.py:189-212), on device."""
+    out = {}
+    for key, first in samples[0].items():
+        col = [s[key] for s in samples]
+        if isinstance(first, SparseTensor):
+            out[key] = _stack_sparse(col)
+        elif isinstance(first, torch.Tensor):
+            out[key] = torch.stack(col, 0)
+        else:
+            out[key] = col
+    dev = out["lidar"].coords.device
+    for sfx in ("", "_ms"):
+        if "lidar" + sfx in out:
+            sizes = torch.tensor([s["lidar" + sfx].coords.shape[0] for s in samples])
+            out["offset" + sfx] = torch.cumsum(sizes, 0).int().to(dev)
+    if "num_points_ms" in out:
+        n_ms = [int(s["num_points_ms"]) for s in samples]
+        n_cur = [int(s["num_points"]) for s in samples]
+        mask = torch.zeros(sum(n_ms), dtype=torch.bool, device=dev)
+        cur = 0
+        for a, b in zip(n_cur, n_ms):
+            mask[cur:cur + a] = True          # the current frame is the prefix of every fused cloud
+            cur += b
+        out["point_mask"] = mask
+    return out
+
+
+def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[int]) -> Dict:
+    """scans[b] = dict(points=[T+1 tensors, current LAST], labels=[...], poses=[...], name=str).
+    Returns the collated batch_dict MinkUNetMs consumes."""
+    samples = []
+    for s in scans:
+        pts, lab, poses = s["points"], s["labels"], s["poses"]
+        t = len(pts) - 1
+        raw_ms, lab_ms = fuse_multiscan(pts[t], lab[t], pts[:t], lab[:t], poses[t], poses[:t],
+                                        [i - t for i in range(t)], steps)
+        samples.append(voxelize_sample_ms(pts[t], lab[t].long(), raw_ms, lab_ms, voxel_size, s.get("name", "")))
+    return collate_batch(samples)

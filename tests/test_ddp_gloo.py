@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: two gloo processes exercise the data-parallel helpers (scan sharding, DDP gradient
+averaging == single process on the concatenated batch, max-over-ranks timing, confusion all-reduce)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from taseg_amd import parallel as P
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _net():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 5))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, _, w = P.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    seeds = P.shard_seeds(rank, world, batch=2)
+    net = P.wrap_ddp(_net())
+    g = torch.Generator().manual_seed(seeds[0])
+    x, y = torch.randn(6, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+    torch.nn.functional.cross_entropy(net(x), y).backward()
+    grads = [p.grad.clone() for p in net.parameters()]
+    tmax = P.reduce_max(float(rank + 1))
+    hist = P.reduce_confusion(torch.full((3, 3), rank + 1, dtype=torch.int64))
+    out.put((rank, seeds, [g.tolist() for g in grads], tmax, hist.tolist()))   # plain lists: no shared-memory handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, g0, t0, h0), (_, s1, g1, t1, h1) = res
+    assert not set(s0) & set(s1)                                   # ranks never share a scan
+    g0, g1 = [torch.tensor(a) for a in g0], [torch.tensor(b) for b in g1]
+    h0, h1 = torch.tensor(h0), torch.tensor(h1)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b)                                # DDP left identical averaged grads on both ranks
+    # ... equal to the single-process gradient of the mean of the two per-rank losses
+    net = _net()
+    total = 0
+    for seeds in (s0, s1):
+        g = torch.Generator().manual_seed(seeds[0])
+        x, y = torch.randn(6, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+        total = total + torch.nn.functional.cross_entropy(net(x), y) / 2
+    total.backward()
+    for a, p in zip(g0, net.parameters()):
+        assert torch.allclose(a, p.grad, atol=1e-6)
+    assert t0 == t1 == 2.0
+    assert int(h0[0, 0]) == 3 and torch.equal(h0, h1)
+
+
+def test_single_process_helpers_are_noops():
+    assert P.shard_seeds(3, 8, 2) == [3000, 3010]
+    m = _net()
+    assert P.wrap_ddp(m) is m and P.reduce_max(1.5) == 1.5

@@ -91,6 +91,7 @@ def test_minkunet_vs_oracle_bigger_scan():
         want = om.forward_minkunet(coords, feats).numpy()
     grabbed = {}
     h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o))
+    h2 = model.stem[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("kmaps", o.kmaps))
     x = SparseTensor(feats.cuda(), torch.from_numpy(coords).cuda())
     model.train()            # take the training branch (returns before the eval un-voxelisation) ...
     for m in model.modules():
@@ -100,12 +101,14 @@ def test_minkunet_vs_oracle_bigger_scan():
         model({"lidar": x, "targets": SparseTensor(torch.zeros(len(coords), dtype=torch.long).cuda(), x.C),
                "offset": torch.tensor([0])})
     h.remove()
+    h2.remove()
     got = grabbed["logits"].cpu().numpy()
     assert np.abs(got - want).max() <= LOGIT_TOL
-    # rulebooks of the whole pyramid: bit-exact against the oracle's
+    # rulebooks of the whole pyramid (5 submanifold + 4 strided maps): bit-exact against the oracle's
+    assert len(grabbed["kmaps"]) == len(om.debug["kmaps"]) == 9
     for (stride, ks, st), (nbmaps, nbsizes, sizes) in om.debug["kmaps"].items():
         key = ((stride,) * 3, (ks,) * 3, (st,) * 3, (1, 1, 1))
-        km = x.kmaps[key]
+        km = grabbed["kmaps"][key]
         assert km.sizes == sizes
         assert np.array_equal(km.nbmaps.cpu().numpy(), nbmaps)
         assert np.array_equal(km.nbsizes.cpu().numpy(), nbsizes)

@@ -326,3 +326,23 @@ def test_fuse_voxelise_quantize_golden(B, g_multiscan):
     idx, inv = B.sparse_quantize(c4)
     same(idx, widx.astype(np.int32))
     same(inv, winv.astype(np.int32))
+
+
+def test_device_multiscan_stage_golden(g_multiscan):
+    """fuse + class-step filter + time flag + double voxelisation + collate on device == the reference's
+    numpy dataset code (semantickitti_ms.py / semantickitti_voxel_ms.py), bit for bit, bs = 2"""
+    from taseg_amd.data.stage import build_multiscan_batch
+    g = g_multiscan
+    Tn = int(g["T"])
+    lm = g["learning_map"]
+    scans = []
+    for b in range(2):
+        scans.append({"points": [T(g[f"b{b}_points_t{t}"]) for t in range(Tn + 1)],
+                      "labels": [T(lm[g[f"b{b}_rawlabels_t{t}"]]) for t in range(Tn + 1)],
+                      "poses": [T(g[f"b{b}_pose_t{t}"]) for t in range(Tn + 1)], "name": str(b)})
+    batch = build_multiscan_batch(scans, 0.05, g["steps"].tolist())
+    for key in ("lidar", "lidar_ms", "inverse_map", "inverse_map_ms", "targets", "targets_ms"):
+        same(batch[key].C, g[f"batch_{key}_C"])
+        same(batch[key].F.to(torch.from_numpy(g[f"batch_{key}_F"]).dtype), g[f"batch_{key}_F"])
+    for key in ("num_points", "num_points_ms", "offset", "offset_ms", "point_mask"):
+        same(batch[key].to(torch.from_numpy(g[f"batch_{key}"]).dtype), g[f"batch_{key}"])
