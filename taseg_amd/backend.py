@@ -289,16 +289,28 @@ class _Timed:
         return False
 
 
-def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None):
-    """The template instantiation ts_conv_nbr / ts_conv_wgrad picks (mirrors csrc/conv.hip)."""
+def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None, n_out=0):
+    """The template instantiation ts_conv_nbr / ts_conv_wgrad picks (mirrors the heuristic in csrc/conv.hip)."""
     if wgrad_cb is not None:
         units = ((c_out_or_ca + 15) // 16) * ((min(64, wgrad_cb) + 15) // 16)
         per_wave = (units + 3) // 4
         maxu = next(m for m in (2, 4, 8, 16, 24) if per_wave <= m)
         return f"conv_wgrad_kernel<{maxu}>"
-    nsplit = (c_out_or_ca + 255) // 256
-    o_tile = ((c_out_or_ca + nsplit - 1) // nsplit + 15) & ~15
-    bm, maxu = ((128, 4) if o_tile <= 32 else (128, 8) if o_tile <= 64 else (64, 8) if o_tile <= 128 else (64, 16))
+    c16 = (c_out_or_ca + 15) & ~15
+    tiles64 = -(-n_out // 64)
+    if c16 <= 64:
+        o_tile = c16
+    elif tiles64 * (-(-c16 // 128)) >= 1024:
+        o_tile = 128 if (c16 % 128 == 0 or c16 > 256) else (c16 if c16 <= 128 else 64)
+    else:
+        o_tile = 64 if (c16 % 64 == 0 or c16 > 128) else c16
+    if 64 < c16 <= 128 and c16 % 64 != 0:
+        o_tile = c16
+    bm = 128 if (o_tile <= 64 and tiles64 >= 2048) else 64
+    if bm == 128:
+        maxu = 4 if o_tile <= 32 else 8
+    else:
+        maxu = 2 if o_tile <= 32 else 4 if o_tile <= 64 else 8 if o_tile <= 128 else 16
     return f"conv_nbr_kernel<{bm},{maxu},{'true' if weight_transposed else 'false'}>"
 
 
@@ -315,7 +327,7 @@ def conv_nbr(in_feat, kernel, nbr, n_out, weight_transposed=False):
     if nbr.shape != (k, n_out):
         raise ValueError(f"neighbour table shape {tuple(nbr.shape)} != {(k, n_out)}")
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=in_feat.device)
-    with _Timed("conv_nbr", name=conv_kernel_name(c_out, weight_transposed), nbr=nbr, c_red=c_red, c_out=c_out, k=k,
+    with _Timed("conv_nbr", name=conv_kernel_name(c_out, weight_transposed, n_out=n_out), nbr=nbr, c_red=c_red, c_out=c_out, k=k,
                 n_in=in_feat.shape[0], n_out=n_out):
         L.check(L.load().ts_conv_nbr(L.ptr(in_feat), in_feat.shape[0], c_red, L.ptr(kernel), k,
                                      1 if weight_transposed else 0, L.ptr(nbr), L.ptr(out), n_out, c_out,

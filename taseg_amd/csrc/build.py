@@ -17,6 +17,9 @@ SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "quantize.hip"]
 LIB = os.path.join(PKG, "libtaseg_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# files whose float results must equal numpy's bit for bit (pose fuse, voxel rounding): hipcc's default
+# -ffp-contract=fast would fuse a*b+c into one rounding
+EXTRA = {"pointops.hip": ["-ffp-contract=off"], "quantize.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include")]
 
@@ -39,7 +42,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in _deps()):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -39,11 +39,16 @@ template <int BM, int MAXU, bool WT>
 __global__ __launch_bounds__(256) void conv_nbr_kernel(const float *__restrict__ X, int R,
                                                        const float *__restrict__ W,
                                                        const int *__restrict__ nbr, int64_t n_out, int K,
-                                                       float *__restrict__ Y, int O_total, int o_tile) {
+                                                       float *__restrict__ Y, int O_total, int o_tile,
+                                                       int k_per_group) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int o0 = blockIdx.y * o_tile;
+  // blockIdx.z = group of kernel offsets handled by this workgroup (small problems are split
+  // over offsets to fill the chip; the groups' tiles are then combined with float atomics)
+  const int k_begin = blockIdx.z * k_per_group;
+  const int k_end = min(K, k_begin + k_per_group);
   const int OT = min(o_tile, O_total - o0);
   const int O16 = (OT + 15) & ~15;
   const int OP = O16 + 4;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_nbr_kernel(const float *__restrict__
   const bool w_vec = WT ? (((R & 3) == 0) && ((((uintptr_t)W) & 15) == 0))
                         : (((O_total & 3) == 0) && ((o0 & 3) == 0) && ((((uintptr_t)W) & 15) == 0));
 
-  for (int k = 0; k < K; ++k) {
+  for (int k = k_begin; k < k_end; ++k) {
     __syncthreads();  // previous offset fully folded into outT; lists / tiles reusable
     // ---- compact the rows of this tile that have a neighbour at offset k
     int idx = -1, rank = 0;
@@ -213,7 +218,15 @@ __global__ __launch_bounds__(256) void conv_nbr_kernel(const float *__restrict__
     }
   }
   __syncthreads();
-  // ---- write the tile once, coalesced
+  // ---- write the tile once, coalesced (or add it, when the offsets were split over workgroups)
+  if (gridDim.z > 1) {
+    for (int e = tid; e < nrows * OT; e += 256) {
+      int rr = e / OT, cc = e - rr * OT;
+      float v = outT[rr * OP + cc];
+      if (v != 0.f) atomicAdd(&Y[(row0 + rr) * O_total + o0 + cc], v);
+    }
+    return;
+  }
   const bool y_vec = ((O_total & 3) == 0) && ((o0 & 3) == 0) && ((OT & 3) == 0) && ((((uintptr_t)Y) & 15) == 0);
   if (y_vec) {
     const int q4 = OT >> 2;
@@ -231,11 +244,12 @@ __global__ __launch_bounds__(256) void conv_nbr_kernel(const float *__restrict__
 
 template <int BM, int MAXU, bool WT>
 static int launch_conv_nbr(const float *X, int R, const float *W, const int *nbr, int64_t n_out, int K, float *Y,
-                           int O_total, int o_tile, hipStream_t stream) {
+                           int O_total, int o_tile, int kgroups, hipStream_t stream) {
   const int O16 = (std::min(o_tile, O_total) + 15) & ~15;
   const int OP = O16 + 4;
   size_t lds = (size_t)(BM * OP + BM * CV_AP + (WT ? O16 * CV_AP : CV_CK * OP)) * 4 + (size_t)(2 * BM + 8) * 4;
   TS_REQUIRE(lds <= 160 * 1024, TS_ERR_UNSUPPORTED, "conv_nbr: LDS tile %zu B exceeds 160 KiB", lds);
+  TS_REQUIRE((BM / 16) * (O16 / 16) <= 4 * MAXU, TS_ERR_UNSUPPORTED, "conv_nbr: tile does not fit the instantiation");
   auto kern = conv_nbr_kernel<BM, MAXU, WT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -243,8 +257,11 @@ static int launch_conv_nbr(const float *X, int R, const float *W, const int *nbr
                  "hipFuncSetAttribute");
     attr_set = true;
   }
-  dim3 grid((unsigned)ts_cdiv(n_out, BM), (unsigned)ts_cdiv(O_total, o_tile));
-  kern<<<grid, 256, lds, stream>>>(X, R, W, nbr, n_out, K, Y, O_total, o_tile);
+  const int kpg = (K + kgroups - 1) / kgroups;
+  kgroups = (K + kpg - 1) / kpg;
+  if (kgroups > 1) TS_CHECK_HIP(hipMemsetAsync(Y, 0, (size_t)n_out * O_total * 4, stream), "conv_nbr memset");
+  dim3 grid((unsigned)ts_cdiv(n_out, BM), (unsigned)ts_cdiv(O_total, o_tile), (unsigned)kgroups);
+  kern<<<grid, 256, lds, stream>>>(X, R, W, nbr, n_out, K, Y, O_total, o_tile, kpg);
   TS_CHECK_LAUNCH("conv_nbr");
   return TS_OK;
 }
@@ -293,16 +310,36 @@ extern "C" int ts_conv_nbr(const float *in_feat, int64_t n_in, int32_t c_in, con
     TS_CHECK_LAUNCH("conv_nbr_scalar");
     return TS_OK;
   }
-  // column tiling: at most 256 output channels per workgroup
-  int nsplit = (c_out + 255) / 256;
-  int o_tile = ((c_out + nsplit - 1) / nsplit + 15) & ~15;
+  // Tiling heuristic.  A workgroup owns (BM rows) x (o_tile columns) x (a group of offsets):
+  //   - large problems: wide column tiles (gathered rows are reused across more columns);
+  //   - small problems (deep U-Net levels: a few thousand rows): narrow column tiles and the offsets
+  //     split over workgroups, so that >= ~768 workgroups exist and several are resident per CU
+  //     (they hide each other's gather latency).
+  const int c16 = (c_out + 15) & ~15;
+  const int64_t tiles64 = ts_cdiv(n_out, 64);
+  int o_tile;
+  if (c16 <= 32) o_tile = c16;
+  else if (c16 <= 64) o_tile = c16;
+  else if (tiles64 * ts_cdiv(c16, 128) >= 1024) o_tile = (c16 % 128 == 0 || c16 > 256) ? 128 : (c16 <= 128 ? c16 : 64);
+  else o_tile = (c16 % 64 == 0 || c16 > 128) ? 64 : c16;  // 96 stays one tile
+  if (c16 > 64 && c16 <= 128 && c16 % 64 != 0) o_tile = c16;
+  const int bm = (o_tile <= 64 && tiles64 >= 2048) ? 128 : 64;
+  const int64_t wgs = ts_cdiv(n_out, bm) * ts_cdiv(c_out, o_tile);
+  int kgroups = 1;
+  if (wgs < 768 && K >= 4) {
+    kgroups = (int)std::min<int64_t>(ts_cdiv(768, wgs), K >= 9 ? K / 3 : K / 2);
+    if (kgroups < 1) kgroups = 1;
+  }
   const bool wt = weight_transposed != 0;
 #define TS_LAUNCH(BM, MAXU)                                                                                        \
-  (wt ? launch_conv_nbr<BM, MAXU, true>(in_feat, c_in, kernel, nbr, n_out, K, out_feat, c_out, o_tile, stream)     \
-      : launch_conv_nbr<BM, MAXU, false>(in_feat, c_in, kernel, nbr, n_out, K, out_feat, c_out, o_tile, stream))
+  (wt ? launch_conv_nbr<BM, MAXU, true>(in_feat, c_in, kernel, nbr, n_out, K, out_feat, c_out, o_tile, kgroups,    \
+                                        stream)                                                                    \
+      : launch_conv_nbr<BM, MAXU, false>(in_feat, c_in, kernel, nbr, n_out, K, out_feat, c_out, o_tile, kgroups,   \
+                                         stream))
   // MAXU = ceil((BM / 16) * (o_tile / 16) / 4)
-  if (o_tile <= 32) return TS_LAUNCH(128, 4);
-  if (o_tile <= 64) return TS_LAUNCH(128, 8);
+  if (bm == 128) return o_tile <= 32 ? TS_LAUNCH(128, 4) : TS_LAUNCH(128, 8);
+  if (o_tile <= 32) return TS_LAUNCH(64, 2);
+  if (o_tile <= 64) return TS_LAUNCH(64, 4);
   if (o_tile <= 128) return TS_LAUNCH(64, 8);
   return TS_LAUNCH(64, 16);
 #undef TS_LAUNCH
@@ -428,8 +465,9 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   const int CT16 = (ct + 15) & ~15;
   size_t lds = (size_t)WG_PS * ((CA16 + 4) + (CT16 + 4)) * 4;
   int nsplit = (int)ts_cdiv(CB, WG_COT);
-  // aim for ~2048 workgroups over the whole launch
-  int64_t chunks_per_k = std::max<int64_t>(1, 2048 / ((int64_t)K * nsplit));
+  // aim for ~768 workgroups over the whole launch: every workgroup ends with C_a x 64 float atomics,
+  // so fewer, longer pair chunks keep the atomic bytes per flop low
+  int64_t chunks_per_k = std::max<int64_t>(1, 768 / ((int64_t)K * nsplit));
   int64_t ppw = ts_cdiv(max_pairs < 1 ? 1 : max_pairs, chunks_per_k);
   ppw = std::max<int64_t>(256, (ppw + WG_PS - 1) / WG_PS * WG_PS);
   int nchunks = (int)ts_cdiv(max_pairs < 1 ? 1 : max_pairs, ppw);
