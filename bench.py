@@ -134,13 +134,21 @@ def summarise_profile(records, steps):
             if key not in pairs_cache:
                 pairs_cache[key] = int((m["nbr"] >= 0).sum())
             p = pairs_cache[key]
-        else:
+        elif kind == "conv_wgrad":
             key = m["nboffs"].data_ptr()
             if key not in pairs_cache:
                 pairs_cache[key] = int(m["nboffs"][-1])
             p = pairs_cache[key]
+        else:
+            p = m["pairs"]
         flops = 2.0 * p * m["c_red"] * m["c_out"]
-        byts = p * (m["c_red"] * 4 + 2 * m["c_out"] * 4 + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+        if kind == "pair_gemm":      # gather read + Z write + rulebook + weights  (first half of the 8(d) figure)
+            byts = p * (m["c_red"] * 4 + m["c_out"] * 4 + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+        elif kind == "gather_sum":   # Z read + output write + position table       (second half)
+            flops = float(p * m["c_out"])
+            byts = p * m["c_out"] * 4 + m["n_rows"] * m["c_out"] * 4 + m["k"] * m["n_rows"] * 4
+        else:
+            byts = p * (m["c_red"] * 4 + 2 * m["c_out"] * 4 + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
         g = groups.setdefault(m["name"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         g["launches"] += 1
         g["ms"] += ms

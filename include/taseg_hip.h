@@ -160,10 +160,13 @@ int ts_unique_i64(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *invers
  *   nbsizes  [K] int32        : hits per offset (== conv.py:168);
  *   nboffs   [K+1] int32      : exclusive prefix of nbsizes (nboffs[K] = P). */
 size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int32_t n_offsets);
+/*   pos_out  [K, n_out] int32 : row of nbmaps holding the pair (k, j), or -1  (may be NULL);
+ *   pos_in   [K, n_in]  int32 : row of nbmaps holding the pair of input i at offset k, or -1 (may be NULL). */
 int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords,
                   int64_t n_out, const int32_t *offsets, int32_t n_offsets, int32_t *nbr,
                   int32_t *nbr_t, int32_t *nbmaps, int32_t *nbsizes, int32_t *nboffs,
-                  void *ws, size_t ws_bytes, ts_stream_t stream);
+                  int32_t *pos_out, int32_t *pos_in, void *ws, size_t ws_bytes,
+                  ts_stream_t stream);
 
 /* Neighbour table from an explicit rulebook (the reference-form entry points
  * above go through this): nbr[k, col_out] = col_in for every pair of offset k.
@@ -202,6 +205,22 @@ int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t
                   const int32_t *nbmaps, const int32_t *nboffs, int32_t kernel_volume,
                   int32_t col_a, int64_t max_pairs_per_offset, float *grad_kernel,
                   ts_stream_t stream);
+
+/* Two-pass convolution on the rulebook itself (the default forward / dgrad path):
+ *   pass 1  ts_conv_pair_gemm :  z[p, :] = feat[g_p, :] @ W_{k(p)}   for every pair p of nbmaps,
+ *           g_p = nbmaps[p][gather_col], k(p) = the offset whose [nboffs[k], nboffs[k+1]) holds p;
+ *           one dense MFMA GEMM over all pairs (row gather fused into the A-operand load);
+ *   pass 2  ts_conv_gather_sum:  out[j, :] = sum_k z[pos[k, j], :]   (pos = pos_out or pos_in of
+ *           ts_build_kmap; -1 entries skipped), k ascending - deterministic, no atomics.
+ * Together they equal ts_conv_nbr / the reference's gather -> GEMM -> scatter
+ * (convolution_cuda.cu:101-164) with the K per-offset launches collapsed into one.
+ * weight_transposed as in ts_conv_nbr.  z has n_pairs rows of c_out floats (caller-allocated). */
+int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in, const float *kernel,
+                      int32_t kernel_volume, int32_t weight_transposed, const int32_t *nbmaps,
+                      const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, float *z,
+                      int32_t c_out, ts_stream_t stream);
+int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t kernel_volume,
+                       int64_t n_rows, int64_t n_pairs, float *out, ts_stream_t stream);
 
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics). */

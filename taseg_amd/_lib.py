@@ -39,12 +39,14 @@ SIGNATURES = {
     "ts_unique_workspace_bytes": (_sz, [_i64]),
     "ts_unique_i64": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_build_kmap_workspace_bytes": (_sz, [_i64, _i64, _i32]),
-    "ts_build_kmap": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_build_kmap": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_nbr_from_nbmaps": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "ts_trilinear_workspace_bytes": (_sz, [_i64]),
     "ts_trilinear_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "ts_conv_nbr": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ts_conv_wgrad": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "ts_conv_pair_gemm": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "ts_conv_gather_sum": (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_quantize_workspace_bytes": (_sz, [_i64]),

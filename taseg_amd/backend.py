@@ -217,11 +217,11 @@ def unique_i64(keys, return_inverse=True):
     return (uniq[:m], inv[:n]) if return_inverse else uniq[:m]
 
 
-def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=True):
+def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=False, want_pos=True):
     """Neighbour table + reference-order rulebook (conv.py:156-176) in one call, no host sync.
 
     Returns dict(nbr [K,n_out], nbr_t [K,n_in] | None, nbmaps [K*n_out,2] capacity | None,
-                 nbsizes [K], nboffs [K+1]).
+                 nbsizes [K], nboffs [K+1], pos_out [K,n_out] | None, pos_in [K,n_in] | None).
     """
     L.require_device(in_coords, out_coords, offsets)
     in_coords, out_coords, offsets = _i32(in_coords, "in_coords"), _i32(out_coords, "out_coords"), _i32(offsets, "offsets")
@@ -234,10 +234,53 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Tru
     nbmaps = torch.empty((max(k * n_out, 1), 2), dtype=torch.int32, device=dev) if want_pairs else None
     nbsizes = torch.empty(k, dtype=torch.int32, device=dev)
     nboffs = torch.empty(k + 1, dtype=torch.int32, device=dev)
+    pos_out = torch.empty((k, n_out), dtype=torch.int32, device=dev) if want_pos else None
+    pos_in = torch.empty((k, n_in), dtype=torch.int32, device=dev) if want_pos else None
     L.check(lib.ts_build_kmap(L.ptr(in_coords), n_in, L.ptr(out_coords), n_out, L.ptr(offsets), k, L.ptr(nbr),
-                              L.ptr(nbr_t), L.ptr(nbmaps), L.ptr(nbsizes), L.ptr(nboffs), L.ptr(ws), ws.numel(),
-                              L.stream()), "ts_build_kmap")
-    return dict(nbr=nbr, nbr_t=nbr_t, nbmaps=nbmaps, nbsizes=nbsizes, nboffs=nboffs)
+                              L.ptr(nbr_t), L.ptr(nbmaps), L.ptr(nbsizes), L.ptr(nboffs), L.ptr(pos_out),
+                              L.ptr(pos_in), L.ptr(ws), ws.numel(), L.stream()), "ts_build_kmap")
+    return dict(nbr=nbr, nbr_t=nbr_t, nbmaps=nbmaps, nbsizes=nbsizes, nboffs=nboffs, pos_out=pos_out, pos_in=pos_in)
+
+
+def pair_gemm_kernel_name(c_out, weight_transposed=False):
+    bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (128, 2)
+    return f"pair_gemm_kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
+
+
+def conv_pair_gemm(feat, kernel, nbmaps, nboffs, n_pairs, gather_col, weight_transposed=False):
+    """Pass 1 of the two-pass convolution: z[p] = feat[nbmaps[p][gather_col]] @ (kernel[k(p)] or its transpose)."""
+    L.require_device(feat, kernel, nbmaps, nboffs)
+    feat, kernel = _f32(feat, "feat"), _f32(kernel, "kernel")
+    nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
+    if kernel.ndim != 3:
+        raise ValueError("kernel must be [K, c_in, c_out]")
+    k = kernel.shape[0]
+    c_red, c_out = (kernel.shape[2], kernel.shape[1]) if weight_transposed else (kernel.shape[1], kernel.shape[2])
+    if feat.shape[1] != c_red:
+        raise ValueError("Input feature size and kernel size mismatch")
+    z = torch.empty((int(n_pairs), c_out), dtype=torch.float32, device=feat.device)
+    with _Timed("pair_gemm", name=pair_gemm_kernel_name(c_out, weight_transposed), pairs=int(n_pairs), c_red=c_red,
+                c_out=c_out, k=k):
+        L.check(L.load().ts_conv_pair_gemm(L.ptr(feat), feat.shape[0], c_red, L.ptr(kernel), k,
+                                           1 if weight_transposed else 0, L.ptr(nbmaps), L.ptr(nboffs),
+                                           int(n_pairs), int(gather_col), L.ptr(z), c_out, L.stream()),
+                "ts_conv_pair_gemm")
+    return z
+
+
+def conv_gather_sum(z, pos, n_rows):
+    """Pass 2: out[j] = sum_k z[pos[k, j]] (k ascending, -1 skipped)."""
+    L.require_device(z, pos)
+    z, pos = _f32(z, "z"), _i32(pos, "pos")
+    k = pos.shape[0]
+    if pos.shape != (k, n_rows):
+        raise ValueError(f"position table shape {tuple(pos.shape)} != {(k, n_rows)}")
+    out = torch.empty((n_rows, z.shape[1]), dtype=torch.float32, device=z.device)
+    with _Timed("gather_sum", name="gather_sum_kernel<4>" if z.shape[1] % 4 == 0 else "gather_sum_kernel<1>",
+                pairs=z.shape[0], c_red=0, c_out=z.shape[1], k=k, n_rows=n_rows):
+        L.check(L.load().ts_conv_gather_sum(L.ptr(z), z.shape[1], L.ptr(pos), k, n_rows, z.shape[0], L.ptr(out),
+                                            L.stream()), "ts_conv_gather_sum")
+    return out
 
 
 def trilinear_map(points, vox_coords, stride):

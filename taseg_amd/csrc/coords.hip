@@ -276,7 +276,8 @@ __global__ void kmap_sizes_kernel(const unsigned *__restrict__ blk_offs, int K, 
 __global__ __launch_bounds__(KM_BLOCK) void kmap_compact_kernel(const int *__restrict__ nbr, int64_t n_out,
                                                                int64_t n_in, const unsigned *__restrict__ blk_offs,
                                                                int nblk, int2 *__restrict__ nbmaps,
-                                                               int *__restrict__ nbr_t) {
+                                                               int *__restrict__ nbr_t, int *__restrict__ pos_out,
+                                                               int *__restrict__ pos_in) {
   __shared__ unsigned wave_cnt[KM_BLOCK / 64];
   int k = blockIdx.y;
   int64_t j = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
@@ -292,7 +293,10 @@ __global__ __launch_bounds__(KM_BLOCK) void kmap_compact_kernel(const int *__res
   if (hit) {
     if (nbmaps) nbmaps[base + rank] = make_int2(r, (int)j);
     if (nbr_t) nbr_t[(int64_t)k * n_in + r] = (int)j;
+    if (pos_in) pos_in[(int64_t)k * n_in + r] = (int)(base + rank);
   }
+  // position of pair (k, j) in the rulebook, per output row (coalesced; -1 = no pair)
+  if (pos_out && j < n_out) pos_out[(int64_t)k * n_out + j] = hit ? (int)(base + rank) : -1;
 }
 
 extern "C" size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int32_t K) {
@@ -303,8 +307,11 @@ extern "C" size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int
 
 extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords, int64_t n_out,
                              const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t, int32_t *nbmaps,
-                             int32_t *nbsizes, int32_t *nboffs, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+                             int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws,
+                             size_t ws_bytes, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (pos_in && n_in > 0 && K > 0)
+    if (hipMemsetAsync(pos_in, 0xFF, (size_t)K * n_in * 4, stream) != hipSuccess) return TS_ERR_LAUNCH_FAILED;
   TS_REQUIRE(n_in >= 0 && n_out >= 0 && K > 0 && K <= 4096, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: bad sizes");
   TS_REQUIRE(n_in < (1LL << 30) && n_out < (1LL << 30) && (int64_t)K * n_out < (1LL << 31), TS_ERR_UNSUPPORTED,
              "ts_build_kmap: problem too large for int32 indexing");
@@ -339,7 +346,7 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
   kmap_probe_kernel<<<nblk, KM_BLOCK, (size_t)K * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
                                                                blk_counts, nblk);
   TS_CHECK_LAUNCH("ts_build_kmap/probe");
-  if (!nbmaps && !nbr_t && !nbsizes && !nboffs) return TS_OK;
+  if (!nbmaps && !nbr_t && !nbsizes && !nboffs && !pos_out && !pos_in) return TS_OK;
   size_t need = 0;
   TS_CHECK_HIP(rocprim::exclusive_scan(nullptr, need, blk_counts, blk_offs, 0u, n_cnt, rocprim::plus<unsigned>(), stream),
                "scan size query");
@@ -348,9 +355,10 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
                "scan");
   kmap_sizes_kernel<<<(int)ts_cdiv(K + 1, 256), 256, 0, stream>>>(blk_offs, K, nblk, nbsizes, nboffs);
   TS_CHECK_LAUNCH("ts_build_kmap/sizes");
-  if (nbmaps || nbr_t) {
+  if (nbmaps || nbr_t || pos_out || pos_in) {
     dim3 grid(nblk, K);
-    kmap_compact_kernel<<<grid, KM_BLOCK, 0, stream>>>(nbr, n_out, n_in, blk_offs, nblk, (int2 *)nbmaps, nbr_t);
+    kmap_compact_kernel<<<grid, KM_BLOCK, 0, stream>>>(nbr, n_out, n_in, blk_offs, nblk, (int2 *)nbmaps, nbr_t,
+                                                       pos_out, pos_in);
     TS_CHECK_LAUNCH("ts_build_kmap/compact");
   }
   return TS_OK;

@@ -147,19 +147,21 @@ class KernelMap:
 
     def __init__(self, tables, sizes):
         self.nbr = tables["nbr"]
-        self.nbr_t = tables["nbr_t"]
         self.nbmaps_buf = tables["nbmaps"]
         self.nbsizes_dev = tables["nbsizes"]
         self.nboffs = tables["nboffs"]
+        self.pos_out = tables["pos_out"]      # [K, n_out] row of nbmaps per (offset, output voxel) or -1
+        self.pos_in = tables["pos_in"]        # [K, n_in]  row of nbmaps per (offset, input voxel) or -1
         self.sizes = sizes
         self._nbmaps = None
+        # number of pairs P: the one host read of a kernel map (sizes the pair-GEMM grid and its Z buffer)
+        self.total = int(self.nboffs[-1].item())
 
     @property
     def nbmaps(self) -> torch.Tensor:
-        """Exact [P, 2] int64 rulebook like the reference's (one host sync, cached)."""
+        """Exact [P, 2] int64 rulebook like the reference's."""
         if self._nbmaps is None:
-            total = int(self.nboffs[-1].item())
-            self._nbmaps = self.nbmaps_buf[:total].long()
+            self._nbmaps = self.nbmaps_buf[:self.total].long()
         return self._nbmaps
 
     @property
@@ -195,14 +197,17 @@ class _SparseConv(Function):
         if feats.shape[1] != weight.shape[1]:
             raise ValueError("Input feature size and kernel size mismatch")
         n_in, n_out = kmap.sizes
+        # pass 1: z[p] = feats[source row of pair p] @ W[k(p)];  pass 2: out[row] = sum_k z[pos[k, row]]
         if not transposed:
             if feats.shape[0] != n_in:
                 raise ValueError(f"conv3d: {feats.shape[0]} input rows but the kernel map has {n_in}")
-            out = B.conv_nbr(feats, weight, kmap.nbr, n_out, weight_transposed=False)
+            z = B.conv_pair_gemm(feats, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=0)
+            out = B.conv_gather_sum(z, kmap.pos_out, n_out)
         else:
             if feats.shape[0] != n_out:
                 raise ValueError(f"conv3d (transposed): {feats.shape[0]} input rows but the kernel map has {n_out}")
-            out = B.conv_nbr(feats, weight, kmap.nbr_t, n_in, weight_transposed=False)
+            z = B.conv_pair_gemm(feats, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=1)
+            out = B.conv_gather_sum(z, kmap.pos_in, n_in)
         ctx.kmap, ctx.transposed = kmap, transposed
         ctx.save_for_backward(feats, weight)
         return out
@@ -217,9 +222,12 @@ class _SparseConv(Function):
         k = weight.shape[0]
         grad_feats = grad_weight = None
         if ctx.needs_input_grad[0]:
-            # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T over the inverse table
-            table, rows = (kmap.nbr_t, n_in) if not transposed else (kmap.nbr, n_out)
-            grad_feats = B.conv_nbr(grad_out, weight, table, rows, weight_transposed=True)
+            # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T : the same two passes with the roles of the
+            # rulebook columns swapped and W transposed
+            z = B.conv_pair_gemm(grad_out, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total,
+                                 gather_col=0 if transposed else 1, weight_transposed=True)
+            table, rows = (kmap.pos_in, n_in) if not transposed else (kmap.pos_out, n_out)
+            grad_feats = B.conv_gather_sum(z, table, rows)
         if ctx.needs_input_grad[1]:
             grad_weight = B.conv_wgrad(feats, grad_out, kmap.nbmaps_buf, kmap.nboffs, k,
                                        col_a=1 if transposed else 0, max_pairs=n_out)

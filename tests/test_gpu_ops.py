@@ -104,7 +104,7 @@ def test_downsample_and_kmaps_golden(B, F, g_ops):
         same(km["nbsizes"], g_ops[f"k3_s{ts}_nbsizes"])
         down = F.spdownsample(cur, 2, 2, ts)
         same(down, g_ops[f"down_s{ts}"])
-        km2 = B.build_kmap(cur, down, get_kernel_offsets(2, ts, 1, device=DEV))
+        km2 = B.build_kmap(cur, down, get_kernel_offsets(2, ts, 1, device=DEV), want_inverse=True)
         total2 = int(km2["nboffs"][-1])
         assert total2 == cur.shape[0]
         same(km2["nbr"], g_ops[f"k2_s{ts}_results"])
@@ -115,6 +115,13 @@ def test_downsample_and_kmaps_golden(B, F, g_ops):
         kk, jj = np.nonzero(nbr >= 0)
         assert np.array_equal(nbr_t[kk, nbr[kk, jj]], jj)
         assert (nbr_t >= 0).sum() == (nbr >= 0).sum()
+        # position tables point at the rulebook rows of their pairs
+        nbm = km2["nbmaps"][:total2].cpu().numpy()
+        po, pi = km2["pos_out"].cpu().numpy(), km2["pos_in"].cpu().numpy()
+        assert np.array_equal(po >= 0, nbr >= 0) and np.array_equal(pi >= 0, nbr_t >= 0)
+        assert np.array_equal(nbm[po[kk, jj], 1], jj) and np.array_equal(nbm[po[kk, jj], 0], nbr[kk, jj])
+        ki, ii = np.nonzero(pi >= 0)
+        assert np.array_equal(nbm[pi[ki, ii], 0], ii) and np.array_equal(nbm[pi[ki, ii], 1], nbr_t[ki, ii])
         cur, ts = down, ts * 2
 
 
@@ -129,7 +136,7 @@ def test_kmap_dense_blob_vs_oracle(B, F):
     from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
     c = _blob(3)
     res, nbmaps, nbsizes = O.build_kmap(c, c, O.get_kernel_offsets(3, 1, 1))
-    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV), want_inverse=True)
     same(km["nbr"], res.astype(np.int32))
     same(km["nbmaps"][:int(km["nboffs"][-1])], nbmaps.astype(np.int32))
     same(km["nbsizes"], nbsizes.astype(np.int32))
@@ -265,6 +272,30 @@ def test_conv_dense_blob_vs_oracle(B, F, ci, co):
     y.F.backward(T(gyn))
     close(x.grad, want_gx, 2e-5)
     close(w.grad, want_gw, 2e-5)
+
+
+def test_conv_two_pass_equals_neighbour_table_kernel(B, F):
+    """pair GEMM + gather-sum == the output-stationary ts_conv_nbr kernel == the scalar cross-check"""
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    c = _blob(9, n=6000, extent=26)
+    rs = np.random.RandomState(9)
+    for ci, co in ((32, 96), (96, 32), (256, 128)):
+        x, w = T(rs.randn(len(c), ci).astype(np.float32)), T((rs.randn(27, ci, co) / 30).astype(np.float32))
+        km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+        total = int(km["nboffs"][-1])
+        z = B.conv_pair_gemm(x, w, km["nbmaps"], km["nboffs"], total, gather_col=0)
+        y2 = B.conv_gather_sum(z, km["pos_out"], len(c))
+        y1 = B.conv_nbr(x, w, km["nbr"], len(c))
+        B.set_conv_impl(1)
+        try:
+            y0 = B.conv_nbr(x, w, km["nbr"], len(c))
+        finally:
+            B.set_conv_impl(0)
+        close(y2, y0, 2e-5)
+        close(y1, y0, 2e-5)
+        # deterministic: two runs are bitwise identical
+        z_b = B.conv_pair_gemm(x, w, km["nbmaps"], km["nboffs"], total, gather_col=0)
+        assert torch.equal(B.conv_gather_sum(z_b, km["pos_out"], len(c)), y2)
 
 
 def test_conv_reference_form_entry_points(B, g_ops):
