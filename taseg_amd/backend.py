@@ -335,10 +335,11 @@ class _Timed:
 def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None, n_out=0):
     """The template instantiation ts_conv_nbr / ts_conv_wgrad picks (mirrors the heuristic in csrc/conv.hip)."""
     if wgrad_cb is not None:
-        units = ((c_out_or_ca + 15) // 16) * ((min(64, wgrad_cb) + 15) // 16)
-        per_wave = (units + 3) // 4
-        maxu = next(m for m in (2, 4, 8, 16, 24) if per_wave <= m)
-        return f"conv_wgrad_kernel<{maxu}>"
+        ca, cb = c_out_or_ca, wgrad_cb
+        cmax, cmin = max(ca, cb), min(ca, cb)
+        tm, tn = ((32, 32) if cmax <= 32 else (32, 128) if ca <= 32 else (128, 32) if cb <= 32
+                  else (64, 64) if (cmax <= 64 or cmin <= 48) else (128, 128))
+        return f"wgrad_gemm_kernel<{tm},{tn}>"
     c16 = (c_out_or_ca + 15) & ~15
     tiles64 = -(-n_out // 64)
     if c16 <= 64:

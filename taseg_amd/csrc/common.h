@@ -11,6 +11,7 @@
 #define TS_WAVE 64
 
 void ts_set_error(const char *fmt, ...);
+extern int g_ts_conv_impl;  // 0 = MFMA kernels, 1 = scalar cross-check kernels (ts_set_conv_impl)
 
 #define TS_REQUIRE(cond, code, ...)  \
   do {                               \

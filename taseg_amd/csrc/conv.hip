@@ -24,8 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CV_CK 32          // reduction-slice depth staged per step
 #define CV_AP (CV_CK + 4)  // LDS row pitch (floats) of K-major tiles: 16-B aligned, bank-skewed
 
-static int g_conv_impl = 0;
-extern "C" void ts_set_conv_impl(int32_t impl) { g_conv_impl = impl; }
+int g_ts_conv_impl = 0;
+extern "C" void ts_set_conv_impl(int32_t impl) { g_ts_conv_impl = impl; }
 
 // ======================================================================================
 // conv_nbr_kernel
@@ -303,7 +303,7 @@ extern "C" int ts_conv_nbr(const float *in_feat, int64_t n_in, int32_t c_in, con
   TS_REQUIRE(kernel && nbr && out_feat && (in_feat || n_in == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_nbr: null pointer");
   TS_REQUIRE(n_out * (int64_t)c_out < (1LL << 40) && (int64_t)K * n_out < (1LL << 31), TS_ERR_UNSUPPORTED,
              "ts_conv_nbr: problem too large");
-  if (g_conv_impl == 1) {
+  if (g_ts_conv_impl == 1) {
     int64_t total = n_out * c_out;
     conv_nbr_scalar_kernel<<<(unsigned)ts_cdiv(total, 256), 256, 0, stream>>>(
         in_feat, c_in, kernel, weight_transposed ? 1 : 0, nbr, n_out, K, out_feat, c_out);
@@ -343,193 +343,6 @@ extern "C" int ts_conv_nbr(const float *in_feat, int64_t n_in, int32_t c_in, con
   if (o_tile <= 128) return TS_LAUNCH(64, 8);
   return TS_LAUNCH(64, 16);
 #undef TS_LAUNCH
-}
-
-// ======================================================================================
-// conv_wgrad_kernel
-// ======================================================================================
-#define WG_PS 32  // pairs staged per step (two 16-deep MFMA blocks)
-#define WG_COT 64  // dW columns per workgroup
-
-template <int MAXU>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ A, int CA,
-                                                         const float *__restrict__ B, int CB,
-                                                         const int2 *__restrict__ nbmaps,
-                                                         const int *__restrict__ nboffs, int col_a, int pairs_per_wg,
-                                                         float *__restrict__ dW) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r16 = lane & 15, g = lane >> 4;
-  const int k = blockIdx.y;
-  const int beg = nboffs[k] + blockIdx.x * pairs_per_wg;
-  const int end = min(nboffs[k + 1], beg + pairs_per_wg);
-  if (beg >= end) return;  // uniform
-  const int co0 = blockIdx.z * WG_COT;
-  const int cot = min(WG_COT, CB - co0);
-  const int CA16 = (CA + 15) & ~15, CT16 = (cot + 15) & ~15;
-  const int CAP = CA16 + 4, CTP = CT16 + 4;
-  const int NBc = CT16 >> 4;
-  const int U = (CA16 >> 4) * NBc;
-
-  float *Xl = smem;                 // [WG_PS][CAP]
-  float *Yl = Xl + WG_PS * CAP;     // [WG_PS][CTP]
-
-  int u_rb[MAXU], u_cb[MAXU];
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) {
-    int u = wave + 4 * i;
-    u_rb[i] = u / NBc;
-    u_cb[i] = u - u_rb[i] * NBc;
-  }
-  f32x4 acc[MAXU];
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const bool a_vec = ((CA & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
-  const bool b_vec = ((CB & 3) == 0) && ((co0 & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
-  const int qa = CA16 >> 2, qb = CT16 >> 2;
-
-  for (int p0 = beg; p0 < end; p0 += WG_PS) {
-    const int np = min(WG_PS, end - p0);
-    __syncthreads();
-    for (int e = tid; e < WG_PS * qa; e += 256) {
-      int pp = e / qa, c4 = (e - pp * qa) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < np) {
-        int2 pr = nbmaps[p0 + pp];
-        const float *src = A + (int64_t)(col_a ? pr.y : pr.x) * CA + c4;
-        if (a_vec && c4 + 3 < CA) {
-          v = *(const float4 *)src;
-        } else {
-          if (c4 + 0 < CA) v.x = src[0];
-          if (c4 + 1 < CA) v.y = src[1];
-          if (c4 + 2 < CA) v.z = src[2];
-          if (c4 + 3 < CA) v.w = src[3];
-        }
-      }
-      *(float4 *)&Xl[pp * CAP + c4] = v;
-    }
-    for (int e = tid; e < WG_PS * qb; e += 256) {
-      int pp = e / qb, c4 = (e - pp * qb) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < np) {
-        int2 pr = nbmaps[p0 + pp];
-        const float *src = B + (int64_t)(col_a ? pr.x : pr.y) * CB + co0 + c4;
-        if (b_vec && c4 + 3 < cot) {
-          v = *(const float4 *)src;
-        } else {
-          if (c4 + 0 < cot) v.x = src[0];
-          if (c4 + 1 < cot) v.y = src[1];
-          if (c4 + 2 < cot) v.z = src[2];
-          if (c4 + 3 < cot) v.w = src[3];
-        }
-      }
-      *(float4 *)&Yl[pp * CTP + c4] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < WG_PS; j += 16) {
-#pragma unroll
-      for (int i = 0; i < MAXU; ++i) {
-        if (wave + 4 * i < U) {
-          const float *ap = &Xl[(j + 4 * g) * CAP + u_rb[i] * 16 + r16];
-          const float *bp = &Yl[(j + 4 * g) * CTP + u_cb[i] * 16 + r16];
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bp[0], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[CAP], bp[CTP], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * CAP], bp[2 * CTP], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[3 * CAP], bp[3 * CTP], acc[i], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // partial tile -> dW[k] (row = ci, col = co): float atomics, 64-B segments per lane group
-  float *dwk = dW + (int64_t)k * CA * CB;
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) {
-    if (wave + 4 * i < U) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int ci = u_rb[i] * 16 + 4 * g + q;
-        int co = u_cb[i] * 16 + r16;
-        if (ci < CA && co < cot) atomicAdd(&dwk[(int64_t)ci * CB + co0 + co], acc[i][q]);
-      }
-    }
-  }
-}
-
-template <int MAXU>
-static int launch_wgrad(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
-                        int col_a, int64_t max_pairs, float *dW, hipStream_t stream) {
-  const int CA16 = (CA + 15) & ~15;
-  const int ct = std::min(WG_COT, CB);
-  const int CT16 = (ct + 15) & ~15;
-  size_t lds = (size_t)WG_PS * ((CA16 + 4) + (CT16 + 4)) * 4;
-  int nsplit = (int)ts_cdiv(CB, WG_COT);
-  // aim for ~768 workgroups over the whole launch: every workgroup ends with C_a x 64 float atomics,
-  // so fewer, longer pair chunks keep the atomic bytes per flop low
-  int64_t chunks_per_k = std::max<int64_t>(1, 768 / ((int64_t)K * nsplit));
-  int64_t ppw = ts_cdiv(max_pairs < 1 ? 1 : max_pairs, chunks_per_k);
-  ppw = std::max<int64_t>(256, (ppw + WG_PS - 1) / WG_PS * WG_PS);
-  int nchunks = (int)ts_cdiv(max_pairs < 1 ? 1 : max_pairs, ppw);
-  auto kern = conv_wgrad_kernel<MAXU>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                 "hipFuncSetAttribute");
-    attr_set = true;
-  }
-  dim3 grid(nchunks, K, nsplit);
-  kern<<<grid, 256, lds, stream>>>(A, CA, B, CB, nbmaps, nboffs, col_a, (int)ppw, dW);
-  TS_CHECK_LAUNCH("conv_wgrad");
-  return TS_OK;
-}
-
-__global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const float *__restrict__ A, int CA,
-                                                                const float *__restrict__ B, int CB,
-                                                                const int2 *__restrict__ nbmaps,
-                                                                const int *__restrict__ nboffs, int col_a,
-                                                                float *__restrict__ dW) {
-  int k = blockIdx.y;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= CA * CB) return;
-  int ci = e / CB, co = e - ci * CB;
-  float s = 0.f;
-  for (int p = nboffs[k]; p < nboffs[k + 1]; ++p) {
-    int2 pr = nbmaps[p];
-    int ia = col_a ? pr.y : pr.x, ib = col_a ? pr.x : pr.y;
-    s = fmaf(A[(int64_t)ia * CA + ci], B[(int64_t)ib * CB + co], s);
-  }
-  dW[(int64_t)k * CA * CB + e] = s;
-}
-
-extern "C" int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
-                             const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
-                             int64_t max_pairs_per_offset, float *grad_kernel, ts_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && max_pairs_per_offset >= 0, TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_wgrad: bad sizes");
-  TS_REQUIRE(grad_kernel && nboffs, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
-  TS_REQUIRE(c_a <= 384, TS_ERR_UNSUPPORTED, "ts_conv_wgrad: c_a > 384 not supported");
-  TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
-  if (max_pairs_per_offset == 0) return TS_OK;
-  TS_REQUIRE(a_feat && b_feat && nbmaps, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
-  const int2 *nm = (const int2 *)nbmaps;
-  col_a = col_a ? 1 : 0;
-  if (g_conv_impl == 1) {
-    dim3 grid((unsigned)ts_cdiv((int64_t)c_a * c_b, 256), K);
-    conv_wgrad_scalar_kernel<<<grid, 256, 0, stream>>>(a_feat, c_a, b_feat, c_b, nm, nboffs, col_a, grad_kernel);
-    TS_CHECK_LAUNCH("conv_wgrad_scalar");
-    return TS_OK;
-  }
-  int U = ((c_a + 15) / 16) * ((std::min(WG_COT, (int)c_b) + 15) / 16);
-  int per_wave = (U + 3) / 4;
-#define TS_WG(MAXU) launch_wgrad<MAXU>(a_feat, c_a, b_feat, c_b, nm, nboffs, K, col_a, max_pairs_per_offset, grad_kernel, stream)
-  if (per_wave <= 2) return TS_WG(2);
-  if (per_wave <= 4) return TS_WG(4);
-  if (per_wave <= 8) return TS_WG(8);
-  if (per_wave <= 16) return TS_WG(16);
-  return TS_WG(24);
-#undef TS_WG
 }
 
 // ======================================================================================

@@ -281,3 +281,187 @@ extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos,
   TS_CHECK_LAUNCH("conv_gather_sum");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------- weight gradient
+//   dW_k[ci, co] = sum_{pairs p of k}  A[pa_p, ci] * B[pb_p, co]
+// One workgroup = (offset k, chunk of its pairs, TM x TN tile of dW_k): a "TN" GEMM whose reduction runs over
+// the pair list.  Both operands are gathered rows, staged 32 pairs at a time; each wave owns a
+// (TM/2) x (TN/2) register tile so every LDS fragment feeds TM/32 or TN/32 MFMAs.  Partial tiles of the
+// chunks are combined with float atomics (dW is small: the atomic bytes are ~1 / (chunk pairs / 2) of the flops).
+#define WG_PS 32
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict__ A, int CA,
+                                                         const float *__restrict__ B, int CB,
+                                                         const int2 *__restrict__ nbmaps,
+                                                         const int *__restrict__ nboffs, int col_a, int pairs_per_wg,
+                                                         float *__restrict__ dW) {
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int XP = TM + 4, YP = TN + 4;
+  __shared__ __attribute__((aligned(16))) float Xl[WG_PS * XP];
+  __shared__ __attribute__((aligned(16))) float Yl[WG_PS * YP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int k = blockIdx.y;
+  const int beg = nboffs[k] + blockIdx.x * pairs_per_wg;
+  const int end = min(nboffs[k + 1], beg + pairs_per_wg);
+  if (beg >= end) return;  // uniform
+  const int tiles_n = (CB + TN - 1) / TN;
+  const int ci0 = (blockIdx.z / tiles_n) * TM, co0 = (blockIdx.z % tiles_n) * TN;
+  const int ca = min(TM, CA - ci0), cb = min(TN, CB - co0);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool a_vec = ((CA & 3) == 0) && ((ci0 & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool b_vec = ((CB & 3) == 0) && ((co0 & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
+
+  for (int p0 = beg; p0 < end; p0 += WG_PS) {
+    const int np = min(WG_PS, end - p0);
+    __syncthreads();
+    for (int e = tid; e < WG_PS * (TM / 4); e += 256) {
+      const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < np && c4 < ca) {
+        const int2 pr = nbmaps[p0 + pp];
+        const float *src = A + (int64_t)(col_a ? pr.y : pr.x) * CA + ci0 + c4;
+        if (a_vec && c4 + 3 < ca) {
+          v = *(const float4 *)src;
+        } else {
+          if (c4 + 0 < ca) v.x = src[0];
+          if (c4 + 1 < ca) v.y = src[1];
+          if (c4 + 2 < ca) v.z = src[2];
+          if (c4 + 3 < ca) v.w = src[3];
+        }
+      }
+      *(float4 *)&Xl[pp * XP + c4] = v;
+    }
+    for (int e = tid; e < WG_PS * (TN / 4); e += 256) {
+      const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < np && c4 < cb) {
+        const int2 pr = nbmaps[p0 + pp];
+        const float *src = B + (int64_t)(col_a ? pr.x : pr.y) * CB + co0 + c4;
+        if (b_vec && c4 + 3 < cb) {
+          v = *(const float4 *)src;
+        } else {
+          if (c4 + 0 < cb) v.x = src[0];
+          if (c4 + 1 < cb) v.y = src[1];
+          if (c4 + 2 < cb) v.z = src[2];
+          if (c4 + 3 < cb) v.w = src[3];
+        }
+      }
+      *(float4 *)&Yl[pp * YP + c4] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WG_PS; j += 16) {
+      float a[MI][4], b[NI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const float *ap = &Xl[(j + 4 * g) * XP + (wr * MI + mi) * 16 + r16];
+        a[mi][0] = ap[0];
+        a[mi][1] = ap[XP];
+        a[mi][2] = ap[2 * XP];
+        a[mi][3] = ap[3 * XP];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float *bp = &Yl[(j + 4 * g) * YP + (wc * NI + ni) * 16 + r16];
+        b[ni][0] = bp[0];
+        b[ni][1] = bp[YP];
+        b[ni][2] = bp[2 * YP];
+        b[ni][3] = bp[3 * YP];
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        if ((wr * MI + mi) * 16 >= ca) continue;  // uniform per wave
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if ((wc * NI + ni) * 16 >= cb) continue;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float *dwk = dW + (int64_t)k * CA * CB;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int co = (wc * NI + ni) * 16 + r16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ci = (wr * MI + mi) * 16 + 4 * g + q;
+        if (ci < ca && co < cb) atomicAdd(&dwk[(int64_t)(ci0 + ci) * CB + co0 + co], acc[mi][ni][q]);
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+static int launch_wgrad(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
+                        int col_a, int64_t max_pairs, float *dW, hipStream_t stream) {
+  const int tiles = (int)(ts_cdiv(CA, TM) * ts_cdiv(CB, TN));
+  // ~1024 workgroups over the launch, chunks of at least 256 pairs
+  int64_t chunks_per_k = std::max<int64_t>(1, 1024 / ((int64_t)K * tiles));
+  int64_t ppw = ts_cdiv(max_pairs < 1 ? 1 : max_pairs, chunks_per_k);
+  ppw = std::max<int64_t>(256, (ppw + WG_PS - 1) / WG_PS * WG_PS);
+  const int nchunks = (int)ts_cdiv(max_pairs < 1 ? 1 : max_pairs, ppw);
+  dim3 grid(nchunks, K, tiles);
+  wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, col_a, (int)ppw, dW);
+  TS_CHECK_LAUNCH("conv_wgrad");
+  return TS_OK;
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const float *__restrict__ A, int CA,
+                                                                const float *__restrict__ B, int CB,
+                                                                const int2 *__restrict__ nbmaps,
+                                                                const int *__restrict__ nboffs, int col_a,
+                                                                float *__restrict__ dW) {
+  int k = blockIdx.y;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= CA * CB) return;
+  int ci = e / CB, co = e - ci * CB;
+  float s = 0.f;
+  for (int p = nboffs[k]; p < nboffs[k + 1]; ++p) {
+    int2 pr = nbmaps[p];
+    int ia = col_a ? pr.y : pr.x, ib = col_a ? pr.x : pr.y;
+    s = fmaf(A[(int64_t)ia * CA + ci], B[(int64_t)ib * CB + co], s);
+  }
+  dW[(int64_t)k * CA * CB + e] = s;
+}
+
+extern "C" int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
+                             const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
+                             int64_t max_pairs_per_offset, float *grad_kernel, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && max_pairs_per_offset >= 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_wgrad: bad sizes");
+  TS_REQUIRE(grad_kernel && nboffs, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
+  TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
+  if (max_pairs_per_offset == 0) return TS_OK;
+  TS_REQUIRE(a_feat && b_feat && nbmaps, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
+  const int2 *nm = (const int2 *)nbmaps;
+  col_a = col_a ? 1 : 0;
+  if (g_ts_conv_impl == 1) {
+    dim3 grid((unsigned)ts_cdiv((int64_t)c_a * c_b, 256), K);
+    conv_wgrad_scalar_kernel<<<grid, 256, 0, stream>>>(a_feat, c_a, b_feat, c_b, nm, nboffs, col_a, grad_kernel);
+    TS_CHECK_LAUNCH("conv_wgrad_scalar");
+    return TS_OK;
+  }
+  const int cmax = std::max(c_a, c_b), cmin = std::min(c_a, c_b);
+#define TS_WG(TM, TN) launch_wgrad<TM, TN>(a_feat, c_a, b_feat, c_b, nm, nboffs, K, col_a, max_pairs_per_offset, grad_kernel, stream)
+  if (cmax <= 32) return TS_WG(32, 32);
+  if (c_a <= 32) return TS_WG(32, 128);    // stem: C_in = 4 / 5
+  if (c_b <= 32) return TS_WG(128, 32);
+  if (cmax <= 64 || cmin <= 48) return TS_WG(64, 64);
+  return TS_WG(128, 128);
+#undef TS_WG
+}
