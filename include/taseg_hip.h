@@ -200,10 +200,11 @@ int ts_conv_nbr(const float *in_feat, int64_t n_in, int32_t c_in, const float *k
 
 /* Weight gradient:  grad_kernel[k] = sum_{pairs p of k} a[pa_p, :]^T b[pb_p, :]
  * with (pa, pb) = nbmaps columns (col_a, 1-col_a); a is [*, c_a], b is [*, c_b],
- * grad_kernel [K, c_a, c_b] is overwritten (zeroed then accumulated). */
+ * grad_kernel [K, c_a, c_b] is overwritten (zeroed then accumulated).
+ * n_pairs = nboffs[K], the rulebook length, known to the host (it sizes the grid). */
 int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
                   const int32_t *nbmaps, const int32_t *nboffs, int32_t kernel_volume,
-                  int32_t col_a, int64_t max_pairs_per_offset, float *grad_kernel,
+                  int32_t col_a, int64_t n_pairs, float *grad_kernel,
                   ts_stream_t stream);
 
 /* Two-pass convolution on the rulebook itself (the default forward / dgrad path):

@@ -438,5 +438,6 @@ extern "C" int ts_convolution_backward(const float *in_feat, int64_t n_in, int32
     rc = ts_conv_nbr(grad_out, n_out, c_out, kernel, K, 1, nbr, grad_in, n_in, c_in, stream_);
     if (rc != TS_OK) return rc;
   }
-  return ts_conv_wgrad(in_feat, c_in, grad_out, c_out, nbmap, nboffs, K, transpose ? 1 : 0, mx, grad_kernel, stream_);
+  (void)mx;
+  return ts_conv_wgrad(in_feat, c_in, grad_out, c_out, nbmap, nboffs, K, transpose ? 1 : 0, total, grad_kernel, stream_);
 }

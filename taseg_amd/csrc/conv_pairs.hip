@@ -22,7 +22,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PG_BK 32
 #define PG_AP (PG_BK + 4)
 
-// BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns)
+// BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
+// Software pipeline: the (offset, C_in-slice) steps of a tile are flattened; the global loads of step s+1 are
+// issued into registers right after the barrier of step s and land while its MFMAs run; LDS is double
+// buffered so one barrier per step suffices.
+struct PgStep {
+  int k, s0, s1, c0;
+};
+
 template <int BN, int WR, bool WT>
 __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict__ X, int R,
                                                         const float *__restrict__ W, int O_total,
@@ -33,10 +40,14 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   constexpr int MI = (PG_BM / 16) / WR;   // 16-row blocks per wave
   constexpr int NI = (BN / 16) / WC;      // 16-col blocks per wave
   constexpr int BP = BN + 4;              // pitch of the [k][col] weight tile
+  constexpr int A_FLOATS = PG_BM * PG_AP;
+  constexpr int B_FLOATS = WT ? BN * PG_AP : PG_BK * BP;
+  constexpr int A_IT = PG_BM * (PG_BK / 4) / 256;   // float4 per thread per A slice (4)
+  constexpr int B_IT = (BN * (PG_BK / 4) + 255) / 256;  // float4 per thread per B slice
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *At = smem;                                       // [128][36]
-  float *Bt = At + PG_BM * PG_AP;                         // !WT: [32][BN+4]   WT: [BN][36]
-  int *rowidx = (int *)(Bt + (WT ? BN * PG_AP : PG_BK * BP));  // [128]
+  float *Abuf = smem;                         // 2 x [128][36]
+  float *Bbuf = Abuf + 2 * A_FLOATS;          // 2 x (!WT: [32][BN+4] | WT: [BN][36])
+  int *rowidx = (int *)(Bbuf + 2 * B_FLOATS);  // [128]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
@@ -62,6 +73,20 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
     if ((int64_t)b <= p0) k_lo = k;
     if ((int64_t)b <= p0 + np - 1) k_hi = k;
   }
+  auto segment = [&](int k, int &s0, int &s1) {
+    s0 = max((int)((int64_t)nboffs[k] - p0), 0);
+    s1 = min((int)((int64_t)nboffs[k + 1] - p0), np);
+  };
+  auto advance = [&](PgStep st) -> PgStep {  // next (offset, slice); k > k_hi when exhausted
+    st.c0 += PG_BK;
+    if (st.c0 < R) return st;
+    st.c0 = 0;
+    for (++st.k; st.k <= k_hi; ++st.k) {
+      segment(st.k, st.s0, st.s1);
+      if (st.s1 > st.s0) break;
+    }
+    return st;
+  };
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -73,22 +98,51 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   const bool w_vec = WT ? (((R & 3) == 0) && ((((uintptr_t)W) & 15) == 0))
                         : (((O_total & 3) == 0) && ((((uintptr_t)W) & 15) == 0));
 
-  for (int k = k_lo; k <= k_hi; ++k) {
-    const int s0 = max((int)((int64_t)nboffs[k] - p0), 0);
-    const int s1 = min((int)((int64_t)nboffs[k + 1] - p0), np);
-    if (s1 <= s0) continue;  // uniform
-    for (int c0 = 0; c0 < R; c0 += PG_BK) {
-      const int ck = min(PG_BK, R - c0);
-      const int ck16 = (ck + 15) & ~15;
-      __syncthreads();  // rowidx visible / previous slice's fragment reads finished
-      // ---- A: gathered rows of this offset's segment, zero elsewhere
-      for (int e = tid; e < PG_BM * (PG_BK / 4); e += 256) {
-        int rr = e >> 3, c4 = (e & 7) << 2;
-        if (c4 >= ck16) continue;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr >= s0 && rr < s1) {
-          const float *src = X + (int64_t)rowidx[rr] * R + c0 + c4;
-          if (x_vec && c4 + 3 < ck) {
+  float4 ra[A_IT], rb[B_IT];
+  // ---- global -> registers for one step
+  auto load_regs = [&](const PgStep &st) {
+    const int ck = min(PG_BK, R - st.c0);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      const int rr = e >> 3, c4 = (e & 7) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr >= st.s0 && rr < st.s1 && c4 < ck) {
+        const float *src = X + (int64_t)rowidx[rr] * R + st.c0 + c4;
+        if (x_vec && c4 + 3 < ck) {
+          v = *(const float4 *)src;
+        } else {
+          if (c4 + 0 < ck) v.x = src[0];
+          if (c4 + 1 < ck) v.y = src[1];
+          if (c4 + 2 < ck) v.z = src[2];
+          if (c4 + 3 < ck) v.w = src[3];
+        }
+      }
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!WT) {
+        const int q4 = BN >> 2;
+        const int kk = e / q4, c4 = (e - kk * q4) << 2;
+        if (kk < ck && c4 < OT) {
+          const float *src = W + ((int64_t)st.k * R + st.c0 + kk) * O_total + o0 + c4;
+          if (w_vec && c4 + 3 < OT) {
+            v = *(const float4 *)src;
+          } else {
+            if (c4 + 0 < OT) v.x = src[0];
+            if (c4 + 1 < OT) v.y = src[1];
+            if (c4 + 2 < OT) v.z = src[2];
+            if (c4 + 3 < OT) v.w = src[3];
+          }
+        }
+      } else {
+        const int col = e >> 3, c4 = (e & 7) << 2;
+        if (col < OT && c4 < ck) {
+          const float *src = W + ((int64_t)st.k * O_total + o0 + col) * R + st.c0 + c4;
+          if (w_vec && c4 + 3 < ck) {
             v = *(const float4 *)src;
           } else {
             if (c4 + 0 < ck) v.x = src[0];
@@ -97,88 +151,86 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
             if (c4 + 3 < ck) v.w = src[3];
           }
         }
-        *(float4 *)&At[rr * PG_AP + c4] = v;
       }
-      // ---- B: the W_k slice
+      rb[it] = v;
+    }
+  };
+  // ---- registers -> LDS buffer
+  auto store_lds = [&](float *At, float *Bt) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      *(float4 *)&At[(e >> 3) * PG_AP + ((e & 7) << 2)] = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
       if (!WT) {
-        const int q4 = O16 >> 2;
-        const float *wk = W + ((int64_t)k * R + c0) * O_total + o0;
-        for (int e = tid; e < ck16 * q4; e += 256) {
-          int kk = e / q4, c4 = (e - kk * q4) << 2;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kk < ck) {
-            const float *src = wk + (int64_t)kk * O_total + c4;
-            if (w_vec && c4 + 3 < OT) {
-              v = *(const float4 *)src;
-            } else {
-              if (c4 + 0 < OT) v.x = src[0];
-              if (c4 + 1 < OT) v.y = src[1];
-              if (c4 + 2 < OT) v.z = src[2];
-              if (c4 + 3 < OT) v.w = src[3];
-            }
-          }
-          *(float4 *)&Bt[kk * BP + c4] = v;
-        }
+        const int q4 = BN >> 2;
+        const int kk = e / q4, c4 = (e - kk * q4) << 2;
+        if (kk < PG_BK) *(float4 *)&Bt[kk * BP + c4] = rb[it];
       } else {
-        const float *wk = W + ((int64_t)k * O_total + o0) * R + c0;
-        for (int e = tid; e < O16 * (PG_BK / 4); e += 256) {
-          int col = e >> 3, c4 = (e & 7) << 2;
-          if (c4 >= ck16) continue;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (col < OT) {
-            const float *src = wk + (int64_t)col * R + c4;
-            if (w_vec && c4 + 3 < ck) {
-              v = *(const float4 *)src;
-            } else {
-              if (c4 + 0 < ck) v.x = src[0];
-              if (c4 + 1 < ck) v.y = src[1];
-              if (c4 + 2 < ck) v.z = src[2];
-              if (c4 + 3 < ck) v.w = src[3];
-            }
-          }
-          *(float4 *)&Bt[col * PG_AP + c4] = v;
-        }
+        const int col = e >> 3, c4 = (e & 7) << 2;
+        if (col < BN) *(float4 *)&Bt[col * PG_AP + c4] = rb[it];
       }
-      __syncthreads();
-      // ---- MFMA.  k-slot permutation as in conv.hip: lane group g supplies reduction index 4 g + s in
-      // step s, so A (and W^T) fragments are single 16-byte LDS reads.
-      for (int j = 0; j < ck16; j += 16) {
-        float4 a[MI];
+    }
+  };
+
+  PgStep cur;
+  cur.k = k_lo - 1;
+  cur.c0 = R;  // so that advance() finds the first non-empty offset
+  cur.s0 = cur.s1 = 0;
+  __syncthreads();  // rowidx visible
+  cur = advance(cur);
+  load_regs(cur);
+  int buf = 0;
+  while (cur.k <= k_hi) {
+    float *At = Abuf + buf * A_FLOATS, *Bt = Bbuf + buf * B_FLOATS;
+    store_lds(At, Bt);
+    __syncthreads();
+    const PgStep nxt = advance(cur);
+    if (nxt.k <= k_hi) load_regs(nxt);  // in flight while this step's MFMAs run
+    const int ck16 = (min(PG_BK, R - cur.c0) + 15) & ~15;
+    // ---- MFMA.  k-slot permutation as in conv.hip: lane group g supplies reduction index 4 g + s in
+    // step s, so A (and W^T) fragments are single 16-byte LDS reads.
+    for (int j = 0; j < ck16; j += 16) {
+      float4 a[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int mb = wr * MI + mi;
+        a[mi] = *(const float4 *)&At[(mb * 16 + r16) * PG_AP + j + 4 * g];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nb = wc * NI + ni;
+        if (nb * 16 >= O16) continue;  // uniform per wave
+        float b0, b1, b2, b3;
+        if (!WT) {
+          const float *bp = &Bt[(j + 4 * g) * BP + nb * 16 + r16];
+          b0 = bp[0];
+          b1 = bp[BP];
+          b2 = bp[2 * BP];
+          b3 = bp[3 * BP];
+        } else {
+          const float4 b = *(const float4 *)&Bt[(nb * 16 + r16) * PG_AP + j + 4 * g];
+          b0 = b.x;
+          b1 = b.y;
+          b2 = b.z;
+          b3 = b.w;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int mb = wr * MI + mi;
-          a[mi] = *(const float4 *)&At[(mb * 16 + r16) * PG_AP + j + 4 * g];
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int nb = wc * NI + ni;
-          if (nb * 16 >= O16) continue;  // uniform per wave
-          float b0, b1, b2, b3;
-          if (!WT) {
-            const float *bp = &Bt[(j + 4 * g) * BP + nb * 16 + r16];
-            b0 = bp[0];
-            b1 = bp[BP];
-            b2 = bp[2 * BP];
-            b3 = bp[3 * BP];
-          } else {
-            const float4 b = *(const float4 *)&Bt[(nb * 16 + r16) * PG_AP + j + 4 * g];
-            b0 = b.x;
-            b1 = b.y;
-            b2 = b.z;
-            b3 = b.w;
-          }
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const int mb = wr * MI + mi;
-            if (mb * 16 >= s1 || mb * 16 + 16 <= s0) continue;  // row block outside this offset's segment
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].x, b0, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].y, b1, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].z, b2, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].w, b3, acc[mi][ni], 0, 0, 0);
-          }
+          if (mb * 16 >= cur.s1 || mb * 16 + 16 <= cur.s0) continue;  // row block outside this offset's segment
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].x, b0, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].y, b1, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].z, b2, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].w, b3, acc[mi][ni], 0, 0, 0);
         }
       }
     }
+    cur = nxt;
+    buf ^= 1;
   }
   // ---- Z rows (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg)
 #pragma unroll
@@ -198,7 +250,14 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
 template <int BN, int WR, bool WT>
 static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
                             int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
-  size_t lds = (size_t)(PG_BM * PG_AP + (WT ? BN * PG_AP : PG_BK * (BN + 4))) * 4 + PG_BM * 4;
+  size_t lds = (size_t)2 * (PG_BM * PG_AP + (WT ? BN * PG_AP : PG_BK * (BN + 4))) * 4 + PG_BM * 4;
+  auto kern = pair_gemm_kernel<BN, WR, WT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                 "hipFuncSetAttribute");
+    attr_set = true;
+  }
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
   pair_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
   TS_CHECK_LAUNCH("conv_pair_gemm");
@@ -284,138 +343,159 @@ extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos,
 
 // ------------------------------------------------------------------------------------- weight gradient
 //   dW_k[ci, co] = sum_{pairs p of k}  A[pa_p, ci] * B[pb_p, co]
-// One workgroup = (offset k, chunk of its pairs, TM x TN tile of dW_k): a "TN" GEMM whose reduction runs over
-// the pair list.  Both operands are gathered rows, staged 32 pairs at a time; each wave owns a
-// (TM/2) x (TN/2) register tile so every LDS fragment feeds TM/32 or TN/32 MFMAs.  Partial tiles of the
-// chunks are combined with float atomics (dW is small: the atomic bytes are ~1 / (chunk pairs / 2) of the flops).
+// One workgroup = (chunk of consecutive rulebook pairs, TM x TN tile of dW): a "TN" GEMM whose reduction runs
+// over the pair list.  Chunks are cut from the flat list (equal work per workgroup; the grid is sized from P),
+// a chunk that crosses an offset boundary flushes its accumulators there.  The chunk's pair indices are staged
+// in LDS once; both operands are gathered rows, staged 32 pairs at a time; each wave owns a (TM/2) x (TN/2)
+// register tile so every LDS fragment feeds TM/32 or TN/32 MFMAs.  Partial tiles are combined with float
+// atomics (dW is small: atomic bytes are 1 / (chunk / 2) of the flops).
 #define WG_PS 32
+#define WG_MAXCHUNK 1024
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict__ A, int CA,
                                                          const float *__restrict__ B, int CB,
                                                          const int2 *__restrict__ nbmaps,
-                                                         const int *__restrict__ nboffs, int col_a, int pairs_per_wg,
-                                                         float *__restrict__ dW) {
+                                                         const int *__restrict__ nboffs, int K, int P, int col_a,
+                                                         int chunk, float *__restrict__ dW) {
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int XP = TM + 4, YP = TN + 4;
   __shared__ __attribute__((aligned(16))) float Xl[WG_PS * XP];
   __shared__ __attribute__((aligned(16))) float Yl[WG_PS * YP];
+  __shared__ int idxA[WG_MAXCHUNK], idxB[WG_MAXCHUNK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  const int k = blockIdx.y;
-  const int beg = nboffs[k] + blockIdx.x * pairs_per_wg;
-  const int end = min(nboffs[k + 1], beg + pairs_per_wg);
-  if (beg >= end) return;  // uniform
+  const int p_beg = blockIdx.x * chunk;
+  const int p_end = min(P, p_beg + chunk);
+  if (p_beg >= p_end) return;  // uniform
   const int tiles_n = (CB + TN - 1) / TN;
-  const int ci0 = (blockIdx.z / tiles_n) * TM, co0 = (blockIdx.z % tiles_n) * TN;
+  const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
   const int ca = min(TM, CA - ci0), cb = min(TN, CB - co0);
 
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = tid; t < p_end - p_beg; t += 256) {
+    const int2 pr = nbmaps[p_beg + t];
+    idxA[t] = col_a ? pr.y : pr.x;
+    idxB[t] = col_a ? pr.x : pr.y;
+  }
+  int k = 0;
+  for (int kk = 0; kk < K; ++kk)
+    if (nboffs[kk] <= p_beg) k = kk;  // offset containing the first pair (uniform scalar scan)
 
+  f32x4 acc[MI][NI];
   const bool a_vec = ((CA & 3) == 0) && ((ci0 & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
   const bool b_vec = ((CB & 3) == 0) && ((co0 & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
 
-  for (int p0 = beg; p0 < end; p0 += WG_PS) {
-    const int np = min(WG_PS, end - p0);
-    __syncthreads();
-    for (int e = tid; e < WG_PS * (TM / 4); e += 256) {
-      const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < np && c4 < ca) {
-        const int2 pr = nbmaps[p0 + pp];
-        const float *src = A + (int64_t)(col_a ? pr.y : pr.x) * CA + ci0 + c4;
-        if (a_vec && c4 + 3 < ca) {
-          v = *(const float4 *)src;
-        } else {
-          if (c4 + 0 < ca) v.x = src[0];
-          if (c4 + 1 < ca) v.y = src[1];
-          if (c4 + 2 < ca) v.z = src[2];
-          if (c4 + 3 < ca) v.w = src[3];
-        }
-      }
-      *(float4 *)&Xl[pp * XP + c4] = v;
+  int p = p_beg;
+  while (p < p_end && k < K) {
+    const int kend = min(nboffs[k + 1], p_end);
+    if (kend <= p) {  // offset without pairs in this chunk
+      ++k;
+      continue;
     }
-    for (int e = tid; e < WG_PS * (TN / 4); e += 256) {
-      const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < np && c4 < cb) {
-        const int2 pr = nbmaps[p0 + pp];
-        const float *src = B + (int64_t)(col_a ? pr.x : pr.y) * CB + co0 + c4;
-        if (b_vec && c4 + 3 < cb) {
-          v = *(const float4 *)src;
-        } else {
-          if (c4 + 0 < cb) v.x = src[0];
-          if (c4 + 1 < cb) v.y = src[1];
-          if (c4 + 2 < cb) v.z = src[2];
-          if (c4 + 3 < cb) v.w = src[3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int p0 = p; p0 < kend; p0 += WG_PS) {
+      const int np = min(WG_PS, kend - p0);
+      const int l0 = p0 - p_beg;
+      __syncthreads();  // indices visible (first step) / previous fragments consumed
+      for (int e = tid; e < WG_PS * (TM / 4); e += 256) {
+        const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pp < np && c4 < ca) {
+          const float *src = A + (int64_t)idxA[l0 + pp] * CA + ci0 + c4;
+          if (a_vec && c4 + 3 < ca) {
+            v = *(const float4 *)src;
+          } else {
+            if (c4 + 0 < ca) v.x = src[0];
+            if (c4 + 1 < ca) v.y = src[1];
+            if (c4 + 2 < ca) v.z = src[2];
+            if (c4 + 3 < ca) v.w = src[3];
+          }
         }
+        *(float4 *)&Xl[pp * XP + c4] = v;
       }
-      *(float4 *)&Yl[pp * YP + c4] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < WG_PS; j += 16) {
-      float a[MI][4], b[NI][4];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const float *ap = &Xl[(j + 4 * g) * XP + (wr * MI + mi) * 16 + r16];
-        a[mi][0] = ap[0];
-        a[mi][1] = ap[XP];
-        a[mi][2] = ap[2 * XP];
-        a[mi][3] = ap[3 * XP];
+      for (int e = tid; e < WG_PS * (TN / 4); e += 256) {
+        const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pp < np && c4 < cb) {
+          const float *src = B + (int64_t)idxB[l0 + pp] * CB + co0 + c4;
+          if (b_vec && c4 + 3 < cb) {
+            v = *(const float4 *)src;
+          } else {
+            if (c4 + 0 < cb) v.x = src[0];
+            if (c4 + 1 < cb) v.y = src[1];
+            if (c4 + 2 < cb) v.z = src[2];
+            if (c4 + 3 < cb) v.w = src[3];
+          }
+        }
+        *(float4 *)&Yl[pp * YP + c4] = v;
       }
+      __syncthreads();
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const float *bp = &Yl[(j + 4 * g) * YP + (wc * NI + ni) * 16 + r16];
-        b[ni][0] = bp[0];
-        b[ni][1] = bp[YP];
-        b[ni][2] = bp[2 * YP];
-        b[ni][3] = bp[3 * YP];
-      }
+      for (int j = 0; j < WG_PS; j += 16) {
+        float a[MI][4], b[NI][4];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if ((wr * MI + mi) * 16 >= ca) continue;  // uniform per wave
+        for (int mi = 0; mi < MI; ++mi) {
+          const float *ap = &Xl[(j + 4 * g) * XP + (wr * MI + mi) * 16 + r16];
+          a[mi][0] = ap[0];
+          a[mi][1] = ap[XP];
+          a[mi][2] = ap[2 * XP];
+          a[mi][3] = ap[3 * XP];
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          if ((wc * NI + ni) * 16 >= cb) continue;
+          const float *bp = &Yl[(j + 4 * g) * YP + (wc * NI + ni) * 16 + r16];
+          b[ni][0] = bp[0];
+          b[ni][1] = bp[YP];
+          b[ni][2] = bp[2 * YP];
+          b[ni][3] = bp[3 * YP];
+        }
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi) {
+          if ((wr * MI + mi) * 16 >= ca) continue;  // uniform per wave
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if ((wc * NI + ni) * 16 >= cb) continue;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+          }
         }
       }
     }
-  }
-  float *dwk = dW + (int64_t)k * CA * CB;
+    // flush this offset's partial tile
+    float *dwk = dW + (int64_t)k * CA * CB;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int co = (wc * NI + ni) * 16 + r16;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int co = (wc * NI + ni) * 16 + r16;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ci = (wr * MI + mi) * 16 + 4 * g + q;
-        if (ci < ca && co < cb) atomicAdd(&dwk[(int64_t)(ci0 + ci) * CB + co0 + co], acc[mi][ni][q]);
+        for (int q = 0; q < 4; ++q) {
+          const int ci = (wr * MI + mi) * 16 + 4 * g + q;
+          if (ci < ca && co < cb) atomicAdd(&dwk[(int64_t)(ci0 + ci) * CB + co0 + co], acc[mi][ni][q]);
+        }
       }
     }
+    p = kend;
+    ++k;
   }
 }
 
 template <int TM, int TN>
 static int launch_wgrad(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
-                        int col_a, int64_t max_pairs, float *dW, hipStream_t stream) {
+                        int col_a, int64_t n_pairs, float *dW, hipStream_t stream) {
   const int tiles = (int)(ts_cdiv(CA, TM) * ts_cdiv(CB, TN));
-  // ~1024 workgroups over the launch, chunks of at least 256 pairs
-  int64_t chunks_per_k = std::max<int64_t>(1, 1024 / ((int64_t)K * tiles));
-  int64_t ppw = ts_cdiv(max_pairs < 1 ? 1 : max_pairs, chunks_per_k);
-  ppw = std::max<int64_t>(256, (ppw + WG_PS - 1) / WG_PS * WG_PS);
-  const int nchunks = (int)ts_cdiv(max_pairs < 1 ? 1 : max_pairs, ppw);
-  dim3 grid(nchunks, K, tiles);
-  wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, col_a, (int)ppw, dW);
+  // ~1536 workgroups over the launch, chunks of 128 .. 1024 pairs (multiples of the 32-pair step)
+  int64_t chunk = ts_cdiv(n_pairs * tiles, 1536);
+  chunk = std::min<int64_t>(WG_MAXCHUNK, std::max<int64_t>(128, (chunk + WG_PS - 1) / WG_PS * WG_PS));
+  dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
+  wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
+                                                     (int)chunk, dW);
   TS_CHECK_LAUNCH("conv_wgrad");
   return TS_OK;
 }
@@ -440,13 +520,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const float *__r
 
 extern "C" int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
                              const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
-                             int64_t max_pairs_per_offset, float *grad_kernel, ts_stream_t stream_) {
+                             int64_t n_pairs, float *grad_kernel, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && max_pairs_per_offset >= 0, TS_ERR_INVALID_ARGUMENT,
+  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && n_pairs >= 0 && n_pairs < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
              "ts_conv_wgrad: bad sizes");
   TS_REQUIRE(grad_kernel && nboffs, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
   TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
-  if (max_pairs_per_offset == 0) return TS_OK;
+  if (n_pairs == 0) return TS_OK;
   TS_REQUIRE(a_feat && b_feat && nbmaps, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
   const int2 *nm = (const int2 *)nbmaps;
   col_a = col_a ? 1 : 0;
@@ -457,7 +537,7 @@ extern "C" int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_fe
     return TS_OK;
   }
   const int cmax = std::max(c_a, c_b), cmin = std::min(c_a, c_b);
-#define TS_WG(TM, TN) launch_wgrad<TM, TN>(a_feat, c_a, b_feat, c_b, nm, nboffs, K, col_a, max_pairs_per_offset, grad_kernel, stream)
+#define TS_WG(TM, TN) launch_wgrad<TM, TN>(a_feat, c_a, b_feat, c_b, nm, nboffs, K, col_a, n_pairs, grad_kernel, stream)
   if (cmax <= 32) return TS_WG(32, 32);
   if (c_a <= 32) return TS_WG(32, 128);    // stem: C_in = 4 / 5
   if (c_b <= 32) return TS_WG(128, 32);

@@ -230,7 +230,7 @@ class _SparseConv(Function):
             grad_feats = B.conv_gather_sum(z, table, rows)
         if ctx.needs_input_grad[1]:
             grad_weight = B.conv_wgrad(feats, grad_out, kmap.nbmaps_buf, kmap.nboffs, k,
-                                       col_a=1 if transposed else 0, max_pairs=n_out)
+                                       col_a=1 if transposed else 0, max_pairs=kmap.total)
         return grad_feats, grad_weight, None, None
 
 
