@@ -243,7 +243,7 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
 
 
 def pair_gemm_kernel_name(c_out, weight_transposed=False):
-    bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (128, 2)
+    bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (96, 2) if c_out % 96 == 0 else (128, 2)
     return f"pair_gemm_kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
 
 
@@ -276,7 +276,7 @@ def conv_gather_sum(z, pos, n_rows):
     if pos.shape != (k, n_rows):
         raise ValueError(f"position table shape {tuple(pos.shape)} != {(k, n_rows)}")
     out = torch.empty((n_rows, z.shape[1]), dtype=torch.float32, device=z.device)
-    with _Timed("gather_sum", name="gather_sum_kernel<4>" if z.shape[1] % 4 == 0 else "gather_sum_kernel<1>",
+    with _Timed("gather_sum", name=(f"gather_sum_kernel<4,{k if k in (8, 27) else 0}>" if z.shape[1] % 4 == 0 else "gather_sum_kernel<1,0>"),
                 pairs=z.shape[0], c_red=0, c_out=z.shape[1], k=k, n_rows=n_rows):
         L.check(L.load().ts_conv_gather_sum(L.ptr(z), z.shape[1], L.ptr(pos), k, n_rows, z.shape[0], L.ptr(out),
                                             L.stream()), "ts_conv_gather_sum")

@@ -281,12 +281,15 @@ extern "C" int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in
        : launch_pair_gemm<BN, WR, false>(feat, c_in, kernel, c_out, nm, nboffs, K, n_pairs, gc, z, stream))
   if (c_out <= 32) return TS_PG(32, 4);
   if (c_out <= 64) return TS_PG(64, 2);
+  if (c_out % 96 == 0) return TS_PG(96, 2);  // 96 / 192 / 384 channels: three 16-col blocks per wave, no padding
   return TS_PG(128, 2);
 #undef TS_PG
 }
 
 // ------------------------------------------------------------------------------------- pass 2
-template <int VEC>
+// KT > 0: kernel volume known at compile time (27, 8): all K position loads are issued first, then all row
+// loads - up to K independent 16-byte loads in flight per lane.  KT == 0: generic loop.
+template <int VEC, int KT>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ Z, int C,
                                                          const int *__restrict__ pos, int K, int64_t n,
                                                          int64_t n_pairs, float *__restrict__ out) {
@@ -300,18 +303,37 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    if (KT > 0 && VEC == 4) {
+      int p[KT > 0 ? KT : 1];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) p[k] = pos[(int64_t)k * n + j];
+      float4 f[KT > 0 ? KT : 1];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        f[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p[k] >= 0 && p[k] < n_pairs) f[k] = *(const float4 *)(Z + (int64_t)p[k] * C + c);
+      }
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {  // k ascending: fixed summation order
+        acc[0] += f[k].x;
+        acc[1 % VEC] += f[k].y;
+        acc[2 % VEC] += f[k].z;
+        acc[3 % VEC] += f[k].w;
+      }
+    } else {
 #pragma unroll 4
-    for (int k = 0; k < K; ++k) {
-      const int p = pos[(int64_t)k * n + j];
-      if (p >= 0 && p < n_pairs) {
-        if (VEC == 4) {
-          const float4 f = *(const float4 *)(Z + (int64_t)p * C + c);
-          acc[0] += f.x;
-          acc[1 % VEC] += f.y;
-          acc[2 % VEC] += f.z;
-          acc[3 % VEC] += f.w;
-        } else {
-          acc[0] += Z[(int64_t)p * C + c];
+      for (int k = 0; k < K; ++k) {
+        const int p = pos[(int64_t)k * n + j];
+        if (p >= 0 && p < n_pairs) {
+          if (VEC == 4) {
+            const float4 f = *(const float4 *)(Z + (int64_t)p * C + c);
+            acc[0] += f.x;
+            acc[1 % VEC] += f.y;
+            acc[2 % VEC] += f.z;
+            acc[3 % VEC] += f.w;
+          } else {
+            acc[0] += Z[(int64_t)p * C + c];
+          }
         }
       }
     }
@@ -332,10 +354,15 @@ extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos,
   const bool vec = (c % 4 == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
   if (vec) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 4), 256), 1 << 20);
-    gather_sum_kernel<4><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+    if (K == 27)
+      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+    else if (K == 8)
+      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+    else
+      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
   } else {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * c, 256), 1 << 20);
-    gather_sum_kernel<1><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
   }
   TS_CHECK_LAUNCH("conv_gather_sum");
   return TS_OK;
@@ -360,8 +387,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict
                                                          int chunk, float *__restrict__ dW) {
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int XP = TM + 4, YP = TN + 4;
-  __shared__ __attribute__((aligned(16))) float Xl[WG_PS * XP];
-  __shared__ __attribute__((aligned(16))) float Yl[WG_PS * YP];
+  __shared__ __attribute__((aligned(16))) float Xl[2 * WG_PS * XP];  // double buffered
+  __shared__ __attribute__((aligned(16))) float Yl[2 * WG_PS * YP];
   __shared__ int idxA[WG_MAXCHUNK], idxB[WG_MAXCHUNK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
@@ -383,106 +410,155 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict
     if (nboffs[kk] <= p_beg) k = kk;  // offset containing the first pair (uniform scalar scan)
 
   f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool a_vec = ((CA & 3) == 0) && ((ci0 & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
   const bool b_vec = ((CB & 3) == 0) && ((co0 & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
 
-  int p = p_beg;
-  while (p < p_end && k < K) {
-    const int kend = min(nboffs[k + 1], p_end);
-    if (kend <= p) {  // offset without pairs in this chunk
-      ++k;
-      continue;
+  // flattened (offset, 32-pair step) sequence of this chunk; k == K when exhausted
+  struct WStep {
+    int k, p0, np;
+  };
+  auto advance = [&](WStep st) -> WStep {
+    int kend = min(nboffs[st.k + 1], p_end);
+    int pn = st.p0 + WG_PS;
+    if (pn < kend) {
+      st.p0 = pn;
+      st.np = min(WG_PS, kend - pn);
+      return st;
+    }
+    pn = kend;
+    for (++st.k; st.k < K && pn < p_end; ++st.k) {
+      kend = min(nboffs[st.k + 1], p_end);
+      if (kend > pn) {
+        st.p0 = pn;
+        st.np = min(WG_PS, kend - pn);
+        return st;
+      }
+    }
+    st.k = K;
+    return st;
+  };
+  constexpr int A_IT = WG_PS * (TM / 4) / 256, B_IT = WG_PS * (TN / 4) / 256;
+  float4 ra[A_IT > 0 ? A_IT : 1], rb[B_IT > 0 ? B_IT : 1];
+  auto load_regs = [&](const WStep &st) {
+    const int l0 = st.p0 - p_beg;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < st.np && c4 < ca) {
+        const float *src = A + (int64_t)idxA[l0 + pp] * CA + ci0 + c4;
+        if (a_vec && c4 + 3 < ca) {
+          v = *(const float4 *)src;
+        } else {
+          if (c4 + 0 < ca) v.x = src[0];
+          if (c4 + 1 < ca) v.y = src[1];
+          if (c4 + 2 < ca) v.z = src[2];
+          if (c4 + 3 < ca) v.w = src[3];
+        }
+      }
+      ra[it] = v;
     }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < st.np && c4 < cb) {
+        const float *src = B + (int64_t)idxB[l0 + pp] * CB + co0 + c4;
+        if (b_vec && c4 + 3 < cb) {
+          v = *(const float4 *)src;
+        } else {
+          if (c4 + 0 < cb) v.x = src[0];
+          if (c4 + 1 < cb) v.y = src[1];
+          if (c4 + 2 < cb) v.z = src[2];
+          if (c4 + 3 < cb) v.w = src[3];
+        }
+      }
+      rb[it] = v;
+    }
+  };
+  auto store_lds = [&](float *xl, float *yl) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
+      *(float4 *)&xl[pp * XP + c4] = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
+      *(float4 *)&yl[pp * YP + c4] = rb[it];
+    }
+  };
 
-    for (int p0 = p; p0 < kend; p0 += WG_PS) {
-      const int np = min(WG_PS, kend - p0);
-      const int l0 = p0 - p_beg;
-      __syncthreads();  // indices visible (first step) / previous fragments consumed
-      for (int e = tid; e < WG_PS * (TM / 4); e += 256) {
-        const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pp < np && c4 < ca) {
-          const float *src = A + (int64_t)idxA[l0 + pp] * CA + ci0 + c4;
-          if (a_vec && c4 + 3 < ca) {
-            v = *(const float4 *)src;
-          } else {
-            if (c4 + 0 < ca) v.x = src[0];
-            if (c4 + 1 < ca) v.y = src[1];
-            if (c4 + 2 < ca) v.z = src[2];
-            if (c4 + 3 < ca) v.w = src[3];
-          }
-        }
-        *(float4 *)&Xl[pp * XP + c4] = v;
+  WStep cur;
+  cur.k = k;
+  cur.p0 = p_beg;
+  cur.np = min(WG_PS, min(nboffs[k + 1], p_end) - p_beg);
+  __syncthreads();  // pair indices visible
+  load_regs(cur);
+  int buf = 0;
+  while (cur.k < K) {
+    float *xl = Xl + buf * (WG_PS * XP), *yl = Yl + buf * (WG_PS * YP);
+    store_lds(xl, yl);
+    __syncthreads();
+    const WStep nxt = advance(cur);
+    if (nxt.k < K) load_regs(nxt);  // lands while this step's MFMAs run
+#pragma unroll
+    for (int j = 0; j < WG_PS; j += 16) {
+      float a[MI][4], b[NI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const float *ap = &xl[(j + 4 * g) * XP + (wr * MI + mi) * 16 + r16];
+        a[mi][0] = ap[0];
+        a[mi][1] = ap[XP];
+        a[mi][2] = ap[2 * XP];
+        a[mi][3] = ap[3 * XP];
       }
-      for (int e = tid; e < WG_PS * (TN / 4); e += 256) {
-        const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pp < np && c4 < cb) {
-          const float *src = B + (int64_t)idxB[l0 + pp] * CB + co0 + c4;
-          if (b_vec && c4 + 3 < cb) {
-            v = *(const float4 *)src;
-          } else {
-            if (c4 + 0 < cb) v.x = src[0];
-            if (c4 + 1 < cb) v.y = src[1];
-            if (c4 + 2 < cb) v.z = src[2];
-            if (c4 + 3 < cb) v.w = src[3];
-          }
-        }
-        *(float4 *)&Yl[pp * YP + c4] = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < WG_PS; j += 16) {
-        float a[MI][4], b[NI][4];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const float *ap = &Xl[(j + 4 * g) * XP + (wr * MI + mi) * 16 + r16];
-          a[mi][0] = ap[0];
-          a[mi][1] = ap[XP];
-          a[mi][2] = ap[2 * XP];
-          a[mi][3] = ap[3 * XP];
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const float *bp = &Yl[(j + 4 * g) * YP + (wc * NI + ni) * 16 + r16];
-          b[ni][0] = bp[0];
-          b[ni][1] = bp[YP];
-          b[ni][2] = bp[2 * YP];
-          b[ni][3] = bp[3 * YP];
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          if ((wr * MI + mi) * 16 >= ca) continue;  // uniform per wave
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            if ((wc * NI + ni) * 16 >= cb) continue;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // flush this offset's partial tile
-    float *dwk = dW + (int64_t)k * CA * CB;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int co = (wc * NI + ni) * 16 + r16;
+        const float *bp = &yl[(j + 4 * g) * YP + (wc * NI + ni) * 16 + r16];
+        b[ni][0] = bp[0];
+        b[ni][1] = bp[YP];
+        b[ni][2] = bp[2 * YP];
+        b[ni][3] = bp[3 * YP];
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ci = (wr * MI + mi) * 16 + 4 * g + q;
-          if (ci < ca && co < cb) atomicAdd(&dwk[(int64_t)(ci0 + ci) * CB + co0 + co], acc[mi][ni][q]);
+      for (int mi = 0; mi < MI; ++mi) {
+        if ((wr * MI + mi) * 16 >= ca) continue;  // uniform per wave
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if ((wc * NI + ni) * 16 >= cb) continue;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
         }
       }
     }
-    p = kend;
-    ++k;
+    if (nxt.k != cur.k) {  // last step of this offset inside the chunk: flush its partial tile
+      float *dwk = dW + (int64_t)cur.k * CA * CB;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int co = (wc * NI + ni) * 16 + r16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ci = (wr * MI + mi) * 16 + 4 * g + q;
+            if (ci < ca && co < cb) atomicAdd(&dwk[(int64_t)(ci0 + ci) * CB + co0 + co], acc[mi][ni][q]);
+          }
+          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    cur = nxt;
+    buf ^= 1;
   }
 }
 
