@@ -223,6 +223,22 @@ int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in, const flo
 int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t kernel_volume,
                        int64_t n_rows, int64_t n_pairs, float *out, ts_stream_t stream);
 
+/* Per-channel reductions of BatchNorm over the [n, c] feature matrix of a sparse tensor (the reference runs
+ * nn.BatchNorm1d / nn.SyncBatchNorm on conv outputs, pcseg/.../minkunet/minkunet.py:23-29; the elementwise
+ * halves stay torch.batch_norm_elemt / batch_norm_backward_elemt).  sums is double [2, c], zeroed here:
+ *   ts_bn_stats:            sums[0] = sum_n x,   sums[1] = sum_n x^2
+ *   ts_bn_backward_reduce:  sums[0] = sum_n dy,  sums[1] = sum_n dy * (x - mean)
+ * c must be a multiple of 4 (<= 1024), pointers 16-byte aligned. */
+int ts_bn_stats(const float *x, int64_t n, int32_t c, double *sums, ts_stream_t stream);
+int ts_bn_backward_reduce(const float *grad_out, const float *x, const float *mean, int64_t n,
+                          int32_t c, double *sums, ts_stream_t stream);
+/* mean[c], invstd[c] from the sums of ts_bn_stats over `total` rows (*total_dev if non-NULL - e.g. the
+ * all-reduced count of SyncBN - else total_host) and the nn.BatchNorm momentum update of the running
+ * buffers (unbiased variance; either may be NULL). */
+int ts_bn_finalize(const double *sums, const double *total_dev, double total_host, int32_t c, float eps,
+                   float momentum, float *running_mean, float *running_var, float *mean,
+                   float *invstd, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics). */
 void ts_set_conv_impl(int32_t impl);

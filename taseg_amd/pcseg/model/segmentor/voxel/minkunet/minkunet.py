@@ -20,14 +20,12 @@ from .utils import initial_voxelize, voxel_to_point
 __all__ = ["MinkUNet"]
 
 
-class SyncBatchNorm(nn.SyncBatchNorm):
-    def forward(self, input: SparseTensor) -> SparseTensor:
-        return fapply(input, super().forward)
+class SyncBatchNorm(spnn.SyncBatchNorm):
+    """nn.SyncBatchNorm applied to SparseTensor features (minkunet.py:23-25); training-mode reductions on HIP."""
 
 
-class BatchNorm(nn.BatchNorm1d):
-    def forward(self, input: SparseTensor) -> SparseTensor:
-        return fapply(input, super().forward)
+class BatchNorm(spnn.BatchNorm):
+    """nn.BatchNorm1d applied to SparseTensor features (minkunet.py:27-29); training-mode reductions on HIP."""
 
 
 def _norm(channels: int, if_dist: bool) -> nn.Module:

@@ -9,7 +9,7 @@ from ..utils.misc import make_ntuple
 from . import functional as F
 from .utils import fapply
 
-__all__ = ["Conv3d", "BatchNorm", "ReLU", "LeakyReLU"]
+__all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU"]
 
 
 class Conv3d(nn.Module):
@@ -59,9 +59,33 @@ class Conv3d(nn.Module):
                         dilation=self.dilation, transposed=self.transposed)
 
 
+def _bn_forward(mod, feats, torch_forward, group=None):
+    """Training mode with batch statistics -> our reduction kernels; everything else (eval mode,
+    momentum=None cumulative averaging, odd channel counts) -> the stock torch module."""
+    from .batchnorm import batch_norm_train, fast_path_ok
+    if mod.training and mod.momentum is not None and mod.affine and fast_path_ok(feats):
+        if mod.track_running_stats and mod.num_batches_tracked is not None:
+            mod.num_batches_tracked.add_(1)
+        rm = mod.running_mean if mod.track_running_stats else None
+        rv = mod.running_var if mod.track_running_stats else None
+        return batch_norm_train(feats, mod.weight, mod.bias, rm, rv, mod.momentum, mod.eps, group)
+    return torch_forward(feats)
+
+
 class BatchNorm(nn.BatchNorm1d):
     def forward(self, input: SparseTensor) -> SparseTensor:
-        return fapply(input, super().forward)
+        return fapply(input, lambda f: _bn_forward(self, f, super(BatchNorm, self).forward))
+
+
+class SyncBatchNorm(nn.SyncBatchNorm):
+    """nn.SyncBatchNorm over sparse features: statistics over all ranks (one all-reduce of [2C+1] doubles)."""
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        import torch.distributed as dist
+        group = None
+        if self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            group = self.process_group if self.process_group is not None else dist.group.WORLD
+        return fapply(input, lambda f: _bn_forward(self, f, super(SyncBatchNorm, self).forward, group))
 
 
 class ReLU(nn.ReLU):

@@ -377,3 +377,35 @@ def test_device_multiscan_stage_golden(g_multiscan):
         same(batch[key].F.to(torch.from_numpy(g[f"batch_{key}_F"]).dtype), g[f"batch_{key}_F"])
     for key in ("num_points", "num_points_ms", "offset", "offset_ms", "point_mask"):
         same(batch[key].to(torch.from_numpy(g[f"batch_{key}"]).dtype), g[f"batch_{key}"])
+
+
+@pytest.mark.parametrize("n,c", [(5000, 32), (20011, 96), (777, 256), (3, 16)])
+def test_batchnorm_train_matches_torch(n, c):
+    """our reductions + torch's elementwise halves == nn.BatchNorm1d (training): output, grads, running stats"""
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse import nn as spnn
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c, device=DEV) * 2 + 0.5)
+    ref = torch.nn.BatchNorm1d(c).to(DEV).train()
+    ours = spnn.BatchNorm(c).to(DEV).train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+        ours.weight.copy_(ref.weight)
+        ours.bias.copy_(ref.bias)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = ref(xa)
+    yb = ours(SparseTensor(xb, torch.zeros(n, 4, dtype=torch.int32, device=DEV))).F
+    close(yb, ya, 2e-5)
+    gy = torch.randn_like(ya)
+    ya.backward(gy)
+    yb.backward(gy)
+    close(xb.grad, xa.grad, 5e-5)
+    close(ours.weight.grad, ref.weight.grad, 5e-5)
+    close(ours.bias.grad, ref.bias.grad, 5e-5)
+    close(ours.running_mean, ref.running_mean, 1e-5)
+    close(ours.running_var, ref.running_var, 1e-5)
+    assert int(ours.num_batches_tracked) == 1
+    # eval mode goes through the stock module
+    ours.eval(), ref.eval()
+    close(ours(SparseTensor(x, torch.zeros(n, 4, dtype=torch.int32, device=DEV))).F, ref(x), 1e-5)
