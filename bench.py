@@ -257,7 +257,10 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom["kernel"])
+                # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+                # command (profiles/parse_traffic.py applies the gfx950 corrections)
+                entry = json.load(open(tpath)).get(dom["kernel"])
+                traffic = entry["hbm_bytes_per_launch"] if entry else None
             roofline.update(traffic=traffic, kernel=dom["kernel"], avg_us=dom["avg_us"],
                             launches_per_step=dom["launches_per_step"],
                             algorithmic_bytes_per_launch=dom["bytes_per_launch"],
@@ -270,7 +273,7 @@ def main():
                                    f"bs={args.batch}/GPU, voxel 0.05 m, fp32, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}"},
-            "loss": float(loss),
+            "loss": float(loss.detach()),
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in prof[:8]],
         }

@@ -1,0 +1,48 @@
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
+profiles/traffic.json: average HBM bytes per launch for each of our kernels, corrected as
+MI355X_MICROARCH.md prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE under-reports wide coalesced reads by exactly 2x; both counters are in KiB).
+
+    python profiles/parse_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.match(r"(?:void )?([A-Za-z_0-9]+)(<[^>]*>)?", name)
+    if not m:
+        return name
+    base, targs = m.group(1), (m.group(2) or "")
+    return base + targs.replace(" ", "")
+
+
+def collect(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            tot[k] += float(row["Counter_Value"])
+            cnt[k] += 1
+    return {k: tot[k] / cnt[k] for k in tot}, cnt
+
+
+if __name__ == "__main__":
+    fetch, n1 = collect(sys.argv[1], "FETCH_SIZE")
+    write, n2 = collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not any(s in k for s in ("pair_gemm", "gather_sum", "wgrad_gemm", "bn_reduce", "conv_nbr", "kmap_",
+                                    "devoxelize", "voxelize", "trilinear", "table_", "hash_kernel")):
+            continue
+        f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
+        out[k] = {"hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0, "fetch_kib_raw": f_kib, "write_kib": w_kib,
+                  "launches_sampled": int(n1.get(k, 0))}
+    json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:42s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  ({v['launches_sampled']} launches)")
