@@ -20,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PG_BM 128
 #define PG_BK 32
-#define PG_AP (PG_BK + 4)
+#define PG_AP (PG_BK + 8)  // 40-dword pitch: ds_read_b128 fragment reads (row = lane & 15, +4 dwords per lane group) hit 16 distinct slots
 
 // BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
 // Software pipeline: the (offset, C_in-slice) steps of a tile are flattened; the global loads of step s+1 are
