@@ -335,10 +335,8 @@ class _Timed:
 def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None, n_out=0):
     """The template instantiation ts_conv_nbr / ts_conv_wgrad picks (mirrors the heuristic in csrc/conv.hip)."""
     if wgrad_cb is not None:
-        ca, cb = c_out_or_ca, wgrad_cb
-        cmax, cmin = max(ca, cb), min(ca, cb)
-        tm, tn = ((32, 32) if cmax <= 32 else (32, 128) if ca <= 32 else (128, 32) if cb <= 32
-                  else (64, 64) if (cmax <= 64 or cmin <= 48) else (128, 128))
+        pick = lambda c: 32 if c <= 32 else 64 if c <= 64 else 96 if c % 96 == 0 else 128  # noqa: E731
+        tm, tn = pick(c_out_or_ca), pick(wgrad_cb)
         return f"wgrad_gemm_kernel<{tm},{tn}>"
     c16 = (c_out_or_ca + 15) & ~15
     tiles64 = -(-n_out // 64)

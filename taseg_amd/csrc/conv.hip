@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void conv_nbr_kernel(const float *__restrict__
                                                        float *__restrict__ Y, int O_total, int o_tile,
                                                        int k_per_group) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: conditions on it become s_cbranch, not exec masks
   const int r16 = lane & 15, g = lane >> 4;
   const int o0 = blockIdx.y * o_tile;
   // blockIdx.z = group of kernel offsets handled by this workgroup (small problems are split

@@ -20,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PG_BM 128
 #define PG_BK 32
-#define PG_AP (PG_BK + 8)  // 40-dword pitch: ds_read_b128 fragment reads (row = lane & 15, +4 dwords per lane group) hit 16 distinct slots
+#define PG_AP (PG_BK + 4)
 
 // BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
 // Software pipeline: the (offset, C_in-slice) steps of a tile are flattened; the global loads of step s+1 are
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   float *Bbuf = Abuf + 2 * A_FLOATS;          // 2 x (!WT: [32][BN+4] | WT: [BN][36])
   int *rowidx = (int *)(Bbuf + 2 * B_FLOATS);  // [128]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: conditions on it become s_cbranch, not exec masks
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave / WC, wc = wave % WC;
   const int64_t p0 = (int64_t)blockIdx.x * PG_BM;
@@ -194,38 +195,44 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
     // ---- MFMA.  k-slot permutation as in conv.hip: lane group g supplies reduction index 4 g + s in
     // step s, so A (and W^T) fragments are single 16-byte LDS reads.
     for (int j = 0; j < ck16; j += 16) {
-      float4 a[MI];
+      float a[MI][4], b[NI][4];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int mb = wr * MI + mi;
-        a[mi] = *(const float4 *)&At[(mb * 16 + r16) * PG_AP + j + 4 * g];
+        const float4 v = *(const float4 *)&At[(mb * 16 + r16) * PG_AP + j + 4 * g];
+        a[mi][0] = v.x;
+        a[mi][1] = v.y;
+        a[mi][2] = v.z;
+        a[mi][3] = v.w;
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int nb = wc * NI + ni;
-        if (nb * 16 >= O16) continue;  // uniform per wave
-        float b0, b1, b2, b3;
         if (!WT) {
           const float *bp = &Bt[(j + 4 * g) * BP + nb * 16 + r16];
-          b0 = bp[0];
-          b1 = bp[BP];
-          b2 = bp[2 * BP];
-          b3 = bp[3 * BP];
+          b[ni][0] = bp[0];
+          b[ni][1] = bp[BP];
+          b[ni][2] = bp[2 * BP];
+          b[ni][3] = bp[3 * BP];
         } else {
-          const float4 b = *(const float4 *)&Bt[(nb * 16 + r16) * PG_AP + j + 4 * g];
-          b0 = b.x;
-          b1 = b.y;
-          b2 = b.z;
-          b3 = b.w;
+          const float4 v = *(const float4 *)&Bt[(nb * 16 + r16) * PG_AP + j + 4 * g];
+          b[ni][0] = v.x;
+          b[ni][1] = v.y;
+          b[ni][2] = v.z;
+          b[ni][3] = v.w;
         }
+      }
+      // reduction step outermost: consecutive MFMAs hit different accumulators (a dependent
+      // v_mfma_f32_16x16x4_f32 chain issues every 40 cycles instead of 32)
+      // No per-block guards in the hot loop (they cost a branch per MFMA): rows outside the offset's
+      // segment and columns beyond C_out were staged as zeros, so their blocks just add 0.
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          const int mb = wr * MI + mi;
-          if (mb * 16 >= cur.s1 || mb * 16 + 16 <= cur.s0) continue;  // row block outside this offset's segment
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].x, b0, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].y, b1, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].z, b2, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].w, b3, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s4], b[ni][s4], acc[mi][ni], 0, 0, 0);
         }
       }
     }
@@ -390,7 +397,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict
   __shared__ __attribute__((aligned(16))) float Xl[2 * WG_PS * XP];  // double buffered
   __shared__ __attribute__((aligned(16))) float Yl[2 * WG_PS * YP];
   __shared__ int idxA[WG_MAXCHUNK], idxB[WG_MAXCHUNK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: conditions on it become s_cbranch, not exec masks
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
   const int p_beg = blockIdx.x * chunk;
@@ -529,14 +537,14 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict
         b[ni][2] = bp[2 * YP];
         b[ni][3] = bp[3 * YP];
       }
+      // reduction step outermost (independent accumulators back to back); no per-block guards: channels
+      // beyond C_a / C_b were staged as zeros
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if ((wr * MI + mi) * 16 >= ca) continue;  // uniform per wave
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if ((wc * NI + ni) * 16 >= cb) continue;
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+          for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
         }
       }
@@ -612,12 +620,23 @@ extern "C" int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_fe
     TS_CHECK_LAUNCH("conv_wgrad_scalar");
     return TS_OK;
   }
-  const int cmax = std::max(c_a, c_b), cmin = std::min(c_a, c_b);
+  // tile per dimension: the smallest of {32, 64, 96, 128} that covers min(C, 128) without padding a 96-multiple
+  auto pick = [](int c) { return c <= 32 ? 32 : c <= 64 ? 64 : (c % 96 == 0 ? 96 : 128); };
+  const int tm = pick(c_a), tn = pick(c_b);
 #define TS_WG(TM, TN) launch_wgrad<TM, TN>(a_feat, c_a, b_feat, c_b, nm, nboffs, K, col_a, n_pairs, grad_kernel, stream)
-  if (cmax <= 32) return TS_WG(32, 32);
-  if (c_a <= 32) return TS_WG(32, 128);    // stem: C_in = 4 / 5
-  if (c_b <= 32) return TS_WG(128, 32);
-  if (cmax <= 64 || cmin <= 48) return TS_WG(64, 64);
-  return TS_WG(128, 128);
+#define TS_WG_ROW(TM)                    \
+  switch (tn) {                          \
+    case 32: return TS_WG(TM, 32);       \
+    case 64: return TS_WG(TM, 64);       \
+    case 96: return TS_WG(TM, 96);       \
+    default: return TS_WG(TM, 128);      \
+  }
+  switch (tm) {
+    case 32: TS_WG_ROW(32)
+    case 64: TS_WG_ROW(64)
+    case 96: TS_WG_ROW(96)
+    default: TS_WG_ROW(128)
+  }
+#undef TS_WG_ROW
 #undef TS_WG
 }
