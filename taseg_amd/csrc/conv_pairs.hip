@@ -14,8 +14,6 @@
 // Reference algorithm: torchsparse backend/convolution/convolution_cuda.cu:101-164 runs, per offset, a
 // gather kernel, a cuBLAS GEMM and a read-modify-write scatter kernel (3 K launches, host-synchronised).
 // HBM traffic here: Z written once and read once (2 P C_out s bytes) + Y; the gathers hit L2 / Infinity Cache.
-#include <stdlib.h>
-
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -24,19 +22,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PG_BK 32
 #define PG_AP (PG_BK + 4)
 
-// BN = output columns per workgroup tile, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
-//
-// PERSISTENT + SOFTWARE PIPELINED.  A tile (128 pairs x BN columns) is only C_in/32 steps long, so its
-// prologue (pair indices, offset search, first gather: ~4 us of dependent latency) used to cost as much as its
-// MFMAs.  Now gridDim.x workgroups stride over the tiles and the (tile, offset, C_in-slice) steps form ONE
-// stream: the global loads of the next step - also across a tile boundary - are issued into registers right
-// after the barrier of the current step and land while its MFMAs run; LDS is double buffered (one barrier per
-// step); pair indices are fetched two tiles ahead into a 3-slot LDS ring; the K+1 offset prefix sums sit in LDS.
-#define PG_RING 3
-#define PG_MAXK 64
-
+// BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
+// Software pipeline: the (offset, C_in-slice) steps of a tile are flattened; the global loads of step s+1 are
+// issued into registers right after the barrier of step s and land while its MFMAs run; LDS is double
+// buffered so one barrier per step suffices.
 struct PgStep {
-  int tile;        // flattened tile id (row tile * n_col + col tile); >= n_tiles when exhausted
   int k, s0, s1, c0;
 };
 
@@ -45,7 +35,7 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
                                                         const float *__restrict__ W, int O_total,
                                                         const int2 *__restrict__ nbmaps,
                                                         const int *__restrict__ nboffs, int K, int64_t P, int gcol,
-                                                        float *__restrict__ Z, int n_col, int n_tiles) {
+                                                        float *__restrict__ Z) {
   constexpr int WC = 4 / WR;
   constexpr int MI = (PG_BM / 16) / WR;   // 16-row blocks per wave
   constexpr int NI = (BN / 16) / WC;      // 16-col blocks per wave
@@ -55,79 +45,48 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   constexpr int A_IT = PG_BM * (PG_BK / 4) / 256;   // float4 per thread per A slice (4)
   constexpr int B_IT = (BN * (PG_BK / 4) + 255) / 256;  // float4 per thread per B slice
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Abuf = smem;                          // 2 x [128][36]
-  float *Bbuf = Abuf + 2 * A_FLOATS;           // 2 x (!WT: [32][BN+4] | WT: [BN][36])
-  int *rowidx = (int *)(Bbuf + 2 * B_FLOATS);  // [PG_RING][128] gather rows of the tiles in flight
-  int *offs = rowidx + PG_RING * PG_BM;        // [K+1] copy of nboffs
+  float *Abuf = smem;                         // 2 x [128][36]
+  float *Bbuf = Abuf + 2 * A_FLOATS;          // 2 x (!WT: [32][BN+4] | WT: [BN][36])
+  int *rowidx = (int *)(Bbuf + 2 * B_FLOATS);  // [128]
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: conditions on it become s_cbranch, not exec masks
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave / WC, wc = wave % WC;
-  const int G = gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * PG_BM;
+  const int np = (int)min((int64_t)PG_BM, P - p0);
+  const int o0 = blockIdx.y * BN;
+  const int OT = min(BN, O_total - o0);
+  const int O16 = (OT + 15) & ~15;
 
-  // ---- per-tile geometry (all wave-uniform)
-  auto tile_p0 = [&](int t) -> int64_t { return (int64_t)(t / n_col) * PG_BM; };
-  auto tile_np = [&](int t) -> int { return (int)min((int64_t)PG_BM, P - tile_p0(t)); };
-  auto tile_o0 = [&](int t) -> int { return (t % n_col) * BN; };
-  // gather-row index of pair (tile row base + tid) -> register; stored into ring slot later
-  auto fetch_rowidx = [&](int t) -> int {
+  if (tid < PG_BM) {
     int v = -1;
-    if (t < n_tiles && tid < PG_BM) {
-      const int64_t p = tile_p0(t) + tid;
-      if (p < P) {
-        const int2 pr = nbmaps[p];
-        v = gcol ? pr.y : pr.x;
-      }
+    if (tid < np) {
+      int2 pr = nbmaps[p0 + tid];
+      v = gcol ? pr.y : pr.x;
     }
-    return v;
+    rowidx[tid] = v;
+  }
+  // offsets overlapping this tile (wave-uniform scalar scan of the K+1 prefix sums)
+  int k_lo = 0, k_hi = 0;
+  for (int k = 0; k < K; ++k) {
+    int b = nboffs[k];
+    if ((int64_t)b <= p0) k_lo = k;
+    if ((int64_t)b <= p0 + np - 1) k_hi = k;
+  }
+  auto segment = [&](int k, int &s0, int &s1) {
+    s0 = max((int)((int64_t)nboffs[k] - p0), 0);
+    s1 = min((int)((int64_t)nboffs[k + 1] - p0), np);
   };
-  auto segment = [&](int t, int k, int &s0, int &s1) {
-    const int64_t p0 = tile_p0(t);
-    s0 = max((int)((int64_t)offs[k] - p0), 0);
-    s1 = min((int)((int64_t)offs[k + 1] - p0), tile_np(t));
-  };
-  // first (offset, slice) step of tile t: smallest k whose segment intersects the tile
-  auto first_step = [&](int t) -> PgStep {
-    PgStep st;
-    st.tile = t;
-    st.k = 0;
-    st.s0 = st.s1 = 0;
-    st.c0 = 0;
-    if (t >= n_tiles) return st;
-    for (int k = 0; k < K; ++k) {
-      int s0, s1;
-      segment(t, k, s0, s1);
-      if (s1 > s0) {
-        st.k = k;
-        st.s0 = s0;
-        st.s1 = s1;
-        break;
-      }
-    }
-    st.k = __builtin_amdgcn_readfirstlane(st.k);
-    st.s0 = __builtin_amdgcn_readfirstlane(st.s0);
-    st.s1 = __builtin_amdgcn_readfirstlane(st.s1);
-    return st;
-  };
-  // next step of the stream; crosses into tile t + G when the tile is exhausted
-  auto advance = [&](PgStep st) -> PgStep {
+  auto advance = [&](PgStep st) -> PgStep {  // next (offset, slice); k > k_hi when exhausted
     st.c0 += PG_BK;
     if (st.c0 < R) return st;
     st.c0 = 0;
-    const int np = tile_np(st.tile);
-    for (int k = st.k + 1; k < K; ++k) {
-      if ((int64_t)offs[k] - tile_p0(st.tile) >= np) break;  // later offsets start beyond the tile
-      int s0, s1;
-      segment(st.tile, k, s0, s1);
-      if (s1 > s0) {
-        st.k = __builtin_amdgcn_readfirstlane(k);
-        st.s0 = __builtin_amdgcn_readfirstlane(s0);
-        st.s1 = __builtin_amdgcn_readfirstlane(s1);
-        return st;
-      }
+    for (++st.k; st.k <= k_hi; ++st.k) {
+      segment(st.k, st.s0, st.s1);
+      if (st.s1 > st.s0) break;
     }
-    return first_step(st.tile + G);
+    return st;
   };
 
   f32x4 acc[MI][NI];
@@ -144,16 +103,13 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   // ---- global -> registers for one step
   auto load_regs = [&](const PgStep &st) {
     const int ck = min(PG_BK, R - st.c0);
-    const int *ridx = rowidx + ((st.tile / G) % PG_RING) * PG_BM;
-    const int o0 = tile_o0(st.tile);
-    const int OT = min(BN, O_total - o0);
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int e = tid + it * 256;
       const int rr = e >> 3, c4 = (e & 7) << 2;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rr >= st.s0 && rr < st.s1 && c4 < ck) {
-        const float *src = X + (int64_t)ridx[rr] * R + st.c0 + c4;
+        const float *src = X + (int64_t)rowidx[rr] * R + st.c0 + c4;
         if (x_vec && c4 + 3 < ck) {
           v = *(const float4 *)src;
         } else {
@@ -221,40 +177,20 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
     }
   };
 
-  // ---- workgroup prologue: offsets -> LDS, pair indices of this workgroup's first two tiles -> ring
-  const int t0 = blockIdx.x;
-  for (int k = tid; k <= K; k += 256) offs[k] = nboffs[k];
-  {
-    const int v0 = fetch_rowidx(t0), v1 = fetch_rowidx(t0 + G);
-    if (tid < PG_BM) {
-      rowidx[0 * PG_BM + tid] = v0;
-      rowidx[1 * PG_BM + tid] = v1;
-    }
-  }
-  __syncthreads();
-  PgStep cur = first_step(t0);
-  int ring_pending_tile = -1;  // tile whose indices sit in `ring_reg`, to be written at the next store phase
-  int ring_reg = -1;
-  if (cur.tile < n_tiles) load_regs(cur);
+  PgStep cur;
+  cur.k = k_lo - 1;
+  cur.c0 = R;  // so that advance() finds the first non-empty offset
+  cur.s0 = cur.s1 = 0;
+  __syncthreads();  // rowidx visible
+  cur = advance(cur);
+  load_regs(cur);
   int buf = 0;
-  bool tile_start = true;
-  while (cur.tile < n_tiles) {
+  while (cur.k <= k_hi) {
     float *At = Abuf + buf * A_FLOATS, *Bt = Bbuf + buf * B_FLOATS;
     store_lds(At, Bt);
-    if (ring_pending_tile >= 0) {  // indices fetched one step ago: visible to everyone after the barrier below
-      if (tid < PG_BM) rowidx[((ring_pending_tile / G) % PG_RING) * PG_BM + tid] = ring_reg;
-      ring_pending_tile = -1;
-    }
     __syncthreads();
-    if (tile_start) {  // first step of a tile: fetch the pair indices two tiles ahead (ring slot is free:
-                       // its previous owner, tile - G, finished before this tile started)
-      ring_pending_tile = cur.tile + 2 * G;
-      ring_reg = fetch_rowidx(ring_pending_tile);
-      if (ring_pending_tile >= n_tiles) ring_pending_tile = -1;
-      tile_start = false;
-    }
     const PgStep nxt = advance(cur);
-    if (nxt.tile < n_tiles) load_regs(nxt);  // in flight while this step's MFMAs run
+    if (nxt.k <= k_hi) load_regs(nxt);  // in flight while this step's MFMAs run
     const int ck16 = (min(PG_BK, R - cur.c0) + 15) & ~15;
     // ---- MFMA.  k-slot permutation as in conv.hip: lane group g supplies reduction index 4 g + s in
     // step s, so A (and W^T) fragments are single 16-byte LDS reads.
@@ -286,10 +222,10 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
           b[ni][3] = v.w;
         }
       }
+      // reduction step outermost: consecutive MFMAs hit different accumulators (a dependent
+      // v_mfma_f32_16x16x4_f32 chain issues every 40 cycles instead of 32)
       // No per-block guards in the hot loop (they cost a branch per MFMA): rows outside the offset's
-      // segment and columns beyond C_out were staged as zeros, so their blocks just add 0.  Reduction step
-      // outermost: consecutive MFMAs hit different accumulators (a dependent v_mfma_f32_16x16x4_f32
-      // chain issues every 40 cycles instead of 32).
+      // segment and columns beyond C_out were staged as zeros, so their blocks just add 0.
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
@@ -300,37 +236,28 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
         }
       }
     }
-    if (nxt.tile != cur.tile) {
-      // ---- tile finished: Z rows (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg), then reset
-      const int64_t p0 = tile_p0(cur.tile);
-      const int np = tile_np(cur.tile), o0 = tile_o0(cur.tile);
-      const int OT = min(BN, O_total - o0);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int col = (wc * NI + ni) * 16 + r16;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = (wr * MI + mi) * 16 + 4 * g + q;
-            if (row < np && col < OT) Z[(p0 + row) * O_total + o0 + col] = acc[mi][ni][q];
-          }
-          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      tile_start = true;
-    }
     cur = nxt;
     buf ^= 1;
+  }
+  // ---- Z rows (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = (wc * NI + ni) * 16 + r16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (wr * MI + mi) * 16 + 4 * g + q;
+        if (row < np && col < OT) Z[(p0 + row) * O_total + o0 + col] = acc[mi][ni][q];
+      }
+    }
   }
 }
 
 template <int BN, int WR, bool WT>
 static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
                             int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
-  TS_REQUIRE(K <= PG_MAXK, TS_ERR_UNSUPPORTED, "conv_pair_gemm: kernel volume > %d", PG_MAXK);
-  size_t lds = (size_t)2 * (PG_BM * PG_AP + (WT ? BN * PG_AP : PG_BK * (BN + 4))) * 4 +
-               (size_t)(PG_RING * PG_BM + PG_MAXK + 4) * 4;
+  size_t lds = (size_t)2 * (PG_BM * PG_AP + (WT ? BN * PG_AP : PG_BK * (BN + 4))) * 4 + PG_BM * 4;
   auto kern = pair_gemm_kernel<BN, WR, WT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -338,12 +265,8 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
                  "hipFuncSetAttribute");
     attr_set = true;
   }
-  const int n_col = (int)ts_cdiv(O_total, BN);
-  const int64_t n_tiles = ts_cdiv(P, PG_BM) * n_col;
-  TS_REQUIRE(n_tiles < (1LL << 30), TS_ERR_UNSUPPORTED, "conv_pair_gemm: too many tiles");
-  // persistent grid: two workgroups per CU (LDS-limited residency), fewer if there are fewer tiles
-  const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 2 * 256);
-  kern<<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, n_col, (int)n_tiles);
+  dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
+  pair_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
   TS_CHECK_LAUNCH("conv_pair_gemm");
   return TS_OK;
 }
