@@ -103,14 +103,14 @@ __global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const float *__rest
       float wk = wp[k];
       if (VEC == 4) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0) f = *(const float4 *)(feat + (int64_t)id * c + j);
+        if (id >= 0 && wk != 0.f) f = *(const float4 *)(feat + (int64_t)id * c + j);  // w == 0: nothing to fetch
         acc[0] += wk * f.x;
         acc[1 % VEC] += wk * f.y;
         acc[2 % VEC] += wk * f.z;
         acc[3 % VEC] += wk * f.w;
       } else {
         float f = 0.f;
-        if (id >= 0) f = feat[(int64_t)id * c + j];
+        if (id >= 0 && wk != 0.f) f = feat[(int64_t)id * c + j];
         acc[0] += wk * f;
       }
     }
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_kernel(const float *__rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       int id = ip[k];
-      if (id >= 0 && id < m) atomicAdd(&gfeat[(int64_t)id * c + j], wp[k] * g);
+      // corners with zero weight (points sitting on a voxel centre: 7 of 8) add nothing: skip the atomic
+      if (id >= 0 && id < m && wp[k] != 0.f) atomicAdd(&gfeat[(int64_t)id * c + j], wp[k] * g);
     }
   }
 }

@@ -234,6 +234,51 @@ class _SparseConv(Function):
         return grad_feats, grad_weight, None, None
 
 
+class _PointwiseConv(Function):
+    """1x1x1 convolution (conv.py:135-140: `feats.matmul(weight)`).  Forward and the input gradient are plain
+    dense GEMMs (rocBLAS/hipBLASLt through torch); the weight gradient x^T @ gy is a tall-skinny reduction
+    (N ~ 1e5 rows, C <= 384) for which the library picks a tile-per-output kernel with no split over N
+    (380 us per call here), so it runs on our split-over-rows `ts_conv_wgrad` with an identity rulebook."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, feats, weight, ident):
+        ctx.save_for_backward(feats, weight)
+        ctx.ident = ident
+        return feats.matmul(weight)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        feats, weight = ctx.saved_tensors
+        pairs, offs = ctx.ident
+        grad_out = grad_out.contiguous()
+        grad_feats = grad_out.matmul(weight.t()) if ctx.needs_input_grad[0] else None
+        grad_weight = None
+        if ctx.needs_input_grad[1]:
+            grad_weight = B.conv_wgrad(feats.contiguous(), grad_out, pairs, offs, 1, col_a=0,
+                                       max_pairs=feats.shape[0]).view_as(weight)
+        return grad_feats, grad_weight, None
+
+
+_ident_cache = {}
+
+
+def _identity_rulebook(input: SparseTensor):
+    """(pairs [n,2] = (i, i), nboffs = [0, n]) for the 1x1x1 weight gradient; a handful of row counts per step,
+    kept in a small module-level cache (NOT in input.kmaps, which mirrors the reference's dictionary)."""
+    n, dev = input.feats.shape[0], input.feats.device
+    key = (n, dev)
+    hit = _ident_cache.get(key)
+    if hit is None:
+        if len(_ident_cache) >= 32:
+            _ident_cache.pop(next(iter(_ident_cache)))
+        ar = torch.arange(n, dtype=torch.int32, device=dev)
+        hit = (torch.stack([ar, ar], dim=1).contiguous(), torch.tensor([0, n], dtype=torch.int32, device=dev))
+        _ident_cache[key] = hit
+    return hit
+
+
 def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optional[torch.Tensor] = None,
            stride: Union[int, List[int], Tuple[int, ...]] = 1, dilation: Union[int, Tuple[int, ...]] = 1,
            transposed: bool = False) -> SparseTensor:
@@ -247,7 +292,10 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optiona
 
     if kernel_size == ones and stride == ones and dilation == ones:
         out_stride, out_coords = input.stride, input.coords
-        out_feats = input.feats.matmul(weight)   # plain dense GEMM -> rocBLAS/hipBLASLt
+        if input.feats.is_cuda and input.feats.dtype == torch.float32 and weight.requires_grad:
+            out_feats = _PointwiseConv.apply(input.feats, weight, _identity_rulebook(input))
+        else:
+            out_feats = input.feats.matmul(weight)   # plain dense GEMM -> rocBLAS/hipBLASLt
     elif not transposed:
         out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
         if out_stride in input.cmaps:
