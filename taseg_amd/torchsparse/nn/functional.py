@@ -22,7 +22,7 @@ from ..utils import make_ntuple
 from .utils import get_kernel_offsets
 
 __all__ = ["conv3d", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
-           "spdownsample", "KernelMap", "build_kernel_map"]
+           "spdownsample", "KernelMap", "build_kernel_map", "build_pyramid"]
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = torch.amp.custom_bwd(device_type="cuda")
@@ -154,8 +154,15 @@ class KernelMap:
         self.pos_in = tables["pos_in"]        # [K, n_in]  row of nbmaps per (offset, input voxel) or -1
         self.sizes = sizes
         self._nbmaps = None
-        # number of pairs P: the one host read of a kernel map (sizes the pair-GEMM grid and its Z buffer)
-        self.total = int(self.nboffs[-1].item())
+        self._total = None
+
+    @property
+    def total(self) -> int:
+        """number of pairs P: the one host read of a kernel map (sizes the pair-GEMM grid and its Z buffer);
+        `build_pyramid` fills it for all maps of a forward pass with a single device->host copy"""
+        if self._total is None:
+            self._total = int(self.nboffs[-1].item())
+        return self._total
 
     @property
     def nbmaps(self) -> torch.Tensor:
@@ -232,6 +239,42 @@ class _SparseConv(Function):
             grad_weight = B.conv_wgrad(feats, grad_out, kmap.nbmaps_buf, kmap.nboffs, k,
                                        col_a=1 if transposed else 0, max_pairs=kmap.total)
         return grad_feats, grad_weight, None, None
+
+
+def build_pyramid(x: SparseTensor, num_levels: int = 4, kernel_size: int = 3, down_kernel: int = 2) -> None:
+    """Build, up front, every coordinate set and kernel map a U-Net pass over `x` will ask for: the
+    submanifold (kernel 3, stride 1) map at each of the num_levels + 1 strides and the strided (kernel 2,
+    stride 2) map between consecutive strides - exactly the entries (same keys, same contents) that
+    `conv3d` would create lazily (conv.py:144-177).  Doing it before the first convolution keeps the host
+    reads (coordinate counts, pair totals) at the front of the step, where the device queue is short, instead
+    of stalling the launch stream in the middle of the network; the pair totals of all maps come back in ONE
+    device->host copy."""
+    ks, dk, ones = make_ntuple(kernel_size, 3), make_ntuple(down_kernel, 3), (1, 1, 1)
+    cur = x
+    x.cmaps.setdefault(x.stride, x.coords)
+    coords, stride = x.coords, x.stride
+    maps = []
+    for level in range(num_levels + 1):
+        key = (stride, ks, ones, ones)
+        if key not in x.kmaps:
+            x.kmaps[key] = build_kernel_map(coords, coords, ks, stride, 1)
+        maps.append(x.kmaps[key])
+        if level == num_levels:
+            break
+        nxt = tuple(s * d for s, d in zip(stride, dk))
+        if nxt not in x.cmaps:
+            x.cmaps[nxt] = spdownsample(coords, dk, dk, stride)
+        key = (stride, dk, dk, ones)
+        if key not in x.kmaps:
+            x.kmaps[key] = build_kernel_map(coords, x.cmaps[nxt], dk, stride, 1)
+        maps.append(x.kmaps[key])
+        coords, stride = x.cmaps[nxt], nxt
+    pending = [m for m in maps if m._total is None]
+    if pending:
+        totals = torch.stack([m.nboffs[-1] for m in pending]).tolist()      # one sync for all maps
+        for m, t in zip(pending, totals):
+            m._total = int(t)
+    del cur
 
 
 class _PointwiseConv(Function):
