@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   const bool w_vec = WT ? (((R & 3) == 0) && ((((uintptr_t)W) & 15) == 0))
                         : (((O_total & 3) == 0) && ((((uintptr_t)W) & 15) == 0));
 
-  float4 ra[A_IT], rb[B_IT];
+  float4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];  // two register stages: loads run two steps ahead
   // ---- global -> registers for one step
-  auto load_regs = [&](const PgStep &st) {
+  auto load_regs = [&](const PgStep &st, float4 (&ra)[A_IT], float4 (&rb)[B_IT]) {
     const int ck = min(PG_BK, R - st.c0);
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
     }
   };
   // ---- registers -> LDS buffer
-  auto store_lds = [&](float *At, float *Bt) {
+  auto store_lds = [&](float *At, float *Bt, const float4 (&ra)[A_IT], const float4 (&rb)[B_IT]) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int e = tid + it * 256;
@@ -177,23 +177,9 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
     }
   };
 
-  PgStep cur;
-  cur.k = k_lo - 1;
-  cur.c0 = R;  // so that advance() finds the first non-empty offset
-  cur.s0 = cur.s1 = 0;
-  __syncthreads();  // rowidx visible
-  cur = advance(cur);
-  load_regs(cur);
-  int buf = 0;
-  while (cur.k <= k_hi) {
-    float *At = Abuf + buf * A_FLOATS, *Bt = Bbuf + buf * B_FLOATS;
-    store_lds(At, Bt);
-    __syncthreads();
-    const PgStep nxt = advance(cur);
-    if (nxt.k <= k_hi) load_regs(nxt);  // in flight while this step's MFMAs run
-    const int ck16 = (min(PG_BK, R - cur.c0) + 15) & ~15;
-    // ---- MFMA.  k-slot permutation as in conv.hip: lane group g supplies reduction index 4 g + s in
-    // step s, so A (and W^T) fragments are single 16-byte LDS reads.
+  // ---- MFMA over one staged slice.  k-slot permutation as in conv.hip: lane group g supplies reduction index
+  // 4 g + s in step s, so A (and W^T) fragments are single 16-byte LDS reads.
+  auto mma = [&](const float *At, const float *Bt, int ck16) {
     for (int j = 0; j < ck16; j += 16) {
       float a[MI][4], b[NI][4];
 #pragma unroll
@@ -222,10 +208,10 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
           b[ni][3] = v.w;
         }
       }
-      // reduction step outermost: consecutive MFMAs hit different accumulators (a dependent
-      // v_mfma_f32_16x16x4_f32 chain issues every 40 cycles instead of 32)
       // No per-block guards in the hot loop (they cost a branch per MFMA): rows outside the offset's
-      // segment and columns beyond C_out were staged as zeros, so their blocks just add 0.
+      // segment and columns beyond C_out were staged as zeros, so their blocks just add 0.  Reduction step
+      // outermost: consecutive MFMAs hit different accumulators (a dependent v_mfma_f32_16x16x4_f32 chain
+      // issues every 40 cycles instead of 32).
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
@@ -236,8 +222,42 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
         }
       }
     }
-    cur = nxt;
-    buf ^= 1;
+  };
+
+  // ---- pipeline: the loads of step t are issued at iteration t - 2 (two register stages), written to the LDS
+  // buffer t % 2 at iteration t, consumed by the MFMAs of iteration t.  One barrier per step.
+  PgStep cur;
+  cur.k = k_lo - 1;
+  cur.c0 = R;  // so that advance() finds the first non-empty offset
+  cur.s0 = cur.s1 = 0;
+  __syncthreads();  // rowidx visible
+  cur = advance(cur);
+  PgStep nxt = advance(cur);
+  load_regs(cur, ra0, rb0);
+  if (nxt.k <= k_hi) load_regs(nxt, ra1, rb1);
+  while (true) {
+    {  // even phase: `cur` sits in register stage 0, LDS buffer 0
+      store_lds(Abuf, Bbuf, ra0, rb0);
+      __syncthreads();
+      PgStep nn = nxt;
+      if (nxt.k <= k_hi) nn = advance(nxt);
+      if (nxt.k <= k_hi && nn.k <= k_hi) load_regs(nn, ra0, rb0);
+      mma(Abuf, Bbuf, (min(PG_BK, R - cur.c0) + 15) & ~15);
+      cur = nxt;
+      nxt = nn;
+      if (cur.k > k_hi) break;
+    }
+    {  // odd phase: register stage 1, LDS buffer 1
+      store_lds(Abuf + A_FLOATS, Bbuf + B_FLOATS, ra1, rb1);
+      __syncthreads();
+      PgStep nn = nxt;
+      if (nxt.k <= k_hi) nn = advance(nxt);
+      if (nxt.k <= k_hi && nn.k <= k_hi) load_regs(nn, ra1, rb1);
+      mma(Abuf + A_FLOATS, Bbuf + B_FLOATS, (min(PG_BK, R - cur.c0) + 15) & ~15);
+      cur = nxt;
+      nxt = nn;
+      if (cur.k > k_hi) break;
+    }
   }
   // ---- Z rows (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg)
 #pragma unroll
@@ -574,8 +594,9 @@ template <int TM, int TN>
 static int launch_wgrad(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
                         int col_a, int64_t n_pairs, float *dW, hipStream_t stream) {
   const int tiles = (int)(ts_cdiv(CA, TM) * ts_cdiv(CB, TN));
-  // ~1536 workgroups over the launch, chunks of 128 .. 1024 pairs (multiples of the 32-pair step)
-  int64_t chunk = ts_cdiv(n_pairs * tiles, 1536);
+  // ~512 workgroups over the launch (one resident round at 2 per CU): every workgroup ends with a TM x TN tile of
+  // float atomics (64 KB at 128 x 128), so chunks must be long - 128 .. 1024 pairs, multiples of the 32-pair step
+  int64_t chunk = ts_cdiv(n_pairs * tiles, 512);
   chunk = std::min<int64_t>(WG_MAXCHUNK, std::max<int64_t>(128, (chunk + WG_PS - 1) / WG_PS * WG_PS));
   dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
   wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
