@@ -117,3 +117,172 @@ extern "C" int ts_bn_finalize(const double *sums, const double *total_dev, doubl
   TS_CHECK_LAUNCH("ts_bn_finalize");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Fused BatchNorm-apply (+ residual add) (+ ReLU) and its backward: one pass each instead of
+// batch_norm_elemt -> add -> relu (forward) and relu-backward -> reduce -> batch_norm_backward_elemt (backward).
+//   forward   out = act((x - mean) * invstd * w + b [+ res])
+//   backward  g = gout * (out > 0)          (act = relu; the mask is recovered from the saved output)
+//             sums[0] = sum g, sums[1] = sum g (x - mean)                            (ts_bn_act_backward_reduce)
+//             gx = (g - sums[0]/N - (x - mean) invstd^2 sums[1]/N) invstd w ,  gres = g   (ts_bn_act_backward)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float4 *__restrict__ X, const float4 *__restrict__ RES,
+                                                         const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd,
+                                                         const float *__restrict__ w, const float *__restrict__ b,
+                                                         int64_t total4, int cq, int relu, float4 *__restrict__ OUT) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total4; e += step) {
+    const int q = (int)(e % cq) * 4;
+    const float4 x = X[e];
+    const float4 m = *(const float4 *)(mean + q), s = *(const float4 *)(invstd + q);
+    const float4 ww = *(const float4 *)(w + q), bb = *(const float4 *)(b + q);
+    float4 y;
+    y.x = (x.x - m.x) * s.x * ww.x + bb.x;
+    y.y = (x.y - m.y) * s.y * ww.y + bb.y;
+    y.z = (x.z - m.z) * s.z * ww.z + bb.z;
+    y.w = (x.w - m.w) * s.w * ww.w + bb.w;
+    if (RES) {
+      const float4 r = RES[e];
+      y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    }
+    if (relu) {
+      y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+    }
+    OUT[e] = y;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float *__restrict__ GOUT,
+                                                                const float *__restrict__ OUT,
+                                                                const float *__restrict__ X,
+                                                                const float *__restrict__ mean, int64_t n, int c,
+                                                                double *__restrict__ sums) {
+  __shared__ float red[2][256 * 4];
+  const int cq = c >> 2, rpp = 256 / cq;
+  const int tid = threadIdx.x, ty = tid / cq, tx = tid - ty * cq;
+  const bool active = ty < rpp;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0;
+  if (active) mu = *(const float4 *)(mean + 4 * tx);
+  const int64_t r_beg = (int64_t)blockIdx.x * BN_ROWS_PER_WG, r_end = min(n, r_beg + BN_ROWS_PER_WG);
+  if (active) {
+#pragma unroll 4
+    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
+      const float4 x = *(const float4 *)(X + r * c + 4 * tx);
+      float4 d = *(const float4 *)(GOUT + r * c + 4 * tx);
+      if (OUT) {
+        const float4 o = *(const float4 *)(OUT + r * c + 4 * tx);
+        d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
+        d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+      }
+      s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
+      s1.x += d.x * (x.x - mu.x); s1.y += d.y * (x.y - mu.y);
+      s1.z += d.z * (x.z - mu.z); s1.w += d.w * (x.w - mu.w);
+    }
+  }
+  *(float4 *)&red[0][tid * 4] = s0;
+  *(float4 *)&red[1][tid * 4] = s1;
+  __syncthreads();
+  for (int ch = tid; ch < c; ch += 256) {
+    const int q = ch >> 2, l = ch & 3;
+    float a = 0.f, bsum = 0.f;
+    for (int y = 0; y < rpp; ++y) {
+      a += red[0][(y * cq + q) * 4 + l];
+      bsum += red[1][(y * cq + q) * 4 + l];
+    }
+    atomicAdd(&sums[ch], (double)a);
+    atomicAdd(&sums[c + ch], (double)bsum);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float4 *__restrict__ GOUT, const float4 *__restrict__ OUT,
+                                                         const float4 *__restrict__ X, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd,
+                                                         const float *__restrict__ w, const double *__restrict__ sums,
+                                                         const double *__restrict__ total_dev, double total_host,
+                                                         int64_t total4, int c, float4 *__restrict__ GX,
+                                                         float4 *__restrict__ GRES) {
+  const int cq = c >> 2;
+  const double total = total_dev ? *total_dev : total_host;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total4; e += step) {
+    const int q = (int)(e % cq) * 4;
+    float4 g = GOUT[e];
+    if (OUT) {
+      const float4 o = OUT[e];
+      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+      g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    if (GRES) GRES[e] = g;
+    const float4 x = X[e];
+    const float4 m = *(const float4 *)(mean + q), s = *(const float4 *)(invstd + q), ww = *(const float4 *)(w + q);
+    float gx[4];
+    const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w}, mv[4] = {m.x, m.y, m.z, m.w},
+                sv[4] = {s.x, s.y, s.z, s.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const float mdy = (float)(sums[q + l] / total);
+      const float k2 = (float)(sums[c + q + l] / total) * sv[l] * sv[l];
+      gx[l] = (gv[l] - mdy - (xv[l] - mv[l]) * k2) * sv[l] * wv[l];
+    }
+    GX[e] = make_float4(gx[0], gx[1], gx[2], gx[3]);
+  }
+}
+
+static bool bn_aligned(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int ts_bn_act_forward(const float *x, const float *residual, const float *mean, const float *invstd,
+                                 const float *weight, const float *bias, int64_t n, int32_t c, int32_t relu, float *out,
+                                 ts_stream_t stream) {
+  TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0, TS_ERR_UNSUPPORTED, "ts_bn_act_forward: C must be a multiple of 4");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(x && mean && invstd && weight && bias && out, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_forward: null pointer");
+  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && bn_aligned(mean) && bn_aligned(invstd) && bn_aligned(weight) &&
+                 bn_aligned(bias) && (!residual || bn_aligned(residual)),
+             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_forward: pointers must be 16-byte aligned");
+  const int64_t total4 = n * (c / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
+  bn_act_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd,
+                                                           weight, bias, total4, c / 4, relu, (float4 *)out);
+  TS_CHECK_LAUNCH("ts_bn_act_forward");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_act_backward_reduce(const float *grad_out, const float *out, const float *x, const float *mean,
+                                         int64_t n, int32_t c, double *sums, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_bn_act_backward_reduce: bad C");
+  TS_REQUIRE(sums, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: null sums");
+  TS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream), "bn memset");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(grad_out && x && mean, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: null pointer");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(mean) && (!out || bn_aligned(out)),
+             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: pointers must be 16-byte aligned");
+  bn_act_bwd_reduce_kernel<<<(unsigned)ts_cdiv(n, BN_ROWS_PER_WG), 256, 0, stream>>>(grad_out, out, x, mean, n, c, sums);
+  TS_CHECK_LAUNCH("ts_bn_act_backward_reduce");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_act_backward(const float *grad_out, const float *out, const float *x, const float *mean,
+                                  const float *invstd, const float *weight, const double *sums, const double *total_dev,
+                                  double total_host, int64_t n, int32_t c, float *grad_x, float *grad_residual,
+                                  ts_stream_t stream) {
+  TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0, TS_ERR_UNSUPPORTED, "ts_bn_act_backward: C must be a multiple of 4");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(grad_out && x && mean && invstd && weight && sums && grad_x, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_backward: null pointer");
+  TS_REQUIRE(total_dev || total_host > 0.0, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward: empty batch");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) && (!out || bn_aligned(out)) &&
+                 (!grad_residual || bn_aligned(grad_residual)) && bn_aligned(mean) && bn_aligned(invstd) &&
+                 bn_aligned(weight),
+             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward: pointers must be 16-byte aligned");
+  const int64_t total4 = n * (c / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
+  bn_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_out, (const float4 *)out,
+                                                           (const float4 *)x, mean, invstd, weight, sums, total_dev,
+                                                           total_host, total4, c, (float4 *)grad_x,
+                                                           (float4 *)grad_residual);
+  TS_CHECK_LAUNCH("ts_bn_act_backward");
+  return TS_OK;
+}

@@ -44,7 +44,7 @@ class BasicConvolutionBlock(nn.Module):
         )
 
     def forward(self, x):
-        return self.net(x)
+        return spnn.bn_act(self.net[1], self.net[0](x), relu=True)      # conv -> fused BN + ReLU
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -59,7 +59,7 @@ class BasicDeconvolutionBlock(nn.Module):
         )
 
     def forward(self, x):
-        return self.net(x)
+        return spnn.bn_act(self.net[1], self.net[0](x), relu=True)
 
 
 def _shortcut(inc, outc, stride, if_dist):
@@ -85,7 +85,11 @@ class ResidualBlock(nn.Module):
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):
-        return self.relu(self.net(x) + self.downsample(x))
+        # relu(net(x) + downsample(x)) with the BN / add / ReLU tails fused (same module parameters / buffers)
+        h = spnn.bn_act(self.net[1], self.net[0](x), relu=True)
+        y = self.net[3](h)
+        shortcut = x if isinstance(self.downsample, nn.Identity) else self.downsample(x)
+        return spnn.bn_act(self.net[4], y, relu=True, residual=shortcut)
 
 
 class Bottleneck(nn.Module):
@@ -222,7 +226,8 @@ class MinkUNetBackbone(BaseSegmentor):
         # all coordinate sets / kernel maps of the pass, built before the first convolution (same cache
         # entries conv3d would create lazily; keeps host reads out of the middle of the launch stream)
         spF.build_pyramid(x0, num_levels=4)
-        x0 = self.stem(x0)
+        x0 = spnn.bn_act(self.stem[1], self.stem[0](x0), relu=True)          # stem = 2 x (conv, BN, ReLU)
+        x0 = spnn.bn_act(self.stem[4], self.stem[3](x0), relu=True)
         z0 = voxel_to_point(x0, z, nearest=False)
 
         x1 = self.stage1(x0)

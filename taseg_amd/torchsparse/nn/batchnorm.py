@@ -59,6 +59,65 @@ class _BatchNormTrain(Function):
         return grad_x, grad_weight, grad_bias, None, None, None, None, None
 
 
+class _BatchNormActTrain(Function):
+    """act(BN(x) [+ residual]) in training mode, forward and backward each as (one reduction + one elementwise
+    pass) over [N, C]: ts_bn_stats -> ts_bn_finalize -> ts_bn_act_forward, and
+    ts_bn_act_backward_reduce -> ts_bn_act_backward (the ReLU mask is taken from the saved output)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group):
+        x = x.contiguous()
+        n, c = x.shape
+        sums = B.bn_stats(x)
+        total_dev = None
+        if group is not None:
+            pack = torch.cat([sums.view(-1), torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
+            dist.all_reduce(pack, group=group)
+            sums, total_dev = pack[:2 * c].view(2, c), pack[2 * c:]
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        lib = L.load()
+        L.check(lib.ts_bn_finalize(L.ptr(sums), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
+                                   L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.stream()),
+                "ts_bn_finalize")
+        if residual is not None:
+            residual = residual.contiguous()
+        out = torch.empty_like(x)
+        L.check(lib.ts_bn_act_forward(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd), L.ptr(weight),
+                                      L.ptr(bias), n, c, 1 if relu else 0, L.ptr(out), L.stream()),
+                "ts_bn_act_forward")
+        ctx.save_for_backward(x, weight, mean, invstd, out if relu else None)
+        ctx.group, ctx.total_dev, ctx.has_res = group, total_dev, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, mean, invstd, out = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        n, c = x.shape
+        lib = L.load()
+        sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
+        L.check(lib.ts_bn_act_backward_reduce(L.ptr(grad_out), L.ptr(out), L.ptr(x), L.ptr(mean), n, c, L.ptr(sums),
+                                              L.stream()), "ts_bn_act_backward_reduce")
+        local = sums.float()
+        grad_weight = local[1] * invstd if ctx.needs_input_grad[2] else None
+        grad_bias = local[0] if ctx.needs_input_grad[3] else None
+        if ctx.group is not None:
+            dist.all_reduce(sums, group=ctx.group)
+        grad_x = torch.empty_like(x)
+        grad_res = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(out), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                       L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
+                                       L.ptr(grad_x), L.ptr(grad_res), L.stream()), "ts_bn_act_backward")
+        return grad_x, grad_res, grad_weight, grad_bias, None, None, None, None, None, None
+
+
+def batch_norm_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=True, residual=None,
+                         group=None):
+    """act(BN(x) [+ residual]) with batch statistics, fused elementwise passes."""
+    return _BatchNormActTrain.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group)
+
+
 def batch_norm_train(x, weight, bias, running_mean, running_var, momentum, eps, group=None):
     """y = BN(x) with batch statistics (over all ranks of `group` when given); updates the running buffers."""
     return _BatchNormTrain.apply(x, weight, bias, running_mean, running_var, momentum, eps, group)

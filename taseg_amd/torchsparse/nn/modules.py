@@ -9,7 +9,7 @@ from ..utils.misc import make_ntuple
 from . import functional as F
 from .utils import fapply
 
-__all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU"]
+__all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act"]
 
 
 class Conv3d(nn.Module):
@@ -70,6 +70,38 @@ def _bn_forward(mod, feats, torch_forward, group=None):
         rv = mod.running_var if mod.track_running_stats else None
         return batch_norm_train(feats, mod.weight, mod.bias, rm, rv, mod.momentum, mod.eps, group)
     return torch_forward(feats)
+
+
+def _sync_group(mod):
+    import torch.distributed as dist
+    if isinstance(mod, nn.SyncBatchNorm) and mod.training and dist.is_available() and dist.is_initialized() \
+            and dist.get_world_size() > 1:
+        return mod.process_group if mod.process_group is not None else dist.group.WORLD
+    return None
+
+
+def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None) -> SparseTensor:
+    """relu(BN(input) [+ residual]) for a BatchNorm / SyncBatchNorm module `mod` - the tail of every conv block of
+    the MinkUNet family (minkunet.py:42-51, 117-129).  Training mode runs as two fused passes on the HIP
+    kernels; otherwise the stock modules are chained exactly like the reference does."""
+    from .batchnorm import batch_norm_act_train, fast_path_ok
+    feats = input.feats
+    res = None if residual is None else residual.feats
+    if mod.training and mod.momentum is not None and mod.affine and fast_path_ok(feats) \
+            and (res is None or (res.shape == feats.shape and res.dtype == feats.dtype)):
+        if mod.track_running_stats and mod.num_batches_tracked is not None:
+            mod.num_batches_tracked.add_(1)
+        rm = mod.running_mean if mod.track_running_stats else None
+        rv = mod.running_var if mod.track_running_stats else None
+        out = batch_norm_act_train(feats, mod.weight, mod.bias, rm, rv, mod.momentum, mod.eps, relu=relu,
+                                   residual=res, group=_sync_group(mod))
+        return input._like(out)
+    out = mod(input).feats
+    if res is not None:
+        out = out + res
+    if relu:
+        out = torch.relu(out)
+    return input._like(out)
 
 
 class BatchNorm(nn.BatchNorm1d):

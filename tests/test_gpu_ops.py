@@ -409,3 +409,39 @@ def test_batchnorm_train_matches_torch(n, c):
     # eval mode goes through the stock module
     ours.eval(), ref.eval()
     close(ours(SparseTensor(x, torch.zeros(n, 4, dtype=torch.int32, device=DEV))).F, ref(x), 1e-5)
+
+
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (True, False)])
+def test_fused_bn_act_matches_torch(with_res, relu):
+    """relu(BN(x) + residual) fused (2 passes fwd, 2 passes bwd) == the chained torch modules"""
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse import nn as spnn
+    torch.manual_seed(3)
+    n, c = 9001, 64
+    co = torch.zeros(n, 4, dtype=torch.int32, device=DEV)
+    x = torch.randn(n, c, device=DEV) * 1.5 + 0.3
+    r = torch.randn(n, c, device=DEV)
+    ref = torch.nn.BatchNorm1d(c).to(DEV).train()
+    ours = spnn.BatchNorm(c).to(DEV).train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+        ours.weight.copy_(ref.weight)
+        ours.bias.copy_(ref.bias)
+    xa, xb, ra, rb = (t.clone().requires_grad_() for t in (x, x, r, r))
+    ya = ref(xa)
+    if with_res:
+        ya = ya + ra
+    if relu:
+        ya = torch.relu(ya)
+    yb = spnn.bn_act(ours, SparseTensor(xb, co), relu=relu, residual=SparseTensor(rb, co) if with_res else None).F
+    close(yb, ya, 2e-5)
+    gy = torch.randn_like(ya)
+    ya.backward(gy)
+    yb.backward(gy)
+    close(xb.grad, xa.grad, 5e-5)
+    if with_res:
+        close(rb.grad, ra.grad, 1e-6)
+    close(ours.weight.grad, ref.weight.grad, 5e-5)
+    close(ours.bias.grad, ref.bias.grad, 5e-5)
+    close(ours.running_var, ref.running_var, 1e-5)
