@@ -241,17 +241,18 @@ int ts_bn_finalize(const double *sums, const double *total_dev, double total_hos
 
 /* Fused elementwise halves of a conv block (the reference chains BatchNorm -> [+ shortcut] -> ReLU as separate
  * modules, minkunet.py:42-51,117-129: one full pass over [n, c] each):
- *   ts_bn_act_forward          out = act((x - mean) * invstd * weight + bias [+ residual]),  act = relu if relu != 0
- *   ts_bn_act_backward_reduce  g = grad_out * (out > 0) (all ones if out == NULL);
+ *   ts_bn_act_forward          out = act((x - mean) * invstd * weight + bias [+ residual]),  act = relu if relu != 0;
+ *                              mask (optional, uint8 [n * c / 4]) gets the 4 sign bits of every float4 of `out`
+ *   ts_bn_act_backward_reduce  g = grad_out * (out > 0) through that mask (all ones if mask == NULL);
  *                              sums[0] = sum_n g, sums[1] = sum_n g (x - mean)        (double [2, c], zeroed here)
  *   ts_bn_act_backward         grad_x = (g - sums[0]/N - (x - mean) invstd^2 sums[1]/N) invstd weight,
  *                              grad_residual = g (optional); N = *total_dev if non-NULL else total_host. */
 int ts_bn_act_forward(const float *x, const float *residual, const float *mean, const float *invstd,
                       const float *weight, const float *bias, int64_t n, int32_t c, int32_t relu,
-                      float *out, ts_stream_t stream);
-int ts_bn_act_backward_reduce(const float *grad_out, const float *out, const float *x, const float *mean,
+                      float *out, uint8_t *mask, ts_stream_t stream);
+int ts_bn_act_backward_reduce(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
                               int64_t n, int32_t c, double *sums, ts_stream_t stream);
-int ts_bn_act_backward(const float *grad_out, const float *out, const float *x, const float *mean,
+int ts_bn_act_backward(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
                        const float *invstd, const float *weight, const double *sums,
                        const double *total_dev, double total_host, int64_t n, int32_t c, float *grad_x,
                        float *grad_residual, ts_stream_t stream);

@@ -50,7 +50,7 @@ SIGNATURES = {
     "ts_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "ts_bn_backward_reduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "ts_bn_finalize": (_i32, [_vp, _vp, _c.c_double, _i32, _c.c_float, _c.c_float, _vp, _vp, _vp, _vp, _vp]),
-    "ts_bn_act_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "ts_bn_act_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "ts_bn_act_backward_reduce": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "ts_bn_act_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_double, _i64, _i32, _vp, _vp, _vp]),
     "ts_set_conv_impl": (None, [_i32]),

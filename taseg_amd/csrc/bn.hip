@@ -122,14 +122,15 @@ extern "C" int ts_bn_finalize(const double *sums, const double *total_dev, doubl
 // Fused BatchNorm-apply (+ residual add) (+ ReLU) and its backward: one pass each instead of
 // batch_norm_elemt -> add -> relu (forward) and relu-backward -> reduce -> batch_norm_backward_elemt (backward).
 //   forward   out = act((x - mean) * invstd * w + b [+ res])
-//   backward  g = gout * (out > 0)          (act = relu; the mask is recovered from the saved output)
+//   backward  g = gout * (out > 0)          (act = relu; the forward stores a 4-bit sign mask per float4)
 //             sums[0] = sum g, sums[1] = sum g (x - mean)                            (ts_bn_act_backward_reduce)
 //             gx = (g - sums[0]/N - (x - mean) invstd^2 sums[1]/N) invstd w ,  gres = g   (ts_bn_act_backward)
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float4 *__restrict__ X, const float4 *__restrict__ RES,
                                                          const float *__restrict__ mean,
                                                          const float *__restrict__ invstd,
                                                          const float *__restrict__ w, const float *__restrict__ b,
-                                                         int64_t total4, int cq, int relu, float4 *__restrict__ OUT) {
+                                                         int64_t total4, int cq, int relu, float4 *__restrict__ OUT,
+                                                         unsigned char *__restrict__ MASK) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (; e < total4; e += step) {
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float4 *__restric
       y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
     }
     if (relu) {
+      // 4-bit sign mask per float4 (1 byte per 16 bytes of activations): all the backward needs of `out`
+      if (MASK) MASK[e] = (unsigned char)((y.x > 0.f) | ((y.y > 0.f) << 1) | ((y.z > 0.f) << 2) | ((y.w > 0.f) << 3));
       y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
     }
     OUT[e] = y;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float4 *__restric
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float *__restrict__ GOUT,
-                                                                const float *__restrict__ OUT,
+                                                                const unsigned char *__restrict__ MASK,
                                                                 const float *__restrict__ X,
                                                                 const float *__restrict__ mean, int64_t n, int c,
                                                                 double *__restrict__ sums) {
@@ -170,10 +173,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float *__r
     for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
       const float4 x = *(const float4 *)(X + r * c + 4 * tx);
       float4 d = *(const float4 *)(GOUT + r * c + 4 * tx);
-      if (OUT) {
-        const float4 o = *(const float4 *)(OUT + r * c + 4 * tx);
-        d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
-        d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+      if (MASK) {
+        const unsigned mk = MASK[r * cq + tx];
+        d.x = (mk & 1) ? d.x : 0.f; d.y = (mk & 2) ? d.y : 0.f;
+        d.z = (mk & 4) ? d.z : 0.f; d.w = (mk & 8) ? d.w : 0.f;
       }
       s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
       s1.x += d.x * (x.x - mu.x); s1.y += d.y * (x.y - mu.y);
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float *__r
   }
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float4 *__restrict__ GOUT, const float4 *__restrict__ OUT,
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float4 *__restrict__ GOUT,
+                                                         const unsigned char *__restrict__ MASK,
                                                          const float4 *__restrict__ X, const float *__restrict__ mean,
                                                          const float *__restrict__ invstd,
                                                          const float *__restrict__ w, const double *__restrict__ sums,
@@ -209,10 +213,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float4 *__restric
   for (; e < total4; e += step) {
     const int q = (int)(e % cq) * 4;
     float4 g = GOUT[e];
-    if (OUT) {
-      const float4 o = OUT[e];
-      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
-      g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    if (MASK) {
+      const unsigned mk = MASK[e];
+      g.x = (mk & 1) ? g.x : 0.f; g.y = (mk & 2) ? g.y : 0.f;
+      g.z = (mk & 4) ? g.z : 0.f; g.w = (mk & 8) ? g.w : 0.f;
     }
     if (GRES) GRES[e] = g;
     const float4 x = X[e];
@@ -234,7 +238,7 @@ static bool bn_aligned(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int ts_bn_act_forward(const float *x, const float *residual, const float *mean, const float *invstd,
                                  const float *weight, const float *bias, int64_t n, int32_t c, int32_t relu, float *out,
-                                 ts_stream_t stream) {
+                                 uint8_t *mask, ts_stream_t stream) {
   TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0, TS_ERR_UNSUPPORTED, "ts_bn_act_forward: C must be a multiple of 4");
   if (n == 0) return TS_OK;
   TS_REQUIRE(x && mean && invstd && weight && bias && out, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_forward: null pointer");
@@ -244,12 +248,12 @@ extern "C" int ts_bn_act_forward(const float *x, const float *residual, const fl
   const int64_t total4 = n * (c / 4);
   const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
   bn_act_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd,
-                                                           weight, bias, total4, c / 4, relu, (float4 *)out);
+                                                           weight, bias, total4, c / 4, relu, (float4 *)out, mask);
   TS_CHECK_LAUNCH("ts_bn_act_forward");
   return TS_OK;
 }
 
-extern "C" int ts_bn_act_backward_reduce(const float *grad_out, const float *out, const float *x, const float *mean,
+extern "C" int ts_bn_act_backward_reduce(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
                                          int64_t n, int32_t c, double *sums, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_bn_act_backward_reduce: bad C");
@@ -257,14 +261,14 @@ extern "C" int ts_bn_act_backward_reduce(const float *grad_out, const float *out
   TS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream), "bn memset");
   if (n == 0) return TS_OK;
   TS_REQUIRE(grad_out && x && mean, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: null pointer");
-  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(mean) && (!out || bn_aligned(out)),
-             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: pointers must be 16-byte aligned");
-  bn_act_bwd_reduce_kernel<<<(unsigned)ts_cdiv(n, BN_ROWS_PER_WG), 256, 0, stream>>>(grad_out, out, x, mean, n, c, sums);
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(mean), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_backward_reduce: pointers must be 16-byte aligned");
+  bn_act_bwd_reduce_kernel<<<(unsigned)ts_cdiv(n, BN_ROWS_PER_WG), 256, 0, stream>>>(grad_out, mask, x, mean, n, c, sums);
   TS_CHECK_LAUNCH("ts_bn_act_backward_reduce");
   return TS_OK;
 }
 
-extern "C" int ts_bn_act_backward(const float *grad_out, const float *out, const float *x, const float *mean,
+extern "C" int ts_bn_act_backward(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
                                   const float *invstd, const float *weight, const double *sums, const double *total_dev,
                                   double total_host, int64_t n, int32_t c, float *grad_x, float *grad_residual,
                                   ts_stream_t stream) {
@@ -273,13 +277,13 @@ extern "C" int ts_bn_act_backward(const float *grad_out, const float *out, const
   TS_REQUIRE(grad_out && x && mean && invstd && weight && sums && grad_x, TS_ERR_INVALID_ARGUMENT,
              "ts_bn_act_backward: null pointer");
   TS_REQUIRE(total_dev || total_host > 0.0, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward: empty batch");
-  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) && (!out || bn_aligned(out)) &&
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) &&
                  (!grad_residual || bn_aligned(grad_residual)) && bn_aligned(mean) && bn_aligned(invstd) &&
                  bn_aligned(weight),
              TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward: pointers must be 16-byte aligned");
   const int64_t total4 = n * (c / 4);
   const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
-  bn_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_out, (const float4 *)out,
+  bn_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_out, mask,
                                                            (const float4 *)x, mean, invstd, weight, sums, total_dev,
                                                            total_host, total4, c, (float4 *)grad_x,
                                                            (float4 *)grad_residual);

@@ -62,7 +62,7 @@ class _BatchNormTrain(Function):
 class _BatchNormActTrain(Function):
     """act(BN(x) [+ residual]) in training mode, forward and backward each as (one reduction + one elementwise
     pass) over [N, C]: ts_bn_stats -> ts_bn_finalize -> ts_bn_act_forward, and
-    ts_bn_act_backward_reduce -> ts_bn_act_backward (the ReLU mask is taken from the saved output)."""
+    ts_bn_act_backward_reduce -> ts_bn_act_backward (the ReLU mask is a 4-bit-per-float4 byte array written by the forward)."""
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group):
@@ -83,21 +83,22 @@ class _BatchNormActTrain(Function):
         if residual is not None:
             residual = residual.contiguous()
         out = torch.empty_like(x)
+        mask = torch.empty(n * (c // 4), dtype=torch.uint8, device=x.device) if relu else None
         L.check(lib.ts_bn_act_forward(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd), L.ptr(weight),
-                                      L.ptr(bias), n, c, 1 if relu else 0, L.ptr(out), L.stream()),
+                                      L.ptr(bias), n, c, 1 if relu else 0, L.ptr(out), L.ptr(mask), L.stream()),
                 "ts_bn_act_forward")
-        ctx.save_for_backward(x, weight, mean, invstd, out if relu else None)
+        ctx.save_for_backward(x, weight, mean, invstd, mask)
         ctx.group, ctx.total_dev, ctx.has_res = group, total_dev, residual is not None
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight, mean, invstd, out = ctx.saved_tensors
+        x, weight, mean, invstd, mask = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         n, c = x.shape
         lib = L.load()
         sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
-        L.check(lib.ts_bn_act_backward_reduce(L.ptr(grad_out), L.ptr(out), L.ptr(x), L.ptr(mean), n, c, L.ptr(sums),
+        L.check(lib.ts_bn_act_backward_reduce(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), n, c, L.ptr(sums),
                                               L.stream()), "ts_bn_act_backward_reduce")
         local = sums.float()
         grad_weight = local[1] * invstd if ctx.needs_input_grad[2] else None
@@ -106,7 +107,7 @@ class _BatchNormActTrain(Function):
             dist.all_reduce(sums, group=ctx.group)
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(out), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+        L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                        L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
                                        L.ptr(grad_x), L.ptr(grad_res), L.stream()), "ts_bn_act_backward")
         return grad_x, grad_res, grad_weight, grad_bias, None, None, None, None, None, None
