@@ -23,6 +23,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
 VOXEL = 0.05
+EVENT_EVERY = 4             # per-launch HIP events bracket the conv kernels of every 4th timed step
 
 
 def parse():
@@ -34,6 +35,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=2, help="scans per GPU per step")
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="build batch i's rulebooks at the head of step i on the launch stream instead of "
+                         "during step i-1 on the staging stream")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
     ap.add_argument("--cpu-sector-deg", type=float, default=180.0)
     return ap.parse_args()
 
@@ -210,12 +215,23 @@ def main():
         def make_batch():
             return {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset}
 
+    from taseg_amd.data.stage import DevicePrefetcher
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare)
+
     def step():
+        # one step = stage one batch (rulebooks / index plan; for minkunet_ms also the temporal aggregation and
+        # voxelisation) + forward + loss + backward + clip + SGD.  With the prefetcher the batch staged inside
+        # step i is the one step i+1 trains on (every timed step still stages exactly one batch).
         opt.zero_grad(set_to_none=True)
-        ret, _, _ = net(make_batch())
+        if pf is None:
+            ret, _, _ = net(make_batch())
+        else:
+            ret, _, _ = net(pf.next())
         ret["loss"].mean().backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
+        if pf is not None:
+            pf.prefetch()
         return ret["loss"]
 
     def fence():
@@ -227,13 +243,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    B.profile_begin()
+    if not args.no_kernel_events:
+        B.profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if not args.no_kernel_events:
+            B.profile_pause(i % EVENT_EVERY != 0)      # HIP events around the conv kernels of every 4th timed step
         loss = step()
     fence()
     dt = time.perf_counter() - t0
     records = B.profile_end()
+    profiled_steps = len(range(0, args.steps, EVENT_EVERY))
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -242,7 +262,7 @@ def main():
     value = args.batch * world * args.steps / dt
 
     if rank == 0:
-        prof = summarise_profile(records, args.steps)
+        prof = summarise_profile(records, profiled_steps)
         dom = prof[0] if prof else None
         roofline = None
         if dom:

@@ -301,16 +301,24 @@ def trilinear_map(points, vox_coords, stride):
 
 # Optional per-launch timing (bench.py): HIP events on the launch stream around the conv kernels.
 _prof = None
+_prof_store = None
 
 
 def profile_begin():
+    global _prof, _prof_store
+    _prof = _prof_store = []
+
+
+def profile_pause(paused):
+    """Stop / resume recording without dropping what was collected (bench.py samples every n-th step: two
+    events per launch cost ~5 us of host time each, ~3 ms per step when every launch is bracketed)."""
     global _prof
-    _prof = []
+    _prof = None if paused else _prof_store
 
 
 def profile_end():
-    global _prof
-    out, _prof = _prof, None
+    global _prof, _prof_store
+    out, _prof, _prof_store = _prof_store, None, None
     return out or []
 
 

@@ -20,7 +20,8 @@ import torch
 from .. import backend as B
 from ..torchsparse import SparseTensor
 
-__all__ = ["fuse_multiscan", "voxelize_sample_ms", "voxelize_sample", "collate_batch", "build_multiscan_batch"]
+__all__ = ["fuse_multiscan", "voxelize_sample_ms", "voxelize_sample", "collate_batch", "build_multiscan_batch",
+           "DevicePrefetcher"]
 
 
 def _keep_table(steps: Sequence[int], delta: int, device) -> torch.Tensor:
@@ -130,3 +131,70 @@ def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[
                                         [i - t for i in range(t)], steps)
         samples.append(voxelize_sample_ms(pts[t], lab[t].long(), raw_ms, lab_ms, voxel_size, s.get("name", "")))
     return collate_batch(samples)
+
+
+class DevicePrefetcher:
+    """Double-buffered device-side data stage: the batch of step i+1 (temporal aggregation, voxelisation and
+    the model's index plan - everything that does not depend on parameters) is built on a second HIP stream
+    while the launch stream still executes step i, the role the reference gives its DataLoader workers
+    (tools/train.py builds the loader with workers + pin_memory so batch i+1 is ready when step i ends).
+
+    The stage needs a few host reads (voxel counts, pair totals).  On the launch stream each of them would
+    drain the whole queue of step i first; on the side stream they only wait for the stage's own kernels, so
+    the host keeps running ahead of the device.
+
+        pf = DevicePrefetcher(make_batch, model.prepare)
+        for _ in range(steps):
+            batch = pf.next()          # staged earlier; the current stream waits on its ready-event
+            ... forward / backward / optimizer step on `batch` ...
+            pf.prefetch()              # stage the following batch (optional: next() does it if needed)
+
+    Memory: tensors of a staged batch are allocated on the side stream and consumed on the launch stream, so
+    the prefetcher keeps every batch alive until an event recorded on the launch stream after its step has
+    completed - nothing is returned to the side stream's pool while a kernel of the launch stream may still
+    read it.
+    """
+
+    def __init__(self, make_batch, prepare=None, device=None):
+        self.make_batch, self.prepare = make_batch, prepare
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._staged = None          # (batch, ready_event)
+        self._inflight = []          # [(batch, done_event)] handed out, possibly still read by the launch stream
+        self._current = None
+
+    def _retire(self):
+        if self._current is not None:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self._inflight.append((self._current, done))
+            self._current = None
+        self._inflight = [(b, e) for b, e in self._inflight if not e.query()]
+
+    def prefetch(self):
+        if self._staged is not None:
+            return
+        self._retire()
+        if not self._inflight:
+            # first use (or idle device): inputs created on the launch stream must be complete
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            batch = self.make_batch()
+            if self.prepare is not None:
+                self.prepare(batch)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        self._staged = (batch, ready)
+
+    def next(self):
+        self.prefetch()
+        batch, ready = self._staged
+        self._staged = None
+        torch.cuda.current_stream(self.device).wait_event(ready)
+        self._current = batch
+        return batch
+
+    def close(self):
+        self._retire()
+        torch.cuda.synchronize(self.device)
+        self._inflight, self._staged = [], None

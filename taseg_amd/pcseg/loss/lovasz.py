@@ -10,16 +10,27 @@ import torch
 __all__ = ["lovasz_softmax", "lovasz_softmax_flat"]
 
 
-def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, classes="present") -> torch.Tensor:
-    """probas [P, C] class probabilities, labels [P]; mean over classes of dot(sorted errors, Lovasz grad)."""
+def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, classes="present", valid=None) -> torch.Tensor:
+    """probas [P, C] class probabilities, labels [P]; mean over classes of dot(sorted errors, Lovasz grad).
+
+    `valid` (bool [P], optional) marks the rows that count.  Dropping the other rows (`probas[valid]`, what
+    lovasz_losses.py:222-226 does) needs their number on the host - a device->host read that drains the whole
+    forward pass from the launch queue right before backward.  Giving those rows zero foreground and zero error
+    instead yields the same value: zero errors sort behind every positive error, where the Lovasz gradient is
+    multiplied by 0, and the prefix sums in front of them (exact small integers in fp32) do not change."""
     if probas.numel() == 0:
         return probas * 0.0
     num_classes = probas.size(1)
     cls = torch.arange(num_classes, device=probas.device)
     # class-major [C, P] layout: sort / cumsum run along the contiguous last dimension (a cumsum over
     # dim 0 of a [P, C] tensor falls into a slow outer-dim scan kernel: 34 ms per call at P = 180k)
-    fg = (labels.view(1, -1) == cls.view(-1, 1)).to(probas.dtype)          # [C, P] one-hot foreground
+    hit = labels.view(1, -1) == cls.view(-1, 1)
+    if valid is not None:
+        hit = hit & valid.view(1, -1)
+    fg = hit.to(probas.dtype)                                              # [C, P] one-hot foreground
     errors = (fg - probas.t()).abs()
+    if valid is not None:
+        errors = errors * valid.view(1, -1).to(probas.dtype)
     errors_sorted, perm = torch.sort(errors, dim=1, descending=True)
     fg_sorted = torch.gather(fg, 1, perm)
     # gradient of the Lovasz extension of the Jaccard loss w.r.t. sorted errors (Alg. 1)
@@ -49,7 +60,5 @@ def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=No
     if probas.dim() != 2:
         raise ValueError("lovasz_softmax here expects point-wise [P, C] probabilities")
     labels = labels.view(-1)
-    if ignore is not None:
-        valid = labels != ignore
-        probas, labels = probas[valid], labels[valid]
-    return lovasz_softmax_flat(probas, labels, classes=classes)
+    valid = (labels != ignore) if ignore is not None else None
+    return lovasz_softmax_flat(probas, labels, classes=classes, valid=valid)

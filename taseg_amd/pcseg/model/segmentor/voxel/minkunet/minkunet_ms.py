@@ -6,18 +6,23 @@ pose-aligned history scans + time flag, built by the data stage) is already voxe
 unlike `MinkUNet` there is no device re-voxelisation: the stem consumes it directly
 (minkunet_ms.py:386-392).  Same parameters / state_dict as `MinkUNet`.
 """
-from taseg_amd.torchsparse import PointTensor
 from .minkunet import MinkUNetBackbone
 
 __all__ = ["MinkUNetMs"]
 
 
 class MinkUNetMs(MinkUNetBackbone):
+    def prepare(self, batch_dict):
+        x_ms = batch_dict["lidar_ms"]
+        plan = self._index_plan(x_ms.C, x_ms.C.float())
+        batch_dict["_plan"] = plan
+        return plan
+
     def forward(self, batch_dict, return_logit=False, return_tta=False):
         x_ms = batch_dict["lidar_ms"]
         x_ms.F = x_ms.F[:, :self.in_feature_dim]
-        z_ms = PointTensor(x_ms.F, x_ms.C.float())
-        out_ms = self._unet(x_ms, z_ms)
+        plan = batch_dict.get("_plan") or self.prepare(batch_dict)
+        out_ms = self._unet(x_ms.F, x_ms.F, plan)
 
         if self.training:
             target_ms = batch_dict["targets_ms"].F.long().cuda(non_blocking=True)

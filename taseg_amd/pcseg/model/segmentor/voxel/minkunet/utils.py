@@ -13,28 +13,33 @@ from taseg_amd import backend as B
 from taseg_amd.torchsparse import PointTensor, SparseTensor
 from taseg_amd.torchsparse.nn import functional as F
 
-__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "voxel_to_point_fov"]
+__all__ = ["initial_voxelize", "voxelize_index", "point_to_voxel", "voxel_to_point", "voxel_to_point_fov"]
 
 
-def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
-    """utils.py:11-36.  Re-voxelise the points of `z` on device: stride-1 voxels are ordered by
-    ASCENDING COORDINATE HASH (torch.unique of the FNV hashes), features / coordinates are
-    mean-pooled, and `z` gets the point->voxel map cached for later `point_to_voxel` calls."""
+def voxelize_index(z: PointTensor, init_res, after_res):
+    """The index half of `initial_voxelize` (utils.py:11-26): stride-1 voxel coordinates ordered by ascending
+    coordinate hash, the point->voxel map and the per-voxel point counts.  Touches no features, so a data
+    stage can run it ahead of the forward pass.  Rescales `z.C` in place like the reference (:35)."""
     scaled = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
     cell = torch.floor(scaled)
     pc_hash = F.sphash(cell.int())
     sparse_hash, inverse = B.unique_i64(pc_hash)
     idx_query = inverse.long()
     counts = F.spcount(inverse, len(sparse_hash))
-
     coords = torch.round(F.spvoxelize(cell, idx_query, counts)).int()
-    feats = F.spvoxelize(z.F, idx_query, counts)
-
-    out = SparseTensor(feats, coords, 1)
-    out.cmaps.setdefault(out.stride, out.coords)
     z.additional_features["idx_query"][1] = idx_query
     z.additional_features["counts"][1] = counts
     z.C = scaled
+    return coords, idx_query, counts
+
+
+def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
+    """utils.py:11-36.  Re-voxelise the points of `z` on device: stride-1 voxels are ordered by
+    ASCENDING COORDINATE HASH (torch.unique of the FNV hashes), features / coordinates are
+    mean-pooled, and `z` gets the point->voxel map cached for later `point_to_voxel` calls."""
+    coords, idx_query, counts = voxelize_index(z, init_res, after_res)
+    out = SparseTensor(F.spvoxelize(z.F, idx_query, counts), coords, 1)
+    out.cmaps.setdefault(out.stride, out.coords)
     return out
 
 
