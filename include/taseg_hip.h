@@ -258,7 +258,8 @@ int ts_bn_act_backward(const float *grad_out, const uint8_t *mask, const float *
                        float *grad_residual, ts_stream_t stream);
 
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
- * 1 = scalar reference kernels (one thread per output element, atomics). */
+ * 1 = scalar reference kernels (one thread per output element, atomics),
+ * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply. */
 void ts_set_conv_impl(int32_t impl);
 
 /* ------------------------------------------------------------------------ */

@@ -242,9 +242,10 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
     return dict(nbr=nbr, nbr_t=nbr_t, nbmaps=nbmaps, nbsizes=nbsizes, nboffs=nboffs, pos_out=pos_out, pos_in=pos_in)
 
 
-def pair_gemm_kernel_name(c_out, weight_transposed=False):
+def pair_gemm_kernel_name(c_out, weight_transposed=False, c_red=None):
     bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (96, 2) if c_out % 96 == 0 else (128, 2)
-    return f"pair_gemm_kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
+    fast = c_red is not None and c_red % 32 == 0 and c_out % bn == 0
+    return f"pair_gemm_{'fast_' if fast else ''}kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
 
 
 def conv_pair_gemm(feat, kernel, nbmaps, nboffs, n_pairs, gather_col, weight_transposed=False):
@@ -259,7 +260,7 @@ def conv_pair_gemm(feat, kernel, nbmaps, nboffs, n_pairs, gather_col, weight_tra
     if feat.shape[1] != c_red:
         raise ValueError("Input feature size and kernel size mismatch")
     z = torch.empty((int(n_pairs), c_out), dtype=torch.float32, device=feat.device)
-    with _Timed("pair_gemm", name=pair_gemm_kernel_name(c_out, weight_transposed), pairs=int(n_pairs), c_red=c_red,
+    with _Timed("pair_gemm", name=pair_gemm_kernel_name(c_out, weight_transposed, c_red), pairs=int(n_pairs), c_red=c_red,
                 c_out=c_out, k=k):
         L.check(L.load().ts_conv_pair_gemm(L.ptr(feat), feat.shape[0], c_red, L.ptr(kernel), k,
                                            1 if weight_transposed else 0, L.ptr(nbmaps), L.ptr(nboffs),
@@ -345,7 +346,8 @@ def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None, n_out=
     if wgrad_cb is not None:
         pick = lambda c: 32 if c <= 32 else 64 if c <= 64 else 96 if c % 96 == 0 else 128  # noqa: E731
         tm, tn = pick(c_out_or_ca), pick(wgrad_cb)
-        return f"wgrad_gemm_kernel<{tm},{tn}>"
+        fast = c_out_or_ca % tm == 0 and wgrad_cb % tn == 0
+        return f"wgrad_gemm_{'fast_' if fast else ''}kernel<{tm},{tn}>"
     c16 = (c_out_or_ca + 15) & ~15
     tiles64 = -(-n_out // 64)
     if c16 <= 64:
@@ -419,7 +421,7 @@ def bn_backward_reduce(grad_out, x, mean):
 
 
 def set_conv_impl(impl):
-    """0 = MFMA kernels (default), 1 = scalar cross-check kernels."""
+    """0 = MFMA kernels (default), 1 = scalar cross-check kernels, 2 = MFMA kernels, guarded generic staging only."""
     L.load().ts_set_conv_impl(int(impl))
 
 

@@ -31,7 +31,7 @@ struct PgStep {
 };
 
 template <int BN, int WR, bool WT>
-__global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict__ X, int R,
+__global__ __launch_bounds__(256, 2) void pair_gemm_kernel(const float *__restrict__ X, int R,
                                                         const float *__restrict__ W, int O_total,
                                                         const int2 *__restrict__ nbmaps,
                                                         const int *__restrict__ nboffs, int K, int64_t P, int gcol,
@@ -274,6 +274,195 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
   }
 }
 
+// Fast path of pass 1 for the shapes every layer but the stem takes: C_in % 32 == 0, C_out % BN == 0, 16-byte
+// aligned operands.  Same tiling, pipeline and MFMA order as pair_gemm_kernel (bit-identical results), but the
+// staging code has no per-element guards: a thread keeps the 4 gathered row pointers of its A slots in registers
+// for the whole tile (read straight from the rulebook, no LDS round trip), every global access is one
+// unconditional 16-byte load, rows outside the current offset's segment are zeroed with a select after the load.
+// The generic kernel spends most of its issue slots on exec-mask branches around each of those loads.
+template <int BN, int WR, bool WT>
+__global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__restrict__ X, int R,
+                                                             const float *__restrict__ W, int O_total,
+                                                             const int2 *__restrict__ nbmaps,
+                                                             const int *__restrict__ nboffs, int K, int64_t P,
+                                                             int gcol, float *__restrict__ Z) {
+  constexpr int WC = 4 / WR;
+  constexpr int MI = (PG_BM / 16) / WR;
+  constexpr int NI = (BN / 16) / WC;
+  constexpr int BP = BN + 4;
+  constexpr int A_FLOATS = PG_BM * PG_AP;
+  constexpr int B_FLOATS = WT ? BN * PG_AP : PG_BK * BP;
+  constexpr int A_IT = PG_BM * (PG_BK / 4) / 256;  // 4
+  constexpr int B_IT = BN * (PG_BK / 4) / 256;     // BN / 32, exact for BN in {32, 64, 96, 128}
+  static_assert(BN % 32 == 0, "BN must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Abuf = smem;
+  float *Bbuf = Abuf + 2 * A_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave / WC, wc = wave % WC;
+  const int64_t p0 = (int64_t)blockIdx.x * PG_BM;
+  const int np = (int)min((int64_t)PG_BM, P - p0);
+  const int o0 = blockIdx.y * BN;
+
+  // gathered rows of this thread's A slots: slot it covers tile row (tid >> 3) + 32 it, floats 4 (tid & 7) ..+3
+  const int arow0 = tid >> 3, acol = (tid & 7) << 2;
+  const float *aptr[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int rr = arow0 + 32 * it;
+    const int2 pr = nbmaps[min(p0 + rr, P - 1)];
+    aptr[it] = X + (int64_t)(gcol ? pr.y : pr.x) * R + acol;
+  }
+  // this thread's B slots (element offsets relative to the (offset, slice) base)
+  int boff[B_IT], bdst[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int e = tid + it * 256;
+    if (!WT) {
+      constexpr int q4 = BN >> 2;
+      const int kk = e / q4, c4 = (e - kk * q4) << 2;
+      boff[it] = kk * O_total + c4;
+      bdst[it] = kk * BP + c4;
+    } else {
+      const int col = e >> 3, c4 = (e & 7) << 2;
+      boff[it] = col * R + c4;
+      bdst[it] = col * PG_AP + c4;
+    }
+  }
+
+  int k_lo = 0, k_hi = 0;
+  for (int k = 0; k < K; ++k) {
+    int b = nboffs[k];
+    if ((int64_t)b <= p0) k_lo = k;
+    if ((int64_t)b <= p0 + np - 1) k_hi = k;
+  }
+  auto segment = [&](int k, int &s0, int &s1) {
+    s0 = max((int)((int64_t)nboffs[k] - p0), 0);
+    s1 = min((int)((int64_t)nboffs[k + 1] - p0), np);
+  };
+  auto advance = [&](PgStep st) -> PgStep {
+    st.c0 += PG_BK;
+    if (st.c0 < R) return st;
+    st.c0 = 0;
+    for (++st.k; st.k <= k_hi; ++st.k) {
+      segment(st.k, st.s0, st.s1);
+      if (st.s1 > st.s0) break;
+    }
+    return st;
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[A_IT], rb[B_IT];  // one register stage: the loads of step t+1 fly during the MFMAs of step t
+  auto load_regs = [&](const PgStep &st) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      ra[it] = *(const f32x4 *)(aptr[it] + st.c0);
+    }
+    const float *wb = WT ? W + ((int64_t)st.k * O_total + o0) * R + st.c0
+                         : W + ((int64_t)st.k * R + st.c0) * O_total + o0;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const f32x4 *)(wb + boff[it]);
+  };
+  // rows outside the step's segment are zeroed here, not at the load: a select right after the load would make
+  // the wave wait for the data before the MFMAs instead of after them
+  auto store_lds = [&](float *At, float *Bt, const PgStep &st) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int rr = arow0 + 32 * it;
+      const bool in = rr >= st.s0 && rr < st.s1;
+      *(f32x4 *)&At[rr * PG_AP + acol] = in ? ra[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) *(f32x4 *)&Bt[bdst[it]] = rb[it];
+  };
+  auto mma = [&](const float *At, const float *Bt) {
+#pragma unroll
+    for (int j = 0; j < PG_BK; j += 16) {
+      float a[MI][4], b[NI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const float4 v = *(const float4 *)&At[((wr * MI + mi) * 16 + r16) * PG_AP + j + 4 * g];
+        a[mi][0] = v.x;
+        a[mi][1] = v.y;
+        a[mi][2] = v.z;
+        a[mi][3] = v.w;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nb = wc * NI + ni;
+        if (!WT) {
+          const float *bp = &Bt[(j + 4 * g) * BP + nb * 16 + r16];
+          b[ni][0] = bp[0];
+          b[ni][1] = bp[BP];
+          b[ni][2] = bp[2 * BP];
+          b[ni][3] = bp[3 * BP];
+        } else {
+          const float4 v = *(const float4 *)&Bt[(nb * 16 + r16) * PG_AP + j + 4 * g];
+          b[ni][0] = v.x;
+          b[ni][1] = v.y;
+          b[ni][2] = v.z;
+          b[ni][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s4], b[ni][s4], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  PgStep cur;
+  cur.k = k_lo - 1;
+  cur.c0 = R;
+  cur.s0 = cur.s1 = 0;
+  cur = advance(cur);
+  load_regs(cur);
+  for (int t = 0;; ++t) {
+    float *At = Abuf + (t & 1) * A_FLOATS, *Bt = Bbuf + (t & 1) * B_FLOATS;
+    store_lds(At, Bt, cur);
+    __syncthreads();   // LDS is double buffered: one barrier per step
+    const PgStep nxt = advance(cur);
+    const bool more = nxt.k <= k_hi;
+    if (more) load_regs(nxt);
+    mma(At, Bt);
+    if (!more) break;
+    cur = nxt;
+  }
+  float *zt = Z + p0 * O_total + o0;
+  if (np == PG_BM) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          zt[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * O_total + (wc * NI + ni) * 16 + r16] = acc[mi][ni][q];
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (wr * MI + mi) * 16 + 4 * g + q;
+          if (row < np) zt[(int64_t)row * O_total + (wc * NI + ni) * 16 + r16] = acc[mi][ni][q];
+        }
+  }
+}
+
 template <int BN, int WR, bool WT>
 static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
                             int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
@@ -286,7 +475,20 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
     attr_set = true;
   }
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
-  pair_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
+  const bool fast = (R % PG_BK == 0) && (O_total % BN == 0) && ((((uintptr_t)X) | ((uintptr_t)W)) & 15) == 0 &&
+                    g_ts_conv_impl != 2;
+  if (fast) {
+    auto fkern = pair_gemm_fast_kernel<BN, WR, WT>;
+    static bool fattr_set = false;
+    if (!fattr_set) {
+      TS_CHECK_HIP(hipFuncSetAttribute((const void *)fkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                   "hipFuncSetAttribute");
+      fattr_set = true;
+    }
+    pair_gemm_fast_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
+  } else {
+    pair_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
+  }
   TS_CHECK_LAUNCH("conv_pair_gemm");
   return TS_OK;
 }
@@ -407,7 +609,7 @@ extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos,
 #define WG_MAXCHUNK 1024
 
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict__ A, int CA,
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const float *__restrict__ A, int CA,
                                                          const float *__restrict__ B, int CB,
                                                          const int2 *__restrict__ nbmaps,
                                                          const int *__restrict__ nboffs, int K, int P, int col_a,
@@ -590,6 +792,163 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float *__restrict
   }
 }
 
+// Fast path of the weight gradient for full tiles (C_a % TM == 0, C_b % TN == 0, 16-byte aligned rows): same
+// chunking, staging order and MFMA order as wgrad_gemm_kernel, without per-element guards - every gathered row
+// slice is one unconditional 16-byte load (pair slots beyond a short step re-read the step's last pair and are
+// zeroed when they are written to LDS), the flush is unguarded.
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__restrict__ A, int CA,
+                                                              const float *__restrict__ B, int CB,
+                                                              const int2 *__restrict__ nbmaps,
+                                                              const int *__restrict__ nboffs, int K, int P,
+                                                              int col_a, int chunk, float *__restrict__ dW) {
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int XP = TM + 4, YP = TN + 4;
+  constexpr int A_IT = TM / 32, B_IT = TN / 32;  // float4 slots per thread per 32-pair step
+  __shared__ __attribute__((aligned(16))) float Xl[2 * WG_PS * XP];
+  __shared__ __attribute__((aligned(16))) float Yl[2 * WG_PS * YP];
+  __shared__ int idxA[WG_MAXCHUNK], idxB[WG_MAXCHUNK];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int p_beg = blockIdx.x * chunk;
+  const int p_end = min(P, p_beg + chunk);
+  if (p_beg >= p_end) return;  // uniform
+  const int tiles_n = CB / TN;
+  const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
+
+  for (int t = tid; t < p_end - p_beg; t += 256) {
+    const int2 pr = nbmaps[p_beg + t];
+    idxA[t] = col_a ? pr.y : pr.x;
+    idxB[t] = col_a ? pr.x : pr.y;
+  }
+  int k = 0;
+  for (int kk = 0; kk < K; ++kk)
+    if (nboffs[kk] <= p_beg) k = kk;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  struct WStep {
+    int k, p0, np;
+  };
+  auto advance = [&](WStep st) -> WStep {
+    int kend = min(nboffs[st.k + 1], p_end);
+    int pn = st.p0 + WG_PS;
+    if (pn < kend) {
+      st.p0 = pn;
+      st.np = min(WG_PS, kend - pn);
+      return st;
+    }
+    pn = kend;
+    for (++st.k; st.k < K && pn < p_end; ++st.k) {
+      kend = min(nboffs[st.k + 1], p_end);
+      if (kend > pn) {
+        st.p0 = pn;
+        st.np = min(WG_PS, kend - pn);
+        return st;
+      }
+    }
+    st.k = K;
+    return st;
+  };
+  const float *abase = A + ci0, *bbase = B + co0;
+  f32x4 ra[A_IT], rb[B_IT];
+  auto load_regs = [&](const WStep &st) {
+    const int l0 = st.p0 - p_beg, last = st.np - 1;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
+      ra[it] = *(const f32x4 *)(abase + (int64_t)idxA[l0 + min(pp, last)] * CA + c4);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
+      rb[it] = *(const f32x4 *)(bbase + (int64_t)idxB[l0 + min(pp, last)] * CB + c4);
+    }
+  };
+  auto store_lds = [&](float *xl, float *yl, const WStep &st) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TM / 4), c4 = (e - pp * (TM / 4)) << 2;
+      *(f32x4 *)&xl[pp * XP + c4] = pp < st.np ? ra[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TN / 4), c4 = (e - pp * (TN / 4)) << 2;
+      *(f32x4 *)&yl[pp * YP + c4] = pp < st.np ? rb[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  WStep cur;
+  cur.k = k;
+  cur.p0 = p_beg;
+  cur.np = min(WG_PS, min(nboffs[k + 1], p_end) - p_beg);
+  __syncthreads();  // pair indices visible
+  load_regs(cur);
+  int buf = 0;
+  while (cur.k < K) {
+    float *xl = Xl + buf * (WG_PS * XP), *yl = Yl + buf * (WG_PS * YP);
+    store_lds(xl, yl, cur);
+    __syncthreads();
+    const WStep nxt = advance(cur);
+    if (nxt.k < K) load_regs(nxt);
+#pragma unroll
+    for (int j = 0; j < WG_PS; j += 16) {
+      float a[MI][4], b[NI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const float *ap = &xl[(j + 4 * g) * XP + (wr * MI + mi) * 16 + r16];
+        a[mi][0] = ap[0];
+        a[mi][1] = ap[XP];
+        a[mi][2] = ap[2 * XP];
+        a[mi][3] = ap[3 * XP];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float *bp = &yl[(j + 4 * g) * YP + (wc * NI + ni) * 16 + r16];
+        b[ni][0] = bp[0];
+        b[ni][1] = bp[YP];
+        b[ni][2] = bp[2 * YP];
+        b[ni][3] = bp[3 * YP];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    if (nxt.k != cur.k) {
+      float *dwk = dW + (int64_t)cur.k * CA * CB + (int64_t)ci0 * CB + co0;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            atomicAdd(&dwk[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * CB + (wc * NI + ni) * 16 + r16],
+                      acc[mi][ni][q]);
+          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    cur = nxt;
+    buf ^= 1;
+  }
+}
+
 template <int TM, int TN>
 static int launch_wgrad(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
                         int col_a, int64_t n_pairs, float *dW, hipStream_t stream) {
@@ -599,8 +958,14 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   int64_t chunk = ts_cdiv(n_pairs * tiles, 512);
   chunk = std::min<int64_t>(WG_MAXCHUNK, std::max<int64_t>(128, (chunk + WG_PS - 1) / WG_PS * WG_PS));
   dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
-  wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
-                                                     (int)chunk, dW);
+  const bool fast = (CA % TM == 0) && (CB % TN == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
+                    g_ts_conv_impl != 2;
+  if (fast)
+    wgrad_gemm_fast_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
+                                                            (int)chunk, dW);
+  else
+    wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
+                                                       (int)chunk, dW);
   TS_CHECK_LAUNCH("conv_wgrad");
   return TS_OK;
 }

@@ -298,6 +298,35 @@ def test_conv_two_pass_equals_neighbour_table_kernel(B, F):
         assert torch.equal(B.conv_gather_sum(z_b, km["pos_out"], len(c)), y2)
 
 
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 64), (128, 128), (384, 256), (256, 192)])
+def test_conv_fast_path_equals_generic_kernels(B, F, ci, co):
+    """the unguarded full-tile kernels (C_in % 32 == 0, C_out % tile == 0) against the guarded generic ones
+    (ts_set_conv_impl(2)): pair GEMM bit-identical in both orientations, weight gradient to atomics-order noise"""
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    c = _blob(11, n=5000, extent=24)
+    rs = np.random.RandomState(ci + co)
+    x = T(rs.randn(len(c), ci).astype(np.float32))
+    gy = T(rs.randn(len(c), co).astype(np.float32))
+    w = T((rs.randn(27, ci, co) / 30).astype(np.float32))
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+    total = int(km["nboffs"][-1])
+
+    def run():
+        z = B.conv_pair_gemm(x, w, km["nbmaps"], km["nboffs"], total, gather_col=0)
+        zt = B.conv_pair_gemm(gy, w, km["nbmaps"], km["nboffs"], total, gather_col=1, weight_transposed=True)
+        gw = B.conv_wgrad(x, gy, km["nbmaps"], km["nboffs"], 27, col_a=0, max_pairs=total)
+        return z, zt, gw
+
+    fast = run()
+    B.set_conv_impl(2)
+    try:
+        generic = run()
+    finally:
+        B.set_conv_impl(0)
+    assert torch.equal(fast[0], generic[0]) and torch.equal(fast[1], generic[1])
+    close(fast[2], generic[2], 1e-5)
+
+
 def test_conv_reference_form_entry_points(B, g_ops):
     """the ten-function lower boundary: explicit nbmaps + host nbsizes, plain and transposed"""
     c = g_ops["coords"]
