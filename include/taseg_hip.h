@@ -257,6 +257,26 @@ int ts_bn_act_backward(const float *grad_out, const uint8_t *mask, const float *
                        const double *total_dev, double total_host, int64_t n, int32_t c, float *grad_x,
                        float *grad_residual, ts_stream_t stream);
 
+/* Single-process training BatchNorm (+ residual) (+ ReLU) in ONE call per direction - what nn.BatchNorm1d in
+ * training mode followed by the residual add and ReLU of the MinkUNet blocks computes (R minkunet.py:42-51,
+ * 110-129; torch/nn/functional.py batch_norm).  Reductions go through <= 512 float partial slices in `ws`
+ * (ts_bn_train_workspace_bytes(c) bytes, 16-byte aligned; stream-ordered scratch) that a finish kernel adds in
+ * double: no memset, no atomics, results independent of workgroup scheduling.
+ *   forward : mean/invstd [C] (saved for backward), running_mean/var updated in place and
+ *             *num_batches_tracked incremented (each may be NULL),
+ *             out = act((x - mean) invstd weight + bias [+ residual]), mask = 4-bit ReLU sign per float4 (relu only)
+ *   backward: grad_x, grad_residual (optional, = masked grad_out), grad_weight [C], grad_bias [C] (optional)
+ * SyncBatchNorm keeps using the split entry points above (the all-reduce sits between reduction and apply). */
+size_t ts_bn_train_workspace_bytes(int32_t c);
+int ts_bn_act_train_forward(const float *x, const float *residual, const float *weight, const float *bias,
+                            float *running_mean, float *running_var, int64_t *num_batches_tracked, int64_t n,
+                            int32_t c, float eps, float momentum, int32_t relu, float *mean, float *invstd,
+                            float *out, uint8_t *mask, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_bn_act_train_backward(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
+                             const float *invstd, const float *weight, int64_t n, int32_t c, float *grad_x,
+                             float *grad_residual, float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes,
+                             ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply. */

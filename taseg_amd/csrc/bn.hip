@@ -290,3 +290,235 @@ extern "C" int ts_bn_act_backward(const float *grad_out, const uint8_t *mask, co
   TS_CHECK_LAUNCH("ts_bn_act_backward");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Single-process training BatchNorm (+ residual) (+ ReLU), one host call per direction.
+//
+// The reductions above end in 2 C double atomics per workgroup into a zeroed buffer and are sized at 512 rows per
+// workgroup - 59 workgroups for a 30k-row matrix on a 256-CU device.  Here every launch is cut into <= 512
+// slices of at least 32 rows, each slice writes its float partial sums to scratch (no memset, no atomics, and the
+// result does not depend on the order workgroups finish in), and a small second kernel adds the partials in
+// double and finishes the per-channel math: mean / invstd / running statistics in the forward pass; grad_weight,
+// grad_bias and the two coefficients of the input gradient in the backward pass (which the elementwise kernel
+// then reads as floats instead of dividing doubles per element).
+//   forward   ts_bn_act_train_forward  = bn_partial<0> -> bn_fwd_finish -> bn_act_fwd
+//   backward  ts_bn_act_train_backward = bn_partial<1|2> -> bn_bwd_finish -> bn_act_bwd_coef
+#define BN_MAX_SLICES 512
+
+// MODE 0: (x, x^2)   1: (dy, dy (x - mean))   2: same with the ReLU mask applied to dy
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ X, const float *__restrict__ DY,
+                                                         const unsigned char *__restrict__ MASK,
+                                                         const float *__restrict__ mean, int64_t n, int c,
+                                                         int rows_per_wg, float *__restrict__ part) {
+  __shared__ float red[2][256 * 4];
+  const int cq = c >> 2, rpp = 256 / cq;
+  const int tid = threadIdx.x, ty = tid / cq, tx = tid - ty * cq;
+  const bool active = ty < rpp;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0;
+  if (MODE != 0 && active) mu = *(const float4 *)(mean + 4 * tx);
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_wg, r_end = min(n, r_beg + rows_per_wg);
+  if (active) {
+#pragma unroll 4
+    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
+      const float4 x = *(const float4 *)(X + r * c + 4 * tx);
+      if (MODE == 0) {
+        s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
+        s1.x += x.x * x.x; s1.y += x.y * x.y; s1.z += x.z * x.z; s1.w += x.w * x.w;
+      } else {
+        float4 d = *(const float4 *)(DY + r * c + 4 * tx);
+        if (MODE == 2) {
+          const unsigned mk = MASK[r * cq + tx];
+          d.x = (mk & 1) ? d.x : 0.f; d.y = (mk & 2) ? d.y : 0.f;
+          d.z = (mk & 4) ? d.z : 0.f; d.w = (mk & 8) ? d.w : 0.f;
+        }
+        s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
+        s1.x += d.x * (x.x - mu.x); s1.y += d.y * (x.y - mu.y);
+        s1.z += d.z * (x.z - mu.z); s1.w += d.w * (x.w - mu.w);
+      }
+    }
+  }
+  *(float4 *)&red[0][tid * 4] = s0;
+  *(float4 *)&red[1][tid * 4] = s1;
+  __syncthreads();
+  float *out = part + (int64_t)blockIdx.x * 2 * c;
+  for (int ch = tid; ch < c; ch += 256) {
+    const int q = ch >> 2, l = ch & 3;
+    float a = 0.f, b = 0.f;
+    for (int y = 0; y < rpp; ++y) {
+      a += red[0][(y * cq + q) * 4 + l];
+      b += red[1][(y * cq + q) * 4 + l];
+    }
+    out[ch] = a;
+    out[c + ch] = b;
+  }
+}
+
+// 16 channels per workgroup, 16 lanes per channel over the slices; double accumulation, fixed order.
+__device__ __forceinline__ void bn_sum_slices(const float *__restrict__ part, int slices, int c, int ch, int lane16,
+                                              double (&red)[2][16][17], double &s0, double &s1) {
+  double a = 0.0, b = 0.0;
+  if (ch < c) {
+    for (int g = lane16; g < slices; g += 16) {
+      a += (double)part[(int64_t)g * 2 * c + ch];
+      b += (double)part[(int64_t)g * 2 * c + c + ch];
+    }
+  }
+  const int cl = threadIdx.x & 15;
+  red[0][cl][lane16] = a;
+  red[1][cl][lane16] = b;
+  __syncthreads();
+  s0 = s1 = 0.0;
+  if (lane16 == 0) {
+    for (int i = 0; i < 16; ++i) {
+      s0 += red[0][cl][i];
+      s1 += red[1][cl][i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finish_kernel(const float *__restrict__ part, int slices, double total,
+                                                            int c, float eps, float momentum,
+                                                            float *__restrict__ running_mean,
+                                                            float *__restrict__ running_var, float *__restrict__ mean,
+                                                            float *__restrict__ invstd,
+                                                            int64_t *__restrict__ num_batches_tracked) {
+  __shared__ double red[2][16][17];
+  const int ch = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  double s0, s1;
+  bn_sum_slices(part, slices, c, ch, lane16, red, s0, s1);
+  if (lane16 != 0 || ch >= c) return;
+  const double m = s0 / total;
+  double var = s1 / total - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[ch] = (float)m;
+  invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+  if (running_var) {
+    const double unbiased = total > 1.0 ? var * total / (total - 1.0) : var;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float *__restrict__ part, int slices, double total,
+                                                            int c, const float *__restrict__ invstd,
+                                                            float *__restrict__ coef, float *__restrict__ grad_weight,
+                                                            float *__restrict__ grad_bias) {
+  __shared__ double red[2][16][17];
+  const int ch = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  double s0, s1;
+  bn_sum_slices(part, slices, c, ch, lane16, red, s0, s1);
+  if (lane16 != 0 || ch >= c) return;
+  const float is = invstd[ch];
+  coef[ch] = (float)(s0 / total);                  // mean of dy
+  coef[c + ch] = (float)(s1 / total) * is * is;    // mean of dy (x - mean), times invstd^2
+  if (grad_bias) grad_bias[ch] = (float)s0;
+  if (grad_weight) grad_weight[ch] = (float)s1 * is;
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_coef_kernel(const float4 *__restrict__ GOUT,
+                                                              const unsigned char *__restrict__ MASK,
+                                                              const float4 *__restrict__ X,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd,
+                                                              const float *__restrict__ w,
+                                                              const float *__restrict__ coef, int64_t total4, int c,
+                                                              float4 *__restrict__ GX, float4 *__restrict__ GRES) {
+  const int cq = c >> 2;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total4; e += step) {
+    const int q = (int)(e % cq) * 4;
+    float4 g = GOUT[e];
+    if (MASK) {
+      const unsigned mk = MASK[e];
+      g.x = (mk & 1) ? g.x : 0.f; g.y = (mk & 2) ? g.y : 0.f;
+      g.z = (mk & 4) ? g.z : 0.f; g.w = (mk & 8) ? g.w : 0.f;
+    }
+    if (GRES) GRES[e] = g;
+    const float4 x = X[e];
+    const float4 m = *(const float4 *)(mean + q), s = *(const float4 *)(invstd + q), ww = *(const float4 *)(w + q);
+    const float4 c0 = *(const float4 *)(coef + q), c1 = *(const float4 *)(coef + c + q);
+    float4 gx;
+    gx.x = (g.x - c0.x - (x.x - m.x) * c1.x) * s.x * ww.x;
+    gx.y = (g.y - c0.y - (x.y - m.y) * c1.y) * s.y * ww.y;
+    gx.z = (g.z - c0.z - (x.z - m.z) * c1.z) * s.z * ww.z;
+    gx.w = (g.w - c0.w - (x.w - m.w) * c1.w) * s.w * ww.w;
+    GX[e] = gx;
+  }
+}
+
+static inline int bn_rows_per_slice(int64_t n, int c) {
+  const int rpp = 256 / (c >> 2);                       // rows one pass of a workgroup covers
+  int64_t rows = std::max<int64_t>(ts_cdiv(n, BN_MAX_SLICES), 32);
+  rows = ts_cdiv(rows, rpp) * rpp;                      // whole passes
+  return (int)rows;
+}
+
+extern "C" size_t ts_bn_train_workspace_bytes(int32_t c) {
+  // float partials [BN_MAX_SLICES][2][C] + float coefficients [2][C]
+  return ((size_t)BN_MAX_SLICES * 2 * c + 2 * (size_t)c) * sizeof(float);
+}
+
+extern "C" int ts_bn_act_train_forward(const float *x, const float *residual, const float *weight, const float *bias,
+                                       float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                       int64_t n, int32_t c, float eps, float momentum, int32_t relu, float *mean,
+                                       float *invstd, float *out, uint8_t *mask, void *ws, size_t ws_bytes,
+                                       ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n > 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED,
+             "ts_bn_act_train_forward: need N > 0 and C a multiple of 4, <= 1024");
+  TS_REQUIRE(x && weight && bias && mean && invstd && out && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_forward: null pointer");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_forward: workspace too small");
+  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && bn_aligned(mean) && bn_aligned(invstd) && bn_aligned(weight) &&
+                 bn_aligned(bias) && (!residual || bn_aligned(residual)) && bn_aligned(ws),
+             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_train_forward: pointers must be 16-byte aligned");
+  float *part = (float *)ws;
+  const int rows = bn_rows_per_slice(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);
+  bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, 16), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum,
+                                                                     running_mean, running_var, mean, invstd,
+                                                                     num_batches_tracked);
+  const int64_t total4 = n * (c / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
+  bn_act_fwd_kernel<<<grid, 256, 0, stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd, weight, bias,
+                                              total4, c / 4, relu, (float4 *)out, mask);
+  TS_CHECK_LAUNCH("ts_bn_act_train_forward");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_act_train_backward(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
+                                        const float *invstd, const float *weight, int64_t n, int32_t c, float *grad_x,
+                                        float *grad_residual, float *grad_weight, float *grad_bias, void *ws,
+                                        size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n > 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED,
+             "ts_bn_act_train_backward: need N > 0 and C a multiple of 4, <= 1024");
+  TS_REQUIRE(grad_out && x && mean && invstd && weight && grad_x && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_backward: null pointer");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_backward: workspace too small");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) && bn_aligned(mean) && bn_aligned(invstd) &&
+                 bn_aligned(weight) && (!grad_residual || bn_aligned(grad_residual)) && bn_aligned(ws),
+             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_train_backward: pointers must be 16-byte aligned");
+  float *part = (float *)ws;
+  float *coef = part + (size_t)BN_MAX_SLICES * 2 * c;
+  const int rows = bn_rows_per_slice(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  if (mask)
+    bn_partial_kernel<2><<<slices, 256, 0, stream>>>(x, grad_out, mask, mean, n, c, rows, part);
+  else
+    bn_partial_kernel<1><<<slices, 256, 0, stream>>>(x, grad_out, nullptr, mean, n, c, rows, part);
+  bn_bwd_finish_kernel<<<(unsigned)ts_cdiv(c, 16), 256, 0, stream>>>(part, slices, (double)n, c, invstd, coef,
+                                                                     grad_weight, grad_bias);
+  const int64_t total4 = n * (c / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
+  bn_act_bwd_coef_kernel<<<grid, 256, 0, stream>>>((const float4 *)grad_out, mask, (const float4 *)x, mean, invstd,
+                                                   weight, coef, total4, c, (float4 *)grad_x, (float4 *)grad_residual);
+  TS_CHECK_LAUNCH("ts_bn_act_train_backward");
+  return TS_OK;
+}

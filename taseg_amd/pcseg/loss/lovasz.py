@@ -35,8 +35,12 @@ def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, classes="pre
     fg_sorted = torch.gather(fg, 1, perm)
     # gradient of the Lovasz extension of the Jaccard loss w.r.t. sorted errors (Alg. 1)
     gts = fg_sorted.sum(dim=1, keepdim=True)
-    intersection = gts - fg_sorted.cumsum(dim=1)
-    union = gts + (1.0 - fg_sorted).cumsum(dim=1)
+    # one scan instead of two: cumsum(1 - fg) = (position + 1) - cumsum(fg); all terms are integers < 2^24,
+    # exact in fp32, so the values are those of the reference's two cumsums
+    cum_fg = fg_sorted.cumsum(dim=1)
+    rank = torch.arange(1, fg_sorted.shape[1] + 1, device=fg_sorted.device, dtype=fg_sorted.dtype).view(1, -1)
+    intersection = gts - cum_fg
+    union = gts + (rank - cum_fg)
     jaccard = 1.0 - intersection / union
     grad = torch.cat([jaccard[:, :1], jaccard[:, 1:] - jaccard[:, :-1]], dim=1)
     per_class = (errors_sorted * grad).sum(dim=1)                          # [C]

@@ -65,28 +65,38 @@ class _BatchNormActTrain(Function):
     ts_bn_act_backward_reduce -> ts_bn_act_backward (the ReLU mask is a 4-bit-per-float4 byte array written by the forward)."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, group):
         x = x.contiguous()
         n, c = x.shape
-        sums = B.bn_stats(x)
+        lib = L.load()
+        if residual is not None:
+            residual = residual.contiguous()
+        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)        # mean, invstd
+        mean, invstd = stats[0], stats[1]
+        out = torch.empty_like(x)
+        mask = torch.empty(n * (c // 4), dtype=torch.uint8, device=x.device) if relu else None
         total_dev = None
-        if group is not None:
+        if group is None:
+            # single process: partial reductions, statistics and the elementwise pass in one backend call
+            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+            L.check(lib.ts_bn_act_train_forward(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
+                                                L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), n, c, float(eps),
+                                                float(momentum), 1 if relu else 0, L.ptr(mean), L.ptr(invstd),
+                                                L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream()),
+                    "ts_bn_act_train_forward")
+        else:
+            if nbt is not None:
+                nbt.add_(1)
+            sums = B.bn_stats(x)
             pack = torch.cat([sums.view(-1), torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
             dist.all_reduce(pack, group=group)
             sums, total_dev = pack[:2 * c].view(2, c), pack[2 * c:]
-        mean = torch.empty(c, dtype=torch.float32, device=x.device)
-        invstd = torch.empty_like(mean)
-        lib = L.load()
-        L.check(lib.ts_bn_finalize(L.ptr(sums), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
-                                   L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.stream()),
-                "ts_bn_finalize")
-        if residual is not None:
-            residual = residual.contiguous()
-        out = torch.empty_like(x)
-        mask = torch.empty(n * (c // 4), dtype=torch.uint8, device=x.device) if relu else None
-        L.check(lib.ts_bn_act_forward(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd), L.ptr(weight),
-                                      L.ptr(bias), n, c, 1 if relu else 0, L.ptr(out), L.ptr(mask), L.stream()),
-                "ts_bn_act_forward")
+            L.check(lib.ts_bn_finalize(L.ptr(sums), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
+                                       L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd),
+                                       L.stream()), "ts_bn_finalize")
+            L.check(lib.ts_bn_act_forward(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd), L.ptr(weight),
+                                          L.ptr(bias), n, c, 1 if relu else 0, L.ptr(out), L.ptr(mask), L.stream()),
+                    "ts_bn_act_forward")
         ctx.save_for_backward(x, weight, mean, invstd, mask)
         ctx.group, ctx.total_dev, ctx.has_res = group, total_dev, residual is not None
         return out
@@ -97,28 +107,38 @@ class _BatchNormActTrain(Function):
         grad_out = grad_out.contiguous()
         n, c = x.shape
         lib = L.load()
+        grad_x = torch.empty_like(x)
+        grad_res = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        if ctx.group is None:
+            gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)      # grad_weight, grad_bias
+            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+            L.check(lib.ts_bn_act_train_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                                 L.ptr(weight), n, c, L.ptr(grad_x), L.ptr(grad_res), L.ptr(gwb[0]),
+                                                 L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()),
+                    "ts_bn_act_train_backward")
+            return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
         sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
         L.check(lib.ts_bn_act_backward_reduce(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), n, c, L.ptr(sums),
                                               L.stream()), "ts_bn_act_backward_reduce")
         local = sums.float()
         grad_weight = local[1] * invstd if ctx.needs_input_grad[2] else None
         grad_bias = local[0] if ctx.needs_input_grad[3] else None
-        if ctx.group is not None:
-            dist.all_reduce(sums, group=ctx.group)
-        grad_x = torch.empty_like(x)
-        grad_res = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        dist.all_reduce(sums, group=ctx.group)
         L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                        L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
                                        L.ptr(grad_x), L.ptr(grad_res), L.stream()), "ts_bn_act_backward")
-        return grad_x, grad_res, grad_weight, grad_bias, None, None, None, None, None, None
+        return grad_x, grad_res, grad_weight, grad_bias, None, None, None, None, None, None, None
 
 
 def batch_norm_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=True, residual=None,
-                         group=None):
-    """act(BN(x) [+ residual]) with batch statistics, fused elementwise passes."""
-    return _BatchNormActTrain.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group)
+                         group=None, num_batches_tracked=None):
+    """act(BN(x) [+ residual]) with batch statistics, fused elementwise passes; updates the running buffers and
+    (when given) increments `num_batches_tracked`."""
+    return _BatchNormActTrain.apply(x, residual, weight, bias, running_mean, running_var, num_batches_tracked,
+                                    momentum, eps, relu, group)
 
 
-def batch_norm_train(x, weight, bias, running_mean, running_var, momentum, eps, group=None):
+def batch_norm_train(x, weight, bias, running_mean, running_var, momentum, eps, group=None, num_batches_tracked=None):
     """y = BN(x) with batch statistics (over all ranks of `group` when given); updates the running buffers."""
-    return _BatchNormTrain.apply(x, weight, bias, running_mean, running_var, momentum, eps, group)
+    return batch_norm_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, residual=None,
+                                group=group, num_batches_tracked=num_batches_tracked)

@@ -64,11 +64,11 @@ def _bn_forward(mod, feats, torch_forward, group=None):
     momentum=None cumulative averaging, odd channel counts) -> the stock torch module."""
     from .batchnorm import batch_norm_train, fast_path_ok
     if mod.training and mod.momentum is not None and mod.affine and fast_path_ok(feats):
-        if mod.track_running_stats and mod.num_batches_tracked is not None:
-            mod.num_batches_tracked.add_(1)
         rm = mod.running_mean if mod.track_running_stats else None
         rv = mod.running_var if mod.track_running_stats else None
-        return batch_norm_train(feats, mod.weight, mod.bias, rm, rv, mod.momentum, mod.eps, group)
+        nbt = mod.num_batches_tracked if mod.track_running_stats else None
+        return batch_norm_train(feats, mod.weight, mod.bias, rm, rv, mod.momentum, mod.eps, group,
+                                num_batches_tracked=nbt)
     return torch_forward(feats)
 
 
@@ -89,12 +89,11 @@ def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor =
     res = None if residual is None else residual.feats
     if mod.training and mod.momentum is not None and mod.affine and fast_path_ok(feats) \
             and (res is None or (res.shape == feats.shape and res.dtype == feats.dtype)):
-        if mod.track_running_stats and mod.num_batches_tracked is not None:
-            mod.num_batches_tracked.add_(1)
         rm = mod.running_mean if mod.track_running_stats else None
         rv = mod.running_var if mod.track_running_stats else None
+        nbt = mod.num_batches_tracked if mod.track_running_stats else None
         out = batch_norm_act_train(feats, mod.weight, mod.bias, rm, rv, mod.momentum, mod.eps, relu=relu,
-                                   residual=res, group=_sync_group(mod))
+                                   residual=res, group=_sync_group(mod), num_batches_tracked=nbt)
         return input._like(out)
     out = mod(input).feats
     if res is not None:
