@@ -277,6 +277,19 @@ int ts_bn_act_train_backward(const float *grad_out, const uint8_t *mask, const f
                              float *grad_residual, float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes,
                              ts_stream_t stream);
 
+/* Trilinear devoxelisation backward over runs of points that share their 8-corner index tuple (the points of one
+ * interpolation cell).  Same result as ts_devoxelize_backward up to float summation order; the corner
+ * contributions of a run are accumulated in registers and added to grad_feat once per run.
+ *   ts_devox_order             order[n] = permutation grouping equal tuples (radix sort on 8 * first present corner
+ *                              voxel + corner number; n_vox < 2^28); ws >= ts_devox_order_workspace_bytes(n)
+ *   ts_devoxelize_backward_runs  grad_feat[m, c] (zeroed here) += runs; `order` may be NULL (natural order);
+ *                              c % 4 == 0, 16-byte aligned rows */
+size_t ts_devox_order_workspace_bytes(int64_t n);
+int ts_devox_order(const int32_t *idx, int64_t n, int64_t n_vox, int32_t *order, void *ws, size_t ws_bytes,
+                   ts_stream_t stream);
+int ts_devoxelize_backward_runs(const float *grad_out, const int32_t *idx, const float *weight, const int32_t *order,
+                                int64_t n, int32_t c, int64_t m, float *grad_feat, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply. */

@@ -14,7 +14,7 @@ from . import _lib as L
 __all__ = [
     "hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda",
     "voxelize_forward_cuda", "voxelize_backward_cuda",
-    "devoxelize_forward_cuda", "devoxelize_backward_cuda",
+    "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
     "fuse_scan", "voxel_coords", "sparse_quantize", "set_conv_impl",
@@ -124,6 +124,35 @@ def devoxelize_backward_cuda(top_grad, indices, weight, n):
     out = torch.empty((int(n), c), dtype=torch.float32, device=top_grad.device)
     L.check(L.load().ts_devoxelize_backward(L.ptr(top_grad), L.ptr(indices), L.ptr(weight), npts, c, int(n),
                                             L.ptr(out), L.stream()), "ts_devoxelize_backward")
+    return out
+
+
+def devox_order(indices, n_vox):
+    """int32 [n] walk order that groups points with identical 8-corner tuples (one interpolation cell) for
+    `devoxelize_backward_runs`."""
+    L.require_device(indices)
+    indices = _i32(indices, "indices")
+    n = indices.shape[0]
+    lib = L.load()
+    ws = L.workspace(lib.ts_devox_order_workspace_bytes(n), indices.device)
+    order = torch.empty(n, dtype=torch.int32, device=indices.device)
+    L.check(lib.ts_devox_order(L.ptr(indices), n, int(n_vox), L.ptr(order), L.ptr(ws), ws.numel(), L.stream()),
+            "ts_devox_order")
+    return order
+
+
+def devoxelize_backward_runs(top_grad, indices, weight, n, order=None):
+    """devoxelize_backward_cuda with the atomics issued once per run of points sharing their corner tuple."""
+    L.require_device(top_grad, indices, weight, order)
+    top_grad, indices, weight = _f32(top_grad, "top_grad"), _i32(indices, "indices"), _f32(weight, "weight")
+    if order is not None:
+        order = _i32(order, "order")
+        if order.shape[0] != top_grad.shape[0]:
+            raise ValueError("order must hold one entry per point")
+    npts, c = top_grad.shape
+    out = torch.empty((int(n), c), dtype=torch.float32, device=top_grad.device)
+    L.check(L.load().ts_devoxelize_backward_runs(L.ptr(top_grad), L.ptr(indices), L.ptr(weight), L.ptr(order), npts, c,
+                                                 int(n), L.ptr(out), L.stream()), "ts_devoxelize_backward_runs")
     return out
 
 

@@ -354,23 +354,37 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
   }
 }
 
-// 16 channels per workgroup, 16 lanes per channel over the slices; double accumulation, fixed order.
-__device__ __forceinline__ void bn_sum_slices(const float *__restrict__ part, int slices, int c, int ch, int lane16,
-                                              double (&red)[2][16][17], double &s0, double &s1) {
-  double a = 0.0, b = 0.0;
-  if (ch < c) {
-    for (int g = lane16; g < slices; g += 16) {
-      a += (double)part[(int64_t)g * 2 * c + ch];
-      b += (double)part[(int64_t)g * 2 * c + c + ch];
-    }
+// 8 channels per workgroup, 32 lanes per channel over the slices (<= 16 partials per lane, all loads issued
+// before the first add); double accumulation in a fixed order.
+#define BN_FIN_CH 8
+#define BN_FIN_LANES 32
+__device__ __forceinline__ void bn_sum_slices(const float *__restrict__ part, int slices, int c, int ch, int sl,
+                                              double (&red)[2][BN_FIN_CH][BN_FIN_LANES + 1], double &s0, double &s1) {
+  constexpr int PER = BN_MAX_SLICES / BN_FIN_LANES;
+  // unconditional loads from clamped addresses, masked afterwards: a predicated load compiles to a branch plus
+  // a full wait per element (32 serialised round trips, 10 us for this tiny kernel)
+  float va[PER], vb[PER];
+  const int chc = min(ch, c - 1);
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int g = min(sl + t * BN_FIN_LANES, slices - 1);
+    va[t] = part[(int64_t)g * 2 * c + chc];
+    vb[t] = part[(int64_t)g * 2 * c + c + chc];
   }
-  const int cl = threadIdx.x & 15;
-  red[0][cl][lane16] = a;
-  red[1][cl][lane16] = b;
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const bool ok = sl + t * BN_FIN_LANES < slices;
+    a += ok ? (double)va[t] : 0.0;
+    b += ok ? (double)vb[t] : 0.0;
+  }
+  const int cl = threadIdx.x % BN_FIN_CH;
+  red[0][cl][sl] = a;
+  red[1][cl][sl] = b;
   __syncthreads();
   s0 = s1 = 0.0;
-  if (lane16 == 0) {
-    for (int i = 0; i < 16; ++i) {
+  if (sl == 0) {
+    for (int i = 0; i < BN_FIN_LANES; ++i) {
       s0 += red[0][cl][i];
       s1 += red[1][cl][i];
     }
@@ -383,12 +397,12 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_kernel(const float *__restr
                                                             float *__restrict__ running_var, float *__restrict__ mean,
                                                             float *__restrict__ invstd,
                                                             int64_t *__restrict__ num_batches_tracked) {
-  __shared__ double red[2][16][17];
-  const int ch = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  __shared__ double red[2][BN_FIN_CH][BN_FIN_LANES + 1];
+  const int ch = blockIdx.x * BN_FIN_CH + (threadIdx.x % BN_FIN_CH), sl = threadIdx.x / BN_FIN_CH;
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   double s0, s1;
-  bn_sum_slices(part, slices, c, ch, lane16, red, s0, s1);
-  if (lane16 != 0 || ch >= c) return;
+  bn_sum_slices(part, slices, c, ch, sl, red, s0, s1);
+  if (sl != 0 || ch >= c) return;
   const double m = s0 / total;
   double var = s1 / total - m * m;
   if (var < 0.0) var = 0.0;
@@ -405,11 +419,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float *__restr
                                                             int c, const float *__restrict__ invstd,
                                                             float *__restrict__ coef, float *__restrict__ grad_weight,
                                                             float *__restrict__ grad_bias) {
-  __shared__ double red[2][16][17];
-  const int ch = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+  __shared__ double red[2][BN_FIN_CH][BN_FIN_LANES + 1];
+  const int ch = blockIdx.x * BN_FIN_CH + (threadIdx.x % BN_FIN_CH), sl = threadIdx.x / BN_FIN_CH;
   double s0, s1;
-  bn_sum_slices(part, slices, c, ch, lane16, red, s0, s1);
-  if (lane16 != 0 || ch >= c) return;
+  bn_sum_slices(part, slices, c, ch, sl, red, s0, s1);
+  if (sl != 0 || ch >= c) return;
   const float is = invstd[ch];
   coef[ch] = (float)(s0 / total);                  // mean of dy
   coef[c + ch] = (float)(s1 / total) * is * is;    // mean of dy (x - mean), times invstd^2
@@ -480,7 +494,7 @@ extern "C" int ts_bn_act_train_forward(const float *x, const float *residual, co
   const int rows = bn_rows_per_slice(n, c);
   const int slices = (int)ts_cdiv(n, rows);
   bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);
-  bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, 16), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum,
+  bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum,
                                                                      running_mean, running_var, mean, invstd,
                                                                      num_batches_tracked);
   const int64_t total4 = n * (c / 4);
@@ -513,7 +527,7 @@ extern "C" int ts_bn_act_train_backward(const float *grad_out, const uint8_t *ma
     bn_partial_kernel<2><<<slices, 256, 0, stream>>>(x, grad_out, mask, mean, n, c, rows, part);
   else
     bn_partial_kernel<1><<<slices, 256, 0, stream>>>(x, grad_out, nullptr, mean, n, c, rows, part);
-  bn_bwd_finish_kernel<<<(unsigned)ts_cdiv(c, 16), 256, 0, stream>>>(part, slices, (double)n, c, invstd, coef,
+  bn_bwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, invstd, coef,
                                                                      grad_weight, grad_bias);
   const int64_t total4 = n * (c / 4);
   const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);

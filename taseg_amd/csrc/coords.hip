@@ -466,3 +466,54 @@ extern "C" int ts_trilinear_map(const float *points, int64_t n_points, const int
   TS_CHECK_LAUNCH("ts_trilinear_map");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------ devoxelize run order
+// Permutation of the points that brings points of the same interpolation cell (identical 8-corner index tuple)
+// next to each other: key = 8 * (first present corner voxel) + (its corner number), which identifies the cell.
+// ts_devoxelize_backward_runs walks the points in this order and adds a whole run of equal tuples to the voxel
+// gradient once.  Any permutation is valid input there; this one makes the runs long (n / #cells points).
+__global__ __launch_bounds__(256) void devox_key_kernel(const int *__restrict__ idx, int64_t n,
+                                                        unsigned *__restrict__ keys, int *__restrict__ vals) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 a = *(const int4 *)(idx + i * 8), b = *(const int4 *)(idx + i * 8 + 4);
+  const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 7; k >= 0; --k)
+    if (id[k] >= 0) key = ((unsigned)id[k] << 3) | (unsigned)k;
+  keys[i] = key;
+  vals[i] = (int)i;
+}
+
+extern "C" size_t ts_devox_order_workspace_bytes(int64_t n) {
+  size_t nn = (size_t)(n < 0 ? 0 : n);
+  return 3 * ts_align_up(nn * 4, 256) + ts_align_up(nn * 16 + (4u << 20), 256);
+}
+
+extern "C" int ts_devox_order(const int32_t *idx, int64_t n, int64_t n_vox, int32_t *order, void *ws, size_t ws_bytes,
+                              ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && n_vox >= 0 && n < (1LL << 31), TS_ERR_INVALID_ARGUMENT, "ts_devox_order: bad sizes");
+  TS_REQUIRE(n_vox < (1LL << 28), TS_ERR_UNSUPPORTED, "ts_devox_order: too many voxels for a 32-bit run key");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(idx && order && ws, TS_ERR_INVALID_ARGUMENT, "ts_devox_order: null pointer");
+  TS_REQUIRE((((uintptr_t)idx) & 15) == 0, TS_ERR_INVALID_ARGUMENT, "ts_devox_order: idx must be 16-byte aligned");
+  TS_REQUIRE(ws_bytes >= ts_devox_order_workspace_bytes(n), TS_ERR_INVALID_ARGUMENT, "ts_devox_order: workspace too small");
+  char *p = (char *)ws;
+  const size_t kb = ts_align_up((size_t)n * 4, 256);
+  unsigned *keys = (unsigned *)p;
+  unsigned *keys_out = (unsigned *)(p + kb);
+  int *vals = (int *)(p + 2 * kb);
+  void *tmp = p + 3 * kb;
+  size_t tmp_bytes = ws_bytes - 3 * kb, need = 0;
+  devox_key_kernel<<<(unsigned)ts_cdiv(n, 256), 256, 0, stream>>>(idx, n, keys, vals);
+  TS_CHECK_LAUNCH("ts_devox_order/keys");
+  unsigned end_bit = 32;
+  TS_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, need, keys, keys_out, vals, order, (size_t)n, 0u, end_bit, stream),
+               "radix_sort_pairs size query");
+  TS_REQUIRE(need <= tmp_bytes, TS_ERR_INVALID_ARGUMENT, "ts_devox_order: workspace too small for the sort");
+  TS_CHECK_HIP(rocprim::radix_sort_pairs(tmp, need, keys, keys_out, vals, order, (size_t)n, 0u, end_bit, stream),
+               "radix_sort_pairs");
+  return TS_OK;
+}

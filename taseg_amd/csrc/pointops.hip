@@ -145,6 +145,73 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_kernel(const float *__rest
   }
 }
 
+// backward over runs of points with identical corner tuples (points of one interpolation cell): the lane group of
+// a run accumulates w[i,k] * gout[i,:] for the 8 corners in registers and issues the atomics once per run.
+// `order` (optional) is the walk order (ts_devox_order groups equal tuples); each group of c/4 lanes takes
+// `run_len` consecutive positions.  With n / #cells points per cell this divides the atomic count - and the
+// contention on the few coarse voxels (stride 16: ~70 points per cell, 8 x 256 atomics per point before) - by
+// the run length.
+__global__ __launch_bounds__(256) void devoxelize_bwd_runs_kernel(const float *__restrict__ gout,
+                                                                  const int *__restrict__ idx,
+                                                                  const float *__restrict__ w,
+                                                                  const int *__restrict__ order, int64_t n, int c,
+                                                                  int64_t m, int run_len, float *__restrict__ gfeat) {
+  const int cq = c >> 2, groups = 256 / cq;
+  const int grp = threadIdx.x / cq, lane = threadIdx.x - grp * cq;
+  if (grp >= groups) return;
+  const int64_t p_beg = ((int64_t)blockIdx.x * groups + grp) * run_len;
+  const int64_t p_end = min(n, p_beg + run_len);
+  int cur[8];
+  float4 acc[8];
+  unsigned live = 0;  // corners that received a non-zero weight in the current run
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    cur[k] = -1;
+    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if ((live >> k) & 1) {
+        float *dst = gfeat + (int64_t)cur[k] * c + 4 * lane;
+        atomicAdd(dst + 0, acc[k].x);
+        atomicAdd(dst + 1, acc[k].y);
+        atomicAdd(dst + 2, acc[k].z);
+        atomicAdd(dst + 3, acc[k].w);
+      }
+      acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    live = 0;
+  };
+  for (int64_t p = p_beg; p < p_end; ++p) {
+    const int64_t i = order ? order[p] : p;
+    const int4 ia = *(const int4 *)(idx + i * 8), ib = *(const int4 *)(idx + i * 8 + 4);
+    const float4 wa = *(const float4 *)(w + i * 8), wb = *(const float4 *)(w + i * 8 + 4);
+    const int id[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+    const float wk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) same = same && (id[k] == cur[k]);
+    if (!same) {
+      if (live) flush();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cur[k] = id[k];
+    }
+    const float4 g = *(const float4 *)(gout + i * c + 4 * lane);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (id[k] >= 0 && id[k] < m && wk[k] != 0.f) {
+        acc[k].x += wk[k] * g.x;
+        acc[k].y += wk[k] * g.y;
+        acc[k].z += wk[k] * g.z;
+        acc[k].w += wk[k] * g.w;
+        live |= 1u << k;
+      }
+    }
+  }
+  if (live) flush();
+}
+
 extern "C" int ts_devoxelize_forward(const float *feat, const int32_t *idx, const float *weight, int64_t n,
                                      int32_t c, int64_t m, float *out, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -232,5 +299,27 @@ extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, 
   int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
   fuse_scan_kernel<<<grid, 256, 0, stream>>>((const float4 *)points, n, pose0, pose, (float4 *)out);
   TS_CHECK_LAUNCH("ts_fuse_scan");
+  return TS_OK;
+}
+
+extern "C" int ts_devoxelize_backward_runs(const float *grad_out, const int32_t *idx, const float *weight,
+                                           const int32_t *order, int64_t n, int32_t c, int64_t m, float *grad_feat,
+                                           ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_runs: bad sizes");
+  TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_runs: C must be a multiple of 4, <= 1024");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(grad_feat, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_runs: null pointer");
+  TS_CHECK_HIP(hipMemsetAsync(grad_feat, 0, (size_t)m * c * 4, stream), "devoxelize memset");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(grad_out && idx && weight, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_runs: null pointer");
+  TS_REQUIRE(((((uintptr_t)grad_out) | ((uintptr_t)idx) | ((uintptr_t)weight) | ((uintptr_t)grad_feat)) & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_runs: pointers must be 16-byte aligned");
+  const int run_len = 32;
+  const int groups = 256 / (c >> 2);
+  const int64_t n_groups = ts_cdiv(n, run_len);
+  devoxelize_bwd_runs_kernel<<<(unsigned)ts_cdiv(n_groups, groups), 256, 0, stream>>>(grad_out, idx, weight, order, n,
+                                                                                      c, m, run_len, grad_feat);
+  TS_CHECK_LAUNCH("ts_devoxelize_backward_runs");
   return TS_OK;
 }

@@ -233,13 +233,15 @@ class MinkUNetBackbone(BaseSegmentor):
         with torch.no_grad():
             probe = SparseTensor(None, coords, 1)
             spF.build_pyramid(probe, num_levels=4)
-            tri_idx, tri_w = {}, {}
+            tri_idx, tri_w, tri_order = {}, {}, {}
             pc = point_coords.contiguous()
             for s in (1, 16, 4):
                 key = (s, s, s)
                 tri_idx[key], tri_w[key] = B.trilinear_map(pc, probe.cmaps[key], s)
+                if s > 1:   # many points per interpolation cell: group them for the devoxelize backward
+                    tri_order[key] = B.devox_order(tri_idx[key], probe.cmaps[key].shape[0])
         return dict(coords=coords, point_coords=pc, cmaps=probe.cmaps, kmaps=probe.kmaps, tri_idx=tri_idx,
-                    tri_w=tri_w, **extra)
+                    tri_w=tri_w, tri_order=tri_order, **extra)
 
     def prepare(self, batch_dict):
         """Build the index plan of `batch_dict` and leave it under batch_dict['_plan'] (forward() does this
@@ -251,6 +253,7 @@ class MinkUNetBackbone(BaseSegmentor):
         x0 = SparseTensor(feats, plan["coords"], 1)
         x0.cmaps, x0.kmaps = plan["cmaps"], plan["kmaps"]
         z = PointTensor(point_feats, plan["point_coords"], idx_query=plan["tri_idx"], weights=plan["tri_w"])
+        z.additional_features["devox_order"] = plan["tri_order"]
         if "vox_idx" in plan:
             z.additional_features["idx_query"][1] = plan["vox_idx"]
             z.additional_features["counts"][1] = plan["vox_counts"]

@@ -75,7 +75,8 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> Po
         idx_query, weights = _trilinear(x, z, nearest)
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
-    out = PointTensor(F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s]), z.C,
+    order = (z.additional_features.get("devox_order") or {}).get(x.s)     # backward walk order, if the plan built one
+    out = PointTensor(F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s], order), z.C,
                       idx_query=z.idx_query, weights=z.weights)
     out.additional_features = z.additional_features
     return out

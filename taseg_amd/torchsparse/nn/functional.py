@@ -78,23 +78,29 @@ def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) 
 class _Devoxelize(Function):
     @staticmethod
     @_fwd
-    def forward(ctx, feats, idx, weights):
+    def forward(ctx, feats, idx, weights, order=None):
         idx = idx.int().contiguous()
         weights = weights.contiguous()
         out = B.devoxelize_forward_cuda(feats.contiguous(), idx, weights)
-        ctx.saved = (idx, weights, feats.shape[0])
+        ctx.saved = (idx, weights, feats.shape[0], order)
         return out
 
     @staticmethod
     @_bwd
     def backward(ctx, grad_out):
-        idx, weights, m = ctx.saved
-        return B.devoxelize_backward_cuda(grad_out.contiguous(), idx, weights, m), None, None
+        idx, weights, m, order = ctx.saved
+        grad_out = grad_out.contiguous()
+        if grad_out.shape[1] % 4 == 0 and grad_out.shape[1] <= 1024:
+            return B.devoxelize_backward_runs(grad_out, idx, weights, m, order), None, None, None
+        return B.devoxelize_backward_cuda(grad_out, idx, weights, m), None, None, None
 
 
-def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
-    """devoxelize.py:96-98: out[i] = sum_k weights[i,k] * feats[coords[i,k]]."""
-    return _Devoxelize.apply(feats, coords, weights)
+def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tensor,
+                 order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """devoxelize.py:96-98: out[i] = sum_k weights[i,k] * feats[coords[i,k]].  `order` (optional, from
+    `backend.devox_order`) only schedules the backward pass: points of the same interpolation cell are walked
+    together so their contributions reach the voxel gradient as one atomic per run."""
+    return _Devoxelize.apply(feats, coords, weights, order)
 
 
 def calc_ti_weights(coords: torch.Tensor, idx_query: torch.Tensor, scale: float = 1) -> torch.Tensor:

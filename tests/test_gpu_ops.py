@@ -218,6 +218,32 @@ def test_devoxelize_adjoint_property(B, F):
     close(ax, O.devoxelize_forward(x, idx, w), 1e-5)
 
 
+@pytest.mark.parametrize("c", [32, 96, 256])
+@pytest.mark.parametrize("stride", [1, 4, 16])
+def test_devoxelize_backward_runs_equals_atomic_kernel(B, F, c, stride):
+    """run-grouped backward (with and without the cell order) == the per-point atomic kernel == the oracle adjoint,
+    on real trilinear maps: many points per cell at coarse strides, points on voxel centres at stride 1"""
+    from taseg_amd.data.synthetic import synth_scan
+    pts, _ = synth_scan(3, n_points=30000)
+    pc = np.unique(np.round(pts[:, :3] / 0.05).astype(np.int32), axis=0)
+    pc -= pc.min(0, keepdims=True)
+    coords = T(np.concatenate([pc, np.zeros((len(pc), 1), np.int32)], 1))
+    vox = F.spdownsample(coords, stride, stride, 1) if stride > 1 else coords
+    points = coords.float() + (0.0 if stride == 1 else 0.25)
+    idx, w = B.trilinear_map(points.contiguous(), vox, stride)
+    order = B.devox_order(idx, vox.shape[0])
+    assert sorted(order.tolist()) == list(range(len(pc)))                 # a permutation
+    first = (idx >= 0).int().argmax(1)                                   # first present corner identifies the cell
+    key = torch.where((idx >= 0).any(1), idx.gather(1, first[:, None])[:, 0].long() * 8 + first, torch.tensor(1 << 40, device=DEV))
+    assert bool((key[order.long()][1:] >= key[order.long()][:-1]).all())  # equal tuples are adjacent (sorted by cell key)
+    g = T(np.random.RandomState(c + stride).randn(len(pc), c).astype(np.float32))
+    want = B.devoxelize_backward_cuda(g, idx, w, vox.shape[0])
+    close(B.devoxelize_backward_runs(g, idx, w, vox.shape[0], order), want, 2e-5)
+    close(B.devoxelize_backward_runs(g, idx, w, vox.shape[0], None), want, 2e-5)
+    if c == 32:
+        close(want, O.devoxelize_backward(g.cpu().numpy(), idx.cpu().numpy(), w.cpu().numpy(), vox.shape[0]), 2e-5)
+
+
 # --------------------------------------------------------------------------- convolution
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("tag", ["a", "b"])
