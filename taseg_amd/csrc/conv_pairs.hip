@@ -275,11 +275,16 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_kernel(const float *__restri
 }
 
 // Fast path of pass 1 for the shapes every layer but the stem takes: C_in % 32 == 0, C_out % BN == 0, 16-byte
-// aligned operands.  Same tiling, pipeline and MFMA order as pair_gemm_kernel (bit-identical results), but the
-// staging code has no per-element guards: a thread keeps the 4 gathered row pointers of its A slots in registers
-// for the whole tile (read straight from the rulebook, no LDS round trip), every global access is one
-// unconditional 16-byte load, rows outside the current offset's segment are zeroed with a select after the load.
-// The generic kernel spends most of its issue slots on exec-mask branches around each of those loads.
+// aligned operands, K <= 63.  Same MFMA tiling and summation order as pair_gemm_kernel (bit-identical Z), but
+//  * tiles are cut per offset (tile t of offset k covers pairs nboffs[k] + 128 t ..), so no tile straddles an
+//    offset boundary: every workgroup runs exactly C_in / 32 steps.  (With flat 128-pair tiles the ~K straddlers
+//    run twice as long as the rest and set the duration of small layers.)  The grid is sized from the upper
+//    bound ceil(P / 128) + K; the tile -> (offset, first pair) map comes from the K + 1 prefix sums held in one
+//    VGPR (wave scan + ballot), surplus workgroups exit;
+//  * the staging code has no per-element guards: a thread keeps the 4 gathered row pointers of its A slots in
+//    registers for the whole tile (read straight from the rulebook), every global access is one unconditional
+//    16-byte load, rows beyond the tile's pairs are zeroed when they are written to LDS (a select right after the
+//    load would make the wave wait for the data before the MFMAs instead of after them).
 template <int BN, int WR, bool WT>
 __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__restrict__ X, int R,
                                                              const float *__restrict__ W, int O_total,
@@ -303,9 +308,23 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__r
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave / WC, wc = wave % WC;
-  const int64_t p0 = (int64_t)blockIdx.x * PG_BM;
-  const int np = (int)min((int64_t)PG_BM, P - p0);
   const int o0 = blockIdx.y * BN;
+
+  // ---- tile -> (offset k, first pair, rows): lane l holds nboffs[l] and the tile count of offset l
+  const int offv = nboffs[min(lane, K)];
+  const int offn = nboffs[min(lane + 1, K)];
+  int incl = lane < K ? (offn - offv + PG_BM - 1) / PG_BM : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int tile = blockIdx.x;
+  if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;  // uniform: beyond the last tile
+  const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
+  const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
+  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * PG_BM;
+  const int np = min(PG_BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
 
   // gathered rows of this thread's A slots: slot it covers tile row (tid >> 3) + 32 it, floats 4 (tid & 7) ..+3
   const int arow0 = tid >> 3, acol = (tid & 7) << 2;
@@ -313,10 +332,10 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__r
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int rr = arow0 + 32 * it;
-    const int2 pr = nbmaps[min(p0 + rr, P - 1)];
+    const int2 pr = nbmaps[p0 + min(rr, np - 1)];
     aptr[it] = X + (int64_t)(gcol ? pr.y : pr.x) * R + acol;
   }
-  // this thread's B slots (element offsets relative to the (offset, slice) base)
+  // this thread's B slots (element offsets relative to the slice base)
   int boff[B_IT], bdst[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
@@ -332,27 +351,7 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__r
       bdst[it] = col * PG_AP + c4;
     }
   }
-
-  int k_lo = 0, k_hi = 0;
-  for (int k = 0; k < K; ++k) {
-    int b = nboffs[k];
-    if ((int64_t)b <= p0) k_lo = k;
-    if ((int64_t)b <= p0 + np - 1) k_hi = k;
-  }
-  auto segment = [&](int k, int &s0, int &s1) {
-    s0 = max((int)((int64_t)nboffs[k] - p0), 0);
-    s1 = min((int)((int64_t)nboffs[k + 1] - p0), np);
-  };
-  auto advance = [&](PgStep st) -> PgStep {
-    st.c0 += PG_BK;
-    if (st.c0 < R) return st;
-    st.c0 = 0;
-    for (++st.k; st.k <= k_hi; ++st.k) {
-      segment(st.k, st.s0, st.s1);
-      if (st.s1 > st.s0) break;
-    }
-    return st;
-  };
+  const float *wk = WT ? W + ((int64_t)k * O_total + o0) * R : W + (int64_t)k * R * O_total + o0;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -360,29 +359,26 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__r
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[A_IT], rb[B_IT];  // one register stage: the loads of step t+1 fly during the MFMAs of step t
-  auto load_regs = [&](const PgStep &st) {
+  f32x4 ra[A_IT], rb[B_IT];  // one register stage: the loads of slice c0 + 32 fly during the MFMAs of slice c0
+  auto load_regs = [&](int c0) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      ra[it] = *(const f32x4 *)(aptr[it] + st.c0);
-    }
-    const float *wb = WT ? W + ((int64_t)st.k * O_total + o0) * R + st.c0
-                         : W + ((int64_t)st.k * R + st.c0) * O_total + o0;
+    for (int it = 0; it < A_IT; ++it) ra[it] = *(const f32x4 *)(aptr[it] + c0);
+    const float *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(const f32x4 *)(wb + boff[it]);
   };
-  // rows outside the step's segment are zeroed here, not at the load: a select right after the load would make
-  // the wave wait for the data before the MFMAs instead of after them
-  auto store_lds = [&](float *At, float *Bt, const PgStep &st) {
+  auto store_lds = [&](float *At, float *Bt) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int rr = arow0 + 32 * it;
-      const bool in = rr >= st.s0 && rr < st.s1;
-      *(f32x4 *)&At[rr * PG_AP + acol] = in ? ra[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      *(f32x4 *)&At[rr * PG_AP + acol] = rr < np ? ra[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) *(f32x4 *)&Bt[bdst[it]] = rb[it];
   };
+  // MFMA over one staged slice.  k-slot permutation as in conv.hip: lane group g supplies reduction index
+  // 4 g + s in step s, so A (and W^T) fragments are single 16-byte LDS reads.  Reduction step outermost:
+  // consecutive MFMAs hit different accumulators.
   auto mma = [&](const float *At, const float *Bt) {
 #pragma unroll
     for (int j = 0; j < PG_BK; j += 16) {
@@ -424,24 +420,15 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__r
     }
   };
 
-  PgStep cur;
-  cur.k = k_lo - 1;
-  cur.c0 = R;
-  cur.s0 = cur.s1 = 0;
-  cur = advance(cur);
-  load_regs(cur);
-  for (int t = 0;; ++t) {
+  load_regs(0);
+  for (int c0 = 0, t = 0; c0 < R; c0 += PG_BK, ++t) {
     float *At = Abuf + (t & 1) * A_FLOATS, *Bt = Bbuf + (t & 1) * B_FLOATS;
-    store_lds(At, Bt, cur);
+    store_lds(At, Bt);
     __syncthreads();   // LDS is double buffered: one barrier per step
-    const PgStep nxt = advance(cur);
-    const bool more = nxt.k <= k_hi;
-    if (more) load_regs(nxt);
+    if (c0 + PG_BK < R) load_regs(c0 + PG_BK);
     mma(At, Bt);
-    if (!more) break;
-    cur = nxt;
   }
-  float *zt = Z + p0 * O_total + o0;
+  float *zt = Z + (int64_t)p0 * O_total + o0;
   if (np == PG_BM) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -476,16 +463,16 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
   }
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
   const bool fast = (R % PG_BK == 0) && (O_total % BN == 0) && ((((uintptr_t)X) | ((uintptr_t)W)) & 15) == 0 &&
-                    g_ts_conv_impl != 2;
+                    K <= 63 && g_ts_conv_impl != 2;
   if (fast) {
-    auto fkern = pair_gemm_fast_kernel<BN, WR, WT>;
     static bool fattr_set = false;
     if (!fattr_set) {
-      TS_CHECK_HIP(hipFuncSetAttribute((const void *)fkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                   "hipFuncSetAttribute");
+      TS_CHECK_HIP(hipFuncSetAttribute((const void *)pair_gemm_fast_kernel<BN, WR, WT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
       fattr_set = true;
     }
-    pair_gemm_fast_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
+    dim3 fgrid((unsigned)(ts_cdiv(P, PG_BM) + K), grid.y);   // upper bound on sum_k ceil(n_k / 128)
+    pair_gemm_fast_kernel<BN, WR, WT><<<fgrid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
   } else {
     pair_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
   }
@@ -823,9 +810,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__
     idxA[t] = col_a ? pr.y : pr.x;
     idxB[t] = col_a ? pr.x : pr.y;
   }
-  int k = 0;
-  for (int kk = 0; kk < K; ++kk)
-    if (nboffs[kk] <= p_beg) k = kk;
+  // prefix sums in one VGPR, offset of the first pair by ballot (see pair_gemm_fast_kernel)
+  const int offv = nboffs[min(lane, K)];
+  const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < K && offv <= p_beg)) - 1;
+  auto off_at = [&](int kk) { return __builtin_amdgcn_readlane(offv, kk); };
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -837,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__
     int k, p0, np;
   };
   auto advance = [&](WStep st) -> WStep {
-    int kend = min(nboffs[st.k + 1], p_end);
+    int kend = min(off_at(st.k + 1), p_end);
     int pn = st.p0 + WG_PS;
     if (pn < kend) {
       st.p0 = pn;
@@ -846,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__
     }
     pn = kend;
     for (++st.k; st.k < K && pn < p_end; ++st.k) {
-      kend = min(nboffs[st.k + 1], p_end);
+      kend = min(off_at(st.k + 1), p_end);
       if (kend > pn) {
         st.p0 = pn;
         st.np = min(WG_PS, kend - pn);
@@ -891,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__
   WStep cur;
   cur.k = k;
   cur.p0 = p_beg;
-  cur.np = min(WG_PS, min(nboffs[k + 1], p_end) - p_beg);
+  cur.np = min(WG_PS, min(off_at(k + 1), p_end) - p_beg);
   __syncthreads();  // pair indices visible
   load_regs(cur);
   int buf = 0;
@@ -959,7 +947,7 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   chunk = std::min<int64_t>(WG_MAXCHUNK, std::max<int64_t>(128, (chunk + WG_PS - 1) / WG_PS * WG_PS));
   dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
   const bool fast = (CA % TM == 0) && (CB % TN == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
-                    g_ts_conv_impl != 2;
+                    K <= 63 && g_ts_conv_impl != 2;
   if (fast)
     wgrad_gemm_fast_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
                                                             (int)chunk, dW);
