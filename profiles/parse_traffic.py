@@ -37,8 +37,8 @@ if __name__ == "__main__":
     write, n2 = collect(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("pair_gemm", "gather_sum", "wgrad_gemm", "bn_reduce", "conv_nbr", "kmap_",
-                                    "devoxelize", "voxelize", "trilinear", "table_", "hash_kernel")):
+        if not any(s in k for s in ("pair_gemm", "gather_sum", "wgrad_gemm", "bn_", "conv_nbr", "kmap_",
+                                    "devoxelize", "voxelize", "trilinear", "table_", "hash_kernel", "devox_")):
             continue
         f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
         out[k] = {"hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0, "fetch_kib_raw": f_kib, "write_kib": w_kib,
