@@ -290,6 +290,20 @@ int ts_devox_order(const int32_t *idx, int64_t n, int64_t n_vox, int32_t *order,
 int ts_devoxelize_backward_runs(const float *grad_out, const int32_t *idx, const float *weight, const int32_t *order,
                                 int64_t n, int32_t c, int64_t m, float *grad_feat, ts_stream_t stream);
 
+/* TIAF image -> point gather (R pcseg/model/segmentor/voxel/minkunet/unet2d.py:180-214) on the NCHW stack:
+ *   out[n, c] = feat[first_frame(b_n) + row_n / H, c, (row_n % H) >> shift, col_n >> shift]
+ * feat [T, C, H >> shift, W >> shift] f32 (the stacked camera frames of all samples), pix [n, 2] f32 = (row, col) in
+ * the sample's tall (T_b * H, W) image (truncated like the reference's `.long()`), pbatch [n] sample index,
+ * frame_end [n_batch] cumulative frame counts (`offset_img`), shift = 0 (full scale) or 2 (the 1/4-scale map,
+ * `row // 4, col // 4`).  *err is set to 1 if a pixel falls outside its sample's frames (the reference raises).
+ * The backward zeroes grad_feat and accumulates with float atomics. */
+int ts_image_gather_forward(const float *feat, const float *pix, const int32_t *pbatch, const int32_t *frame_end,
+                            int64_t n_pts, int32_t n_batch, int32_t T, int32_t C, int32_t H, int32_t W,
+                            int32_t shift, float *out, int32_t *err, ts_stream_t stream);
+int ts_image_gather_backward(const float *grad_out, const float *pix, const int32_t *pbatch, const int32_t *frame_end,
+                             int64_t n_pts, int32_t n_batch, int32_t T, int32_t C, int32_t H, int32_t W,
+                             int32_t shift, float *grad_feat, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply. */

@@ -301,3 +301,21 @@ def trilinear_map(points_float4, vox_coords, stride):
     idx = sphashquery(sphash(base, off), sphash(vox_coords))            # [8, N]
     w = calc_ti_weights(p, idx, scale=s)
     return idx.T.copy(), w.T.copy()
+
+
+def image_gather(feat, pix, pbatch, frame_end, shift=0):
+    """R/pcseg/model/segmentor/voxel/minkunet/unet2d.py:180-209: the frames [start:end] of every sample are laid out
+    as one tall NHWC image (`permute(0, 2, 3, 1)[start:end].reshape(-1, w, c)`) and indexed with
+    (`row.long()`, `col.long()`), the 1/4-scale map with (`row // 4`, `col // 4`); per-sample results are
+    concatenated in sample order (= point order for a collated, batch-sorted FOV cloud).
+    feat [T, C, H >> shift, W >> shift], pix [n, 2] float, pbatch [n] int, frame_end [B] cumulative."""
+    feat = np.asarray(feat)
+    pix = np.asarray(pix).astype(np.int64)           # .long(): truncation of non-negative floats
+    pbatch = np.asarray(pbatch)
+    outs, start = [], 0
+    for b, end in enumerate(np.asarray(frame_end).tolist()):
+        tall = np.transpose(feat[start:end], (0, 2, 3, 1)).reshape(-1, feat.shape[3], feat.shape[1])
+        p = pix[pbatch == b]
+        outs.append(tall[p[:, 0] >> shift, p[:, 1] >> shift])
+        start = end
+    return np.concatenate(outs, 0)

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ts_devox_order_workspace_bytes": (_sz, [_i64]),
     "ts_devox_order": (_i32, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "ts_devoxelize_backward_runs": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ts_image_gather_forward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ts_image_gather_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_quantize_workspace_bytes": (_sz, [_i64]),

@@ -17,7 +17,7 @@ __all__ = [
     "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
-    "fuse_scan", "voxel_coords", "sparse_quantize", "set_conv_impl",
+    "fuse_scan", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
 
@@ -447,6 +447,40 @@ def bn_backward_reduce(grad_out, x, mean):
     L.check(L.load().ts_bn_backward_reduce(L.ptr(grad_out), L.ptr(x), L.ptr(mean), x.shape[0], x.shape[1],
                                            L.ptr(sums), L.stream()), "ts_bn_backward_reduce")
     return sums
+
+
+def image_gather_forward(feat, pix, pbatch, frame_end, height, width, shift=0):
+    """out[n, c] = feat[first_frame(b_n) + row_n // H, c, (row_n % H) >> shift, col_n >> shift]  (unet2d.py:180-214).
+
+    feat [T, C, H >> shift, W >> shift]; pix [n, 2] float (row in the sample's stacked frames, col); pbatch [n]
+    int32; frame_end [B] int32 cumulative frame counts.  Returns (out [n, C], err int32[1]) - err != 0 if a pixel
+    lies outside its sample's frames (checked lazily by the caller: reading it is a host sync)."""
+    L.require_device(feat, pix, pbatch, frame_end)
+    feat, pix = _f32(feat, "feat"), _f32(pix, "pix")
+    pbatch, frame_end = _i32(pbatch, "pbatch"), _i32(frame_end, "frame_end")
+    t, c, hs, ws = feat.shape
+    if (hs, ws) != (height >> shift, width >> shift):
+        raise ValueError(f"feature map {hs}x{ws} does not match {height}x{width} >> {shift}")
+    n = pix.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=feat.device)
+    err = torch.zeros(1, dtype=torch.int32, device=feat.device)
+    L.check(L.load().ts_image_gather_forward(L.ptr(feat), L.ptr(pix), L.ptr(pbatch), L.ptr(frame_end), n,
+                                             frame_end.shape[0], t, c, int(height), int(width), int(shift),
+                                             L.ptr(out), L.ptr(err), L.stream()), "ts_image_gather_forward")
+    return out, err
+
+
+def image_gather_backward(grad_out, pix, pbatch, frame_end, frames, height, width, shift=0):
+    """Adjoint of image_gather_forward: grad_feat [T, C, H >> shift, W >> shift] (float atomics)."""
+    L.require_device(grad_out, pix, pbatch, frame_end)
+    grad_out, pix = _f32(grad_out, "grad_out"), _f32(pix, "pix")
+    pbatch, frame_end = _i32(pbatch, "pbatch"), _i32(frame_end, "frame_end")
+    n, c = grad_out.shape
+    out = torch.empty((int(frames), c, height >> shift, width >> shift), dtype=torch.float32, device=grad_out.device)
+    L.check(L.load().ts_image_gather_backward(L.ptr(grad_out), L.ptr(pix), L.ptr(pbatch), L.ptr(frame_end), n,
+                                              frame_end.shape[0], int(frames), c, int(height), int(width), int(shift),
+                                              L.ptr(out), L.stream()), "ts_image_gather_backward")
+    return out
 
 
 def set_conv_impl(impl):

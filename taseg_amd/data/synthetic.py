@@ -49,6 +49,8 @@ def fill_parameters(module, seed=0):
             elif name.endswith(".kernel"):
                 fan = t.shape[-2] * (t.shape[0] if t.ndim == 3 else 1)
                 t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (3.0 / fan) ** 0.5)
+            elif t.ndim == 4:  # dense Conv2d weight [out, in, kh, kw] (TIAF image branch)
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (3.0 / (t.shape[1] * t.shape[2] * t.shape[3])) ** 0.5)
             elif t.ndim == 2:  # linear weight
                 t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (3.0 / t.shape[1]) ** 0.5)
             elif name.endswith("weight"):  # BN gamma
@@ -169,3 +171,28 @@ def synth_scan(seed, n_points=120000, n_beams=64, n_az=2083, pose=None, scene_se
     inten = rs.uniform(0.0, 1.0, len(idx))
     out = np.concatenate([pts, inten[:, None]], 1).astype(np.float32)
     return out, label[idx].astype(np.uint8)
+
+
+TIAF_CFG = dict(INPUT_FEAT="rgb", INPUT_FEAT_LIDAR="lidar-image", IMAGE_BACKBONE_TYPE="UNet2D",
+                LIDAR_BACKBONE_TYPE="UNet3D", LOSS_WEIGHT=[0, 1, 0.5, 0.5, 1], FUSION_TYPE="cat", ENSEMBLE_TYPE="replace")
+"""MODEL section of the reference's TIAF config (tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10_fsa_tiaf.yaml:29-36)."""
+
+
+def synth_tiaf_sample(coords, feats, seed, frames=2, height=32, width=64):
+    """Camera side of one synthetic TIAF sample for a voxelised cloud (coords [n,3] int, feats [n,>=4] metric
+    x,y,z,intensity...): a stack of `frames` random RGB frames + label maps, and the FOV subset of the cloud
+    (a 77 degree frontal wedge) with the pixel every FOV voxel projects to: row counts through the sample's
+    stacked frames (frame * height + v), as the reference's dataset stores it in the last two feature columns
+    (semantickitti_voxel_ms_mm.py; consumed by unet2d.py:196-209)."""
+    rs = np.random.RandomState(seed)
+    x, y, z = feats[:, 0], feats[:, 1], feats[:, 2]
+    fov = np.nonzero((x > 0.5) & (np.abs(y) < 0.8 * x))[0]
+    az = np.arctan2(y[fov], x[fov]) / np.arctan(0.8)                    # -1 .. 1 across the image
+    u = np.clip(((1.0 - az) * 0.5 * width).astype(np.int64), 0, width - 1)
+    v = np.clip(((2.0 - z[fov]) / 5.0 * height).astype(np.int64), 0, height - 1)
+    t = rs.randint(0, frames, size=len(fov))                            # which temporal frame sees the point
+    pix = np.stack([t * height + v, u], 1).astype(np.float32)
+    images = rs.rand(frames, 3, height, width).astype(np.float32)
+    sem = rs.randint(0, 20, size=(frames, 1, height, width)).astype(np.int64)
+    fov_feats = np.concatenate([feats[fov, :4].astype(np.float32), pix], 1)
+    return dict(fov_index=fov, fov_coords=coords[fov], fov_feats=fov_feats, images=images, semantic=sem)

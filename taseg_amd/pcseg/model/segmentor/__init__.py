@@ -3,14 +3,16 @@ hot-path models exist here; the other OpenPCSeg backbones are out of scope (SURV
 from .base_segmentors import BaseSegmentor
 from .voxel.minkunet.minkunet import MinkUNet
 from .voxel.minkunet.minkunet_ms import MinkUNetMs
+from .voxel.minkunet.minkunet_ms_mm import MinkUNetMsMm
 
 __all__ = {
     "MinkUNet": MinkUNet,
     "MinkUNetMs": MinkUNetMs,
+    "MinkUNetMsMm": MinkUNetMsMm,
 }
 
 _OUT_OF_SCOPE = ("RangeNet++", "SalsaNext", "FIDNet", "CENet", "Cylinder_TS", "SPVCNN", "RPVNet",
-                 "MinkUNetMsKd", "MinkUNetMsMm", "MinkUNetMsMmNus")
+                 "MinkUNetMsKd", "MinkUNetMsMmNus")
 
 
 def build_segmentor(model_cfgs, num_class):

@@ -250,6 +250,11 @@ class MinkUNetBackbone(BaseSegmentor):
 
     def _unet(self, feats: torch.Tensor, point_feats: torch.Tensor, plan) -> torch.Tensor:
         """stem .. classifier on the stride-1 voxel features and their point view; returns logits [N, num_class]."""
+        return self.classifier(torch.cat(self._unet_point_features(feats, point_feats, plan), dim=1))
+
+    def _unet_point_features(self, feats: torch.Tensor, point_feats: torch.Tensor, plan):
+        """The encoder / decoder pass; returns the three per-point feature blocks the classifier concatenates:
+        stride-16 encoder output, stride-4 and stride-1 decoder outputs, each devoxelised onto the points."""
         x0 = SparseTensor(feats, plan["coords"], 1)
         x0.cmaps, x0.kmaps = plan["cmaps"], plan["kmaps"]
         z = PointTensor(point_feats, plan["point_coords"], idx_query=plan["tri_idx"], weights=plan["tri_w"])
@@ -276,8 +281,7 @@ class MinkUNetBackbone(BaseSegmentor):
         y3 = self.up3[1](torchsparse.cat([self.up3[0](y2), x1]))
         y4 = self.up4[1](torchsparse.cat([self.up4[0](y3), x0]))
         z3 = voxel_to_point(y4, z2)
-
-        return self.classifier(torch.cat([z1.F, z2.F, z3.F], dim=1))
+        return z1.F, z2.F, z3.F
 
     def _train_outputs(self, logits, target, coords_xyz, offset):
         loss = self.criterion_losses(logits, target, xyz=coords_xyz, offset=offset)

@@ -1,0 +1,159 @@
+"""MinkUNetMsMm - TASeg's TIAF segmentor: temporal image aggregation and fusion
+(reference pcseg/model/segmentor/voxel/minkunet/minkunet_ms_mm.py:186-571).
+
+Three branches, five losses:
+  * `image_backbone` (UNet2D, dense, PyTorch-ROCm) on the stack of temporal camera frames; its logits and two decoder
+    feature maps are gathered at the pixels the FOV points project to (HIP `ts_image_gather_*`);
+  * `lidar_backbone` (UNet3D, sparse, HIP backend) on the FOV cloud with [LiDAR attributes | image features];
+  * the MinkUNet of `MinkUNetMs` on the whole fused cloud; the FOV encoder's stride-16 / 4 / 1 voxel features are
+    trilinearly devoxelised onto ALL points (`voxel_to_point_fov`), concatenated with the main branch's point
+    features and classified by `classifier_fusion` on the points that overlap the FOV cloud.
+Module names / state_dict follow the reference, so its checkpoints (and its `fix_part_param` fine-tuning recipe) load.
+"""
+import torch
+from torch import nn
+
+from taseg_amd.torchsparse import PointTensor
+from .minkunet import LazyScalar, MinkUNetBackbone
+from .unet2d import UNet2D
+from .unet3d import UNet3D
+from .utils import voxel_to_point_fov
+
+__all__ = ["MinkUNetMsMm"]
+
+
+class MinkUNetMsMm(MinkUNetBackbone):
+    def __init__(self, model_cfgs, num_class: int):
+        super().__init__(model_cfgs, num_class)
+        exp = self.block.expansion
+        cr = model_cfgs.get("cr", 1.0)
+        cs = [int(cr * x) for x in model_cfgs.get("PLANES", [32, 32, 64, 128, 256, 256, 128, 96, 96])]
+        self.input_feat = model_cfgs.get("INPUT_FEAT")
+        self.input_feat_lidar = model_cfgs.get("INPUT_FEAT_LIDAR")
+        self.image_channel_in = 3 * ("rgb" in self.input_feat) + 1 * ("depth" in self.input_feat) \
+            + 4 * ("lidar" in self.input_feat)
+        self.image_backbone_type = model_cfgs.get("IMAGE_BACKBONE_TYPE")
+        if self.image_backbone_type != "UNet2D":
+            raise NotImplementedError(f"IMAGE_BACKBONE_TYPE '{self.image_backbone_type}'")
+        self.image_backbone = UNet2D(self.image_channel_in, self.num_class)
+        self.image_channel_out = 96 + 128
+        self.lidar_channel_in = (self.in_feature_dim - 1) * ("lidar" in self.input_feat_lidar) \
+            + self.image_channel_out * ("image" in self.input_feat_lidar) \
+            + self.num_class * ("logit" in self.input_feat_lidar)
+        self.lidar_backbone_type = model_cfgs.get("LIDAR_BACKBONE_TYPE")
+        if self.lidar_backbone_type != "UNet3D":
+            raise NotImplementedError(f"LIDAR_BACKBONE_TYPE '{self.lidar_backbone_type}'")
+        # the reference's UNet3D hard-wires SyncBatchNorm (unet3d.py:200); it degrades to local statistics when
+        # no process group is up, which is also what our SyncBatchNorm does
+        self.lidar_backbone = UNet3D(self.lidar_channel_in, self.num_class, if_dist=True)
+
+        (self.lidar_weight, self.fusion_weight, self.image_weight_s, self.image_weight_d,
+         self.image_lidar_weight) = model_cfgs.get("LOSS_WEIGHT")
+        self.fusion_type = model_cfgs.get("FUSION_TYPE")
+        self.ensemble_type = model_cfgs.get("ENSEMBLE_TYPE")
+        if self.fusion_type != "cat":
+            raise NotImplementedError("only FUSION_TYPE 'cat' exists in the reference (minkunet_ms_mm.py:380,489)")
+        point_channels = (cs[4] + cs[6] + cs[8]) * exp
+        self.fusion_channel = 2 * point_channels
+        self.classifier_fusion = nn.Sequential(
+            nn.Linear(self.fusion_channel, point_channels), nn.BatchNorm1d(point_channels), nn.ReLU(inplace=True),
+            nn.Linear(point_channels, self.num_class))
+        self.weight_initialization()
+
+    def prepare(self, batch_dict):
+        x_ms = batch_dict["lidar_ms"]
+        plan = self._index_plan(x_ms.C, x_ms.C.float())
+        batch_dict["_plan"] = plan
+        return plan
+
+    def forward(self, batch_dict, return_logit=False, return_tta=False):
+        maps = []
+        if "rgb" in self.input_feat:
+            maps.append(batch_dict["image_ms"])
+        if "depth" in self.input_feat:
+            maps.append(batch_dict["depth_map_ms"])
+        if "lidar" in self.input_feat:
+            maps.append(batch_dict["lidar_map_ms"])
+        batch_dict["image_input"] = torch.cat(maps, dim=1)
+        batch_dict = self.image_backbone(batch_dict)
+
+        # FOV cloud: [LiDAR attributes | gathered image features | gathered image logits]
+        x_fov = batch_dict["lidar_fov_ms"]
+        cols = []
+        if "lidar" in self.input_feat_lidar:
+            cols.append(x_fov.F[:, :self.in_feature_dim - 1])
+        if "image" in self.input_feat_lidar:
+            cols.append(batch_dict["image_features_fov"])
+        if "logit" in self.input_feat_lidar:
+            cols.append(batch_dict["image_logits_fov"])
+        x_fov.F = torch.cat(cols, dim=-1)
+        fov_logits, x4_fov, y2_fov, y4_fov = self.lidar_backbone(batch_dict)
+
+        # main branch on the fused cloud
+        x_ms = batch_dict["lidar_ms"]
+        x_ms.F = x_ms.F[:, :self.in_feature_dim]
+        plan = batch_dict.get("_plan") or self.prepare(batch_dict)
+        z1, z2, z3 = self._unet_point_features(x_ms.F, x_ms.F, plan)
+        out_ms = self.classifier(torch.cat([z1, z2, z3], dim=1))
+
+        # FOV encoder features onto every point of the fused cloud (minkunet_ms_mm.py:483,494,505)
+        pts = PointTensor(x_ms.F, plan["point_coords"])
+        z1_fov = voxel_to_point_fov(x4_fov, pts).F
+        z2_fov = voxel_to_point_fov(y2_fov, pts).F
+        z3_fov = voxel_to_point_fov(y4_fov, pts).F
+        overlap = z1_fov.sum(-1) != 0
+        fusion_features = torch.cat([z1, z2, z3, z1_fov, z2_fov, z3_fov], dim=1)
+        out_fusion = self.classifier_fusion(fusion_features[overlap])
+
+        if self.training:
+            target = batch_dict["targets_ms"].F.long().cuda(non_blocking=True)
+            img_logits = batch_dict["image_logits"].permute(0, 2, 3, 1).reshape(-1, self.num_class)
+            img_targets = batch_dict["semantic_map_ms"].permute(0, 2, 3, 1).reshape(-1).to(target.dtype)
+            fov_targets = batch_dict["image_targets_fov"].to(target.dtype)
+            crit = self.criterion_losses
+            parts = {
+                "loss_lidar": crit(out_ms, target, xyz=x_ms.C[:, :3].float(), offset=batch_dict["offset_ms"])
+                * self.lidar_weight,
+                "loss_fusion": crit(out_fusion, target[overlap]) * self.fusion_weight,
+                "loss_image_s": crit(batch_dict["image_logits_fov"], fov_targets) * self.image_weight_s,
+                "loss_image_d": crit(img_logits, img_targets) * self.image_weight_d,
+                "loss_image_lidar": crit(fov_logits, fov_targets) * self.image_lidar_weight,
+            }
+            loss = sum(parts.values())
+            disp = {"loss": LazyScalar(loss), **{k: LazyScalar(v) for k, v in parts.items()}}
+            return {"loss": loss}, disp, dict(disp)
+
+        if self.ensemble_type == "replace":
+            out_ms = out_ms.clone()
+            out_ms[overlap] = out_fusion
+        invs_ms = batch_dict["inverse_map_ms"]
+        all_labels = batch_dict["targets_mapped"]
+        point_mask = batch_dict["point_mask"]
+        num_points_ms = batch_dict["num_points_ms"]
+        point_predict, point_labels, point_predict_logits = [], [], []
+        cursor = 0
+        for idx in range(int(invs_ms.C[:, -1].max()) + 1):
+            scene = x_ms.C[:, -1] == idx
+            cur_inv = invs_ms.F[invs_ms.C[:, -1] == idx]
+            n_ms = int(num_points_ms[idx])
+            mapped = out_ms[scene][cur_inv][point_mask[cursor: cursor + n_ms]]
+            n_cur = int(batch_dict["num_points"][idx])
+            if return_logit or return_tta:
+                point_predict.append(mapped.softmax(1)[:n_cur].cpu().numpy())
+            else:
+                point_predict.append(mapped.argmax(1)[:n_cur].cpu().numpy())
+                point_predict_logits.append(mapped[:n_cur].cpu().numpy())
+            point_labels.append(all_labels.F[all_labels.C[:, -1] == idx][:n_cur].cpu().numpy())
+            cursor += n_ms
+        return {"point_predict": point_predict, "point_labels": point_labels, "name": batch_dict["name"],
+                "point_predict_logits": point_predict_logits}
+
+    def forward_ensemble(self, batch_dict):
+        return self.forward(batch_dict, return_tta=True)
+
+    def fix_part_param(self):
+        """Freeze the fused-cloud MinkUNet; train the image branch, the FOV encoder and the fusion head
+        (minkunet_ms_mm.py:566-571: the TIAF stage starts from a trained MinkUNetMs checkpoint)."""
+        for name, p in self.named_parameters():
+            if not any(tag in name for tag in ("image_backbone", "classifier_fusion", "lidar_backbone")):
+                p.requires_grad = False

@@ -45,5 +45,10 @@ def g_minkunet_ms():
 
 
 @pytest.fixture(scope="session")
+def g_minkunet_ms_mm():
+    return _load("model_minkunet_ms_mm.npz")
+
+
+@pytest.fixture(scope="session")
 def g_multiscan():
     return _load("multiscan.npz")

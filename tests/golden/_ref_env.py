@@ -128,6 +128,25 @@ def setup_pcseg():
     return MinkUNet, MinkUNetMs
 
 
+def setup_pcseg_mm():
+    """The reference's TIAF segmentor (minkunet_ms_mm.py; call after setup_pcseg).  Its UNet3D hard-wires
+    nn.SyncBatchNorm, whose training forward refuses CPU tensors; with one process its statistics are the local
+    ones, i.e. nn.BatchNorm1d's - patched in for the CPU golden run."""
+    import torch.nn.functional as TF
+
+    def sync_bn_forward(self, x):
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        use_batch = self.training or (self.running_mean is None and self.running_var is None)
+        return TF.batch_norm(x, self.running_mean if not self.training or self.track_running_stats else None,
+                             self.running_var if not self.training or self.track_running_stats else None,
+                             self.weight, self.bias, use_batch, self.momentum, self.eps)
+
+    torch.nn.SyncBatchNorm.forward = sync_bn_forward
+    from pcseg.model.segmentor.voxel.minkunet.minkunet_ms_mm import MinkUNetMsMm
+    return MinkUNetMsMm
+
+
 def setup_datasets():
     from pcseg.data.dataset.semantickitti.semantickitti_ms import SemantickittiMsDataset
     from pcseg.data.dataset.semantickitti.semantickitti_voxel_ms import SemkittiVoxelMsDataset

@@ -21,8 +21,8 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
 import _ref_env  # noqa: E402
-from taseg_amd.data.synthetic import (FLEXIBLE_STEPS_KITTI, fill_parameters, make_model_cfg, synth_pose,  # noqa: E402
-                                      synth_scan)
+from taseg_amd.data.synthetic import (FLEXIBLE_STEPS_KITTI, TIAF_CFG, fill_parameters, make_model_cfg,  # noqa: E402
+                                      synth_pose, synth_scan, synth_tiaf_sample)
 
 torch.set_num_threads(1)
 BACKEND_DESC = _ref_env.setup_torchsparse()
@@ -232,6 +232,96 @@ def gen_model(cls, name, in_dim, key, fname):
     print(fname, "N =", coords.shape[0], "loss(train/eval) =", out["train_loss"], out["eval_loss"])
 
 
+# ----------------------------------------------------------------------------------------- TIAF (MinkUNetMsMm)
+def make_tiaf_batch(seeds):
+    """lidar_ms (voxelised fused cloud, 5 features) + camera stack + FOV cloud, collated like
+    semantickitti_voxel_ms_mm.py does: SparseTensors through sparse_collate_fn, image stacks concatenated along
+    the frame axis with cumulative `offset_img`."""
+    samples, images, sems, frames = [], [], [], []
+    for s in seeds:
+        pts, lab = small_scan(s)
+        pc_, inds, _ = dataset_voxelize(pts, lab)
+        feat = np.concatenate([pts, np.ones_like(pts[:, :1])], 1)[inds]
+        cam = synth_tiaf_sample(pc_[inds], feat, seed=s)
+        samples.append({"lidar_ms": SparseTensor(feat, pc_[inds]), "targets_ms": SparseTensor(lab[inds], pc_[inds]),
+                        "lidar_fov_ms": SparseTensor(cam["fov_feats"], cam["fov_coords"])})
+        images.append(cam["images"])
+        sems.append(cam["semantic"])
+        frames.append(len(cam["images"]))
+    batch = sparse_collate_fn(samples)
+    batch["image_ms"] = torch.from_numpy(np.concatenate(images))
+    batch["semantic_map_ms"] = torch.from_numpy(np.concatenate(sems))
+    batch["offset_img"] = torch.tensor(np.cumsum(frames))
+    batch["offset_ms"] = torch.tensor([0])
+    return batch
+
+
+def run_model_mm(cls, training):
+    # cr must be 1.0: the FOV encoder's widths are fixed (unet3d.py:194), classifier_fusion expects 2 x 480 inputs
+    cfg = make_model_cfg("MinkUNetMsMm", in_dim=5, cr=1.0, num_layer=[1] * 8, **TIAF_CFG)
+    torch.manual_seed(0)
+    model = cls(cfg, 20)
+    fill_parameters(model, seed=3)
+    bd = make_tiaf_batch([31, 32])
+    for k in ("lidar_ms", "lidar_fov_ms"):
+        bd[k].F = bd[k].F.float()
+        bd[k].C = bd[k].C.int()
+    inputs = {"coords": bd["lidar_ms"].C.numpy().copy(), "feats": bd["lidar_ms"].F.numpy().copy(),
+              "labels": bd["targets_ms"].F.numpy().astype(np.int64),
+              "fov_coords": bd["lidar_fov_ms"].C.numpy().copy(), "fov_feats": bd["lidar_fov_ms"].F.numpy().copy(),
+              "images": bd["image_ms"].numpy().copy(), "semantic": bd["semantic_map_ms"].numpy().copy(),
+              "offset_img": bd["offset_img"].numpy().copy()}
+    captured = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, key=key: captured.__setitem__(key, o.detach().numpy().copy()))
+             for key, m in (("logits", model.classifier), ("fusion_logits", model.classifier_fusion),
+                            ("fov_logits", model.lidar_backbone.classifier),
+                            ("image_logits", model.image_backbone.classifier))]
+    model.train()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.eval()                      # Dropout2d(0.2) of the image branch is random: off for the fixture
+        if not training and isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    ret, _, disp = model(bd)
+    for h in hooks:
+        h.remove()
+    loss = ret["loss"]
+    model.zero_grad()
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    tag = "train" if training else "eval"
+    keep = ["stem.0.kernel", "stage4.1.net.0.kernel", "up4.1.0.net.3.kernel", "image_backbone.stem.0.conv1.weight",
+            "image_backbone.stage3.conv2.weight", "image_backbone.up4.conv1.weight", "lidar_backbone.stem.0.kernel",
+            "lidar_backbone.stage4.1.net.0.kernel", "lidar_backbone.classifier.0.weight",
+            "classifier_fusion.0.weight", "classifier_fusion.3.weight"]
+    res = {f"{tag}_{k}": v for k, v in captured.items()}
+    res[f"{tag}_loss"] = np.array(loss.item())
+    res[f"{tag}_loss_parts"] = np.array([float(disp[k]) for k in ("loss_lidar", "loss_fusion", "loss_image_s",
+                                                                 "loss_image_d", "loss_image_lidar")])
+    for k in keep:
+        g = grads[k].numpy()
+        res[f"{tag}_grad/{k}"] = g[..., ::4, ::4] if g.size > 200000 else g   # every 4th row / column: fixture size
+    names = [n for n, p in model.named_parameters() if p.grad is not None]
+    res[f"{tag}_gradnames"] = np.array(names)
+    res[f"{tag}_gradnorms"] = np.array([float(grads[n].norm()) for n in names])
+    return cfg, model, inputs, res
+
+
+def gen_model_mm(fname="model_minkunet_ms_mm.npz"):
+    cls = _ref_env.setup_pcseg_mm()
+    out = {"backend": np.array(BACKEND_DESC)}
+    for training in (True, False):
+        cfg, model, inputs, res = run_model_mm(cls, training)
+        out.update(res)
+    out.update(inputs)
+    sd = model.state_dict()
+    out["state_keys"] = np.array(list(sd.keys()))
+    out["state_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "N =", inputs["coords"].shape[0], "N_fov =", inputs["fov_coords"].shape[0],
+          "loss(train/eval) =", out["train_loss"], out["eval_loss"], out["train_loss_parts"])
+
+
 # ----------------------------------------------------------------------------------------- multi-scan data stage
 def gen_multiscan():
     SemMs, SemVoxMs, _ = _ref_env.setup_datasets()
@@ -295,10 +385,14 @@ def gen_multiscan():
 
 if __name__ == "__main__":
     print("reference backend:", BACKEND_DESC)
+    if "--only-mm" in sys.argv:
+        gen_model_mm()
+        sys.exit(0)
     gen_ops()
     gen_model(MinkUNet, "MinkUNet", 4, "lidar", "model_minkunet.npz")
     gen_model(MinkUNetMs, "MinkUNetMs", 5, "lidar_ms", "model_minkunet_ms.npz")
     gen_multiscan()
+    gen_model_mm()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -1,0 +1,137 @@
+"""TIAF on the GPU: the image -> point gather kernel against plain indexing,
+and `MinkUNetMsMm` (UNet2D + UNet3D + fused-cloud MinkUNet + fusion head, five losses) against the logits / losses /
+gradients the REAL reference produced for the same inputs and parameters (tests/golden/model_minkunet_ms_mm.npz)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from taseg_amd.data.synthetic import TIAF_CFG, fill_parameters, make_model_cfg  # noqa: E402
+
+LOGIT_TOL = 1e-3
+
+
+def _reference_gather(feat, pix, pbatch, frame_end, shift):
+    """oracle.ts_oracle.image_gather with torch indexing (differentiable, for the adjoint check)."""
+    outs, start = [], 0
+    for b, end in enumerate(frame_end.tolist()):
+        tall = feat[start:end].permute(0, 2, 3, 1).reshape(-1, feat.shape[3], feat.shape[1])
+        p = pix[pbatch == b].long()
+        outs.append(tall[p[:, 0] >> shift, p[:, 1] >> shift])
+        start = end
+    return torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("shift,c", [(0, 96), (2, 128), (0, 1), (0, 20)])
+def test_image_gather_matches_indexing(shift, c):
+    from taseg_amd import backend as B
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import image_gather
+    g = torch.Generator().manual_seed(5)
+    frames, H, W = [3, 2, 4], 24, 40
+    frame_end = torch.tensor(np.cumsum(frames), dtype=torch.int32, device="cuda")
+    feat = torch.randn(sum(frames), c, H >> shift, W >> shift, generator=g).cuda().requires_grad_()
+    n = 5000
+    pbatch = torch.sort(torch.randint(0, 3, (n,), generator=g)).values.int().cuda()     # batch-sorted, as collated
+    rows = torch.stack([torch.randint(0, frames[b] * H, (1,), generator=g) for b in pbatch.tolist()]).view(-1)
+    pix = torch.stack([rows, torch.randint(0, W, (n,), generator=g)], 1).float().cuda()
+    out, err = image_gather(feat, pix, pbatch, frame_end, H, W, shift)
+    want = _reference_gather(feat, pix, pbatch, frame_end, shift)
+    assert int(err) == 0 and torch.equal(out, want)
+    from oracle import ts_oracle as O
+    assert np.array_equal(out.detach().cpu().numpy(), O.image_gather(feat.detach().cpu().numpy(), pix.cpu().numpy(),
+                                                                     pbatch.cpu().numpy(), frame_end.cpu().numpy(), shift))
+    w = torch.randn(n, c, generator=g).cuda()
+    (g_ours,) = torch.autograd.grad((out * w).sum(), feat)
+    (g_ref,) = torch.autograd.grad((want * w).sum(), feat)
+    assert float((g_ours - g_ref).abs().max()) <= 1e-5 * max(1.0, float(g_ref.abs().max()))
+    # a pixel beyond the sample's frames is reported, not read
+    bad = pix.clone()
+    bad[0, 0] = frames[0] * H + 1
+    _, err = B.image_gather_forward(feat.detach(), bad, pbatch, frame_end, H, W, shift)
+    assert int(err) == 1
+
+
+def _tiaf_batch(g):
+    from taseg_amd.torchsparse import SparseTensor
+    dev = "cuda"
+    coords = torch.from_numpy(g["coords"]).to(dev)
+    fov_coords = torch.from_numpy(g["fov_coords"]).to(dev)
+    return {
+        "lidar_ms": SparseTensor(torch.from_numpy(g["feats"]).to(dev), coords),
+        "targets_ms": SparseTensor(torch.from_numpy(g["labels"]).to(dev), coords),
+        "lidar_fov_ms": SparseTensor(torch.from_numpy(g["fov_feats"]).to(dev), fov_coords),
+        "image_ms": torch.from_numpy(g["images"]).to(dev),
+        "semantic_map_ms": torch.from_numpy(g["semantic"]).to(dev),
+        "offset_img": torch.from_numpy(g["offset_img"]).to(dev),
+        "offset_ms": torch.tensor([0], device=dev),
+    }
+
+
+def _build_mm():
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg("MinkUNetMsMm", in_dim=5, cr=1.0, num_layer=[1] * 8, **TIAF_CFG)
+    return cfg, fill_parameters(build_network(cfg, 20), seed=3).cuda()
+
+
+def test_tiaf_state_dict_matches_reference(g_minkunet_ms_mm):
+    _, model = _build_mm()
+    sd = model.state_dict()
+    ours = {k: ",".join(map(str, v.shape)) for k, v in sd.items()}
+    ref = dict(zip(g_minkunet_ms_mm["state_keys"].tolist(), g_minkunet_ms_mm["state_shapes"].tolist()))
+    assert ours == ref          # same names and shapes (registration order of the extra branches differs)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_tiaf_model_vs_reference_golden(g_minkunet_ms_mm, training):
+    g = g_minkunet_ms_mm
+    tag = "train" if training else "eval"
+    _, model = _build_mm()
+    model.train()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.eval()
+        if not training and isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    grabbed = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, key=key: grabbed.__setitem__(key, o.detach().cpu().numpy()))
+             for key, m in (("logits", model.classifier), ("fusion_logits", model.classifier_fusion),
+                            ("fov_logits", model.lidar_backbone.classifier),
+                            ("image_logits", model.image_backbone.classifier))]
+    bd = _tiaf_batch(g)
+    ret, tb, _ = model(bd)
+    for h in hooks:
+        h.remove()
+    assert int(bd["image_gather_err"]) == 0
+    for key in ("image_logits", "fov_logits", "logits", "fusion_logits"):
+        assert grabbed[key].shape == g[f"{tag}_{key}"].shape, key
+        assert np.abs(grabbed[key] - g[f"{tag}_{key}"]).max() <= LOGIT_TOL, key
+    parts = np.array([float(tb[k]) for k in ("loss_lidar", "loss_fusion", "loss_image_s", "loss_image_d",
+                                              "loss_image_lidar")])
+    assert np.abs(parts - g[f"{tag}_loss_parts"]).max() <= 1e-3
+    assert abs(float(tb["loss"]) - float(g[f"{tag}_loss"])) <= 2e-3
+    model.zero_grad()
+    ret["loss"].backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    tol = 2e-2 if training else 1e-4
+    for k in g:
+        if k.startswith(f"{tag}_grad/"):
+            a, b = grads[k.split("/", 1)[1]].cpu().numpy(), g[k]
+            if a.shape != b.shape:
+                a = a[..., ::4, ::4]
+            # the dense image branch runs on MIOpen (different convolution algorithms than the CPU reference)
+            ktol = max(tol, 1e-3) if "image_backbone" in k else tol
+            assert np.linalg.norm(a - b) <= ktol * np.linalg.norm(b), k
+    names = g[f"{tag}_gradnames"].tolist()
+    assert sorted(names) == sorted(grads)
+    norms = np.array([float(grads[n].norm()) for n in names])
+    assert np.allclose(norms, g[f"{tag}_gradnorms"], rtol=5e-2 if training else 2e-3, atol=1e-6)
+
+
+def test_tiaf_fix_part_param():
+    _, model = _build_mm()
+    model.fix_part_param()
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    free = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert frozen and all(not n.startswith(("image_backbone", "lidar_backbone", "classifier_fusion")) for n in frozen)
+    assert free and all(n.startswith(("image_backbone", "lidar_backbone", "classifier_fusion")) for n in free)

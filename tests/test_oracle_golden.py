@@ -181,3 +181,20 @@ def test_model_oracle_vs_reference(request, name, in_dim, fix, training):
         if key.startswith(f"{tag}_grad/"):
             a, b = params[key.split("/", 1)[1]].grad.numpy(), g[key]
             assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b), key
+
+
+def test_image_gather_oracle_reproduces_the_reference_image_loss(g_minkunet_ms_mm):
+    """TIAF row a16: the reference's sparse image loss (weight 0.5, minkunet_ms_mm.py:523) is CE + Lovasz over its
+    gathered logits / label map; recomputing it from the fixture's dense image logits with the oracle gather pins
+    the gather's index convention (stacked frames, (row, col) in the last two FOV feature columns)."""
+    g = g_minkunet_ms_mm
+    for tag in ("train", "eval"):
+        args = (g["fov_feats"][:, -2:], g["fov_coords"][:, 3], g["offset_img"])
+        logits = O.image_gather(g[f"{tag}_image_logits"], *args)
+        target = O.image_gather(g["semantic"].astype(np.float32), *args)[:, 0].astype(np.int64)
+        loss = 0.5 * float(OM.loss_ce_lovasz(torch.from_numpy(logits), torch.from_numpy(target)))
+        assert abs(loss - float(g[f"{tag}_loss_parts"][2])) <= 1e-5
+        dense = np.transpose(g[f"{tag}_image_logits"], (0, 2, 3, 1)).reshape(-1, 20)
+        dense_t = np.transpose(g["semantic"], (0, 2, 3, 1)).reshape(-1)
+        loss_d = 0.5 * float(OM.loss_ce_lovasz(torch.from_numpy(dense), torch.from_numpy(dense_t)))
+        assert abs(loss_d - float(g[f"{tag}_loss_parts"][3])) <= 1e-5
