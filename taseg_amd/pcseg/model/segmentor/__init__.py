@@ -3,16 +3,17 @@ hot-path models exist here; the other OpenPCSeg backbones are out of scope (SURV
 from .base_segmentors import BaseSegmentor
 from .voxel.minkunet.minkunet import MinkUNet
 from .voxel.minkunet.minkunet_ms import MinkUNetMs
-from .voxel.minkunet.minkunet_ms_mm import MinkUNetMsMm
+from .voxel.minkunet.minkunet_ms_mm import MinkUNetMsMm, MinkUNetMsMmNus
 
 __all__ = {
     "MinkUNet": MinkUNet,
     "MinkUNetMs": MinkUNetMs,
     "MinkUNetMsMm": MinkUNetMsMm,
+    "MinkUNetMsMmNus": MinkUNetMsMmNus,
 }
 
 _OUT_OF_SCOPE = ("RangeNet++", "SalsaNext", "FIDNet", "CENet", "Cylinder_TS", "SPVCNN", "RPVNet",
-                 "MinkUNetMsKd", "MinkUNetMsMmNus")
+                 "MinkUNetMsKd")
 
 
 def build_segmentor(model_cfgs, num_class):

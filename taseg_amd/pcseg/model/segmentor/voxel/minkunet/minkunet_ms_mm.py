@@ -19,7 +19,7 @@ from .unet2d import UNet2D
 from .unet3d import UNet3D
 from .utils import voxel_to_point_fov
 
-__all__ = ["MinkUNetMsMm"]
+__all__ = ["MinkUNetMsMm", "MinkUNetMsMmNus"]
 
 
 class MinkUNetMsMm(MinkUNetBackbone):
@@ -59,6 +59,10 @@ class MinkUNetMsMm(MinkUNetBackbone):
             nn.Linear(self.fusion_channel, point_channels), nn.BatchNorm1d(point_channels), nn.ReLU(inplace=True),
             nn.Linear(point_channels, self.num_class))
         self.weight_initialization()
+
+    def _fov_targets(self, batch_dict):
+        """labels of the FOV points: the camera label map at their pixels (minkunet_ms_mm.py:457)"""
+        return batch_dict["image_targets_fov"]
 
     def prepare(self, batch_dict):
         x_ms = batch_dict["lidar_ms"]
@@ -109,7 +113,7 @@ class MinkUNetMsMm(MinkUNetBackbone):
             target = batch_dict["targets_ms"].F.long().cuda(non_blocking=True)
             img_logits = batch_dict["image_logits"].permute(0, 2, 3, 1).reshape(-1, self.num_class)
             img_targets = batch_dict["semantic_map_ms"].permute(0, 2, 3, 1).reshape(-1).to(target.dtype)
-            fov_targets = batch_dict["image_targets_fov"].to(target.dtype)
+            fov_targets = self._fov_targets(batch_dict).to(target.dtype)
             crit = self.criterion_losses
             parts = {
                 "loss_lidar": crit(out_ms, target, xyz=x_ms.C[:, :3].float(), offset=batch_dict["offset_ms"])
@@ -157,3 +161,11 @@ class MinkUNetMsMm(MinkUNetBackbone):
         for name, p in self.named_parameters():
             if not any(tag in name for tag in ("image_backbone", "classifier_fusion", "lidar_backbone")):
                 p.requires_grad = False
+
+
+class MinkUNetMsMmNus(MinkUNetMsMm):
+    """nuScenes twin (minkunet_ms_mm_nus.py): identical network; the FOV points carry their own LiDAR labels
+    (`targets_fov_ms`), used for both the sparse image loss and the FOV-encoder loss (:454-455, :526)."""
+
+    def _fov_targets(self, batch_dict):
+        return batch_dict["targets_fov_ms"].F.reshape(-1)

@@ -135,3 +135,29 @@ def test_tiaf_fix_part_param():
     free = [n for n, p in model.named_parameters() if p.requires_grad]
     assert frozen and all(not n.startswith(("image_backbone", "lidar_backbone", "classifier_fusion")) for n in frozen)
     assert free and all(n.startswith(("image_backbone", "lidar_backbone", "classifier_fusion")) for n in free)
+
+
+def test_tiaf_nuscenes_twin_uses_point_labels(g_minkunet_ms_mm):
+    """MinkUNetMsMmNus == MinkUNetMsMm except that the FOV losses read `targets_fov_ms` (minkunet_ms_mm_nus.py:454-455)."""
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    g = g_minkunet_ms_mm
+    cfg = make_model_cfg("MinkUNetMsMmNus", in_dim=5, cr=1.0, num_layer=[1] * 8, **TIAF_CFG)
+    nus = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+    _, kitti = _build_mm()
+    kitti.train()
+    for model in (nus, kitti):
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+                m.eval()
+    bd = _tiaf_batch(g)
+    _, tb_k, _ = kitti(bd)
+    bd2 = _tiaf_batch(g)
+    bd2["targets_fov_ms"] = SparseTensor(bd["image_targets_fov"].clone(), bd2["lidar_fov_ms"].C)   # same labels
+    _, tb_n, _ = nus(bd2)
+    assert abs(float(tb_k["loss"]) - float(tb_n["loss"])) <= 1e-5
+    bd3 = _tiaf_batch(g)
+    bd3["targets_fov_ms"] = SparseTensor(bd["image_targets_fov"].roll(1), bd3["lidar_fov_ms"].C)   # other labels
+    _, tb_z, _ = nus(bd3)
+    assert abs(float(tb_z["loss_image_s"]) - float(tb_k["loss_image_s"])) > 1e-3
+    assert abs(float(tb_z["loss_image_d"]) - float(tb_k["loss_image_d"])) <= 1e-5      # dense image loss unaffected
