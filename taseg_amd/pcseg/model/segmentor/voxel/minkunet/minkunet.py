@@ -197,7 +197,7 @@ class MinkUNetBackbone(BaseSegmentor):
         self.up3 = decoder_stage(cs[7], cs[1] * exp, self.num_layer[6])
         self.up4 = decoder_stage(cs[8], cs[0], self.num_layer[7])
 
-        self.classifier = nn.Sequential(nn.Linear((cs[4] + cs[6] + cs[8]) * exp, self.num_class))
+        self.classifier = nn.Sequential(spnn.PointLinear((cs[4] + cs[6] + cs[8]) * exp, self.num_class))
         self.weight_initialization()
         self.dropout = nn.Dropout(model_cfgs.get("DROPOUT_P", 0.3), True)
 

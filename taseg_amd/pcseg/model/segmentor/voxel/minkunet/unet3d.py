@@ -47,7 +47,7 @@ class UNet3D(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self.dropout = nn.Dropout(0.0, True)
-        self.classifier = nn.Sequential(nn.Linear((cs[0] + cs[2] + cs[4]) * self.block.expansion, num_class))
+        self.classifier = nn.Sequential(spnn.PointLinear((cs[0] + cs[2] + cs[4]) * self.block.expansion, num_class))
 
     def forward(self, batch_dict):
         x = batch_dict["lidar_fov_ms"]

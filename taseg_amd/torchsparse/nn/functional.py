@@ -22,7 +22,7 @@ from ..utils import make_ntuple
 from .utils import get_kernel_offsets
 
 __all__ = ["conv3d", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
-           "spdownsample", "KernelMap", "build_kernel_map", "build_pyramid"]
+           "spdownsample", "KernelMap", "build_kernel_map", "build_pyramid", "point_linear"]
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = torch.amp.custom_bwd(device_type="cuda")
@@ -310,13 +310,51 @@ class _PointwiseConv(Function):
         return grad_feats, grad_weight, None
 
 
+class _PointLinear(Function):
+    """y = x W^T + b over per-point features (the classifier heads, minkunet.py:334-336).  The library GEMMs serve
+    forward and input gradient; the weight gradient gy^T x is the same tall-skinny reduction as in
+    `_PointwiseConv` (N ~ 2e5 rows, 20 x 480 outputs: hipBLASLt runs 15 workgroups for 480 us) and goes through
+    `ts_conv_wgrad` with the identity rulebook."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, weight, bias, ident):
+        ctx.save_for_backward(x, weight)
+        ctx.ident, ctx.has_bias = ident, bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        pairs, offs = ctx.ident
+        grad_out = grad_out.contiguous()
+        grad_x = grad_out.matmul(weight) if ctx.needs_input_grad[0] else None
+        grad_w = None
+        if ctx.needs_input_grad[1]:
+            grad_w = B.conv_wgrad(x.contiguous(), grad_out, pairs, offs, 1, col_a=0, max_pairs=x.shape[0])[0].t()
+        grad_b = grad_out.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return grad_x, grad_w, grad_b, None
+
+
+def point_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.functional.linear for [N, C] point features with the weight gradient on the HIP split-over-rows kernel."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 4096 and weight.requires_grad \
+            and torch.is_grad_enabled():
+        return _PointLinear.apply(x, weight, bias, _identity_rows(x.shape[0], x.device))
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 _ident_cache = {}
 
 
 def _identity_rulebook(input: SparseTensor):
+    return _identity_rows(input.feats.shape[0], input.feats.device)
+
+
+def _identity_rows(n, dev):
     """(pairs [n,2] = (i, i), nboffs = [0, n]) for the 1x1x1 weight gradient; a handful of row counts per step,
     kept in a small module-level cache (NOT in input.kmaps, which mirrors the reference's dictionary)."""
-    n, dev = input.feats.shape[0], input.feats.device
     key = (n, dev)
     hit = _ident_cache.get(key)
     if hit is None:

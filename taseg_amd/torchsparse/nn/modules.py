@@ -127,3 +127,11 @@ class ReLU(nn.ReLU):
 class LeakyReLU(nn.LeakyReLU):
     def forward(self, input: SparseTensor) -> SparseTensor:
         return fapply(input, super().forward)
+
+
+class PointLinear(nn.Linear):
+    """nn.Linear over [N, C] point features (same parameters / state_dict); training on a ROCm device routes the
+    weight gradient through the HIP reduction kernel (functional.point_linear)."""
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return F.point_linear(input, self.weight, self.bias)
