@@ -39,6 +39,11 @@ def parse():
                     help="build batch i's rulebooks at the head of step i on the launch stream instead of "
                          "during step i-1 on the staging stream")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
+    ap.add_argument("--local-bn", action="store_true",
+                    help="plain BatchNorm (per-rank statistics) instead of the reference configs' SyncBatchNorm")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-GPU code path (RCCL process group, DDP, SyncBatchNorm collectives) even with "
+                         "one rank - a single-GPU check of what `--gpus N` executes")
     ap.add_argument("--cpu-sector-deg", type=float, default=180.0)
     return ap.parse_args()
 
@@ -178,9 +183,14 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")      # RCCL on ROCm
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ["TASEG_SYNCBN_SINGLE_RANK"] = "1"
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)      # RCCL on ROCm
 
     from taseg_amd import backend as B
     from taseg_amd.data.synthetic import make_model_cfg
@@ -189,12 +199,14 @@ def main():
 
     ms = args.workload == "minkunet_ms"
     name = "MinkUNetMs" if ms else "MinkUNet"
-    cfg = make_model_cfg(name, in_dim=5 if ms else 4, cr=1.0, if_dist=world > 1)
+    cfg = make_model_cfg(name, in_dim=5 if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn)
     torch.manual_seed(0)
     model = build_network(cfg, 20).cuda().train()
     net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
+    if use_dist:
+        # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
+                                                        broadcast_buffers=False, static_graph=True)
     opt = torch.optim.SGD(model.parameters(), lr=0.02 * args.batch * world, momentum=0.9, weight_decay=1e-4)
 
     nvox = [0]
@@ -300,6 +312,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.points, args.cpu_sector_deg)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL prints its version banner through C stdio: flush it BEFORE the line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

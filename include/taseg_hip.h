@@ -277,6 +277,16 @@ int ts_bn_act_train_backward(const float *grad_out, const uint8_t *mask, const f
                              float *grad_residual, float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes,
                              ts_stream_t stream);
 
+/* SyncBatchNorm reductions (the all-reduce over ranks happens between these and the elementwise entry points):
+ *   ts_bn_sync_stats            pack[0..C) = sum x, pack[C..2C) = sum x^2, pack[2C] = n     (double [2C + 1])
+ *   ts_bn_sync_backward_reduce  sums[0..C) = sum g, sums[C..2C) = sum g (x - mean), g = grad_out masked by the ReLU
+ *                               mask when given; grad_weight / grad_bias [C] = this rank's parameter gradients
+ * ws as for ts_bn_act_train_*. */
+int ts_bn_sync_stats(const float *x, int64_t n, int32_t c, double *pack, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_bn_sync_backward_reduce(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
+                               const float *invstd, int64_t n, int32_t c, double *sums, float *grad_weight,
+                               float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* Trilinear devoxelisation backward over runs of points that share their 8-corner index tuple (the points of one
  * interpolation cell).  Same result as ts_devoxelize_backward up to float summation order; the corner
  * contributions of a run are accumulated in registers and added to grad_feat once per run.

@@ -536,3 +536,67 @@ extern "C" int ts_bn_act_train_backward(const float *grad_out, const uint8_t *ma
   TS_CHECK_LAUNCH("ts_bn_act_train_backward");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// SyncBatchNorm halves: the same sliced reductions, finished into DOUBLE sums that the host all-reduces
+// (one collective of [2C + 1] doubles in the forward pass, [2C] in the backward pass - torch's SyncBatchNorm
+// all-gathers per-rank mean / invstd / count instead).  The elementwise halves are ts_bn_finalize +
+// ts_bn_act_forward and ts_bn_act_backward above.
+__global__ __launch_bounds__(256) void bn_sums_finish_kernel(const float *__restrict__ part, int slices, int c,
+                                                             double count, const float *__restrict__ invstd,
+                                                             double *__restrict__ sums,
+                                                             float *__restrict__ grad_weight,
+                                                             float *__restrict__ grad_bias) {
+  __shared__ double red[2][BN_FIN_CH][BN_FIN_LANES + 1];
+  const int ch = blockIdx.x * BN_FIN_CH + (threadIdx.x % BN_FIN_CH), sl = threadIdx.x / BN_FIN_CH;
+  double s0, s1;
+  bn_sum_slices(part, slices, c, ch, sl, red, s0, s1);
+  if (count >= 0.0 && blockIdx.x == 0 && threadIdx.x == 0) sums[2 * c] = count;   // forward pack: [sum, sumsq, n]
+  if (sl != 0 || ch >= c) return;
+  sums[ch] = s0;
+  sums[c + ch] = s1;
+  if (grad_bias) grad_bias[ch] = (float)s0;                       // local (per-rank) parameter gradients
+  if (grad_weight) grad_weight[ch] = (float)s1 * invstd[ch];
+}
+
+extern "C" int ts_bn_sync_stats(const float *x, int64_t n, int32_t c, double *pack, void *ws, size_t ws_bytes,
+                                ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n > 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED,
+             "ts_bn_sync_stats: need N > 0 and C a multiple of 4, <= 1024");
+  TS_REQUIRE(x && pack && ws && bn_aligned(x) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT, "ts_bn_sync_stats: bad pointer");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT, "ts_bn_sync_stats: workspace too small");
+  float *part = (float *)ws;
+  const int rows = bn_rows_per_slice(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);
+  bn_sums_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, c, (double)n, nullptr, pack,
+                                                                           nullptr, nullptr);
+  TS_CHECK_LAUNCH("ts_bn_sync_stats");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_sync_backward_reduce(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
+                                          const float *invstd, int64_t n, int32_t c, double *sums, float *grad_weight,
+                                          float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n > 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED,
+             "ts_bn_sync_backward_reduce: need N > 0 and C a multiple of 4, <= 1024");
+  TS_REQUIRE(grad_out && x && mean && invstd && sums && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_sync_backward_reduce: null pointer");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(mean) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_sync_backward_reduce: pointers must be 16-byte aligned");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_sync_backward_reduce: workspace too small");
+  float *part = (float *)ws;
+  const int rows = bn_rows_per_slice(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  if (mask)
+    bn_partial_kernel<2><<<slices, 256, 0, stream>>>(x, grad_out, mask, mean, n, c, rows, part);
+  else
+    bn_partial_kernel<1><<<slices, 256, 0, stream>>>(x, grad_out, nullptr, mean, n, c, rows, part);
+  bn_sums_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, c, -1.0, invstd, sums,
+                                                                           grad_weight, grad_bias);
+  TS_CHECK_LAUNCH("ts_bn_sync_backward_reduce");
+  return TS_OK;
+}

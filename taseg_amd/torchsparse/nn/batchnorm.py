@@ -85,13 +85,16 @@ class _BatchNormActTrain(Function):
                                                 L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream()),
                     "ts_bn_act_train_forward")
         else:
+            # SyncBatchNorm: local sums -> ONE all-reduce of [2C + 1] doubles -> statistics + elementwise pass
             if nbt is not None:
                 nbt.add_(1)
-            sums = B.bn_stats(x)
-            pack = torch.cat([sums.view(-1), torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
+            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+            pack = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+            L.check(lib.ts_bn_sync_stats(L.ptr(x), n, c, L.ptr(pack), L.ptr(ws), ws.numel(), L.stream()),
+                    "ts_bn_sync_stats")
             dist.all_reduce(pack, group=group)
-            sums, total_dev = pack[:2 * c].view(2, c), pack[2 * c:]
-            L.check(lib.ts_bn_finalize(L.ptr(sums), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
+            total_dev = pack[2 * c:]
+            L.check(lib.ts_bn_finalize(L.ptr(pack), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
                                        L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd),
                                        L.stream()), "ts_bn_finalize")
             L.check(lib.ts_bn_act_forward(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd), L.ptr(weight),
@@ -118,16 +121,16 @@ class _BatchNormActTrain(Function):
                     "ts_bn_act_train_backward")
             return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
         sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
-        L.check(lib.ts_bn_act_backward_reduce(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), n, c, L.ptr(sums),
-                                              L.stream()), "ts_bn_act_backward_reduce")
-        local = sums.float()
-        grad_weight = local[1] * invstd if ctx.needs_input_grad[2] else None
-        grad_bias = local[0] if ctx.needs_input_grad[3] else None
+        gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)          # this rank's grad_weight, grad_bias
+        ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+        L.check(lib.ts_bn_sync_backward_reduce(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd), n, c,
+                                               L.ptr(sums), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(),
+                                               L.stream()), "ts_bn_sync_backward_reduce")
         dist.all_reduce(sums, group=ctx.group)
         L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                        L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
                                        L.ptr(grad_x), L.ptr(grad_res), L.stream()), "ts_bn_act_backward")
-        return grad_x, grad_res, grad_weight, grad_bias, None, None, None, None, None, None, None
+        return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
 
 
 def batch_norm_act_train(x, weight, bias, running_mean, running_var, momentum, eps, relu=True, residual=None,

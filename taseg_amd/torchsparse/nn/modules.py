@@ -73,9 +73,12 @@ def _bn_forward(mod, feats, torch_forward, group=None):
 
 
 def _sync_group(mod):
+    """process group whose ranks share batch statistics, or None for local statistics.  A one-rank group behaves
+    like None; TASEG_SYNCBN_SINGLE_RANK=1 keeps the collective path on anyway (lets one GPU exercise it)."""
+    import os
     import torch.distributed as dist
     if isinstance(mod, nn.SyncBatchNorm) and mod.training and dist.is_available() and dist.is_initialized() \
-            and dist.get_world_size() > 1:
+            and (dist.get_world_size() > 1 or os.environ.get("TASEG_SYNCBN_SINGLE_RANK") == "1"):
         return mod.process_group if mod.process_group is not None else dist.group.WORLD
     return None
 
@@ -112,10 +115,7 @@ class SyncBatchNorm(nn.SyncBatchNorm):
     """nn.SyncBatchNorm over sparse features: statistics over all ranks (one all-reduce of [2C+1] doubles)."""
 
     def forward(self, input: SparseTensor) -> SparseTensor:
-        import torch.distributed as dist
-        group = None
-        if self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            group = self.process_group if self.process_group is not None else dist.group.WORLD
+        group = _sync_group(self)
         return fapply(input, lambda f: _bn_forward(self, f, super(SyncBatchNorm, self).forward, group))
 
 

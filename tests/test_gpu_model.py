@@ -135,3 +135,57 @@ def test_eval_branch_unvoxelises(g_minkunet):
     assert [len(p) for p in out["point_predict"]] == [m + 50 for m in per_scan]
     assert out["point_predict_logits"][0].shape == (per_scan[0] + 50, 20)
     assert n == sum(per_scan)
+
+
+def test_syncbn_collective_path_on_one_rank(tmp_path):
+    """The SyncBatchNorm / DDP code path that `bench.py --gpus N` executes, on a one-rank RCCL group: fused BN+act
+    with the all-reduce between reduction and apply must equal the single-process path, and a DDP-wrapped training
+    step must run (the multi-GPU scaling bench cannot be launched from the build box)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.environ["REPO"])
+import torch.distributed as dist
+os.environ["TASEG_SYNCBN_SINGLE_RANK"] = "1"
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+torch.cuda.set_device(0)
+from taseg_amd.torchsparse.nn.batchnorm import batch_norm_act_train
+g = torch.Generator().manual_seed(0)
+n, c = 20011, 96
+x = torch.randn(n, c, generator=g).cuda().requires_grad_()
+res = torch.randn(n, c, generator=g).cuda().requires_grad_()
+w = (torch.rand(c, generator=g) + 0.5).cuda().requires_grad_()
+b = torch.randn(c, generator=g).cuda().requires_grad_()
+outs = []
+for group in (None, dist.group.WORLD):
+    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    y = batch_norm_act_train(x, w, b, rm, rv, 0.1, 1e-5, relu=True, residual=res, group=group)
+    gx, gr, gw, gb = torch.autograd.grad((y * y).sum(), (x, res, w, b))
+    outs.append([t.detach().cpu() for t in (y, gx, gr, gw, gb, rm, rv)])
+for a, bb in zip(*outs):
+    assert torch.allclose(a, bb, rtol=2e-4, atol=2e-4), float((a - bb).abs().max())
+# one DDP + SyncBatchNorm training step of the segmentor
+from taseg_amd.data.synthetic import make_model_cfg, synth_scan
+from taseg_amd.pcseg.model import build_network
+from taseg_amd.torchsparse import SparseTensor
+from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8, if_dist=True)
+model = build_network(cfg, 20).cuda().train()
+net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True)
+pts, lab = synth_scan(1, n_points=20000, n_beams=32, n_az=1000)
+pc = np.round(pts[:, :3] / 0.05).astype(np.int32); pc -= pc.min(0)
+_, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+bd = {"lidar": SparseTensor(torch.from_numpy(pts[idx]).cuda(), coords),
+      "targets": SparseTensor(torch.from_numpy(lab[idx].astype(np.int64)).cuda(), coords), "offset": torch.tensor([0])}
+ret, _, _ = net(bd)
+ret["loss"].mean().backward()
+assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+dist.destroy_process_group()
+print("SYNC_OK")
+'''
+    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "SYNC_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
