@@ -31,9 +31,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms"])
-    ap.add_argument("--batch", type=int, default=2, help="scans per GPU per step")
-    ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms", "nuscenes_ms"],
+                    help="minkunet = BASELINE configs[1] (headline); minkunet_ms = configs[2] (4-scan TFA); "
+                         "nuscenes_ms = configs[4] shape: 32-beam 34.7k-point sweeps, 15 history sweeps, voxel 0.1 m, "
+                         "17 classes, bs 4 (fp32 here)")
+    ap.add_argument("--batch", type=int, default=None, help="scans per GPU per step (default 2; 4 for nuscenes_ms)")
+    ap.add_argument("--points", type=int, default=None, help="points per scan (default 120000; 34700 for nuscenes_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build batch i's rulebooks at the head of step i on the launch stream instead of "
@@ -69,7 +72,7 @@ def make_scans(rank, batch, points, workload):
             torch.from_numpy(np.concatenate(labels)).to(dev), npts)
 
 
-def make_multiscans(rank, batch, points, history=4):
+def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label_map=None):
     """Raw resident scans for the "4-scan TFA" workload: per sample the
     current scan plus `history` earlier scans of the same scene seen from the ego poses
     synth_pose(t) (1.1 m and 0.4 deg per frame).  The temporal aggregation + voxelisation itself runs on the
@@ -82,7 +85,9 @@ def make_multiscans(rank, batch, points, history=4):
         pts, labs, poses = [], [], []
         for t in range(history + 1):               # frame t: current = history, oldest = 0
             pose = synth_pose(history - t)
-            p, l = synth_scan(seed + t, n_points=points, pose=pose, scene_seed=seed)
+            p, l = synth_scan(seed + t, n_points=points, pose=pose, scene_seed=seed, n_beams=n_beams, n_az=n_az)
+            if label_map is not None:
+                l = np.asarray(label_map, dtype=l.dtype)[l]
             pts.append(torch.from_numpy(p).to(dev))
             labs.append(torch.from_numpy(l.astype(np.int64)).to(dev))
             poses.append(torch.from_numpy(pose).to(dev))
@@ -197,11 +202,19 @@ def main():
     from taseg_amd.pcseg.model import build_network
     from taseg_amd.torchsparse import SparseTensor
 
-    ms = args.workload == "minkunet_ms"
+    nusc = args.workload == "nuscenes_ms"
+    ms = args.workload in ("minkunet_ms", "nuscenes_ms")
+    if args.batch is None:
+        args.batch = 4 if nusc else 2
+    if args.points is None:
+        args.points = 34700 if nusc else 120000
+    voxel = 0.1 if nusc else VOXEL
+    num_class = 17 if nusc else 20
     name = "MinkUNetMs" if ms else "MinkUNet"
-    cfg = make_model_cfg(name, in_dim=5 if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn)
+    # nuScenes FSA feeds 4 features (the time flag column is cut by IN_FEATURE_DIM: 4, nuscenes fsa yaml:16,27)
+    cfg = make_model_cfg(name, in_dim=(4 if nusc else 5) if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn)
     torch.manual_seed(0)
-    model = build_network(cfg, 20).cuda().train()
+    model = build_network(cfg, num_class).cuda().train()
     net = model
     if use_dist:
         # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
@@ -212,11 +225,16 @@ def main():
     nvox = [0]
     if ms:
         from taseg_amd.data.stage import build_multiscan_batch
-        from taseg_amd.data.synthetic import FLEXIBLE_STEPS_KITTI
-        scans, npts = make_multiscans(rank, args.batch, args.points)
+        from taseg_amd.data.synthetic import FLEXIBLE_STEPS_KITTI, FLEXIBLE_STEPS_NUSC, KITTI_TO_NUSC
+        if nusc:
+            scans, npts = make_multiscans(rank, args.batch, args.points, history=15, n_beams=32, n_az=1090,
+                                          label_map=KITTI_TO_NUSC)
+        else:
+            scans, npts = make_multiscans(rank, args.batch, args.points)
+        steps_cfg = FLEXIBLE_STEPS_NUSC if nusc else FLEXIBLE_STEPS_KITTI
 
         def make_batch():
-            bd = build_multiscan_batch(scans, VOXEL, FLEXIBLE_STEPS_KITTI)
+            bd = build_multiscan_batch(scans, voxel, steps_cfg)
             nvox[0] = int(bd["lidar_ms"].C.shape[0])
             return bd
     else:
@@ -298,18 +316,20 @@ def main():
                             algorithmic_bytes_per_launch=dom["bytes_per_launch"],
                             algorithmic_flops_per_launch=dom["flops_per_launch"])
         line = {
-            "metric": "scans/sec (train fwd+bwd) at ~120k pts/scan", "value": value, "unit": "scans/s",
+            "metric": "scans/sec (train fwd+bwd) at ~120k pts/scan" if not nusc else
+            "scans/sec (train fwd+bwd), nuScenes-shaped sweeps", "value": value, "unit": "scans/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name} mk34 cr1.0 ({'4-scan TFA multi-scan' if ms else 'single-frame'}), "
-                                   f"bs={args.batch}/GPU, voxel 0.05 m, fp32, rulebook+fwd+loss+bwd+SGD step",
+            "config": {"workload": f"{name} mk34 cr1.0 ("
+                                   f"{'nuScenes-shaped 15-sweep FSA' if nusc else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
+                                   f"bs={args.batch}/GPU, voxel {voxel:g} m, fp32, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}"},
             "loss": float(loss.detach()),
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in prof[:8]],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not nusc:      # cpu_baseline is defined on the KITTI-shaped scan
             line["cpu_baseline"] = cpu_baseline(cfg, args.points, args.cpu_sector_deg)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         import ctypes

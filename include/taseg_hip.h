@@ -347,6 +347,10 @@ int ts_sparse_quantize(const int32_t *coords, int64_t n, int32_t *out_index, int
  * 4x4 row-major float32 on the device; out [n,4]. */
 int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose,
                  float *out, ts_stream_t stream);
+/* The same transform for the concatenated history scans of a sample: point i uses poses[scan_idx[i]]
+ * (poses [n_scans, 4, 4] row-major).  Bit-identical to n_scans calls of ts_fuse_scan. */
+int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64_t n, const float *pose0, const float *poses,
+                  int32_t n_scans, float *out, ts_stream_t stream);
 
 #ifdef __cplusplus
 }

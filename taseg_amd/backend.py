@@ -17,7 +17,7 @@ __all__ = [
     "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
-    "fuse_scan", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
+    "fuse_scan", "fuse_scans", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
 
@@ -496,6 +496,18 @@ def fuse_scan(points, pose0, pose):
     out = torch.empty_like(points)
     L.check(L.load().ts_fuse_scan(L.ptr(points), points.shape[0], L.ptr(pose0), L.ptr(pose), L.ptr(out), L.stream()),
             "ts_fuse_scan")
+    return out
+
+
+def fuse_scans(points, scan_idx, pose0, poses):
+    """fuse_scan for the concatenated history scans of one sample: point i is transformed with poses[scan_idx[i]]."""
+    L.require_device(points, scan_idx, pose0, poses)
+    points, pose0, poses = _f32(points, "points"), _f32(pose0, "pose0"), _f32(poses, "poses")
+    scan_idx = _i32(scan_idx, "scan_idx")
+    assert points.ndim == 2 and points.shape[1] == 4 and pose0.shape == (4, 4) and poses.shape[1:] == (4, 4)
+    out = torch.empty_like(points)
+    L.check(L.load().ts_fuse_scans(L.ptr(points), L.ptr(scan_idx), points.shape[0], L.ptr(pose0), L.ptr(poses),
+                                   poses.shape[0], L.ptr(out), L.stream()), "ts_fuse_scans")
     return out
 
 

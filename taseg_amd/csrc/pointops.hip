@@ -288,6 +288,59 @@ __global__ __launch_bounds__(256) void fuse_scan_kernel(const float4 *__restrict
   }
 }
 
+// All history scans of a sample in one launch: point i uses poses[scan_idx[i]].  Same arithmetic, same order.
+__global__ __launch_bounds__(256) void fuse_scans_kernel(const float4 *__restrict__ pts,
+                                                         const int *__restrict__ scan_idx, int64_t n,
+                                                         const float *__restrict__ pose0,
+                                                         const float *__restrict__ poses, int n_scans,
+                                                         float4 *__restrict__ out) {
+#pragma clang fp contract(off)
+  float Q[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Q[i] = pose0[i];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float4 p = pts[i];
+    const int sidx = min(max(scan_idx[i], 0), n_scans - 1);
+    const float *P = poses + 16 * sidx;
+    const float h[4] = {p.x, p.y, p.z, 1.0f};
+    float nw[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float s = __fmul_rn(h[0], P[j * 4 + 0]);
+      s = __fadd_rn(s, __fmul_rn(h[1], P[j * 4 + 1]));
+      s = __fadd_rn(s, __fmul_rn(h[2], P[j * 4 + 2]));
+      s = __fadd_rn(s, __fmul_rn(h[3], P[j * 4 + 3]));
+      nw[j] = __fsub_rn(s, Q[j * 4 + 3]);
+    }
+    float o[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float s = __fmul_rn(nw[0], Q[0 * 4 + j]);
+      s = __fadd_rn(s, __fmul_rn(nw[1], Q[1 * 4 + j]));
+      s = __fadd_rn(s, __fmul_rn(nw[2], Q[2 * 4 + j]));
+      o[j] = s;
+    }
+    out[i] = make_float4(o[0], o[1], o[2], p.w);
+  }
+}
+
+extern "C" int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64_t n, const float *pose0,
+                             const float *poses, int32_t n_scans, float *out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && n_scans > 0, TS_ERR_INVALID_ARGUMENT, "ts_fuse_scans: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(points && scan_idx && pose0 && poses && out, TS_ERR_INVALID_ARGUMENT, "ts_fuse_scans: null pointer");
+  TS_REQUIRE(((uintptr_t)points & 15) == 0 && ((uintptr_t)out & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_fuse_scans: points/out must be 16-byte aligned");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
+  fuse_scans_kernel<<<grid, 256, 0, stream>>>((const float4 *)points, scan_idx, n, pose0, poses, n_scans,
+                                              (float4 *)out);
+  TS_CHECK_LAUNCH("ts_fuse_scans");
+  return TS_OK;
+}
+
 extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose, float *out,
                             ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

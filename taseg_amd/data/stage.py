@@ -24,9 +24,46 @@ __all__ = ["fuse_multiscan", "voxelize_sample_ms", "voxelize_sample", "collate_b
            "DevicePrefetcher"]
 
 
-def _keep_table(steps: Sequence[int], delta: int, device) -> torch.Tensor:
-    """bool[num_classes]: is class c aggregated from the scan `delta` frames away (semantickitti_ms.py:303-308)."""
-    return torch.tensor([bool(s) and abs(delta) % s == 0 for s in steps], dtype=torch.bool, device=device)
+_static_cache = {}
+
+
+def _history_index(lengths: Sequence[int], deltas: Sequence[int], steps: Sequence[int], device):
+    """Per-layout helpers that depend only on the scan lengths and the schedule, cached: scan index of every
+    concatenated history point, and the [T, C] table "is class c aggregated from the scan delta frames away"
+    (semantickitti_ms.py:303-308: steps[c] != 0 and |delta| % steps[c] == 0)."""
+    key = (tuple(lengths), tuple(deltas), tuple(steps), str(device))
+    hit = _static_cache.get(key)
+    if hit is None:
+        if len(_static_cache) >= 64:
+            _static_cache.pop(next(iter(_static_cache)))
+        scan_idx = torch.repeat_interleave(torch.arange(len(lengths), dtype=torch.int32),
+                                           torch.tensor(list(lengths), dtype=torch.int64)).to(device)
+        table = torch.tensor([[bool(st) and abs(d) % st == 0 for st in steps] for d in deltas], dtype=torch.bool)
+        hit = (scan_idx, table.to(device))
+        _static_cache[key] = hit
+    return hit
+
+
+def _fuse_history(cur_pts, cur_lab, hist_pts, hist_lab, pose0, hist_poses, deltas, steps):
+    """All history scans in one pass: concatenate, transform every point with its scan's pose (ts_fuse_scans),
+    look the class-step decision up per point.  Returns the un-filtered stack [current | history] (x, y, z,
+    intensity, time flag), its labels and the keep mask; order = current scan first, then history oldest first, each
+    in file order - the order the reference's loop produces (semantickitti_ms.py:140-149)."""
+    dev = cur_pts.device
+    n_cur = cur_pts.shape[0]
+    if len(hist_pts) == 0:
+        flag = torch.ones((n_cur, 1), dtype=cur_pts.dtype, device=dev)
+        return torch.cat([cur_pts[:, :4], flag], 1), cur_lab.long(), torch.ones(n_cur, dtype=torch.bool, device=dev)
+    scan_idx, table = _history_index([p.shape[0] for p in hist_pts], deltas, steps, dev)
+    hp = torch.cat([p[:, :4] for p in hist_pts], 0).contiguous()
+    hl = torch.cat(hist_lab, 0).long()
+    fused = B.fuse_scans(hp, scan_idx, pose0, torch.stack(list(hist_poses), 0))
+    keep = table.view(-1)[scan_idx.long() * table.shape[1] + hl]
+    pts = torch.cat([cur_pts[:, :4], fused], 0)
+    flag = torch.zeros((pts.shape[0], 1), dtype=pts.dtype, device=dev)
+    flag[:n_cur] = 1                               # append_time_flag (semantickitti_ms.py:253-257)
+    mask = torch.cat([torch.ones(n_cur, dtype=torch.bool, device=dev), keep])
+    return torch.cat([pts, flag], 1), torch.cat([cur_lab.long(), hl]), mask
 
 
 def fuse_multiscan(cur_pts, cur_lab, hist_pts: List[torch.Tensor], hist_lab: List[torch.Tensor], pose0,
@@ -37,19 +74,8 @@ def fuse_multiscan(cur_pts, cur_lab, hist_pts: List[torch.Tensor], hist_lab: Lis
     *_lab: class ids (learning-map ids, 0..C-1); poses: 4x4 float32 (world <- sensor);
     deltas[i] < 0 is the frame offset of hist_pts[i].  History order is preserved (oldest first, as the
     reference iterates delta = -MULTISCAN .. -1)."""
-    dev = cur_pts.device
-    parts, labs = [cur_pts[:, :4]], [cur_lab.long()]
-    for pts, lab, pose, delta in zip(hist_pts, hist_lab, hist_poses, deltas):
-        keep = _keep_table(steps, delta, dev)[lab.long()]
-        if not bool(keep.any()):
-            continue
-        sel = pts[keep].contiguous()            # filter first: fuse only what survives (same values, less work)
-        parts.append(B.fuse_scan(sel[:, :4].contiguous(), pose0, pose))
-        labs.append(lab[keep].long())
-    fused = torch.cat(parts, 0)
-    flag = torch.zeros((fused.shape[0], 1), dtype=fused.dtype, device=dev)
-    flag[:cur_pts.shape[0]] = 1                  # append_time_flag (semantickitti_ms.py:253-257)
-    return torch.cat([fused, flag], 1), torch.cat(labs, 0)
+    raw, lab, mask = _fuse_history(cur_pts, cur_lab, hist_pts, hist_lab, pose0, hist_poses, deltas, steps)
+    return raw[mask], lab[mask]
 
 
 def _quantize(points, voxel_size, shift=None):
@@ -66,11 +92,14 @@ def voxelize_sample(points, labels, voxel_size, name="") -> Dict:
             "num_points": torch.tensor([points.shape[0]])}
 
 
-def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name="") -> Dict:
+def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name="", keep=None) -> Dict:
     """Multi-scan sample (semantickitti_voxel_ms.py:121-187): both clouds voxelised, the single-frame one
-    shifted by the fused cloud's minimum."""
+    shifted by the fused cloud's minimum.  `keep` (optional bool mask over points_ms) is AND-ed with the clamp
+    so the class-step filter and the clamp cost one compaction (one host read) instead of two."""
     lo = points[:, :3].min(0).values
     clamp = (points_ms[:, :3] >= lo).all(1)                               # :121-124
+    if keep is not None:
+        clamp = clamp & keep
     points_ms, labels_ms = points_ms[clamp].contiguous(), labels_ms[clamp]
     pc_ms, mins_ms, inds_ms, inverse_ms = _quantize(points_ms, voxel_size)
     pc, _, inds, inverse = _quantize(points, voxel_size, shift=mins_ms)   # pc_ -= pc_ms_.min(0)  (:130)
@@ -127,9 +156,10 @@ def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[
     for s in scans:
         pts, lab, poses = s["points"], s["labels"], s["poses"]
         t = len(pts) - 1
-        raw_ms, lab_ms = fuse_multiscan(pts[t], lab[t], pts[:t], lab[:t], poses[t], poses[:t],
-                                        [i - t for i in range(t)], steps)
-        samples.append(voxelize_sample_ms(pts[t], lab[t].long(), raw_ms, lab_ms, voxel_size, s.get("name", "")))
+        raw_all, lab_all, keep = _fuse_history(pts[t], lab[t], pts[:t], lab[:t], poses[t], poses[:t],
+                                               [i - t for i in range(t)], steps)
+        samples.append(voxelize_sample_ms(pts[t], lab[t].long(), raw_all, lab_all, voxel_size, s.get("name", ""),
+                                          keep=keep))
     return collate_batch(samples)
 
 

@@ -16,6 +16,10 @@ import torch
 CAR, PERSON, ROAD, SIDEWALK, BUILDING, VEGETATION, TRUNK, TERRAIN, POLE = 1, 6, 9, 11, 13, 15, 16, 17, 18
 # reference FSA schedule (tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10_fsa.yaml:17)
 FLEXIBLE_STEPS_KITTI = [0, 0, 2, 2, 2, 2, 2, 2, 2, 0, 4, 4, 4, 0, 4, 0, 2, 4, 2, 2]
+# nuScenes FSA schedule, 17 classes (tools/cfgs/voxel/nuscenes/minkunet_mk34_cr10_fsa.yaml:22)
+FLEXIBLE_STEPS_NUSC = [0, 1, 1, 1, 3, 1, 1, 3, 1, 3, 3, 0, 1, 1, 1, 1, 1]
+# synthetic surface classes (SemanticKITTI ids above) folded onto 17 nuScenes-style ids; 0 stays "ignore"
+KITTI_TO_NUSC = [0, 4, 2, 3, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 1, 16, 10, 14, 10, 16]
 GROUND_Z = -1.73
 
 
