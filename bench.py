@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
     ap.add_argument("--local-bn", action="store_true",
                     help="plain BatchNorm (per-rank statistics) instead of the reference configs' SyncBatchNorm")
+    ap.add_argument("--torch-ddp", action="store_true",
+                    help="average gradients with torch's DistributedDataParallel instead of parallel.GradBucketReducer")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL process group, DDP, SyncBatchNorm collectives) even with "
                          "one rank - a single-GPU check of what `--gpus N` executes")
@@ -216,7 +218,11 @@ def main():
     torch.manual_seed(0)
     model = build_network(cfg, num_class).cuda().train()
     net = model
-    if use_dist:
+    reducer = None
+    if use_dist and not args.torch_ddp:
+        from taseg_amd.parallel import GradBucketReducer
+        reducer = GradBucketReducer(model)          # flat buckets, all-reduce overlapped with backward
+    elif use_dist:
         # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
                                                         broadcast_buffers=False, static_graph=True)
@@ -258,6 +264,8 @@ def main():
         else:
             ret, _, _ = net(pf.next())
         ret["loss"].mean().backward()
+        if reducer is not None:
+            reducer.finish()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
         if pf is not None:
@@ -273,6 +281,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if dist is not None:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # every rank: push RCCL's C-stdio version banner out before the result line
     if not args.no_kernel_events:
         B.profile_begin()
     t0 = time.perf_counter()

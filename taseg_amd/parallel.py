@@ -12,7 +12,8 @@ from typing import List
 import torch
 import torch.distributed as dist
 
-__all__ = ["env_rank", "init_distributed", "shard_seeds", "wrap_ddp", "reduce_max", "reduce_confusion"]
+__all__ = ["env_rank", "init_distributed", "shard_seeds", "wrap_ddp", "reduce_max", "reduce_confusion",
+           "GradBucketReducer"]
 
 
 def env_rank():
@@ -58,3 +59,89 @@ def reduce_confusion(hist: torch.Tensor) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist
+
+
+class GradBucketReducer:
+    """Gradient averaging over ranks in a few flat buckets, overlapped with backward - what DDP's reducer does,
+    minus its per-parameter device copies.  With `gradient_as_bucket_view` DDP copies every freshly produced
+    gradient into its bucket separately (380 parameters -> 380 small kernels, 1.6 ms per step here); this reducer
+    waits until the last gradient of a bucket exists, moves the whole bucket with ONE multi-tensor copy, re-points
+    `p.grad` at the bucket views (no copy back), and all-reduces the flat buffer asynchronously.
+
+        reducer = GradBucketReducer(model)            # after the process group is up; broadcasts rank 0's weights
+        loss.backward()                               # hooks launch a bucket's all-reduce when it is complete
+        reducer.finish()                              # before clip / optimizer.step(): wait for the collectives
+
+    Buckets follow reverse registration order (roughly the order gradients appear).  Parameters that received no
+    gradient in a step count as zeros.  Works with any backend (RCCL on GPU, gloo in the CPU tests)."""
+
+    def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: float = 32.0, broadcast: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= bucket_mb * (1 << 20):
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._add_bucket(cur)
+        self._works = []
+        if broadcast and self.world > 1:
+            for b in self.buckets:                  # every rank starts from rank 0's parameters (DDP does the same)
+                torch._foreach_copy_(b["views"], [p.data for p in b["params"]])
+                dist.broadcast(b["flat"], src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                               group=self.group)
+                torch._foreach_copy_([p.data for p in b["params"]], b["views"])
+        for b in self.buckets:
+            for p in b["params"]:
+                p.register_post_accumulate_grad_hook(self._make_hook(b))
+
+    def _add_bucket(self, params):
+        first = params[0]
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=first.dtype, device=first.device)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buckets.append({"params": list(params), "flat": flat, "views": views, "pending": len(params),
+                             "launched": False})
+
+    def _make_hook(self, bucket):
+        def hook(_param):
+            bucket["pending"] -= 1
+            if bucket["pending"] == 0:
+                self._launch(bucket)
+        return hook
+
+    def _launch(self, bucket):
+        src, dst = [], []
+        for p, v in zip(bucket["params"], bucket["views"]):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(bucket["params"], bucket["views"]):
+            p.grad = v                               # the optimizer reads the reduced values in place
+        if self.world > 1:
+            bucket["flat"].div_(self.world)
+            self._works.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
+        bucket["launched"] = True
+
+    def finish(self):
+        """Launch what backward left incomplete (unused parameters), wait for every collective, re-arm."""
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        for b in self.buckets:
+            b["pending"], b["launched"] = len(b["params"]), False

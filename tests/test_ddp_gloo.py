@@ -74,3 +74,57 @@ def test_single_process_helpers_are_noops():
     assert P.shard_seeds(3, 8, 2) == [3000, 3010]
     m = _net()
     assert P.wrap_ddp(m) is m and P.reduce_max(1.5) == 1.5
+
+
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    P.init_distributed(backend="gloo")
+    net = _net()
+    if rank == 1:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)                         # rank 1 starts elsewhere: the reducer must broadcast rank 0's weights
+    extra = torch.nn.Parameter(torch.ones(3))       # a parameter that never gets a gradient
+    net.register_parameter("unused", extra)
+    red = P.GradBucketReducer(net, bucket_mb=0.0002)          # tiny buckets: several collectives per step
+    w0 = [p.detach().clone() for p in net.parameters()]
+    rows = []
+    for step in range(2):                           # two steps: hooks must re-arm
+        for p in net.parameters():
+            p.grad = None
+        g = torch.Generator().manual_seed(100 * step + rank)
+        x, y = torch.randn(6, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+        torch.nn.functional.cross_entropy(net[2](net[1](net[0](x))), y).backward()
+        red.finish()
+        rows.append([p.grad.clone().tolist() for p in net.parameters()])
+    out.put((rank, [w.tolist() for w in w0], rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w_a, rows_a), (_, w_b, rows_b) = res
+    assert w_a == w_b                                              # broadcast: both ranks hold rank 0's weights
+    for step in range(2):
+        net = _net()
+        net.register_parameter("unused", torch.nn.Parameter(torch.ones(3)))
+        total = 0.0
+        for rank in range(world):
+            g = torch.Generator().manual_seed(100 * step + rank)
+            x, y = torch.randn(6, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+            total = total + torch.nn.functional.cross_entropy(net[2](net[1](net[0](x))), y) / world
+        total.backward()
+        want = [p.grad if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
+        for got_a, got_b, w in zip(rows_a[step], rows_b[step], want):
+            assert torch.allclose(torch.tensor(got_a), w, atol=1e-6) and torch.allclose(torch.tensor(got_b), w, atol=1e-6)
