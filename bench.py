@@ -221,7 +221,9 @@ def main():
     reducer = None
     if use_dist and not args.torch_ddp:
         from taseg_amd.parallel import GradBucketReducer
-        reducer = GradBucketReducer(model)          # flat buckets, all-reduce overlapped with backward
+        # own communicator: the 32 MB bucket transfers must not queue in front of the small SyncBatchNorm
+        # all-reduces of the layers still running backward (one RCCL stream per communicator)
+        reducer = GradBucketReducer(model, process_group=dist.new_group(backend="nccl"))
     elif use_dist:
         # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,

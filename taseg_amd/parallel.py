@@ -72,6 +72,8 @@ class GradBucketReducer:
         loss.backward()                               # hooks launch a bucket's all-reduce when it is complete
         reducer.finish()                              # before clip / optimizer.step(): wait for the collectives
 
+    Pass a dedicated `process_group` (dist.new_group()) when other small collectives (SyncBatchNorm) run during
+    backward: collectives of one communicator execute in order on one stream.
     Buckets follow reverse registration order (roughly the order gradients appear).  Parameters that received no
     gradient in a step count as zeros.  Works with any backend (RCCL on GPU, gloo in the CPU tests)."""
 
