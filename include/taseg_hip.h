@@ -316,7 +316,9 @@ int ts_image_gather_backward(const float *grad_out, const float *pix, const int3
 
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
- * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply. */
+ * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,
+ * 3 / 4 = full-tile pair GEMM with one workgroup per tile everywhere / persistent workgroups everywhere
+ *         (default: persistent for the forward weight layout only). */
 void ts_set_conv_impl(int32_t impl);
 
 /* ------------------------------------------------------------------------ */

@@ -274,7 +274,8 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
 def pair_gemm_kernel_name(c_out, weight_transposed=False, c_red=None):
     bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (96, 2) if c_out % 96 == 0 else (128, 2)
     fast = c_red is not None and c_red % 32 == 0 and c_out % bn == 0
-    return f"pair_gemm_{'fast_' if fast else ''}kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
+    kind = "" if not fast else ("fast_" if weight_transposed else "persist_")
+    return f"pair_gemm_{kind}kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
 
 
 def conv_pair_gemm(feat, kernel, nbmaps, nboffs, n_pairs, gather_col, weight_transposed=False):

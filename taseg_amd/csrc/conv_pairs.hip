@@ -450,6 +450,206 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_fast_kernel(const float *__r
   }
 }
 
+// Persistent form of pair_gemm_fast_kernel: gridDim.x workgroups walk the tile list with stride gridDim.x and run
+// ONE software pipeline across tile boundaries - the rulebook rows of the next tile are fetched while the current
+// tile computes, its first slice is loaded during the current tile's last MFMA step, and the Z stores of a
+// finished tile drain while the next one is already multiplying.  Same tiles, same MFMA order, same Z.
+template <int BN, int WR, bool WT>
+__global__ __launch_bounds__(256, 2) void pair_gemm_persist_kernel(const float *__restrict__ X, int R,
+                                                                const float *__restrict__ W, int O_total,
+                                                                const int2 *__restrict__ nbmaps,
+                                                                const int *__restrict__ nboffs, int K, int64_t P,
+                                                                int gcol, float *__restrict__ Z) {
+  constexpr int WC = 4 / WR;
+  constexpr int MI = (PG_BM / 16) / WR;
+  constexpr int NI = (BN / 16) / WC;
+  constexpr int BP = BN + 4;
+  constexpr int A_FLOATS = PG_BM * PG_AP;
+  constexpr int B_FLOATS = WT ? BN * PG_AP : PG_BK * BP;
+  constexpr int A_IT = PG_BM * (PG_BK / 4) / 256;
+  constexpr int B_IT = BN * (PG_BK / 4) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Abuf = smem;
+  float *Bbuf = Abuf + 2 * A_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave / WC, wc = wave % WC;
+  const int o0 = blockIdx.y * BN;
+
+  const int offv = nboffs[min(lane, K)];
+  const int offn = nboffs[min(lane + 1, K)];
+  int incl = lane < K ? (offn - offv + PG_BM - 1) / PG_BM : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  auto locate = [&](int t, int &k, int &p0, int &np) {
+    k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= t));
+    const int t_in_k = t - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
+    p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * PG_BM;
+    np = min(PG_BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  };
+
+  const int arow0 = tid >> 3, acol = (tid & 7) << 2;
+  int boff[B_IT], bdst[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int e = tid + it * 256;
+    if (!WT) {
+      constexpr int q4 = BN >> 2;
+      const int kk = e / q4, c4 = (e - kk * q4) << 2;
+      boff[it] = kk * O_total + c4;
+      bdst[it] = kk * BP + c4;
+    } else {
+      const int col = e >> 3, c4 = (e & 7) << 2;
+      boff[it] = col * R + c4;
+      bdst[it] = col * PG_AP + c4;
+    }
+  }
+  auto weights_of = [&](int k) { return WT ? W + ((int64_t)k * O_total + o0) * R : W + (int64_t)k * R * O_total + o0; };
+  auto row_index = [&](int p0, int np, int it) {
+    const int2 pr = nbmaps[p0 + min(arow0 + 32 * it, np - 1)];
+    return gcol ? pr.y : pr.x;
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[A_IT], rb[B_IT];
+  int np_regs;   // rows of the tile whose slice sits in ra / rb
+  auto load_regs = [&](const float *const (&ap)[A_IT], const float *wk, int c0) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) ra[it] = *(const f32x4 *)(ap[it] + c0);
+    const float *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const f32x4 *)(wb + boff[it]);
+  };
+  auto store_lds = [&](float *At, float *Bt) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int rr = arow0 + 32 * it;
+      *(f32x4 *)&At[rr * PG_AP + acol] = rr < np_regs ? ra[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) *(f32x4 *)&Bt[bdst[it]] = rb[it];
+  };
+  auto mma = [&](const float *At, const float *Bt) {
+#pragma unroll
+    for (int j = 0; j < PG_BK; j += 16) {
+      float a[MI][4], b[NI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const float4 v = *(const float4 *)&At[((wr * MI + mi) * 16 + r16) * PG_AP + j + 4 * g];
+        a[mi][0] = v.x;
+        a[mi][1] = v.y;
+        a[mi][2] = v.z;
+        a[mi][3] = v.w;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nb = wc * NI + ni;
+        if (!WT) {
+          const float *bp = &Bt[(j + 4 * g) * BP + nb * 16 + r16];
+          b[ni][0] = bp[0];
+          b[ni][1] = bp[BP];
+          b[ni][2] = bp[2 * BP];
+          b[ni][3] = bp[3 * BP];
+        } else {
+          const float4 v = *(const float4 *)&Bt[(nb * 16 + r16) * PG_AP + j + 4 * g];
+          b[ni][0] = v.x;
+          b[ni][1] = v.y;
+          b[ni][2] = v.z;
+          b[ni][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s4], b[ni][s4], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  int k, p0, np;
+  locate(tile, k, p0, np);
+  const float *aptr[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) aptr[it] = X + (int64_t)row_index(p0, np, it) * R + acol;
+  const float *wk = weights_of(k);
+  np_regs = np;
+  load_regs(aptr, wk, 0);
+  int t = 0;
+  for (;;) {
+    const int nxt = tile + gridDim.x;
+    const bool has_next = nxt < total;
+    int kn = 0, p0n = 0, npn = 1, idxn[A_IT];
+    if (has_next) {   // rulebook rows of the next tile: in flight during this tile's steps
+      locate(nxt, kn, p0n, npn);
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) idxn[it] = row_index(p0n, npn, it);
+    }
+    const float *aptr_n[A_IT];
+    const float *wk_n = wk;
+    for (int c0 = 0; c0 < R; c0 += PG_BK, ++t) {
+      float *At = Abuf + (t & 1) * A_FLOATS, *Bt = Bbuf + (t & 1) * B_FLOATS;
+      store_lds(At, Bt);
+      __syncthreads();
+      if (c0 + PG_BK < R) {
+        load_regs(aptr, wk, c0 + PG_BK);
+      } else if (has_next) {   // last step of this tile: first slice of the next one
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) aptr_n[it] = X + (int64_t)idxn[it] * R + acol;
+        wk_n = weights_of(kn);
+        np_regs = npn;
+        load_regs(aptr_n, wk_n, 0);
+      }
+      mma(At, Bt);
+    }
+    // Z rows of the finished tile (the stores drain while the next tile's MFMAs run)
+    // (`ot` is laundered through an empty asm so the 64 store offsets are recomputed per tile instead of being
+    // hoisted out of the tile loop, where they would occupy 64+ VGPRs for the whole kernel)
+    int ot = O_total;
+    asm volatile("" : "+s"(ot));
+    float *zt = Z + (int64_t)p0 * ot + o0 + (wc * NI) * 16 + r16;
+    const int row0 = wr * MI * 16 + 4 * g;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + mi * 16 + q;
+        float *zr = zt + row * ot;
+        if (row < np) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) zr[ni * 16] = acc[mi][ni][q];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!has_next) break;
+    tile = nxt;
+    k = kn;
+    p0 = p0n;
+    np = npn;
+    wk = wk_n;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) aptr[it] = aptr_n[it];
+  }
+}
+
 template <int BN, int WR, bool WT>
 static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
                             int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
@@ -472,6 +672,19 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
       fattr_set = true;
     }
     dim3 fgrid((unsigned)(ts_cdiv(P, PG_BM) + K), grid.y);   // upper bound on sum_k ceil(n_k / 128)
+    // measured on the MinkUNet layer shapes (tools/ab_pair_gemm.sh): the persistent pipeline wins 3-9 % with the
+    // forward weight layout and loses with the transposed one (256 VGPRs there) -> forward only.
+    // ts_set_conv_impl(3) = one workgroup per tile everywhere, (4) = persistent everywhere.
+    if ((!WT && g_ts_conv_impl != 3) || g_ts_conv_impl == 4) {
+      static bool pattr_set = false;
+      if (!pattr_set) {
+        TS_CHECK_HIP(hipFuncSetAttribute((const void *)pair_gemm_persist_kernel<BN, WR, WT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+        pattr_set = true;
+      }
+      dim3 pgrid(std::min<unsigned>(fgrid.x, std::max(1u, 512u / grid.y)), grid.y);   // 2 workgroups per CU
+      pair_gemm_persist_kernel<BN, WR, WT><<<pgrid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
+    } else
     pair_gemm_fast_kernel<BN, WR, WT><<<fgrid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);
   } else {
     pair_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z);

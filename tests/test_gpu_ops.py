@@ -344,13 +344,16 @@ def test_conv_fast_path_equals_generic_kernels(B, F, ci, co):
         return z, zt, gw
 
     fast = run()
-    B.set_conv_impl(2)
-    try:
-        generic = run()
-    finally:
-        B.set_conv_impl(0)
-    assert torch.equal(fast[0], generic[0]) and torch.equal(fast[1], generic[1])
-    close(fast[2], generic[2], 1e-5)
+    variants = []
+    for impl in (2, 3, 4):          # generic guarded kernels / one workgroup per tile / persistent workgroups
+        B.set_conv_impl(impl)
+        try:
+            variants.append(run())
+        finally:
+            B.set_conv_impl(0)
+    for other in variants:
+        assert torch.equal(fast[0], other[0]) and torch.equal(fast[1], other[1])
+        close(fast[2], other[2], 1e-5)
 
 
 def test_conv_reference_form_entry_points(B, g_ops):
