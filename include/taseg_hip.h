@@ -314,6 +314,21 @@ int ts_image_gather_backward(const float *grad_out, const float *pix, const int3
                              int64_t n_pts, int32_t n_batch, int32_t T, int32_t C, int32_t H, int32_t W,
                              int32_t shift, float *grad_feat, ts_stream_t stream);
 
+/* ---- fp16 storage / fp32 accumulation (the reference trains under AMP: conv.py:19 `custom_fwd(cast_inputs=half)`).
+ * `void *` operands are IEEE half arrays.  Channel counts must be multiples of 32, K <= 63.
+ *   ts_cast_weights_f16      w f32 [K, Ci, Co] -> w16 [K, Ci, Co] and / or w16t [K, Co, Ci] (either may be NULL)
+ *   ts_conv_pair_gemm_f16    z[p, :] = feat[nbmaps[p][gather_col], :] @ W_k(p); `w_rows` [K, c_out, c_red] holds, per
+ *                            offset, one row per OUTPUT column contiguous in the reduction index: w16t for the forward
+ *                            pass (c_red = Ci), w16 for the input gradient (c_red = Co, c_out = Ci)
+ *   ts_conv_gather_sum_f16   out[j, :] = sum_k z[pos[k, j], :]  (fp32 accumulation, k ascending) */
+int ts_cast_weights_f16(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *w16, void *w16t,
+                        ts_stream_t stream);
+int ts_conv_pair_gemm_f16(const void *feat, int64_t n_rows, int32_t c_red, const void *w_rows, int32_t K,
+                          const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, void *z,
+                          int32_t c_out, ts_stream_t stream);
+int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
+                           void *out, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,

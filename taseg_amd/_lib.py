@@ -64,6 +64,9 @@ SIGNATURES = {
     "ts_devoxelize_backward_runs": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "ts_image_gather_forward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_image_gather_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "ts_conv_gather_sum_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

@@ -314,6 +314,57 @@ def conv_gather_sum(z, pos, n_rows):
     return out
 
 
+def _f16(t, name):
+    if t.dtype != torch.float16:
+        raise TypeError(f"{name} must be float16 (got {t.dtype})")
+    return t.contiguous()
+
+
+def cast_weights_f16(kernel, want=(True, True)):
+    """fp32 [K, Ci, Co] -> (w16 [K, Ci, Co], w16t [K, Co, Ci]) half copies in one pass (None where not wanted)."""
+    L.require_device(kernel)
+    kernel = _f32(kernel, "kernel")
+    k, ci, co = kernel.shape
+    w16 = torch.empty((k, ci, co), dtype=torch.float16, device=kernel.device) if want[0] else None
+    w16t = torch.empty((k, co, ci), dtype=torch.float16, device=kernel.device) if want[1] else None
+    L.check(L.load().ts_cast_weights_f16(L.ptr(kernel), k, ci, co, L.ptr(w16), L.ptr(w16t), L.stream()),
+            "ts_cast_weights_f16")
+    return w16, w16t
+
+
+def conv_pair_gemm_f16(feat, w_rows, nbmaps, nboffs, n_pairs, gather_col):
+    """Pass 1 in half storage: z[p] = feat[nbmaps[p][gather_col]] @ W_k(p); w_rows [K, c_out, c_red] (one row per
+    output column, contiguous in the reduction index: w16t for forward, w16 for the input gradient)."""
+    L.require_device(feat, w_rows, nbmaps, nboffs)
+    feat, w_rows = _f16(feat, "feat"), _f16(w_rows, "w_rows")
+    nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
+    k, c_out, c_red = w_rows.shape
+    if feat.shape[1] != c_red:
+        raise ValueError("Input feature size and kernel size mismatch")
+    z = torch.empty((int(n_pairs), c_out), dtype=torch.float16, device=feat.device)
+    with _Timed("pair_gemm", name=f"pair_gemm_h_kernel<{128 if c_out % 128 == 0 else 96 if c_out % 96 == 0 else 64 if c_out % 64 == 0 else 32}>",
+                pairs=int(n_pairs), c_red=c_red, c_out=c_out, k=k, esize=2):
+        L.check(L.load().ts_conv_pair_gemm_f16(L.ptr(feat), feat.shape[0], c_red, L.ptr(w_rows), k, L.ptr(nbmaps),
+                                               L.ptr(nboffs), int(n_pairs), int(gather_col), L.ptr(z), c_out,
+                                               L.stream()), "ts_conv_pair_gemm_f16")
+    return z
+
+
+def conv_gather_sum_f16(z, pos, n_rows):
+    """Pass 2 in half storage (fp32 accumulation)."""
+    L.require_device(z, pos)
+    z, pos = _f16(z, "z"), _i32(pos, "pos")
+    k = pos.shape[0]
+    if pos.shape != (k, n_rows):
+        raise ValueError(f"position table shape {tuple(pos.shape)} != {(k, n_rows)}")
+    out = torch.empty((n_rows, z.shape[1]), dtype=torch.float16, device=z.device)
+    with _Timed("gather_sum", name=f"gather_sum_h_kernel<{k if k in (8, 27) else 0}>", pairs=z.shape[0], c_red=0,
+                c_out=z.shape[1], k=k, n_rows=n_rows, esize=2):
+        L.check(L.load().ts_conv_gather_sum_f16(L.ptr(z), z.shape[1], L.ptr(pos), k, n_rows, z.shape[0], L.ptr(out),
+                                                L.stream()), "ts_conv_gather_sum_f16")
+    return out
+
+
 def trilinear_map(points, vox_coords, stride):
     """8-corner voxel indices and trilinear weights of `voxel_to_point` (minkunet/utils.py:72-82)."""
     L.require_device(points, vox_coords)

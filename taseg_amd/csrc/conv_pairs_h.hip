@@ -1,0 +1,275 @@
+// fp16-storage / fp32-accumulate form of the two-pass sparse convolution (the reference's default training mode is
+// AMP: TS/torchsparse/nn/functional/conv.py:19 casts features and kernel to half, convolution_cuda.cu runs the
+// per-offset GEMMs in half and accumulates its scatter in half; here every accumulation is fp32).
+//
+//   ts_cast_weights_f16      W f32 [K, Ci, Co] -> W16 [K, Ci, Co] and W16T [K, Co, Ci] (one pass; rows contiguous in
+//                            the reduction dimension for forward (W16T) and dgrad (W16))
+//   pair_gemm_h_kernel       Z[p, :] = X[g_p, :] @ W_k  with v_mfma_f32_16x16x32_f16 (16x the f32 MFMA rate: the
+//                            kernel is bound by the gathered-row and Z traffic, half of the fp32 path's)
+//   gather_sum_h_kernel      Y[j, :] = sum_k Z[pos[k, j], :], fp32 accumulation, half in / half out
+// Tiling = pair_gemm_fast_kernel (128 pairs x BN columns per workgroup, tiles cut per offset, 32-deep slices,
+// double-buffered LDS, one register stage).  Lane l of the MFMA holds A[row l & 15][k = 8 (l >> 4) + j] and
+// B[k = 8 (l >> 4) + j][col l & 15], j = 0..7: with both operands stored row-major in the reduction index every
+// fragment is one 16-byte LDS read.  The Z tile goes through LDS once more so that rows leave as 16-byte chunks.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+#define PH_BM 128
+#define PH_BK 32            // halves per slice (64 bytes of every gathered row)
+#define PH_AP (PH_BK + 8)   // LDS pitch in halves: 80 bytes = 20 dwords (4 mod 8)
+
+__global__ __launch_bounds__(256) void cast_weights_f16_kernel(const float *__restrict__ w, int K, int ci, int co,
+                                                               _Float16 *__restrict__ w16, _Float16 *__restrict__ w16t) {
+  // one thread per (k, ci, co) element, co fastest: coalesced read and W16 write; the transposed write is strided
+  // (weights are <= 2.6 M elements per layer and L2 resident)
+  const int64_t total = (int64_t)K * ci * co;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    const _Float16 h = (_Float16)w[e];
+    if (w16) w16[e] = h;
+    if (w16t) {
+      const int64_t k = e / ((int64_t)ci * co);
+      const int r = (int)(e - k * ci * co);
+      const int i = r / co, o = r - i * co;
+      w16t[(k * co + o) * ci + i] = h;
+    }
+  }
+}
+
+extern "C" int ts_cast_weights_f16(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *w16, void *w16t,
+                                   ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(K > 0 && c_in > 0 && c_out > 0, TS_ERR_INVALID_ARGUMENT, "ts_cast_weights_f16: bad sizes");
+  TS_REQUIRE(w && (w16 || w16t), TS_ERR_INVALID_ARGUMENT, "ts_cast_weights_f16: null pointer");
+  const int64_t total = (int64_t)K * c_in * c_out;
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total, 256), 1 << 16);
+  cast_weights_f16_kernel<<<grid, 256, 0, stream>>>(w, K, c_in, c_out, (_Float16 *)w16, (_Float16 *)w16t);
+  TS_CHECK_LAUNCH("ts_cast_weights_f16");
+  return TS_OK;
+}
+
+// X [*, R] half rows; Wr [K, O_total, R] half (row = output column, contiguous in the reduction index); Z [P, O_total] half
+template <int BN, int WR>
+__global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__restrict__ X, int R,
+                                                          const _Float16 *__restrict__ Wr, int O_total,
+                                                          const int2 *__restrict__ nbmaps,
+                                                          const int *__restrict__ nboffs, int K, int gcol,
+                                                          _Float16 *__restrict__ Z) {
+  constexpr int WC = 4 / WR;
+  constexpr int MI = (PH_BM / 16) / WR;
+  constexpr int NI = (BN / 16) / WC;
+  constexpr int A_HALVES = PH_BM * PH_AP;
+  constexpr int B_HALVES = BN * PH_AP;
+  constexpr int A_IT = PH_BM * (PH_BK / 8) / 256;   // 16-byte chunks per thread per A slice (2)
+  constexpr int B_IT = (BN * (PH_BK / 8) + 255) / 256;
+  constexpr int ZP = BN + 8;                        // pitch of the Z tile image (halves)
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+  _Float16 *Abuf = smem_h;
+  _Float16 *Bbuf = Abuf + 2 * A_HALVES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave / WC, wc = wave % WC;
+  const int o0 = blockIdx.y * BN;
+
+  // tile -> (offset k, first pair, rows), as in pair_gemm_fast_kernel
+  const int offv = nboffs[min(lane, K)];
+  const int offn = nboffs[min(lane + 1, K)];
+  int incl = lane < K ? (offn - offv + PH_BM - 1) / PH_BM : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int tile = blockIdx.x;
+  if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
+  const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
+  const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
+  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * PH_BM;
+  const int np = min(PH_BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+
+  // A slots: chunk (tid & 3) of tile row (tid >> 2) + 64 it
+  const int arow0 = tid >> 2, acol = (tid & 3) << 3;
+  const _Float16 *aptr[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int2 pr = nbmaps[p0 + min(arow0 + 64 * it, np - 1)];
+    aptr[it] = X + (int64_t)(gcol ? pr.y : pr.x) * R + acol;
+  }
+  // B slots: chunk (e & 3) of weight row (e >> 2)
+  const _Float16 *wk = Wr + ((int64_t)k * O_total + o0) * R;
+  int boff[B_IT], bdst[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int e = tid + it * 256;
+    const int col = min(e >> 2, BN - 1), c8 = (e & 3) << 3;
+    boff[it] = col * R + c8;
+    bdst[it] = col * PH_AP + c8;
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  h8 ra[A_IT], rb[B_IT];
+  auto load_regs = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) ra[it] = *(const h8 *)(aptr[it] + c0);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const h8 *)(wk + c0 + boff[it]);
+  };
+  auto store_lds = [&](_Float16 *At, _Float16 *Bt) {
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int rr = arow0 + 64 * it;
+      *(h8 *)&At[rr * PH_AP + acol] = rr < np ? ra[it] : zero;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      if (B_IT * 256 == BN * 4 || tid + it * 256 < BN * 4) *(h8 *)&Bt[bdst[it]] = rb[it];
+  };
+  auto mma = [&](const _Float16 *At, const _Float16 *Bt) {
+    h8 a[MI], b[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *(const h8 *)&At[((wr * MI + mi) * 16 + r16) * PH_AP + 8 * g];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *(const h8 *)&Bt[((wc * NI + ni) * 16 + r16) * PH_AP + 8 * g];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  load_regs(0);
+  int t = 0;
+  for (int c0 = 0; c0 < R; c0 += PH_BK, ++t) {
+    _Float16 *At = Abuf + (t & 1) * A_HALVES, *Bt = Bbuf + (t & 1) * B_HALVES;
+    store_lds(At, Bt);
+    __syncthreads();
+    if (c0 + PH_BK < R) load_regs(c0 + PH_BK);
+    mma(At, Bt);
+  }
+  // Z tile: accumulators -> half -> LDS image [row][col] -> 16-byte chunks of whole rows
+  __syncthreads();
+  _Float16 *Zt = smem_h;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        Zt[((wr * MI + mi) * 16 + 4 * g + q) * ZP + (wc * NI + ni) * 16 + r16] = (_Float16)acc[mi][ni][q];
+  __syncthreads();
+  constexpr int CH = BN / 8;   // 16-byte chunks per row
+  for (int e = tid; e < PH_BM * CH; e += 256) {
+    const int row = e / CH, ch = e - row * CH;
+    if (row < np) *(h8 *)(Z + (int64_t)(p0 + row) * O_total + o0 + ch * 8) = *(const h8 *)&Zt[row * ZP + ch * 8];
+  }
+}
+
+template <int BN, int WR>
+static int launch_pair_gemm_h(const _Float16 *X, int R, const _Float16 *Wr, int O_total, const int2 *nbmaps,
+                              const int *nboffs, int K, int64_t P, int gcol, _Float16 *Z, hipStream_t stream) {
+  const size_t stage = (size_t)2 * (PH_BM * PH_AP + BN * PH_AP) * 2;
+  const size_t ztile = (size_t)PH_BM * (BN + 8) * 2;
+  const size_t lds = std::max(stage, ztile);
+  dim3 grid((unsigned)(ts_cdiv(P, PH_BM) + K), (unsigned)(O_total / BN));
+  pair_gemm_h_kernel<BN, WR><<<grid, 256, lds, stream>>>(X, R, Wr, O_total, nbmaps, nboffs, K, gcol, Z);
+  TS_CHECK_LAUNCH("conv_pair_gemm_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_conv_pair_gemm_f16(const void *feat, int64_t n_rows, int32_t c_red, const void *w_rows, int32_t K,
+                                     const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
+                                     void *z, int32_t c_out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n_rows >= 0 && c_red > 0 && c_out > 0 && K > 0 && K <= 63 && n_pairs >= 0 && n_pairs < (1LL << 31),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_pair_gemm_f16: bad sizes");
+  TS_REQUIRE(c_red % PH_BK == 0 && c_out % 32 == 0, TS_ERR_UNSUPPORTED,
+             "ts_conv_pair_gemm_f16: channel counts must be multiples of 32");
+  if (n_pairs == 0) return TS_OK;
+  TS_REQUIRE(feat && w_rows && nbmaps && nboffs && z, TS_ERR_INVALID_ARGUMENT, "ts_conv_pair_gemm_f16: null pointer");
+  TS_REQUIRE(((((uintptr_t)feat) | ((uintptr_t)w_rows) | ((uintptr_t)z)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_pair_gemm_f16: pointers must be 16-byte aligned");
+  const _Float16 *x = (const _Float16 *)feat, *w = (const _Float16 *)w_rows;
+  const int2 *nm = (const int2 *)nbmaps;
+  const int gc = gather_col ? 1 : 0;
+#define TS_PH(BN, WR) launch_pair_gemm_h<BN, WR>(x, c_red, w, c_out, nm, nboffs, K, n_pairs, gc, (_Float16 *)z, stream)
+  if (c_out % 128 == 0) return TS_PH(128, 2);
+  if (c_out % 96 == 0) return TS_PH(96, 2);
+  if (c_out % 64 == 0) return TS_PH(64, 2);
+  return TS_PH(32, 4);
+#undef TS_PH
+}
+
+// ------------------------------------------------------------------------------------- pass 2, half storage
+template <int KT>
+__global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__restrict__ Z, int C,
+                                                           const int *__restrict__ pos, int K, int64_t n_rows,
+                                                           _Float16 *__restrict__ out) {
+  const int c8n = C >> 3;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = n_rows * c8n, step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    const int64_t j = e / c8n;
+    const int c8 = (int)(e - j * c8n) << 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (KT > 0) {
+      int p[KT > 0 ? KT : 1];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) p[k] = pos[(int64_t)k * n_rows + j];
+      h8 v[KT > 0 ? KT : 1];
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+        v[k] = p[k] >= 0 ? *(const h8 *)(Z + (int64_t)p[k] * C + c8) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += (float)v[k][i];
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const int p = pos[(int64_t)k * n_rows + j];
+        if (p >= 0) {
+          const h8 v = *(const h8 *)(Z + (int64_t)p * C + c8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+        }
+      }
+    }
+    h8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)acc[i];
+    *(h8 *)(out + j * C + c8) = o;
+  }
+}
+
+extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
+                                      int64_t n_pairs, void *out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(c > 0 && (c & 7) == 0 && K > 0 && n_rows >= 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_gather_sum_f16: bad sizes (C must be a multiple of 8)");
+  if (n_rows == 0) return TS_OK;
+  TS_REQUIRE(pos && out && (z || n_pairs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum_f16: null pointer");
+  TS_REQUIRE(((((uintptr_t)z) | ((uintptr_t)out)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_gather_sum_f16: pointers must be 16-byte aligned");
+  const int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 8), 256), 1 << 20);
+  const _Float16 *zz = (const _Float16 *)z;
+  if (K == 27)
+    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out);
+  else if (K == 8)
+    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out);
+  else
+    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out);
+  TS_CHECK_LAUNCH("ts_conv_gather_sum_f16");
+  return TS_OK;
+}

@@ -356,6 +356,40 @@ def test_conv_fast_path_equals_generic_kernels(B, F, ci, co):
         close(fast[2], other[2], 1e-5)
 
 
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 64), (128, 128), (384, 256), (256, 192), (32, 128)])
+def test_conv_f16_path_vs_fp32_on_rounded_operands(B, F, ci, co):
+    """half-storage pair GEMM + gather-sum (forward and input gradient) against the fp32 kernels run on the SAME
+    half-rounded operands: fp32 accumulation everywhere, so only the half rounding of Z and of the output remains
+    (2^-11 relative each, summed over <= 27 terms)"""
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    c = _blob(13, n=5000, extent=24)
+    rs = np.random.RandomState(ci * 7 + co)
+    x = T(rs.randn(len(c), ci).astype(np.float32)).half()
+    gy = T(rs.randn(len(c), co).astype(np.float32)).half()
+    w = T((rs.randn(27, ci, co) / np.sqrt(27 * ci)).astype(np.float32))
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+    total = int(km["nboffs"][-1])
+    w16, w16t = B.cast_weights_f16(w)
+    assert torch.equal(w16, w.half()) and torch.equal(w16t, w.half().transpose(1, 2).contiguous())
+    # forward
+    z = B.conv_pair_gemm_f16(x, w16t, km["nbmaps"], km["nboffs"], total, gather_col=0)
+    y = B.conv_gather_sum_f16(z, km["pos_out"], len(c))
+    z32 = B.conv_pair_gemm(x.float(), w16.float(), km["nbmaps"], km["nboffs"], total, gather_col=0)
+    y32 = B.conv_gather_sum(z32, km["pos_out"], len(c))
+    assert y.dtype == torch.float16
+    close(z.float(), z32, 1e-3)
+    close(y.float(), y32, 3e-3)
+    # input gradient: gather output rows, W_k^T
+    zt = B.conv_pair_gemm_f16(gy, w16, km["nbmaps"], km["nboffs"], total, gather_col=1)
+    gx = B.conv_gather_sum_f16(zt, km["pos_in"], len(c))
+    zt32 = B.conv_pair_gemm(gy.float(), w16.float(), km["nbmaps"], km["nboffs"], total, gather_col=1, weight_transposed=True)
+    gx32 = B.conv_gather_sum(zt32, km["pos_in"], len(c))
+    close(zt.float(), zt32, 1e-3)
+    close(gx.float(), gx32, 3e-3)
+    # deterministic
+    assert torch.equal(B.conv_pair_gemm_f16(x, w16t, km["nbmaps"], km["nboffs"], total, gather_col=0), z)
+
+
 def test_conv_reference_form_entry_points(B, g_ops):
     """the ten-function lower boundary: explicit nbmaps + host nbsizes, plain and transposed"""
     c = g_ops["coords"]
