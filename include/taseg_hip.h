@@ -328,6 +328,11 @@ int ts_conv_pair_gemm_f16(const void *feat, int64_t n_rows, int32_t c_red, const
                           int32_t c_out, ts_stream_t stream);
 int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
                            void *out, ts_stream_t stream);
+/*   ts_conv_wgrad_f16        grad_kernel[k] (fp32 [K, c_a, c_b], zeroed here) = sum_pairs a[pa]^T b[pb], half rows in,
+ *                            fp32 accumulation (MFMA fragments via ds_read_b64_tr_b16), chunk partials by float atomics */
+int ts_conv_wgrad_f16(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b, const int32_t *nbmaps,
+                      const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
+                      ts_stream_t stream);
 
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_gather_sum_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp]),
+    "ts_conv_wgrad_f16": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

@@ -365,6 +365,21 @@ def conv_gather_sum_f16(z, pos, n_rows):
     return out
 
 
+def conv_wgrad_f16(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
+    """grad_kernel[k] = sum_pairs a[pa]^T b[pb] from half rows -> fp32 [K, c_a, c_b]."""
+    L.require_device(a_feat, b_feat, nbmaps, nboffs)
+    a_feat, b_feat = _f16(a_feat, "a_feat"), _f16(b_feat, "b_feat")
+    nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
+    out = torch.empty((kernel_volume, a_feat.shape[1], b_feat.shape[1]), dtype=torch.float32, device=a_feat.device)
+    pick = lambda c: 128 if c % 128 == 0 else 96 if c % 96 == 0 else 64 if c % 64 == 0 else 32  # noqa: E731
+    with _Timed("conv_wgrad", name=f"wgrad_h_kernel<{pick(a_feat.shape[1])},{pick(b_feat.shape[1])}>", nboffs=nboffs,
+                c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume, esize=2):
+        L.check(L.load().ts_conv_wgrad_f16(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
+                                           L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
+                                           L.ptr(out), L.stream()), "ts_conv_wgrad_f16")
+    return out
+
+
 def trilinear_map(points, vox_coords, stride):
     """8-corner voxel indices and trilinear weights of `voxel_to_point` (minkunet/utils.py:72-82)."""
     L.require_device(points, vox_coords)

@@ -273,3 +273,218 @@ extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *p
   TS_CHECK_LAUNCH("ts_conv_gather_sum_f16");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------- weight gradient, half inputs
+//   dW_k[ci, co] (fp32) = sum_{pairs p of k} A[pa_p, ci] * B[pb_p, co],   A, B half rows
+// Chunking / flushing as wgrad_gemm_fast_kernel.  The reduction runs over the PAIR index, but both operands arrive
+// pair-major (one gathered row per pair); they are staged as they come ([pair][channel] images, 16-byte chunks) and
+// the MFMA fragments - 8 consecutive pairs of one channel per lane - are read with gfx950's transposing LDS load
+// ds_read_b64_tr_b16: a 16-lane group reads a 4-pair x 16-channel block and every lane receives the 4 pairs of its
+// channel (lane 4q + p of the group addresses pair row q, channels 4p .. 4p+3).
+typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define WH_PS 64            // pairs per step (two 32-deep MFMA k-blocks)
+#define WH_MAXCHUNK 1024
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void wgrad_h_kernel(const _Float16 *__restrict__ A, int CA,
+                                                      const _Float16 *__restrict__ B, int CB,
+                                                      const int2 *__restrict__ nbmaps, const int *__restrict__ nboffs,
+                                                      int K, int P, int col_a, int chunk, float *__restrict__ dW) {
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int XP = TM + 8, YP = TN + 8;              // pitches in halves (16-byte multiples, 4 mod 8 dwords)
+  constexpr int A_IT = (WH_PS * (TM / 8) + 255) / 256, B_IT = (WH_PS * (TN / 8) + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_w[];
+  _Float16 *Xl = smem_w;                               // 2 x [64][XP]
+  _Float16 *Yl = Xl + 2 * WH_PS * XP;                  // 2 x [64][YP]
+  int *idxA = (int *)(Yl + 2 * WH_PS * YP), *idxB = idxA + WH_MAXCHUNK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int p_beg = blockIdx.x * chunk;
+  const int p_end = min(P, p_beg + chunk);
+  if (p_beg >= p_end) return;
+  const int tiles_n = CB / TN;
+  const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
+
+  for (int t = tid; t < p_end - p_beg; t += 256) {
+    const int2 pr = nbmaps[p_beg + t];
+    idxA[t] = col_a ? pr.y : pr.x;
+    idxB[t] = col_a ? pr.x : pr.y;
+  }
+  const int offv = nboffs[min(lane, K)];
+  const int k0 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < K && offv <= p_beg)) - 1;
+  auto off_at = [&](int kk) { return __builtin_amdgcn_readlane(offv, kk); };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  struct WStep {
+    int k, p0, np;
+  };
+  auto advance = [&](WStep st) -> WStep {
+    int kend = min(off_at(st.k + 1), p_end);
+    int pn = st.p0 + WH_PS;
+    if (pn < kend) {
+      st.p0 = pn;
+      st.np = min(WH_PS, kend - pn);
+      return st;
+    }
+    pn = kend;
+    for (++st.k; st.k < K && pn < p_end; ++st.k) {
+      kend = min(off_at(st.k + 1), p_end);
+      if (kend > pn) {
+        st.p0 = pn;
+        st.np = min(WH_PS, kend - pn);
+        return st;
+      }
+    }
+    st.k = K;
+    return st;
+  };
+  const _Float16 *abase = A + ci0, *bbase = B + co0;
+  h8 ra[A_IT], rb[B_IT];
+  auto load_regs = [&](const WStep &st) {
+    const int l0 = st.p0 - p_beg, last = st.np - 1;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = min(tid + it * 256, WH_PS * (TM / 8) - 1);
+      const int pp = e / (TM / 8), c8 = (e - pp * (TM / 8)) << 3;
+      ra[it] = *(const h8 *)(abase + (int64_t)idxA[l0 + min(pp, last)] * CA + c8);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = min(tid + it * 256, WH_PS * (TN / 8) - 1);
+      const int pp = e / (TN / 8), c8 = (e - pp * (TN / 8)) << 3;
+      rb[it] = *(const h8 *)(bbase + (int64_t)idxB[l0 + min(pp, last)] * CB + c8);
+    }
+  };
+  auto store_lds = [&](_Float16 *xl, _Float16 *yl, const WStep &st) {
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TM / 8), c8 = (e - pp * (TM / 8)) << 3;
+      if (e < WH_PS * (TM / 8)) *(h8 *)&xl[pp * XP + c8] = pp < st.np ? ra[it] : zero;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * 256;
+      const int pp = e / (TN / 8), c8 = (e - pp * (TN / 8)) << 3;
+      if (e < WH_PS * (TN / 8)) *(h8 *)&yl[pp * YP + c8] = pp < st.np ? rb[it] : zero;
+    }
+  };
+  // transposed fragment: 8 consecutive pairs (rows r0 .. r0+7 of the image) of channel c0 + r16
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  auto frag = [&](const _Float16 *img, int pitch, int r0, int c0) -> h8 {
+    typedef hv4 __attribute__((address_space(3))) * lds_hv4;
+    const hv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + tq) * pitch + c0 + 4 * tp));
+    const hv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + 4 + tq) * pitch + c0 + 4 * tp));
+    h8 v;
+    v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+    v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+    return v;
+  };
+
+  WStep cur;
+  cur.k = k0;
+  cur.p0 = p_beg;
+  cur.np = min(WH_PS, min(off_at(k0 + 1), p_end) - p_beg);
+  __syncthreads();  // pair indices visible
+  load_regs(cur);
+  int buf = 0;
+  while (cur.k < K) {
+    _Float16 *xl = Xl + buf * (WH_PS * XP), *yl = Yl + buf * (WH_PS * YP);
+    store_lds(xl, yl, cur);
+    __syncthreads();
+    const WStep nxt = advance(cur);
+    if (nxt.k < K) load_regs(nxt);
+#pragma unroll
+    for (int kb = 0; kb < WH_PS; kb += 32) {
+      h8 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = frag(xl, XP, kb + 8 * g, (wr * MI + mi) * 16);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = frag(yl, YP, kb + 8 * g, (wc * NI + ni) * 16);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (nxt.k != cur.k) {
+      float *dwk = dW + (int64_t)cur.k * CA * CB + (int64_t)ci0 * CB + co0;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            atomicAdd(&dwk[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * CB + (wc * NI + ni) * 16 + r16],
+                      acc[mi][ni][q]);
+          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    cur = nxt;
+    buf ^= 1;
+  }
+}
+
+template <int TM, int TN>
+static int launch_wgrad_h(const _Float16 *A, int CA, const _Float16 *B, int CB, const int2 *nbmaps, const int *nboffs,
+                          int K, int col_a, int64_t n_pairs, float *dW, hipStream_t stream) {
+  const int tiles = (CA / TM) * (CB / TN);
+  int64_t chunk = ts_cdiv(n_pairs * tiles, 512);
+  chunk = std::min<int64_t>(WH_MAXCHUNK, std::max<int64_t>(128, (chunk + WH_PS - 1) / WH_PS * WH_PS));
+  dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
+  const size_t lds = (size_t)2 * WH_PS * ((TM + 8) + (TN + 8)) * 2 + 2 * WH_MAXCHUNK * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TS_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_h_kernel<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024), "hipFuncSetAttribute");
+    attr_set = true;
+  }
+  wgrad_h_kernel<TM, TN><<<grid, 256, lds, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a, (int)chunk, dW);
+  TS_CHECK_LAUNCH("conv_wgrad_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_conv_wgrad_f16(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b,
+                                 const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
+                                 int64_t n_pairs, float *grad_kernel, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && K <= 63 && n_pairs >= 0 && n_pairs < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_wgrad_f16: bad sizes");
+  TS_REQUIRE(c_a % 32 == 0 && c_b % 32 == 0, TS_ERR_UNSUPPORTED, "ts_conv_wgrad_f16: channel counts must be multiples of 32");
+  TS_REQUIRE(grad_kernel && nboffs, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_f16: null pointer");
+  TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
+  if (n_pairs == 0) return TS_OK;
+  TS_REQUIRE(a_feat && b_feat && nbmaps, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_f16: null pointer");
+  TS_REQUIRE(((((uintptr_t)a_feat) | ((uintptr_t)b_feat)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_wgrad_f16: pointers must be 16-byte aligned");
+  const _Float16 *a = (const _Float16 *)a_feat, *b = (const _Float16 *)b_feat;
+  const int2 *nm = (const int2 *)nbmaps;
+  col_a = col_a ? 1 : 0;
+  auto pick = [](int c) { return c % 128 == 0 ? 128 : c % 96 == 0 ? 96 : c % 64 == 0 ? 64 : 32; };
+  const int tm = pick(c_a), tn = pick(c_b);
+#define TS_WH(TM, TN) launch_wgrad_h<TM, TN>(a, c_a, b, c_b, nm, nboffs, K, col_a, n_pairs, grad_kernel, stream)
+#define TS_WH_ROW(TM)                    \
+  switch (tn) {                          \
+    case 32: return TS_WH(TM, 32);       \
+    case 64: return TS_WH(TM, 64);       \
+    case 96: return TS_WH(TM, 96);       \
+    default: return TS_WH(TM, 128);      \
+  }
+  switch (tm) {
+    case 32: TS_WH_ROW(32)
+    case 64: TS_WH_ROW(64)
+    case 96: TS_WH_ROW(96)
+    default: TS_WH_ROW(128)
+  }
+#undef TS_WH_ROW
+#undef TS_WH
+}

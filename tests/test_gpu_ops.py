@@ -388,6 +388,11 @@ def test_conv_f16_path_vs_fp32_on_rounded_operands(B, F, ci, co):
     close(gx.float(), gx32, 3e-3)
     # deterministic
     assert torch.equal(B.conv_pair_gemm_f16(x, w16t, km["nbmaps"], km["nboffs"], total, gather_col=0), z)
+    # weight gradient: half rows in, fp32 out (transposing LDS reads feed the MFMA)
+    gw = B.conv_wgrad_f16(x, gy, km["nbmaps"], km["nboffs"], 27, col_a=0, max_pairs=total)
+    gw32 = B.conv_wgrad(x.float(), gy.float(), km["nbmaps"], km["nboffs"], 27, col_a=0, max_pairs=total)
+    assert gw.dtype == torch.float32
+    close(gw, gw32, 2e-5)            # identical products, fp32 accumulation in a different order
 
 
 def test_conv_reference_form_entry_points(B, g_ops):

@@ -59,6 +59,18 @@ if "dgrad" in what:
     timed(lambda: B.conv_pair_gemm(gy, w, km.nbmaps_buf, km.nboffs, P, 1, weight_transposed=True), "dgrad", flops)
 if "wgrad" in what:
     timed(lambda: B.conv_wgrad(xf, gy, km.nbmaps_buf, km.nboffs, 27, col_a=0, max_pairs=P), "wgrad", flops)
+if "f16" in what:
+    w16, w16t = B.cast_weights_f16(w)
+    xh, gyh = xf.half(), gy.half()
+    timed(lambda: B.cast_weights_f16(w), "cast16")
+    timed(lambda: B.conv_pair_gemm_f16(xh, w16t, km.nbmaps_buf, km.nboffs, P, 0), "fwd16", flops,
+          P * (args.cin + args.cout) * 2)
+    timed(lambda: B.conv_pair_gemm_f16(gyh, w16, km.nbmaps_buf, km.nboffs, P, 1), "dgrad16", flops,
+          P * (args.cin + args.cout) * 2)
+    timed(lambda: B.conv_wgrad_f16(xh, gyh, km.nbmaps_buf, km.nboffs, 27, col_a=0, max_pairs=P), "wgrad16", flops,
+          P * (args.cin + args.cout) * 2)
+    zh = B.conv_pair_gemm_f16(xh, w16t, km.nbmaps_buf, km.nboffs, P, 0)
+    timed(lambda: B.conv_gather_sum_f16(zh, km.pos_out, n), "gsum16", None, P * args.cout * 2 + n * args.cout * 2 + 27 * n * 4)
 if "gsum" in what:
     z = B.conv_pair_gemm(xf, w, km.nbmaps_buf, km.nboffs, P, 0)
     timed(lambda: B.conv_gather_sum(z, km.pos_out, n), "gsum", None, P * args.cout * 4 + n * args.cout * 4 + 27 * n * 4)
