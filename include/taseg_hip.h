@@ -334,6 +334,17 @@ int ts_conv_wgrad_f16(const void *a_feat, int32_t c_a, const void *b_feat, int32
                       const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
                       ts_stream_t stream);
 
+/* Half-storage forms of ts_bn_act_train_*: x / residual / out / grad_* are IEEE half [n, c] (c % 8 == 0), the mask is
+ * one byte per 8 elements; statistics, affine parameters, their gradients and all arithmetic are fp32. */
+int ts_bn_act_train_forward_f16(const void *x, const void *residual, const float *weight, const float *bias,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, int64_t n,
+                                int32_t c, float eps, float momentum, int32_t relu, float *mean, float *invstd,
+                                void *out, uint8_t *mask, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_bn_act_train_backward_f16(const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                                 const float *invstd, const float *weight, int64_t n, int32_t c, void *grad_x,
+                                 void *grad_residual, float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes,
+                                 ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,

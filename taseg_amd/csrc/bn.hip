@@ -600,3 +600,197 @@ extern "C" int ts_bn_sync_backward_reduce(const float *grad_out, const uint8_t *
   TS_CHECK_LAUNCH("ts_bn_sync_backward_reduce");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Half-storage variants of the single-process training BatchNorm (+ residual) (+ ReLU): activations, residual and
+// gradients are IEEE half in HBM, every reduction / normalisation runs in fp32 (statistics, affine parameters and
+// parameter gradients stay fp32, as under torch.autocast).  One thread handles 8 channels (one 16-byte chunk);
+// the ReLU mask keeps 1 bit per element (one byte per chunk).
+typedef _Float16 bn_h8 __attribute__((ext_vector_type(8)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_h_kernel(const _Float16 *__restrict__ X,
+                                                           const _Float16 *__restrict__ DY,
+                                                           const unsigned char *__restrict__ MASK,
+                                                           const float *__restrict__ mean, int64_t n, int c,
+                                                           int rows_per_wg, float *__restrict__ part) {
+  __shared__ float red[2][256 * 8];
+  const int cq = c >> 3, rpp = 256 / cq;
+  const int tid = threadIdx.x, ty = tid / cq, tx = tid - ty * cq;
+  const bool active = ty < rpp;
+  float s0[8], s1[8], mu[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s0[i] = s1[i] = mu[i] = 0.f;
+  if (MODE != 0 && active) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mu[i] = mean[8 * tx + i];
+  }
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_wg, r_end = min(n, r_beg + rows_per_wg);
+  if (active) {
+#pragma unroll 2
+    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
+      const bn_h8 x = *(const bn_h8 *)(X + r * c + 8 * tx);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = (float)x[i];
+          s0[i] += v;
+          s1[i] += v * v;
+        }
+      } else {
+        const bn_h8 d = *(const bn_h8 *)(DY + r * c + 8 * tx);
+        const unsigned mk = MODE == 2 ? MASK[r * cq + tx] : 0xFFu;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float dv = ((mk >> i) & 1) ? (float)d[i] : 0.f;
+          s0[i] += dv;
+          s1[i] += dv * ((float)x[i] - mu[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    red[0][tid * 8 + i] = s0[i];
+    red[1][tid * 8 + i] = s1[i];
+  }
+  __syncthreads();
+  float *out = part + (int64_t)blockIdx.x * 2 * c;
+  for (int ch = tid; ch < c; ch += 256) {
+    const int q = ch >> 3, l = ch & 7;
+    float a = 0.f, b = 0.f;
+    for (int y = 0; y < rpp; ++y) {
+      a += red[0][(y * cq + q) * 8 + l];
+      b += red[1][(y * cq + q) * 8 + l];
+    }
+    out[ch] = a;
+    out[c + ch] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_h_kernel(const bn_h8 *__restrict__ X, const bn_h8 *__restrict__ RES,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ w, const float *__restrict__ b,
+                                                           int64_t total8, int cq, int relu, bn_h8 *__restrict__ OUT,
+                                                           unsigned char *__restrict__ MASK) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total8; e += step) {
+    const int q = (int)(e % cq) * 8;
+    const bn_h8 x = X[e];
+    bn_h8 r;
+    if (RES) r = RES[e];
+    bn_h8 y;
+    unsigned mk = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = ((float)x[i] - mean[q + i]) * invstd[q + i] * w[q + i] + b[q + i];
+      if (RES) v += (float)r[i];
+      if (relu) {
+        mk |= (v > 0.f ? 1u : 0u) << i;
+        v = fmaxf(v, 0.f);
+      }
+      y[i] = (_Float16)v;
+    }
+    if (relu && MASK) MASK[e] = (unsigned char)mk;
+    OUT[e] = y;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_coef_h_kernel(const bn_h8 *__restrict__ GOUT,
+                                                                const unsigned char *__restrict__ MASK,
+                                                                const bn_h8 *__restrict__ X,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ coef, int64_t total8, int c,
+                                                                bn_h8 *__restrict__ GX, bn_h8 *__restrict__ GRES) {
+  const int cq = c >> 3;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total8; e += step) {
+    const int q = (int)(e % cq) * 8;
+    const bn_h8 gin = GOUT[e], x = X[e];
+    const unsigned mk = MASK ? MASK[e] : 0xFFu;
+    bn_h8 g, gx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float gv = ((mk >> i) & 1) ? (float)gin[i] : 0.f;
+      g[i] = (_Float16)gv;
+      const float is = invstd[q + i];
+      gx[i] = (_Float16)((gv - coef[q + i] - ((float)x[i] - mean[q + i]) * coef[c + q + i]) * is * w[q + i]);
+    }
+    if (GRES) GRES[e] = g;
+    GX[e] = gx;
+  }
+}
+
+static inline int bn_rows_per_slice_h(int64_t n, int c) {
+  const int rpp = 256 / (c >> 3);
+  int64_t rows = std::max<int64_t>(ts_cdiv(n, BN_MAX_SLICES), 32);
+  rows = ts_cdiv(rows, rpp) * rpp;
+  return (int)rows;
+}
+
+extern "C" int ts_bn_act_train_forward_f16(const void *x, const void *residual, const float *weight, const float *bias,
+                                           float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                           int64_t n, int32_t c, float eps, float momentum, int32_t relu, float *mean,
+                                           float *invstd, void *out, uint8_t *mask, void *ws, size_t ws_bytes,
+                                           ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n > 0 && c > 0 && (c & 7) == 0 && c <= 2048, TS_ERR_UNSUPPORTED,
+             "ts_bn_act_train_forward_f16: need N > 0 and C a multiple of 8, <= 2048");
+  TS_REQUIRE(x && weight && bias && mean && invstd && out && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_forward_f16: null pointer");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_forward_f16: workspace too small");
+  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && (!residual || bn_aligned(residual)) && bn_aligned(ws),
+             TS_ERR_INVALID_ARGUMENT, "ts_bn_act_train_forward_f16: pointers must be 16-byte aligned");
+  float *part = (float *)ws;
+  const int rows = bn_rows_per_slice_h(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  bn_partial_h_kernel<0><<<slices, 256, 0, stream>>>((const _Float16 *)x, nullptr, nullptr, nullptr, n, c, rows, part);
+  bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum,
+                                                                           running_mean, running_var, mean, invstd,
+                                                                           num_batches_tracked);
+  const int64_t total8 = n * (c / 8);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total8, 256), 1 << 16);
+  bn_act_fwd_h_kernel<<<grid, 256, 0, stream>>>((const bn_h8 *)x, (const bn_h8 *)residual, mean, invstd, weight, bias,
+                                                total8, c / 8, relu, (bn_h8 *)out, mask);
+  TS_CHECK_LAUNCH("ts_bn_act_train_forward_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_act_train_backward_f16(const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                                            const float *invstd, const float *weight, int64_t n, int32_t c,
+                                            void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
+                                            void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n > 0 && c > 0 && (c & 7) == 0 && c <= 2048, TS_ERR_UNSUPPORTED,
+             "ts_bn_act_train_backward_f16: need N > 0 and C a multiple of 8, <= 2048");
+  TS_REQUIRE(grad_out && x && mean && invstd && weight && grad_x && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_backward_f16: null pointer");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_train_backward_f16: workspace too small");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) && (!grad_residual || bn_aligned(grad_residual)) &&
+                 bn_aligned(ws), TS_ERR_INVALID_ARGUMENT, "ts_bn_act_train_backward_f16: pointers must be 16-byte aligned");
+  float *part = (float *)ws;
+  float *coef = part + (size_t)BN_MAX_SLICES * 2 * c;
+  const int rows = bn_rows_per_slice_h(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  if (mask)
+    bn_partial_h_kernel<2><<<slices, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_out, mask, mean, n, c,
+                                                       rows, part);
+  else
+    bn_partial_h_kernel<1><<<slices, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_out, nullptr, mean, n,
+                                                       c, rows, part);
+  bn_bwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, invstd, coef,
+                                                                           grad_weight, grad_bias);
+  const int64_t total8 = n * (c / 8);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total8, 256), 1 << 16);
+  bn_act_bwd_coef_h_kernel<<<grid, 256, 0, stream>>>((const bn_h8 *)grad_out, mask, (const bn_h8 *)x, mean, invstd, weight,
+                                                     coef, total8, c, (bn_h8 *)grad_x, (bn_h8 *)grad_residual);
+  TS_CHECK_LAUNCH("ts_bn_act_train_backward_f16");
+  return TS_OK;
+}

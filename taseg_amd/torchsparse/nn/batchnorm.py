@@ -15,8 +15,9 @@ __all__ = ["batch_norm_train", "fast_path_ok"]
 
 
 def fast_path_ok(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 \
-        and x.shape[0] > 0
+    if not (x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.shape[1] <= 1024):
+        return False
+    return (x.dtype == torch.float32 and x.shape[1] % 4 == 0) or (x.dtype == torch.float16 and x.shape[1] % 8 == 0)
 
 
 class _BatchNormTrain(Function):
@@ -66,17 +67,28 @@ class _BatchNormActTrain(Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, group):
-        x = x.contiguous()
+        half = x.dtype == torch.float16 and group is None
+        x = x.contiguous() if (half or x.dtype == torch.float32) else x.contiguous().float()
         n, c = x.shape
         lib = L.load()
         if residual is not None:
-            residual = residual.contiguous()
+            residual = residual.contiguous().to(x.dtype)
         stats = torch.empty((2, c), dtype=torch.float32, device=x.device)        # mean, invstd
         mean, invstd = stats[0], stats[1]
         out = torch.empty_like(x)
-        mask = torch.empty(n * (c // 4), dtype=torch.uint8, device=x.device) if relu else None
+        per = 8 if half else 4                         # elements per mask byte
+        mask = torch.empty(n * (c // per), dtype=torch.uint8, device=x.device) if relu else None
         total_dev = None
-        if group is None:
+        ctx.half = half
+        if half:
+            # half activations in / out, fp32 statistics and arithmetic (what autocast does to batch_norm)
+            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+            L.check(lib.ts_bn_act_train_forward_f16(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
+                                                    L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), n, c,
+                                                    float(eps), float(momentum), 1 if relu else 0, L.ptr(mean),
+                                                    L.ptr(invstd), L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(),
+                                                    L.stream()), "ts_bn_act_train_forward_f16")
+        elif group is None:
             # single process: partial reductions, statistics and the elementwise pass in one backend call
             ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
             L.check(lib.ts_bn_act_train_forward(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
@@ -107,11 +119,19 @@ class _BatchNormActTrain(Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, weight, mean, invstd, mask = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
+        grad_out = grad_out.contiguous().to(x.dtype)
         n, c = x.shape
         lib = L.load()
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        if ctx.half:
+            gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+            L.check(lib.ts_bn_act_train_backward_f16(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                                     L.ptr(weight), n, c, L.ptr(grad_x), L.ptr(grad_res),
+                                                     L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()),
+                    "ts_bn_act_train_backward_f16")
+            return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
         if ctx.group is None:
             gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)      # grad_weight, grad_bias
             ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)

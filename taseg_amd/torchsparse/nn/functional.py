@@ -54,20 +54,22 @@ def spcount(coords: torch.Tensor, num) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------ voxelize / devoxelize
 class _Voxelize(Function):
-    @staticmethod
-    @_fwd
-    def forward(ctx, feats, idx, counts):
-        idx = idx.int().contiguous()
-        counts = counts.int().contiguous()
-        out = B.voxelize_forward_cuda(feats.contiguous(), idx, counts)
-        ctx.saved = (idx, counts, feats.shape[0])
-        return out
+    """fp32 kernels; under autocast / for half features the result is stored in half like the reference's
+    `custom_fwd(cast_inputs=torch.half)` op (voxelize.py:13) - accumulation stays fp32."""
 
     @staticmethod
-    @_bwd
+    def forward(ctx, feats, idx, counts):
+        half = _amp_half(feats)
+        idx = idx.int().contiguous()
+        counts = counts.int().contiguous()
+        out = B.voxelize_forward_cuda(feats.contiguous().float(), idx, counts)
+        ctx.saved = (idx, counts, feats.shape[0], feats.dtype)
+        return out.half() if half else out
+
+    @staticmethod
     def backward(ctx, grad_out):
-        idx, counts, n = ctx.saved
-        return B.voxelize_backward_cuda(grad_out.contiguous(), idx, counts, n), None, None
+        idx, counts, n, dtype = ctx.saved
+        return B.voxelize_backward_cuda(grad_out.contiguous().float(), idx, counts, n).to(dtype), None, None
 
 
 def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
@@ -76,23 +78,24 @@ def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) 
 
 
 class _Devoxelize(Function):
-    @staticmethod
-    @_fwd
-    def forward(ctx, feats, idx, weights, order=None):
-        idx = idx.int().contiguous()
-        weights = weights.contiguous()
-        out = B.devoxelize_forward_cuda(feats.contiguous(), idx, weights)
-        ctx.saved = (idx, weights, feats.shape[0], order)
-        return out
+    """fp32 kernels; half result under autocast / for half features (devoxelize.py:54), fp32 accumulation."""
 
     @staticmethod
-    @_bwd
+    def forward(ctx, feats, idx, weights, order=None):
+        half = _amp_half(feats)
+        idx = idx.int().contiguous()
+        weights = weights.contiguous().float()
+        out = B.devoxelize_forward_cuda(feats.contiguous().float(), idx, weights)
+        ctx.saved = (idx, weights, feats.shape[0], order, feats.dtype)
+        return out.half() if half else out
+
+    @staticmethod
     def backward(ctx, grad_out):
-        idx, weights, m, order = ctx.saved
-        grad_out = grad_out.contiguous()
+        idx, weights, m, order, dtype = ctx.saved
+        grad_out = grad_out.contiguous().float()
         if grad_out.shape[1] % 4 == 0 and grad_out.shape[1] <= 1024:
-            return B.devoxelize_backward_runs(grad_out, idx, weights, m, order), None, None, None
-        return B.devoxelize_backward_cuda(grad_out, idx, weights, m), None, None, None
+            return B.devoxelize_backward_runs(grad_out, idx, weights, m, order).to(dtype), None, None, None
+        return B.devoxelize_backward_cuda(grad_out, idx, weights, m).to(dtype), None, None, None
 
 
 def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tensor,
@@ -198,52 +201,84 @@ def build_kernel_map(in_coords, out_coords, kernel_size, tensor_stride, dilation
 
 
 # ------------------------------------------------------------------------------ convolution
+def _amp_half(feats: torch.Tensor) -> bool:
+    """Should this op store its result in half?  The reference decorates its sparse ops with
+    `custom_fwd(cast_inputs=torch.half)` (conv.py:19, voxelize.py:13, devoxelize.py:54): under torch.autocast inputs
+    are cast to half and outputs are half.  Half features are also accepted outside autocast."""
+    return feats.is_cuda and (feats.dtype == torch.float16 or torch.is_autocast_enabled("cuda"))
+
+
+def _half_ok(*channels) -> bool:
+    return all(c % 32 == 0 for c in channels)
+
+
 class _SparseConv(Function):
     """conv.py:16-119 on the neighbour tables.  `transposed` swaps the roles of the two
-    index columns exactly like convolution_cuda.cu:21,34."""
+    index columns exactly like convolution_cuda.cu:21,34.
+
+    fp32: pair GEMM + gather-sum + weight gradient on the f32 MFMA kernels.  Half storage (autocast or half
+    features; channel counts % 32 == 0): features, Z and the feature gradients are half, the fp32 master weight is
+    cast once per call (ts_cast_weights_f16 writes the forward and the dgrad layout), every accumulation is fp32 and
+    the weight gradient comes back in fp32."""
 
     @staticmethod
-    @_fwd
     def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool):
-        feats = feats.contiguous()
-        weight = weight.contiguous()
         if feats.shape[1] != weight.shape[1]:
             raise ValueError("Input feature size and kernel size mismatch")
         n_in, n_out = kmap.sizes
-        # pass 1: z[p] = feats[source row of pair p] @ W[k(p)];  pass 2: out[row] = sum_k z[pos[k, row]]
-        if not transposed:
-            if feats.shape[0] != n_in:
-                raise ValueError(f"conv3d: {feats.shape[0]} input rows but the kernel map has {n_in}")
-            z = B.conv_pair_gemm(feats, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=0)
-            out = B.conv_gather_sum(z, kmap.pos_out, n_out)
-        else:
-            if feats.shape[0] != n_out:
-                raise ValueError(f"conv3d (transposed): {feats.shape[0]} input rows but the kernel map has {n_out}")
-            z = B.conv_pair_gemm(feats, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=1)
-            out = B.conv_gather_sum(z, kmap.pos_in, n_in)
-        ctx.kmap, ctx.transposed = kmap, transposed
-        ctx.save_for_backward(feats, weight)
+        rows_expected = n_out if transposed else n_in
+        if feats.shape[0] != rows_expected:
+            raise ValueError(f"conv3d{' (transposed)' if transposed else ''}: {feats.shape[0]} input rows but the "
+                             f"kernel map has {rows_expected}")
+        want_half = _amp_half(feats)
+        half = want_half and _half_ok(weight.shape[1], weight.shape[2])
+        gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
+        with torch.autocast("cuda", enabled=False):
+            if half:
+                fh = feats.contiguous().half()
+                w16, w16t = B.cast_weights_f16(weight.detach().float())
+                z = B.conv_pair_gemm_f16(fh, w16t, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
+                out = B.conv_gather_sum_f16(z, table, rows)
+                ctx.save_for_backward(fh, w16)
+            else:
+                # pass 1: z[p] = feats[source row of pair p] @ W[k(p)];  pass 2: out[row] = sum_k z[pos[k, row]]
+                f32, w32 = feats.contiguous().float(), weight.contiguous().float()
+                z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
+                out = B.conv_gather_sum(z, table, rows)
+                ctx.save_for_backward(f32, w32)
+                if want_half:
+                    out = out.half()          # stem (C_in = 4 / 5): fp32 kernels, half result like the reference
+        ctx.kmap, ctx.transposed, ctx.half, ctx.in_dtype = kmap, transposed, half, feats.dtype
         return out
 
     @staticmethod
-    @_bwd
     def backward(ctx, grad_out):
         feats, weight = ctx.saved_tensors
         kmap, transposed = ctx.kmap, ctx.transposed
-        grad_out = grad_out.contiguous()
         n_in, n_out = kmap.sizes
         k = weight.shape[0]
         grad_feats = grad_weight = None
-        if ctx.needs_input_grad[0]:
-            # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T : the same two passes with the roles of the
-            # rulebook columns swapped and W transposed
-            z = B.conv_pair_gemm(grad_out, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total,
-                                 gather_col=0 if transposed else 1, weight_transposed=True)
-            table, rows = (kmap.pos_in, n_in) if not transposed else (kmap.pos_out, n_out)
-            grad_feats = B.conv_gather_sum(z, table, rows)
-        if ctx.needs_input_grad[1]:
-            grad_weight = B.conv_wgrad(feats, grad_out, kmap.nbmaps_buf, kmap.nboffs, k,
-                                       col_a=1 if transposed else 0, max_pairs=kmap.total)
+        gcol = 0 if transposed else 1
+        table, rows = (kmap.pos_in, n_in) if not transposed else (kmap.pos_out, n_out)
+        with torch.autocast("cuda", enabled=False):
+            if ctx.half:
+                gh = grad_out.contiguous().half()
+                if ctx.needs_input_grad[0]:
+                    # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T: rows of W_k (= w16) are the output columns
+                    z = B.conv_pair_gemm_f16(gh, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
+                    grad_feats = B.conv_gather_sum_f16(z, table, rows).to(ctx.in_dtype)
+                if ctx.needs_input_grad[1]:
+                    grad_weight = B.conv_wgrad_f16(feats, gh, kmap.nbmaps_buf, kmap.nboffs, k,
+                                                   col_a=1 if transposed else 0, max_pairs=kmap.total)
+            else:
+                g32 = grad_out.contiguous().float()
+                if ctx.needs_input_grad[0]:
+                    z = B.conv_pair_gemm(g32, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol,
+                                         weight_transposed=True)
+                    grad_feats = B.conv_gather_sum(z, table, rows).to(ctx.in_dtype)
+                if ctx.needs_input_grad[1]:
+                    grad_weight = B.conv_wgrad(feats, g32, kmap.nbmaps_buf, kmap.nboffs, k,
+                                               col_a=1 if transposed else 0, max_pairs=kmap.total)
         return grad_feats, grad_weight, None, None
 
 
@@ -287,26 +322,35 @@ class _PointwiseConv(Function):
     """1x1x1 convolution (conv.py:135-140: `feats.matmul(weight)`).  Forward and the input gradient are plain
     dense GEMMs (rocBLAS/hipBLASLt through torch); the weight gradient x^T @ gy is a tall-skinny reduction
     (N ~ 1e5 rows, C <= 384) for which the library picks a tile-per-output kernel with no split over N
-    (380 us per call here), so it runs on our split-over-rows `ts_conv_wgrad` with an identity rulebook."""
+    (380 us per call here), so it runs on our split-over-rows `ts_conv_wgrad` with an identity rulebook.
+    Half storage (autocast / half features): half GEMMs, fp32 weight gradient from `ts_conv_wgrad_f16`."""
 
     @staticmethod
-    @_fwd
     def forward(ctx, feats, weight, ident):
-        ctx.save_for_backward(feats, weight)
-        ctx.ident = ident
-        return feats.matmul(weight)
+        half = _amp_half(feats)
+        with torch.autocast("cuda", enabled=False):
+            f = feats.contiguous().half() if half else feats.contiguous().float()
+            w = weight.detach().half() if half else weight.detach().float()
+            out = f.matmul(w)
+        ctx.save_for_backward(f, w)
+        ctx.ident, ctx.half, ctx.in_dtype = ident, half, feats.dtype
+        return out
 
     @staticmethod
-    @_bwd
     def backward(ctx, grad_out):
         feats, weight = ctx.saved_tensors
         pairs, offs = ctx.ident
-        grad_out = grad_out.contiguous()
-        grad_feats = grad_out.matmul(weight.t()) if ctx.needs_input_grad[0] else None
-        grad_weight = None
-        if ctx.needs_input_grad[1]:
-            grad_weight = B.conv_wgrad(feats.contiguous(), grad_out, pairs, offs, 1, col_a=0,
-                                       max_pairs=feats.shape[0]).view_as(weight)
+        with torch.autocast("cuda", enabled=False):
+            grad_out = grad_out.contiguous().to(feats.dtype)
+            grad_feats = grad_out.matmul(weight.t()).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
+            grad_weight = None
+            if ctx.needs_input_grad[1]:
+                if ctx.half and _half_ok(feats.shape[1], grad_out.shape[1]):
+                    grad_weight = B.conv_wgrad_f16(feats, grad_out, pairs, offs, 1, col_a=0, max_pairs=feats.shape[0])
+                else:
+                    grad_weight = B.conv_wgrad(feats.float(), grad_out.float(), pairs, offs, 1, col_a=0,
+                                               max_pairs=feats.shape[0])
+                grad_weight = grad_weight.view(weight.shape)
         return grad_feats, grad_weight, None
 
 
@@ -379,7 +423,7 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optiona
 
     if kernel_size == ones and stride == ones and dilation == ones:
         out_stride, out_coords = input.stride, input.coords
-        if input.feats.is_cuda and input.feats.dtype == torch.float32 and weight.requires_grad:
+        if input.feats.is_cuda and input.feats.dtype in (torch.float32, torch.float16) and weight.requires_grad:
             out_feats = _PointwiseConv.apply(input.feats, weight, _identity_rulebook(input))
         else:
             out_feats = input.feats.matmul(weight)   # plain dense GEMM -> rocBLAS/hipBLASLt

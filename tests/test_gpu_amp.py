@@ -1,0 +1,88 @@
+"""Half-storage (AMP) path on the GPU - BASELINE configs[4] "fp16 MFMA path", SURVEY.md section 8(d) parity gates for
+fp16: report max / mean logit deviation and argmax agreement against the fp32 path (no bit-exact claim)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, synth_scan  # noqa: E402
+
+
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
+@pytest.mark.parametrize("n,c", [(20011, 96), (4097, 32), (900, 256)])
+def test_bn_act_half_matches_fp32_kernels(n, c, with_res, relu):
+    from taseg_amd.torchsparse.nn.batchnorm import batch_norm_act_train
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 2 + 0.5).cuda().half()
+    res = torch.randn(n, c, generator=g).cuda().half() if with_res else None
+    w = (torch.rand(c, generator=g) + 0.5).cuda()
+    b = torch.randn(c, generator=g).cuda()
+    gy = torch.randn(n, c, generator=g).cuda().half()
+    outs = []
+    for dtype in (torch.float16, torch.float32):
+        xi = x.to(dtype).requires_grad_()
+        ri = None if res is None else res.to(dtype).requires_grad_()
+        wi, bi = w.clone().requires_grad_(), b.clone().requires_grad_()
+        rm, rv, nbt = torch.zeros(c).cuda(), torch.ones(c).cuda(), torch.zeros((), dtype=torch.long).cuda()
+        y = batch_norm_act_train(xi, wi, bi, rm, rv, 0.1, 1e-5, relu=relu, residual=ri, num_batches_tracked=nbt)
+        assert y.dtype == dtype
+        grads = torch.autograd.grad(y, [xi, wi, bi] + ([ri] if ri is not None else []), gy.to(dtype))
+        outs.append([y.float(), rm, rv, nbt.float()] + [t.float() for t in grads])
+    names = ["y", "running_mean", "running_var", "nbt", "gx", "gw", "gb", "gres"]
+    for name, a, bb in zip(names, outs[0], outs[1]):
+        scale = max(1.0, float(bb.abs().max()))
+        assert float((a - bb).abs().max()) <= 4e-3 * scale, name     # half rounding of y / gx (2^-11 relative)
+
+
+def _scan_batch(seed=5, n_points=30000):
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    pts, lab = synth_scan(seed, n_points=n_points, n_beams=32, n_az=1400)
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+    coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+
+    def make():
+        return {"lidar": SparseTensor(torch.from_numpy(pts[idx]).cuda(), coords),
+                "targets": SparseTensor(torch.from_numpy(lab[idx].astype(np.int64)).cuda(), coords),
+                "offset": torch.tensor([0])}
+    return make, len(idx)
+
+
+def test_minkunet_autocast_vs_fp32():
+    """One training step of MinkUNet (mk34 widths) under torch.autocast against the fp32 step: half features and Z,
+    fp32 accumulation - logits within a few 1e-2, near-total argmax agreement, gradients aligned."""
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=1.0, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+    make, n = _scan_batch()
+    res = {}
+    for mode in ("fp32", "amp"):
+        grabbed = {}
+        h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach().float()))
+        h2 = model.stage2[1].register_forward_hook(lambda m, i, o: grabbed.__setitem__("feat_dtype", o.F.dtype))
+        model.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=(mode == "amp")):
+            ret, _, _ = model(make())
+        ret["loss"].float().backward()
+        h.remove()
+        h2.remove()
+        res[mode] = (grabbed["logits"], float(ret["loss"]), grabbed["feat_dtype"],
+                     {k: p.grad.detach().float().clone() for k, p in model.named_parameters()})
+        for m in model.modules():                       # same running statistics for the second pass
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+    (l32, loss32, d32, g32), (l16, loss16, d16, g16) = res["fp32"], res["amp"]
+    assert d32 == torch.float32 and d16 == torch.float16          # features really are half inside the network
+    dev = (l16 - l32).abs()
+    agree = float((l16.argmax(1) == l32.argmax(1)).float().mean())
+    print(f"AMP vs fp32 on {n} voxels: max |dlogit| {float(dev.max()):.4f}, mean {float(dev.mean()):.5f}, "
+          f"argmax agreement {100 * agree:.2f} %, loss {loss16:.5f} vs {loss32:.5f}")
+    assert float(dev.max()) < 0.25 and float(dev.mean()) < 0.02 and agree > 0.99
+    assert abs(loss16 - loss32) < 2e-2
+    for k in ("stem.0.kernel", "stage2.1.net.0.kernel", "stage4.1.net.3.kernel", "up2.1.0.net.0.kernel", "classifier.0.weight"):
+        cos = float(torch.nn.functional.cosine_similarity(g16[k].flatten(), g32[k].flatten(), dim=0))
+        assert cos > 0.99, (k, cos)
+        assert g16[k].dtype == torch.float32
