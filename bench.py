@@ -22,6 +22,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
+MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (same guide; no sparsity)
 VOXEL = 0.05
 EVENT_EVERY = 4             # per-launch HIP events bracket the conv kernels of every 4th timed step
 
@@ -42,8 +43,13 @@ def parse():
                     help="build batch i's rulebooks at the head of step i on the launch stream instead of "
                          "during step i-1 on the staging stream")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
+    ap.add_argument("--amp", action="store_true",
+                    help="torch.autocast(float16) + loss scaling, the reference's default training mode (dist_train.sh "
+                         "--amp): half-storage conv / BN kernels with fp32 accumulation; reported as dtype f16")
     ap.add_argument("--local-bn", action="store_true",
                     help="plain BatchNorm (per-rank statistics) instead of the reference configs' SyncBatchNorm")
+    ap.add_argument("--torch-optim", action="store_true",
+                    help="torch.optim.SGD + clip_grad_norm_ (+ GradScaler under --amp) instead of taseg_amd.optim.FlatSGD")
     ap.add_argument("--torch-ddp", action="store_true",
                     help="average gradients with torch's DistributedDataParallel instead of parallel.GradBucketReducer")
     ap.add_argument("--force-dist", action="store_true",
@@ -159,13 +165,14 @@ def summarise_profile(records, steps):
         else:
             p = m["pairs"]
         flops = 2.0 * p * m["c_red"] * m["c_out"]
+        es = m.get("esize", 4)       # bytes per stored feature element (2 on the half-storage path)
         if kind == "pair_gemm":      # gather read + Z write + rulebook + weights  (first half of the 8(d) figure)
-            byts = p * (m["c_red"] * 4 + m["c_out"] * 4 + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+            byts = p * (m["c_red"] * es + m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * es
         elif kind == "gather_sum":   # Z read + output write + position table       (second half)
             flops = float(p * m["c_out"])
-            byts = p * m["c_out"] * 4 + m["n_rows"] * m["c_out"] * 4 + m["k"] * m["n_rows"] * 4
+            byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4
         else:
-            byts = p * (m["c_red"] * 4 + 2 * m["c_out"] * 4 + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+            byts = p * (m["c_red"] * es + 2 * m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
         g = groups.setdefault(m["name"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         g["launches"] += 1
         g["ms"] += ms
@@ -219,16 +226,23 @@ def main():
     model = build_network(cfg, num_class).cuda().train()
     net = model
     reducer = None
-    if use_dist and not args.torch_ddp:
-        from taseg_amd.parallel import GradBucketReducer
-        # own communicator: the 32 MB bucket transfers must not queue in front of the small SyncBatchNorm
-        # all-reduces of the layers still running backward (one RCCL stream per communicator)
-        reducer = GradBucketReducer(model, process_group=dist.new_group(backend="nccl"))
-    elif use_dist:
-        # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
-                                                        broadcast_buffers=False, static_graph=True)
-    opt = torch.optim.SGD(model.parameters(), lr=0.02 * args.batch * world, momentum=0.9, weight_decay=1e-4)
+    lr, mom, wd = 0.02 * args.batch * world, 0.9, 1e-4
+    flat = not args.torch_optim
+    if flat:
+        # flat-bucket SGD (taseg_amd.optim): gradients land in flat buckets during backward (all-reduced over ranks on
+        # their own communicator when N > 1), unscale + clip + SGD + loss-scale update in 3 launch kinds, no host read
+        from taseg_amd.optim import FlatSGD
+        group = dist.new_group(backend="nccl") if use_dist else None
+        opt = FlatSGD(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=10.0, amp=args.amp, process_group=group)
+    else:
+        if use_dist and not args.torch_ddp:
+            from taseg_amd.parallel import GradBucketReducer
+            reducer = GradBucketReducer(model, process_group=dist.new_group(backend="nccl"))
+        elif use_dist:
+            # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
+                                                            broadcast_buffers=False, static_graph=True)
+        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=mom, weight_decay=wd)
 
     nvox = [0]
     if ms:
@@ -256,20 +270,30 @@ def main():
     from taseg_amd.data.stage import DevicePrefetcher
     pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare)
 
+    scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
+
     def step():
         # one step = stage one batch (rulebooks / index plan; for minkunet_ms also the temporal aggregation and
         # voxelisation) + forward + loss + backward + clip + SGD.  With the prefetcher the batch staged inside
         # step i is the one step i+1 trains on (every timed step still stages exactly one batch).
         opt.zero_grad(set_to_none=True)
-        if pf is None:
-            ret, _, _ = net(make_batch())
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            if pf is None:
+                ret, _, _ = net(make_batch())
+            else:
+                ret, _, _ = net(pf.next())
+        loss = ret["loss"].float().mean()
+        if flat:
+            (loss * opt.loss_scale()).backward()
+            opt.step()                   # reducer.finish() + grad stats + decide + apply, all on the device
         else:
-            ret, _, _ = net(pf.next())
-        ret["loss"].mean().backward()
-        if reducer is not None:
-            reducer.finish()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
-        opt.step()
+            scaler.scale(loss).backward()
+            if reducer is not None:
+                reducer.finish()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+            scaler.step(opt)
+            scaler.update()
         if pf is not None:
             pf.prefetch()
         return ret["loss"]
@@ -309,11 +333,12 @@ def main():
         dom = prof[0] if prof else None
         roofline = None
         if dom:
-            t_mfma = dom["flops_per_launch"] / (MFMA_F32_PEAK_TF * 1e12)
+            mfma_peak = MFMA_F16_PEAK_TF if args.amp else MFMA_F32_PEAK_TF
+            t_mfma = dom["flops_per_launch"] / (mfma_peak * 1e12)
             t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
             if t_mfma >= t_hbm:
-                roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                            "frac": dom["tflops"] / MFMA_F32_PEAK_TF}
+                roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": mfma_peak, "unit": "TFLOP/s",
+                            "frac": dom["tflops"] / mfma_peak}
             else:
                 roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": dom["gbs"] / HBM_PEAK_GBS}
@@ -332,10 +357,11 @@ def main():
             "metric": "scans/sec (train fwd+bwd) at ~120k pts/scan" if not nusc else
             "scans/sec (train fwd+bwd), nuScenes-shaped sweeps", "value": value, "unit": "scans/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 storage / f32 accumulate (torch.autocast)" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": f"{name} mk34 cr1.0 ("
                                    f"{'nuScenes-shaped 15-sweep FSA' if nusc else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
-                                   f"bs={args.batch}/GPU, voxel {voxel:g} m, fp32, rulebook+fwd+loss+bwd+SGD step",
+                                   f"bs={args.batch}/GPU, voxel {voxel:g} m, {'AMP fp16' if args.amp else 'fp32'}, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}"},
             "loss": float(loss.detach()),

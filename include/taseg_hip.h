@@ -345,6 +345,19 @@ int ts_bn_act_train_backward_f16(const void *grad_out, const uint8_t *mask, cons
                                  void *grad_residual, float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes,
                                  ts_stream_t stream);
 
+/* Flat-buffer optimizer step of the training loop (R/train.py:399-417: GradScaler.unscale_ -> clip_grad_norm_ ->
+ * SGD step -> GradScaler.update), decided on the device - no host read.  `state` = float[8] on the device:
+ * [0] loss scale, [1] growth tracker, [2] gradient multiplier (clip coefficient / scale), [3] skip flag, [4] total norm.
+ *   ts_sgd_grad_stats  *sumsq += sum g^2 (double), *nonfinite |= any non-finite        (call once per bucket)
+ *   ts_sgd_decide      norm of the unscaled gradients, clip coefficient min(1, max_norm / (norm + 1e-6)), skip flag,
+ *                      loss-scale update (amp != 0); clears sumsq / nonfinite for the next step
+ *   ts_sgd_apply       d = g * state[2] + wd * p; m = first_step ? d : momentum * m + d; p -= lr * m   (skipped if flagged) */
+int ts_sgd_grad_stats(const float *grad, int64_t n, double *sumsq, int32_t *nonfinite, ts_stream_t stream);
+int ts_sgd_decide(double *sumsq, int32_t *nonfinite, float *state, float max_norm, float growth, float backoff,
+                  int32_t growth_interval, int32_t amp, ts_stream_t stream);
+int ts_sgd_apply(float *param, const float *grad, float *momentum_buf, int64_t n, const float *state, float lr,
+                 float momentum, float weight_decay, int32_t first_step, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,

@@ -86,3 +86,45 @@ def test_minkunet_autocast_vs_fp32():
         cos = float(torch.nn.functional.cosine_similarity(g16[k].flatten(), g32[k].flatten(), dim=0))
         assert cos > 0.99, (k, cos)
         assert g16[k].dtype == torch.float32
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_flat_sgd_matches_torch_sgd_clip_and_gradscaler(amp):
+    """FlatSGD == GradScaler.unscale_ + clip_grad_norm_(max_norm) + SGD(momentum, weight_decay).step + GradScaler.update,
+    including a step with non-finite gradients (skipped, loss scale halved) and a growth of the scale."""
+    from taseg_amd.optim import FlatSGD
+
+    def net():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 7)).cuda()
+
+    a, b = net(), net()
+    ref_opt = torch.optim.SGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    scaler = torch.amp.GradScaler("cuda", enabled=amp, init_scale=1024.0, growth_interval=3)
+    ours = FlatSGD(b, lr=0.05, momentum=0.9, weight_decay=1e-3, max_norm=0.5, amp=amp, init_scale=1024.0,
+                   growth_interval=3, bucket_mb=0.002)
+    g = torch.Generator().manual_seed(0)
+    for it in range(8):
+        x = torch.randn(16, 24, generator=g).cuda()
+        y = torch.randint(0, 7, (16,), generator=g).cuda()
+        # one overflowing step (AMP only: without a GradScaler torch lets NaNs into the weights, FlatSGD skips the step)
+        poison = float("inf") if (amp and it == 4) else 1.0
+        ref_opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(a(x), y) * poison
+        scaler.scale(loss).backward()
+        scaler.unscale_(ref_opt)
+        torch.nn.utils.clip_grad_norm_(a.parameters(), 0.5)
+        scaler.step(ref_opt)
+        scaler.update()
+        ours.zero_grad()
+        loss_b = torch.nn.functional.cross_entropy(b(x), y) * poison
+        (loss_b * ours.loss_scale()).backward()
+        ours.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), it
+        if amp:
+            assert float(ours.state[0]) == float(scaler.get_scale()), it
+    if amp:
+        assert float(ours.state[0]) != 1024.0               # the schedule moved (backoff at it 4, growth later)
+    sd = b.state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in zip(sd, b.parameters()))      # parameters still serialise normally
