@@ -185,13 +185,20 @@ class DevicePrefetcher:
     read it.
     """
 
-    def __init__(self, make_batch, prepare=None, device=None):
+    def __init__(self, make_batch, prepare=None, device=None, threaded=False):
         self.make_batch, self.prepare = make_batch, prepare
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
-        self._staged = None          # (batch, ready_event)
+        self._staged = None          # (batch, ready_event) or a Future of it
         self._inflight = []          # [(batch, done_event)] handed out, possibly still read by the launch stream
         self._current = None
+        # threaded=True runs the stage on a worker thread (its host reads release the GIL while they wait).  Measured
+        # here it LOSES 6 % in the launch-bound AMP step - the stage's ~150 Python-level calls contend for the GIL with
+        # the training thread - so the default stays in-line.
+        self._pool = None
+        if threaded:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="taseg-stage")
 
     def _retire(self):
         if self._current is not None:
@@ -208,23 +215,36 @@ class DevicePrefetcher:
         if not self._inflight:
             # first use (or idle device): inputs created on the launch stream must be complete
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.stream):
+        if self._pool is not None:
+            self._staged = self._pool.submit(self._stage)
+        else:
+            self._staged = self._stage()
+
+    def _stage(self):
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(self.stream), torch.no_grad():
             batch = self.make_batch()
             if self.prepare is not None:
                 self.prepare(batch)
             ready = torch.cuda.Event()
             ready.record(self.stream)
-        self._staged = (batch, ready)
+        return batch, ready
 
     def next(self):
         self.prefetch()
-        batch, ready = self._staged
+        staged = self._staged
+        batch, ready = staged.result() if hasattr(staged, "result") else staged
         self._staged = None
         torch.cuda.current_stream(self.device).wait_event(ready)
         self._current = batch
         return batch
 
     def close(self):
+        if hasattr(self._staged, "result"):
+            self._staged.result()
         self._retire()
         torch.cuda.synchronize(self.device)
         self._inflight, self._staged = [], None
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
