@@ -52,15 +52,13 @@ class FlatSGD:
         L.require_device(self.reducer.buckets[0]["flat"])
         # parameters move into flat buckets too (p.data becomes a view): the update is one launch per bucket
         for b in self.reducer.buckets:
-            flat = torch.empty_like(b["flat"])
-            off = 0
-            for p in b["params"]:
+            flat = torch.zeros_like(b["flat"])
+            for p, off in zip(b["params"], b["offsets"]):      # same (64-byte aligned) layout as the gradient bucket
                 if p.dtype != torch.float32:
                     raise TypeError("FlatSGD keeps fp32 master parameters")
                 view = flat[off:off + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                off += p.numel()
             b["pflat"], b["mflat"] = flat, torch.zeros_like(flat)
         self.state = torch.zeros(8, dtype=torch.float32, device=dev)
         self.state[0] = init_scale if amp else 1.0

@@ -102,16 +102,19 @@ class GradBucketReducer:
             for p in b["params"]:
                 p.register_post_accumulate_grad_hook(self._make_hook(b))
 
+    ALIGN = 16      # elements: every tensor starts on a 64-byte boundary of the flat buffer (kernels that take
+                    # parameters, e.g. the BatchNorm ones, require 16-byte aligned pointers; padding stays zero)
+
     def _add_bucket(self, params):
         first = params[0]
-        total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=first.dtype, device=first.device)
-        views, off = [], 0
+        offsets, off = [], 0
         for p in params:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        self.buckets.append({"params": list(params), "flat": flat, "views": views, "pending": len(params),
-                             "launched": False})
+            offsets.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        flat = torch.zeros(off, dtype=first.dtype, device=first.device)
+        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, params)]
+        self.buckets.append({"params": list(params), "flat": flat, "views": views, "offsets": offsets,
+                             "pending": len(params), "launched": False})
 
     def _make_hook(self, bucket):
         def hook(_param):

@@ -128,3 +128,6 @@ def test_flat_sgd_matches_torch_sgd_clip_and_gradscaler(amp):
         assert float(ours.state[0]) != 1024.0               # the schedule moved (backoff at it 4, growth later)
     sd = b.state_dict()
     assert all(torch.equal(sd[k], v) for k, v in zip(sd, b.parameters()))      # parameters still serialise normally
+    # every tensor starts on a 64-byte boundary of its flat bucket (the 7-element bias must not misalign its successors:
+    # the BatchNorm kernels take parameter pointers and require 16-byte alignment)
+    assert all(p.data_ptr() % 64 == 0 and p.grad.data_ptr() % 64 == 0 for p in b.parameters())

@@ -9,7 +9,9 @@ from taseg_amd.torchsparse import SparseTensor
 
 cfg = make_model_cfg("MinkUNet", in_dim=4, cr=1.0)
 model = build_network(cfg, 20).cuda().train()
-opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+from taseg_amd.optim import FlatSGD
+AMP = "--amp" in sys.argv
+opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=10.0, amp=AMP)
 coords, feats, labels, _ = bench.make_scans(0, 2, 120000, "minkunet")
 offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
 
@@ -19,9 +21,9 @@ pf = DevicePrefetcher(lambda: {"lidar": SparseTensor(feats, coords), "targets": 
 
 def step():
     opt.zero_grad(set_to_none=True)
-    ret, _, _ = model(pf.next())
-    ret["loss"].mean().backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=AMP):
+        ret, _, _ = model(pf.next())
+    (ret["loss"].float().mean() * opt.loss_scale()).backward()
     opt.step()
     pf.prefetch()
 
