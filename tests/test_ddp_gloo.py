@@ -87,7 +87,8 @@ def _reducer_worker(rank, world, port, out):
                 p.add_(1.0)                         # rank 1 starts elsewhere: the reducer must broadcast rank 0's weights
     extra = torch.nn.Parameter(torch.ones(3))       # a parameter that never gets a gradient
     net.register_parameter("unused", extra)
-    red = P.GradBucketReducer(net, bucket_mb=0.0002)          # tiny buckets: several collectives per step
+    # tiny buckets: several collectives per step; a dedicated group, as bench.py / FlatSGD pass it
+    red = P.GradBucketReducer(net, process_group=dist.new_group(backend="gloo"), bucket_mb=0.0002)
     w0 = [p.detach().clone() for p in net.parameters()]
     rows = []
     for step in range(2):                           # two steps: hooks must re-arm
