@@ -1,6 +1,6 @@
 // Diagnostic (not part of the product): what does v_mfma_f32_16x16x4_f32 sustain on this chip
 //  (a) from registers only, (b) with the pair-GEMM's LDS fragment reads in the loop?
-// hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+// hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/mfma_peak.hip -o tools/mfma_peak && tools/mfma_peak   (binary is git-ignored)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
