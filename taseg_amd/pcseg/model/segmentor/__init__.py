@@ -3,17 +3,18 @@ hot-path models exist here; the other OpenPCSeg backbones are out of scope (SURV
 from .base_segmentors import BaseSegmentor
 from .voxel.minkunet.minkunet import MinkUNet
 from .voxel.minkunet.minkunet_ms import MinkUNetMs
+from .voxel.minkunet.minkunet_ms_kd import MinkUNetMsKd
 from .voxel.minkunet.minkunet_ms_mm import MinkUNetMsMm, MinkUNetMsMmNus
 
 __all__ = {
     "MinkUNet": MinkUNet,
     "MinkUNetMs": MinkUNetMs,
+    "MinkUNetMsKd": MinkUNetMsKd,
     "MinkUNetMsMm": MinkUNetMsMm,
     "MinkUNetMsMmNus": MinkUNetMsMmNus,
 }
 
-_OUT_OF_SCOPE = ("RangeNet++", "SalsaNext", "FIDNet", "CENet", "Cylinder_TS", "SPVCNN", "RPVNet",
-                 "MinkUNetMsKd")
+_OUT_OF_SCOPE = ("RangeNet++", "SalsaNext", "FIDNet", "CENet", "Cylinder_TS", "SPVCNN", "RPVNet")
 
 
 def build_segmentor(model_cfgs, num_class):

@@ -50,5 +50,10 @@ def g_minkunet_ms_mm():
 
 
 @pytest.fixture(scope="session")
+def g_minkunet_ms_kd():
+    return _load("model_minkunet_ms_kd.npz")
+
+
+@pytest.fixture(scope="session")
 def g_multiscan():
     return _load("multiscan.npz")

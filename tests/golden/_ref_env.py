@@ -147,6 +147,12 @@ def setup_pcseg_mm():
     return MinkUNetMsMm
 
 
+def setup_pcseg_kd():
+    """The reference's mask-distillation segmentor (minkunet_ms_kd.py; call after setup_pcseg)."""
+    from pcseg.model.segmentor.voxel.minkunet.minkunet_ms_kd import MinkUNetMsKd
+    return MinkUNetMsKd
+
+
 def setup_datasets():
     from pcseg.data.dataset.semantickitti.semantickitti_ms import SemantickittiMsDataset
     from pcseg.data.dataset.semantickitti.semantickitti_voxel_ms import SemkittiVoxelMsDataset

@@ -322,6 +322,91 @@ def gen_model_mm(fname="model_minkunet_ms_mm.npz"):
           "loss(train/eval) =", out["train_loss"], out["eval_loss"], out["train_loss_parts"])
 
 
+# ----------------------------------------------------------------------------------------- KD (MinkUNetMsKd)
+KD_CFG = dict(SAMPLING_TYPE="random", MAX_VOXEL=100000, FEAT_KD="mse", FEAT_KD_WEIGHT=10.0)
+"""MODEL section of minkunet_mk34_cr10_fsa_kd.yaml:32-35; MAX_VOXEL raised so the random sub-sampling (:624-626) never
+triggers and the fixture is deterministic."""
+
+
+def make_kd_batch(seeds):
+    """Teacher cloud = the voxelised scan; student cloud = 85 % of its voxels plus a few voxels the teacher lacks
+    (the two aggregations of the reference differ in which history points they keep)."""
+    samples = []
+    for s in seeds:
+        pts, lab = small_scan(s)
+        pc_, inds, _ = dataset_voxelize(pts, lab)
+        feat = np.concatenate([pts, np.ones_like(pts[:, :1])], 1)[inds]
+        coords, labels = pc_[inds], lab[inds]
+        rs = np.random.RandomState(s)
+        keep = np.sort(rs.choice(len(coords), int(0.85 * len(coords)), replace=False))
+        extra = coords[rs.choice(len(coords), 40, replace=False)] + np.array([[0, 0, 300]], dtype=coords.dtype)  # above every real voxel: no duplicates
+        s_coords = np.concatenate([coords[keep], extra])
+        s_feat = np.concatenate([feat[keep], feat[:40]])
+        s_lab = np.concatenate([labels[keep], labels[:40]])
+        order = np.lexsort((s_coords[:, 2], s_coords[:, 1], s_coords[:, 0]))
+        samples.append({"lidar_ms": SparseTensor(s_feat[order], s_coords[order]),
+                        "targets_ms": SparseTensor(s_lab[order], s_coords[order]),
+                        "lidar_ms_gt": SparseTensor(feat, coords)})
+    batch = sparse_collate_fn(samples)
+    batch["offset_ms"] = torch.tensor([0])
+    return batch
+
+
+def run_model_kd(cls, training):
+    cfg = make_model_cfg("MinkUNetMsKd", in_dim=5, cr=0.5, num_layer=[1] * 8, **KD_CFG)
+    torch.manual_seed(0)
+    model = cls(cfg, 20)
+    fill_parameters(model, seed=3)
+    bd = make_kd_batch([41, 42])
+    for k in ("lidar_ms", "lidar_ms_gt"):
+        bd[k].F = bd[k].F.float()
+        bd[k].C = bd[k].C.int()
+    inputs = {"coords": bd["lidar_ms"].C.numpy().copy(), "feats": bd["lidar_ms"].F.numpy().copy(),
+              "labels": bd["targets_ms"].F.numpy().astype(np.int64),
+              "gt_coords": bd["lidar_ms_gt"].C.numpy().copy(), "gt_feats": bd["lidar_ms_gt"].F.numpy().copy()}
+    captured = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, key=key: captured.__setitem__(key, o.detach().numpy().copy()))
+             for key, m in (("logits", model.classifier), ("teacher_logits", model.classifier_gt))]
+    model.train()
+    if not training:
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+    ret, _, disp = model(bd)
+    for h in hooks:
+        h.remove()
+    loss = ret["loss"]
+    model.zero_grad()
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    tag = "train" if training else "eval"
+    res = {f"{tag}_{k}": v for k, v in captured.items()}
+    res[f"{tag}_loss"] = np.array(loss.item())
+    res[f"{tag}_loss_parts"] = np.array([float(disp["loss_seg"]), float(disp["loss_feat_kd"])])
+    for k in ["stem.0.kernel", "stage2.1.net.0.kernel", "up4.1.0.net.3.kernel", "classifier.0.weight"]:
+        res[f"{tag}_grad/{k}"] = grads[k].numpy()
+    res[f"{tag}_teacher_has_grad"] = np.array([grads[n] is not None for n in grads if "_gt" in n])
+    names = [n for n in grads if grads[n] is not None]
+    res[f"{tag}_gradnames"] = np.array(names)
+    res[f"{tag}_gradnorms"] = np.array([float(grads[n].norm()) for n in names])
+    return cfg, model, inputs, res
+
+
+def gen_model_kd(fname="model_minkunet_ms_kd.npz"):
+    cls = _ref_env.setup_pcseg_kd()
+    out = {"backend": np.array(BACKEND_DESC)}
+    for training in (True, False):
+        cfg, model, inputs, res = run_model_kd(cls, training)
+        out.update(res)
+    out.update(inputs)
+    sd = model.state_dict()
+    out["state_keys"] = np.array(list(sd.keys()))
+    out["state_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "N =", inputs["coords"].shape[0], "N_gt =", inputs["gt_coords"].shape[0],
+          "loss(train/eval) =", out["train_loss"], out["eval_loss"], out["train_loss_parts"])
+
+
 # ----------------------------------------------------------------------------------------- multi-scan data stage
 def gen_multiscan():
     SemMs, SemVoxMs, _ = _ref_env.setup_datasets()
@@ -388,11 +473,15 @@ if __name__ == "__main__":
     if "--only-mm" in sys.argv:
         gen_model_mm()
         sys.exit(0)
+    if "--only-kd" in sys.argv:
+        gen_model_kd()
+        sys.exit(0)
     gen_ops()
     gen_model(MinkUNet, "MinkUNet", 4, "lidar", "model_minkunet.npz")
     gen_model(MinkUNetMs, "MinkUNetMs", 5, "lidar_ms", "model_minkunet_ms.npz")
     gen_multiscan()
     gen_model_mm()
+    gen_model_kd()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

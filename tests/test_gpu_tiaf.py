@@ -161,3 +161,71 @@ def test_tiaf_nuscenes_twin_uses_point_labels(g_minkunet_ms_mm):
     _, tb_z, _ = nus(bd3)
     assert abs(float(tb_z["loss_image_s"]) - float(tb_k["loss_image_s"])) > 1e-3
     assert abs(float(tb_z["loss_image_d"]) - float(tb_k["loss_image_d"])) <= 1e-5      # dense image loss unaffected
+
+
+# --------------------------------------------------------------------------- mask distillation (MinkUNetMsKd)
+def _build_kd():
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg("MinkUNetMsKd", in_dim=5, cr=0.5, num_layer=[1] * 8, SAMPLING_TYPE="random", MAX_VOXEL=100000,
+                         FEAT_KD="mse", FEAT_KD_WEIGHT=10.0)
+    return cfg, fill_parameters(build_network(cfg, 20), seed=3).cuda()
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_kd_model_vs_reference_golden(g_minkunet_ms_kd, training):
+    """student + frozen teacher + hash-matched feature MSE against the reference's logits (both networks), the two loss
+    terms and the student's gradients (tests/golden/model_minkunet_ms_kd.npz)"""
+    from taseg_amd.torchsparse import SparseTensor
+    g = g_minkunet_ms_kd
+    tag = "train" if training else "eval"
+    _, model = _build_kd()
+    sd = model.state_dict()
+    assert {k: ",".join(map(str, v.shape)) for k, v in sd.items()} == \
+        dict(zip(g["state_keys"].tolist(), g["state_shapes"].tolist()))
+    model.train()
+    if not training:
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+    coords, gt_coords = torch.from_numpy(g["coords"]).cuda(), torch.from_numpy(g["gt_coords"]).cuda()
+    bd = {"lidar_ms": SparseTensor(torch.from_numpy(g["feats"]).cuda(), coords),
+          "targets_ms": SparseTensor(torch.from_numpy(g["labels"]).cuda(), coords),
+          "lidar_ms_gt": SparseTensor(torch.from_numpy(g["gt_feats"]).cuda(), gt_coords),
+          "offset_ms": torch.tensor([0], device="cuda")}
+    grabbed = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, key=key: grabbed.__setitem__(key, o.detach().cpu().numpy()))
+             for key, m in (("logits", model.classifier), ("teacher_logits", model.classifier_gt))]
+    ret, tb, _ = model(bd)
+    for h in hooks:
+        h.remove()
+    for key in ("teacher_logits", "logits"):
+        assert np.abs(grabbed[key] - g[f"{tag}_{key}"]).max() <= LOGIT_TOL, key
+    parts = np.array([float(tb["loss_seg"]), float(tb["loss_feat_kd"])])
+    assert np.abs(parts - g[f"{tag}_loss_parts"]).max() <= 2e-3 * max(1.0, float(np.abs(g[f"{tag}_loss_parts"]).max()))
+    model.zero_grad()
+    ret["loss"].backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert not any("_gt" in n for n in grads)                       # the teacher ran without a graph
+    assert sorted(grads) == sorted(g[f"{tag}_gradnames"].tolist())
+    tol = 2e-2 if training else 1e-4
+    for k in g:
+        if k.startswith(f"{tag}_grad/"):
+            a, b = grads[k.split("/", 1)[1]].cpu().numpy(), g[k]
+            assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b), k
+
+
+def test_kd_checkpoint_loader_fills_the_teacher(tmp_path):
+    """a MinkUNetMs checkpoint initialises student AND teacher (minkunet_ms_kd.py:680-717); fix_part_param freezes `_gt`"""
+    import logging
+    from taseg_amd.pcseg.model import build_network
+    src = fill_parameters(build_network(make_model_cfg("MinkUNetMs", in_dim=5, cr=0.5, num_layer=[1] * 8), 20), seed=9)
+    path = tmp_path / "ms.pth"
+    torch.save({"model_state": {"module." + k: v for k, v in src.state_dict().items()}}, path)
+    _, kd = _build_kd()
+    kd.load_params_from_file(str(path), logging.getLogger("kd"), to_cpu=True)
+    sd, ref = kd.state_dict(), src.state_dict()
+    for k, v in ref.items():
+        head, _, rest = k.partition(".")
+        assert torch.equal(sd[k].cpu(), v) and torch.equal(sd[f"{head}_gt.{rest}"].cpu(), v), k
+    kd.fix_part_param()
+    assert all(p.requires_grad != ("_gt" in n) for n, p in kd.named_parameters())
