@@ -223,18 +223,11 @@ int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in, const flo
 int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t kernel_volume,
                        int64_t n_rows, int64_t n_pairs, float *out, ts_stream_t stream);
 
-/* Per-channel reductions of BatchNorm over the [n, c] feature matrix of a sparse tensor (the reference runs
- * nn.BatchNorm1d / nn.SyncBatchNorm on conv outputs, pcseg/.../minkunet/minkunet.py:23-29; the elementwise
- * halves stay torch.batch_norm_elemt / batch_norm_backward_elemt).  sums is double [2, c], zeroed here:
- *   ts_bn_stats:            sums[0] = sum_n x,   sums[1] = sum_n x^2
- *   ts_bn_backward_reduce:  sums[0] = sum_n dy,  sums[1] = sum_n dy * (x - mean)
- * c must be a multiple of 4 (<= 1024), pointers 16-byte aligned. */
-int ts_bn_stats(const float *x, int64_t n, int32_t c, double *sums, ts_stream_t stream);
-int ts_bn_backward_reduce(const float *grad_out, const float *x, const float *mean, int64_t n,
-                          int32_t c, double *sums, ts_stream_t stream);
-/* mean[c], invstd[c] from the sums of ts_bn_stats over `total` rows (*total_dev if non-NULL - e.g. the
- * all-reduced count of SyncBN - else total_host) and the nn.BatchNorm momentum update of the running
- * buffers (unbiased variance; either may be NULL). */
+/* BatchNorm over the [n, c] feature matrix of a sparse tensor (the reference runs nn.BatchNorm1d / nn.SyncBatchNorm on
+ * conv outputs, pcseg/.../minkunet/minkunet.py:23-29).  c must be a multiple of 4 (<= 1024), pointers 16-byte aligned. */
+/* mean[c], invstd[c] from sums = double [2, c] (sum x, sum x^2; e.g. the all-reduced pack of ts_bn_sync_stats) over
+ * `total` rows (*total_dev if non-NULL - the all-reduced count of SyncBN - else total_host) and the nn.BatchNorm
+ * momentum update of the running buffers (unbiased variance; either may be NULL). */
 int ts_bn_finalize(const double *sums, const double *total_dev, double total_host, int32_t c, float eps,
                    float momentum, float *running_mean, float *running_var, float *mean,
                    float *invstd, ts_stream_t stream);
@@ -243,15 +236,13 @@ int ts_bn_finalize(const double *sums, const double *total_dev, double total_hos
  * modules, minkunet.py:42-51,117-129: one full pass over [n, c] each):
  *   ts_bn_act_forward          out = act((x - mean) * invstd * weight + bias [+ residual]),  act = relu if relu != 0;
  *                              mask (optional, uint8 [n * c / 4]) gets the 4 sign bits of every float4 of `out`
- *   ts_bn_act_backward_reduce  g = grad_out * (out > 0) through that mask (all ones if mask == NULL);
- *                              sums[0] = sum_n g, sums[1] = sum_n g (x - mean)        (double [2, c], zeroed here)
- *   ts_bn_act_backward         grad_x = (g - sums[0]/N - (x - mean) invstd^2 sums[1]/N) invstd weight,
+ *   ts_bn_act_backward         g = grad_out * (out > 0) through that mask (all ones if mask == NULL); with
+ *                              sums = double [2, c] (sum g, sum g (x - mean); ts_bn_sync_backward_reduce, all-reduced):
+ *                              grad_x = (g - sums[0]/N - (x - mean) invstd^2 sums[1]/N) invstd weight,
  *                              grad_residual = g (optional); N = *total_dev if non-NULL else total_host. */
 int ts_bn_act_forward(const float *x, const float *residual, const float *mean, const float *invstd,
                       const float *weight, const float *bias, int64_t n, int32_t c, int32_t relu,
                       float *out, uint8_t *mask, ts_stream_t stream);
-int ts_bn_act_backward_reduce(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
-                              int64_t n, int32_t c, double *sums, ts_stream_t stream);
 int ts_bn_act_backward(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
                        const float *invstd, const float *weight, const double *sums,
                        const double *total_dev, double total_host, int64_t n, int32_t c, float *grad_x,

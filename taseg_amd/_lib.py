@@ -47,11 +47,8 @@ SIGNATURES = {
     "ts_conv_wgrad": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "ts_conv_pair_gemm": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_gather_sum": (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp]),
-    "ts_bn_stats": (_i32, [_vp, _i64, _i32, _vp, _vp]),
-    "ts_bn_backward_reduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "ts_bn_finalize": (_i32, [_vp, _vp, _c.c_double, _i32, _c.c_float, _c.c_float, _vp, _vp, _vp, _vp, _vp]),
     "ts_bn_act_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "ts_bn_act_backward_reduce": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "ts_bn_act_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_double, _i64, _i32, _vp, _vp, _vp]),
     "ts_bn_train_workspace_bytes": (_sz, [_i32]),
     "ts_bn_act_train_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _i32, _vp,

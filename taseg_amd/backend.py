@@ -497,25 +497,6 @@ def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
     return out
 
 
-def bn_stats(x):
-    """double [2, C]: per-channel sum and sum of squares of x [N, C] (C % 4 == 0)."""
-    L.require_device(x)
-    x = _f32(x, "x")
-    sums = torch.empty((2, x.shape[1]), dtype=torch.float64, device=x.device)
-    L.check(L.load().ts_bn_stats(L.ptr(x), x.shape[0], x.shape[1], L.ptr(sums), L.stream()), "ts_bn_stats")
-    return sums
-
-
-def bn_backward_reduce(grad_out, x, mean):
-    """double [2, C]: sum dy and sum dy * (x - mean) per channel."""
-    L.require_device(grad_out, x, mean)
-    grad_out, x, mean = _f32(grad_out, "grad_out"), _f32(x, "x"), _f32(mean, "mean")
-    sums = torch.empty((2, x.shape[1]), dtype=torch.float64, device=x.device)
-    L.check(L.load().ts_bn_backward_reduce(L.ptr(grad_out), L.ptr(x), L.ptr(mean), x.shape[0], x.shape[1],
-                                           L.ptr(sums), L.stream()), "ts_bn_backward_reduce")
-    return sums
-
-
 def image_gather_forward(feat, pix, pbatch, frame_end, height, width, shift=0):
     """out[n, c] = feat[first_frame(b_n) + row_n // H, c, (row_n % H) >> shift, col_n >> shift]  (unet2d.py:180-214).
 

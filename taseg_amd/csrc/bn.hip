@@ -1,90 +1,15 @@
-// Per-channel reductions of BatchNorm over [N, C] voxel features.
+// BatchNorm over [N, C] voxel features, training mode.
 //
 // The reference runs nn.BatchNorm1d / nn.SyncBatchNorm on the feature matrix of every sparse conv
-// (R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-29, TS/torchsparse/nn/utils/apply.py:10-16): two
-// full passes over N x C per conv.  PyTorch's channels-last reduction kernels reach ~1.4 TB/s on these tall,
-// narrow matrices (N = 1e5, C = 32..256); the two reductions are therefore done here:
-//   ts_bn_stats            sums[0][c] = sum_n x[n,c],           sums[1][c] = sum_n x[n,c]^2
-//   ts_bn_backward_reduce  sums[0][c] = sum_n dy[n,c],          sums[1][c] = sum_n dy[n,c] (x[n,c] - mean[c])
-// The elementwise halves (normalise, input gradient) stay torch.batch_norm_elemt / batch_norm_backward_elemt.
-// Accumulation: float per lane over <= 64 rows, float across the rows of a workgroup (LDS), double across
-// workgroups (global_atomic_add_f64) - so variance = E[x^2] - E[x]^2 is formed from double sums.
+// (R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-29, TS/torchsparse/nn/utils/apply.py:10-16), followed by
+// the residual add and the ReLU as separate passes.  This file holds
+//   * the elementwise halves: BN apply (+ residual) (+ ReLU) forward / backward (ts_bn_act_forward / _backward),
+//     statistics finalisation (ts_bn_finalize);
+//   * the sliced reductions + finish kernels and the one-call-per-direction training entry points
+//     (ts_bn_act_train_forward / _backward, fp32 and half storage);
+//   * the SyncBatchNorm reduction halves whose double sums the host all-reduces (ts_bn_sync_*).
+// Accumulation: float per lane over one slice (<= ~350 rows), double across slices.
 #include "common.h"
-
-#define BN_ROWS_PER_WG 512
-
-template <bool BWD>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ X, const float *__restrict__ DY,
-                                                        const float *__restrict__ mean, int64_t n, int c,
-                                                        double *__restrict__ sums) {
-  __shared__ float red[2][256 * 4];
-  const int cq = c >> 2;                 // float4 groups per row
-  const int rpp = 256 / cq;              // rows per pass
-  const int tid = threadIdx.x;
-  const int ty = tid / cq, tx = tid - ty * cq;
-  const bool active = ty < rpp;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (BWD && active) mu = *(const float4 *)(mean + 4 * tx);
-  const int64_t r_beg = (int64_t)blockIdx.x * BN_ROWS_PER_WG;
-  const int64_t r_end = min(n, r_beg + BN_ROWS_PER_WG);
-  if (active) {
-#pragma unroll 4
-    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
-      const float4 x = *(const float4 *)(X + r * c + 4 * tx);
-      if (!BWD) {
-        s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
-        s1.x += x.x * x.x; s1.y += x.y * x.y; s1.z += x.z * x.z; s1.w += x.w * x.w;
-      } else {
-        const float4 d = *(const float4 *)(DY + r * c + 4 * tx);
-        s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
-        s1.x += d.x * (x.x - mu.x); s1.y += d.y * (x.y - mu.y);
-        s1.z += d.z * (x.z - mu.z); s1.w += d.w * (x.w - mu.w);
-      }
-    }
-  }
-  *(float4 *)&red[0][tid * 4] = s0;
-  *(float4 *)&red[1][tid * 4] = s1;
-  __syncthreads();
-  // thread t < c reduces channel t over the rpp row slots
-  for (int ch = tid; ch < c; ch += 256) {
-    const int q = ch >> 2, l = ch & 3;
-    float a = 0.f, b = 0.f;
-    for (int y = 0; y < rpp; ++y) {
-      a += red[0][(y * cq + q) * 4 + l];
-      b += red[1][(y * cq + q) * 4 + l];
-    }
-    atomicAdd(&sums[ch], (double)a);
-    atomicAdd(&sums[c + ch], (double)b);
-  }
-}
-
-static int bn_launch(bool bwd, const float *x, const float *dy, const float *mean, int64_t n, int32_t c, double *sums,
-                     hipStream_t stream, const char *what) {
-  TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "%s: C must be a multiple of 4, <= 1024", what);
-  TS_REQUIRE(sums, TS_ERR_INVALID_ARGUMENT, "%s: null sums", what);
-  TS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream), "bn memset");
-  if (n == 0) return TS_OK;
-  TS_REQUIRE(x && (!bwd || (dy && mean)), TS_ERR_INVALID_ARGUMENT, "%s: null pointer", what);
-  TS_REQUIRE((((uintptr_t)x) & 15) == 0 && (!bwd || ((((uintptr_t)dy) & 15) == 0 && (((uintptr_t)mean) & 15) == 0)),
-             TS_ERR_INVALID_ARGUMENT, "%s: pointers must be 16-byte aligned", what);
-  const unsigned grid = (unsigned)ts_cdiv(n, BN_ROWS_PER_WG);
-  if (bwd)
-    bn_reduce_kernel<true><<<grid, 256, 0, stream>>>(x, dy, mean, n, c, sums);
-  else
-    bn_reduce_kernel<false><<<grid, 256, 0, stream>>>(x, nullptr, nullptr, n, c, sums);
-  TS_CHECK_LAUNCH(what);
-  return TS_OK;
-}
-
-extern "C" int ts_bn_stats(const float *x, int64_t n, int32_t c, double *sums, ts_stream_t stream) {
-  return bn_launch(false, x, nullptr, nullptr, n, c, sums, (hipStream_t)stream, "ts_bn_stats");
-}
-
-extern "C" int ts_bn_backward_reduce(const float *grad_out, const float *x, const float *mean, int64_t n, int32_t c,
-                                     double *sums, ts_stream_t stream) {
-  return bn_launch(true, x, grad_out, mean, n, c, sums, (hipStream_t)stream, "ts_bn_backward_reduce");
-}
 
 // mean / invstd from the double sums + running-statistics update (nn.BatchNorm1d semantics: biased variance
 // for normalisation, unbiased for running_var, momentum update), one tiny launch instead of ~8 tensor ops.
@@ -156,48 +81,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float4 *__restric
   }
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float *__restrict__ GOUT,
-                                                                const unsigned char *__restrict__ MASK,
-                                                                const float *__restrict__ X,
-                                                                const float *__restrict__ mean, int64_t n, int c,
-                                                                double *__restrict__ sums) {
-  __shared__ float red[2][256 * 4];
-  const int cq = c >> 2, rpp = 256 / cq;
-  const int tid = threadIdx.x, ty = tid / cq, tx = tid - ty * cq;
-  const bool active = ty < rpp;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0;
-  if (active) mu = *(const float4 *)(mean + 4 * tx);
-  const int64_t r_beg = (int64_t)blockIdx.x * BN_ROWS_PER_WG, r_end = min(n, r_beg + BN_ROWS_PER_WG);
-  if (active) {
-#pragma unroll 4
-    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
-      const float4 x = *(const float4 *)(X + r * c + 4 * tx);
-      float4 d = *(const float4 *)(GOUT + r * c + 4 * tx);
-      if (MASK) {
-        const unsigned mk = MASK[r * cq + tx];
-        d.x = (mk & 1) ? d.x : 0.f; d.y = (mk & 2) ? d.y : 0.f;
-        d.z = (mk & 4) ? d.z : 0.f; d.w = (mk & 8) ? d.w : 0.f;
-      }
-      s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
-      s1.x += d.x * (x.x - mu.x); s1.y += d.y * (x.y - mu.y);
-      s1.z += d.z * (x.z - mu.z); s1.w += d.w * (x.w - mu.w);
-    }
-  }
-  *(float4 *)&red[0][tid * 4] = s0;
-  *(float4 *)&red[1][tid * 4] = s1;
-  __syncthreads();
-  for (int ch = tid; ch < c; ch += 256) {
-    const int q = ch >> 2, l = ch & 3;
-    float a = 0.f, bsum = 0.f;
-    for (int y = 0; y < rpp; ++y) {
-      a += red[0][(y * cq + q) * 4 + l];
-      bsum += red[1][(y * cq + q) * 4 + l];
-    }
-    atomicAdd(&sums[ch], (double)a);
-    atomicAdd(&sums[c + ch], (double)bsum);
-  }
-}
-
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float4 *__restrict__ GOUT,
                                                          const unsigned char *__restrict__ MASK,
                                                          const float4 *__restrict__ X, const float *__restrict__ mean,
@@ -250,21 +133,6 @@ extern "C" int ts_bn_act_forward(const float *x, const float *residual, const fl
   bn_act_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd,
                                                            weight, bias, total4, c / 4, relu, (float4 *)out, mask);
   TS_CHECK_LAUNCH("ts_bn_act_forward");
-  return TS_OK;
-}
-
-extern "C" int ts_bn_act_backward_reduce(const float *grad_out, const uint8_t *mask, const float *x, const float *mean,
-                                         int64_t n, int32_t c, double *sums, ts_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(n >= 0 && c > 0 && (c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_bn_act_backward_reduce: bad C");
-  TS_REQUIRE(sums, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: null sums");
-  TS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream), "bn memset");
-  if (n == 0) return TS_OK;
-  TS_REQUIRE(grad_out && x && mean, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_reduce: null pointer");
-  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(mean), TS_ERR_INVALID_ARGUMENT,
-             "ts_bn_act_backward_reduce: pointers must be 16-byte aligned");
-  bn_act_bwd_reduce_kernel<<<(unsigned)ts_cdiv(n, BN_ROWS_PER_WG), 256, 0, stream>>>(grad_out, mask, x, mean, n, c, sums);
-  TS_CHECK_LAUNCH("ts_bn_act_backward_reduce");
   return TS_OK;
 }
 

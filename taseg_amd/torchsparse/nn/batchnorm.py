@@ -1,15 +1,14 @@
-"""Training-mode BatchNorm over sparse-tensor features with the two per-channel reductions on our HIP
-kernels (ts_bn_stats / ts_bn_backward_reduce) and the elementwise halves on torch's
-`batch_norm_elemt` / `batch_norm_backward_elemt` - the same decomposition torch's own SyncBatchNorm uses
-(torch/nn/modules/_functions.py), so the sync variant is one all-reduce of a [2C+1] vector instead of an
-all-gather of per-rank statistics.  Semantics = nn.BatchNorm1d / nn.SyncBatchNorm in training mode
-(reference: minkunet.py:23-29 wraps them with fapply)."""
+"""Training-mode BatchNorm (+ residual) (+ ReLU) over sparse-tensor features on the HIP kernels of csrc/bn.hip.
+Semantics = nn.BatchNorm1d / nn.SyncBatchNorm in training mode followed by the residual add and ReLU of the MinkUNet
+blocks (reference: minkunet.py:23-29 wraps the torch modules with fapply, :42-51 / :110-129 chain the passes).
+Single process: one backend call per direction (`ts_bn_act_train_*`, fp32 or half storage).  SyncBatchNorm: local
+sliced sums -> ONE all-reduce of [2C+1] (forward) / [2C] (backward) doubles -> elementwise kernels; torch's own
+SyncBatchNorm (torch/nn/modules/_functions.py) all-gathers per-rank mean / invstd / count instead."""
 import torch
 import torch.distributed as dist
 from torch.autograd import Function
 
 from ... import _lib as L
-from ... import backend as B
 
 __all__ = ["batch_norm_train", "fast_path_ok"]
 
@@ -20,50 +19,9 @@ def fast_path_ok(x: torch.Tensor) -> bool:
     return (x.dtype == torch.float32 and x.shape[1] % 4 == 0) or (x.dtype == torch.float16 and x.shape[1] % 8 == 0)
 
 
-class _BatchNormTrain(Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, group):
-        x = x.contiguous()
-        n, c = x.shape
-        sums = B.bn_stats(x)
-        total_dev = None
-        if group is not None:
-            pack = torch.cat([sums.view(-1), torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
-            dist.all_reduce(pack, group=group)
-            sums, total_dev = pack[:2 * c].view(2, c), pack[2 * c:]
-        mean = torch.empty(c, dtype=torch.float32, device=x.device)
-        invstd = torch.empty_like(mean)
-        L.check(L.load().ts_bn_finalize(L.ptr(sums), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
-                                        L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd),
-                                        L.stream()), "ts_bn_finalize")
-        out = torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps)
-        ctx.save_for_backward(x, weight, mean, invstd)
-        ctx.group = group
-        ctx.count = (total_dev.to(torch.int32) if total_dev is not None
-                     else torch.full((1,), n, dtype=torch.int32, device=x.device))
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        x, weight, mean, invstd = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
-        sums = B.bn_backward_reduce(grad_out, x, mean)
-        local = sums.float()
-        grad_weight = local[1] * invstd if ctx.needs_input_grad[1] else None
-        grad_bias = local[0] if ctx.needs_input_grad[2] else None
-        if ctx.group is not None:
-            dist.all_reduce(sums, group=ctx.group)
-            local = sums.float()
-        grad_x = None
-        if ctx.needs_input_grad[0]:
-            grad_x = torch.batch_norm_backward_elemt(grad_out, x, mean, invstd, weight, local[0], local[1], ctx.count)
-        return grad_x, grad_weight, grad_bias, None, None, None, None, None
-
-
 class _BatchNormActTrain(Function):
     """act(BN(x) [+ residual]) in training mode, forward and backward each as (one reduction + one elementwise
-    pass) over [N, C]: ts_bn_stats -> ts_bn_finalize -> ts_bn_act_forward, and
-    ts_bn_act_backward_reduce -> ts_bn_act_backward (the ReLU mask is a 4-bit-per-float4 byte array written by the forward)."""
+    pass) over [N, C]; the ReLU mask is one bit per element written by the forward."""
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, group):
