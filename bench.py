@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL process group, DDP, SyncBatchNorm collectives) even with "
                          "one rank - a single-GPU check of what `--gpus N` executes")
-    ap.add_argument("--cpu-sector-deg", type=float, default=180.0)
+    ap.add_argument("--cpu-sector-deg", type=float, default=360.0,
+                    help="azimuth sector of one scan the CPU baseline runs on (360 = the whole scan, ~15 s of CPU work)")
     return ap.parse_args()
 
 
@@ -119,7 +120,7 @@ def cpu_baseline(cfg, points, sector_deg):
         kind = "port"
     pts, lab = synth_scan(0, n_points=points)
     az = np.degrees(np.arctan2(pts[:, 1], pts[:, 0]))
-    keep = np.abs(az) < sector_deg / 2
+    keep = np.abs(az) <= sector_deg / 2
     pts, lab = pts[keep], lab[keep]
     pc = np.round(pts[:, :3] / VOXEL).astype(np.int32)
     pc -= pc.min(0, keepdims=True)
