@@ -15,7 +15,6 @@ all-reduce over ranks when there are several), whose buckets this optimizer shar
     opt.step()                                  # reducer.finish() + the three launches
 """
 import torch
-import torch.distributed as dist
 
 from . import _lib as L
 from .parallel import GradBucketReducer
@@ -29,25 +28,7 @@ class FlatSGD:
                  backoff_factor: float = 0.5, growth_interval: int = 2000, process_group=None, bucket_mb: float = 32.0):
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
         self.amp, self.growth, self.backoff, self.interval = amp, growth_factor, backoff_factor, growth_interval
-        distributed = dist.is_available() and dist.is_initialized()
-        if distributed:
-            self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb)
-        else:
-            self.reducer = GradBucketReducer.__new__(GradBucketReducer)
-            self.reducer.group, self.reducer.world, self.reducer.buckets, self.reducer._works = None, 1, [], []
-            params = [p for p in model.parameters() if p.requires_grad]
-            cur, cur_bytes = [], 0
-            for p in reversed(params):
-                cur.append(p)
-                cur_bytes += p.numel() * p.element_size()
-                if cur_bytes >= bucket_mb * (1 << 20):
-                    self.reducer._add_bucket(cur)
-                    cur, cur_bytes = [], 0
-            if cur:
-                self.reducer._add_bucket(cur)
-            for b in self.reducer.buckets:
-                for p in b["params"]:
-                    p.register_post_accumulate_grad_hook(self.reducer._make_hook(b))
+        self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb)
         dev = self.reducer.buckets[0]["flat"].device
         L.require_device(self.reducer.buckets[0]["flat"])
         # parameters move into flat buckets too (p.data becomes a view): the update is one launch per bucket

@@ -79,7 +79,8 @@ class GradBucketReducer:
 
     def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: float = 32.0, broadcast: bool = True):
         self.group = process_group
-        self.world = dist.get_world_size(process_group)
+        # also usable without a process group (one process): the buckets then only flatten the gradients
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []
         cur, cur_bytes = [], 0

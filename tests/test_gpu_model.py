@@ -189,3 +189,51 @@ print("SYNC_OK")
     env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "SYNC_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_prefetched_batches_train_like_inline_ones():
+    """DevicePrefetcher (index plan of batch i+1 built on the staging stream during step i) must not change results:
+    three SGD steps over alternating batches give the same losses and final weights as staging inside forward()."""
+    from taseg_amd.data.stage import DevicePrefetcher
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    data = []
+    for seed in (3, 4):
+        pts, lab = synth_scan(seed, n_points=20000, n_beams=32, n_az=1000)
+        pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+        pc -= pc.min(0)
+        _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+        coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+        data.append((torch.from_numpy(pts[idx]).cuda(), coords, torch.from_numpy(lab[idx].astype(np.int64)).cuda()))
+
+    def run(prefetch):
+        cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
+        model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        it = [0]
+
+        def make_batch():
+            f, c, l = data[it[0] % 2]
+            it[0] += 1
+            return {"lidar": SparseTensor(f, c), "targets": SparseTensor(l, c), "offset": torch.tensor([0])}
+
+        pf = DevicePrefetcher(make_batch, model.prepare) if prefetch else None
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            ret, _, _ = model(pf.next() if pf else make_batch())
+            ret["loss"].backward()
+            opt.step()
+            if pf:
+                pf.prefetch()
+            losses.append(float(ret["loss"]))
+        if pf:
+            pf.close()
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    la, wa = run(False)
+    lb, wb = run(True)
+    assert np.allclose(la, lb, rtol=0, atol=1e-5)
+    for a, b in zip(wa, wb):            # weight-gradient partials are combined with float atomics: not bitwise
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
