@@ -349,6 +349,21 @@ int ts_sgd_decide(double *sumsq, int32_t *nonfinite, float *state, float max_nor
 int ts_sgd_apply(float *param, const float *grad, float *momentum_buf, int64_t n, const float *state, float lr,
                  float momentum, float weight_decay, int32_t first_step, ts_stream_t stream);
 
+/* Half-storage forms of the SyncBatchNorm halves (ts_bn_sync_stats, ts_bn_act_forward, ts_bn_sync_backward_reduce,
+ * ts_bn_act_backward): activations / gradients IEEE half [n, c] (c % 8 == 0), mask one byte per 8 elements, everything
+ * else as in the fp32 forms.  ts_bn_act_backward_f16 needs 2 c floats of 16-byte aligned scratch. */
+int ts_bn_sync_stats_f16(const void *x, int64_t n, int32_t c, double *pack, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_bn_act_forward_f16(const void *x, const void *residual, const float *mean, const float *invstd,
+                          const float *weight, const float *bias, int64_t n, int32_t c, int32_t relu, void *out,
+                          uint8_t *mask, ts_stream_t stream);
+int ts_bn_sync_backward_reduce_f16(const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                                   const float *invstd, int64_t n, int32_t c, double *sums, float *grad_weight,
+                                   float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_bn_act_backward_f16(const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                           const float *invstd, const float *weight, const double *sums, const double *total_dev,
+                           double total_host, int64_t n, int32_t c, void *grad_x, void *grad_residual, void *ws,
+                           size_t ws_bytes, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,

@@ -71,6 +71,11 @@ SIGNATURES = {
     "ts_sgd_grad_stats": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "ts_sgd_decide": (_i32, [_vp, _vp, _vp, _c.c_float, _c.c_float, _c.c_float, _i32, _i32, _vp]),
     "ts_sgd_apply": (_i32, [_vp, _vp, _vp, _i64, _vp, _c.c_float, _c.c_float, _c.c_float, _i32, _vp]),
+    "ts_bn_sync_stats_f16": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "ts_bn_act_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "ts_bn_sync_backward_reduce_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_bn_act_backward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_double, _i64, _i32, _vp, _vp, _vp, _sz,
+                                      _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

@@ -662,3 +662,108 @@ extern "C" int ts_bn_act_train_backward_f16(const void *grad_out, const uint8_t 
   TS_CHECK_LAUNCH("ts_bn_act_train_backward_f16");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// SyncBatchNorm halves for half-storage activations (the reference's actual recipe is AMP + DDP + SyncBatchNorm,
+// R/dist_train.sh:17-19): the same double sums cross the ranks, activations and gradients stay half in HBM.
+__global__ void bn_coef_from_sums_kernel(const double *__restrict__ sums, const double *__restrict__ total_dev,
+                                         double total_host, const float *__restrict__ invstd, int c,
+                                         float *__restrict__ coef) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const double total = total_dev ? *total_dev : total_host;
+  const float is = invstd[ch];
+  coef[ch] = (float)(sums[ch] / total);
+  coef[c + ch] = (float)(sums[c + ch] / total) * is * is;
+}
+
+static int bn_h_check(const char *what, int64_t n, int32_t c) {
+  TS_REQUIRE(n > 0 && c > 0 && (c & 7) == 0 && c <= 2048, TS_ERR_UNSUPPORTED, "%s: need N > 0 and C a multiple of 8, <= 2048",
+             what);
+  return TS_OK;
+}
+
+extern "C" int ts_bn_sync_stats_f16(const void *x, int64_t n, int32_t c, double *pack, void *ws, size_t ws_bytes,
+                                    ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_h_check("ts_bn_sync_stats_f16", n, c);
+  if (rc != TS_OK) return rc;
+  TS_REQUIRE(x && pack && ws && bn_aligned(x) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT, "ts_bn_sync_stats_f16: bad pointer");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT, "ts_bn_sync_stats_f16: workspace too small");
+  float *part = (float *)ws;
+  const int rows = bn_rows_per_slice_h(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  bn_partial_h_kernel<0><<<slices, 256, 0, stream>>>((const _Float16 *)x, nullptr, nullptr, nullptr, n, c, rows, part);
+  bn_sums_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, c, (double)n, nullptr, pack,
+                                                                           nullptr, nullptr);
+  TS_CHECK_LAUNCH("ts_bn_sync_stats_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_act_forward_f16(const void *x, const void *residual, const float *mean, const float *invstd,
+                                     const float *weight, const float *bias, int64_t n, int32_t c, int32_t relu,
+                                     void *out, uint8_t *mask, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_h_check("ts_bn_act_forward_f16", n, c);
+  if (rc != TS_OK) return rc;
+  TS_REQUIRE(x && mean && invstd && weight && bias && out, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_forward_f16: null pointer");
+  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && (!residual || bn_aligned(residual)), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_forward_f16: pointers must be 16-byte aligned");
+  const int64_t total8 = n * (c / 8);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total8, 256), 1 << 16);
+  bn_act_fwd_h_kernel<<<grid, 256, 0, stream>>>((const bn_h8 *)x, (const bn_h8 *)residual, mean, invstd, weight, bias,
+                                                total8, c / 8, relu, (bn_h8 *)out, mask);
+  TS_CHECK_LAUNCH("ts_bn_act_forward_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_sync_backward_reduce_f16(const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                                              const float *invstd, int64_t n, int32_t c, double *sums,
+                                              float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes,
+                                              ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_h_check("ts_bn_sync_backward_reduce_f16", n, c);
+  if (rc != TS_OK) return rc;
+  TS_REQUIRE(grad_out && x && mean && invstd && sums && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_sync_backward_reduce_f16: null pointer");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_sync_backward_reduce_f16: pointers must be 16-byte aligned");
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_sync_backward_reduce_f16: workspace too small");
+  float *part = (float *)ws;
+  const int rows = bn_rows_per_slice_h(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  if (mask)
+    bn_partial_h_kernel<2><<<slices, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_out, mask, mean, n, c,
+                                                       rows, part);
+  else
+    bn_partial_h_kernel<1><<<slices, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_out, nullptr, mean, n,
+                                                       c, rows, part);
+  bn_sums_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, c, -1.0, invstd, sums,
+                                                                           grad_weight, grad_bias);
+  TS_CHECK_LAUNCH("ts_bn_sync_backward_reduce_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_bn_act_backward_f16(const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                                      const float *invstd, const float *weight, const double *sums,
+                                      const double *total_dev, double total_host, int64_t n, int32_t c, void *grad_x,
+                                      void *grad_residual, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_h_check("ts_bn_act_backward_f16", n, c);
+  if (rc != TS_OK) return rc;
+  TS_REQUIRE(grad_out && x && mean && invstd && weight && sums && grad_x && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_bn_act_backward_f16: null pointer");
+  TS_REQUIRE(total_dev || total_host > 0.0, TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_f16: empty batch");
+  TS_REQUIRE(ws_bytes >= 2 * (size_t)c * sizeof(float), TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_f16: workspace too small");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) && (!grad_residual || bn_aligned(grad_residual)) &&
+                 bn_aligned(ws), TS_ERR_INVALID_ARGUMENT, "ts_bn_act_backward_f16: pointers must be 16-byte aligned");
+  float *coef = (float *)ws;
+  bn_coef_from_sums_kernel<<<(unsigned)ts_cdiv(c, 256), 256, 0, stream>>>(sums, total_dev, total_host, invstd, c, coef);
+  const int64_t total8 = n * (c / 8);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total8, 256), 1 << 16);
+  bn_act_bwd_coef_h_kernel<<<grid, 256, 0, stream>>>((const bn_h8 *)grad_out, mask, (const bn_h8 *)x, mean, invstd, weight,
+                                                     coef, total8, c, (bn_h8 *)grad_x, (bn_h8 *)grad_residual);
+  TS_CHECK_LAUNCH("ts_bn_act_backward_f16");
+  return TS_OK;
+}

@@ -25,10 +25,11 @@ class _BatchNormActTrain(Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, group):
-        half = x.dtype == torch.float16 and group is None
+        half = x.dtype == torch.float16
         x = x.contiguous() if (half or x.dtype == torch.float32) else x.contiguous().float()
         n, c = x.shape
         lib = L.load()
+        sfx = "_f16" if half else ""
         if residual is not None:
             residual = residual.contiguous().to(x.dtype)
         stats = torch.empty((2, c), dtype=torch.float32, device=x.device)        # mean, invstd
@@ -37,41 +38,32 @@ class _BatchNormActTrain(Function):
         per = 8 if half else 4                         # elements per mask byte
         mask = torch.empty(n * (c // per), dtype=torch.uint8, device=x.device) if relu else None
         total_dev = None
-        ctx.half = half
-        if half:
-            # half activations in / out, fp32 statistics and arithmetic (what autocast does to batch_norm)
-            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
-            L.check(lib.ts_bn_act_train_forward_f16(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
-                                                    L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), n, c,
-                                                    float(eps), float(momentum), 1 if relu else 0, L.ptr(mean),
-                                                    L.ptr(invstd), L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(),
-                                                    L.stream()), "ts_bn_act_train_forward_f16")
-        elif group is None:
+        ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+        if group is None:
             # single process: partial reductions, statistics and the elementwise pass in one backend call
-            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
-            L.check(lib.ts_bn_act_train_forward(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
-                                                L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), n, c, float(eps),
-                                                float(momentum), 1 if relu else 0, L.ptr(mean), L.ptr(invstd),
-                                                L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream()),
-                    "ts_bn_act_train_forward")
+            # (half storage: activations half in / out, statistics and arithmetic fp32 - what autocast does to batch_norm)
+            fn = getattr(lib, "ts_bn_act_train_forward" + sfx)
+            L.check(fn(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                       L.ptr(nbt), n, c, float(eps), float(momentum), 1 if relu else 0, L.ptr(mean), L.ptr(invstd),
+                       L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream()), "ts_bn_act_train_forward" + sfx)
         else:
             # SyncBatchNorm: local sums -> ONE all-reduce of [2C + 1] doubles -> statistics + elementwise pass
             if nbt is not None:
                 nbt.add_(1)
-            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
             pack = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
-            L.check(lib.ts_bn_sync_stats(L.ptr(x), n, c, L.ptr(pack), L.ptr(ws), ws.numel(), L.stream()),
-                    "ts_bn_sync_stats")
+            L.check(getattr(lib, "ts_bn_sync_stats" + sfx)(L.ptr(x), n, c, L.ptr(pack), L.ptr(ws), ws.numel(),
+                                                           L.stream()), "ts_bn_sync_stats" + sfx)
             dist.all_reduce(pack, group=group)
             total_dev = pack[2 * c:]
             L.check(lib.ts_bn_finalize(L.ptr(pack), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
                                        L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd),
                                        L.stream()), "ts_bn_finalize")
-            L.check(lib.ts_bn_act_forward(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd), L.ptr(weight),
-                                          L.ptr(bias), n, c, 1 if relu else 0, L.ptr(out), L.ptr(mask), L.stream()),
-                    "ts_bn_act_forward")
+            L.check(getattr(lib, "ts_bn_act_forward" + sfx)(L.ptr(x), L.ptr(residual), L.ptr(mean), L.ptr(invstd),
+                                                            L.ptr(weight), L.ptr(bias), n, c, 1 if relu else 0,
+                                                            L.ptr(out), L.ptr(mask), L.stream()),
+                    "ts_bn_act_forward" + sfx)
         ctx.save_for_backward(x, weight, mean, invstd, mask)
-        ctx.group, ctx.total_dev, ctx.has_res = group, total_dev, residual is not None
+        ctx.group, ctx.total_dev, ctx.has_res, ctx.half = group, total_dev, residual is not None, half
         return out
 
     @staticmethod
@@ -80,34 +72,31 @@ class _BatchNormActTrain(Function):
         grad_out = grad_out.contiguous().to(x.dtype)
         n, c = x.shape
         lib = L.load()
+        sfx = "_f16" if ctx.half else ""
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        if ctx.half:
-            gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
-            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
-            L.check(lib.ts_bn_act_train_backward_f16(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
-                                                     L.ptr(weight), n, c, L.ptr(grad_x), L.ptr(grad_res),
-                                                     L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()),
-                    "ts_bn_act_train_backward_f16")
-            return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
-        if ctx.group is None:
-            gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)      # grad_weight, grad_bias
-            ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
-            L.check(lib.ts_bn_act_train_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
-                                                 L.ptr(weight), n, c, L.ptr(grad_x), L.ptr(grad_res), L.ptr(gwb[0]),
-                                                 L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()),
-                    "ts_bn_act_train_backward")
-            return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
-        sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
         gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)          # this rank's grad_weight, grad_bias
         ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
-        L.check(lib.ts_bn_sync_backward_reduce(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd), n, c,
-                                               L.ptr(sums), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(),
-                                               L.stream()), "ts_bn_sync_backward_reduce")
-        dist.all_reduce(sums, group=ctx.group)
-        L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
-                                       L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
-                                       L.ptr(grad_x), L.ptr(grad_res), L.stream()), "ts_bn_act_backward")
+        if ctx.group is None:
+            L.check(getattr(lib, "ts_bn_act_train_backward" + sfx)(
+                L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd), L.ptr(weight), n, c, L.ptr(grad_x),
+                L.ptr(grad_res), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()),
+                "ts_bn_act_train_backward" + sfx)
+        else:
+            sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
+            L.check(getattr(lib, "ts_bn_sync_backward_reduce" + sfx)(
+                L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd), n, c, L.ptr(sums), L.ptr(gwb[0]),
+                L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()), "ts_bn_sync_backward_reduce" + sfx)
+            dist.all_reduce(sums, group=ctx.group)
+            if ctx.half:
+                L.check(lib.ts_bn_act_backward_f16(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                                   L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
+                                                   L.ptr(grad_x), L.ptr(grad_res), L.ptr(ws), ws.numel(), L.stream()),
+                        "ts_bn_act_backward_f16")
+            else:
+                L.check(lib.ts_bn_act_backward(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                               L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,
+                                               L.ptr(grad_x), L.ptr(grad_res), L.stream()), "ts_bn_act_backward")
         return grad_x, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
 
 

@@ -158,14 +158,17 @@ x = torch.randn(n, c, generator=g).cuda().requires_grad_()
 res = torch.randn(n, c, generator=g).cuda().requires_grad_()
 w = (torch.rand(c, generator=g) + 0.5).cuda().requires_grad_()
 b = torch.randn(c, generator=g).cuda().requires_grad_()
-outs = []
-for group in (None, dist.group.WORLD):
-    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
-    y = batch_norm_act_train(x, w, b, rm, rv, 0.1, 1e-5, relu=True, residual=res, group=group)
-    gx, gr, gw, gb = torch.autograd.grad((y * y).sum(), (x, res, w, b))
-    outs.append([t.detach().cpu() for t in (y, gx, gr, gw, gb, rm, rv)])
-for a, bb in zip(*outs):
-    assert torch.allclose(a, bb, rtol=2e-4, atol=2e-4), float((a - bb).abs().max())
+for dtype, tol in ((torch.float32, 2e-4), (torch.float16, 2e-2)):      # fp32 and half-storage activations
+    outs = []
+    for group in (None, dist.group.WORLD):
+        xi, ri = x.detach().to(dtype).requires_grad_(), res.detach().to(dtype).requires_grad_()
+        rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+        y = batch_norm_act_train(xi, w, b, rm, rv, 0.1, 1e-5, relu=True, residual=ri, group=group)
+        assert y.dtype == dtype
+        gx, gr, gw, gb = torch.autograd.grad((y.float() * y.float()).sum(), (xi, ri, w, b))
+        outs.append([t.detach().float().cpu() for t in (y, gx, gr, gw, gb, rm, rv)])
+    for a, bb in zip(*outs):
+        assert torch.allclose(a, bb, rtol=tol, atol=tol), (dtype, float((a - bb).abs().max()))
 # one DDP + SyncBatchNorm training step of the segmentor
 from taseg_amd.data.synthetic import make_model_cfg, synth_scan
 from taseg_amd.pcseg.model import build_network
