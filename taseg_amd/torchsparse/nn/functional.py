@@ -212,6 +212,25 @@ def _half_ok(*channels) -> bool:
     return all(c % 32 == 0 for c in channels)
 
 
+class _NoCtx:
+    __slots__ = ()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def _no_autocast():
+    """Context in which our kernels run: autocast off (they choose their own precision).  A real context manager
+    only when autocast is on - this is entered ~200 times per step."""
+    return torch.autocast("cuda", enabled=False) if torch.is_autocast_enabled("cuda") else _NO_CTX
+
+
 class _SparseConv(Function):
     """conv.py:16-119 on the neighbour tables.  `transposed` swaps the roles of the two
     index columns exactly like convolution_cuda.cu:21,34.
@@ -233,7 +252,7 @@ class _SparseConv(Function):
         want_half = _amp_half(feats)
         half = want_half and _half_ok(weight.shape[1], weight.shape[2])
         gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
-        with torch.autocast("cuda", enabled=False):
+        with _no_autocast():
             if half:
                 fh = feats.contiguous().half()
                 w16, w16t = B.cast_weights_f16(weight.detach().float())
@@ -260,7 +279,7 @@ class _SparseConv(Function):
         grad_feats = grad_weight = None
         gcol = 0 if transposed else 1
         table, rows = (kmap.pos_in, n_in) if not transposed else (kmap.pos_out, n_out)
-        with torch.autocast("cuda", enabled=False):
+        with _no_autocast():
             if ctx.half:
                 gh = grad_out.contiguous().half()
                 if ctx.needs_input_grad[0]:
@@ -328,7 +347,7 @@ class _PointwiseConv(Function):
     @staticmethod
     def forward(ctx, feats, weight, ident):
         half = _amp_half(feats)
-        with torch.autocast("cuda", enabled=False):
+        with _no_autocast():
             f = feats.contiguous().half() if half else feats.contiguous().float()
             w = weight.detach().half() if half else weight.detach().float()
             out = f.matmul(w)
@@ -340,7 +359,7 @@ class _PointwiseConv(Function):
     def backward(ctx, grad_out):
         feats, weight = ctx.saved_tensors
         pairs, offs = ctx.ident
-        with torch.autocast("cuda", enabled=False):
+        with _no_autocast():
             grad_out = grad_out.contiguous().to(feats.dtype)
             grad_feats = grad_out.matmul(weight.t()).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
             grad_weight = None
