@@ -542,3 +542,35 @@ def test_fused_bn_act_matches_torch(with_res, relu):
     close(ours.weight.grad, ref.weight.grad, 5e-5)
     close(ours.bias.grad, ref.bias.grad, 5e-5)
     close(ours.running_var, ref.running_var, 1e-5)
+
+
+def test_new_entry_points_accept_empty_inputs(B):
+    """zero points / pairs / voxels must return empty (or zero) results, not launch over bad grids"""
+    dev = DEV
+    e4 = torch.empty((0, 4), dtype=torch.float32, device=dev)
+    assert B.fuse_scans(e4, torch.empty(0, dtype=torch.int32, device=dev), torch.eye(4, device=dev),
+                        torch.eye(4, device=dev)[None]).shape == (0, 4)
+    idx = torch.empty((0, 8), dtype=torch.int32, device=dev)
+    w = torch.empty((0, 8), dtype=torch.float32, device=dev)
+    assert B.devox_order(idx, 10).shape == (0,)
+    g = B.devoxelize_backward_runs(torch.empty((0, 32), device=dev), idx, w, 10, None)
+    assert g.shape == (10, 32) and float(g.abs().sum()) == 0.0
+    feat = torch.randn(2, 8, 4, 6, device=dev)
+    out, err = B.image_gather_forward(feat, torch.empty((0, 2), device=dev), torch.empty(0, dtype=torch.int32, device=dev),
+                                      torch.tensor([2], dtype=torch.int32, device=dev), 4, 6)
+    assert out.shape == (0, 8) and int(err) == 0
+    gf = B.image_gather_backward(torch.empty((0, 8), device=dev), torch.empty((0, 2), device=dev),
+                                 torch.empty(0, dtype=torch.int32, device=dev),
+                                 torch.tensor([2], dtype=torch.int32, device=dev), 2, 4, 6)
+    assert gf.shape == (2, 8, 4, 6) and float(gf.abs().sum()) == 0.0
+    # no pairs at all: an isolated voxel convolved with a kernel whose centre is the only hit still works; a rulebook
+    # with zero pairs yields zeros
+    nb = torch.empty((1, 2), dtype=torch.int32, device=dev)
+    offs = torch.zeros(28, dtype=torch.int32, device=dev)
+    z = B.conv_pair_gemm_f16(torch.randn(5, 32, device=dev).half(), torch.randn(27, 32, 32, device=dev).half(), nb, offs, 0, 0)
+    assert z.shape == (0, 32)
+    gw = B.conv_wgrad_f16(torch.randn(5, 32, device=dev).half(), torch.randn(5, 32, device=dev).half(), nb, offs, 27, 0, 0)
+    assert gw.shape == (27, 32, 32) and float(gw.abs().sum()) == 0.0
+    pos = torch.full((27, 5), -1, dtype=torch.int32, device=dev)
+    y = B.conv_gather_sum_f16(z, pos, 5)
+    assert y.shape == (5, 32) and float(y.float().abs().sum()) == 0.0
