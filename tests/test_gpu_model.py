@@ -235,8 +235,16 @@ def test_prefetched_batches_train_like_inline_ones():
             pf.close()
         return losses, [p.detach().clone() for p in model.parameters()]
 
+    def rel(wx, wy):
+        return max(float((a - b).norm() / a.norm().clamp_min(1e-12)) for a, b in zip(wx, wy))
+
     la, wa = run(False)
+    la2, wa2 = run(False)
     lb, wb = run(True)
-    assert np.allclose(la, lb, rtol=0, atol=1e-5)
-    for a, b in zip(wa, wb):            # weight-gradient partials are combined with float atomics: not bitwise
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    # weight-gradient partials are combined with float atomics, so two identical runs differ in the last bits and
+    # train-mode BN over the few stride-16 voxels of these small scans amplifies that: the run-to-run spread of the
+    # inline path is the yardstick for the prefetched one (per-tensor relative L2)
+    noise, diff = rel(wa, wa2), rel(wa, wb)
+    print(f"prefetch: losses {la} / {lb}; weights rel L2 inline-vs-inline {noise:.2e}, inline-vs-prefetched {diff:.2e}")
+    assert np.allclose(la, lb, rtol=0, atol=max(1e-5, 10 * float(np.abs(np.array(la) - np.array(la2)).max())))
+    assert diff <= max(1e-4, 10 * noise), (diff, noise)
