@@ -23,6 +23,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (same guide; no sparsity)
+MFMA_SPLIT_PEAK_TF = MFMA_F16_PEAK_TF / 6   # fp32 products as six bf16 MFMAs (csrc/conv_pairs_s.hip): 416.7 TF/s of fp32 flops
 VOXEL = 0.05
 EVENT_EVERY = 4             # per-launch HIP events bracket the conv kernels of every 4th timed step
 
@@ -55,6 +56,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL process group, DDP, SyncBatchNorm collectives) even with "
                          "one rank - a single-GPU check of what `--gpus N` executes")
+    ap.add_argument("--conv-impl", type=int, default=0,
+                    help="ts_set_conv_impl: 0 = default (full-tile fp32 GEMMs as split-bf16 MFMAs), 5 = v_mfma_f32_16x16x4_f32")
     ap.add_argument("--cpu-sector-deg", type=float, default=360.0,
                     help="azimuth sector of one scan the CPU baseline runs on (360 = the whole scan, ~15 s of CPU work)")
     return ap.parse_args()
@@ -212,6 +215,7 @@ def main():
     from taseg_amd.pcseg.model import build_network
     from taseg_amd.torchsparse import SparseTensor
 
+    B.set_conv_impl(args.conv_impl)
     nusc = args.workload == "nuscenes_ms"
     ms = args.workload in ("minkunet_ms", "nuscenes_ms")
     if args.batch is None:
@@ -334,7 +338,7 @@ def main():
         dom = prof[0] if prof else None
         roofline = None
         if dom:
-            mfma_peak = MFMA_F16_PEAK_TF if args.amp else MFMA_F32_PEAK_TF
+            mfma_peak = MFMA_F16_PEAK_TF if args.amp else MFMA_SPLIT_PEAK_TF if "_s_kernel" in dom["kernel"] else MFMA_F32_PEAK_TF
             t_mfma = dom["flops_per_launch"] / (mfma_peak * 1e12)
             t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
             if t_mfma >= t_hbm:

@@ -364,7 +364,8 @@ int ts_bn_act_backward_f16(const void *grad_out, const uint8_t *mask, const void
                            double total_host, int64_t n, int32_t c, void *grad_x, void *grad_residual, void *ws,
                            size_t ws_bytes, ts_stream_t stream);
 
-/* Debug / cross-check implementation selector: 0 = MFMA kernels (default),
+/* Debug / cross-check implementation selector: 0 = MFMA kernels (default; full-tile fp32 GEMMs run on the bf16 matrix
+ * pipe through the exact three-way operand split of csrc/conv_pairs_s.hip), 5 = the same with v_mfma_f32_16x16x4_f32,
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,
  * 3 / 4 = full-tile pair GEMM with one workgroup per tile everywhere / persistent workgroups everywhere

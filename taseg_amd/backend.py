@@ -274,6 +274,8 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
 def pair_gemm_kernel_name(c_out, weight_transposed=False, c_red=None):
     bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (96, 2) if c_out % 96 == 0 else (128, 2)
     fast = c_red is not None and c_red % 32 == 0 and c_out % bn == 0
+    if fast and _conv_impl == 0:
+        return f"pair_gemm_s_kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
     kind = "" if not fast else ("fast_" if weight_transposed else "persist_")
     return f"pair_gemm_{kind}kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
 
@@ -396,6 +398,8 @@ def trilinear_map(points, vox_coords, stride):
     return idx, w
 
 
+_conv_impl = 0      # mirrors the library's selector (kernel names reported to bench.py)
+
 # Optional per-launch timing (bench.py): HIP events on the launch stream around the conv kernels.
 _prof = None
 _prof_store = None
@@ -464,6 +468,8 @@ def conv_kernel_name(c_out_or_ca, weight_transposed=False, wgrad_cb=None, n_out=
         pick = lambda c: 32 if c <= 32 else 64 if c <= 64 else 96 if c % 96 == 0 else 128  # noqa: E731
         tm, tn = pick(c_out_or_ca), pick(wgrad_cb)
         fast = c_out_or_ca % tm == 0 and wgrad_cb % tn == 0
+        if fast and _conv_impl == 0:
+            return f"wgrad_s_kernel<{tm},{tn}>"
         return f"wgrad_gemm_{'fast_' if fast else ''}kernel<{tm},{tn}>"
     c16 = (c_out_or_ca + 15) & ~15
     tiles64 = -(-n_out // 64)
@@ -553,7 +559,10 @@ def image_gather_backward(grad_out, pix, pbatch, frame_end, frames, height, widt
 
 
 def set_conv_impl(impl):
-    """0 = MFMA kernels (default), 1 = scalar cross-check kernels, 2 = MFMA kernels, guarded generic staging only."""
+    """0 = MFMA kernels (default: full-tile fp32 GEMMs as split-bf16 MFMAs), 1 = scalar cross-check kernels, 2 = guarded
+    generic f32 MFMA staging only, 3 / 4 = f32 MFMA one workgroup per tile / persistent, 5 = f32 MFMA default choice."""
+    global _conv_impl
+    _conv_impl = int(impl)
     L.load().ts_set_conv_impl(int(impl))
 
 

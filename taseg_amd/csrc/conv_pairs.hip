@@ -22,6 +22,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PG_BK 32
 #define PG_AP (PG_BK + 4)
 
+// split-bf16 forms of the full-tile kernels (conv_pairs_s.hip); selected unless ts_set_conv_impl asks for the f32 MFMA
+int ts_pair_gemm_split(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs, int K,
+                       int64_t P, int gcol, float *Z, int bn, int wt, hipStream_t stream);
+int ts_wgrad_split(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
+                   int col_a, int64_t n_pairs, float *dW, int tm, int tn, hipStream_t stream);
+
 // BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
 // Software pipeline: the (offset, C_in-slice) steps of a tile are flattened; the global loads of step s+1 are
 // issued into registers right after the barrier of step s and land while its MFMAs run; LDS is double
@@ -664,6 +670,8 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
   const bool fast = (R % PG_BK == 0) && (O_total % BN == 0) && ((((uintptr_t)X) | ((uintptr_t)W)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
+  if (fast && g_ts_conv_impl == 0)   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
+    return ts_pair_gemm_split(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, BN, WT ? 1 : 0, stream);
   if (fast) {
     static bool fattr_set = false;
     if (!fattr_set) {
@@ -1161,6 +1169,8 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
   const bool fast = (CA % TM == 0) && (CB % TN == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
+  if (fast && g_ts_conv_impl == 0)
+    return ts_wgrad_split(A, CA, B, CB, nbmaps, nboffs, K, col_a, n_pairs, dW, TM, TN, stream);
   if (fast)
     wgrad_gemm_fast_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
                                                             (int)chunk, dW);

@@ -343,7 +343,11 @@ def test_conv_fast_path_equals_generic_kernels(B, F, ci, co):
         gw = B.conv_wgrad(x, gy, km["nbmaps"], km["nboffs"], 27, col_a=0, max_pairs=total)
         return z, zt, gw
 
-    fast = run()
+    B.set_conv_impl(5)              # f32 MFMA full-tile kernels (the default, impl 0, runs the split-bf16 ones)
+    try:
+        fast = run()
+    finally:
+        B.set_conv_impl(0)
     variants = []
     for impl in (2, 3, 4):          # generic guarded kernels / one workgroup per tile / persistent workgroups
         B.set_conv_impl(impl)
@@ -354,6 +358,53 @@ def test_conv_fast_path_equals_generic_kernels(B, F, ci, co):
     for other in variants:
         assert torch.equal(fast[0], other[0]) and torch.equal(fast[1], other[1])
         close(fast[2], other[2], 1e-5)
+
+
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 64), (128, 128), (384, 256), (256, 192), (32, 128)])
+@pytest.mark.parametrize("scale", [1.0, 1e-6])
+def test_conv_split_bf16_kernels_are_fp32_grade(B, F, ci, co, scale):
+    """the default full-tile kernels evaluate fp32 products as six bf16 x bf16 MFMAs on the exact three-way split of
+    both operands (csrc/conv_pairs_s.hip).  Against a float64 evaluation of the same pairs their error must be of the
+    size of the f32-MFMA kernels' own (ts_set_conv_impl(5)) - fp32 grade, nowhere near bf16 (4e-3) - also for tiny
+    operands (gradients late in training: 1e-6)."""
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    c = _blob(13, n=4000, extent=22)
+    rs = np.random.RandomState(ci * 7 + co)
+    xn = (rs.randn(len(c), ci) * scale).astype(np.float32)
+    gyn = (rs.randn(len(c), co) * scale).astype(np.float32)
+    wn = (rs.randn(27, ci, co) / 30).astype(np.float32)
+    x, gy, w = T(xn), T(gyn), T(wn)
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+    total = int(km["nboffs"][-1])
+    nb = km["nbmaps"][:total].cpu().numpy()
+    offs = km["nboffs"].cpu().numpy()
+    w64, x64, gy64 = wn.astype(np.float64), xn.astype(np.float64), gyn.astype(np.float64)
+    z_ref, zt_ref, gw_ref = np.zeros((total, co)), np.zeros((total, ci)), np.zeros((27, ci, co))
+    for k in range(27):
+        sl = slice(offs[k], offs[k + 1])
+        z_ref[sl] = x64[nb[sl, 0]] @ w64[k]
+        zt_ref[sl] = gy64[nb[sl, 1]] @ w64[k].T
+        gw_ref[k] = x64[nb[sl, 0]].T @ gy64[nb[sl, 1]]
+
+    def run():
+        z = B.conv_pair_gemm(x, w, km["nbmaps"], km["nboffs"], total, gather_col=0)
+        zt = B.conv_pair_gemm(gy, w, km["nbmaps"], km["nboffs"], total, gather_col=1, weight_transposed=True)
+        gw = B.conv_wgrad(x, gy, km["nbmaps"], km["nboffs"], 27, col_a=0, max_pairs=total)
+        return [t.cpu().numpy().astype(np.float64) for t in (z, zt, gw)]
+
+    split = run()
+    B.set_conv_impl(5)
+    try:
+        exact = run()
+    finally:
+        B.set_conv_impl(0)
+    for name, got, ref, want in zip(("z", "zt", "gw"), split, exact, (z_ref, zt_ref, gw_ref)):
+        s = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-6 * s, (name, np.abs(got - ref).max() / s)     # ~10 ulp of the scale
+        if True:
+            e_split, e_mfma = np.abs(got - want).max() / s, np.abs(ref - want).max() / s
+            print(f"{name} ci={ci} co={co} scale={scale:g}: max err / scale  split {e_split:.2e}  f32-mfma {e_mfma:.2e}")
+            assert e_split <= max(4 * e_mfma, 5e-7), (name, e_split, e_mfma)
 
 
 @pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 64), (128, 128), (384, 256), (256, 192), (32, 128)])
