@@ -70,19 +70,19 @@ __device__ __forceinline__ bf8 frag_tr(const unsigned short *img, int pitch, int
   } while (0)
 
 // X [*, R] fp32 rows; W = [K, R, O_total] (WT = false) or [K, O_total, R] (WT = true); Z [P, O_total] fp32
-template <int BN, int WR, bool WT>
-__global__ __launch_bounds__(256, 2) void pair_gemm_s_kernel(const float *__restrict__ X, int R,
+template <int BM, int BN, int WR, bool WT, bool XCD>
+__global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(const float *__restrict__ X, int R,
                                                           const float *__restrict__ W, int O_total,
                                                           const int2 *__restrict__ nbmaps,
                                                           const int *__restrict__ nboffs, int K, int gcol,
                                                           float *__restrict__ Z) {
   constexpr int WC = 4 / WR;
-  constexpr int MI = (PS_BM / 16) / WR;
+  constexpr int MI = (BM / 16) / WR;
   constexpr int NI = (BN / 16) / WC;
   constexpr int BP = BN + 8;                                   // pitch of a [k][col] weight plane
-  constexpr int A_PLANE = PS_BM * PS_AP;
+  constexpr int A_PLANE = BM * PS_AP;
   constexpr int B_PLANE = WT ? BN * PS_AP : PS_BK * BP;
-  constexpr int A_IT = PS_BM * (PS_BK / 8) / 256;              // 8-float chunks per thread per A slice (2)
+  constexpr int A_IT = BM * (PS_BK / 8) / 256;              // 8-float chunks per thread per A slice (2)
   constexpr int B_CHUNKS = BN * (PS_BK / 8);                   // 8-float chunks of a weight slice (either layout)
   constexpr int B_IT = (B_CHUNKS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_s[];
@@ -99,18 +99,21 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_s_kernel(const float *__rest
   // tile -> (offset k, first pair, rows), as in pair_gemm_fast_kernel
   const int offv = nboffs[min(lane, K)];
   const int offn = nboffs[min(lane + 1, K)];
-  int incl = lane < K ? (offn - offv + PS_BM - 1) / PS_BM : 0;
+  int incl = lane < K ? (offn - offv + BM - 1) / BM : 0;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int up = __shfl_up(incl, d, 64);
     if (lane >= d) incl += up;
   }
-  const int tile = blockIdx.x;
+  // workgroups go round-robin over the 8 XCDs (gridDim.x is a multiple of 8): XCD x takes the x-th eighth of the tile
+  // list, i.e. 3 - 4 consecutive offsets, so that its L2 holds the weight slices it multiplies with (27 W_k of a
+  // 256 x 256 layer are 7 MB, an XCD's L2 4 MB)
+  const int tile = XCD ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
   const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
   const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
-  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * PS_BM;
-  const int np = min(PS_BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
+  const int np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
 
   // A slots: 8-float chunk (tid & 3) of tile row (tid >> 2) + 64 it
   const int arow0 = tid >> 2, acol = (tid & 3) << 3;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_s_kernel(const float *__rest
     mma();
   }
   float *zt = Z + (int64_t)p0 * O_total + o0;
-  if (np == PS_BM) {
+  if (np == BM) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -235,27 +238,35 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_s_kernel(const float *__rest
   }
 }
 
-template <int BN, int WR, bool WT>
+template <int BM, int BN, int WR, bool WT>
 static int launch_pair_gemm_s(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
                               int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
-  const size_t lds = (size_t)3 * (PS_BM * PS_AP + (WT ? BN * PS_AP : PS_BK * (BN + 8))) * 2;
-  dim3 grid((unsigned)(ts_cdiv(P, PS_BM) + K), (unsigned)(O_total / BN));
-  pair_gemm_s_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
+  const size_t lds = (size_t)3 * (BM * PS_AP + (WT ? BN * PS_AP : PS_BK * (BN + 8))) * 2;
+  dim3 grid((unsigned)((ts_cdiv(P, BM) + K + 7) / 8 * 8), (unsigned)(O_total / BN));
+  if (g_ts_conv_impl == 8)    // tiles in launch order (A/B of the XCD remap)
+    pair_gemm_s_kernel<BM, BN, WR, WT, false><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
+  else
+    pair_gemm_s_kernel<BM, BN, WR, WT, true><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
   TS_CHECK_LAUNCH("conv_pair_gemm (split)");
   return TS_OK;
 }
 
-// called by ts_conv_pair_gemm for the full-tile shapes (R % 32 == 0, O_total % bn == 0, 16-byte aligned, K <= 63)
+// called by ts_conv_pair_gemm for the full-tile shapes (R % 32 == 0, O_total % bn == 0, 16-byte aligned, K <= 63).
+// Measured and NOT adopted (profiles/r01_v14_ab_tiles.txt): 64 x 64 tiles for the layers with few pairs (strides 8 / 16:
+// 4x the workgroups, 4 per CU) are 0 - 10 % slower than the 128-row tiles - those layers are bound by the bytes each
+// tile pulls through L2, not by latency or occupancy - and so is launch order vs the XCD-contiguous tile order
+// (+-3 %).  ts_set_conv_impl(6) selects the small tiles, (8) launch-order tiles.
 int ts_pair_gemm_split(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs, int K,
                        int64_t P, int gcol, float *Z, int bn, int wt, hipStream_t stream) {
-#define TS_PS(BN, WR)                                                                                   \
-  (wt ? launch_pair_gemm_s<BN, WR, true>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream)       \
-      : launch_pair_gemm_s<BN, WR, false>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream))
+#define TS_PS(BM, BN, WR)                                                                                   \
+  (wt ? launch_pair_gemm_s<BM, BN, WR, true>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream)       \
+      : launch_pair_gemm_s<BM, BN, WR, false>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream))
+  if (g_ts_conv_impl == 6 && O_total % 64 == 0) return TS_PS(64, 64, 2);
   switch (bn) {
-    case 32: return TS_PS(32, 4);
-    case 64: return TS_PS(64, 2);
-    case 96: return TS_PS(96, 2);
-    default: return TS_PS(128, 2);
+    case 32: return TS_PS(128, 32, 4);
+    case 64: return TS_PS(128, 64, 2);
+    case 96: return TS_PS(128, 96, 2);
+    default: return TS_PS(128, 128, 2);
   }
 #undef TS_PS
 }
