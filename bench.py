@@ -381,6 +381,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
+        from taseg_amd import rccl
+        rccl.shutdown()                  # library-owned SyncBatchNorm communicators
         dist.destroy_process_group()
 
 

@@ -364,6 +364,29 @@ int ts_bn_act_backward_f16(const void *grad_out, const uint8_t *mask, const void
                            double total_host, int64_t n, int32_t c, void *grad_x, void *grad_residual, void *ws,
                            size_t ws_bytes, ts_stream_t stream);
 
+/* SyncBatchNorm with the statistics all-reduce issued by the library on the CALLER'S stream (csrc/rccl.hip): RCCL is
+ * bound at run time with dlopen (ts_rccl_load: path of the librccl.so the host framework already uses), the library
+ * owns one communicator per SyncBatchNorm group (ts_rccl_unique_id on one rank, the 128-byte id distributed by the
+ * host, ts_rccl_comm_init collectively), and one call per direction runs local sliced sums -> ncclAllReduce of
+ * [2C + 1] / [2C] doubles -> elementwise pass.  Replaces nn.SyncBatchNorm (minkunet.py:23-25; torch/nn/modules/
+ * _functions.py SyncBatchNorm) whose collectives go through the process group's own stream.
+ * pack [2C + 1] / sums [2C]: double scratch; pack[2C] afterwards holds the global row count (= total_dev of the
+ * backward call).  half = 1: IEEE-half activations / gradients.  ws as ts_bn_train_workspace_bytes(c). */
+int ts_rccl_load(const char *librccl_path);
+int ts_rccl_unique_id(void *id128);
+int ts_rccl_comm_init(const void *id128, int32_t nranks, int32_t rank, void **comm);
+int ts_rccl_comm_destroy(void *comm);
+int ts_rccl_allreduce_f64(void *comm, double *buf, int64_t count, ts_stream_t stream);
+int ts_bn_sync_forward(void *comm, const void *x, const void *residual, const float *weight, const float *bias,
+                       float *running_mean, float *running_var, int64_t *num_batches_tracked, int64_t n, int32_t c,
+                       float eps, float momentum,
+                       int32_t relu, int32_t half, double *pack, float *mean, float *invstd, void *out, uint8_t *mask,
+                       void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_bn_sync_backward(void *comm, const void *grad_out, const uint8_t *mask, const void *x, const float *mean,
+                        const float *invstd, const float *weight, const double *total_dev, int64_t n, int32_t c,
+                        int32_t half, double *sums, void *grad_x, void *grad_residual, float *grad_weight,
+                        float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default; full-tile fp32 GEMMs run on the bf16 matrix
  * pipe through the exact three-way operand split of csrc/conv_pairs_s.hip), 5 = the same with v_mfma_f32_16x16x4_f32,
  * 1 = scalar reference kernels (one thread per output element, atomics),

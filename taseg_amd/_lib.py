@@ -76,6 +76,15 @@ SIGNATURES = {
     "ts_bn_sync_backward_reduce_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_bn_act_backward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_double, _i64, _i32, _vp, _vp, _vp, _sz,
                                       _vp]),
+    "ts_rccl_load": (_i32, [_c.c_char_p]),
+    "ts_rccl_unique_id": (_i32, [_vp]),
+    "ts_rccl_comm_init": (_i32, [_vp, _i32, _i32, _c.POINTER(_vp)]),
+    "ts_rccl_comm_destroy": (_i32, [_vp]),
+    "ts_rccl_allreduce_f64": (_i32, [_vp, _vp, _i64, _vp]),
+    "ts_bn_sync_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _i32, _i32, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_bn_sync_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _sz, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

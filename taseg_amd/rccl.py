@@ -1,0 +1,79 @@
+"""Library-owned RCCL communicators for SyncBatchNorm (csrc/rccl.hip).
+
+`direct_comm(group)` returns an opaque communicator handle over the ranks of a torch.distributed process group, or
+None when the direct path is unavailable (TASEG_RCCL_DIRECT=0, librccl.so not loadable, a failed self-test on any
+rank) - callers then fall back to `dist.all_reduce` on the group.  Creation is collective: every rank of the group
+reaches it at the same point (the first SyncBatchNorm forward of the first step).  The 128-byte RCCL id travels over
+the process group itself; before the communicator is trusted one all-reduce is checked against the group's own, and
+the ranks agree on the outcome, so either all of them use the direct path or none does.
+"""
+import ctypes
+import os
+import warnings
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+_comms = {}
+
+
+def _agree(ok, group, dev):
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+def _create(group):
+    lib = L.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ok = True
+    try:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        L.check(lib.ts_rccl_load(path.encode() if os.path.exists(path) else None), "ts_rccl_load")
+    except Exception as e:  # noqa: BLE001 - any failure means "use the process group instead"
+        warnings.warn(f"taseg_amd: direct RCCL path unavailable ({e}); SyncBatchNorm uses torch.distributed")
+        ok = False
+    if not _agree(ok, group, dev):
+        return None
+    rank, nranks = dist.get_rank(group), dist.get_world_size(group)
+    idbuf = (ctypes.c_ubyte * 128)()
+    if rank == 0:
+        L.check(lib.ts_rccl_unique_id(idbuf), "ts_rccl_unique_id")
+    idt = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=dev)
+    dist.broadcast(idt, src=dist.get_global_rank(group, 0), group=group)
+    idbytes = (ctypes.c_ubyte * 128)(*idt.cpu().tolist())
+    comm = ctypes.c_void_p()
+    rc = lib.ts_rccl_comm_init(idbytes, nranks, rank, ctypes.byref(comm))
+    ok = rc == 0 and bool(comm.value)
+    if ok:
+        # self-test against the process group's own all-reduce (sum of rank-dependent doubles)
+        t = torch.tensor([rank + 1.0, 1.0, 0.5 * rank], dtype=torch.float64, device=dev)
+        want = t.clone()
+        rc = lib.ts_rccl_allreduce_f64(comm, L.ptr(t), 3, L.stream())
+        dist.all_reduce(want, group=group)
+        ok = rc == 0 and torch.equal(t, want)
+    if not _agree(ok, group, dev):
+        if comm.value:
+            lib.ts_rccl_comm_destroy(comm)
+        warnings.warn("taseg_amd: direct RCCL communicator failed its self-test; SyncBatchNorm uses torch.distributed")
+        return None
+    return comm
+
+
+def direct_comm(group):
+    """Communicator handle (ctypes.c_void_p) for `group`, created on first use; None = use dist.all_reduce."""
+    key = id(group)
+    if key not in _comms:
+        _comms[key] = None if os.environ.get("TASEG_RCCL_DIRECT", "1") == "0" else _create(group)
+    return _comms[key]
+
+
+def shutdown():
+    """Destroy the communicators (call before dist.destroy_process_group())."""
+    lib = L.load()
+    for key, comm in list(_comms.items()):
+        if comm is not None and comm.value:
+            lib.ts_rccl_comm_destroy(comm)
+        del _comms[key]

@@ -9,6 +9,7 @@ import torch.distributed as dist
 from torch.autograd import Function
 
 from ... import _lib as L
+from ...rccl import direct_comm
 
 __all__ = ["batch_norm_train", "fast_path_ok"]
 
@@ -39,6 +40,7 @@ class _BatchNormActTrain(Function):
         mask = torch.empty(n * (c // per), dtype=torch.uint8, device=x.device) if relu else None
         total_dev = None
         ws = L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+        comm = None if group is None else direct_comm(group)
         if group is None:
             # single process: partial reductions, statistics and the elementwise pass in one backend call
             # (half storage: activations half in / out, statistics and arithmetic fp32 - what autocast does to batch_norm)
@@ -46,8 +48,19 @@ class _BatchNormActTrain(Function):
             L.check(fn(L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                        L.ptr(nbt), n, c, float(eps), float(momentum), 1 if relu else 0, L.ptr(mean), L.ptr(invstd),
                        L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream()), "ts_bn_act_train_forward" + sfx)
+        elif comm is not None:
+            # SyncBatchNorm, library-owned communicator: local sums -> ncclAllReduce([2C + 1] doubles) -> statistics ->
+            # elementwise pass, ONE backend call, everything in order on this stream (csrc/rccl.hip)
+            pack = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+            L.check(lib.ts_bn_sync_forward(comm, L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
+                                           L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), n, c, float(eps),
+                                           float(momentum), 1 if relu else 0, 1 if half else 0, L.ptr(pack), L.ptr(mean),
+                                           L.ptr(invstd), L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream()),
+                    "ts_bn_sync_forward")
+            total_dev = pack[2 * c:]
         else:
-            # SyncBatchNorm: local sums -> ONE all-reduce of [2C + 1] doubles -> statistics + elementwise pass
+            # SyncBatchNorm through the process group: local sums -> ONE all-reduce of [2C + 1] doubles -> statistics +
+            # elementwise pass
             if nbt is not None:
                 nbt.add_(1)
             pack = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
@@ -63,7 +76,7 @@ class _BatchNormActTrain(Function):
                                                             L.ptr(out), L.ptr(mask), L.stream()),
                     "ts_bn_act_forward" + sfx)
         ctx.save_for_backward(x, weight, mean, invstd, mask)
-        ctx.group, ctx.total_dev, ctx.has_res, ctx.half = group, total_dev, residual is not None, half
+        ctx.group, ctx.total_dev, ctx.has_res, ctx.half, ctx.comm = group, total_dev, residual is not None, half, comm
         return out
 
     @staticmethod
@@ -82,6 +95,12 @@ class _BatchNormActTrain(Function):
                 L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd), L.ptr(weight), n, c, L.ptr(grad_x),
                 L.ptr(grad_res), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()),
                 "ts_bn_act_train_backward" + sfx)
+        elif ctx.comm is not None:
+            sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
+            L.check(lib.ts_bn_sync_backward(ctx.comm, L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                            L.ptr(weight), L.ptr(ctx.total_dev), n, c, 1 if ctx.half else 0, L.ptr(sums),
+                                            L.ptr(grad_x), L.ptr(grad_res), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws),
+                                            ws.numel(), L.stream()), "ts_bn_sync_backward")
         else:
             sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
             L.check(getattr(lib, "ts_bn_sync_backward_reduce" + sfx)(

@@ -158,17 +158,28 @@ x = torch.randn(n, c, generator=g).cuda().requires_grad_()
 res = torch.randn(n, c, generator=g).cuda().requires_grad_()
 w = (torch.rand(c, generator=g) + 0.5).cuda().requires_grad_()
 b = torch.randn(c, generator=g).cuda().requires_grad_()
+from taseg_amd import rccl
+comm = rccl.direct_comm(dist.group.WORLD)
+assert comm is not None and comm.value, "library-owned RCCL communicator was not created"
 for dtype, tol in ((torch.float32, 2e-4), (torch.float16, 2e-2)):      # fp32 and half-storage activations
     outs = []
-    for group in (None, dist.group.WORLD):
+    # single process | SyncBN with the library's own communicator (csrc/rccl.hip) | SyncBN through the process group
+    for group, direct in ((None, True), (dist.group.WORLD, True), (dist.group.WORLD, False)):
+        rccl._comms[id(dist.group.WORLD)] = comm if direct else None
         xi, ri = x.detach().to(dtype).requires_grad_(), res.detach().to(dtype).requires_grad_()
         rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
-        y = batch_norm_act_train(xi, w, b, rm, rv, 0.1, 1e-5, relu=True, residual=ri, group=group)
-        assert y.dtype == dtype
+        nbt = torch.zeros((), dtype=torch.int64).cuda()
+        y = batch_norm_act_train(xi, w, b, rm, rv, 0.1, 1e-5, relu=True, residual=ri, group=group,
+                                 num_batches_tracked=nbt)
+        assert y.dtype == dtype and int(nbt) == 1
         gx, gr, gw, gb = torch.autograd.grad((y.float() * y.float()).sum(), (xi, ri, w, b))
         outs.append([t.detach().float().cpu() for t in (y, gx, gr, gw, gb, rm, rv)])
-    for a, bb in zip(*outs):
-        assert torch.allclose(a, bb, rtol=tol, atol=tol), (dtype, float((a - bb).abs().max()))
+    for other in outs[1:]:
+        for a, bb in zip(outs[0], other):
+            assert torch.allclose(a, bb, rtol=tol, atol=tol), (dtype, float((a - bb).abs().max()))
+    for a, bb in zip(outs[1], outs[2]):          # the two transports run the same kernels: identical results
+        assert torch.equal(a, bb)
+rccl._comms[id(dist.group.WORLD)] = comm
 # one DDP + SyncBatchNorm training step of the segmentor
 from taseg_amd.data.synthetic import make_model_cfg, synth_scan
 from taseg_amd.pcseg.model import build_network
@@ -186,6 +197,7 @@ bd = {"lidar": SparseTensor(torch.from_numpy(pts[idx]).cuda(), coords),
 ret, _, _ = net(bd)
 ret["loss"].mean().backward()
 assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+rccl.shutdown()
 dist.destroy_process_group()
 print("SYNC_OK")
 '''
