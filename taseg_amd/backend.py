@@ -275,7 +275,7 @@ def pair_gemm_kernel_name(c_out, weight_transposed=False, c_red=None):
     bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (96, 2) if c_out % 96 == 0 else (128, 2)
     fast = c_red is not None and c_red % 32 == 0 and c_out % bn == 0
     if fast and _conv_impl == 0:
-        return f"pair_gemm_s_kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
+        return f"pair_gemm_s_kernel<128,{bn},{wr},{'true' if weight_transposed else 'false'},true>"
     kind = "" if not fast else ("fast_" if weight_transposed else "persist_")
     return f"pair_gemm_{kind}kernel<{bn},{wr},{'true' if weight_transposed else 'false'}>"
 
