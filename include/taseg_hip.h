@@ -387,6 +387,28 @@ int ts_bn_sync_backward(void *comm, const void *grad_out, const uint8_t *mask, c
                         int32_t half, double *sums, void *grad_x, void *grad_residual, float *grad_weight,
                         float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
 
+/* One call per direction for conv -> BatchNorm(train) [+ residual] [-> ReLU], the unit of the MinkUNet family
+ * (minkunet.py:31-129: BasicConvolutionBlock, BasicDeconvolutionBlock, the two halves of ResidualBlock).  Chains the
+ * launches of ts_conv_pair_gemm / ts_conv_gather_sum (or the _f16 forms, half = 1) and ts_bn_act_train_* (comm == NULL)
+ * or ts_bn_sync_* (comm = a ts_rccl_comm_init communicator) on `stream`; Z, the gradient w.r.t. the convolution output
+ * and the transposed half weight live in `ws` (ts_conv_block_workspace_bytes).  Arguments: csrc/block.hip. */
+size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
+                                     int32_t half);
+int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
+                          const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
+                          const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight,
+                          const float *bn_bias, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                          float eps, float momentum, int32_t relu, int32_t half, void *comm, double *pack, void *conv_out,
+                          float *mean, float *invstd, void *out, uint8_t *mask, void *w16, void *ws, size_t ws_bytes,
+                          ts_stream_t stream);
+int ts_conv_block_backward(const void *grad_out, const uint8_t *mask, const void *conv_out, const float *mean,
+                           const float *invstd, const float *bn_weight, const double *total_dev, void *comm, double *sums,
+                           int64_t n_out, int32_t c_out, int32_t half, const void *feat, int64_t n_feat_rows, int32_t c_in,
+                           const void *weights, int32_t K, const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs,
+                           int32_t dgrad_gather_col, const int32_t *pos_dgrad, int64_t n_dgrad_rows, int32_t wgrad_col_a,
+                           void *grad_feat, void *grad_residual, float *grad_kernel, float *grad_bn_weight,
+                           float *grad_bn_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default; full-tile fp32 GEMMs run on the bf16 matrix
  * pipe through the exact three-way operand split of csrc/conv_pairs_s.hip), 5 = the same with v_mfma_f32_16x16x4_f32,
  * 1 = scalar reference kernels (one thread per output element, atomics),

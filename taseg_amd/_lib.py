@@ -85,6 +85,12 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_bn_sync_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _sz, _vp]),
+    "ts_conv_block_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    "ts_conv_block_forward": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _sz, _vp]),
+    "ts_conv_block_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp,
+                                      _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

@@ -1,0 +1,145 @@
+// One host call per direction for the unit the MinkUNet family is made of: sparse conv -> BatchNorm (training mode)
+// [+ residual] [-> ReLU]   (reference: BasicConvolutionBlock / BasicDeconvolutionBlock / ResidualBlock,
+// R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:31-129; per block the reference dispatches conv3d, BatchNorm1d /
+// SyncBatchNorm, the shortcut add and ReLU as separate autograd nodes and ~10 launches with a host synchronisation).
+//
+// No new arithmetic: the entry points chain the launches of ts_conv_pair_gemm / ts_conv_gather_sum /
+// ts_bn_act_train_* (or their half-storage and SyncBatchNorm forms) on the caller's stream and place the
+// intermediates that never leave the call (Z, the BatchNorm input gradient, the transposed half weight) in the
+// caller's workspace.  What they remove is host work: the step of a 2-scan batch is ~1200 launches, and with one
+// Python -> C crossing and one autograd node per block instead of four / two the host side of the step drops below
+// the device side on slow hosts too.
+#include "common.h"
+
+static inline size_t blk_align(size_t x) { return ts_align_up(x, 256); }
+
+// scratch for either direction of one block (bytes); esize = 2 for half storage
+extern "C" size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out,
+                                                int32_t K, int32_t half) {
+  const size_t es = half ? 2 : 4;
+  const size_t cmax = (size_t)std::max(c_in, c_out);
+  size_t total = blk_align((size_t)n_pairs * cmax * es);            // Z (forward: c_out wide, backward: c_in wide)
+  total += blk_align((size_t)n_rows_max * cmax * es);               // gradient w.r.t. the convolution output
+  if (half) total += blk_align((size_t)K * c_in * c_out * 2);       // W16T of the forward pass
+  total += blk_align(ts_bn_train_workspace_bytes(std::max(c_in, c_out)));
+  return total;
+}
+
+#define TS_TRY(expr)              \
+  do {                            \
+    const int rc_ = (expr);       \
+    if (rc_ != TS_OK) return rc_; \
+  } while (0)
+
+// out = act(BN(conv(feat)) [+ residual]).
+//   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
+//   `gather_col` and the position table pos [K, n_out] of the rows being produced (pos_out, or pos_in for a transposed
+//   convolution); conv_out [n_out, c_out] is kept for the backward pass (BatchNorm input), as are mean / invstd / mask
+//   and - half storage - w16 [K, c_in, c_out].  comm != NULL: SyncBatchNorm on that communicator (pack [2 c_out + 1]
+//   doubles; pack[2 c_out] = global row count afterwards).
+extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
+                                     const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
+                                     const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual,
+                                     const float *bn_weight, const float *bn_bias, float *running_mean,
+                                     float *running_var, int64_t *num_batches_tracked, float eps, float momentum,
+                                     int32_t relu, int32_t half, void *comm, double *pack, void *conv_out, float *mean,
+                                     float *invstd, void *out, uint8_t *mask, void *w16, void *ws, size_t ws_bytes,
+                                     ts_stream_t stream) {
+  TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_forward: bad sizes");
+  TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_forward: workspace too small");
+  TS_REQUIRE(!half || w16, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_forward: half storage needs the w16 buffer");
+  const size_t es = half ? 2 : 4;
+  const size_t cmax = (size_t)std::max(c_in, c_out);
+  char *p = (char *)ws;
+  void *z = p;
+  p += blk_align((size_t)n_pairs * cmax * es);
+  p += blk_align((size_t)n_out * cmax * es);
+  void *w16t = nullptr;
+  if (half) {
+    w16t = p;
+    p += blk_align((size_t)K * c_in * c_out * 2);
+  }
+  void *bn_ws = p;
+  const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+  if (half) {
+    TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, w16t, stream));
+    TS_TRY(ts_conv_pair_gemm_f16(feat, n_feat_rows, c_in, w16t, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
+    TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
+  } else {
+    TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
+                             (float *)z, c_out, stream));
+    TS_TRY(ts_conv_gather_sum((const float *)z, c_out, pos, K, n_out, n_pairs, (float *)conv_out, stream));
+  }
+  if (comm)
+    return ts_bn_sync_forward(comm, conv_out, residual, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked,
+                              n_out, c_out, eps, momentum, relu, half, pack, mean, invstd, out, mask, bn_ws, bn_ws_bytes,
+                              stream);
+  if (half)
+    return ts_bn_act_train_forward_f16(conv_out, residual, bn_weight, bn_bias, running_mean, running_var,
+                                       num_batches_tracked, n_out, c_out, eps, momentum, relu, mean, invstd, out, mask,
+                                       bn_ws, bn_ws_bytes, stream);
+  return ts_bn_act_train_forward((const float *)conv_out, (const float *)residual, bn_weight, bn_bias, running_mean,
+                                 running_var, num_batches_tracked, n_out, c_out, eps, momentum, relu, mean, invstd,
+                                 (float *)out, mask, bn_ws, bn_ws_bytes, stream);
+}
+
+// Backward of ts_conv_block_forward.  weights = the fp32 kernel, or (half storage) the w16 buffer the forward filled.
+// dgrad_gather_col / pos_dgrad [K, n_dgrad_rows] / wgrad_col_a select the rulebook columns exactly like
+// torchsparse's ConvolutionFunction.backward (conv.py:72-119; transposed swaps them).  grad_feat may be NULL (first
+// layer).  grad_residual (may be NULL) receives the masked output gradient.
+extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask, const void *conv_out, const float *mean,
+                                      const float *invstd, const float *bn_weight, const double *total_dev, void *comm,
+                                      double *sums, int64_t n_out, int32_t c_out, int32_t half, const void *feat,
+                                      int64_t n_feat_rows, int32_t c_in, const void *weights, int32_t K,
+                                      const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs,
+                                      int32_t dgrad_gather_col, const int32_t *pos_dgrad, int64_t n_dgrad_rows,
+                                      int32_t wgrad_col_a, void *grad_feat, void *grad_residual, float *grad_kernel,
+                                      float *grad_bn_weight, float *grad_bn_bias, void *ws, size_t ws_bytes,
+                                      ts_stream_t stream) {
+  TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_backward: bad sizes");
+  TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_backward: workspace too small");
+  const size_t es = half ? 2 : 4;
+  const size_t cmax = (size_t)std::max(c_in, c_out);
+  char *p = (char *)ws;
+  void *z = p;
+  p += blk_align((size_t)n_pairs * cmax * es);
+  void *grad_conv = p;
+  p += blk_align((size_t)n_out * cmax * es);
+  if (half) p += blk_align((size_t)K * c_in * c_out * 2);
+  void *bn_ws = p;
+  const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+  if (comm) {
+    TS_TRY(ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums,
+                               grad_conv, grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));
+  } else if (half) {
+    TS_TRY(ts_bn_act_train_backward_f16(grad_out, mask, conv_out, mean, invstd, bn_weight, n_out, c_out, grad_conv,
+                                        grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));
+  } else {
+    TS_TRY(ts_bn_act_train_backward((const float *)grad_out, mask, (const float *)conv_out, mean, invstd, bn_weight, n_out,
+                                    c_out, (float *)grad_conv, (float *)grad_residual, grad_bn_weight, grad_bn_bias, bn_ws,
+                                    bn_ws_bytes, stream));
+  }
+  if (half) {
+    if (grad_feat) {
+      TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
+                                   stream));
+      TS_TRY(ts_conv_gather_sum_f16(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, stream));
+    }
+    if (grad_kernel)
+      TS_TRY(ts_conv_wgrad_f16(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel, stream));
+  } else {
+    if (grad_feat) {
+      TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs,
+                               n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
+      TS_TRY(ts_conv_gather_sum((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat, stream));
+    }
+    if (grad_kernel)
+      TS_TRY(ts_conv_wgrad((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a,
+                           n_pairs, grad_kernel, stream));
+  }
+  return TS_OK;
+}

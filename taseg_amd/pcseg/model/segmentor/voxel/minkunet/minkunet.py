@@ -45,7 +45,7 @@ class BasicConvolutionBlock(nn.Module):
         )
 
     def forward(self, x):
-        return spnn.bn_act(self.net[1], self.net[0](x), relu=True)      # conv -> fused BN + ReLU
+        return spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True)      # conv -> BN -> ReLU, one node
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -60,7 +60,7 @@ class BasicDeconvolutionBlock(nn.Module):
         )
 
     def forward(self, x):
-        return spnn.bn_act(self.net[1], self.net[0](x), relu=True)
+        return spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True)
 
 
 def _shortcut(inc, outc, stride, if_dist):
@@ -87,10 +87,9 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         # relu(net(x) + downsample(x)) with the BN / add / ReLU tails fused (same module parameters / buffers)
-        h = spnn.bn_act(self.net[1], self.net[0](x), relu=True)
-        y = self.net[3](h)
+        h = spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True)
         shortcut = x if isinstance(self.downsample, nn.Identity) else self.downsample(x)
-        return spnn.bn_act(self.net[4], y, relu=True, residual=shortcut)
+        return spnn.conv_bn_act(self.net[3], self.net[4], h, relu=True, residual=shortcut)
 
 
 class Bottleneck(nn.Module):
@@ -262,8 +261,8 @@ class MinkUNetBackbone(BaseSegmentor):
         if "vox_idx" in plan:
             z.additional_features["idx_query"][1] = plan["vox_idx"]
             z.additional_features["counts"][1] = plan["vox_counts"]
-        x0 = spnn.bn_act(self.stem[1], self.stem[0](x0), relu=True)          # stem = 2 x (conv, BN, ReLU)
-        x0 = spnn.bn_act(self.stem[4], self.stem[3](x0), relu=True)
+        x0 = spnn.conv_bn_act(self.stem[0], self.stem[1], x0, relu=True)          # stem = 2 x (conv, BN, ReLU)
+        x0 = spnn.conv_bn_act(self.stem[3], self.stem[4], x0, relu=True)
         z0 = voxel_to_point(x0, z, nearest=False)
 
         x1 = self.stage1(x0)

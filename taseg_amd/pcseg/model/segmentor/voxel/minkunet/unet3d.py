@@ -55,8 +55,8 @@ class UNet3D(nn.Module):
         z = PointTensor(x.F, x.C.float())
         x = SparseTensor(x.F, x.C, x.s)                       # fresh caches: the FOV cloud has its own rulebooks
         spF.build_pyramid(x, num_levels=4)
-        x0 = spnn.bn_act(self.stem[1], self.stem[0](x), relu=True)
-        x0 = spnn.bn_act(self.stem[4], self.stem[3](x0), relu=True)
+        x0 = spnn.conv_bn_act(self.stem[0], self.stem[1], x, relu=True)
+        x0 = spnn.conv_bn_act(self.stem[3], self.stem[4], x0, relu=True)
         z0 = voxel_to_point(x0, z, nearest=False)
         x1 = self.stage1(x0)
         x2 = self.stage2(x1)

@@ -21,7 +21,7 @@ from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from .utils import get_kernel_offsets
 
-__all__ = ["conv3d", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
+__all__ = ["conv3d", "conv_geometry", "conv_block_ok", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
            "spdownsample", "KernelMap", "build_kernel_map", "build_pyramid", "point_linear"]
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -446,7 +446,19 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optiona
             out_feats = _PointwiseConv.apply(input.feats, weight, _identity_rulebook(input))
         else:
             out_feats = input.feats.matmul(weight)   # plain dense GEMM -> rocBLAS/hipBLASLt
-    elif not transposed:
+    else:
+        kmap, out_coords, out_stride = conv_geometry(input, kernel_size, stride, dilation, transposed)
+        out_feats = _SparseConv.apply(input.feats, weight, kmap, transposed)
+    if bias is not None:
+        out_feats = out_feats + bias
+    return _conv_output(input, out_feats, out_coords, out_stride)
+
+
+def conv_geometry(input: SparseTensor, kernel_size, stride, dilation, transposed):
+    """Coordinate / kernel-map protocol of conv3d (conv.py:144-199) for a kernel larger than 1x1x1: returns
+    (kernel map, output coordinates, output stride), creating and caching `cmaps` / `kmaps` entries like the reference."""
+    ones = (1, 1, 1)
+    if not transposed:
         out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
         if out_stride in input.cmaps:
             out_coords = input.cmaps[out_stride]
@@ -457,17 +469,104 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optiona
         key = (input.stride, kernel_size, stride, dilation)
         if key not in input.kmaps:
             input.kmaps[key] = build_kernel_map(input.coords, out_coords, kernel_size, input.stride, dilation)
-        out_feats = _SparseConv.apply(input.feats, weight, input.kmaps[key], False)
-    else:
-        out_stride = tuple(input.stride[k] // stride[k] for k in range(3))
-        out_coords = input.cmaps[out_stride]
-        out_feats = _SparseConv.apply(input.feats, weight, input.kmaps[(out_stride, kernel_size, stride, dilation)],
-                                      True)
-    if bias is not None:
-        out_feats = out_feats + bias
+        return input.kmaps[key], out_coords, out_stride
+    out_stride = tuple(input.stride[k] // stride[k] for k in range(3))
+    return input.kmaps[(out_stride, kernel_size, stride, dilation)], input.cmaps[out_stride], out_stride
 
+
+def _conv_output(input: SparseTensor, out_feats, out_coords, out_stride) -> SparseTensor:
     output = SparseTensor(coords=out_coords, feats=out_feats, stride=out_stride)
     output.cmaps = input.cmaps
     output.cmaps.setdefault(out_stride, out_coords)
     output.kmaps = input.kmaps
     return output
+
+
+class _ConvBlock(Function):
+    """act(BN(conv(x)) [+ residual]) in training mode as ONE autograd node and one backend call per direction
+    (csrc/block.hip).  Same launches and arithmetic as `_SparseConv` followed by `_BatchNormActTrain`; Z, the gradient
+    w.r.t. the convolution output and the transposed half weight live in the per-stream workspace."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half):
+        running_mean, running_var, nbt, momentum, eps = bn_state
+        lib = B.L.load()
+        L = B.L
+        n_in, n_out = kmap.sizes
+        k, c_in, c_out = weight.shape
+        gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
+        dt = torch.float16 if half else torch.float32
+        x = feats.contiguous().to(dt)
+        w32 = weight.detach().contiguous().float()
+        res = None if residual is None else residual.contiguous().to(dt)
+        dev = x.device
+        conv_out = torch.empty((rows, c_out), dtype=dt, device=dev)
+        out = torch.empty((rows, c_out), dtype=dt, device=dev)
+        stats = torch.empty((2, c_out), dtype=torch.float32, device=dev)
+        mask = torch.empty(rows * (c_out // (8 if half else 4)), dtype=torch.uint8, device=dev) if relu else None
+        w16 = torch.empty((k, c_in, c_out), dtype=torch.float16, device=dev) if half else None
+        pack = torch.empty(2 * c_out + 1, dtype=torch.float64, device=dev) if comm is not None else None
+        total = kmap.total
+        ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+        L.check(lib.ts_conv_block_forward(
+            L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol,
+            L.ptr(table), rows, c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
+            L.ptr(running_var), L.ptr(nbt), float(eps), float(momentum), 1 if relu else 0, 1 if half else 0, comm,
+            L.ptr(pack), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(out), L.ptr(mask), L.ptr(w16), L.ptr(ws),
+            ws.numel(), L.stream()), "ts_conv_block_forward")
+        ctx.save_for_backward(x, w16 if half else w32, conv_out, stats, mask, bn_weight)
+        ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
+        ctx.total_dev = None if pack is None else pack[2 * c_out:]
+        ctx.in_dtype, ctx.res_dtype = feats.dtype, (None if residual is None else residual.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, conv_out, stats, mask, bn_weight = ctx.saved_tensors
+        kmap, transposed, half, comm = ctx.kmap, ctx.transposed, ctx.half, ctx.comm
+        lib = B.L.load()
+        L = B.L
+        n_in, n_out = kmap.sizes
+        k, c_in, c_out = w.shape
+        rows = conv_out.shape[0]
+        dt = conv_out.dtype
+        dev = x.device
+        g = grad_out.contiguous().to(dt)
+        gcol = 0 if transposed else 1
+        table, drows = (kmap.pos_in, n_in) if not transposed else (kmap.pos_out, n_out)
+        need = ctx.needs_input_grad
+        grad_feat = torch.empty((drows, c_in), dtype=dt, device=dev) if need[0] else None
+        grad_w = torch.empty((k, c_in, c_out), dtype=torch.float32, device=dev) if need[1] else None
+        grad_res = torch.empty_like(conv_out) if (ctx.res_dtype is not None and need[2]) else None
+        gwb = torch.empty((2, c_out), dtype=torch.float32, device=dev)
+        sums = torch.empty((2, c_out), dtype=torch.float64, device=dev) if comm is not None else None
+        total = kmap.total
+        ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+        L.check(lib.ts_conv_block_backward(
+            L.ptr(g), L.ptr(mask), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn_weight),
+            L.ptr(ctx.total_dev), comm, L.ptr(sums), rows, c_out, 1 if half else 0, L.ptr(x), x.shape[0], c_in, L.ptr(w), k,
+            L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), drows, 1 if transposed else 0,
+            L.ptr(grad_feat), L.ptr(grad_res), L.ptr(grad_w), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(),
+            L.stream()), "ts_conv_block_backward")
+        if grad_feat is not None and grad_feat.dtype != ctx.in_dtype:
+            grad_feat = grad_feat.to(ctx.in_dtype)
+        if grad_res is not None and grad_res.dtype != ctx.res_dtype:
+            grad_res = grad_res.to(ctx.res_dtype)
+        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None
+
+
+def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", residual, rows: int) -> bool:
+    """Can `_ConvBlock` serve this convolution + training BatchNorm?  (else: conv3d followed by bn_act)"""
+    if not (feats.is_cuda and weight.dim() == 3 and feats.dim() == 2 and torch.is_grad_enabled()):
+        return False
+    half = _amp_half(feats)
+    c_in, c_out = weight.shape[1], weight.shape[2]
+    if half and not (_half_ok(c_in, c_out)):
+        return False
+    if not half and feats.dtype != torch.float32:
+        return False
+    if c_out % (8 if half else 4) != 0 or c_out > 1024 or rows <= 0 or kmap.total <= 0 or weight.shape[0] > 63:
+        return False
+    if feats.shape[1] != c_in:
+        return False
+    return residual is None or tuple(residual.shape) == (rows, c_out)

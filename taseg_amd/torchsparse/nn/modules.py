@@ -1,5 +1,6 @@
 """`torchsparse.nn` modules (TS/torchsparse/nn/modules/{conv,norm,activation}.py)."""
 import math
+import os
 
 import torch
 from torch import nn
@@ -7,9 +8,13 @@ from torch import nn
 from ..tensor import SparseTensor
 from ..utils.misc import make_ntuple
 from . import functional as F
+from ... import backend as _B
 from .utils import fapply
 
-__all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act"]
+__all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act", "conv_bn_act"]
+
+
+_FUSED_BLOCK = os.environ.get("TASEG_FUSED_BLOCK", "1") != "0"
 
 
 class Conv3d(nn.Module):
@@ -104,6 +109,36 @@ def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor =
     if relu:
         out = torch.relu(out)
     return input._like(out)
+
+
+def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None) -> SparseTensor:
+    """relu(BN(conv(input)) [+ residual]) for a Conv3d and its BatchNorm / SyncBatchNorm module: one autograd node and
+    one backend call per direction when the block trains on the HIP path (functional._ConvBlock); otherwise exactly
+    `bn_act(mod, conv(input), relu, residual)`.  TASEG_FUSED_BLOCK=0 always takes the second form."""
+    from ...rccl import direct_comm
+    from .batchnorm import fast_path_ok  # noqa: F401  (same shape rules as the BatchNorm fast path)
+    ones = (1, 1, 1)
+    ks, stride = conv.kernel_size, conv.stride
+    dil = make_ntuple(conv.dilation, ndim=3)
+    if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and mod.momentum is not None and mod.affine \
+            and not (conv._forward_hooks or conv._forward_pre_hooks) and _B._prof is None:
+        # (hooks on the conv module must still fire; bench.py's per-launch events live in the unfused wrappers)
+        group = _sync_group(mod)
+        comm = None if group is None else direct_comm(group)
+        if group is None or comm is not None:
+            kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)
+            n_in, n_out = kmap.sizes
+            rows = n_in if conv.transposed else n_out
+            res = None if residual is None else residual.feats
+            feats = input.feats
+            if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
+                track = mod.track_running_stats
+                state = (mod.running_mean if track else None, mod.running_var if track else None,
+                         mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
+                out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state, relu,
+                                         comm, F._amp_half(feats))
+                return F._conv_output(input, out, out_coords, out_stride)
+    return bn_act(mod, conv(input), relu=relu, residual=residual)
 
 
 class BatchNorm(nn.BatchNorm1d):
