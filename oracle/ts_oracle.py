@@ -319,3 +319,17 @@ def image_gather(feat, pix, pbatch, frame_end, shift=0):
         outs.append(tall[p[:, 0] >> shift, p[:, 1] >> shift])
         start = end
     return np.concatenate(outs, 0)
+
+
+# --------------------------------------------------------------------------- evaluation metrics
+def fast_hist(pred, label, n):
+    """R/train.py:35-40: confusion matrix (rows = label, columns = prediction) over the labels inside [0, n)."""
+    pred, label = np.asarray(pred).reshape(-1), np.asarray(label).reshape(-1)
+    keep = (label >= 0) & (label < n)
+    return np.bincount(n * label[keep].astype(np.int64) + pred[keep].astype(np.int64), minlength=n * n)[:n * n].reshape(n, n)
+
+
+def per_class_iu(hist):
+    """R/train.py:43-44."""
+    hist = np.asarray(hist, dtype=np.float64)
+    return np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist) + 1e-9)

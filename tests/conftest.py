@@ -40,6 +40,11 @@ def g_minkunet():
 
 
 @pytest.fixture(scope="session")
+def g_miou():
+    return _load("miou_minkunet.npz")
+
+
+@pytest.fixture(scope="session")
 def g_minkunet_ms():
     return _load("model_minkunet_ms.npz")
 

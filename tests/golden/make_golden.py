@@ -468,8 +468,77 @@ def gen_multiscan():
           out["batch_lidar_ms_C"].shape)
 
 
+# ----------------------------------------------------------------------------------------- mIoU parity
+MIOU_SEEDS = list(range(5000, 5200))
+
+
+def gen_miou(fname="miou_minkunet.npz"):
+    """SURVEY 8(d) parity gate "mIoU parity": the reference MinkUNet (tiny, parameters fill_parameters(seed=3), BatchNorm
+    on its running statistics) predicts 200 seeded synthetic scans one by one; stored are the per-voxel arg-max
+    classes, the confusion matrix and the per-class IoU computed with the reference's own `fast_hist` / `per_class_iu`
+    definitions (R/train.py:35-45, restated here on numpy: the trainer module itself is not importable)."""
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
+    torch.manual_seed(0)
+    model = MinkUNet(cfg, 20)
+    fill_parameters(model, seed=3)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    captured = {}
+
+    def grab(_m, inputs, output):
+        captured["logits"], captured["feat"] = output, inputs[0]
+
+    model.classifier.register_forward_hook(grab)
+    # seeded random weights put one class ahead everywhere (the mean feature dominates every logit): re-centre the
+    # classifier on the mean point feature of the first scan and scale it up, so that the arg-max depends on what the
+    # network computes per voxel.  The adjusted head travels in the fixture.
+    batch, _ = make_batch([MIOU_SEEDS[0]])
+    lidar = batch["lidar"]
+    lidar.F, lidar.C = lidar.F.float(), lidar.C.int()
+    with torch.no_grad():
+        model({"lidar": lidar, "targets": batch["targets"], "offset": torch.tensor([0])})
+        mu = captured["feat"].mean(0)
+        w = model.classifier[0].weight
+        w -= torch.outer(w @ mu, mu) / (mu @ mu)
+        w *= 8.0 / float((captured["feat"] @ w.t()).std())
+        model.classifier[0].bias.zero_()
+    head_w, head_b = model.classifier[0].weight.detach().numpy().copy(), model.classifier[0].bias.detach().numpy().copy()
+    preds, counts, margins = [], [], []
+    hist = np.zeros((20, 20), dtype=np.int64)
+    for s in MIOU_SEEDS:
+        batch, raw = make_batch([s])
+        lidar = batch["lidar"]
+        lidar.F = lidar.F.float()
+        lidar.C = lidar.C.int()
+        with torch.no_grad():
+            model({"lidar": lidar, "targets": batch["targets"], "offset": torch.tensor([0])})
+        logits = captured["logits"].numpy()
+        pred = logits.argmax(1)
+        top2 = np.sort(logits, axis=1)[:, -2:]
+        margins.append((top2[:, 1] - top2[:, 0]).astype(np.float32))
+        lab = batch["targets"].F.numpy().astype(np.int64)
+        k = (lab >= 0) & (lab < 20)
+        hist += np.bincount(20 * lab[k] + pred[k], minlength=400).reshape(20, 20)
+        preds.append(pred.astype(np.uint8))
+        counts.append(len(pred))
+    iou = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist) + 1e-9)
+    np.savez_compressed(os.path.join(HERE, fname), backend=np.array(BACKEND_DESC), seeds=np.array(MIOU_SEEDS),
+                        counts=np.array(counts), pred=np.concatenate(preds), hist=hist, iou=iou, head_weight=head_w,
+                        head_bias=head_b, margin_quantiles=np.quantile(np.concatenate(margins), [0, 1e-4, 1e-3, 1e-2, 0.5]))
+    print(fname, "scans", len(MIOU_SEEDS), "voxels", int(np.sum(counts)), "mIoU over present classes",
+          float(iou[hist.sum(1) > 0].mean()))
+
+
 if __name__ == "__main__":
     print("reference backend:", BACKEND_DESC)
+    if "--only-miou" in sys.argv:
+        gen_miou()
+        sys.exit(0)
     if "--only-mm" in sys.argv:
         gen_model_mm()
         sys.exit(0)
@@ -482,6 +551,7 @@ if __name__ == "__main__":
     gen_multiscan()
     gen_model_mm()
     gen_model_kd()
+    gen_miou()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -260,3 +260,56 @@ def test_prefetched_batches_train_like_inline_ones():
     print(f"prefetch: losses {la} / {lb}; weights rel L2 inline-vs-inline {noise:.2e}, inline-vs-prefetched {diff:.2e}")
     assert np.allclose(la, lb, rtol=0, atol=max(1e-5, 10 * float(np.abs(np.array(la) - np.array(la2)).max())))
     assert diff <= max(1e-4, 10 * noise), (diff, noise)
+
+
+def test_miou_parity_200_scans(g_miou):
+    """mIoU parity gate of SURVEY 8(d): 200 seeded synthetic scans, identical weights - the HIP model's per-voxel arg-max
+    against the REAL reference's (golden: reference MinkUNet run scan by scan on the CPU; here 8 scans per batch through
+    the HIP kernels), agreement >= 99.9 %, and the confusion matrix / per-class IoU by the reference's definitions."""
+    from taseg_amd import metrics
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=3)
+    with torch.no_grad():
+        model.classifier[0].weight.copy_(torch.from_numpy(g_miou["head_weight"]))
+        model.classifier[0].bias.copy_(torch.from_numpy(g_miou["head_bias"]))
+    model = model.cuda().train()             # training branch (no un-voxelisation) ...
+    for m in model.modules():
+        if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Dropout)):
+            m.eval()                         # ... on running statistics, no dropout
+    grabbed = {}
+    model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o))
+    seeds = g_miou["seeds"].tolist()
+    hist = torch.zeros((20, 20), dtype=torch.int64, device="cuda")
+    preds = []
+    for b0 in range(0, len(seeds), 8):
+        coords, feats, labels = [], [], []
+        for b, seed in enumerate(seeds[b0:b0 + 8]):
+            pts, lab = synth_scan(seed, n_points=1500, n_beams=16, n_az=360)
+            pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+            pc -= pc.min(0)
+            _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+            coords.append(np.concatenate([pc[idx], np.full((len(idx), 1), b, np.int32)], 1))
+            feats.append(pts[idx])
+            labels.append(lab[idx].astype(np.int64))
+        c = torch.from_numpy(np.concatenate(coords)).cuda()
+        lab_t = torch.from_numpy(np.concatenate(labels)).cuda()
+        with torch.no_grad():
+            model({"lidar": SparseTensor(torch.from_numpy(np.concatenate(feats)).cuda(), c),
+                   "targets": SparseTensor(lab_t, c), "offset": torch.tensor([0])})
+        pred = grabbed["logits"].argmax(1)
+        hist += metrics.fast_hist(pred, lab_t, 20)
+        preds.append(pred.cpu().numpy().astype(np.uint8))
+    got = np.concatenate(preds)
+    want = g_miou["pred"]
+    assert got.shape == want.shape
+    agree = float((got == want).mean())
+    same_hist = bool(np.array_equal(hist.cpu().numpy(), g_miou["hist"]))
+    iou = metrics.per_class_iu(hist).cpu().numpy()
+    print(f"mIoU parity: {len(seeds)} scans, {len(want)} voxels, arg-max agreement {100 * agree:.4f} %, confusion matrix "
+          f"identical: {same_hist}, max |IoU - reference| {np.abs(iou - g_miou['iou']).max():.2e}")
+    assert agree >= 0.999
+    assert np.abs(hist.cpu().numpy() - g_miou["hist"]).sum() <= 2 * (1 - agree) * len(want) + 1e-9
+    assert np.abs(iou - g_miou["iou"]).max() <= 1e-3

@@ -198,3 +198,40 @@ def test_image_gather_oracle_reproduces_the_reference_image_loss(g_minkunet_ms_m
         dense_t = np.transpose(g["semantic"], (0, 2, 3, 1)).reshape(-1)
         loss_d = 0.5 * float(OM.loss_ce_lovasz(torch.from_numpy(dense), torch.from_numpy(dense_t)))
         assert abs(loss_d - float(g[f"{tag}_loss_parts"][3])) <= 1e-5
+
+
+def test_oracle_predictions_match_reference_on_miou_scans(g_miou):
+    """mIoU parity gate, CPU half: on the first scans of the 200-scan set the oracle's per-voxel arg-max equals
+    the REAL reference's (tests/golden/miou_minkunet.npz; identical weights incl. the re-centred head of the fixture),
+    and the numpy restatement of fast_hist / per_class_iu (R/train.py:35-45) reproduces the stored matrix on them."""
+    import torch
+    from oracle import model as OM
+    from oracle import ts_oracle as O
+    from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, synth_scan
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=3)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params["classifier.0.weight"] = torch.from_numpy(g_miou["head_weight"])
+    params["classifier.0.bias"] = torch.from_numpy(g_miou["head_bias"])
+    om = OM.OracleMinkUNet(params, cfg, training=False)
+    off = np.concatenate([[0], np.cumsum(g_miou["counts"])])
+    agree = total = 0
+    for i, seed in enumerate(g_miou["seeds"][:6].tolist()):
+        pts, lab = synth_scan(seed, n_points=1500, n_beams=16, n_az=360)
+        pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+        pc -= pc.min(0)
+        idx, _ = O.sparse_quantize(pc)
+        coords = np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)
+        with torch.no_grad():
+            pred = om.forward_minkunet(coords, torch.from_numpy(pts[idx])).numpy().argmax(1)
+        want = g_miou["pred"][off[i]:off[i + 1]]
+        assert len(pred) == len(want)
+        agree += int((pred == want).sum())
+        total += len(want)
+    assert agree >= 0.999 * total, (agree, total)
+    # metric definitions: one-hot check + symmetry of the IoU formula
+    h = O.fast_hist(np.array([1, 2, 2, 0]), np.array([1, 2, 1, 25]), 20)
+    assert h[1, 1] == 1 and h[2, 2] == 1 and h[1, 2] == 1 and h.sum() == 3
+    iu = O.per_class_iu(g_miou["hist"])
+    assert np.allclose(iu, g_miou["iou"], atol=1e-12)
