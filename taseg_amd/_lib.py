@@ -11,7 +11,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtaseg_hip.so")
+LIB_PATH = os.environ.get("TASEG_HIP_LIB") or os.path.join(_HERE, "libtaseg_hip.so")   # override: A/B builds of the kernels
 
 TS_OK = 0
 _c = ctypes

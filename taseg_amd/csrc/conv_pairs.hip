@@ -726,6 +726,14 @@ extern "C" int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in
 // ------------------------------------------------------------------------------------- pass 2
 // KT > 0: kernel volume known at compile time (27, 8): all K position loads are issued first, then all row
 // loads - up to K independent 16-byte loads in flight per lane.  KT == 0: generic loop.
+// every Z row is read exactly once: non-temporal loads keep it out of the way of the position table and of the next
+// kernel's operands in L2 (step 19.33 -> 19.10 ms)
+typedef float ts_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ts_zload(const float4 *p) {
+  const ts_f32x4 v = __builtin_nontemporal_load((const ts_f32x4 *)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+#define TS_ZLOAD(ptr) ts_zload(ptr)
 template <int VEC, int KT>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ Z, int C,
                                                          const int *__restrict__ pos, int K, int64_t n,
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         f[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p[k] >= 0 && p[k] < n_pairs) f[k] = *(const float4 *)(Z + (int64_t)p[k] * C + c);
+        if (p[k] >= 0 && p[k] < n_pairs) f[k] = TS_ZLOAD((const float4 *)(Z + (int64_t)p[k] * C + c));
       }
 #pragma unroll
       for (int k = 0; k < KT; ++k) {  // k ascending: fixed summation order

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__res
       h8 v[KT > 0 ? KT : 1];
 #pragma unroll
       for (int k = 0; k < KT; ++k)
-        v[k] = p[k] >= 0 ? *(const h8 *)(Z + (int64_t)p[k] * C + c8) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        v[k] = p[k] >= 0 ? __builtin_nontemporal_load((const h8 *)(Z + (int64_t)p[k] * C + c8)) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < KT; ++k)
 #pragma unroll
