@@ -337,73 +337,135 @@ def build_pyramid(x: SparseTensor, num_levels: int = 4, kernel_size: int = 3, do
     del cur
 
 
+def _dense_ok(c_in: int, c_out: int) -> bool:
+    """channel counts our pair-GEMM kernels take on their full-tile paths (fp32 split-bf16 and half storage)"""
+    return c_in % 32 == 0 and c_out % 32 == 0
+
+
 class _PointwiseConv(Function):
-    """1x1x1 convolution (conv.py:135-140: `feats.matmul(weight)`).  Forward and the input gradient are plain
-    dense GEMMs (rocBLAS/hipBLASLt through torch); the weight gradient x^T @ gy is a tall-skinny reduction
-    (N ~ 1e5 rows, C <= 384) for which the library picks a tile-per-output kernel with no split over N
-    (380 us per call here), so it runs on our split-over-rows `ts_conv_wgrad` with an identity rulebook.
-    Half storage (autocast / half features): half GEMMs, fp32 weight gradient from `ts_conv_wgrad_f16`."""
+    """1x1x1 convolution (conv.py:135-140: `feats.matmul(weight)`) = a tall-skinny dense GEMM, N ~ 1e5 rows by
+    C <= 384.  All three products run on our kernels with an identity rulebook (pair p = (p, p), one offset):
+    forward and input gradient on the pair GEMM (its Z IS the result: one pair per output row, no pass 2), the weight
+    gradient on the split-over-rows reduction.  hipBLASLt's heuristics pick tile-per-output kernels without a split
+    over N for these shapes (fp32: 130-170 us per call; half: 330-490 us for a 178k x 128 x 96 product that moves
+    80 MB).  Shapes outside the full-tile paths (channels not multiples of 32) keep the library GEMM for forward /
+    input gradient.  Half storage (autocast / half features): half operands and results, fp32 accumulation, fp32
+    weight gradient."""
 
     @staticmethod
     def forward(ctx, feats, weight, ident):
         half = _amp_half(feats)
+        pairs, offs = ident
+        c_in, c_out = weight.shape
+        ours = _dense_ok(c_in, c_out)
+        n = feats.shape[0]
         with _no_autocast():
-            f = feats.contiguous().half() if half else feats.contiguous().float()
-            w = weight.detach().half() if half else weight.detach().float()
-            out = f.matmul(w)
+            if half:
+                f = feats.contiguous().half()
+                if ours:
+                    w16, w16t = B.cast_weights_f16(weight.detach().float().view(1, c_in, c_out))
+                    out = B.conv_pair_gemm_f16(f, w16t, pairs, offs, n, gather_col=0)
+                    w = w16
+                else:
+                    w = weight.detach().half()
+                    out = f.matmul(w)
+            else:
+                f = feats.contiguous().float()
+                w = weight.detach().float()
+                out = B.conv_pair_gemm(f, w.view(1, c_in, c_out), pairs, offs, n, gather_col=0) if ours else f.matmul(w)
         ctx.save_for_backward(f, w)
-        ctx.ident, ctx.half, ctx.in_dtype = ident, half, feats.dtype
+        ctx.ident, ctx.half, ctx.in_dtype, ctx.ours = ident, half, feats.dtype, ours
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         feats, weight = ctx.saved_tensors
         pairs, offs = ctx.ident
+        n = feats.shape[0]
         with _no_autocast():
             grad_out = grad_out.contiguous().to(feats.dtype)
-            grad_feats = grad_out.matmul(weight.t()).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
-            grad_weight = None
+            grad_feats = grad_weight = None
+            if ctx.needs_input_grad[0]:
+                if ctx.ours and ctx.half:       # weight = w16 [1, c_in, c_out]: rows = output columns of the input gradient
+                    grad_feats = B.conv_pair_gemm_f16(grad_out, weight, pairs, offs, n, gather_col=0)
+                elif ctx.ours:
+                    grad_feats = B.conv_pair_gemm(grad_out, weight.view(1, *weight.shape[-2:]), pairs, offs, n,
+                                                  gather_col=0, weight_transposed=True)
+                else:
+                    grad_feats = grad_out.matmul(weight.t())
+                grad_feats = grad_feats.to(ctx.in_dtype)
             if ctx.needs_input_grad[1]:
                 if ctx.half and _half_ok(feats.shape[1], grad_out.shape[1]):
-                    grad_weight = B.conv_wgrad_f16(feats, grad_out, pairs, offs, 1, col_a=0, max_pairs=feats.shape[0])
+                    grad_weight = B.conv_wgrad_f16(feats, grad_out, pairs, offs, 1, col_a=0, max_pairs=n)
                 else:
-                    grad_weight = B.conv_wgrad(feats.float(), grad_out.float(), pairs, offs, 1, col_a=0,
-                                               max_pairs=feats.shape[0])
-                grad_weight = grad_weight.view(weight.shape)
+                    grad_weight = B.conv_wgrad(feats.float(), grad_out.float(), pairs, offs, 1, col_a=0, max_pairs=n)
+                grad_weight = grad_weight.view(weight.shape[-2:])
         return grad_feats, grad_weight, None
 
 
 class _PointLinear(Function):
-    """y = x W^T + b over per-point features (the classifier heads, minkunet.py:334-336).  The library GEMMs serve
-    forward and input gradient; the weight gradient gy^T x is the same tall-skinny reduction as in
-    `_PointwiseConv` (N ~ 2e5 rows, 20 x 480 outputs: hipBLASLt runs 15 workgroups for 480 us) and goes through
-    `ts_conv_wgrad` with the identity rulebook."""
+    """y = x W^T + b over per-point features (the class heads, minkunet.py:334-336: 480 -> 20 over ~2e5 points).  The
+    output width is padded to 32 columns of zeros so that all three products run on our kernels with the identity
+    rulebook like `_PointwiseConv` (the library needs 84 / 171 us for forward / input gradient in fp32 and several
+    hundred in half for a product that only streams x once).  Half storage under autocast, fp32 otherwise."""
 
     @staticmethod
-    @_fwd
     def forward(ctx, x, weight, bias, ident):
-        ctx.save_for_backward(x, weight)
-        ctx.ident, ctx.has_bias = ident, bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        half = _amp_half(x)
+        pairs, offs = ident
+        o, c = weight.shape
+        op = (o + 31) // 32 * 32
+        n = x.shape[0]
+        with _no_autocast():
+            wpad = torch.zeros((1, c, op), dtype=torch.float32, device=x.device)      # W^T, zero columns beyond `o`
+            wpad[0, :, :o] = weight.detach().float().t()
+            if half:
+                xs = x.contiguous().half()
+                w16, w16t = B.cast_weights_f16(wpad)
+                z = B.conv_pair_gemm_f16(xs, w16t, pairs, offs, n, gather_col=0)
+                wsave = w16
+            else:
+                xs = x.contiguous().float()
+                z = B.conv_pair_gemm(xs, wpad, pairs, offs, n, gather_col=0)
+                wsave = wpad
+            y = z[:, :o]
+            y = y + bias.detach().to(z.dtype) if bias is not None else y.contiguous()
+        ctx.save_for_backward(xs, wsave)
+        ctx.ident, ctx.has_bias, ctx.half, ctx.o, ctx.in_dtype = ident, bias is not None, half, o, x.dtype
+        return y
 
     @staticmethod
-    @_bwd
     def backward(ctx, grad_out):
-        x, weight = ctx.saved_tensors
+        xs, wsave = ctx.saved_tensors
         pairs, offs = ctx.ident
-        grad_out = grad_out.contiguous()
-        grad_x = grad_out.matmul(weight) if ctx.needs_input_grad[0] else None
-        grad_w = None
-        if ctx.needs_input_grad[1]:
-            grad_w = B.conv_wgrad(x.contiguous(), grad_out, pairs, offs, 1, col_a=0, max_pairs=x.shape[0])[0].t()
-        grad_b = grad_out.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        o, n = ctx.o, xs.shape[0]
+        op = wsave.shape[2]
+        with _no_autocast():
+            gpad = torch.zeros((n, op), dtype=xs.dtype, device=xs.device)
+            gpad[:, :o] = grad_out
+            grad_x = grad_w = grad_b = None
+            if ctx.needs_input_grad[0]:
+                if ctx.half:
+                    grad_x = B.conv_pair_gemm_f16(gpad, wsave, pairs, offs, n, gather_col=0)
+                else:
+                    grad_x = B.conv_pair_gemm(gpad, wsave, pairs, offs, n, gather_col=0, weight_transposed=True)
+                grad_x = grad_x.to(ctx.in_dtype)
+            if ctx.needs_input_grad[1]:
+                if ctx.half:
+                    gw = B.conv_wgrad_f16(xs, gpad, pairs, offs, 1, col_a=0, max_pairs=n)
+                else:
+                    gw = B.conv_wgrad(xs, gpad, pairs, offs, 1, col_a=0, max_pairs=n)
+                grad_w = gw[0, :, :o].t().contiguous()
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                grad_b = grad_out.float().sum(0)
         return grad_x, grad_w, grad_b, None
 
 
 def point_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.functional.linear for [N, C] point features with the weight gradient on the HIP split-over-rows kernel."""
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 4096 and weight.requires_grad \
-            and torch.is_grad_enabled():
+    """nn.functional.linear for [N, C] point features on the HIP kernels (training on a ROCm device, C a multiple of 32,
+    at most 64 outputs); anything else goes to torch."""
+    if x.is_cuda and x.dim() == 2 and x.shape[0] >= 4096 and x.dtype in (torch.float32, torch.float16) \
+            and x.shape[1] % 32 == 0 and weight.shape[0] <= 64 and weight.requires_grad and torch.is_grad_enabled():
         return _PointLinear.apply(x, weight, bias, _identity_rows(x.shape[0], x.device))
     return torch.nn.functional.linear(x, weight, bias)
 

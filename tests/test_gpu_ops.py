@@ -625,3 +625,49 @@ def test_new_entry_points_accept_empty_inputs(B):
     pos = torch.full((27, 5), -1, dtype=torch.int32, device=dev)
     y = B.conv_gather_sum_f16(z, pos, 5)
     assert y.shape == (5, 32) and float(y.float().abs().sum()) == 0.0
+
+
+# --------------------------------------------------------------------------- dense products on the pair-GEMM kernels
+@pytest.mark.parametrize("ci,co", [(128, 96), (384, 256), (64, 64), (48, 24)])
+@pytest.mark.parametrize("half", [False, True])
+def test_pointwise_conv_on_pair_gemm_kernels(B, F, ci, co, half):
+    """1x1x1 convolution (conv.py:135-140, `feats.matmul(weight)`) through the identity rulebook: forward, input and
+    weight gradient against torch in fp64; (48, 24) takes the library fallback for forward / input gradient."""
+    from taseg_amd.torchsparse import SparseTensor
+    rs = np.random.RandomState(ci + co)
+    n = 20011
+    c = T(np.concatenate([rs.randint(0, 200, size=(n, 3)), np.zeros((n, 1))], 1).astype(np.int32))
+    xn, wn, gn = rs.randn(n, ci), rs.randn(ci, co) / np.sqrt(ci), rs.randn(n, co)
+    dt = torch.float16 if half else torch.float32
+    x = T(xn.astype(np.float32)).to(dt).requires_grad_()
+    w = T(wn.astype(np.float32)).requires_grad_()
+    y = F.conv3d(SparseTensor(x, c, 1), w, 1).F
+    assert y.dtype == dt
+    y.backward(T(gn.astype(np.float32)).to(dt))
+    x64, w64, g64 = x.detach().double().cpu().numpy(), wn, T(gn.astype(np.float32)).to(dt).double().cpu().numpy()
+    tol = 4e-3 if half else 2e-5
+    close(y.float(), x64 @ w64, tol)
+    close(x.grad.float(), g64 @ w64.T, tol)
+    close(w.grad, x64.T @ g64, tol)
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_point_linear_head_on_pair_gemm_kernels(B, F, half):
+    """the 480 -> 20 class head (minkunet.py:334-336) padded to 32 output columns on the pair GEMM / weight-gradient
+    kernels: y, dx, dW, db against fp64; under autocast the head runs in half storage like nn.Linear would"""
+    rs = np.random.RandomState(5)
+    n, c, o = 30011, 480, 20
+    xn, wn, bn_, gn = rs.randn(n, c), rs.randn(o, c) / np.sqrt(c), rs.randn(o), rs.randn(n, o)
+    x = T(xn.astype(np.float32)).requires_grad_()
+    w, b = T(wn.astype(np.float32)).requires_grad_(), T(bn_.astype(np.float32)).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+        y = F.point_linear(x, w, b)
+    assert y.dtype == (torch.float16 if half else torch.float32) and y.shape == (n, o) and y.is_contiguous()
+    g_used = T(gn.astype(np.float32)).to(y.dtype)
+    y.backward(g_used)
+    g64 = g_used.double().cpu().numpy()
+    tol = 4e-3 if half else 2e-5
+    close(y.float(), xn @ wn.T + bn_, tol)
+    close(x.grad, g64 @ wn, tol)
+    close(w.grad, g64.T @ xn, tol)
+    close(b.grad, g64.sum(0), 1e-4)
