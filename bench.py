@@ -25,7 +25,7 @@ MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (same guide; no sparsity)
 MFMA_SPLIT_PEAK_TF = MFMA_F16_PEAK_TF / 6   # fp32 products as six bf16 MFMAs (csrc/conv_pairs_s.hip): 416.7 TF/s of fp32 flops
 VOXEL = 0.05
-EVENT_EVERY = 4             # per-launch HIP events bracket the conv kernels of every 4th timed step
+EVENT_EVERY = 10            # per-launch HIP events bracket the conv kernels of every 10th timed step (those steps run the unfused wrappers)
 
 
 def parse():
@@ -273,7 +273,8 @@ def main():
             return {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset}
 
     from taseg_amd.data.stage import DevicePrefetcher
-    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare)
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare,
+                                                        threaded=os.environ.get("TASEG_STAGE_THREAD", "0") == "1")
 
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
 
