@@ -321,7 +321,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not args.no_kernel_events:
-            B.profile_pause(i % EVENT_EVERY != 0)      # HIP events around the conv kernels of every 4th timed step
+            B.profile_pause(i % EVENT_EVERY != 0)      # HIP events around the conv kernels of every EVENT_EVERY-th timed step
         loss = step()
     fence()
     dt = time.perf_counter() - t0
