@@ -9,6 +9,7 @@ from ..tensor import SparseTensor
 from ..utils.misc import make_ntuple
 from . import functional as F
 from ... import backend as _B
+from ... import _fast
 from .utils import fapply
 
 __all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act", "conv_bn_act"]
@@ -135,8 +136,15 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 track = mod.track_running_stats
                 state = (mod.running_mean if track else None, mod.running_var if track else None,
                          mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
-                out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state, relu,
-                                         comm, F._amp_half(feats))
+                fast = _fast.module()
+                if fast is not None:            # C++ autograd node, same two backend calls (csrc/fastpath)
+                    out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
+                                          kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
+                                          state[1], state[2], float(mod.momentum), float(mod.eps), relu,
+                                          (comm.value or 0) if comm is not None else 0, F._amp_half(feats), _B.L.stream())
+                else:
+                    out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
+                                             relu, comm, F._amp_half(feats))
                 return F._conv_output(input, out, out_coords, out_stride)
     return bn_act(mod, conv(input), relu=relu, residual=residual)
 
