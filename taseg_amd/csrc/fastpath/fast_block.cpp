@@ -21,6 +21,14 @@ struct Api {
   decltype(&ts_conv_block_forward) forward = nullptr;
   decltype(&ts_conv_block_backward) backward = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
+  decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
+  decltype(&ts_downsample) downsample = nullptr;
+  decltype(&ts_build_kmap_workspace_bytes) build_kmap_ws = nullptr;
+  decltype(&ts_build_kmap) build_kmap = nullptr;
+  decltype(&ts_trilinear_workspace_bytes) trilinear_ws = nullptr;
+  decltype(&ts_trilinear_map) trilinear_map = nullptr;
+  decltype(&ts_devox_order_workspace_bytes) devox_order_ws = nullptr;
+  decltype(&ts_devox_order) devox_order = nullptr;
 } api;
 
 void check(int rc, const char *what) {
@@ -150,6 +158,18 @@ void load_backend(const std::string &libpath) {
   api.backward = (decltype(api.backward))dlsym(h, "ts_conv_block_backward");
   api.last_error = (decltype(api.last_error))dlsym(h, "ts_last_error");
   TORCH_CHECK(api.workspace_bytes && api.forward && api.backward, "libtaseg_hip.so lacks the ts_conv_block_* entry points");
+#define TS_BIND(field, sym)                                      \
+  api.field = (decltype(api.field))dlsym(h, sym);                \
+  TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
+  TS_BIND(downsample_ws, "ts_downsample_workspace_bytes");
+  TS_BIND(downsample, "ts_downsample");
+  TS_BIND(build_kmap_ws, "ts_build_kmap_workspace_bytes");
+  TS_BIND(build_kmap, "ts_build_kmap");
+  TS_BIND(trilinear_ws, "ts_trilinear_workspace_bytes");
+  TS_BIND(trilinear_map, "ts_trilinear_map");
+  TS_BIND(devox_order_ws, "ts_devox_order_workspace_bytes");
+  TS_BIND(devox_order, "ts_devox_order");
+#undef TS_BIND
   api.handle = h;
 }
 
@@ -164,7 +184,151 @@ at::Tensor conv_block(const at::Tensor &feats, const at::Tensor &weight, const c
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream);
 }
 
+// ------------------------------------------------------------------------------------------------ index plan
+// Everything of a U-Net pass that depends on coordinates only (MinkUNetBackbone._index_plan): the coordinate set of
+// every stride (spdownsample, downsample.py:25-51), the submanifold (kernel 3) and strided (kernel 2, stride 2)
+// kernel maps with the reference's rulebook order (conv.py:144-177) and the trilinear point <-> voxel maps of
+// voxel_to_point at strides 1, 16 and 4 (minkunet/utils.py:72-82).  Same backend calls as the Python path
+// (functional.build_pyramid, backend.trilinear_map, backend.devox_order), issued here WITHOUT the interpreter lock:
+// the stage has five host reads (4 coordinate counts, the pair totals) during which a Python thread would hold up
+// the training thread; a data-stage thread that calls this function does not.
+namespace {
+
+std::mutex off_mutex;
+std::unordered_map<int64_t, at::Tensor> off_cache;
+
+// nn/utils/kernel.py:11-32 - per axis arange(-size // 2 + 1, size // 2 + 1) * stride; odd volumes enumerate z outermost /
+// x innermost, even volumes x outermost / z innermost
+at::Tensor kernel_offsets(int size, int stride, const at::Tensor &like) {
+  std::lock_guard<std::mutex> lock(off_mutex);
+  const int64_t key = ((int64_t)like.get_device() << 32) | ((int64_t)size << 16) | stride;
+  auto it = off_cache.find(key);
+  if (it != off_cache.end()) return it->second;
+  std::vector<int> ax;
+  const int lo = -((size + 1) / 2) + 1;                             // python: -size // 2 + 1  (3 -> -1, 2 -> 0)
+  for (int i = 0; i < size; ++i) ax.push_back((lo + i) * stride);   // ... up to size // 2
+  std::vector<int> rows;
+  if ((size * size * size) % 2 == 1) {
+    for (int z : ax) for (int y : ax) for (int x : ax) { rows.push_back(x); rows.push_back(y); rows.push_back(z); }
+  } else {
+    for (int x : ax) for (int y : ax) for (int z : ax) { rows.push_back(x); rows.push_back(y); rows.push_back(z); }
+  }
+  at::Tensor t = at::from_blob(rows.data(), {(int64_t)rows.size() / 3, 3}, at::kInt).clone().to(like.device());
+  off_cache[key] = t;
+  return t;
+}
+
+struct Kmap {
+  at::Tensor nbr, nbmaps, nbsizes, nboffs, pos_out, pos_in;
+  int64_t n_in = 0, n_out = 0;
+};
+
+Kmap make_kmap(const at::Tensor &in_c, const at::Tensor &out_c, const at::Tensor &offsets, int64_t stream) {
+  Kmap km;
+  km.n_in = in_c.size(0);
+  km.n_out = out_c.size(0);
+  const int64_t k = offsets.size(0);
+  const auto o = in_c.options();
+  km.nbr = at::empty({k, km.n_out}, o);
+  km.nbmaps = at::empty({std::max<int64_t>(k * km.n_out, 1), 2}, o);
+  km.nbsizes = at::empty({k}, o);
+  km.nboffs = at::empty({k + 1}, o);
+  km.pos_out = at::empty({k, km.n_out}, o);
+  km.pos_in = at::empty({k, km.n_in}, o);
+  at::Tensor ws = workspace(api.build_kmap_ws(km.n_in, km.n_out, (int32_t)k), in_c, stream);
+  check(api.build_kmap((const int32_t *)in_c.data_ptr(), km.n_in, (const int32_t *)out_c.data_ptr(), km.n_out,
+                       (const int32_t *)offsets.data_ptr(), (int32_t)k, (int32_t *)km.nbr.data_ptr(), nullptr,
+                       (int32_t *)km.nbmaps.data_ptr(), (int32_t *)km.nbsizes.data_ptr(), (int32_t *)km.nboffs.data_ptr(),
+                       (int32_t *)km.pos_out.data_ptr(), (int32_t *)km.pos_in.data_ptr(), ws.data_ptr(), (size_t)ws.numel(),
+                       (ts_stream_t)stream),
+        "ts_build_kmap");
+  return km;
+}
+
+std::vector<at::Tensor> kmap_tensors(const Kmap &km) { return {km.nbr, km.nbmaps, km.nbsizes, km.nboffs, km.pos_out, km.pos_in}; }
+
+}  // namespace
+
+// returns (coords per level [L+1], submanifold kmaps [L+1] x 6 tensors, strided kmaps [L] x 6 tensors, pair totals
+// [2L+1] in the order sub0, down0, sub1, down1, ..., trilinear idx [3], weights [3], devox orders [2]) for strides
+// (1, 16, 4) / (16, 4); coords [N, 4] int32, point_coords [P, 4] float32, both on the device, `stream` the caller's
+// current raw stream.
+std::tuple<std::vector<at::Tensor>, std::vector<std::vector<at::Tensor>>, std::vector<std::vector<at::Tensor>>,
+           std::vector<int64_t>, std::vector<at::Tensor>, std::vector<at::Tensor>, std::vector<at::Tensor>>
+index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num_levels, int64_t stream) {
+  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  TORCH_CHECK(coords_in.is_cuda() && coords_in.scalar_type() == at::kInt && coords_in.dim() == 2 && coords_in.size(1) == 4,
+              "index_plan: coords must be a device int32 [N, 4] tensor");
+  TORCH_CHECK(points_in.is_cuda() && points_in.scalar_type() == at::kFloat && points_in.dim() == 2 && points_in.size(1) == 4,
+              "index_plan: point coordinates must be a device float32 [P, 4] tensor");
+  TORCH_CHECK(num_levels == 4, "index_plan: the MinkUNet pyramid has 4 down-sampling levels");
+  py::gil_scoped_release nogil;
+  at::NoGradGuard nograd;
+  at::Tensor coords = coords_in.contiguous(), points = points_in.contiguous();
+  std::vector<at::Tensor> cmaps;
+  std::vector<Kmap> sub, down;
+  cmaps.push_back(coords);
+  int stride = 1;
+  for (int64_t level = 0; level <= num_levels; ++level) {
+    const at::Tensor &cur = cmaps.back();
+    sub.push_back(make_kmap(cur, cur, kernel_offsets(3, stride, cur), stream));
+    if (level == num_levels) break;
+    // spdownsample(kernel 2, stride 2): unique strided coordinates, (b, x, y, z)-sorted; one host read (the count)
+    const int64_t n = cur.size(0);
+    at::Tensor out = at::empty({std::max<int64_t>(n, 1), 4}, cur.options());
+    at::Tensor cnt = at::empty({1}, cur.options());
+    at::Tensor ws = workspace(api.downsample_ws(n), cur, stream);
+    const int step = stride * 2;
+    check(api.downsample((const int32_t *)cur.data_ptr(), n, step, step, step, (int32_t *)out.data_ptr(),
+                         (int32_t *)cnt.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
+          "ts_downsample");
+    const int m = cnt.item<int>();
+    TORCH_CHECK(m >= 0, "downsample: coordinate outside the supported range (0 <= batch < 1024, -2^17 <= x,y,z < 2^17)");
+    at::Tensor nxt = out.narrow(0, 0, m);
+    down.push_back(make_kmap(cur, nxt, kernel_offsets(2, stride, cur), stream));
+    cmaps.push_back(nxt);
+    stride = step;
+  }
+  // pair totals of all maps in ONE device -> host copy
+  std::vector<at::Tensor> lasts;
+  for (int64_t level = 0; level <= num_levels; ++level) {
+    lasts.push_back(sub[level].nboffs.narrow(0, sub[level].nboffs.size(0) - 1, 1));
+    if (level < num_levels) lasts.push_back(down[level].nboffs.narrow(0, down[level].nboffs.size(0) - 1, 1));
+  }
+  at::Tensor tot = at::cat(lasts).cpu();
+  std::vector<int64_t> totals(tot.data_ptr<int>(), tot.data_ptr<int>() + tot.numel());
+  // trilinear maps at strides 1, 16, 4 (+ the devoxelize-backward walk order of the coarse ones)
+  std::vector<at::Tensor> tri_idx, tri_w, orders;
+  const int64_t np = points.size(0);
+  for (int s : {1, 16, 4}) {
+    const int level = s == 1 ? 0 : (s == 4 ? 2 : 4);
+    const at::Tensor &vox = cmaps[level];
+    at::Tensor idx = at::empty({np, 8}, coords.options());
+    at::Tensor w = at::empty({np, 8}, points.options());
+    at::Tensor ws = workspace(api.trilinear_ws(vox.size(0)), coords, stream);
+    check(api.trilinear_map((const float *)points.data_ptr(), np, (const int32_t *)vox.data_ptr(), vox.size(0), s,
+                            (int32_t *)idx.data_ptr(), (float *)w.data_ptr(), ws.data_ptr(), (size_t)ws.numel(),
+                            (ts_stream_t)stream),
+          "ts_trilinear_map");
+    tri_idx.push_back(idx);
+    tri_w.push_back(w);
+    if (s > 1) {
+      at::Tensor order = at::empty({np}, coords.options());
+      at::Tensor ws2 = workspace(api.devox_order_ws(np), coords, stream);
+      check(api.devox_order((const int32_t *)idx.data_ptr(), np, vox.size(0), (int32_t *)order.data_ptr(), ws2.data_ptr(),
+                            (size_t)ws2.numel(), (ts_stream_t)stream),
+            "ts_devox_order");
+      orders.push_back(order);
+    }
+  }
+  std::vector<std::vector<at::Tensor>> sub_t, down_t;
+  for (auto &k : sub) sub_t.push_back(kmap_tensors(k));
+  for (auto &k : down) down_t.push_back(kmap_tensors(k));
+  return {cmaps, sub_t, down_t, totals, tri_idx, tri_w, orders};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("index_plan", &index_plan, "coordinate pyramid + kernel maps + trilinear maps of a MinkUNet pass (releases the GIL)");
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");
   m.def("conv_block", &conv_block, "act(BN(conv(x)) [+ residual]) as one native autograd node");
 }

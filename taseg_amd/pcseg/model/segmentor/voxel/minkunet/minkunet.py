@@ -16,6 +16,7 @@ from taseg_amd.torchsparse.nn import functional as spF
 from taseg_amd.pcseg.loss import Losses
 from ...base_segmentors import BaseSegmentor
 from taseg_amd import backend as B
+from taseg_amd import _fast
 from .utils import voxel_to_point, voxelize_index
 
 __all__ = ["MinkUNet"]
@@ -229,6 +230,28 @@ class MinkUNetBackbone(BaseSegmentor):
         (utils.py:72-82; the U-Net devoxelises at strides 1, 16 and 4).  Built before the first convolution
         so the host reads (voxel counts, pair totals) do not stall the launch stream mid-network; a data stage
         may build it for the NEXT batch on another stream (`taseg_amd.data.stage.DevicePrefetcher`)."""
+        fast = _fast.module()
+        if fast is not None and coords.is_cuda and coords.dtype == torch.int32 and point_coords.dtype == torch.float32:
+            # native, interpreter-lock-free form of the block below (csrc/fastpath: same backend calls, same results)
+            pc = point_coords.contiguous()
+            cm, sub_t, down_t, totals, t_idx, t_w, orders = fast.index_plan(coords.contiguous(), pc, 4, B.L.stream())
+            names = ("nbr", "nbmaps", "nbsizes", "nboffs", "pos_out", "pos_in")
+            cmaps, kmaps = {}, {}
+            for lvl, c in enumerate(cm):
+                s = 1 << lvl
+                cmaps[(s, s, s)] = c
+            for lvl in range(5):
+                s = 1 << lvl
+                km = spF.KernelMap(dict(zip(names, sub_t[lvl])), (cm[lvl].shape[0], cm[lvl].shape[0]))
+                km._total = int(totals[2 * lvl])
+                kmaps[((s, s, s), (3, 3, 3), (1, 1, 1), (1, 1, 1))] = km
+                if lvl < 4:
+                    km = spF.KernelMap(dict(zip(names, down_t[lvl])), (cm[lvl].shape[0], cm[lvl + 1].shape[0]))
+                    km._total = int(totals[2 * lvl + 1])
+                    kmaps[((s, s, s), (2, 2, 2), (2, 2, 2), (1, 1, 1))] = km
+            keys = ((1, 1, 1), (16, 16, 16), (4, 4, 4))
+            return dict(coords=coords, point_coords=pc, cmaps=cmaps, kmaps=kmaps, tri_idx=dict(zip(keys, t_idx)),
+                        tri_w=dict(zip(keys, t_w)), tri_order=dict(zip(keys[1:], orders)), **extra)
         with torch.no_grad():
             probe = SparseTensor(None, coords, 1)
             spF.build_pyramid(probe, num_levels=4)

@@ -313,3 +313,40 @@ def test_miou_parity_200_scans(g_miou):
     assert agree >= 0.999
     assert np.abs(hist.cpu().numpy() - g_miou["hist"]).sum() <= 2 * (1 - agree) * len(want) + 1e-9
     assert np.abs(iou - g_miou["iou"]).max() <= 1e-3
+
+
+def test_native_index_plan_equals_python_plan():
+    """csrc/fastpath index_plan (coordinate pyramid, 9 kernel maps, trilinear maps, devoxelize orders without the
+    interpreter lock) against the Python path it replaces: every tensor bit-identical, same keys, same pair totals."""
+    from taseg_amd import _fast
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import MinkUNetBackbone
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    if _fast.module() is None:
+        pytest.skip("taseg_amd/_fast_block.so has not been built")
+    coords = []
+    for b, seed in enumerate((7, 8)):
+        pts, _ = synth_scan(seed, n_points=20000, n_beams=32, n_az=1000)
+        pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+        pc -= pc.min(0)
+        _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+        coords.append(np.concatenate([pc[idx], np.full((len(idx), 1), b, np.int32)], 1))
+    c = torch.from_numpy(np.concatenate(coords)).cuda()
+    native = MinkUNetBackbone._index_plan(c, c.float())
+    saved, _fast._mod = _fast._mod, None
+    try:
+        python = MinkUNetBackbone._index_plan(c, c.float())
+    finally:
+        _fast._mod = saved
+    assert set(native["cmaps"]) == set(python["cmaps"]) and set(native["kmaps"]) == set(python["kmaps"])
+    for k in python["cmaps"]:
+        assert torch.equal(native["cmaps"][k], python["cmaps"][k]), k
+    for k, want in python["kmaps"].items():
+        got = native["kmaps"][k]
+        assert got.sizes == want.sizes and got.total == want.total, k
+        assert torch.equal(got.nbmaps, want.nbmaps) and torch.equal(got.nbsizes, want.nbsizes), k
+        for name in ("nbr", "nboffs", "pos_out", "pos_in"):
+            assert torch.equal(getattr(got, name), getattr(want, name)), (k, name)
+    for name in ("tri_idx", "tri_w", "tri_order"):
+        assert set(native[name]) == set(python[name])
+        for k in python[name]:
+            assert torch.equal(native[name][k], python[name][k]), (name, k)
