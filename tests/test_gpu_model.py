@@ -350,3 +350,36 @@ def test_native_index_plan_equals_python_plan():
         assert set(native[name]) == set(python[name])
         for k in python[name]:
             assert torch.equal(native[name][k], python[name][k]), (name, k)
+
+
+def test_conv_block_paths_agree(g_minkunet):
+    """conv -> BN -> (+ residual) -> ReLU served three ways - the C++ autograd node (taseg_amd/_fast_block.so), the
+    Python node (`functional._ConvBlock`) and the unfused conv3d + bn_act chain - issues the same kernels: one training
+    step gives the same loss and (up to the float atomics of the weight gradient) the same gradients."""
+    from taseg_amd import _fast
+    from taseg_amd.torchsparse.nn import modules as M
+    results = []
+    for mode in ("native", "python", "unfused"):
+        if mode == "native" and _fast.module() is None:
+            continue
+        saved_mod, saved_flag = _fast._mod, M._FUSED_BLOCK
+        try:
+            if mode != "native":
+                _fast._mod, _fast._tried = None, True
+            M._FUSED_BLOCK = mode != "unfused"
+            cfg, model = _build("MinkUNet", 4)
+            model.train()
+            ret, tb, _ = model(_batch(g_minkunet, "lidar"))
+            ret["loss"].backward()
+            results.append((mode, float(tb["loss"]), [p.grad.detach().clone() for p in model.parameters()],
+                            [b.detach().clone() for b in model.buffers()]))
+        finally:
+            _fast._mod, M._FUSED_BLOCK = saved_mod, saved_flag
+    assert len(results) >= 2
+    ref = results[-1]                                   # the unfused chain
+    for mode, loss, grads, bufs in results[:-1]:
+        assert abs(loss - ref[1]) <= 1e-5, (mode, loss, ref[1])
+        for a, b in zip(grads, ref[2]):
+            assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-7, mode
+        for a, b in zip(bufs, ref[3]):                  # BatchNorm running statistics / counters
+            assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), mode
