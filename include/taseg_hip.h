@@ -317,6 +317,13 @@ int ts_cast_weights_f16(const float *w, int32_t K, int32_t c_in, int32_t c_out, 
 int ts_conv_pair_gemm_f16(const void *feat, int64_t n_rows, int32_t c_red, const void *w_rows, int32_t K,
                           const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, void *z,
                           int32_t c_out, ts_stream_t stream);
+/*   ts_conv_pair_gemm_f16_nat  ts_conv_pair_gemm_f16 with the weight in its natural layout w [K, c_red, c_out] (the forward
+ *                              pass reads the half copy of kernel [K, C_in, C_out] in place; fragments come from the
+ *                              transposing LDS load, no transposed copy of the weight exists) */
+int ts_conv_pair_gemm_f16_nat(const void *feat, int64_t n_rows, int32_t c_red, const void *w, int32_t K,
+                              const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, void *z,
+                              int32_t c_out, ts_stream_t stream);
+
 int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
                            void *out, ts_stream_t stream);
 /*   ts_conv_wgrad_f16        grad_kernel[k] (fp32 [K, c_a, c_b], zeroed here) = sum_pairs a[pa]^T b[pb], half rows in,

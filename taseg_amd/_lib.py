@@ -63,6 +63,7 @@ SIGNATURES = {
     "ts_image_gather_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "ts_conv_pair_gemm_f16_nat": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_gather_sum_f16": (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp]),
     "ts_conv_wgrad_f16": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "ts_bn_act_train_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _i32,

@@ -334,21 +334,25 @@ def cast_weights_f16(kernel, want=(True, True)):
     return w16, w16t
 
 
-def conv_pair_gemm_f16(feat, w_rows, nbmaps, nboffs, n_pairs, gather_col):
-    """Pass 1 in half storage: z[p] = feat[nbmaps[p][gather_col]] @ W_k(p); w_rows [K, c_out, c_red] (one row per
-    output column, contiguous in the reduction index: w16t for forward, w16 for the input gradient)."""
+def conv_pair_gemm_f16(feat, w_rows, nbmaps, nboffs, n_pairs, gather_col, natural=False):
+    """Pass 1 in half storage: z[p] = feat[nbmaps[p][gather_col]] @ W_k(p).  natural=False: w_rows [K, c_out, c_red] (one
+    row per output column, contiguous in the reduction index: how the input gradient reads the half weight
+    [K, C_in, C_out]); natural=True: w_rows [K, c_red, c_out] (how the forward pass reads the same tensor)."""
     L.require_device(feat, w_rows, nbmaps, nboffs)
     feat, w_rows = _f16(feat, "feat"), _f16(w_rows, "w_rows")
     nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
-    k, c_out, c_red = w_rows.shape
+    if natural:
+        k, c_red, c_out = w_rows.shape
+    else:
+        k, c_out, c_red = w_rows.shape
     if feat.shape[1] != c_red:
         raise ValueError("Input feature size and kernel size mismatch")
     z = torch.empty((int(n_pairs), c_out), dtype=torch.float16, device=feat.device)
     with _Timed("pair_gemm", name=f"pair_gemm_h_kernel<{128 if c_out % 128 == 0 else 96 if c_out % 96 == 0 else 64 if c_out % 64 == 0 else 32}>",
                 pairs=int(n_pairs), c_red=c_red, c_out=c_out, k=k, esize=2):
-        L.check(L.load().ts_conv_pair_gemm_f16(L.ptr(feat), feat.shape[0], c_red, L.ptr(w_rows), k, L.ptr(nbmaps),
-                                               L.ptr(nboffs), int(n_pairs), int(gather_col), L.ptr(z), c_out,
-                                               L.stream()), "ts_conv_pair_gemm_f16")
+        fn = L.load().ts_conv_pair_gemm_f16_nat if natural else L.load().ts_conv_pair_gemm_f16
+        L.check(fn(L.ptr(feat), feat.shape[0], c_red, L.ptr(w_rows), k, L.ptr(nbmaps), L.ptr(nboffs), int(n_pairs),
+                   int(gather_col), L.ptr(z), c_out, L.stream()), "ts_conv_pair_gemm_f16")
     return z
 
 

@@ -64,8 +64,11 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   void *bn_ws = p;
   const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
   if (half) {
-    TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, w16t, stream));
-    TS_TRY(ts_conv_pair_gemm_f16(feat, n_feat_rows, c_in, w16t, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
+    // one half copy in the kernel's own layout serves both passes: the forward reads it through the transposing LDS
+    // load (ts_conv_pair_gemm_f16_nat), the input gradient directly
+    (void)w16t;
+    TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
+    TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
     TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
   } else {
     TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,

@@ -53,8 +53,24 @@ extern "C" int ts_cast_weights_f16(const float *w, int32_t K, int32_t c_in, int3
   return TS_OK;
 }
 
-// X [*, R] half rows; Wr [K, O_total, R] half (row = output column, contiguous in the reduction index); Z [P, O_total] half
-template <int BN, int WR>
+// fragment of a [k][col] image: 8 consecutive k rows of column c0 + (lane & 15) through the transposing LDS load
+// (lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3; as in wgrad_h_kernel below)
+typedef __fp16 hv4t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h8 ph_frag_tr(const _Float16 *img, int pitch, int r0, int c0, int tq, int tp) {
+  typedef hv4t __attribute__((address_space(3))) * lds_hv4;
+  const hv4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + tq) * pitch + c0 + 4 * tp));
+  const hv4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + 4 + tq) * pitch + c0 + 4 * tp));
+  h8 v;
+  v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+  v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+  return v;
+}
+
+// X [*, R] half rows; Z [P, O_total] half.  WT = true: Wr [K, O_total, R] (row = output column, contiguous in the
+// reduction index - the input gradient reads the [K, C_in, C_out] half weight this way); WT = false: Wr [K, R, O_total]
+// (the forward pass reads the same [K, C_in, C_out] weight in place, fragments through ds_read_b64_tr_b16 - no
+// transposed copy of the weight is made).
+template <int BN, int WR, bool WT>
 __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__restrict__ X, int R,
                                                           const _Float16 *__restrict__ Wr, int O_total,
                                                           const int2 *__restrict__ nbmaps,
@@ -64,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__r
   constexpr int MI = (PH_BM / 16) / WR;
   constexpr int NI = (BN / 16) / WC;
   constexpr int A_HALVES = PH_BM * PH_AP;
-  constexpr int B_HALVES = BN * PH_AP;
+  constexpr int BP = BN + 8;                        // pitch of the [k][col] weight image (WT = false)
+  constexpr int B_HALVES = WT ? BN * PH_AP : PH_BK * BP;
   constexpr int A_IT = PH_BM * (PH_BK / 8) / 256;   // 16-byte chunks per thread per A slice (2)
   constexpr int B_IT = (BN * (PH_BK / 8) + 255) / 256;
   constexpr int ZP = BN + 8;                        // pitch of the Z tile image (halves)
@@ -75,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__r
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = lane & 3;
   const int wr = wave / WC, wc = wave % WC;
   const int o0 = blockIdx.y * BN;
 
@@ -102,15 +120,22 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__r
     const int2 pr = nbmaps[p0 + min(arow0 + 64 * it, np - 1)];
     aptr[it] = X + (int64_t)(gcol ? pr.y : pr.x) * R + acol;
   }
-  // B slots: chunk (e & 3) of weight row (e >> 2)
-  const _Float16 *wk = Wr + ((int64_t)k * O_total + o0) * R;
+  // B slots: WT: chunk (e & 3) of weight row (e >> 2); natural layout: chunk (e % (BN / 8)) of reduction row e / (BN / 8)
+  const _Float16 *wk = WT ? Wr + ((int64_t)k * O_total + o0) * R : Wr + (int64_t)k * R * O_total + o0;
   int boff[B_IT], bdst[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
-    const int e = tid + it * 256;
-    const int col = min(e >> 2, BN - 1), c8 = (e & 3) << 3;
-    boff[it] = col * R + c8;
-    bdst[it] = col * PH_AP + c8;
+    const int e = min(tid + it * 256, BN * 4 - 1);
+    if (WT) {
+      const int col = e >> 2, c8 = (e & 3) << 3;
+      boff[it] = col * R + c8;
+      bdst[it] = col * PH_AP + c8;
+    } else {
+      constexpr int q8 = BN >> 3;
+      const int kk = e / q8, c8 = (e - kk * q8) << 3;
+      boff[it] = kk * O_total + c8;
+      bdst[it] = kk * BP + c8;
+    }
   }
 
   f32x4 acc[MI][NI];
@@ -123,8 +148,9 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__r
   auto load_regs = [&](int c0) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) ra[it] = *(const h8 *)(aptr[it] + c0);
+    const _Float16 *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) rb[it] = *(const h8 *)(wk + c0 + boff[it]);
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const h8 *)(wb + boff[it]);
   };
   auto store_lds = [&](_Float16 *At, _Float16 *Bt) {
     const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -142,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__r
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a[mi] = *(const h8 *)&At[((wr * MI + mi) * 16 + r16) * PH_AP + 8 * g];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b[ni] = *(const h8 *)&Bt[((wc * NI + ni) * 16 + r16) * PH_AP + 8 * g];
+    for (int ni = 0; ni < NI; ++ni)
+      b[ni] = WT ? *(const h8 *)&Bt[((wc * NI + ni) * 16 + r16) * PH_AP + 8 * g]
+                 : ph_frag_tr(Bt, BP, 8 * g, (wc * NI + ni) * 16, tq, tp);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -177,21 +205,39 @@ __global__ __launch_bounds__(256, 2) void pair_gemm_h_kernel(const _Float16 *__r
   }
 }
 
-template <int BN, int WR>
+template <int BN, int WR, bool WT>
 static int launch_pair_gemm_h(const _Float16 *X, int R, const _Float16 *Wr, int O_total, const int2 *nbmaps,
                               const int *nboffs, int K, int64_t P, int gcol, _Float16 *Z, hipStream_t stream) {
-  const size_t stage = (size_t)2 * (PH_BM * PH_AP + BN * PH_AP) * 2;
+  const size_t stage = (size_t)2 * (PH_BM * PH_AP + (WT ? BN * PH_AP : PH_BK * (BN + 8))) * 2;
   const size_t ztile = (size_t)PH_BM * (BN + 8) * 2;
   const size_t lds = std::max(stage, ztile);
   dim3 grid((unsigned)(ts_cdiv(P, PH_BM) + K), (unsigned)(O_total / BN));
-  pair_gemm_h_kernel<BN, WR><<<grid, 256, lds, stream>>>(X, R, Wr, O_total, nbmaps, nboffs, K, gcol, Z);
+  pair_gemm_h_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, Wr, O_total, nbmaps, nboffs, K, gcol, Z);
   TS_CHECK_LAUNCH("conv_pair_gemm_f16");
   return TS_OK;
 }
 
+static int pair_gemm_f16_any(const void *feat, int64_t n_rows, int32_t c_red, const void *w_rows, int32_t K,
+                             const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, void *z,
+                             int32_t c_out, bool natural, ts_stream_t stream_);
+
 extern "C" int ts_conv_pair_gemm_f16(const void *feat, int64_t n_rows, int32_t c_red, const void *w_rows, int32_t K,
                                      const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
                                      void *z, int32_t c_out, ts_stream_t stream_) {
+  return pair_gemm_f16_any(feat, n_rows, c_red, w_rows, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, false, stream_);
+}
+
+// the same product with the weight in its natural layout w [K, c_red, c_out] (what the forward pass of a convolution
+// has: kernel [K, C_in, C_out]); no transposed half copy needed
+extern "C" int ts_conv_pair_gemm_f16_nat(const void *feat, int64_t n_rows, int32_t c_red, const void *w, int32_t K,
+                                         const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs,
+                                         int32_t gather_col, void *z, int32_t c_out, ts_stream_t stream_) {
+  return pair_gemm_f16_any(feat, n_rows, c_red, w, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, true, stream_);
+}
+
+static int pair_gemm_f16_any(const void *feat, int64_t n_rows, int32_t c_red, const void *w_rows, int32_t K,
+                             const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, void *z,
+                             int32_t c_out, bool natural, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(n_rows >= 0 && c_red > 0 && c_out > 0 && K > 0 && K <= 63 && n_pairs >= 0 && n_pairs < (1LL << 31),
              TS_ERR_INVALID_ARGUMENT, "ts_conv_pair_gemm_f16: bad sizes");
@@ -204,7 +250,9 @@ extern "C" int ts_conv_pair_gemm_f16(const void *feat, int64_t n_rows, int32_t c
   const _Float16 *x = (const _Float16 *)feat, *w = (const _Float16 *)w_rows;
   const int2 *nm = (const int2 *)nbmaps;
   const int gc = gather_col ? 1 : 0;
-#define TS_PH(BN, WR) launch_pair_gemm_h<BN, WR>(x, c_red, w, c_out, nm, nboffs, K, n_pairs, gc, (_Float16 *)z, stream)
+#define TS_PH(BN, WR)                                                                                              \
+  (natural ? launch_pair_gemm_h<BN, WR, false>(x, c_red, w, c_out, nm, nboffs, K, n_pairs, gc, (_Float16 *)z, stream) \
+           : launch_pair_gemm_h<BN, WR, true>(x, c_red, w, c_out, nm, nboffs, K, n_pairs, gc, (_Float16 *)z, stream))
   if (c_out % 128 == 0) return TS_PH(128, 2);
   if (c_out % 96 == 0) return TS_PH(96, 2);
   if (c_out % 64 == 0) return TS_PH(64, 2);

@@ -255,8 +255,8 @@ class _SparseConv(Function):
         with _no_autocast():
             if half:
                 fh = feats.contiguous().half()
-                w16, w16t = B.cast_weights_f16(weight.detach().float())
-                z = B.conv_pair_gemm_f16(fh, w16t, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
+                w16, _ = B.cast_weights_f16(weight.detach().float(), want=(True, False))
+                z = B.conv_pair_gemm_f16(fh, w16, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol, natural=True)
                 out = B.conv_gather_sum_f16(z, table, rows)
                 ctx.save_for_backward(fh, w16)
             else:
@@ -363,8 +363,8 @@ class _PointwiseConv(Function):
             if half:
                 f = feats.contiguous().half()
                 if ours:
-                    w16, w16t = B.cast_weights_f16(weight.detach().float().view(1, c_in, c_out))
-                    out = B.conv_pair_gemm_f16(f, w16t, pairs, offs, n, gather_col=0)
+                    w16, _ = B.cast_weights_f16(weight.detach().float().view(1, c_in, c_out), want=(True, False))
+                    out = B.conv_pair_gemm_f16(f, w16, pairs, offs, n, gather_col=0, natural=True)
                     w = w16
                 else:
                     w = weight.detach().half()
@@ -421,8 +421,8 @@ class _PointLinear(Function):
             wpad[0, :, :o] = weight.detach().float().t()
             if half:
                 xs = x.contiguous().half()
-                w16, w16t = B.cast_weights_f16(wpad)
-                z = B.conv_pair_gemm_f16(xs, w16t, pairs, offs, n, gather_col=0)
+                w16, _ = B.cast_weights_f16(wpad, want=(True, False))
+                z = B.conv_pair_gemm_f16(xs, w16, pairs, offs, n, gather_col=0, natural=True)
                 wsave = w16
             else:
                 xs = x.contiguous().float()

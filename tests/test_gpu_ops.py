@@ -671,3 +671,20 @@ def test_point_linear_head_on_pair_gemm_kernels(B, F, half):
     close(x.grad, g64 @ wn, tol)
     close(w.grad, g64.T @ xn, tol)
     close(b.grad, g64.sum(0), 1e-4)
+
+
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 64), (128, 128), (384, 256), (32, 128)])
+def test_conv_f16_natural_weight_layout_equals_row_layout(B, F, ci, co):
+    """the half pair GEMM reading the weight in place ([K, C_in, C_out], fragments through the transposing LDS load)
+    against the same kernel on the transposed copy [K, C_out, C_in]: same MFMA stream, bit-identical Z"""
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    c = _blob(17, n=4000, extent=22)
+    rs = np.random.RandomState(ci * 3 + co)
+    x = T(rs.randn(len(c), ci).astype(np.float32)).half()
+    w = T((rs.randn(27, ci, co) / 30).astype(np.float32))
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV))
+    total = int(km["nboffs"][-1])
+    w16, w16t = B.cast_weights_f16(w)
+    z_rows = B.conv_pair_gemm_f16(x, w16t, km["nbmaps"], km["nboffs"], total, gather_col=0)
+    z_nat = B.conv_pair_gemm_f16(x, w16, km["nbmaps"], km["nboffs"], total, gather_col=0, natural=True)
+    assert torch.equal(z_rows, z_nat)
