@@ -126,23 +126,32 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                     c_out, (float *)grad_conv, (float *)grad_residual, grad_bn_weight, grad_bn_bias, bn_ws,
                                     bn_ws_bytes, stream));
   }
+  // the gather-sum launch of the input gradient clears the weight-gradient tensor on the side (the weight gradient
+  // accumulates into it with atomics right after): one fill launch less per block
+  const int64_t gk_floats = (int64_t)K * c_in * c_out;
+  const bool side_zero = grad_feat && grad_kernel && n_dgrad_rows > 0 && (gk_floats & 3) == 0 &&
+                         (((uintptr_t)grad_kernel) & 15) == 0;
+  float *zp = side_zero ? grad_kernel : nullptr;
+  const int64_t zn = side_zero ? gk_floats : 0;
   if (half) {
     if (grad_feat) {
       TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
                                    stream));
-      TS_TRY(ts_conv_gather_sum_f16(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, stream));
+      TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, zp, zn, stream));
     }
     if (grad_kernel)
-      TS_TRY(ts_conv_wgrad_f16(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel, stream));
+      TS_TRY(ts_conv_wgrad_f16_ex(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel,
+                                  side_zero ? 1 : 0, stream));
   } else {
     if (grad_feat) {
       TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs,
                                n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
-      TS_TRY(ts_conv_gather_sum((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat, stream));
+      TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat, zp, zn,
+                                   stream));
     }
     if (grad_kernel)
-      TS_TRY(ts_conv_wgrad((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a,
-                           n_pairs, grad_kernel, stream));
+      TS_TRY(ts_conv_wgrad_ex((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a,
+                              n_pairs, grad_kernel, side_zero ? 1 : 0, stream));
   }
   return TS_OK;
 }

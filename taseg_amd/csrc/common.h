@@ -112,3 +112,17 @@ __device__ __forceinline__ int ts_table_find(const TsTable &t, uint64_t key) {
 // Carve a table out of a workspace and reset it on `stream`.
 int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream,
                   size_t *used);
+
+// Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can clear a second buffer
+// on the side (the weight-gradient tensor the NEXT launch accumulates into with atomics - saves its own fill launch),
+// and the weight gradient can be told that its output is already zero.
+int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
+                          float *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream);
+int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
+                              void *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream);
+int ts_conv_wgrad_ex(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
+                     const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
+                     int32_t already_zero, ts_stream_t stream);
+int ts_conv_wgrad_f16_ex(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b, const int32_t *nbmaps,
+                         const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
+                         int32_t already_zero, ts_stream_t stream);

@@ -737,11 +737,13 @@ __device__ __forceinline__ float4 ts_zload(const float4 *p) {
 template <int VEC, int KT>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ Z, int C,
                                                          const int *__restrict__ pos, int K, int64_t n,
-                                                         int64_t n_pairs, float *__restrict__ out) {
+                                                         int64_t n_pairs, float *__restrict__ out,
+                                                         float4 *__restrict__ zero_ptr, int64_t zero_n4) {
   const int cv = C / VEC;
   const int64_t total = n * cv;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = e; i < zero_n4; i += step) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // side job, see common.h
   for (; e < total; e += step) {
     const int64_t j = e / cv;
     const int c = (int)(e - j * cv) * VEC;
@@ -792,7 +794,16 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
 
 extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                   int64_t n_pairs, float *out, ts_stream_t stream_) {
+  return ts_conv_gather_sum_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, 0, stream_);
+}
+
+int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
+                          float *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(zero_floats == 0 || (zero_ptr && (zero_floats & 3) == 0 && (((uintptr_t)zero_ptr) & 15) == 0 && n_rows > 0),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: bad side buffer");
+  float4 *zp = (float4 *)zero_ptr;
+  const int64_t zn = zero_floats / 4;
   TS_REQUIRE(c > 0 && K > 0 && n_rows >= 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: bad sizes");
   if (n_rows == 0) return TS_OK;
   TS_REQUIRE(pos && out && (z || n_pairs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: null pointer");
@@ -800,14 +811,14 @@ extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos,
   if (vec) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 4), 256), 1 << 20);
     if (K == 27)
-      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
     else if (K == 8)
-      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
     else
-      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
   } else {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * c, 256), 1 << 20);
-    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out);
+    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
   }
   TS_CHECK_LAUNCH("conv_gather_sum");
   return TS_OK;
@@ -1210,11 +1221,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const float *__r
 extern "C" int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
                              const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
                              int64_t n_pairs, float *grad_kernel, ts_stream_t stream_) {
+  return ts_conv_wgrad_ex(a_feat, c_a, b_feat, c_b, nbmaps, nboffs, K, col_a, n_pairs, grad_kernel, 0, stream_);
+}
+
+int ts_conv_wgrad_ex(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
+                     const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
+                     int32_t already_zero, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && n_pairs >= 0 && n_pairs < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
              "ts_conv_wgrad: bad sizes");
   TS_REQUIRE(grad_kernel && nboffs, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
-  TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
+  if (!already_zero) TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
   if (n_pairs == 0) return TS_OK;
   TS_REQUIRE(a_feat && b_feat && nbmaps, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad: null pointer");
   const int2 *nm = (const int2 *)nbmaps;

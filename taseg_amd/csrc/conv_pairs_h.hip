@@ -264,10 +264,12 @@ static int pair_gemm_f16_any(const void *feat, int64_t n_rows, int32_t c_red, co
 template <int KT>
 __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__restrict__ Z, int C,
                                                            const int *__restrict__ pos, int K, int64_t n_rows,
-                                                           _Float16 *__restrict__ out) {
+                                                           _Float16 *__restrict__ out, float4 *__restrict__ zero_ptr,
+                                                           int64_t zero_n4) {
   const int c8n = C >> 3;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = n_rows * c8n, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = e; i < zero_n4; i += step) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // side job, see common.h
   for (; e < total; e += step) {
     const int64_t j = e / c8n;
     const int c8 = (int)(e - j * c8n) << 3;
@@ -303,7 +305,16 @@ __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__res
 
 extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                       int64_t n_pairs, void *out, ts_stream_t stream_) {
+  return ts_conv_gather_sum_f16_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, 0, stream_);
+}
+
+int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
+                              void *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(zero_floats == 0 || (zero_ptr && (zero_floats & 3) == 0 && (((uintptr_t)zero_ptr) & 15) == 0 && n_rows > 0),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum_f16: bad side buffer");
+  float4 *zp = (float4 *)zero_ptr;
+  const int64_t zn = zero_floats / 4;
   TS_REQUIRE(c > 0 && (c & 7) == 0 && K > 0 && n_rows >= 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_gather_sum_f16: bad sizes (C must be a multiple of 8)");
   if (n_rows == 0) return TS_OK;
@@ -313,11 +324,11 @@ extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *p
   const int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 8), 256), 1 << 20);
   const _Float16 *zz = (const _Float16 *)z;
   if (K == 27)
-    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out);
+    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, zp, zn);
   else if (K == 8)
-    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out);
+    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, zp, zn);
   else
-    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out);
+    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, zp, zn);
   TS_CHECK_LAUNCH("ts_conv_gather_sum_f16");
   return TS_OK;
 }
@@ -504,12 +515,18 @@ static int launch_wgrad_h(const _Float16 *A, int CA, const _Float16 *B, int CB, 
 extern "C" int ts_conv_wgrad_f16(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b,
                                  const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
                                  int64_t n_pairs, float *grad_kernel, ts_stream_t stream_) {
+  return ts_conv_wgrad_f16_ex(a_feat, c_a, b_feat, c_b, nbmaps, nboffs, K, col_a, n_pairs, grad_kernel, 0, stream_);
+}
+
+int ts_conv_wgrad_f16_ex(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b, const int32_t *nbmaps,
+                         const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
+                         int32_t already_zero, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && K <= 63 && n_pairs >= 0 && n_pairs < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
              "ts_conv_wgrad_f16: bad sizes");
   TS_REQUIRE(c_a % 32 == 0 && c_b % 32 == 0, TS_ERR_UNSUPPORTED, "ts_conv_wgrad_f16: channel counts must be multiples of 32");
   TS_REQUIRE(grad_kernel && nboffs, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_f16: null pointer");
-  TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
+  if (!already_zero) TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, stream), "wgrad memset");
   if (n_pairs == 0) return TS_OK;
   TS_REQUIRE(a_feat && b_feat && nbmaps, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_f16: null pointer");
   TS_REQUIRE(((((uintptr_t)a_feat) | ((uintptr_t)b_feat)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
