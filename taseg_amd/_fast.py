@@ -22,10 +22,15 @@ def module():
     if os.environ.get("TASEG_FAST_BLOCK", "1") == "0" or not os.path.exists(_PATH):
         return None
     import torch  # noqa: F401  (libtorch must be loaded before the extension)
-    spec = importlib.util.spec_from_file_location("_fast_block", _PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    L.load()
-    mod.load_backend(L.LIB_PATH)
+    L.load()          # the kernels themselves are not optional: a missing libtaseg_hip.so raises here
+    try:
+        spec = importlib.util.spec_from_file_location("_fast_block", _PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.load_backend(L.LIB_PATH)
+    except Exception as e:  # noqa: BLE001 - e.g. built against another PyTorch: the Python nodes serve the blocks
+        import warnings
+        warnings.warn(f"taseg_amd: native fast path not usable ({e}); using the Python autograd nodes")
+        return None
     _mod = mod
     return _mod
