@@ -285,6 +285,16 @@ int ts_bn_sync_backward_reduce(const float *grad_out, const uint8_t *mask, const
  *                              voxel + corner number; n_vox < 2^28); ws >= ts_devox_order_workspace_bytes(n)
  *   ts_devoxelize_backward_runs  grad_feat[m, c] (zeroed here) += runs; `order` may be NULL (natural order);
  *                              c % 4 == 0, 16-byte aligned rows */
+/*   ts_devox_csr               inverse of a trilinear map: offsets[n_vox + 1] / entries[8 n] int32, the slots
+ *                              (point * 8 + corner) with a non-zero weight onto voxel v in ascending order;
+ *                              ws >= ts_devox_csr_workspace_bytes(n)
+ *   ts_devoxelize_backward_csr grad_feat[v] = sum over the slots of v of weight[slot] * grad_out[point]: every row written
+ *                              once, no fill, no atomics, fixed summation order (c % 4 == 0, 16-byte aligned rows) */
+size_t ts_devox_csr_workspace_bytes(int64_t n);
+int ts_devox_csr(const int32_t *idx, const float *weight, int64_t n, int64_t n_vox, int32_t *offsets, int32_t *entries,
+                 void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_devoxelize_backward_csr(const float *grad_out, const float *weight, const int32_t *offsets, const int32_t *entries,
+                               int64_t n, int32_t c, int64_t m, float *grad_feat, ts_stream_t stream);
 size_t ts_devox_order_workspace_bytes(int64_t n);
 int ts_devox_order(const int32_t *idx, int64_t n, int64_t n_vox, int32_t *order, void *ws, size_t ws_bytes,
                    ts_stream_t stream);

@@ -14,7 +14,8 @@ from . import _lib as L
 __all__ = [
     "hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda",
     "voxelize_forward_cuda", "voxelize_backward_cuda",
-    "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs",
+    "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs", "devox_csr",
+    "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
     "fuse_scan", "fuse_scans", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
@@ -139,6 +140,34 @@ def devox_order(indices, n_vox):
     L.check(lib.ts_devox_order(L.ptr(indices), n, int(n_vox), L.ptr(order), L.ptr(ws), ws.numel(), L.stream()),
             "ts_devox_order")
     return order
+
+
+def devox_csr(indices, weight, n_vox):
+    """Inverse of a trilinear map for `devoxelize_backward_csr`: (offsets [n_vox + 1], entries [8 n]) int32."""
+    L.require_device(indices, weight)
+    indices, weight = _i32(indices, "indices"), _f32(weight, "weight")
+    n = indices.shape[0]
+    lib = L.load()
+    ws = L.workspace(lib.ts_devox_csr_workspace_bytes(n), indices.device)
+    off = torch.empty(int(n_vox) + 1, dtype=torch.int32, device=indices.device)
+    ent = torch.empty(max(8 * n, 1), dtype=torch.int32, device=indices.device)
+    L.check(lib.ts_devox_csr(L.ptr(indices), L.ptr(weight), n, int(n_vox), L.ptr(off), L.ptr(ent), L.ptr(ws), ws.numel(),
+                             L.stream()), "ts_devox_csr")
+    return off, ent
+
+
+def devoxelize_backward_csr(top_grad, weight, csr, n):
+    """devoxelize_backward_cuda as a gather along the inverse map `csr` = devox_csr(...): no atomics, deterministic."""
+    off, ent = csr
+    L.require_device(top_grad, weight, off, ent)
+    top_grad, weight = _f32(top_grad, "top_grad"), _f32(weight, "weight")
+    npts, c = top_grad.shape
+    if off.shape[0] != int(n) + 1:
+        raise ValueError("inverse map was built for another voxel count")
+    out = torch.empty((int(n), c), dtype=torch.float32, device=top_grad.device)
+    L.check(L.load().ts_devoxelize_backward_csr(L.ptr(top_grad), L.ptr(weight), L.ptr(off), L.ptr(ent), npts, c, int(n),
+                                                L.ptr(out), L.stream()), "ts_devoxelize_backward_csr")
+    return out
 
 
 def devoxelize_backward_runs(top_grad, indices, weight, n, order=None):

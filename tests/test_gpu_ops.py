@@ -688,3 +688,36 @@ def test_conv_f16_natural_weight_layout_equals_row_layout(B, F, ci, co):
     z_rows = B.conv_pair_gemm_f16(x, w16t, km["nbmaps"], km["nboffs"], total, gather_col=0)
     z_nat = B.conv_pair_gemm_f16(x, w16, km["nbmaps"], km["nboffs"], total, gather_col=0, natural=True)
     assert torch.equal(z_rows, z_nat)
+
+
+@pytest.mark.parametrize("stride", [1, 4, 16])
+@pytest.mark.parametrize("c", [32, 96, 256])
+def test_devoxelize_backward_along_inverse_map(B, F, c, stride):
+    """ts_devox_csr + ts_devoxelize_backward_csr (gather per voxel, no atomics) against the atomic kernel and the oracle
+    on real trilinear maps; the inverse map lists exactly the live (point, corner) slots, sorted, and two runs are
+    bitwise identical"""
+    from taseg_amd.data.synthetic import synth_scan
+    pts, _ = synth_scan(5, n_points=30000)
+    pc = np.unique(np.round(pts[:, :3] / 0.05).astype(np.int32), axis=0)
+    pc -= pc.min(0, keepdims=True)
+    coords = T(np.concatenate([pc, np.zeros((len(pc), 1), np.int32)], 1))
+    vox = F.spdownsample(coords, stride, stride, 1) if stride > 1 else coords
+    points = coords.float() + (0.0 if stride == 1 else 0.3)
+    idx, w = B.trilinear_map(points.contiguous(), vox, stride)
+    off, ent = B.devox_csr(idx, w, vox.shape[0])
+    live = ((idx >= 0) & (w != 0)).cpu().numpy()
+    assert int(off[-1]) == int(live.sum()) and int(off[0]) == 0
+    offn, entn = off.cpu().numpy(), ent.cpu().numpy()[:int(off[-1])]
+    assert np.all(np.diff(offn) >= 0)
+    vox_of_slot = idx.cpu().numpy().reshape(-1)[entn]
+    assert np.array_equal(vox_of_slot, np.repeat(np.arange(vox.shape[0]), np.diff(offn)))      # grouped by voxel
+    assert np.all(live.reshape(-1)[entn])
+    within = np.diff(entn) > 0
+    assert np.all(within | (np.diff(vox_of_slot) > 0))                                         # ascending slots per voxel
+    g = T(np.random.RandomState(c + stride).randn(len(pc), c).astype(np.float32))
+    want = B.devoxelize_backward_cuda(g, idx, w, vox.shape[0])
+    got = B.devoxelize_backward_csr(g, w, (off, ent), vox.shape[0])
+    close(got, want, 2e-5)
+    assert torch.equal(got, B.devoxelize_backward_csr(g, w, (off, ent), vox.shape[0]))
+    if c == 32:
+        close(got, O.devoxelize_backward(g.cpu().numpy(), idx.cpu().numpy(), w.cpu().numpy(), vox.shape[0]), 2e-5)
