@@ -295,7 +295,7 @@ class MinkUNetBackbone(BaseSegmentor):
             z.additional_features["counts"][1] = plan["vox_counts"]
         x0 = spnn.conv_bn_act(self.stem[0], self.stem[1], x0, relu=True)          # stem = 2 x (conv, BN, ReLU)
         x0 = spnn.conv_bn_act(self.stem[3], self.stem[4], x0, relu=True)
-        z0 = voxel_to_point(x0, z, nearest=False)
+        z0 = voxel_to_point(x0, z, nearest=False, features=False)      # z0.F is never read (cache carrier only)
 
         x1 = self.stage1(x0)
         x2 = self.stage2(x1)

@@ -66,9 +66,11 @@ def _trilinear(x: SparseTensor, z: PointTensor, nearest: bool):
     return idx_query, weights
 
 
-def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> PointTensor:
+def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False, features: bool = True) -> PointTensor:
     """utils.py:69-107.  Trilinear devoxelisation of x's features onto z's points; the 8-corner
-    indices [N,8] and weights [N,8] are cached in `z` per voxel stride."""
+    indices [N,8] and weights [N,8] are cached in `z` per voxel stride.  features=False only fills that cache and
+    returns a PointTensor without features (MinkUNet's first call, minkunet.py:396: its z0.F is never read - the
+    point-branch MLPs that consume it exist in SPVCNN only)."""
     cached = (z.idx_query is not None and z.weights is not None
               and z.idx_query.get(x.s) is not None and z.weights.get(x.s) is not None)
     if not cached:
@@ -76,8 +78,8 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> Po
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
     order = (z.additional_features.get("devox_order") or {}).get(x.s)     # backward walk order, if the plan built one
-    out = PointTensor(F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s], order), z.C,
-                      idx_query=z.idx_query, weights=z.weights)
+    feats = F.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s], order) if features else None
+    out = PointTensor(feats, z.C, idx_query=z.idx_query, weights=z.weights)
     out.additional_features = z.additional_features
     return out
 
