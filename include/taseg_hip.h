@@ -290,6 +290,18 @@ int ts_bn_sync_backward_reduce(const float *grad_out, const uint8_t *mask, const
  *                              ws >= ts_devox_csr_workspace_bytes(n)
  *   ts_devoxelize_backward_csr grad_feat[v] = sum over the slots of v of weight[slot] * grad_out[point]: every row written
  *                              once, no fill, no atomics, fixed summation order (c % 4 == 0, 16-byte aligned rows) */
+/*   ts_devoxelize_forward_ld / ts_devoxelize_backward_runs_ld / ts_devoxelize_backward_csr_ld: the same with the point-side
+ *                              matrix `ld` floats per row (>= c, multiple of 4): the three devoxelisations of a
+ *                              MinkUNet pass write into / read from column blocks of one [N, 480] matrix (no torch.cat of
+ *                              z1 | z2 | z3 before the class head, no contiguous copies of its gradient slices) */
+int ts_devoxelize_forward_ld(const float *feat, const int32_t *idx, const float *weight, int64_t n, int32_t c, int64_t m,
+                             float *out, int64_t out_ld, ts_stream_t stream);
+int ts_devoxelize_backward_runs_ld(const float *grad_out, int64_t go_ld, const int32_t *idx, const float *weight,
+                                   const int32_t *order, int64_t n, int32_t c, int64_t m, float *grad_feat,
+                                   ts_stream_t stream);
+int ts_devoxelize_backward_csr_ld(const float *grad_out, int64_t go_ld, const float *weight, const int32_t *offsets,
+                                  const int32_t *entries, int64_t n, int32_t c, int64_t m, float *grad_feat,
+                                  ts_stream_t stream);
 size_t ts_devox_csr_workspace_bytes(int64_t n);
 int ts_devox_csr(const int32_t *idx, const float *weight, int64_t n, int64_t n_vox, int32_t *offsets, int32_t *entries,
                  void *ws, size_t ws_bytes, ts_stream_t stream);

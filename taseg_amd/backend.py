@@ -142,6 +142,39 @@ def devox_order(indices, n_vox):
     return order
 
 
+def devoxelize_forward_into(feat, indices, weight, out, col):
+    """devoxelize_forward_cuda writing out[:, col : col + C] of a wider point matrix in place (no later torch.cat)."""
+    L.require_device(feat, indices, weight, out)
+    feat, indices, weight = _f32(feat, "feat"), _i32(indices, "indices"), _f32(weight, "weight")
+    m, c = feat.shape
+    n = indices.shape[0]
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[0] != n or col + c > out.shape[1] or col % 4:
+        raise ValueError("devoxelize_forward_into: out must be a contiguous float32 [n, ld] matrix with room at `col`")
+    L.check(L.load().ts_devoxelize_forward_ld(L.ptr(feat), L.ptr(indices), L.ptr(weight), n, c, m, out.data_ptr() + 4 * col,
+                                              out.shape[1], L.stream()), "ts_devoxelize_forward_ld")
+
+
+def devoxelize_backward_from(grad, col, c, indices, weight, n_vox, order=None):
+    """Adjoint of devoxelize_forward_into for the column block grad[:, col : col + c]; `order` = a walk order
+    (devox_order), an inverse map (devox_csr) or None."""
+    L.require_device(grad, indices, weight)
+    indices, weight = _i32(indices, "indices"), _f32(weight, "weight")
+    if grad.dtype != torch.float32 or not grad.is_contiguous() or col + c > grad.shape[1] or col % 4 or grad.shape[1] % 4:
+        raise ValueError("devoxelize_backward_from: grad must be a contiguous float32 [n, ld] matrix, ld and col % 4 == 0")
+    n, ld = grad.shape
+    out = torch.empty((int(n_vox), c), dtype=torch.float32, device=grad.device)
+    lib = L.load()
+    if isinstance(order, tuple):
+        off, ent = order
+        L.check(lib.ts_devoxelize_backward_csr_ld(grad.data_ptr() + 4 * col, ld, L.ptr(weight), L.ptr(off), L.ptr(ent), n, c,
+                                                  int(n_vox), L.ptr(out), L.stream()), "ts_devoxelize_backward_csr_ld")
+    else:
+        L.check(lib.ts_devoxelize_backward_runs_ld(grad.data_ptr() + 4 * col, ld, L.ptr(indices), L.ptr(weight),
+                                                   L.ptr(order), n, c, int(n_vox), L.ptr(out), L.stream()),
+                "ts_devoxelize_backward_runs_ld")
+    return out
+
+
 def devox_csr(indices, weight, n_vox):
     """Inverse of a trilinear map for `devoxelize_backward_csr`: (offsets [n_vox + 1], entries [8 n]) int32."""
     L.require_device(indices, weight)

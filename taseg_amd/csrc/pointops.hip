@@ -84,7 +84,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const float *__restrict__ feat,
                                                              const int *__restrict__ idx,
                                                              const float *__restrict__ w, int64_t n, int c,
-                                                             float *__restrict__ out) {
+                                                             float *__restrict__ out, int64_t out_ld) {
   const int cv = c / VEC;
   int64_t total = n * cv;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const float *__rest
       }
     }
     if (VEC == 4) {
-      *(float4 *)(out + i * c + j) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+      *(float4 *)(out + i * out_ld + j) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
     } else {
-      out[i * c + j] = acc[0];
+      out[i * out_ld + j] = acc[0];
     }
   }
 }
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_runs_kernel(const float *_
                                                                   const int *__restrict__ idx,
                                                                   const float *__restrict__ w,
                                                                   const int *__restrict__ order, int64_t n, int c,
-                                                                  int64_t m, int run_len, float *__restrict__ gfeat) {
+                                                                  int64_t m, int run_len, float *__restrict__ gfeat,
+                                                                  int64_t go_ld) {
   const int cq = c >> 2, groups = 256 / cq;
   const int grp = threadIdx.x / cq, lane = threadIdx.x - grp * cq;
   if (grp >= groups) return;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_runs_kernel(const float *_
 #pragma unroll
       for (int k = 0; k < 8; ++k) cur[k] = id[k];
     }
-    const float4 g = *(const float4 *)(gout + i * c + 4 * lane);
+    const float4 g = *(const float4 *)(gout + i * go_ld + 4 * lane);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (id[k] >= 0 && id[k] < m && wk[k] != 0.f) {
@@ -214,18 +215,24 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_runs_kernel(const float *_
 
 extern "C" int ts_devoxelize_forward(const float *feat, const int32_t *idx, const float *weight, int64_t n,
                                      int32_t c, int64_t m, float *out, ts_stream_t stream_) {
+  return ts_devoxelize_forward_ld(feat, idx, weight, n, c, m, out, c, stream_);
+}
+
+// out rows `out_ld` floats apart (out_ld >= c): writes a column block of a wider matrix in place of a later torch.cat
+extern "C" int ts_devoxelize_forward_ld(const float *feat, const int32_t *idx, const float *weight, int64_t n, int32_t c,
+                                        int64_t m, float *out, int64_t out_ld, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_forward: bad sizes");
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0 && out_ld >= c, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_forward: bad sizes");
   if (n == 0) return TS_OK;
   TS_REQUIRE(out && idx && weight && (feat || m == 0), TS_ERR_INVALID_ARGUMENT,
              "ts_devoxelize_forward: null pointer");
-  bool vec = (c % 4 == 0) && (((uintptr_t)feat & 15) == 0) && (((uintptr_t)out & 15) == 0);
+  bool vec = (c % 4 == 0) && (out_ld % 4 == 0) && (((uintptr_t)feat & 15) == 0) && (((uintptr_t)out & 15) == 0);
   if (vec) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n * (c / 4), 256), 16384);
-    devoxelize_fwd_kernel<4><<<grid, 256, 0, stream>>>(feat, idx, weight, n, c, out);
+    devoxelize_fwd_kernel<4><<<grid, 256, 0, stream>>>(feat, idx, weight, n, c, out, out_ld);
   } else {
     int grid = (int)std::min<int64_t>(ts_cdiv(n * c, 256), 16384);
-    devoxelize_fwd_kernel<1><<<grid, 256, 0, stream>>>(feat, idx, weight, n, c, out);
+    devoxelize_fwd_kernel<1><<<grid, 256, 0, stream>>>(feat, idx, weight, n, c, out, out_ld);
   }
   TS_CHECK_LAUNCH("ts_devoxelize_forward");
   return TS_OK;
@@ -358,8 +365,16 @@ extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, 
 extern "C" int ts_devoxelize_backward_runs(const float *grad_out, const int32_t *idx, const float *weight,
                                            const int32_t *order, int64_t n, int32_t c, int64_t m, float *grad_feat,
                                            ts_stream_t stream_) {
+  return ts_devoxelize_backward_runs_ld(grad_out, c, idx, weight, order, n, c, m, grad_feat, stream_);
+}
+
+// grad_out rows `go_ld` floats apart: reads a column block of a wider gradient matrix without a contiguous copy
+extern "C" int ts_devoxelize_backward_runs_ld(const float *grad_out, int64_t go_ld, const int32_t *idx,
+                                              const float *weight, const int32_t *order, int64_t n, int32_t c, int64_t m,
+                                              float *grad_feat, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_runs: bad sizes");
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0 && go_ld >= c && (go_ld & 3) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_runs: bad sizes");
   TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_runs: C must be a multiple of 4, <= 1024");
   if (m == 0) return TS_OK;
   TS_REQUIRE(grad_feat, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_runs: null pointer");
@@ -372,7 +387,7 @@ extern "C" int ts_devoxelize_backward_runs(const float *grad_out, const int32_t 
   const int groups = 256 / (c >> 2);
   const int64_t n_groups = ts_cdiv(n, run_len);
   devoxelize_bwd_runs_kernel<<<(unsigned)ts_cdiv(n_groups, groups), 256, 0, stream>>>(grad_out, idx, weight, order, n,
-                                                                                      c, m, run_len, grad_feat);
+                                                                                      c, m, run_len, grad_feat, go_ld);
   TS_CHECK_LAUNCH("ts_devoxelize_backward_runs");
   return TS_OK;
 }
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
                                                                  const float *__restrict__ w,
                                                                  const int *__restrict__ off,
                                                                  const int *__restrict__ ent, int64_t m, int c,
-                                                                 float *__restrict__ gfeat) {
+                                                                 float *__restrict__ gfeat, int64_t go_ld) {
   const int cq = c >> 2, groups = 256 / cq;
   const int grp = threadIdx.x / cq, lane = threadIdx.x - grp * cq;
   if (grp >= groups) return;
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       wt[u] = w[s[u]];
-      g[u] = *(const float4 *)(gout + (int64_t)(s[u] >> 3) * c + 4 * lane);
+      g[u] = *(const float4 *)(gout + (int64_t)(s[u] >> 3) * go_ld + 4 * lane);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
   for (; e < end; ++e) {
     const int s = ent[e];
     const float wt = w[s];
-    const float4 g = *(const float4 *)(gout + (int64_t)(s >> 3) * c + 4 * lane);
+    const float4 g = *(const float4 *)(gout + (int64_t)(s >> 3) * go_ld + 4 * lane);
     acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
   }
   *(float4 *)(gfeat + v * c + 4 * lane) = acc;
@@ -422,8 +437,15 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
 extern "C" int ts_devoxelize_backward_csr(const float *grad_out, const float *weight, const int32_t *offsets,
                                           const int32_t *entries, int64_t n, int32_t c, int64_t m, float *grad_feat,
                                           ts_stream_t stream_) {
+  return ts_devoxelize_backward_csr_ld(grad_out, c, weight, offsets, entries, n, c, m, grad_feat, stream_);
+}
+
+extern "C" int ts_devoxelize_backward_csr_ld(const float *grad_out, int64_t go_ld, const float *weight,
+                                             const int32_t *offsets, const int32_t *entries, int64_t n, int32_t c,
+                                             int64_t m, float *grad_feat, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(n >= 0 && m >= 0 && c > 0, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_csr: bad sizes");
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0 && go_ld >= c && (go_ld & 3) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_csr: bad sizes");
   TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_csr: C must be a multiple of 4, <= 1024");
   if (m == 0) return TS_OK;
   TS_REQUIRE(grad_feat && offsets && (n == 0 || (grad_out && weight && entries)), TS_ERR_INVALID_ARGUMENT,
@@ -432,7 +454,7 @@ extern "C" int ts_devoxelize_backward_csr(const float *grad_out, const float *we
              "ts_devoxelize_backward_csr: rows must be 16-byte aligned");
   const int groups = 256 / (c >> 2);
   devoxelize_bwd_csr_kernel<<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(grad_out, weight, offsets, entries, m, c,
-                                                                             grad_feat);
+                                                                             grad_feat, go_ld);
   TS_CHECK_LAUNCH("ts_devoxelize_backward_csr");
   return TS_OK;
 }

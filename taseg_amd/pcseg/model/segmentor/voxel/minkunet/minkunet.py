@@ -281,11 +281,13 @@ class MinkUNetBackbone(BaseSegmentor):
 
     def _unet(self, feats: torch.Tensor, point_feats: torch.Tensor, plan) -> torch.Tensor:
         """stem .. classifier on the stride-1 voxel features and their point view; returns logits [N, num_class]."""
-        return self.classifier(torch.cat(self._unet_point_features(feats, point_feats, plan), dim=1))
+        return self.classifier(self._unet_point_features(feats, point_feats, plan, concat=True))
 
-    def _unet_point_features(self, feats: torch.Tensor, point_feats: torch.Tensor, plan):
+    def _unet_point_features(self, feats: torch.Tensor, point_feats: torch.Tensor, plan, concat: bool = False):
         """The encoder / decoder pass; returns the three per-point feature blocks the classifier concatenates:
-        stride-16 encoder output, stride-4 and stride-1 decoder outputs, each devoxelised onto the points."""
+        stride-16 encoder output, stride-4 and stride-1 decoder outputs, each devoxelised onto the points.
+        concat=True returns them as ONE [N, C1 + C2 + C3] tensor, interpolated straight into its column blocks
+        (`spF.spdevoxelize_cat`: no torch.cat, no copies of the gradient slices in the backward pass)."""
         x0 = SparseTensor(feats, plan["coords"], 1)
         x0.cmaps, x0.kmaps = plan["cmaps"], plan["kmaps"]
         z = PointTensor(point_feats, plan["point_coords"], idx_query=plan["tri_idx"], weights=plan["tri_w"])
@@ -301,16 +303,29 @@ class MinkUNetBackbone(BaseSegmentor):
         x2 = self.stage2(x1)
         x3 = self.stage3(x2)
         x4 = self.stage4(x3)
-        z1 = voxel_to_point(x4, z0)
+        concat = concat and all(k in plan["tri_idx"] for k in (x4.s, x2.s, x0.s))
+        sources = []                                   # (voxel features before dropout, stride) of z1, z2, z3
+        if concat:
+            sources.append((x4.F, x4.s))
+        else:
+            z1 = voxel_to_point(x4, z0)
 
         x4.F = self.dropout(x4.F)
         y1 = self.up1[1](torchsparse.cat([self.up1[0](x4), x3]))
         y2 = self.up2[1](torchsparse.cat([self.up2[0](y1), x2]))
-        z2 = voxel_to_point(y2, z1)
+        if concat:
+            sources.append((y2.F, y2.s))
+        else:
+            z2 = voxel_to_point(y2, z1)
 
         y2.F = self.dropout(y2.F)
         y3 = self.up3[1](torchsparse.cat([self.up3[0](y2), x1]))
         y4 = self.up4[1](torchsparse.cat([self.up4[0](y3), x0]))
+        if concat:
+            sources.append((y4.F, y4.s))
+            orders = plan["tri_order"]
+            return spF.spdevoxelize_cat([f for f, _ in sources],
+                                        [(plan["tri_idx"][k], plan["tri_w"][k], orders.get(k)) for _, k in sources])
         z3 = voxel_to_point(y4, z2)
         return z1.F, z2.F, z3.F
 

@@ -21,7 +21,7 @@ from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from .utils import get_kernel_offsets
 
-__all__ = ["conv3d", "conv_geometry", "conv_block_ok", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "calc_ti_weights",
+__all__ = ["conv3d", "conv_geometry", "conv_block_ok", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "spdevoxelize_cat", "calc_ti_weights",
            "spdownsample", "KernelMap", "build_kernel_map", "build_pyramid", "point_linear"]
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -109,6 +109,47 @@ def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tenso
     `backend.devox_order`) only schedules the backward pass: points of the same interpolation cell are walked
     together so their contributions reach the voxel gradient as one atomic per run."""
     return _Devoxelize.apply(feats, coords, weights, order)
+
+
+class _DevoxelizeCat(Function):
+    """torch.cat([spdevoxelize(f_i, idx_i, w_i) for i], dim=1) as one node: every source is interpolated straight into its
+    column block of the [N, sum C_i] result and the backward pass reads the gradient blocks in place - no concatenation
+    copy, no contiguous copies of gradient slices (MinkUNet's z1 | z2 | z3 -> class head, minkunet.py:419-421)."""
+
+    @staticmethod
+    def forward(ctx, maps, *feats):
+        half = _amp_half(feats[0])
+        n = maps[0][0].shape[0]
+        cs = [f.shape[1] for f in feats]
+        out = torch.empty((n, sum(cs)), dtype=torch.float32, device=feats[0].device)
+        col = 0
+        for f, (idx, w, _order), c in zip(feats, maps, cs):
+            B.devoxelize_forward_into(f.contiguous().float(), idx, w, out, col)
+            col += c
+        ctx.maps, ctx.cs = maps, cs
+        ctx.rows = [f.shape[0] for f in feats]
+        ctx.dtypes = [f.dtype for f in feats]
+        return out.half() if half else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = grad_out.contiguous().float()
+        grads, col = [], 0
+        for i, ((idx, w, order), c) in enumerate(zip(ctx.maps, ctx.cs)):
+            if ctx.needs_input_grad[1 + i]:
+                grads.append(B.devoxelize_backward_from(g, col, c, idx, w, ctx.rows[i], order).to(ctx.dtypes[i]))
+            else:
+                grads.append(None)
+            col += c
+        return (None, *grads)
+
+
+def spdevoxelize_cat(feats, maps) -> torch.Tensor:
+    """Concatenation along the channels of spdevoxelize(feats[i], *maps[i][:2]); maps[i] = (coords [N, 8], weights
+    [N, 8], order | inverse map | None).  Channel counts must be multiples of 4 (else: the plain ops)."""
+    if all(f.is_cuda and f.shape[1] % 4 == 0 for f in feats):
+        return _DevoxelizeCat.apply([(i.int().contiguous(), w.contiguous().float(), o) for i, w, o in maps], *feats)
+    return torch.cat([spdevoxelize(f, i, w, o) for f, (i, w, o) in zip(feats, maps)], dim=1)
 
 
 def calc_ti_weights(coords: torch.Tensor, idx_query: torch.Tensor, scale: float = 1) -> torch.Tensor:

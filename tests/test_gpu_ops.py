@@ -721,3 +721,32 @@ def test_devoxelize_backward_along_inverse_map(B, F, c, stride):
     assert torch.equal(got, B.devoxelize_backward_csr(g, w, (off, ent), vox.shape[0]))
     if c == 32:
         close(got, O.devoxelize_backward(g.cpu().numpy(), idx.cpu().numpy(), w.cpu().numpy(), vox.shape[0]), 2e-5)
+
+
+def test_devoxelize_cat_equals_cat_of_devoxelize(B, F):
+    """spdevoxelize_cat (three interpolations into column blocks of one matrix, gradient blocks read in place) against
+    torch.cat of three spdevoxelize calls: same values, same feature gradients (walk order / inverse map / plain)"""
+    from taseg_amd.data.synthetic import synth_scan
+    pts, _ = synth_scan(9, n_points=20000)
+    pc = np.unique(np.round(pts[:, :3] / 0.05).astype(np.int32), axis=0)
+    pc -= pc.min(0, keepdims=True)
+    coords = T(np.concatenate([pc, np.zeros((len(pc), 1), np.int32)], 1))
+    rs = np.random.RandomState(3)
+    maps, feats = [], []
+    for stride, c, kind in ((16, 64, "order"), (4, 32, "csr"), (1, 96, None)):
+        vox = F.spdownsample(coords, stride, stride, 1) if stride > 1 else coords
+        points = coords.float() + (0.0 if stride == 1 else 0.3)
+        idx, w = B.trilinear_map(points.contiguous(), vox, stride)
+        order = B.devox_order(idx, vox.shape[0]) if kind == "order" else B.devox_csr(idx, w, vox.shape[0]) if kind == "csr" else None
+        maps.append((idx, w, order))
+        feats.append(T(rs.randn(vox.shape[0], c).astype(np.float32)))
+    gy = T(rs.randn(len(pc), 64 + 32 + 96).astype(np.float32))
+    a = [f.clone().requires_grad_() for f in feats]
+    ya = F.spdevoxelize_cat(a, maps)
+    ya.backward(gy)
+    b = [f.clone().requires_grad_() for f in feats]
+    yb = torch.cat([F.spdevoxelize(f, i, w, o) for f, (i, w, o) in zip(b, maps)], dim=1)
+    yb.backward(gy)
+    assert torch.equal(ya, yb)
+    for fa, fb in zip(a, b):
+        close(fa.grad, fb.grad, 2e-5)
