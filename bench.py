@@ -25,7 +25,7 @@ MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (same guide; no sparsity)
 MFMA_SPLIT_PEAK_TF = MFMA_F16_PEAK_TF / 6   # fp32 products as six bf16 MFMAs (csrc/conv_pairs_s.hip): 416.7 TF/s of fp32 flops
 VOXEL = 0.05
-EVENT_EVERY = 20            # per-launch HIP events bracket the conv kernels of every 20th timed step (those steps run the unfused wrappers)
+EVENT_EVERY = 10            # per-launch HIP events bracket the conv kernels of every 10th timed step (those steps run the unfused wrappers)
 
 
 def parse():
