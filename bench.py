@@ -25,7 +25,8 @@ MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (same guide; no sparsity)
 MFMA_SPLIT_PEAK_TF = MFMA_F16_PEAK_TF / 6   # fp32 products as six bf16 MFMAs (csrc/conv_pairs_s.hip): 416.7 TF/s of fp32 flops
 VOXEL = 0.05
-EVENT_EVERY = 10            # per-launch HIP events bracket the conv kernels of every 10th timed step (those steps run the unfused wrappers)
+EVENT_EVERY = 10            # per-launch HIP events bracket the conv kernels of every 10th timed step (recorded inside the
+                            # block calls; an event pair costs ~3 us of device time per launch: ~2 ms on such a step)
 
 
 def parse():
@@ -161,7 +162,7 @@ def summarise_profile(records, steps):
             if key not in pairs_cache:
                 pairs_cache[key] = int((m["nbr"] >= 0).sum())
             p = pairs_cache[key]
-        elif kind == "conv_wgrad":
+        elif kind == "conv_wgrad" and "nboffs" in m:
             key = m["nboffs"].data_ptr()
             if key not in pairs_cache:
                 pairs_cache[key] = int(m["nboffs"][-1])
@@ -317,7 +318,7 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)      # every rank: push RCCL's C-stdio version banner out before the result line
     if not args.no_kernel_events:
-        B.profile_begin()
+        B.profile_begin(expected_launches=800 * len(range(0, args.steps, EVENT_EVERY)))   # ~330 (bs 2) .. per step
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not args.no_kernel_events:

@@ -438,6 +438,15 @@ int ts_conv_block_backward(const void *grad_out, const uint8_t *mask, const void
                            void *grad_feat, void *grad_residual, float *grad_kernel, float *grad_bn_weight,
                            float *grad_bn_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
 
+/* Per-launch timing inside ts_conv_block_*: while enabled, every pair-GEMM / gather-sum / weight-gradient launch of the
+ * block calls is bracketed by HIP events on the caller's stream.  ts_prof_collect waits for them and writes one record
+ * of 9 doubles per launch: kind (0 pair GEMM, 1 gather-sum, 2 weight gradient), milliseconds, pairs, c_red, c_out, K,
+ * rows, bytes per element, weight-transposed flag; returns the number of records (-1: HIP error).  ts_prof_reserve
+ * creates events ahead of time (two per bracketed launch) so that none is created inside a timed region. */
+void ts_prof_enable(int32_t on);
+int ts_prof_reserve(int64_t n_events);
+int64_t ts_prof_collect(double *records, int64_t capacity);
+
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default; full-tile fp32 GEMMs run on the bf16 matrix
  * pipe through the exact three-way operand split of csrc/conv_pairs_s.hip), 5 = the same with v_mfma_f32_16x16x4_f32,
  * 1 = scalar reference kernels (one thread per output element, atomics),

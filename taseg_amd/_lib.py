@@ -98,6 +98,9 @@ SIGNATURES = {
                                      _vp, _sz, _vp]),
     "ts_conv_block_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp,
                                       _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_prof_enable": (None, [_i32]),
+    "ts_prof_reserve": (_i32, [_i64]),
+    "ts_prof_collect": (_i64, [_vp, _i64]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

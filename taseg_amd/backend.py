@@ -10,6 +10,7 @@ torch (memory + stream plumbing only).
 import torch
 
 from . import _lib as L
+from ._lib import BackendError, check
 
 __all__ = [
     "hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda",
@@ -471,9 +472,15 @@ _prof = None
 _prof_store = None
 
 
-def profile_begin():
+def profile_begin(expected_launches=0):
+    """Start recording per-launch events.  `expected_launches` = bracketed launches until profile_end(): their events
+    are created now instead of inside the recorded steps."""
     global _prof, _prof_store
     _prof = _prof_store = []
+    lib = L.load()
+    if expected_launches:
+        check(lib.ts_prof_reserve(2 * int(expected_launches)), "ts_prof_reserve")
+    lib.ts_prof_enable(1)           # the fused block calls bracket their own launches (csrc/block.hip)
 
 
 def profile_pause(paused):
@@ -481,12 +488,52 @@ def profile_pause(paused):
     events per launch cost ~5 us of host time each, ~3 ms per step when every launch is bracketed)."""
     global _prof
     _prof = None if paused else _prof_store
+    L.load().ts_prof_enable(0 if paused else 1)
+
+
+class _Ms:
+    """stands in for the (start, stop) event pair of a launch the library timed itself"""
+    __slots__ = ("ms",)
+
+    def __init__(self, ms):
+        self.ms = ms
+
+    def elapsed_time(self, _other):
+        return self.ms
 
 
 def profile_end():
+    """[(kind, start, stop, meta)] of the bracketed launches: the Python wrappers' torch events and the records of the
+    fused block calls (`ts_prof_collect`)."""
     global _prof, _prof_store
     out, _prof, _prof_store = _prof_store, None, None
-    return out or []
+    out = out or []
+    lib = L.load()
+    lib.ts_prof_enable(0)
+    import ctypes
+    cap = 1 << 16
+    buf = (ctypes.c_double * (9 * cap))()
+    n = int(lib.ts_prof_collect(buf, cap))
+    if n < 0:
+        raise BackendError("ts_prof_collect failed")
+    for i in range(n):
+        kind, ms, pairs, c_red, c_out, k, rows, esize, wt = buf[9 * i:9 * i + 9]
+        c_red, c_out, k, pairs, rows, esize = int(c_red), int(c_out), int(k), int(pairs), int(rows), int(esize)
+        half = esize == 2
+        pick = lambda c: 128 if c % 128 == 0 else 96 if c % 96 == 0 else 64 if c % 64 == 0 else 32  # noqa: E731
+        if int(kind) == 0:
+            name = f"pair_gemm_h_kernel<{pick(c_out)}>" if half else pair_gemm_kernel_name(c_out, bool(wt), c_red)
+            out.append(("pair_gemm", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k, esize=esize)))
+        elif int(kind) == 1:
+            name = (f"gather_sum_h_kernel<{k if k in (8, 27) else 0}>" if half else
+                    f"gather_sum_kernel<4,{k if k in (8, 27) else 0}>" if c_out % 4 == 0 else "gather_sum_kernel<1,0>")
+            out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,
+                                                          esize=esize)))
+        else:
+            name = f"wgrad_h_kernel<{pick(c_red)},{pick(c_out)}>" if half else conv_kernel_name(c_red, wgrad_cb=c_out)
+            out.append(("conv_wgrad", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k,
+                                                          esize=esize)))
+    return out
 
 
 class _NoTimer:

@@ -9,6 +9,8 @@
 // caller's workspace.  What they remove is host work: the step of a 2-scan batch is ~1200 launches, and with one
 // Python -> C crossing and one autograd node per block instead of four / two the host side of the step drops below
 // the device side on slow hosts too.
+#include <vector>
+
 #include "common.h"
 
 static inline size_t blk_align(size_t x) { return ts_align_up(x, 256); }
@@ -30,6 +32,86 @@ extern "C" size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_
     const int rc_ = (expr);       \
     if (rc_ != TS_OK) return rc_; \
   } while (0)
+
+// ---- per-launch timing of the convolution kernels inside the block calls (bench.py's roofline figures) --------------
+// While recording is on, every pair-GEMM / gather-sum / weight-gradient launch issued by ts_conv_block_* is bracketed by
+// two HIP events on the caller's stream (from a pool created on first use).  ts_prof_collect synchronises the events
+// and returns one record per launch: {kind (0 pair GEMM, 1 gather-sum, 2 weight gradient), milliseconds, pairs,
+// c_red, c_out, K, rows, bytes per element, weight transposed}.  Off (the default): one predictable branch per launch.
+namespace {
+struct ProfRec {
+  int kind;
+  hipEvent_t e0, e1;
+  double meta[7];
+};
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+bool g_prof_on = false;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct ProfScope {
+  bool live = false;
+  ProfRec rec;
+  hipStream_t stream;
+  ProfScope(int kind, ts_stream_t s, double pairs, double c_red, double c_out, double k, double rows, double esize, double wt)
+      : stream((hipStream_t)s) {
+    if (!g_prof_on) return;
+    rec.kind = kind;
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    if (!rec.e0 || !rec.e1) return;
+    const double m[7] = {pairs, c_red, c_out, k, rows, esize, wt};
+    for (int i = 0; i < 7; ++i) rec.meta[i] = m[i];
+    live = hipEventRecord(rec.e0, stream) == hipSuccess;
+  }
+  ~ProfScope() {
+    if (live && hipEventRecord(rec.e1, stream) == hipSuccess) g_prof.push_back(rec);
+  }
+};
+}  // namespace
+
+extern "C" void ts_prof_enable(int32_t on) { g_prof_on = on != 0; }
+
+// create `n_events` events ahead of time (hipEventCreate costs ~15 us; the pool otherwise grows inside the first
+// recorded steps)
+extern "C" int ts_prof_reserve(int64_t n_events) {
+  while ((int64_t)g_prof_pool.size() < n_events) {
+    hipEvent_t e = nullptr;
+    TS_CHECK_HIP(hipEventCreate(&e), "hipEventCreate");
+    g_prof_pool.push_back(e);
+  }
+  return TS_OK;
+}
+
+// records [capacity][9] doubles out; returns the number of records written (and forgets them), or -1 on a HIP error
+extern "C" int64_t ts_prof_collect(double *records, int64_t capacity) {
+  int64_t n = 0;
+  for (const ProfRec &r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return -1;
+    if (n < capacity && records) {
+      double *o = records + n * 9;
+      o[0] = r.kind;
+      o[1] = ms;
+      for (int i = 0; i < 7; ++i) o[2 + i] = r.meta[i];
+      ++n;
+    }
+    g_prof_pool.push_back(r.e0);
+    g_prof_pool.push_back(r.e1);
+  }
+  g_prof.clear();
+  return n;
+}
 
 // out = act(BN(conv(feat)) [+ residual]).
 //   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
@@ -68,12 +150,24 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
     // load (ts_conv_pair_gemm_f16_nat), the input gradient directly
     (void)w16t;
     TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
-    TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
-    TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
+    {
+      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, 0, 2, 0);
+      TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
+    }
+    {
+      ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 2, 0);
+      TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
+    }
   } else {
-    TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
-                             (float *)z, c_out, stream));
-    TS_TRY(ts_conv_gather_sum((const float *)z, c_out, pos, K, n_out, n_pairs, (float *)conv_out, stream));
+    {
+      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, 0, 4, 0);
+      TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
+                               (float *)z, c_out, stream));
+    }
+    {
+      ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 4, 0);
+      TS_TRY(ts_conv_gather_sum((const float *)z, c_out, pos, K, n_out, n_pairs, (float *)conv_out, stream));
+    }
   }
   if (comm)
     return ts_bn_sync_forward(comm, conv_out, residual, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked,
@@ -133,23 +227,32 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                          (((uintptr_t)grad_kernel) & 15) == 0;
   float *zp = side_zero ? grad_kernel : nullptr;
   const int64_t zn = side_zero ? gk_floats : 0;
-  if (half) {
-    if (grad_feat) {
-      TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
-                                   stream));
-      TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, zp, zn, stream));
+  const double es_d = half ? 2 : 4;
+  if (grad_feat) {
+    {
+      ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, 0, es_d, 1);
+      if (half)
+        TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
+                                     stream));
+      else
+        TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs,
+                                 n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
     }
-    if (grad_kernel)
+    {
+      ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, 0);
+      if (half)
+        TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, zp, zn, stream));
+      else
+        TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat, zp,
+                                     zn, stream));
+    }
+  }
+  if (grad_kernel) {
+    ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, 0, es_d, 0);
+    if (half)
       TS_TRY(ts_conv_wgrad_f16_ex(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel,
                                   side_zero ? 1 : 0, stream));
-  } else {
-    if (grad_feat) {
-      TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs,
-                               n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
-      TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat, zp, zn,
-                                   stream));
-    }
-    if (grad_kernel)
+    else
       TS_TRY(ts_conv_wgrad_ex((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a,
                               n_pairs, grad_kernel, side_zero ? 1 : 0, stream));
   }

@@ -122,8 +122,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     ks, stride = conv.kernel_size, conv.stride
     dil = make_ntuple(conv.dilation, ndim=3)
     if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and mod.momentum is not None and mod.affine \
-            and not (conv._forward_hooks or conv._forward_pre_hooks) and _B._prof is None:
-        # (hooks on the conv module must still fire; bench.py's per-launch events live in the unfused wrappers)
+            and not (conv._forward_hooks or conv._forward_pre_hooks):      # hooks on the conv module must still fire
         group = _sync_group(mod)
         comm = None if group is None else direct_comm(group)
         if group is None or comm is not None:
