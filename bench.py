@@ -270,11 +270,20 @@ def main():
         offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
         nvox[0] = int(coords.shape[0])
 
+        _cached = {}
+
         def make_batch():
-            return {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset}
+            bd = {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset}
+            if os.environ.get("TASEG_REUSE_PLAN") == "1":      # diagnostic: what the step costs without any staging work
+                if "_plan" in _cached:
+                    bd["_plan"] = _cached["_plan"]
+                else:
+                    _cached["_plan"] = model.prepare(bd)
+            return bd
 
     from taseg_amd.data.stage import DevicePrefetcher
-    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare,
+    prepare = (lambda bd: bd.get("_plan") or model.prepare(bd)) if os.environ.get("TASEG_REUSE_PLAN") == "1" else model.prepare
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, prepare,
                                                         threaded=os.environ.get("TASEG_STAGE_THREAD", "0") == "1")
 
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
