@@ -356,7 +356,7 @@ def conv_pair_gemm(feat, kernel, nbmaps, nboffs, n_pairs, gather_col, weight_tra
         raise ValueError("Input feature size and kernel size mismatch")
     z = torch.empty((int(n_pairs), c_out), dtype=torch.float32, device=feat.device)
     with _Timed("pair_gemm", name=pair_gemm_kernel_name(c_out, weight_transposed, c_red), pairs=int(n_pairs), c_red=c_red,
-                c_out=c_out, k=k):
+                c_out=c_out, k=k, n_rows=feat.shape[0]):
         L.check(L.load().ts_conv_pair_gemm(L.ptr(feat), feat.shape[0], c_red, L.ptr(kernel), k,
                                            1 if weight_transposed else 0, L.ptr(nbmaps), L.ptr(nboffs),
                                            int(n_pairs), int(gather_col), L.ptr(z), c_out, L.stream()),
@@ -412,7 +412,7 @@ def conv_pair_gemm_f16(feat, w_rows, nbmaps, nboffs, n_pairs, gather_col, natura
         raise ValueError("Input feature size and kernel size mismatch")
     z = torch.empty((int(n_pairs), c_out), dtype=torch.float16, device=feat.device)
     with _Timed("pair_gemm", name=f"pair_gemm_h_kernel<{128 if c_out % 128 == 0 else 96 if c_out % 96 == 0 else 64 if c_out % 64 == 0 else 32}>",
-                pairs=int(n_pairs), c_red=c_red, c_out=c_out, k=k, esize=2):
+                pairs=int(n_pairs), c_red=c_red, c_out=c_out, k=k, esize=2, n_rows=feat.shape[0]):
         fn = L.load().ts_conv_pair_gemm_f16_nat if natural else L.load().ts_conv_pair_gemm_f16
         L.check(fn(L.ptr(feat), feat.shape[0], c_red, L.ptr(w_rows), k, L.ptr(nbmaps), L.ptr(nboffs), int(n_pairs),
                    int(gather_col), L.ptr(z), c_out, L.stream()), "ts_conv_pair_gemm_f16")
@@ -442,7 +442,8 @@ def conv_wgrad_f16(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pai
     out = torch.empty((kernel_volume, a_feat.shape[1], b_feat.shape[1]), dtype=torch.float32, device=a_feat.device)
     pick = lambda c: 128 if c % 128 == 0 else 96 if c % 96 == 0 else 64 if c % 64 == 0 else 32  # noqa: E731
     with _Timed("conv_wgrad", name=f"wgrad_h_kernel<{pick(a_feat.shape[1])},{pick(b_feat.shape[1])}>", nboffs=nboffs,
-                c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume, esize=2):
+                c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume, esize=2, n_rows=a_feat.shape[0],
+                n_rows_b=b_feat.shape[0]):
         L.check(L.load().ts_conv_wgrad_f16(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
                                            L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
                                            L.ptr(out), L.stream()), "ts_conv_wgrad_f16")
@@ -523,7 +524,8 @@ def profile_end():
         pick = lambda c: 128 if c % 128 == 0 else 96 if c % 96 == 0 else 64 if c % 64 == 0 else 32  # noqa: E731
         if int(kind) == 0:
             name = f"pair_gemm_h_kernel<{pick(c_out)}>" if half else pair_gemm_kernel_name(c_out, bool(wt), c_red)
-            out.append(("pair_gemm", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k, esize=esize)))
+            out.append(("pair_gemm", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k, esize=esize,
+                                                         n_rows=rows)))
         elif int(kind) == 1:
             name = (f"gather_sum_h_kernel<{k if k in (8, 27) else 0}>" if half else
                     f"gather_sum_kernel<4,{k if k in (8, 27) else 0}>" if c_out % 4 == 0 else "gather_sum_kernel<1,0>")
@@ -532,7 +534,7 @@ def profile_end():
         else:
             name = f"wgrad_h_kernel<{pick(c_red)},{pick(c_out)}>" if half else conv_kernel_name(c_red, wgrad_cb=c_out)
             out.append(("conv_wgrad", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k,
-                                                          esize=esize)))
+                                                          esize=esize, n_rows=rows, n_rows_b=int(wt))))
     return out
 
 
@@ -630,7 +632,8 @@ def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
     nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
     out = torch.empty((kernel_volume, a_feat.shape[1], b_feat.shape[1]), dtype=torch.float32, device=a_feat.device)
     with _Timed("conv_wgrad", name=conv_kernel_name(a_feat.shape[1], wgrad_cb=b_feat.shape[1]), nboffs=nboffs,
-                c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume):
+                c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume, n_rows=a_feat.shape[0],
+                n_rows_b=b_feat.shape[0]):
         L.check(L.load().ts_conv_wgrad(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
                                        L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
                                        L.ptr(out), L.stream()), "ts_conv_wgrad")

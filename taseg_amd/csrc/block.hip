@@ -37,7 +37,8 @@ extern "C" size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_
 // While recording is on, every pair-GEMM / gather-sum / weight-gradient launch issued by ts_conv_block_* is bracketed by
 // two HIP events on the caller's stream (from a pool created on first use).  ts_prof_collect synchronises the events
 // and returns one record per launch: {kind (0 pair GEMM, 1 gather-sum, 2 weight gradient), milliseconds, pairs,
-// c_red, c_out, K, rows, bytes per element, weight transposed}.  Off (the default): one predictable branch per launch.
+// c_red, c_out, K, rows (pair GEMM / weight gradient: rows of the gathered matrix; gather-sum: rows written), bytes per
+// element, weight transposed (weight gradient: rows of the second operand)}.  Off (the default): one predictable branch per launch.
 namespace {
 struct ProfRec {
   int kind;
@@ -151,7 +152,7 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
     (void)w16t;
     TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
     {
-      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, 0, 2, 0);
+      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 2, 0);
       TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
     }
     {
@@ -160,7 +161,7 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
     }
   } else {
     {
-      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, 0, 4, 0);
+      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 4, 0);
       TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
                                (float *)z, c_out, stream));
     }
@@ -230,7 +231,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   const double es_d = half ? 2 : 4;
   if (grad_feat) {
     {
-      ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, 0, es_d, 1);
+      ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, 1);
       if (half)
         TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
                                      stream));
@@ -248,7 +249,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     }
   }
   if (grad_kernel) {
-    ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, 0, es_d, 0);
+    ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, (double)n_out);
     if (half)
       TS_TRY(ts_conv_wgrad_f16_ex(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel,
                                   side_zero ? 1 : 0, stream));

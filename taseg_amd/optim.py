@@ -66,9 +66,19 @@ class FlatSGD:
                                   float(self.growth), float(self.backoff), int(self.interval), 1 if self.amp else 0, st),
                 "ts_sgd_decide")
         for b in self.reducer.buckets:
+            # parameters that received no gradient on ANY rank this step (an unused head, a frozen branch): torch.optim.SGD
+            # skips them entirely - no weight decay, no momentum update (R/pcseg/optim/__init__.py:15-21 builds that
+            # optimizer).  The flat update touches the whole bucket, so their slices are put back afterwards.
+            keep = []
+            for i in b.get("unused", ()):
+                off, n = b["offsets"][i], b["params"][i].numel()
+                keep.append((off, n, b["pflat"][off:off + n].clone(), b["mflat"][off:off + n].clone()))
             L.check(lib.ts_sgd_apply(L.ptr(b["pflat"]), L.ptr(b["flat"]), L.ptr(b["mflat"]), b["flat"].numel(),
                                      L.ptr(self.state), float(self.lr), float(self.momentum), float(self.weight_decay),
                                      1 if self._first else 0, st), "ts_sgd_apply")
+            for off, n, pv, mv in keep:
+                b["pflat"][off:off + n].copy_(pv)
+                b["mflat"][off:off + n].copy_(mv)
         # (a skipped very first step leaves the momentum buffers zero, which `first` = 0 then treats correctly:
         #  momentum * 0 + d = d)
         self._first = False

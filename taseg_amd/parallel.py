@@ -75,7 +75,9 @@ class GradBucketReducer:
     Pass a dedicated `process_group` (dist.new_group()) when other small collectives (SyncBatchNorm) run during
     backward: collectives of one communicator execute in order on one stream.
     Buckets follow reverse registration order (roughly the order gradients appear).  Parameters that received no
-    gradient in a step count as zeros.  Works with any backend (RCCL on GPU, gloo in the CPU tests)."""
+    gradient in a step are reduced as zeros (every rank must contribute the same buffer) and listed in
+    bucket["unused"] so that the optimizer can leave them untouched like torch.optim.SGD does.  Contract: ONE backward
+    pass per finish(); a second one raises.  Works with any backend (RCCL on GPU, gloo in the CPU tests)."""
 
     def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: float = 32.0, broadcast: bool = True):
         self.group = process_group
@@ -115,10 +117,16 @@ class GradBucketReducer:
         flat = torch.zeros(off, dtype=first.dtype, device=first.device)
         views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, params)]
         self.buckets.append({"params": list(params), "flat": flat, "views": views, "offsets": offsets,
-                             "pending": len(params), "launched": False})
+                             "pending": len(params), "launched": False, "unused": []})
 
     def _make_hook(self, bucket):
         def hook(_param):
+            if bucket["launched"] or bucket["pending"] <= 0:
+                # a second backward before finish() (gradient accumulation, retain_graph): the bucket's all-reduce is
+                # already in flight and p.grad aliases the buffer it reduces - adding into it now would race with
+                # the collective and leave the ranks with different gradients
+                raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket whose all-reduce was already "
+                                   "launched - exactly one backward pass per finish() / optimizer step is supported")
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
                 self._launch(bucket)
@@ -126,6 +134,7 @@ class GradBucketReducer:
 
     def _launch(self, bucket):
         src, dst = [], []
+        bucket["unused"] = [i for i, p in enumerate(bucket["params"]) if p.grad is None]
         for p, v in zip(bucket["params"], bucket["views"]):
             if p.grad is None:
                 v.zero_()

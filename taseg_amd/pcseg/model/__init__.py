@@ -1,13 +1,11 @@
 """`pcseg.model` entry points the OpenPCSeg trainer calls (reference pcseg/model/__init__.py:10-48)."""
-from collections import namedtuple
-
 import numpy as np
 import torch
 
 from ...torchsparse import SparseTensor
 from .segmentor import build_segmentor
 
-__all__ = ["build_network", "load_data_to_gpu", "model_fn_decorator"]
+__all__ = ["build_network", "load_data_to_gpu"]
 
 
 def build_network(model_cfgs, num_class):
@@ -30,18 +28,3 @@ def load_data_to_gpu(batch_dict):
             pass
         else:
             raise ValueError("Invalid type of batch_dict", key, type(val))
-
-
-def model_fn_decorator():
-    ModelReturn = namedtuple("ModelReturn", ["loss", "tb_dict", "disp_dict"])
-
-    def model_func(model, batch_dict):
-        load_data_to_gpu(batch_dict)
-        ret_dict, tb_dict, disp_dict = model(batch_dict)
-        loss = ret_dict["loss"].mean()
-        target = model if hasattr(model, "update_global_step") else model.module
-        if hasattr(target, "update_global_step"):
-            target.update_global_step()
-        return ModelReturn(loss, tb_dict, disp_dict)
-
-    return model_func

@@ -310,7 +310,9 @@ class MinkUNetBackbone(BaseSegmentor):
         else:
             z1 = voxel_to_point(x4, z0)
 
-        x4.F = self.dropout(x4.F)
+        # out of place: `sources` (and the ReLU node that produced x4.F) still hold the features BEFORE dropout - the
+        # reference devoxelises z1 / z2 before its in-place dropout (minkunet.py:400-412)
+        x4.F = torch.nn.functional.dropout(x4.F, self.dropout.p, self.training, False)
         y1 = self.up1[1](torchsparse.cat([self.up1[0](x4), x3]))
         y2 = self.up2[1](torchsparse.cat([self.up2[0](y1), x2]))
         if concat:
@@ -318,7 +320,7 @@ class MinkUNetBackbone(BaseSegmentor):
         else:
             z2 = voxel_to_point(y2, z1)
 
-        y2.F = self.dropout(y2.F)
+        y2.F = torch.nn.functional.dropout(y2.F, self.dropout.p, self.training, False)
         y3 = self.up3[1](torchsparse.cat([self.up3[0](y2), x1]))
         y4 = self.up4[1](torchsparse.cat([self.up4[0](y3), x0]))
         if concat:

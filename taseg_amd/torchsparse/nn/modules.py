@@ -69,6 +69,7 @@ def _bn_forward(mod, feats, torch_forward, group=None):
     """Training mode with batch statistics -> our reduction kernels; everything else (eval mode,
     momentum=None cumulative averaging, odd channel counts) -> the stock torch module."""
     from .batchnorm import batch_norm_train, fast_path_ok
+    _require_rows(feats, group)
     if mod.training and mod.momentum is not None and mod.affine and fast_path_ok(feats):
         rm = mod.running_mean if mod.track_running_stats else None
         rv = mod.running_var if mod.track_running_stats else None
@@ -89,6 +90,15 @@ def _sync_group(mod):
     return None
 
 
+def _require_rows(feats, group):
+    """Which collectives a SyncBatchNorm issues must not depend on rank-local data (a rank taking another transport
+    than its peers hangs the job).  Every shape rule below is a function of channel count and dtype only - except an
+    EMPTY shard, which no kernel path serves: the path shards whole scans, so a rank without voxels is a data-loading
+    error and is reported as one instead of a hang."""
+    if group is not None and feats.shape[0] == 0:
+        raise RuntimeError("SyncBatchNorm: this rank holds no voxels (every rank must receive at least one scan)")
+
+
 def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None) -> SparseTensor:
     """relu(BN(input) [+ residual]) for a BatchNorm / SyncBatchNorm module `mod` - the tail of every conv block of
     the MinkUNet family (minkunet.py:42-51, 117-129).  Training mode runs as two fused passes on the HIP
@@ -96,6 +106,7 @@ def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor =
     from .batchnorm import batch_norm_act_train, fast_path_ok
     feats = input.feats
     res = None if residual is None else residual.feats
+    _require_rows(feats, _sync_group(mod))
     if mod.training and mod.momentum is not None and mod.affine and fast_path_ok(feats) \
             and (res is None or (res.shape == feats.shape and res.dtype == feats.dtype)):
         rm = mod.running_mean if mod.track_running_stats else None
@@ -124,6 +135,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and mod.momentum is not None and mod.affine \
             and not (conv._forward_hooks or conv._forward_pre_hooks):      # hooks on the conv module must still fire
         group = _sync_group(mod)
+        _require_rows(input.feats, group)
         comm = None if group is None else direct_comm(group)
         if group is None or comm is not None:
             kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)

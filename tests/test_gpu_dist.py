@@ -1,0 +1,133 @@
+"""N > 1 on the GPU box: the data-parallel path of bench.py (one scan set per rank, SyncBatchNorm statistics over the
+ranks, gradients averaged by GradBucketReducer during backward - R/dist_train.sh:17-19, R/train.py:247-251) run by
+real rank processes on the real segmentor and HIP kernels, against ONE process on the concatenated batch.
+
+* test_two_ranks_share_one_device: 2 ranks on ONE card (the GPU box has one) with the gloo transport - everything but
+  the RCCL wire: process-group set-up, weight broadcast, bucket hooks, SyncBatchNorm's packed all-reduce, finish().
+* test_two_ranks_rccl: needs >= 2 devices (skipped on the one-GPU box; runs wherever the driver has a multi-GPU
+  node): RCCL transport, SyncBatchNorm on the library-owned communicator vs through torch.distributed, all-reduce
+  bus bandwidth printed.
+* test_bench_gpus_flag: `bench.py --gpus N` must not silently run one rank.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(world, backend, out_dir, extra_env=None):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TASEG_DIST_BACKEND=backend, OUT=str(out_dir), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   OMP_NUM_THREADS="2")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=420)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rc, o, e in outs:
+        assert rc == 0, e[-3000:]
+    return [dict(np.load(os.path.join(out_dir, f"rank{r}.npz"))) for r in range(world)], outs
+
+
+def _single_process(world):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker as W
+    batches = [W.make_scan(41 + r, batch_index=r) for r in range(world)]
+    logits, grads, stats, loss = W.one_step(W.build(False), batches)
+    sizes = np.cumsum([0] + [len(b[0]) for b in batches])
+    return [logits[sizes[r]:sizes[r + 1]] for r in range(world)], grads, stats, loss
+
+
+def _check_against_single(ranks, prefix=""):
+    world = len(ranks)
+    want_logits, want_grads, want_stats, want_loss = _single_process(world)
+    for r, got in enumerate(ranks):
+        # SyncBatchNorm statistics span both ranks: each rank's logits are its slice of the two-scan batch's logits
+        assert np.abs(got[prefix + "logits"] - want_logits[r]).max() <= 1e-3
+    assert abs(np.mean([float(g[prefix + "loss"]) for g in ranks]) - want_loss) <= 1e-4
+    worst = 0.0
+    for name, want in want_grads.items():
+        a, b = ranks[0][prefix + "grad/" + name], ranks[1][prefix + "grad/" + name]
+        assert np.array_equal(a, b), name                       # every rank holds the same averaged gradient
+        err = np.linalg.norm(a - want) / max(np.linalg.norm(want), 1e-12)
+        worst = max(worst, err)
+        assert err <= 2e-3, (name, err)
+    for name, want in want_stats.items():
+        assert np.allclose(ranks[0][prefix + "stat/" + name], want, rtol=1e-4, atol=1e-5), name
+    return worst
+
+
+def test_two_ranks_share_one_device(tmp_path):
+    ranks, _ = _run_ranks(2, "gloo", tmp_path, {"TASEG_RCCL_DIRECT": "0"})
+    worst = _check_against_single(ranks)
+    print(f"2 ranks (gloo, one device) vs one process on the concatenated batch: worst relative gradient error {worst:.2e}")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two ROCm devices (RCCL refuses two ranks on one)")
+def test_two_ranks_rccl(tmp_path):
+    ranks, outs = _run_ranks(2, "nccl", tmp_path)
+    assert int(ranks[0]["direct_rccl"]) == 1, "the library-owned RCCL communicator was not created"
+    _check_against_single(ranks)
+    _check_against_single(ranks, "c10d/")
+    for got in ranks:                  # both SyncBatchNorm transports run the same kernels around the same sums
+        for k in got:
+            if k.startswith("c10d/"):
+                assert np.allclose(got[k], got[k[5:]], rtol=1e-6, atol=1e-7), k
+    line = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    assert line, outs[0][1]
+    print("gradient all-reduce over RCCL:", line[-1])
+    assert json.loads(line[-1])["bus_GBps"] > 1.0
+
+
+def test_bench_gpus_flag():
+    """--gpus N with fewer devices exits non-zero before touching the GPU; --gpus != WORLD_SIZE is refused"""
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "device" in (r.stderr + r.stdout)
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_two_ranks_rehearsal_on_one_device():
+    """`bench.py --gpus 2` starts its own two ranks and reports n_gpus 2 (gloo transport, both ranks on this card: a
+    rehearsal of the launch + reducer + SyncBatchNorm path, not a performance number)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(TASEG_BENCH_SHARE_DEVICE="1", TASEG_DIST_BACKEND="gloo", TASEG_RCCL_DIRECT="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--points", "30000", "--no-cpu-baseline", "--no-kernel-events"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    rec = json.loads(line[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and np.isfinite(rec["loss"])

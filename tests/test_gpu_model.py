@@ -137,6 +137,69 @@ def test_eval_branch_unvoxelises(g_minkunet):
     assert n == sum(per_scan)
 
 
+def test_dropout_does_not_touch_devoxelised_features():
+    """DROPOUT_P > 0 (the default when the key is absent is 0.3): z1 / z2 are devoxelised from the features BEFORE
+    dropout (minkunet.py:400-412).  The concat path collects its sources before the dropout call, so with the same
+    seed it must give the logits of the reference-order path (in-place dropout used to corrupt them)."""
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8, DROPOUT_P=0.3)
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+    pts, lab = synth_scan(5, n_points=20000, n_beams=32, n_az=1000)
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+    coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+    feats = torch.from_numpy(pts[idx]).cuda()
+    outs = []
+    for concat in (True, False):
+        bd = {"lidar": SparseTensor(feats.clone(), coords)}
+        plan = model.prepare(bd)
+        from taseg_amd.torchsparse.nn import functional as spF
+        f0 = spF.spvoxelize(feats, plan["vox_idx"], plan["vox_counts"])
+        torch.manual_seed(123)
+        blocks = model._unet_point_features(f0, feats, plan, concat=concat)
+        z = blocks if concat else torch.cat(blocks, dim=1)
+        outs.append(z.detach().clone())
+        # gradients flow through both forms
+        z.square().mean().backward()
+    a, b = outs
+    assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5
+    # and dropout really was active: the decoder blocks differ from a no-dropout pass
+    cfg0 = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8, DROPOUT_P=0.0)
+    model0 = fill_parameters(build_network(cfg0, 20), seed=3).cuda().train()
+    z0 = model0._unet_point_features(spF.spvoxelize(feats, plan["vox_idx"], plan["vox_counts"]), feats, plan, concat=True)
+    c1 = model.classifier[0].in_features
+    # z1 (stride-16 encoder output, first block) is taken before any dropout: identical; z3 sees dropped-out inputs
+    k1 = int(cfg.PLANES[4] * cfg.cr)
+    assert float((z0[:, :k1] - a[:, :k1]).abs().max()) <= 1e-5
+    assert float((z0[:, k1:] - a[:, k1:]).abs().max()) > 1e-3 and z0.shape[1] == c1
+
+
+def test_flat_sgd_leaves_parameters_without_gradient_alone():
+    """torch.optim.SGD (the reference's optimizer) skips parameters whose .grad is None - no weight decay, no momentum;
+    FlatSGD updates whole buckets and must put such slices back."""
+    from taseg_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({"used": torch.nn.Linear(64, 64), "idle": torch.nn.Linear(64, 64)}).cuda()
+    ref = torch.nn.ModuleDict({"used": torch.nn.Linear(64, 64), "idle": torch.nn.Linear(64, 64)}).cuda()
+    ref.load_state_dict(net.state_dict())
+    opt = FlatSGD(net, lr=0.1, momentum=0.9, weight_decay=0.01)
+    topt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=0.01)
+    x = torch.randn(32, 64, device="cuda")
+    for step in range(3):
+        for model, o in ((net, opt), (ref, topt)):
+            o.zero_grad(set_to_none=True)
+            y = model["used"](x)
+            if step == 2:                     # the idle branch joins in the last step (momentum starts from zero there)
+                y = y + model["idle"](x)
+            y.square().mean().backward()
+            o.step()
+    for (n, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), n
+
+
 def test_syncbn_collective_path_on_one_rank(tmp_path):
     """The SyncBatchNorm / DDP code path that `bench.py --gpus N` executes, on a one-rank RCCL group: fused BN+act
     with the all-reduce between reduction and apply must equal the single-process path, and a DDP-wrapped training

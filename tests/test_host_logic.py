@@ -115,3 +115,57 @@ def test_synthetic_scan_is_deterministic_and_shaped():
     assert set(np.unique(la)) <= set(range(20)) and len(np.unique(la)) >= 6
     h, _ = synth_scan(1001, n_points=4000, n_beams=16, n_az=400, pose=synth_pose(2), scene_seed=1000)
     assert h.shape[1] == 4 and synth_pose(0).tolist() == np.eye(4).tolist()
+
+
+def test_reducer_refuses_a_second_backward():
+    """GradBucketReducer's contract is one backward per finish(): a second one would add into buffers whose
+    all-reduce is already in flight - it must raise, not corrupt."""
+    from taseg_amd.parallel import GradBucketReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    red = GradBucketReducer(net)
+    x = torch.randn(5, 4)
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match="one backward"):
+        net(x).sum().backward()
+    red.finish()
+    for p in net.parameters():
+        p.grad = None
+    net(x).sum().backward()          # re-armed after finish()
+    red.finish()
+    # a parameter that got no gradient is reported, its bucket slice is zero
+    net2 = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 4), "b": torch.nn.Linear(4, 4)})
+    red2 = GradBucketReducer(net2)
+    net2["a"](x).sum().backward()
+    red2.finish()
+    unused = [red2.buckets[0]["params"][i] for i in red2.buckets[0]["unused"]]
+    assert {id(p) for p in unused} == {id(p) for p in net2["b"].parameters()}
+    assert all(float(p.grad.abs().sum()) == 0 for p in net2["b"].parameters())
+
+
+def test_install_as_dropin_binds_reference_import_names():
+    """INTEGRATION.md level 1: unmodified OpenPCSeg imports resolve to this package (R/train.py:195, model/__init__.py)."""
+    import subprocess
+    import sys
+    import os
+    code = (
+        "import taseg_amd; names = taseg_amd.install_as_dropin()\n"
+        "import torchsparse, torchsparse.nn as spnn, torchsparse.nn.functional as F\n"
+        "from torchsparse import SparseTensor, PointTensor\n"
+        "from torchsparse.utils.quantize import sparse_quantize\n"
+        "from torchsparse.utils.collate import sparse_collate_fn\n"
+        "from torchsparse.nn.utils import get_kernel_offsets\n"
+        "from pcseg.model import build_network, load_data_to_gpu\n"
+        "from pcseg.loss import Losses\n"
+        "import torchsparse.backend as B\n"
+        "assert all(hasattr(B, n) for n in ('hash_cuda', 'kernel_hash_cuda', 'hash_query_cuda', 'count_cuda',"
+        " 'voxelize_forward_cuda', 'voxelize_backward_cuda', 'devoxelize_forward_cuda', 'devoxelize_backward_cuda',"
+        " 'convolution_forward_cuda', 'convolution_backward_cuda'))\n"
+        "assert torchsparse is taseg_amd.torchsparse and spnn.Conv3d is taseg_amd.torchsparse.nn.Conv3d\n"
+        "from taseg_amd.data.synthetic import make_model_cfg\n"
+        "m = build_network(make_model_cfg('MinkUNetMs', in_dim=5, cr=0.5, num_layer=[1] * 8), 20)\n"
+        "assert type(m).__name__ == 'MinkUNetMs' and hasattr(m, 'load_params_from_file')\n"
+        "print('DROPIN_OK')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert "DROPIN_OK" in out.stdout, out.stderr[-2000:]
