@@ -31,6 +31,37 @@ EVENT_EVERY = 10            # per-launch HIP events bracket the conv kernels of 
                             # block calls; an event pair costs ~3 us of device time per launch: ~2 ms on such a step)
 
 
+def note(msg):
+    """progress line on stderr (a default run takes minutes: main measurement, CPU baseline legs, side runs)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands out a
+    share of a large host - running one OpenMP thread per visible core of the HOST would oversubscribe the share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +97,9 @@ def parse():
     ap.add_argument("--cpu-sector-deg-all", type=float, default=45.0,
                     help="sector of the all-cores leg (the reference's CPU convolution gets SLOWER with threads: its "
                          "OpenMP pragma is on the inner channel loop; 0 = skip the leg)")
+    ap.add_argument("--cpu-leg", type=int, default=0,
+                    help="(internal) run ONE CPU-baseline leg with this many threads, print its JSON record and exit")
+    ap.add_argument("--cpu-leg-timeout", type=float, default=100.0, help="seconds before a CPU-baseline leg is abandoned")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short runs of the other workloads (minkunet_ms, --amp, nuscenes_ms --amp) that the "
                          "default N=1 run appends as `secondary`")
@@ -117,6 +151,45 @@ def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label
     return scans, npts
 
 
+def make_nusc_samples(rank, batch, points, multiscan=15, step=1.0):
+    """Resident inputs of the nuScenes FSA workload (BASELINE configs[4]): per sample the current keyframe of a synthetic
+    20 Hz drive plus the sweeps the reference's distance rule selects (nuscenes_ms.py:238-276: the frame nearest to every
+    metre of driven distance up to 15 m, and every keyframe on the way), their pseudo labels, and the per-sweep
+    transform parameters.  Sweep selection and the 3x3 pose products are host work the reference caches per keyframe
+    (`token2samplelist`); ego-box filter, transforms, class-step mask and voxelisation run on the device inside the
+    timed step (taseg_amd.data.nuscenes.build_nuscenes_batch)."""
+    from taseg_amd.data.nuscenes import select_sweeps, sweep_params
+    from taseg_amd.data.synthetic import KITTI_TO_NUSC, synth_nusc_sequence, synth_scan
+    dev = torch.device("cuda")
+    seq, world = synth_nusc_sequence()
+    index = len(seq.global_indexes) - 1
+    g0 = int(seq.global_indexes[index])
+    offsets = select_sweeps(seq, index, multiscan, step)
+    params = torch.from_numpy(sweep_params(seq, index, offsets)).to(dev)
+    remap = np.asarray(KITTI_TO_NUSC, dtype=np.int64)
+    samples, npts = [], 0
+
+    def frame(seed, g):
+        p, l = synth_scan(seed + g, n_points=points, n_beams=32, n_az=1090, pose=world[g].astype(np.float32), scene_seed=seed)
+        p5 = np.concatenate([p, np.zeros((len(p), 1), np.float32)], 1)       # x, y, z, intensity, ring
+        return torch.from_numpy(p5).to(dev), torch.from_numpy(remap[l]).to(dev)
+
+    for b in range(batch):
+        seed = 1000 * rank + 100 * b
+        cur, cur_lab = frame(seed, g0)
+        hp, hl, hs = [], [], []
+        for d in offsets:
+            p5, lab = frame(seed, g0 + d)
+            hp.append(p5)
+            hs.append(lab)                                                    # pseudo labels = the synthetic labels
+            hl.append(lab if seq.is_key[g0 + d] else torch.zeros_like(lab))   # sweeps carry no annotation (:318)
+            npts += len(p5)
+        npts += len(cur)
+        samples.append(dict(points=cur, labels=cur_lab, hist_points=hp, hist_labels=hl, hist_pseudo=hs, params=params,
+                            name=f"{rank}/{b}"))
+    return samples, npts, len(offsets)
+
+
 def _cpu_leg(cfg, points, sector_deg, threads):
     """One timed pass (forward + CE/Lovasz loss + backward) of the reference CPU path over an azimuth sector of scan
     seed 0 with `threads` OpenMP / BLAS threads: the oracle model driven by the reference's own compiled CPU kernels
@@ -159,14 +232,14 @@ def _cpu_leg(cfg, points, sector_deg, threads):
                       f"({frac:.3f} scan), fwd+bwd {dt:.1f} s, fp32, {threads} thread(s)"}
 
 
-def cpu_baseline(cfg, points, sector_deg, sector_deg_all):
+def cpu_baseline(args, cfg_name, in_dim):
     """Reference CPU path on bounded samples, at 1 thread (the reference's fastest setting: its OpenMP pragma sits on
     the inner channel loop) AND at all host cores; the headline `value` is
-    the faster of the two, `cores` the threads that leg used."""
-    try:
-        nproc = len(os.sched_getaffinity(0))
-    except AttributeError:
-        nproc = os.cpu_count() or 1
+    the faster of the two, `cores` the threads that leg used.  Each leg is a child process (a fresh OpenMP runtime with
+    its own thread count) under a time limit: with one thread per core the reference's convolution can be orders of
+    magnitude slower than with one."""
+    import subprocess
+    nproc = host_cores()
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -176,11 +249,30 @@ def cpu_baseline(cfg, points, sector_deg, sector_deg_all):
                     break
     except OSError:
         pass
-    legs = [_cpu_leg(cfg, points, sector_deg, 1)]
-    if nproc > 1 and sector_deg_all > 0:
-        legs.append(_cpu_leg(cfg, points, sector_deg_all, nproc))
-    torch.set_num_threads(1)
-    best = max(legs, key=lambda r: r["value"])
+    legs = []
+    plan = [(1, args.cpu_sector_deg)] + ([(nproc, args.cpu_sector_deg_all)] if nproc > 1 and args.cpu_sector_deg_all > 0 else [])
+    for threads, sector in plan:
+        note(f"cpu_baseline leg: {threads} thread(s), {sector:g} deg sector")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--cpu-sector-deg", str(sector),
+               "--points", str(args.points), "--workload", args.workload]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+        rec = {"threads": threads, "value": None, "unit": "scans/s"}
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_leg_timeout)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                rec = json.loads(line[-1])
+            else:
+                rec["error"] = (r.stderr or r.stdout)[-300:]
+        except subprocess.TimeoutExpired:
+            rec["sample"] = (f"{sector:g} deg azimuth sector of one scan did not finish fwd+bwd within "
+                             f"{args.cpu_leg_timeout:g} s at {threads} threads")
+        legs.append(rec)
+    done = [r for r in legs if r.get("value")]
+    if not done:
+        return {"value": None, "unit": "scans/s", "cores": None, "kind": None, "nproc": nproc, "cpu_model": cpu_model,
+                "legs": legs}
+    best = max(done, key=lambda r: r["value"])
     return {"value": best["value"], "unit": "scans/s", "cores": best["threads"], "kind": best["kind"],
             "sample": best["sample"], "nproc": nproc, "cpu_model": cpu_model, "legs": legs}
 
@@ -247,8 +339,8 @@ def secondary_runs(steps=10, warmup=3):
     own JSON line cut down to value / ms_per_step / dtype / config."""
     import subprocess
     out = []
-    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "minkunet_ms", "--amp"],
-                  ["--workload", "nuscenes_ms", "--amp"]):
+    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"]):
+        note("secondary run: " + " ".join(extra))
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
                "--no-kernel-events", "--no-secondary"] + extra
         entry = {"args": " ".join(extra)}
@@ -292,6 +384,12 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.cpu_leg:                       # child of cpu_baseline(): no GPU, one timed CPU pass, one JSON record
+        from taseg_amd.data.synthetic import make_model_cfg
+        ms = args.workload in ("minkunet_ms", "nuscenes_ms")
+        cfg = make_model_cfg("MinkUNetMs" if ms else "MinkUNet", in_dim=5 if ms else 4, cr=1.0)
+        print(json.dumps(_cpu_leg(cfg, args.points or 120000, args.cpu_sector_deg, args.cpu_leg)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", 0))
@@ -357,18 +455,22 @@ def main():
     nvox = [0]
     if ms:
         from taseg_amd.data.stage import build_multiscan_batch
-        from taseg_amd.data.synthetic import FLEXIBLE_STEPS_KITTI, FLEXIBLE_STEPS_NUSC, KITTI_TO_NUSC
+        from taseg_amd.data.synthetic import FLEXIBLE_STEPS_KITTI, FLEXIBLE_STEPS_NUSC
         if nusc:
-            scans, npts = make_multiscans(rank, args.batch, args.points, history=15, n_beams=32, n_az=1090,
-                                          label_map=KITTI_TO_NUSC)
+            from taseg_amd.data.nuscenes import build_nuscenes_batch
+            nsamples, npts, n_sweeps = make_nusc_samples(rank, args.batch, args.points)
+
+            def make_batch():
+                bd = build_nuscenes_batch(nsamples, voxel, FLEXIBLE_STEPS_NUSC)
+                nvox[0] = int(bd["lidar_ms"].C.shape[0])
+                return bd
         else:
             scans, npts = make_multiscans(rank, args.batch, args.points)
-        steps_cfg = FLEXIBLE_STEPS_NUSC if nusc else FLEXIBLE_STEPS_KITTI
 
-        def make_batch():
-            bd = build_multiscan_batch(scans, voxel, steps_cfg)
-            nvox[0] = int(bd["lidar_ms"].C.shape[0])
-            return bd
+            def make_batch():
+                bd = build_multiscan_batch(scans, voxel, FLEXIBLE_STEPS_KITTI)
+                nvox[0] = int(bd["lidar_ms"].C.shape[0])
+                return bd
     else:
         coords, feats, labels, npts = make_scans(rank, args.batch, args.points, args.workload)
         offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
@@ -424,6 +526,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        note(f"{name} {args.workload}: {args.warmup} warm-up + {args.steps} timed steps on {world} rank(s)")
     for _ in range(args.warmup):
         step()
     fence()
@@ -480,7 +584,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 storage / f32 accumulate (torch.autocast)" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": f"{name} mk34 cr1.0 ("
-                                   f"{'nuScenes-shaped 15-sweep FSA' if nusc else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
+                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
                                    f"bs={args.batch}/GPU, voxel {voxel:g} m, {'AMP fp16' if args.amp else 'fp32'}, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}"},
@@ -493,8 +597,9 @@ def main():
             "ideal_fused_bytes_per_step": sum(r["ideal_fused_bytes_per_step"] for r in prof) if prof else None,
         }
         if world == 1 and not args.no_cpu_baseline and not nusc:      # cpu_baseline is defined on the KITTI-shaped scan
-            line["cpu_baseline"] = cpu_baseline(cfg, args.points, args.cpu_sector_deg, args.cpu_sector_deg_all)
-            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            line["cpu_baseline"] = cpu_baseline(args, name, cfg.IN_FEATURE_DIM)
+            if line["cpu_baseline"]["value"]:
+                line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         plain = (world == 1 and not args.force_dist and args.workload == "minkunet" and not args.amp and args.conv_impl == 0
                  and not args.torch_optim and args.batch == 2 and args.points == 120000)
         if plain and not args.no_secondary:

@@ -488,6 +488,18 @@ int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float
 int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64_t n, const float *pose0, const float *poses,
                   int32_t n_scans, float *out, ts_stream_t stream);
 
+/* nuScenes multi-scan fuse (pcseg/data/dataset/nuscenes/nuscenes_ms.py:280-318 per selected sweep, :348-373
+ * transform_point): for point i of the concatenated sweeps, with s = sweep_idx[i] and params[s] = 28 doubles
+ *   { A[9], a[3], flagA, B[9], b[3], flagB, dt, pad }:
+ *   keep[i] = !(|x| < 1.0 && |y| < 1.5) on the RAW coordinates          (ego-box filter, :288 / :306)
+ *   flagA:  p = f32(p . A^T); p = f32(p + a)                            (sweep -> its keyframe's lidar frame, :307-309)
+ *   flagB:  p = f32(p . B + b)                                          (-> the current lidar frame, transform_point)
+ *   out[i] = (p, intensity, f32(dt))                                    (:289 / :310)
+ * Arithmetic in float64 with the fused-multiply-add chain numpy's matmul (dgemm) performs, rounded to float32 where
+ * the reference stores into its float32 array.  points / out [n,5] float32; keep [n] uint8. */
+int ts_fuse_sweeps(const float *points, const int32_t *sweep_idx, int64_t n, const double *params, int32_t n_sweeps,
+                   float *out, uint8_t *keep, ts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -231,7 +231,7 @@ def lovasz_softmax_ref(probas, labels, ignore=0):
         return probas.sum() * 0.0
     losses = []
     for c in range(probas.shape[1]):
-        fg = (labels == c).float()
+        fg = (labels == c).to(probas.dtype)
         if fg.sum() == 0:
             continue
         err = (fg - probas[:, c]).abs()

@@ -18,6 +18,12 @@ FNV_PRIME = np.uint64(1099511628211)
 MASK60 = np.uint64(0x0FFFFFFFFFFFFFFF)
 
 
+def _ft(a):
+    """float32 like the reference, unless the caller hands in float64 arrays (the fp64 evaluation of the same
+    algorithm that tests use as the yardstick for fp32 gradient noise)"""
+    return np.float64 if getattr(a, "dtype", None) == np.float64 else np.float32
+
+
 # --------------------------------------------------------------------------------- hashing
 def sphash(coords, offsets=None):
     """TS/torchsparse/backend/hash/hash_cuda.cu:10-23 (K1) and :27-55 (K2, output [K, N], the
@@ -67,35 +73,35 @@ def spcount(idx, n):
 # --------------------------------------------------------------------------------- voxelize / devoxelize
 def voxelize_forward(feat, idx, counts):
     """TS/.../voxelize/voxelize_cuda.cu:12-25: out[idx[i]] += feat[i] / counts[idx[i]]."""
-    feat = np.asarray(feat, dtype=np.float32)
+    feat = np.asarray(feat, dtype=_ft(feat))
     idx = np.asarray(idx, dtype=np.int64)
     counts = np.asarray(counts)
     m = counts.shape[0]
-    out = np.zeros((m, feat.shape[1]), dtype=np.float32)
+    out = np.zeros((m, feat.shape[1]), dtype=feat.dtype)
     ok = (idx >= 0) & (idx < m)
     ok[ok] &= counts[idx[ok]] != 0
-    np.add.at(out, idx[ok], feat[ok] / counts[idx[ok]].astype(np.float32)[:, None])
+    np.add.at(out, idx[ok], feat[ok] / counts[idx[ok]].astype(feat.dtype)[:, None])
     return out
 
 
 def voxelize_backward(gout, idx, counts, n):
     """TS/.../voxelize/voxelize_cuda.cu:28-41: gfeat[i] = gout[idx[i]] / counts[idx[i]]."""
-    gout = np.asarray(gout, dtype=np.float32)
+    gout = np.asarray(gout, dtype=_ft(gout))
     idx = np.asarray(idx, dtype=np.int64)
     counts = np.asarray(counts)
-    out = np.zeros((n, gout.shape[1]), dtype=np.float32)
+    out = np.zeros((n, gout.shape[1]), dtype=gout.dtype)
     ok = (idx >= 0) & (idx < counts.shape[0])
     ok[ok] &= counts[idx[ok]] != 0
-    out[ok] = gout[idx[ok]] / counts[idx[ok]].astype(np.float32)[:, None]
+    out[ok] = gout[idx[ok]] / counts[idx[ok]].astype(gout.dtype)[:, None]
     return out
 
 
 def devoxelize_forward(feat, idx, w):
     """TS/.../devoxelize/devoxelize_cuda.cu:11-33: out[i] = sum_k w[i,k] * feat[idx[i,k]] in k order."""
-    feat = np.asarray(feat, dtype=np.float32)
+    feat = np.asarray(feat, dtype=_ft(feat))
     idx = np.asarray(idx, dtype=np.int64)
     w = np.asarray(w, dtype=np.float32)
-    out = np.zeros((idx.shape[0], feat.shape[1]), dtype=np.float32)
+    out = np.zeros((idx.shape[0], feat.shape[1]), dtype=feat.dtype)
     for k in range(8):
         ok = idx[:, k] >= 0
         out[ok] += w[ok, k, None] * feat[idx[ok, k]]
@@ -105,10 +111,10 @@ def devoxelize_forward(feat, idx, w):
 def devoxelize_backward(gout, idx, w, m):
     """TS/.../devoxelize/devoxelize_cuda.cu:37-57 (the CUDA adjoint; the CPU twin at
     devoxelize_cpu.cpp:35-59 is wrong): gfeat[idx[i,k]] += w[i,k] * gout[i]."""
-    gout = np.asarray(gout, dtype=np.float32)
+    gout = np.asarray(gout, dtype=_ft(gout))
     idx = np.asarray(idx, dtype=np.int64)
     w = np.asarray(w, dtype=np.float32)
-    out = np.zeros((m, gout.shape[1]), dtype=np.float32)
+    out = np.zeros((m, gout.shape[1]), dtype=gout.dtype)
     for k in range(8):
         ok = idx[:, k] >= 0
         np.add.at(out, idx[ok, k], w[ok, k, None] * gout[ok])
@@ -180,17 +186,17 @@ def build_kmap(in_coords, out_coords, offsets):
 # --------------------------------------------------------------------------------- convolution
 def conv_forward(feats, weight, nbmaps, nbsizes, sizes, transposed=False):
     """TS/.../convolution/convolution_cuda.cu:53-165 (per offset: gather, GEMM, scatter-add)."""
-    feats = np.asarray(feats, dtype=np.float32)
-    weight = np.asarray(weight, dtype=np.float32)
+    feats = np.asarray(feats, dtype=_ft(feats))
+    weight = np.asarray(weight, dtype=feats.dtype)
     n_out = sizes[0] if transposed else sizes[1]
-    out = np.zeros((n_out, weight.shape[-1]), dtype=np.float32)
+    out = np.zeros((n_out, weight.shape[-1]), dtype=feats.dtype)
     a = 0
     for k in range(weight.shape[0]):
         b = a + int(nbsizes[k])
         if b > a:
             i = nbmaps[a:b, 1 if transposed else 0]
             o = nbmaps[a:b, 0 if transposed else 1]
-            np.add.at(out, o, feats[i] @ weight[k])
+            out[o] += feats[i] @ weight[k]      # the reference's non-atomic scatter: a row appears once per offset
         a = b
     return out
 
@@ -198,9 +204,9 @@ def conv_forward(feats, weight, nbmaps, nbsizes, sizes, transposed=False):
 def conv_backward(feats, weight, gout, nbmaps, nbsizes, transposed=False):
     """TS/.../convolution/convolution_cuda.cu:167-278: grad_in (scatter of gout W^T) and
     grad_weight[k] = gather(in)^T gather(gout)."""
-    feats = np.asarray(feats, dtype=np.float32)
-    weight = np.asarray(weight, dtype=np.float32)
-    gout = np.asarray(gout, dtype=np.float32)
+    feats = np.asarray(feats, dtype=_ft(feats))
+    weight = np.asarray(weight, dtype=feats.dtype)
+    gout = np.asarray(gout, dtype=feats.dtype)
     gin = np.zeros_like(feats)
     gw = np.zeros_like(weight)
     a = 0
@@ -209,7 +215,7 @@ def conv_backward(feats, weight, gout, nbmaps, nbsizes, transposed=False):
         if b > a:
             i = nbmaps[a:b, 1 if transposed else 0]
             o = nbmaps[a:b, 0 if transposed else 1]
-            np.add.at(gin, i, gout[o] @ weight[k].T)
+            gin[i] += gout[o] @ weight[k].T
             gw[k] = feats[i].T @ gout[o]
         a = b
     return gin, gw
@@ -333,3 +339,114 @@ def per_class_iu(hist):
     """R/train.py:43-44."""
     hist = np.asarray(hist, dtype=np.float64)
     return np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist) + 1e-9)
+
+
+# --------------------------------------------------------------------------- nuScenes multi-scan fuse
+def quaternion_rotation_matrix(q):
+    """`pyquaternion.Quaternion(q).rotation_matrix` (pyquaternion 0.9.9, the quaternion class nuscenes-devkit depends
+    on; absent from /root/reference and from this image - its published algorithm restated): q = (w, x, y, z) is
+    normalised unless already unit (tolerance 1e-14), the matrix is the lower-right 3x3 of Q(q) . Qbar(q)^T."""
+    q = np.asarray(q, dtype=np.float64).copy()
+    n2 = float(np.dot(q, q))
+    if abs(1.0 - n2) >= 1e-14:
+        n = np.sqrt(n2)
+        if n > 0:
+            q = q / n
+    w, x, y, z = q
+    qm = np.array([[w, -x, -y, -z], [x, w, -z, y], [y, z, w, -x], [z, -y, x, w]])
+    qb = np.array([[w, -x, -y, -z], [x, w, z, -y], [y, -z, w, x], [z, y, -x, w]])
+    return np.dot(qm, qb.conj().transpose())[1:][:, 1:]
+
+
+def nus_transform_point(raw_data, info0, info):
+    """R/pcseg/data/dataset/nuscenes/nuscenes_ms.py:348-373: points of the lidar frame of `info` into the lidar frame of
+    `info0` through ego and global poses.  info* = dict(lidar2ego_rotation q, lidar2ego_translation, ego2global_rotation q,
+    ego2global_translation).  float64 rotation / translation, result stored back into the float32 array."""
+    l2e_r_mat = quaternion_rotation_matrix(info0["lidar2ego_rotation"])
+    e2g_r_mat = quaternion_rotation_matrix(info0["ego2global_rotation"])
+    l2e_t, e2g_t = np.asarray(info0["lidar2ego_translation"]), np.asarray(info0["ego2global_translation"])
+    l2e_r_s_mat = quaternion_rotation_matrix(info["lidar2ego_rotation"])
+    e2g_r_s_mat = quaternion_rotation_matrix(info["ego2global_rotation"])
+    l2e_t_s, e2g_t_s = np.asarray(info["lidar2ego_translation"]), np.asarray(info["ego2global_translation"])
+    back = np.linalg.inv(e2g_r_mat).T @ np.linalg.inv(l2e_r_mat).T
+    R = (l2e_r_s_mat.T @ e2g_r_s_mat.T) @ back
+    T = (l2e_t_s @ e2g_r_s_mat.T + e2g_t_s) @ back
+    T -= e2g_t @ back + l2e_t @ np.linalg.inv(l2e_r_mat).T
+    raw_data[:, :3] = raw_data[:, :3] @ R + T
+    return raw_data
+
+
+def nus_select_sweeps(seq, index, multiscan, step):
+    """nuscenes_ms.py:238-276: walk back from the current keyframe over the sweep list of its scene until the lidar has
+    travelled more than multiscan * step metres (planar distance of each frame's sensor origin in the current lidar
+    frame), pick for every multiple of `step` the frame whose distance is nearest (first one past it otherwise), add
+    every keyframe on the way.  Returns ascending negative frame offsets.
+
+    seq = dict(is_key [F], key_index [F], scene_tokens [F], local_indexes [F], global_indexes [K], s2l_r [F,3,3],
+    s2l_t [F,3], keys = list of K pose dicts)."""
+    g0 = int(seq["global_indexes"][index])
+    info0 = seq["keys"][index]
+    delta, total, dist = 0, [], []
+    while len(dist) == 0 or dist[-1] <= multiscan * step:
+        delta -= 1
+        g = g0 + delta                     # (negative g wraps to the end of the list, as in the reference)
+        if seq["scene_tokens"][g] != seq["scene_tokens"][g0]:
+            dist.append(1000)
+            break
+        origin = np.zeros((1, 5), dtype=float)
+        if not seq["is_key"][g]:
+            origin[:, :3] = origin[:, :3] @ seq["s2l_r"][g].T
+            origin[:, :3] += seq["s2l_t"][g]
+        if seq["local_indexes"][g] != index:
+            origin = nus_transform_point(origin, info0, seq["keys"][int(seq["local_indexes"][g])])
+        total.append(delta)
+        dist.append(np.linalg.norm(origin.reshape(-1)[:2], ord=2))
+    cur, picked = 1, []
+    for i in range(len(total)):
+        if dist[i] - cur * step > 0 or ((dist[i] < dist[i + 1]) and
+                                        (np.abs(dist[i] - cur * step) < np.abs(dist[i + 1] - cur * step))):
+            picked.append(total[i])
+            cur += 1
+        if cur > multiscan:
+            break
+    picked += [d for d in total if seq["is_key"][g0 + d]]
+    return sorted(set(picked))
+
+
+def nus_multiscan_fuse(seq, index, sample_list, points, pseudo, labels, steps):
+    """nuscenes_ms.py:280-346: per selected frame (oldest first) the ego-box filter on the RAW coordinates, the time
+    delta in column 4, the rigid transform(s) into the current lidar frame, the class-step mask on the pseudo labels
+    (`(position + 1) % step == 0`).  points / pseudo / labels: dicts keyed by the frame offset.  Returns the
+    concatenated (raw [n,5] float32, labels [n], pseudo [n], mask [n]) - all AFTER the ego-box filter."""
+    g0 = int(seq["global_indexes"][index])
+    info0 = seq["keys"][index]
+    raws, anns, pseudos, masks = [], [], [], []
+    for pos, d in enumerate(sample_list):
+        g = g0 + d
+        raw = np.array(points[d], dtype=np.float32, copy=True).reshape(-1, 5)
+        no_ego = ~((np.abs(raw[:, 0]) < 1.0) & (np.abs(raw[:, 1]) < 1.5))
+        dt = seq["timestamps"][g0] / 1e6 - seq["timestamps"][g] / 1e6
+        if seq["is_key"][g]:
+            raw[:, 4] = dt
+            raw = nus_transform_point(raw, info0, seq["keys"][int(seq["key_index"][g])])
+            ann = np.asarray(labels[d]).reshape(-1)
+        else:
+            raw[:, :3] = raw[:, :3] @ seq["s2l_r"][g].T
+            raw[:, :3] += seq["s2l_t"][g]
+            raw[:, 4] = dt
+            if seq["local_indexes"][g] != index:
+                raw = nus_transform_point(raw, info0, seq["keys"][int(seq["local_indexes"][g])])
+            ann = np.zeros(raw.shape[0], dtype=np.uint8)
+        ps = np.asarray(pseudo[d]).reshape(-1)
+        raw, ann, ps = raw[no_ego], ann[no_ego], ps[no_ego]
+        m = np.zeros(len(ps), dtype=bool)
+        for cls, st in enumerate(steps):
+            if st == 0:
+                continue
+            if (pos + 1) % st == 0:
+                m = m | (ps == cls)
+        raws.append(raw)
+        anns.append(ann)
+        pseudos.append(ps)
+        masks.append(m)
+    return np.concatenate(raws, 0), np.concatenate(anns, 0), np.concatenate(pseudos, 0), np.concatenate(masks, 0)

@@ -19,7 +19,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
-    "fuse_scan", "fuse_scans", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
 
@@ -703,6 +703,23 @@ def fuse_scans(points, scan_idx, pose0, poses):
     L.check(L.load().ts_fuse_scans(L.ptr(points), L.ptr(scan_idx), points.shape[0], L.ptr(pose0), L.ptr(poses),
                                    poses.shape[0], L.ptr(out), L.stream()), "ts_fuse_scans")
     return out
+
+
+def fuse_sweeps(points, sweep_idx, params):
+    """nuScenes multi-scan fuse for the concatenated selected sweeps of one sample (nuscenes_ms.py:280-318, 348-373):
+    points [n,5] float32, sweep_idx [n] int32, params [S,28] float64 (taseg_amd.data.nuscenes.sweep_params).
+    Returns (out [n,5] float32 = x', y', z', intensity, dt ; keep [n] bool = outside the ego box)."""
+    L.require_device(points, sweep_idx, params)
+    points, sweep_idx = _f32(points, "points"), _i32(sweep_idx, "sweep_idx")
+    if params.dtype != torch.float64 or params.ndim != 2 or params.shape[1] != 28:
+        raise TypeError("params must be float64 [S, 28]")
+    params = params.contiguous()
+    assert points.ndim == 2 and points.shape[1] == 5, points.shape
+    out = torch.empty_like(points)
+    keep = torch.empty(points.shape[0], dtype=torch.uint8, device=points.device)
+    L.check(L.load().ts_fuse_sweeps(L.ptr(points), L.ptr(sweep_idx), points.shape[0], L.ptr(params), params.shape[0],
+                                    L.ptr(out), L.ptr(keep), L.stream()), "ts_fuse_sweeps")
+    return out, keep.bool()
 
 
 def voxel_coords(points, voxel_size, batch_idx=None, n_batch=1, shift=None):

@@ -348,6 +348,66 @@ extern "C" int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64
   return TS_OK;
 }
 
+// nuScenes multi-scan fuse (nuscenes_ms.py:280-318, 348-373): see include/taseg_hip.h.  One thread per point; the 28
+// doubles of a sweep are wave-uniform for long runs of points (sweeps are concatenated).
+__global__ __launch_bounds__(256) void fuse_sweeps_kernel(const float *__restrict__ pts,
+                                                          const int *__restrict__ sweep_idx, int64_t n,
+                                                          const double *__restrict__ params, int n_sweeps,
+                                                          float *__restrict__ out, uint8_t *__restrict__ keep) {
+#pragma clang fp contract(off)  // only the explicit fma() below fuse: numpy's dgemm accumulates x_k * R_kj with FMAs in k order
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float *p = pts + i * 5;
+    const float x = p[0], y = p[1], z = p[2];
+    const int s = min(max(sweep_idx[i], 0), n_sweeps - 1);
+    const double *P = params + 28 * s;
+    keep[i] = !(fabsf(x) < 1.0f && fabsf(y) < 1.5f);
+    float q[3] = {x, y, z};
+    if (P[12] != 0.0) {        // p @ A^T : out_j = sum_k p_k A[j][k]; then += a (each stored as float32)
+      const double d0 = q[0], d1 = q[1], d2 = q[2];
+      float r[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double acc = __builtin_fma(d2, P[3 * j + 2], __builtin_fma(d1, P[3 * j + 1], d0 * P[3 * j + 0]));
+        r[j] = (float)acc;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) q[j] = (float)((double)r[j] + P[9 + j]);
+    }
+    if (P[25] != 0.0) {        // p @ B + b : out_j = sum_k p_k B[k][j] + b_j
+      const double d0 = q[0], d1 = q[1], d2 = q[2];
+      const double *B = P + 13;
+      float r[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double acc = __builtin_fma(d2, B[6 + j], __builtin_fma(d1, B[3 + j], d0 * B[j]));
+        r[j] = (float)(acc + B[9 + j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) q[j] = r[j];
+    }
+    float *o = out + i * 5;
+    o[0] = q[0];
+    o[1] = q[1];
+    o[2] = q[2];
+    o[3] = p[3];
+    o[4] = (float)P[26];
+  }
+}
+
+extern "C" int ts_fuse_sweeps(const float *points, const int32_t *sweep_idx, int64_t n, const double *params,
+                              int32_t n_sweeps, float *out, uint8_t *keep, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && n_sweeps > 0, TS_ERR_INVALID_ARGUMENT, "ts_fuse_sweeps: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(points && sweep_idx && params && out && keep, TS_ERR_INVALID_ARGUMENT, "ts_fuse_sweeps: null pointer");
+  const int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
+  fuse_sweeps_kernel<<<grid, 256, 0, stream>>>(points, sweep_idx, n, params, n_sweeps, out, keep);
+  TS_CHECK_LAUNCH("ts_fuse_sweeps");
+  return TS_OK;
+}
+
 extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose, float *out,
                             ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

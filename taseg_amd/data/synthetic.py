@@ -37,6 +37,14 @@ def make_model_cfg(name="MinkUNet", in_dim=4, cr=1.0, num_layer=(2, 3, 4, 6, 2, 
     return cfg
 
 
+def strided_sample(t, n=2048):
+    """At most ~n evenly strided elements of the flattened array / tensor: how the big golden fixtures store gradients
+    (generator and tests pick the same elements)."""
+    flat = t.reshape(-1)
+    step = max(1, flat.shape[0] // n)
+    return flat[::step]
+
+
 def fill_parameters(module, seed=0):
     """Deterministic parameters that do not depend on construction order: every entry of the
     state_dict is drawn from a generator seeded by crc32(name) (+ seed).  Scales keep activations O(1)."""
@@ -200,3 +208,41 @@ def synth_tiaf_sample(coords, feats, seed, frames=2, height=32, width=64):
     sem = rs.randint(0, 20, size=(frames, 1, height, width)).astype(np.int64)
     fov_feats = np.concatenate([feats[fov, :4].astype(np.float32), pix], 1)
     return dict(fov_index=fov, fov_coords=coords[fov], fov_feats=fov_feats, images=images, semantic=sem)
+
+
+def synth_nusc_sequence(n_key=6, frames_per_key=10, metres_per_frame=0.5, yaw_deg_per_frame=0.3):
+    """A nuScenes-shaped drive for the `nuscenes_ms` workload: 20 Hz lidar frames, every `frames_per_key`-th one a
+    keyframe (2 Hz), the car moving `metres_per_frame` along +x and turning `yaw_deg_per_frame`.  Returns
+    (taseg_amd.data.nuscenes.NuscSequence, world poses [F, 4, 4] float64 of the lidar) - the bookkeeping the
+    reference reads from its info pickles (mmdet3d layout: keyframe poses as quaternions, sweeps with
+    sensor2lidar_rotation / _translation into the following keyframe's lidar frame)."""
+    from .nuscenes import NuscSequence, rotation_matrix
+
+    def yaw_quat(a):
+        return np.array([np.cos(a / 2), 0.0, 0.0, np.sin(a / 2)])
+
+    n_frames = (n_key - 1) * frames_per_key + 1
+    l2e_q, l2e_t = np.array([np.sqrt(0.5), 0.0, 0.0, -np.sqrt(0.5)]), np.array([0.94, 0.0, 0.0])
+    l2e_r = rotation_matrix(l2e_q)
+    e2g_q = np.stack([yaw_quat(np.deg2rad(yaw_deg_per_frame * g)) for g in range(n_frames)])
+    e2g_t = np.stack([np.array([metres_per_frame * g, 0.0, 0.0]) for g in range(n_frames)])
+    world = np.tile(np.eye(4), (n_frames, 1, 1))
+    for g in range(n_frames):
+        e2g_r = rotation_matrix(e2g_q[g])
+        world[g, :3, :3] = e2g_r @ l2e_r
+        world[g, :3, 3] = e2g_r @ l2e_t + e2g_t[g]
+    is_key = np.array([g % frames_per_key == 0 for g in range(n_frames)])
+    keys = np.nonzero(is_key)[0]
+    key_index = np.full(n_frames, -1)
+    key_index[keys] = np.arange(len(keys))
+    local = np.array([int(np.searchsorted(keys, g)) for g in range(n_frames)])      # next keyframe at or after g
+    s2l_r, s2l_t = np.zeros((n_frames, 3, 3)), np.zeros((n_frames, 3))
+    for g in range(n_frames):
+        if not is_key[g]:
+            rel = np.linalg.inv(world[keys[local[g]]]) @ world[g]                      # keyframe lidar <- sweep lidar
+            s2l_r[g], s2l_t[g] = rel[:3, :3], rel[:3, 3]
+    seq = NuscSequence(is_key=is_key, key_index=key_index, timestamps=(1_600_000_000_000_000 + 50_000 * np.arange(n_frames)),
+                       scene_tokens=["scene"] * n_frames, local_indexes=local, s2l_r=s2l_r, s2l_t=s2l_t, global_indexes=keys,
+                       l2e_q=np.tile(l2e_q, (len(keys), 1)), l2e_t=np.tile(l2e_t, (len(keys), 1)), e2g_q=e2g_q[keys],
+                       e2g_t=e2g_t[keys])
+    return seq, world

@@ -62,3 +62,37 @@ def g_minkunet_ms_kd():
 @pytest.fixture(scope="session")
 def g_multiscan():
     return _load("multiscan.npz")
+
+
+@pytest.fixture(scope="session")
+def g_multiscan_nus():
+    return _load("multiscan_nus.npz")
+
+
+@pytest.fixture(scope="session")
+def g_eval_ms():
+    return _load("eval_ms.npz")
+
+
+def nus_sample(g, b):
+    """Sample `b` of tests/golden/multiscan_nus.npz as (oracle sequence dict, taseg_amd NuscSequence, keyframe index,
+    per-offset dicts of points / pseudo labels / mapped labels)."""
+    from taseg_amd.data.nuscenes import NuscSequence
+    p = f"b{b}_"
+    keys = [dict(lidar2ego_rotation=g[p + "key_l2e_q"][i], lidar2ego_translation=g[p + "key_l2e_t"][i],
+                 ego2global_rotation=g[p + "key_e2g_q"][i], ego2global_translation=g[p + "key_e2g_t"][i])
+            for i in range(len(g[p + "key_l2e_q"]))]
+    oseq = dict(is_key=g[p + "is_key"], key_index=g[p + "key_index"], scene_tokens=g[p + "scene_tokens"],
+                local_indexes=g[p + "local_indexes"], global_indexes=g[p + "global_indexes"], s2l_r=g[p + "s2l_r"],
+                s2l_t=g[p + "s2l_t"], timestamps=g[p + "timestamps"], keys=keys)
+    seq = NuscSequence(is_key=g[p + "is_key"], key_index=g[p + "key_index"], timestamps=g[p + "timestamps"],
+                       scene_tokens=g[p + "scene_tokens"].tolist(), local_indexes=g[p + "local_indexes"], s2l_r=g[p + "s2l_r"],
+                       s2l_t=g[p + "s2l_t"], global_indexes=g[p + "global_indexes"], l2e_q=g[p + "key_l2e_q"],
+                       l2e_t=g[p + "key_l2e_t"], e2g_q=g[p + "key_e2g_q"], e2g_t=g[p + "key_e2g_t"])
+    offsets = g[p + "sample_list"].tolist()
+    lm = g["learning_map"]
+    pts = {d: g[f"{p}points_d{-d}"] for d in offsets}
+    pseudo = {d: g[f"{p}pseudo_d{-d}"] for d in offsets}
+    labels = {d: (lm[g[f"{p}rawlabels_d{-d}"]] if f"{p}rawlabels_d{-d}" in g else np.zeros(len(pts[d]), dtype=np.int64))
+              for d in offsets}
+    return oseq, seq, int(g[p + "index"]), pts, pseudo, labels

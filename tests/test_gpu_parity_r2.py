@@ -1,0 +1,207 @@
+"""Parity at the BENCHMARKED configuration and on the rows the round-1 review found unpinned (-m gpu):
+
+* MinkUNet / MinkUNetMs mk34 cr 1.0, bs 2, 44k voxels at ~6.5 rulebook pairs per voxel - HIP logits / loss / BatchNorm
+  statistics against the REAL reference's (tests/golden/model_mk34_*.npz `ref32_*`), gradients against the float64
+  evaluation of the same network (`oracle64_*`) with the reference's own fp32 distance to it as the yardstick;
+* the eval branch's dictionary (un-voxelisation through inverse_map / point_mask), 3-vote TTA accumulation;
+* a checkpoint in the reference's on-disk format loaded through load_params_from_file;
+* the nuScenes FSA data stage on device, bit for bit.
+"""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, nus_sample
+
+pytestmark = pytest.mark.gpu
+
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, strided_sample  # noqa: E402
+
+LOGIT_TOL = 1e-3          # north_star: per-point logits within 1e-3 of the reference
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.mark.parametrize("name,in_dim,key,fname", [("MinkUNet", 4, "lidar", "model_mk34_minkunet.npz"),
+                                                   ("MinkUNetMs", 5, "lidar_ms", "model_mk34_minkunet_ms.npz")])
+@pytest.mark.parametrize("training", [True, False])
+def test_mk34_cr10_vs_reference_and_fp64(name, in_dim, key, fname, training):
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    g = _load(fname)
+    tag = "train_" if training else "eval_"
+    cfg = make_model_cfg(name, in_dim=in_dim, cr=1.0)                     # the bench model: mk34, 37.9 M parameters
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+    if not training:
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+    coords = torch.from_numpy(g["coords"]).cuda()
+    sfx = "" if key == "lidar" else "_ms"
+    bd = {key: SparseTensor(torch.from_numpy(g["feats"]).cuda(), coords),
+          "targets" + sfx: SparseTensor(torch.from_numpy(g["labels"]).cuda(), coords),
+          "offset" + sfx: torch.tensor([0], device="cuda")}
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o))
+    ret, tb, _ = model(bd)
+    h.remove()
+    logits = grabbed["logits"].detach().cpu().numpy()[::8]
+    d_ref = float(np.abs(logits - g["ref32_" + tag + "logits"]).max())
+    d_64 = float(np.abs(logits - g["oracle64_" + tag + "logits"]).max())
+    ref_64 = float(np.abs(g["ref32_" + tag + "logits"] - g["oracle64_" + tag + "logits"]).max())
+    assert d_ref <= LOGIT_TOL and d_64 <= LOGIT_TOL
+    assert abs(float(tb["loss"]) - float(g["ref32_" + tag + "loss"])) <= 1e-3
+    model.zero_grad()
+    ret["loss"].backward()
+    names = g["param_names"].tolist()
+    grads = dict(model.named_parameters())
+    norms = np.array([float(grads[n].grad.double().norm()) for n in names])
+    n64, n32 = g["oracle64_" + tag + "gradnorms"], g["ref32_" + tag + "gradnorms"]
+    ours = np.abs(norms - n64) / np.maximum(n64, 1e-30)
+    refs = np.abs(n32 - n64) / np.maximum(n64, 1e-30)
+    # gradients (all 380 norms, 24 sampled tensors) within 2e-3 of the float64 evaluation - or, where that is larger,
+    # within twice the fp32 noise level of this network, measured as the REFERENCE's own worst distance to the float64
+    # gradients: train-mode BatchNorm over ~40 layers amplifies rounding differences of ANY fp32 evaluation chaotically
+    # (the reference is 1e-3 .. 8e-3 away on the early layers; on running statistics the level is 4e-5 and the 2e-3 bar
+    # applies as is)
+    noise = max(np.linalg.norm(g[k] - g[k.replace("ref32_", "oracle64_")]) / np.linalg.norm(g[k.replace("ref32_", "oracle64_")])
+                for k in g if k.startswith("ref32_" + tag + "grad/"))
+    assert (ours <= max(2e-3, 2 * noise)).all(), \
+        [(names[i], ours[i], refs[i]) for i in np.argsort(-ours)[:5]]
+    worst = (0.0, 0.0, "")
+    for k in [k for k in g if k.startswith("oracle64_" + tag + "grad/")]:
+        pname = k.split("/", 1)[1]
+        got = strided_sample(grads[pname].grad.detach().cpu().numpy(), 2048)
+        want, ref = g[k], g[k.replace("oracle64_", "ref32_")]
+        e_ours = np.linalg.norm(got - want) / np.linalg.norm(want)
+        e_ref = np.linalg.norm(ref - want) / np.linalg.norm(want)
+        worst = max(worst, (e_ours, e_ref, pname))
+        assert e_ours <= max(2e-3, 2 * noise), (pname, e_ours, e_ref, noise)
+    if training:        # running statistics after one training-mode forward
+        bufs = dict(model.named_buffers())
+        for k in [k for k in g if k.startswith("ref32_train_stat/")]:
+            got = strided_sample(bufs[k.split("/", 1)[1]].detach().cpu().numpy(), 2048)
+            assert np.allclose(got, g[k], rtol=2e-4, atol=1e-5), k
+    print(f"{name} mk34 cr1.0 {tag[:-1]}: {len(g['coords'])} voxels; max |logit - reference| {d_ref:.2e}, |logit - fp64| "
+          f"{d_64:.2e} (reference vs fp64 {ref_64:.2e}); gradient norms vs fp64: ours max {ours.max():.2e}, reference max "
+          f"{refs.max():.2e}; worst sampled gradient: ours {worst[0]:.2e} / reference {worst[1]:.2e} ({worst[2]})")
+
+
+def _sparse(g, prefix, key):
+    from taseg_amd.torchsparse import SparseTensor
+    return SparseTensor(torch.from_numpy(g[f"{prefix}{key}_F"]).cuda(), torch.from_numpy(g[f"{prefix}{key}_C"]).cuda())
+
+
+def _eval_batch(g, prefix):
+    bd = {k: _sparse(g, prefix, k) for k in ("lidar", "lidar_ms", "inverse_map", "inverse_map_ms", "targets_mapped",
+                                             "targets_mapped_ms", "targets", "targets_ms")}
+    for k in ("lidar", "lidar_ms"):
+        bd[k].F, bd[k].C = bd[k].F.float(), bd[k].C.int()
+    for k in ("num_points", "num_points_ms", "offset", "offset_ms", "point_mask"):
+        bd[k] = torch.from_numpy(g[prefix + k]).cuda()
+    bd["name"] = g[prefix + "name"].tolist()
+    return bd
+
+
+@pytest.mark.parametrize("tag,name,in_dim", [("minkunet", "MinkUNet", 4), ("minkunet_ms", "MinkUNetMs", 5)])
+def test_eval_dictionary_and_tta_votes(g_eval_ms, tag, name, in_dim):
+    """eval branch (minkunet.py:435-455, minkunet_ms.py:433-458) against the reference's dictionary on dataset-collated
+    batches, and the trainer's vote accumulation (R/train.py:474-477, 499-503) on a 3-vote TTA batch"""
+    from taseg_amd.pcseg import eval as E
+    from taseg_amd.pcseg.model import build_network
+    g = g_eval_ms
+    cfg = make_model_cfg(name, in_dim=in_dim, cr=0.5, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().eval()
+    with torch.no_grad():
+        ret = model(_eval_batch(g, "batch_"))
+        tta = model(_eval_batch(g, "tta_"))
+    for prefix, out, n in ((f"{tag}_", ret, 2), (f"{tag}_tta_", tta, int(g["votes"]))):
+        assert out["name"] == g[prefix + "name"].tolist() and len(out["point_predict"]) == n
+        for b in range(n):
+            want_logits = g[f"{prefix}point_predict_logits_{b}"]
+            got_logits = out["point_predict_logits"][b]
+            assert got_logits.shape == want_logits.shape and np.abs(got_logits - want_logits).max() <= LOGIT_TOL
+            assert np.array_equal(out["point_labels"][b], g[f"{prefix}point_labels_{b}"])
+            want_pred = g[f"{prefix}point_predict_{b}"]
+            assert out["point_predict"][b].shape == want_pred.shape
+            assert (out["point_predict"][b] == want_pred).mean() >= 0.999      # arg-max may flip on a 1e-3 near-tie
+    votes = int(g["votes"])
+    acc = E.accumulate_votes(tta, votes)
+    assert np.abs(acc - g[f"{tag}_tta_sum"]).max() <= votes * LOGIT_TOL
+    payload = E.vote_payload(acc, "semantickitti")
+    assert payload.dtype == np.uint32 and payload.shape == g[f"{tag}_tta_label"].shape
+    assert (payload == g[f"{tag}_tta_label"]).mean() >= 0.999
+    # validation metric path on the same dictionary (R/train.py:535-540, 568-576)
+    hist = E.scan_confusions(ret, np.arange(19))
+    want = sum(E.fast_hist_crop(g[f"{tag}_point_predict_{b}"], g[f"{tag}_point_labels_{b}"], np.arange(19)) for b in range(2))
+    assert hist.shape == (19, 19) and np.abs(hist - want).sum() <= 4
+
+
+def test_reference_format_checkpoint_loads(tmp_path):
+    """R/train.py:319-342 checkpoint layout, DDP-prefixed keys: load_params_from_file (base_segmentors.py:16-37), then
+    the loaded model reproduces the reference model's eval logits"""
+    from taseg_amd.pcseg.model import build_network
+    g = _load("ckpt_minkunet_ms_ref.npz")
+    path = os.path.join(GOLDEN, "ckpt_minkunet_ms_ref.pth")
+    cfg = make_model_cfg("MinkUNetMs", in_dim=5, cr=0.125, num_layer=[1] * 8)
+    model = build_network(cfg, 20)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    log = logging.getLogger("ckpt-test")
+    with pytest.raises(FileNotFoundError):
+        model.load_params_from_file(str(tmp_path / "missing.pth"), log)
+    model.load_params_from_file(path, log, to_cpu=True)
+    state = torch.load(path, map_location="cpu")
+    assert set(state) == {"epoch", "it", "model_state", "optimizer_state", "scaler_state", "scheduler_state"}
+    assert len(state["model_state"]) == int(g["n_entries"]) == len(model.state_dict())
+    changed = 0
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, state["model_state"]["module." + k]), k
+        changed += int(not torch.equal(v, before[k]))
+    assert changed > 100
+    model = model.cuda().eval()
+    with torch.no_grad():
+        ret = model(_eval_batch(g, "batch_"))
+    assert np.abs(ret["point_predict_logits"][0] - g["ref_point_predict_logits_0"]).max() <= LOGIT_TOL
+    assert (ret["point_predict"][0] == g["ref_point_predict_0"]).mean() >= 0.999
+
+
+def test_nuscenes_stage_on_device_matches_reference(g_multiscan_nus):
+    """nuscenes_ms.py:226-373 + nuscenes_voxel_ms.py on device: fused cloud, labels and the collated batch (voxel order,
+    representatives, inverse maps, point mask) bit for bit against the reference dataset code"""
+    from taseg_amd.data import nuscenes as N
+    g = g_multiscan_nus
+    steps = g["steps"].tolist()
+    lm = g["learning_map"]
+    samples = []
+    for b in range(2):
+        _, seq, index, pts, pseudo, labels = nus_sample(g, b)
+        offsets = N.select_sweeps(seq, index, int(g["multiscan"]), float(g["step"]))
+        assert offsets == g[f"b{b}_sample_list"].tolist()
+        params = torch.from_numpy(N.sweep_params(seq, index, offsets)).cuda()
+        cur = torch.from_numpy(g[f"b{b}_points_cur"]).cuda()
+        cur_lab = torch.from_numpy(lm[g[f"b{b}_rawlabels_cur"]]).cuda()
+        hp = [torch.from_numpy(pts[d]).cuda() for d in offsets]
+        hl = [torch.from_numpy(np.asarray(labels[d], dtype=np.int64)).cuda() for d in offsets]
+        hs = [torch.from_numpy(pseudo[d].astype(np.int64)).cuda() for d in offsets]
+        raw, lab, keep = N.fuse_sweeps(cur, cur_lab, hp, hl, hs, params, steps)
+        assert np.array_equal(raw[keep].cpu().numpy(), g[f"b{b}_xyzret_ms"])          # float32 bit for bit
+        assert np.array_equal(lab[keep].cpu().numpy(), g[f"b{b}_labels_ms"])
+        # the un-filtered transform of every sweep point outside the ego box
+        n_cur = cur.shape[0]
+        fused, no_ego = N.B.fuse_sweeps(torch.cat(hp).contiguous(), N._layout([len(p) for p in hp], steps, cur.device)[0], params)
+        assert np.array_equal(fused[no_ego].cpu().numpy(), g[f"b{b}_fused_all"])
+        assert int((~no_ego).sum()) > 0 and raw.shape[0] == n_cur + fused.shape[0]
+        samples.append(dict(points=cur, labels=cur_lab, hist_points=hp, hist_labels=hl, hist_pseudo=hs, params=params,
+                            name=f"s{b}"))
+    batch = N.build_nuscenes_batch(samples, 0.1, steps)
+    for key in ("lidar", "lidar_ms", "inverse_map", "inverse_map_ms", "targets", "targets_ms", "targets_mapped",
+                "targets_mapped_ms"):
+        assert np.array_equal(batch[key].C.cpu().numpy(), g[f"batch_{key}_C"]), key
+        assert np.array_equal(batch[key].F.cpu().numpy(), g[f"batch_{key}_F"]), key
+    for key in ("num_points", "num_points_ms", "offset", "offset_ms", "point_mask"):
+        assert np.array_equal(batch[key].cpu().numpy().reshape(-1), g[f"batch_{key}"].reshape(-1)), key
