@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
                                                           const float *__restrict__ W, int O_total,
                                                           const int2 *__restrict__ nbmaps,
                                                           const int *__restrict__ nboffs, int K, int gcol,
-                                                          float *__restrict__ Z) {
+                                                          float *__restrict__ Z, const int2 *__restrict__ sched,
+                                                          int n_sched) {
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
   constexpr int NI = (BN / 16) / WC;
@@ -111,11 +112,22 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
   // list, i.e. 3 - 4 consecutive offsets, so that its L2 holds the weight slices it multiplies with (27 W_k of a
   // 256 x 256 layer are 7 MB, an XCD's L2 4 MB)
   const int tile = XCD ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
-  const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
-  const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
-  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
-  const int np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  int k, p0, np;
+  if (sched) {
+    // tiles in the order of a schedule table [n_sched] = (offset, first pair): tiles that touch neighbouring output rows
+    // run at the same time on the same XCD, so the rows they gather are served by that XCD's L2
+    if (tile >= n_sched) return;
+    const int2 sc = sched[tile];
+    k = __builtin_amdgcn_readfirstlane(sc.x);
+    p0 = __builtin_amdgcn_readfirstlane(sc.y);
+    np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  } else {
+    if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
+    k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
+    const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
+    p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
+    np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  }
 
   // A slots: 8-float chunk (tid & 3) of tile row (tid >> 2) + 64 it
   const int arow0 = tid >> 2, acol = (tid & 3) << 3;
@@ -245,10 +257,13 @@ static int launch_pair_gemm_s(const float *X, int R, const float *W, int O_total
                               int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
   const size_t lds = (size_t)3 * (BM * PS_AP + (WT ? BN * PS_AP : PS_BK * (BN + 8))) * 2;
   dim3 grid((unsigned)((ts_cdiv(P, BM) + K + 7) / 8 * 8), (unsigned)(O_total / BN));
+  const int2 *sched = (BM == 128 && g_ts_conv_impl == 9) ? g_ts_tile_sched : nullptr;
   if (g_ts_conv_impl == 8)    // tiles in launch order (A/B of the XCD remap)
-    pair_gemm_s_kernel<BM, BN, WR, WT, false><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
+    pair_gemm_s_kernel<BM, BN, WR, WT, false><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z,
+                                                                          nullptr, 0);
   else
-    pair_gemm_s_kernel<BM, BN, WR, WT, true><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
+    pair_gemm_s_kernel<BM, BN, WR, WT, true><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z,
+                                                                         sched, g_ts_tile_sched_n);
   TS_CHECK_LAUNCH("conv_pair_gemm (split)");
   return TS_OK;
 }
