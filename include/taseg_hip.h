@@ -206,6 +206,18 @@ int ts_conv_wgrad(const float *a_feat, int32_t c_a, const float *b_feat, int32_t
                   const int32_t *nbmaps, const int32_t *nboffs, int32_t kernel_volume,
                   int32_t col_a, int64_t n_pairs, float *grad_kernel,
                   ts_stream_t stream);
+/* The same weight gradient with run-to-run identical bits (the reference's grad_kernel[k] = in_buf^T . out_grad_buf,
+ * convolution_cuda.cu:259-263, is one GEMM per offset and therefore deterministic; ts_conv_wgrad combines the partial
+ * tiles of its pair chunks with float atomics): every workgroup stores its partial tile into `ws`, a second launch adds
+ * the tiles of each offset in ascending chunk order.  ws >= ts_conv_wgrad_workspace_bytes(...), 16-byte aligned.
+ * ts_conv_wgrad_f16_det: IEEE-half operands, float32 accumulation and result (the AMP path). */
+size_t ts_conv_wgrad_workspace_bytes(int64_t n_pairs, int32_t c_a, int32_t c_b, int32_t kernel_volume);
+int ts_conv_wgrad_det(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
+                      const int32_t *nboffs, int32_t kernel_volume, int32_t col_a, int64_t n_pairs, float *grad_kernel,
+                      void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_conv_wgrad_f16_det(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b, const int32_t *nbmaps,
+                          const int32_t *nboffs, int32_t kernel_volume, int32_t col_a, int64_t n_pairs,
+                          float *grad_kernel, void *ws, size_t ws_bytes, ts_stream_t stream);
 
 /* Two-pass convolution on the rulebook itself (the default forward / dgrad path):
  *   pass 1  ts_conv_pair_gemm :  z[p, :] = feat[g_p, :] @ W_{k(p)}   for every pair p of nbmaps,

@@ -45,6 +45,9 @@ SIGNATURES = {
     "ts_trilinear_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "ts_conv_nbr": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ts_conv_wgrad": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "ts_conv_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "ts_conv_wgrad_det": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
+    "ts_conv_wgrad_f16_det": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
     "ts_conv_pair_gemm": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_gather_sum": (_i32, [_vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp]),
     "ts_bn_finalize": (_i32, [_vp, _vp, _c.c_double, _i32, _c.c_float, _c.c_float, _vp, _vp, _vp, _vp, _vp]),

@@ -444,9 +444,12 @@ def conv_wgrad_f16(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pai
     with _Timed("conv_wgrad", name=f"wgrad_h_kernel<{pick(a_feat.shape[1])},{pick(b_feat.shape[1])}>", nboffs=nboffs,
                 c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume, esize=2, n_rows=a_feat.shape[0],
                 n_rows_b=b_feat.shape[0]):
-        L.check(L.load().ts_conv_wgrad_f16(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
-                                           L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
-                                           L.ptr(out), L.stream()), "ts_conv_wgrad_f16")
+        lib = L.load()
+        ws = L.workspace(lib.ts_conv_wgrad_workspace_bytes(int(max_pairs), a_feat.shape[1], b_feat.shape[1], kernel_volume),
+                         a_feat.device)
+        L.check(lib.ts_conv_wgrad_f16_det(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
+                                          L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
+                                          L.ptr(out), L.ptr(ws), ws.numel(), L.stream()), "ts_conv_wgrad_f16_det")
     return out
 
 
@@ -626,7 +629,7 @@ def conv_nbr(in_feat, kernel, nbr, n_out, weight_transposed=False):
 
 
 def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
-    """grad_kernel[k] = sum_pairs a[pa]^T b[pb]  ->  [K, c_a, c_b]."""
+    """grad_kernel[k] = sum_pairs a[pa]^T b[pb]  ->  [K, c_a, c_b]; deterministic (partial tiles + ordered sum)."""
     L.require_device(a_feat, b_feat, nbmaps, nboffs)
     a_feat, b_feat = _f32(a_feat, "a_feat"), _f32(b_feat, "b_feat")
     nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
@@ -634,9 +637,12 @@ def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
     with _Timed("conv_wgrad", name=conv_kernel_name(a_feat.shape[1], wgrad_cb=b_feat.shape[1]), nboffs=nboffs,
                 c_red=a_feat.shape[1], c_out=b_feat.shape[1], k=kernel_volume, n_rows=a_feat.shape[0],
                 n_rows_b=b_feat.shape[0]):
-        L.check(L.load().ts_conv_wgrad(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
-                                       L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
-                                       L.ptr(out), L.stream()), "ts_conv_wgrad")
+        lib = L.load()
+        ws = L.workspace(lib.ts_conv_wgrad_workspace_bytes(int(max_pairs), a_feat.shape[1], b_feat.shape[1], kernel_volume),
+                         a_feat.device)
+        L.check(lib.ts_conv_wgrad_det(L.ptr(a_feat), a_feat.shape[1], L.ptr(b_feat), b_feat.shape[1],
+                                      L.ptr(nbmaps), L.ptr(nboffs), kernel_volume, int(col_a), int(max_pairs),
+                                      L.ptr(out), L.ptr(ws), ws.numel(), L.stream()), "ts_conv_wgrad_det")
     return out
 
 

@@ -24,6 +24,7 @@ extern "C" size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_
   total += blk_align((size_t)n_rows_max * cmax * es);               // gradient w.r.t. the convolution output
   if (half) total += blk_align((size_t)K * c_in * c_out * 2);       // W16T of the forward pass
   total += blk_align(ts_bn_train_workspace_bytes(std::max(c_in, c_out)));
+  total += blk_align(ts_wgrad_partial_bytes(n_pairs, c_in, c_out, K));   // weight-gradient partial tiles (backward)
   return total;
 }
 
@@ -221,14 +222,29 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                     c_out, (float *)grad_conv, (float *)grad_residual, grad_bn_weight, grad_bn_bias, bn_ws,
                                     bn_ws_bytes, stream));
   }
-  // the gather-sum launch of the input gradient clears the weight-gradient tensor on the side (the weight gradient
-  // accumulates into it with atomics right after): one fill launch less per block
-  const int64_t gk_floats = (int64_t)K * c_in * c_out;
-  const bool side_zero = grad_feat && grad_kernel && n_dgrad_rows > 0 && (gk_floats & 3) == 0 &&
-                         (((uintptr_t)grad_kernel) & 15) == 0;
-  float *zp = side_zero ? grad_kernel : nullptr;
-  const int64_t zn = side_zero ? gk_floats : 0;
+  // Weight gradient first, as partial tiles (deterministic form, common.h): their ordered sum then rides on the
+  // gather-sum launch of the input gradient - no reduce launch, no fill of grad_kernel, no float atomics.  A block
+  // without an input gradient (the first layer) sums with a launch of its own.
   const double es_d = half ? 2 : 4;
+  float *part = (float *)(((char *)bn_ws) + blk_align(bn_ws_bytes));
+  const bool det = grad_kernel && ((int64_t)c_in * c_out) % 4 == 0 && (((uintptr_t)grad_kernel) & 15) == 0 &&
+                   g_ts_conv_impl != 1;
+  TsWgradReduce job = {};
+  if (grad_kernel) {
+    ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, (double)n_out);
+    if (det) g_ts_wgrad_part = part;
+    int rc;
+    if (half)
+      rc = ts_conv_wgrad_f16_ex(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel,
+                                det ? 1 : 0, stream);
+    else
+      rc = ts_conv_wgrad_ex((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a,
+                            n_pairs, grad_kernel, det ? 1 : 0, stream);
+    g_ts_wgrad_part = nullptr;
+    if (rc != TS_OK) return rc;
+    if (det) job = TsWgradReduce{part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
+  }
+  const bool ride = det && grad_feat && n_dgrad_rows > 0;
   if (grad_feat) {
     {
       ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, 1);
@@ -242,20 +258,13 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     {
       ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, 0);
       if (half)
-        TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, zp, zn, stream));
+        TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, ride ? &job : nullptr,
+                                         stream));
       else
-        TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat, zp,
-                                     zn, stream));
+        TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat,
+                                     ride ? &job : nullptr, stream));
     }
   }
-  if (grad_kernel) {
-    ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, (double)n_out);
-    if (half)
-      TS_TRY(ts_conv_wgrad_f16_ex(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel,
-                                  side_zero ? 1 : 0, stream));
-    else
-      TS_TRY(ts_conv_wgrad_ex((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a,
-                              n_pairs, grad_kernel, side_zero ? 1 : 0, stream));
-  }
+  if (det && !ride) TS_TRY(ts_wgrad_reduce(job, stream));
   return TS_OK;
 }

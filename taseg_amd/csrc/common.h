@@ -115,13 +115,66 @@ __device__ __forceinline__ int ts_table_find(const TsTable &t, uint64_t key) {
 int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream,
                   size_t *used);
 
-// Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can clear a second buffer
-// on the side (the weight-gradient tensor the NEXT launch accumulates into with atomics - saves its own fill launch),
-// and the weight gradient can be told that its output is already zero.
+// ---- deterministic weight gradient ------------------------------------------------------------------------------
+// A weight-gradient workgroup = (chunk c of consecutive rulebook pairs, TM x TN tile).  Instead of adding its partial
+// tile of offset k into dW_k with float atomics (order = whatever workgroup finishes first), it stores the tile into
+// slot (c + k) of a partial buffer [slots][C_a][C_b] - the pairs are ordered by offset, so (c, k) -> c + k is one to
+// one - and dW_k = sum of the slots c0(k) + k .. c1(k) + k in ascending c: a fixed summation order, plain stores, no
+// fill of dW.  The sum is formed by `wgrad_reduce_kernel` or, in the fused block calls, on the side of the gather-sum
+// launch that follows anyway (no extra launch).
+struct TsWgradPlan {
+  int chunk;          // pairs per workgroup along the list
+  int n_chunks;       // ceil(n_pairs / chunk)
+  int64_t slots;      // n_chunks + K
+};
+static inline TsWgradPlan ts_wgrad_plan(int64_t n_pairs, int tiles, int K, int step, int max_chunk) {
+  int64_t chunk = ts_cdiv(n_pairs * tiles, 512);
+  chunk = std::min<int64_t>(max_chunk, std::max<int64_t>(128, (chunk + step - 1) / step * step));
+  TsWgradPlan p;
+  p.chunk = (int)chunk;
+  p.n_chunks = (int)ts_cdiv(std::max<int64_t>(n_pairs, 1), chunk);
+  p.slots = (int64_t)p.n_chunks + K;
+  return p;
+}
+struct TsWgradReduce {       // everything the ordered sum needs (by value into the kernels)
+  const float *part;         // [slots][cacb]
+  const int *nboffs;         // [K + 1]
+  float *dW;                 // [K][cacb]
+  int K, chunk;
+  int64_t cacb4;             // C_a * C_b / 4 (float4 granules; C_a * C_b is a multiple of 4 on this path)
+};
+extern thread_local float *g_ts_wgrad_part;    // != nullptr: the next weight-gradient launch stores partial tiles here
+extern thread_local TsWgradPlan g_ts_wgrad_plan;   // ... and leaves the plan it used here
+int ts_wgrad_reduce(const TsWgradReduce &job, ts_stream_t stream);
+size_t ts_wgrad_partial_bytes(int64_t n_pairs, int32_t c_a, int32_t c_b, int32_t K);
+
+__device__ __forceinline__ void ts_wgrad_reduce_one(const TsWgradReduce &job, int64_t i) {
+  const int k = (int)(i / job.cacb4);
+  const int64_t e = i - (int64_t)k * job.cacb4;
+  const int lo = job.nboffs[k], hi = job.nboffs[k + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (hi > lo) {
+    const int c0 = lo / job.chunk, c1 = (hi - 1) / job.chunk;
+    const float4 *src = (const float4 *)job.part + ((int64_t)c0 + k) * job.cacb4 + e;
+#pragma unroll 4
+    for (int c = c0; c <= c1; ++c, src += job.cacb4) {      // ascending chunk: the fixed summation order
+      const float4 v = *src;
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+  }
+  ((float4 *)job.dW)[i] = acc;
+}
+
+// Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can form the ordered sum
+// of the weight-gradient partials on the side (saves the reduce launch), and the atomic form of the weight gradient
+// can be told that its output is already zero.
 int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                          float *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream);
+                          float *out, const TsWgradReduce *side, ts_stream_t stream);
 int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                              void *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream);
+                              void *out, const TsWgradReduce *side, ts_stream_t stream);
 int ts_conv_wgrad_ex(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
                      const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
                      int32_t already_zero, ts_stream_t stream);

@@ -670,7 +670,7 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
   const bool fast = (R % PG_BK == 0) && (O_total % BN == 0) && ((((uintptr_t)X) | ((uintptr_t)W)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
-  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 9)))   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
+  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 31)))   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
     return ts_pair_gemm_split(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, BN, WT ? 1 : 0, stream);
   if (fast) {
     static bool fattr_set = false;
@@ -738,12 +738,13 @@ template <int VEC, int KT>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ Z, int C,
                                                          const int *__restrict__ pos, int K, int64_t n,
                                                          int64_t n_pairs, float *__restrict__ out,
-                                                         float4 *__restrict__ zero_ptr, int64_t zero_n4) {
+                                                         TsWgradReduce side) {
   const int cv = C / VEC;
   const int64_t total = n * cv;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = e; i < zero_n4; i += step) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // side job, see common.h
+  // side job (common.h): the ordered sum of the weight-gradient partials of the launch before this one
+  for (int64_t i = e; i < (int64_t)side.K * side.cacb4; i += step) ts_wgrad_reduce_one(side, i);
   for (; e < total; e += step) {
     const int64_t j = e / cv;
     const int c = (int)(e - j * cv) * VEC;
@@ -794,16 +795,17 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
 
 extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                   int64_t n_pairs, float *out, ts_stream_t stream_) {
-  return ts_conv_gather_sum_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, 0, stream_);
+  return ts_conv_gather_sum_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, stream_);
 }
 
 int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                          float *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream_) {
+                          float *out, const TsWgradReduce *side_job, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(zero_floats == 0 || (zero_ptr && (zero_floats & 3) == 0 && (((uintptr_t)zero_ptr) & 15) == 0 && n_rows > 0),
-             TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: bad side buffer");
-  float4 *zp = (float4 *)zero_ptr;
-  const int64_t zn = zero_floats / 4;
+  TsWgradReduce side = {};
+  if (side_job) side = *side_job;
+  TS_REQUIRE(!side_job || (n_rows > 0 && side.part && side.dW && side.nboffs && side.chunk > 0 &&
+                           ((((uintptr_t)side.part) | ((uintptr_t)side.dW)) & 15) == 0),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: bad side job");
   TS_REQUIRE(c > 0 && K > 0 && n_rows >= 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: bad sizes");
   if (n_rows == 0) return TS_OK;
   TS_REQUIRE(pos && out && (z || n_pairs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: null pointer");
@@ -811,14 +813,14 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
   if (vec) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 4), 256), 1 << 20);
     if (K == 27)
-      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
+      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
     else if (K == 8)
-      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
+      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
     else
-      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
+      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
   } else {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * c, 256), 1 << 20);
-    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, zp, zn);
+    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
   }
   TS_CHECK_LAUNCH("conv_gather_sum");
   return TS_OK;
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const float *__restr
                                                          const float *__restrict__ B, int CB,
                                                          const int2 *__restrict__ nbmaps,
                                                          const int *__restrict__ nboffs, int K, int P, int col_a,
-                                                         int chunk, float *__restrict__ dW) {
+                                                         int chunk, float *__restrict__ dW, float *__restrict__ part) {
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int XP = TM + 4, YP = TN + 4;
   __shared__ __attribute__((aligned(16))) float Xl[2 * WG_PS * XP];  // double buffered
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const float *__restr
       }
     }
     if (nxt.k != cur.k) {  // last step of this offset inside the chunk: flush its partial tile
-      float *dwk = dW + (int64_t)cur.k * CA * CB;
+      float *dwk = part ? part + ((int64_t)blockIdx.x + cur.k) * CA * CB : dW + (int64_t)cur.k * CA * CB;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -1008,7 +1010,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const float *__restr
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ci = (wr * MI + mi) * 16 + 4 * g + q;
-            if (ci < ca && co < cb) atomicAdd(&dwk[(int64_t)(ci0 + ci) * CB + co0 + co], acc[mi][ni][q]);
+            if (ci < ca && co < cb) {
+              float *dst = &dwk[(int64_t)(ci0 + ci) * CB + co0 + co];
+              if (part)
+                *dst = acc[mi][ni][q];      // slot (chunk + offset) of the partial buffer: plain store, summed in order later
+              else
+                atomicAdd(dst, acc[mi][ni][q]);
+            }
           }
           acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -1028,7 +1036,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__
                                                               const float *__restrict__ B, int CB,
                                                               const int2 *__restrict__ nbmaps,
                                                               const int *__restrict__ nboffs, int K, int P,
-                                                              int col_a, int chunk, float *__restrict__ dW) {
+                                                              int col_a, int chunk, float *__restrict__ dW,
+                                                              float *__restrict__ part) {
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int XP = TM + 4, YP = TN + 4;
   constexpr int A_IT = TM / 32, B_IT = TN / 32;  // float4 slots per thread per 32-pair step
@@ -1159,15 +1168,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_fast_kernel(const float *__
       }
     }
     if (nxt.k != cur.k) {
-      float *dwk = dW + (int64_t)cur.k * CA * CB + (int64_t)ci0 * CB + co0;
+      float *dwk = (part ? part + ((int64_t)blockIdx.x + cur.k) * CA * CB : dW + (int64_t)cur.k * CA * CB) +
+                   (int64_t)ci0 * CB + co0;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            atomicAdd(&dwk[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * CB + (wc * NI + ni) * 16 + r16],
-                      acc[mi][ni][q]);
+          for (int q = 0; q < 4; ++q) {
+            float *dst = &dwk[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * CB + (wc * NI + ni) * 16 + r16];
+            if (part)
+              *dst = acc[mi][ni][q];
+            else
+              atomicAdd(dst, acc[mi][ni][q]);
+          }
           acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -1183,21 +1197,71 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   const int tiles = (int)(ts_cdiv(CA, TM) * ts_cdiv(CB, TN));
   // ~512 workgroups over the launch (one resident round at 2 per CU): every workgroup ends with a TM x TN tile of
   // float atomics (64 KB at 128 x 128), so chunks must be long - 128 .. 1024 pairs, multiples of the 32-pair step
-  int64_t chunk = ts_cdiv(n_pairs * tiles, 512);
-  chunk = std::min<int64_t>(WG_MAXCHUNK, std::max<int64_t>(128, (chunk + WG_PS - 1) / WG_PS * WG_PS));
-  dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
+  const TsWgradPlan plan = ts_wgrad_plan(n_pairs, tiles, K, WG_PS, WG_MAXCHUNK);
+  g_ts_wgrad_plan = plan;
+  const int64_t chunk = plan.chunk;
+  dim3 grid((unsigned)plan.n_chunks, tiles);
+  float *part = g_ts_wgrad_part;
   const bool fast = (CA % TM == 0) && (CB % TN == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
-  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 9)))
+  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 31)))
     return ts_wgrad_split(A, CA, B, CB, nbmaps, nboffs, K, col_a, n_pairs, dW, TM, TN, stream);
   if (fast)
     wgrad_gemm_fast_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
-                                                            (int)chunk, dW);
+                                                            (int)chunk, dW, part);
   else
     wgrad_gemm_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,
-                                                       (int)chunk, dW);
+                                                       (int)chunk, dW, part);
   TS_CHECK_LAUNCH("conv_wgrad");
   return TS_OK;
+}
+
+thread_local float *g_ts_wgrad_part = nullptr;
+thread_local TsWgradPlan g_ts_wgrad_plan = {0, 0, 0};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(TsWgradReduce job) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)job.K * job.cacb4) ts_wgrad_reduce_one(job, i);
+}
+
+int ts_wgrad_reduce(const TsWgradReduce &job, ts_stream_t stream_) {
+  const int64_t n = (int64_t)job.K * job.cacb4;
+  if (n == 0) return TS_OK;
+  wgrad_reduce_kernel<<<(unsigned)ts_cdiv(n, 256), 256, 0, (hipStream_t)stream_>>>(job);
+  TS_CHECK_LAUNCH("wgrad_reduce");
+  return TS_OK;
+}
+
+// bytes of the partial buffer of a deterministic weight gradient: an upper bound over the tilings the launchers pick
+// (the chunk length grows with the tile count, so one tile gives the most chunks; every kernel family steps by 32 pairs
+// and caps chunks at 1024)
+size_t ts_wgrad_partial_bytes(int64_t n_pairs, int32_t c_a, int32_t c_b, int32_t K) {
+  return (size_t)ts_wgrad_plan(n_pairs, 1, K, 32, 1024).slots * c_a * c_b * sizeof(float);
+}
+
+extern "C" size_t ts_conv_wgrad_workspace_bytes(int64_t n_pairs, int32_t c_a, int32_t c_b, int32_t K) {
+  return ts_align_up(ts_wgrad_partial_bytes(n_pairs, c_a, c_b, K), 256);
+}
+
+// Deterministic weight gradient: partial tiles into `ws`, then their ordered sum - run to run identical bits.
+extern "C" int ts_conv_wgrad_det(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b,
+                                 const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
+                                 int64_t n_pairs, float *grad_kernel, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_det: bad sizes");
+  if (g_ts_conv_impl == 1 || ((int64_t)c_a * c_b) % 4 != 0 || ((uintptr_t)grad_kernel & 15) != 0)   // scalar cross-check kernel /
+    return ts_conv_wgrad_ex(a_feat, c_a, b_feat, c_b, nbmaps, nboffs, K, col_a, n_pairs, grad_kernel, 0, stream_);   // odd shapes
+  TS_REQUIRE(ws && ws_bytes >= ts_conv_wgrad_workspace_bytes(n_pairs, c_a, c_b, K) && ((uintptr_t)ws & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_det: workspace too small");
+  if (n_pairs == 0) {
+    TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, (hipStream_t)stream_), "wgrad memset");
+    return TS_OK;
+  }
+  g_ts_wgrad_part = (float *)ws;
+  const int rc = ts_conv_wgrad_ex(a_feat, c_a, b_feat, c_b, nbmaps, nboffs, K, col_a, n_pairs, grad_kernel, 1, stream_);
+  g_ts_wgrad_part = nullptr;
+  if (rc != TS_OK) return rc;
+  const TsWgradReduce job = {(const float *)ws, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_a * c_b / 4};
+  return ts_wgrad_reduce(job, stream_);
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const float *__restrict__ A, int CA,

@@ -264,12 +264,12 @@ static int pair_gemm_f16_any(const void *feat, int64_t n_rows, int32_t c_red, co
 template <int KT>
 __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__restrict__ Z, int C,
                                                            const int *__restrict__ pos, int K, int64_t n_rows,
-                                                           _Float16 *__restrict__ out, float4 *__restrict__ zero_ptr,
-                                                           int64_t zero_n4) {
+                                                           _Float16 *__restrict__ out, TsWgradReduce side) {
   const int c8n = C >> 3;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = n_rows * c8n, step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = e; i < zero_n4; i += step) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // side job, see common.h
+  // side job (common.h): the ordered sum of the weight-gradient partials of the launch before this one
+  for (int64_t i = e; i < (int64_t)side.K * side.cacb4; i += step) ts_wgrad_reduce_one(side, i);
   for (; e < total; e += step) {
     const int64_t j = e / c8n;
     const int c8 = (int)(e - j * c8n) << 3;
@@ -305,16 +305,17 @@ __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__res
 
 extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                       int64_t n_pairs, void *out, ts_stream_t stream_) {
-  return ts_conv_gather_sum_f16_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, 0, stream_);
+  return ts_conv_gather_sum_f16_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, stream_);
 }
 
 int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                              void *out, float *zero_ptr, int64_t zero_floats, ts_stream_t stream_) {
+                              void *out, const TsWgradReduce *side_job, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(zero_floats == 0 || (zero_ptr && (zero_floats & 3) == 0 && (((uintptr_t)zero_ptr) & 15) == 0 && n_rows > 0),
-             TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum_f16: bad side buffer");
-  float4 *zp = (float4 *)zero_ptr;
-  const int64_t zn = zero_floats / 4;
+  TsWgradReduce side = {};
+  if (side_job) side = *side_job;
+  TS_REQUIRE(!side_job || (n_rows > 0 && side.part && side.dW && side.nboffs && side.chunk > 0 &&
+                           ((((uintptr_t)side.part) | ((uintptr_t)side.dW)) & 15) == 0),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum_f16: bad side job");
   TS_REQUIRE(c > 0 && (c & 7) == 0 && K > 0 && n_rows >= 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_gather_sum_f16: bad sizes (C must be a multiple of 8)");
   if (n_rows == 0) return TS_OK;
@@ -324,11 +325,11 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
   const int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 8), 256), 1 << 20);
   const _Float16 *zz = (const _Float16 *)z;
   if (K == 27)
-    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, zp, zn);
+    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side);
   else if (K == 8)
-    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, zp, zn);
+    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side);
   else
-    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, zp, zn);
+    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side);
   TS_CHECK_LAUNCH("ts_conv_gather_sum_f16");
   return TS_OK;
 }
@@ -348,7 +349,8 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void wgrad_h_kernel(const _Float16 *__restrict__ A, int CA,
                                                       const _Float16 *__restrict__ B, int CB,
                                                       const int2 *__restrict__ nbmaps, const int *__restrict__ nboffs,
-                                                      int K, int P, int col_a, int chunk, float *__restrict__ dW) {
+                                                      int K, int P, int col_a, int chunk, float *__restrict__ dW,
+                                                      float *__restrict__ part) {
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int XP = TM + 8, YP = TN + 8;              // pitches in halves (16-byte multiples, 4 mod 8 dwords)
   constexpr int A_IT = (WH_PS * (TM / 8) + 255) / 256, B_IT = (WH_PS * (TN / 8) + 255) / 256;
@@ -475,15 +477,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_h_kernel(const _Float16 *__restr
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
     if (nxt.k != cur.k) {
-      float *dwk = dW + (int64_t)cur.k * CA * CB + (int64_t)ci0 * CB + co0;
+      // deterministic form: the tile goes to slot (chunk + offset) of the partial buffer (common.h, TsWgradPlan)
+      float *dwk = (part ? part + ((int64_t)blockIdx.x + cur.k) * CA * CB : dW + (int64_t)cur.k * CA * CB) +
+                   (int64_t)ci0 * CB + co0;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            atomicAdd(&dwk[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * CB + (wc * NI + ni) * 16 + r16],
-                      acc[mi][ni][q]);
+          for (int q = 0; q < 4; ++q) {
+            float *dst = &dwk[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * CB + (wc * NI + ni) * 16 + r16];
+            if (part)
+              *dst = acc[mi][ni][q];
+            else
+              atomicAdd(dst, acc[mi][ni][q]);
+          }
           acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -497,9 +505,10 @@ template <int TM, int TN>
 static int launch_wgrad_h(const _Float16 *A, int CA, const _Float16 *B, int CB, const int2 *nbmaps, const int *nboffs,
                           int K, int col_a, int64_t n_pairs, float *dW, hipStream_t stream) {
   const int tiles = (CA / TM) * (CB / TN);
-  int64_t chunk = ts_cdiv(n_pairs * tiles, 512);
-  chunk = std::min<int64_t>(WH_MAXCHUNK, std::max<int64_t>(128, (chunk + WH_PS - 1) / WH_PS * WH_PS));
-  dim3 grid((unsigned)ts_cdiv(n_pairs, chunk), tiles);
+  const TsWgradPlan plan = ts_wgrad_plan(n_pairs, tiles, K, WH_PS, WH_MAXCHUNK);
+  g_ts_wgrad_plan = plan;
+  const int64_t chunk = plan.chunk;
+  dim3 grid((unsigned)plan.n_chunks, tiles);
   const size_t lds = (size_t)2 * WH_PS * ((TM + 8) + (TN + 8)) * 2 + 2 * WH_MAXCHUNK * 4;
   static bool attr_set = false;
   if (!attr_set) {
@@ -507,7 +516,8 @@ static int launch_wgrad_h(const _Float16 *A, int CA, const _Float16 *B, int CB, 
                                      160 * 1024), "hipFuncSetAttribute");
     attr_set = true;
   }
-  wgrad_h_kernel<TM, TN><<<grid, 256, lds, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a, (int)chunk, dW);
+  wgrad_h_kernel<TM, TN><<<grid, 256, lds, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a, (int)chunk, dW,
+                                                     g_ts_wgrad_part);
   TS_CHECK_LAUNCH("conv_wgrad_f16");
   return TS_OK;
 }
@@ -516,6 +526,26 @@ extern "C" int ts_conv_wgrad_f16(const void *a_feat, int32_t c_a, const void *b_
                                  const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
                                  int64_t n_pairs, float *grad_kernel, ts_stream_t stream_) {
   return ts_conv_wgrad_f16_ex(a_feat, c_a, b_feat, c_b, nbmaps, nboffs, K, col_a, n_pairs, grad_kernel, 0, stream_);
+}
+
+// Deterministic form (partial tiles into `ws`, ordered sum): see ts_conv_wgrad_det.
+extern "C" int ts_conv_wgrad_f16_det(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b,
+                                     const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int32_t col_a,
+                                     int64_t n_pairs, float *grad_kernel, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  TS_REQUIRE(c_a > 0 && c_b > 0 && K > 0 && n_pairs >= 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_f16_det: bad sizes");
+  TS_REQUIRE(ws && ws_bytes >= ts_conv_wgrad_workspace_bytes(n_pairs, c_a, c_b, K) && ((uintptr_t)ws & 15) == 0 &&
+                 ((uintptr_t)grad_kernel & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_wgrad_f16_det: workspace too small or misaligned");
+  if (n_pairs == 0) {
+    TS_CHECK_HIP(hipMemsetAsync(grad_kernel, 0, (size_t)K * c_a * c_b * 4, (hipStream_t)stream_), "wgrad memset");
+    return TS_OK;
+  }
+  g_ts_wgrad_part = (float *)ws;
+  const int rc = ts_conv_wgrad_f16_ex(a_feat, c_a, b_feat, c_b, nbmaps, nboffs, K, col_a, n_pairs, grad_kernel, 1, stream_);
+  g_ts_wgrad_part = nullptr;
+  if (rc != TS_OK) return rc;
+  const TsWgradReduce job = {(const float *)ws, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_a * c_b / 4};
+  return ts_wgrad_reduce(job, stream_);
 }
 
 int ts_conv_wgrad_f16_ex(const void *a_feat, int32_t c_a, const void *b_feat, int32_t c_b, const int32_t *nbmaps,

@@ -750,3 +750,57 @@ def test_devoxelize_cat_equals_cat_of_devoxelize(B, F):
     assert torch.equal(ya, yb)
     for fa, fb in zip(a, b):
         close(fa.grad, fb.grad, 2e-5)
+
+
+def test_weight_gradient_is_deterministic_and_matches_atomic_form():
+    """ts_conv_wgrad_det (partial tiles + ordered sum; what every training path uses) gives identical bits run to run,
+    agrees with the float64 product and with the atomic form ts_conv_wgrad to fp32 rounding - fp32 and half operands,
+    full-tile and ragged channel counts, an empty offset in the rulebook"""
+    from taseg_amd import _lib as L
+    from taseg_amd import backend as B
+    from taseg_amd.data.synthetic import synth_scan
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.nn import functional as spF
+    pts, _ = synth_scan(9, n_points=30000, n_beams=32, n_az=1000)
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    idx, _ = O.sparse_quantize(pc)
+    coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+    x = SparseTensor(None, coords, 1)
+    spF.build_pyramid(x, 2)
+    lib = L.load()
+    g = torch.Generator().manual_seed(0)
+    for stride, ca, cb in ((1, 96, 96), (2, 64, 128), (1, 20, 36), (4, 256, 256)):
+        km = x.kmaps[((stride,) * 3, (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+        n, P = km.sizes[0], km.total
+        a = torch.randn(n, ca, generator=g).cuda()
+        b = torch.randn(n, cb, generator=g).cuda()
+        runs = [B.conv_wgrad(a, b, km.nbmaps_buf, km.nboffs, 27, col_a=0, max_pairs=P) for _ in range(3)]
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        atomic = torch.empty_like(runs[0])
+        L.check(lib.ts_conv_wgrad(L.ptr(a), ca, L.ptr(b), cb, L.ptr(km.nbmaps_buf), L.ptr(km.nboffs), 27, 0, P,
+                                  L.ptr(atomic), L.stream()), "ts_conv_wgrad")
+        nb = km.nbmaps[:, :].cpu().numpy()
+        sizes = km.nbsizes.cpu().numpy()
+        want = np.zeros((27, ca, cb))
+        a64, b64 = a.double().cpu().numpy(), b.double().cpu().numpy()
+        p0 = 0
+        for k in range(27):
+            sl = nb[p0:p0 + sizes[k]]
+            want[k] = a64[sl[:, 0]].T @ b64[sl[:, 1]]
+            p0 += sizes[k]
+        scale = np.abs(want).max()
+        assert np.abs(runs[0].cpu().numpy() - want).max() <= 2e-5 * scale
+        assert np.abs(atomic.cpu().numpy() - want).max() <= 2e-5 * scale
+        if ca % 32 == 0 and cb % 32 == 0:
+            ah, bh = a.half(), b.half()
+            hr = [B.conv_wgrad_f16(ah, bh, km.nbmaps_buf, km.nboffs, 27, col_a=0, max_pairs=P) for _ in range(2)]
+            assert torch.equal(hr[0], hr[1])
+            wanth = np.zeros_like(want)
+            ah64, bh64 = ah.double().cpu().numpy(), bh.double().cpu().numpy()
+            p0 = 0
+            for k in range(27):
+                sl = nb[p0:p0 + sizes[k]]
+                wanth[k] = ah64[sl[:, 0]].T @ bh64[sl[:, 1]]
+                p0 += sizes[k]
+            assert np.abs(hr[0].cpu().numpy() - wanth).max() <= 2e-5 * scale
