@@ -21,6 +21,9 @@ from .utils import voxel_to_point, voxelize_index
 
 __all__ = ["MinkUNet"]
 
+import os as _os
+_DEVOX_ATOMIC = _os.environ.get("TASEG_DEVOX_ATOMIC", "0") == "1"
+
 
 class SyncBatchNorm(spnn.SyncBatchNorm):
     """nn.SyncBatchNorm applied to SparseTensor features (minkunet.py:23-25); training-mode reductions on HIP."""
@@ -251,8 +254,8 @@ class MinkUNetBackbone(BaseSegmentor):
                     kmaps[((s, s, s), (2, 2, 2), (2, 2, 2), (1, 1, 1))] = km
             keys = ((1, 1, 1), (16, 16, 16), (4, 4, 4))
             tri_idx, tri_w = dict(zip(keys, t_idx)), dict(zip(keys, t_w))
-            tri_order = {keys[1]: orders[0]}
-            for key in (keys[0], keys[2]):
+            tri_order = {keys[1]: orders[0]} if _DEVOX_ATOMIC else {}
+            for key in (keys if not _DEVOX_ATOMIC else (keys[0], keys[2])):
                 tri_order[key] = B.devox_csr(tri_idx[key], tri_w[key], cmaps[key].shape[0])
             return dict(coords=coords, point_coords=pc, cmaps=cmaps, kmaps=kmaps, tri_idx=tri_idx, tri_w=tri_w,
                         tri_order=tri_order, **extra)
@@ -264,10 +267,11 @@ class MinkUNetBackbone(BaseSegmentor):
             for s in (1, 16, 4):
                 key = (s, s, s)
                 tri_idx[key], tri_w[key] = B.trilinear_map(pc, probe.cmaps[key], s)
-                # how the devoxelize backward walks this map: strides 1 and 4 (1 / ~3 live corners per point) gather along
-                # the inverse map, no atomics; stride 16 (~4 live corners, ~60 points per voxel) adds runs of points of
-                # one interpolation cell with atomics, every gradient row read once
-                if s == 16:
+                # how the devoxelize backward walks this map: a gather along the inverse map, no atomics, fixed summation
+                # order (the whole training step is run-to-run deterministic).  TASEG_DEVOX_ATOMIC=1: stride 16 (~4 live
+                # corners, ~60 points per voxel) adds runs of points of one interpolation cell with float atomics instead,
+                # every gradient row read once (147 vs 235 us per step, last-bit noise in the stage-4 gradients)
+                if s == 16 and _DEVOX_ATOMIC:
                     tri_order[key] = B.devox_order(tri_idx[key], probe.cmaps[key].shape[0])
                 else:
                     tri_order[key] = B.devox_csr(tri_idx[key], tri_w[key], probe.cmaps[key].shape[0])
