@@ -38,17 +38,23 @@ def _history_index(lengths: Sequence[int], deltas: Sequence[int], steps: Sequenc
             _static_cache.pop(next(iter(_static_cache)))
         scan_idx = torch.repeat_interleave(torch.arange(len(lengths), dtype=torch.int32),
                                            torch.tensor(list(lengths), dtype=torch.int64)).to(device)
-        table = torch.tensor([[bool(st) and abs(d) % st == 0 for st in steps] for d in deltas], dtype=torch.bool)
+        # last column: pseudo class -1 = a label that is no class's canonical raw id (e.g. a moving-object id): never kept
+        table = torch.tensor([[bool(st) and abs(d) % st == 0 for st in steps] + [False] for d in deltas], dtype=torch.bool)
         hit = (scan_idx, table.to(device))
         _static_cache[key] = hit
     return hit
 
 
-def _fuse_history(cur_pts, cur_lab, hist_pts, hist_lab, pose0, hist_poses, deltas, steps):
+def _fuse_history(cur_pts, cur_lab, hist_pts, hist_lab, pose0, hist_poses, deltas, steps, hist_pseudo=None):
     """All history scans in one pass: concatenate, transform every point with its scan's pose (ts_fuse_scans),
     look the class-step decision up per point.  Returns the un-filtered stack [current | history] (x, y, z,
     intensity, time flag), its labels and the keep mask; order = current scan first, then history oldest first, each
-    in file order - the order the reference's loop produces (semantickitti_ms.py:140-149)."""
+    in file order - the order the reference's loop produces (semantickitti_ms.py:140-149).
+
+    hist_pseudo[i] (optional): the class whose CANONICAL raw id the point's pseudo label is, or -1 - the reference
+    compares the raw pseudo label with LEARNING_MAP_INV[class] (semantickitti_ms.py:303-308), so a raw id that maps to
+    a class without being its canonical id (the moving-object ids 252 .. 259) is never aggregated.  Default: the
+    annotation classes `hist_lab` (exact when labels only hold canonical ids, as the synthetic scans do)."""
     dev = cur_pts.device
     n_cur = cur_pts.shape[0]
     if len(hist_pts) == 0:
@@ -58,7 +64,9 @@ def _fuse_history(cur_pts, cur_lab, hist_pts, hist_lab, pose0, hist_poses, delta
     hp = torch.cat([p[:, :4] for p in hist_pts], 0).contiguous()
     hl = torch.cat(hist_lab, 0).long()
     fused = B.fuse_scans(hp, scan_idx, pose0, torch.stack(list(hist_poses), 0))
-    keep = table.view(-1)[scan_idx.long() * table.shape[1] + hl]
+    ps = hl if hist_pseudo is None else torch.cat(hist_pseudo, 0).long()
+    ps = torch.where(ps < 0, torch.full_like(ps, table.shape[1] - 1), ps)
+    keep = table.view(-1)[scan_idx.long() * table.shape[1] + ps]
     pts = torch.cat([cur_pts[:, :4], fused], 0)
     flag = torch.zeros((pts.shape[0], 1), dtype=pts.dtype, device=dev)
     flag[:n_cur] = 1                               # append_time_flag (semantickitti_ms.py:253-257)
@@ -150,14 +158,16 @@ def collate_batch(samples: List[Dict]) -> Dict:
 
 
 def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[int]) -> Dict:
-    """scans[b] = dict(points=[T+1 tensors, current LAST], labels=[...], poses=[...], name=str).
+    """scans[b] = dict(points=[T+1 tensors, current LAST], labels=[...], poses=[...], name=str
+    [, deltas=[frame offsets of the history scans], pseudo=[pseudo classes of the history scans, see _fuse_history]]).
     Returns the collated batch_dict MinkUNetMs consumes."""
     samples = []
     for s in scans:
         pts, lab, poses = s["points"], s["labels"], s["poses"]
         t = len(pts) - 1
-        raw_all, lab_all, keep = _fuse_history(pts[t], lab[t], pts[:t], lab[:t], poses[t], poses[:t],
-                                               [i - t for i in range(t)], steps)
+        deltas = s.get("deltas") or [i - t for i in range(t)]
+        raw_all, lab_all, keep = _fuse_history(pts[t], lab[t], pts[:t], lab[:t], poses[t], poses[:t], deltas, steps,
+                                               s.get("pseudo"))
         samples.append(voxelize_sample_ms(pts[t], lab[t].long(), raw_all, lab_all, voxel_size, s.get("name", ""),
                                           keep=keep))
     return collate_batch(samples)
