@@ -27,8 +27,9 @@ MFMA_F32_PEAK_TF = 157.3     # dense f32-input MFMA peak (same guide)
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (same guide; no sparsity)
 MFMA_SPLIT_PEAK_TF = MFMA_F16_PEAK_TF / 6   # fp32 products as six bf16 MFMAs (csrc/conv_pairs_s.hip): 416.7 TF/s of fp32 flops
 VOXEL = 0.05
-EVENT_EVERY = 10            # per-launch HIP events bracket the conv kernels of every 10th timed step (recorded inside the
-                            # block calls; an event pair costs ~3 us of device time per launch: ~2 ms on such a step)
+EVENT_EVERY = 20            # per-launch HIP events bracket the conv kernels of every 20th timed step (recorded inside the
+                            # block calls; an event pair costs ~3 us of device time per launch: ~2 ms on such a step,
+                            # i.e. ~0.1 ms per step of the default 20-step run)
 
 
 def note(msg):
@@ -302,7 +303,7 @@ def summarise_profile(records, steps):
             byts = p * (m["c_red"] * es + m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * es
         elif kind == "gather_sum":   # Z read + output write + position table       (second half)
             flops = float(p * m["c_out"])
-            byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4
+            byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4 + m.get("side_bytes", 0.0)
         else:
             byts = p * (m["c_red"] * es + 2 * m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
         # ideal-fused lower bound of the same launch: every feature row read / written once, the

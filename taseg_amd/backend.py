@@ -533,7 +533,7 @@ def profile_end():
             name = (f"gather_sum_h_kernel<{k if k in (8, 27) else 0}>" if half else
                     f"gather_sum_kernel<4,{k if k in (8, 27) else 0}>" if c_out % 4 == 0 else "gather_sum_kernel<1,0>")
             out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,
-                                                          esize=esize)))
+                                                          esize=esize, side_bytes=float(wt))))
         else:
             name = f"wgrad_h_kernel<{pick(c_red)},{pick(c_out)}>" if half else conv_kernel_name(c_red, wgrad_cb=c_out)
             out.append(("conv_wgrad", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k,

@@ -39,7 +39,8 @@ extern "C" size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_
 // two HIP events on the caller's stream (from a pool created on first use).  ts_prof_collect synchronises the events
 // and returns one record per launch: {kind (0 pair GEMM, 1 gather-sum, 2 weight gradient), milliseconds, pairs,
 // c_red, c_out, K, rows (pair GEMM / weight gradient: rows of the gathered matrix; gather-sum: rows written), bytes per
-// element, weight transposed (weight gradient: rows of the second operand)}.  Off (the default): one predictable branch per launch.
+// element, weight transposed (weight gradient: rows of the second operand; gather-sum: bytes of the weight-gradient sum
+// it carries on the side)}.  Off (the default): one predictable branch per launch.
 namespace {
 struct ProfRec {
   int kind;
@@ -256,7 +257,9 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                  n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
     }
     {
-      ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, 0);
+      // the ordered weight-gradient sum riding on this launch reads its partial tiles and writes grad_kernel: real bytes
+      const double side_bytes = ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0;
+      ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, side_bytes);
       if (half)
         TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, ride ? &job : nullptr,
                                          stream));

@@ -11,8 +11,6 @@
 #define TS_WAVE 64
 
 void ts_set_error(const char *fmt, ...);
-extern const int2 *g_ts_tile_sched;   // experiment (ts_set_conv_impl(9)): tile schedule table of the split pair GEMM
-extern int g_ts_tile_sched_n;
 extern int g_ts_conv_impl;  // 0 = MFMA kernels, 1 = scalar cross-check kernels (ts_set_conv_impl)
 
 #define TS_REQUIRE(cond, code, ...)  \

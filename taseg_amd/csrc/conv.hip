@@ -25,12 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CV_AP (CV_CK + 4)  // LDS row pitch (floats) of K-major tiles: 16-B aligned, bank-skewed
 
 int g_ts_conv_impl = 0;
-const int2 *g_ts_tile_sched = nullptr;
-int g_ts_tile_sched_n = 0;
-extern "C" void ts_debug_tile_sched(const void *table, int32_t n) {
-  g_ts_tile_sched = (const int2 *)table;
-  g_ts_tile_sched_n = n;
-}
+
 extern "C" void ts_set_conv_impl(int32_t impl) { g_ts_conv_impl = impl; }
 
 // ======================================================================================

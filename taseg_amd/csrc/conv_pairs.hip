@@ -670,7 +670,7 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
   const bool fast = (R % PG_BK == 0) && (O_total % BN == 0) && ((((uintptr_t)X) | ((uintptr_t)W)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
-  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 31)))   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
+  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 8)))   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
     return ts_pair_gemm_split(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, BN, WT ? 1 : 0, stream);
   if (fast) {
     static bool fattr_set = false;
@@ -1204,7 +1204,7 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   float *part = g_ts_wgrad_part;
   const bool fast = (CA % TM == 0) && (CB % TN == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
-  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 31)))
+  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 8)))
     return ts_wgrad_split(A, CA, B, CB, nbmaps, nboffs, K, col_a, n_pairs, dW, TM, TN, stream);
   if (fast)
     wgrad_gemm_fast_kernel<TM, TN><<<grid, 256, 0, stream>>>(A, CA, B, CB, nbmaps, nboffs, K, (int)n_pairs, col_a,

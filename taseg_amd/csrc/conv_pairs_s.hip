@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
                                                           const float *__restrict__ W, int O_total,
                                                           const int2 *__restrict__ nbmaps,
                                                           const int *__restrict__ nboffs, int K, int gcol,
-                                                          float *__restrict__ Z, const int2 *__restrict__ sched,
-                                                          int n_sched, int abl) {
+                                                          float *__restrict__ Z) {
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
   constexpr int NI = (BN / 16) / WC;
@@ -112,22 +111,11 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
   // list, i.e. 3 - 4 consecutive offsets, so that its L2 holds the weight slices it multiplies with (27 W_k of a
   // 256 x 256 layer are 7 MB, an XCD's L2 4 MB)
   const int tile = XCD ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  int k, p0, np;
-  if (sched) {
-    // tiles in the order of a schedule table [n_sched] = (offset, first pair): tiles that touch neighbouring output rows
-    // run at the same time on the same XCD, so the rows they gather are served by that XCD's L2
-    if (tile >= n_sched) return;
-    const int2 sc = sched[tile];
-    k = __builtin_amdgcn_readfirstlane(sc.x);
-    p0 = __builtin_amdgcn_readfirstlane(sc.y);
-    np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
-  } else {
-    if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
-    k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
-    const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
-    p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
-    np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
-  }
+  if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
+  const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
+  const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
+  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
+  const int np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
 
   // A slots: 8-float chunk (tid & 3) of tile row (tid >> 2) + 64 it
   const int arow0 = tid >> 2, acol = (tid & 3) << 3;
@@ -228,10 +216,9 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
     store_lds();
     __syncthreads();
     if (c0 + PS_BK < R) load_regs(c0 + PS_BK);
-    if (!(abl & 4)) mma();
+    mma();
   }
   float *zt = Z + (int64_t)p0 * O_total + o0;
-  if ((abl & 1) && acc[0][0][0] != 12345.678f) return;        // ablation: no Z stores
   if (np == BM) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -253,270 +240,15 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
   }
 }
 
-// Persistent form of pair_gemm_s_kernel (BM = 128): a workgroup walks a strided list of tiles and overlaps the three
-// phases the one-tile-per-workgroup kernel runs back to back (profiles/r02_ablate.txt: gather + split + LDS 70 us,
-// MFMAs 85 us, Z stores 60 us of a 216 us launch add up almost exactly): the pair indices of the NEXT tile are loaded a
-// whole tile ahead, its first operand slice is issued before the last MFMA block of the current tile, and the Z stores
-// of the current tile (the youngest vector-memory operations: vmcnt counts in issue order) drain while the next
-// tile's first slice is split and multiplied.  Same arithmetic per tile, bit-identical Z.
-template <int BN, int WR, bool WT>
-__global__ __launch_bounds__(256, 2) void pair_gemm_sp_kernel(const float *__restrict__ X, int R,
-                                                           const float *__restrict__ W, int O_total,
-                                                           const int2 *__restrict__ nbmaps,
-                                                           const int *__restrict__ nboffs, int K, int gcol,
-                                                           float *__restrict__ Z) {
-  constexpr int BM = PS_BM;
-  constexpr int WC = 4 / WR;
-  constexpr int MI = (BM / 16) / WR;
-  constexpr int NI = (BN / 16) / WC;
-  constexpr int BP = BN + 8;
-  constexpr int A_PLANE = BM * PS_AP;
-  constexpr int B_PLANE = WT ? BN * PS_AP : PS_BK * BP;
-  constexpr int A_IT = BM * (PS_BK / 8) / 256;
-  constexpr int B_CHUNKS = BN * (PS_BK / 8);
-  constexpr int B_IT = (B_CHUNKS + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem_s[];
-  unsigned short *Ap = smem_s;
-  unsigned short *Bp = Ap + 3 * A_PLANE;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, g = lane >> 4;
-  const int tq = r16 >> 2, tp = lane & 3;
-  const int wr = wave / WC, wc = wave % WC;
-  const int o0 = blockIdx.y * BN;
-
-  const int offv = nboffs[min(lane, K)];
-  const int offn = nboffs[min(lane + 1, K)];
-  int incl = lane < K ? (offn - offv + BM - 1) / BM : 0;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += up;
-  }
-  const int n_tiles = __builtin_amdgcn_readlane(incl, 63);
-  // XCD x (workgroups go round-robin over the XCDs) owns the x-th eighth of the tile list; its workgroups take the
-  // tiles of that range in turn, so at any time they work on neighbouring tiles of the same few offsets
-  const int per_xcd = (n_tiles + 7) >> 3;
-  const int stride = (int)(gridDim.x >> 3);
-  const int t_end = min(n_tiles, ((int)(blockIdx.x & 7) + 1) * per_xcd);
-  int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (t >= t_end) return;
-
-  struct Tile {
-    int k, p0, np;
-  };
-  auto decode = [&](int tile) -> Tile {
-    Tile r;
-    r.k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
-    const int t_in_k = tile - (r.k ? __builtin_amdgcn_readlane(incl, max(r.k - 1, 0)) : 0);
-    r.p0 = __builtin_amdgcn_readlane(offv, r.k) + t_in_k * BM;
-    r.np = min(BM, __builtin_amdgcn_readlane(offv, r.k + 1) - r.p0);
-    return r;
-  };
-
-  const int arow0 = tid >> 2, acol = (tid & 3) << 3;
-  int boff[B_IT], bdst[B_IT];
-#pragma unroll
-  for (int it = 0; it < B_IT; ++it) {
-    const int e = min(tid + it * 256, B_CHUNKS - 1);
-    if (WT) {
-      const int col = e >> 2, c8 = (e & 3) << 3;
-      boff[it] = col * R + c8;
-      bdst[it] = col * PS_AP + c8;
-    } else {
-      constexpr int q8 = BN >> 3;
-      const int kk = e / q8, c8 = (e - kk * q8) << 3;
-      boff[it] = kk * O_total + c8;
-      bdst[it] = kk * BP + c8;
-    }
-  }
-  auto weights_of = [&](int k) -> const float * {
-    return WT ? W + ((int64_t)k * O_total + o0) * R : W + (int64_t)k * R * O_total + o0;
-  };
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float *aptr[A_IT];
-  const float *wk;
-  f32x4 ra[A_IT][2], rb[B_IT][2];
-  auto load_regs = [&](int c0) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      ra[it][0] = *(const f32x4 *)(aptr[it] + c0);
-      ra[it][1] = *(const f32x4 *)(aptr[it] + c0 + 4);
-    }
-    const float *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      rb[it][0] = *(const f32x4 *)(wb + boff[it]);
-      rb[it][1] = *(const f32x4 *)(wb + boff[it] + 4);
-    }
-  };
-  auto store_lds = [&](int np) {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int rr = arow0 + 64 * it;
-      const bool live = rr < np;
-      u32x4 h, m, l;
-      split8(live ? ra[it][0] : zero, live ? ra[it][1] : zero, h, m, l);
-      unsigned short *dst = Ap + rr * PS_AP + acol;
-      *(u32x4 *)dst = h;
-      *(u32x4 *)(dst + A_PLANE) = m;
-      *(u32x4 *)(dst + 2 * A_PLANE) = l;
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      if (B_IT * 256 == B_CHUNKS || tid + it * 256 < B_CHUNKS) {
-        u32x4 h, m, l;
-        split8(rb[it][0], rb[it][1], h, m, l);
-        unsigned short *dst = Bp + bdst[it];
-        *(u32x4 *)dst = h;
-        *(u32x4 *)(dst + B_PLANE) = m;
-        *(u32x4 *)(dst + 2 * B_PLANE) = l;
-      }
-    }
-  };
-  auto mma = [&]() {
-    bf8 a[MI][3];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[mi][p] = *(const bf8 *)&Ap[p * A_PLANE + ((wr * MI + mi) * 16 + r16) * PS_AP + 8 * g];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      bf8 b[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        if (WT)
-          b[p] = *(const bf8 *)&Bp[p * B_PLANE + ((wc * NI + ni) * 16 + r16) * PS_AP + 8 * g];
-        else
-          b[p] = frag_tr(Bp + p * B_PLANE, BP, 8 * g, (wc * NI + ni) * 16, tq, tp);
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) TS_SPLIT_MMA(acc[mi][ni], a[mi], b);
-    }
-  };
-
-  Tile cur = decode(t);
-  int2 npr[A_IT];                       // pair (in, out) rows of the tile after `cur`, loaded one tile ahead
-#pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    const int2 pr = nbmaps[cur.p0 + min(arow0 + 64 * it, cur.np - 1)];
-    aptr[it] = X + (int64_t)(gcol ? pr.y : pr.x) * R + acol;
-  }
-  wk = weights_of(cur.k);
-  load_regs(0);
-  Tile nxt = cur;
-  bool has_next = t + stride < t_end;
-  if (has_next) {
-    nxt = decode(t + stride);
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) npr[it] = nbmaps[nxt.p0 + min(arow0 + 64 * it, nxt.np - 1)];
-  }
-  // Z addressing: wave-uniform tile base + 32-bit lane offset (saddr + voffset stores; 64-bit per-store addresses kept
-  // live across the tile loop cost ~100 VGPRs and spilled)
-  const unsigned zoff0 = (unsigned)((wr * MI * 16 + 4 * g) * O_total + wc * NI * 16 + r16);
-  auto write_z = [&](const Tile &tz) {      // acc -> Z rows of tile tz, then clear acc
-    float *zt = Z + (int64_t)tz.p0 * O_total + o0;
-    const int row0 = wr * MI * 16 + 4 * g;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned zrow = zoff0 + (unsigned)((mi * 16 + q) * O_total);
-        if (tz.np == BM || row0 + mi * 16 + q < tz.np) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) TS_ZSTORE(acc[mi][ni][q], &zt[zrow + (unsigned)(ni * 16)]);
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  bool first = true, pending = false;
-  Tile done = cur;                          // the tile whose sums still sit in acc
-  for (;;) {
-    for (int c0 = 0; c0 < R; c0 += PS_BK) {
-      if (!first) __syncthreads();          // the previous slice's fragments have been read
-      first = false;
-      store_lds(cur.np);                    // waits for this slice's loads only: nothing younger is in flight
-      __syncthreads();
-      if (c0 == 0 && pending) {
-        // the previous tile's sums leave now, in front of the loads of the next slice: loads and stores are counted in
-        // issue order, so these stores drain during the MFMA block below exactly like the loads issued after them
-        write_z(done);
-        pending = false;
-      }
-      if (c0 + PS_BK < R) {
-        load_regs(c0 + PS_BK);
-      } else if (has_next) {                // across the tile boundary: first slice of the next tile
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) aptr[it] = X + (int64_t)(gcol ? npr[it].y : npr[it].x) * R + acol;
-        wk = weights_of(nxt.k);
-        load_regs(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);    // keep the loads above the MFMA block (the scheduler otherwise sinks them)
-      mma();
-    }
-    done = cur;
-    pending = true;
-    if (!has_next) break;
-    cur = nxt;
-    t += stride;
-    has_next = t + stride < t_end;
-    if (has_next) {
-      nxt = decode(t + stride);
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it) npr[it] = nbmaps[nxt.p0 + min(arow0 + 64 * it, nxt.np - 1)];
-    }
-  }
-  write_z(done);
-}
-
-template <int BN, int WR, bool WT>
-static int launch_pair_gemm_sp(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
-                               int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
-  const size_t lds = (size_t)3 * (PS_BM * PS_AP + (WT ? BN * PS_AP : PS_BK * (BN + 8))) * 2;
-  static int occ = 0, n_cu = 0;          // per instantiation: resident workgroups per CU, CUs of the device
-  if (!occ) {
-    int dev = 0;
-    TS_CHECK_HIP(hipGetDevice(&dev), "hipGetDevice");
-    TS_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
-    int o = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, pair_gemm_sp_kernel<BN, WR, WT>, 256, lds) != hipSuccess || o < 1)
-      o = 1;
-    occ = o;
-  }
-  const int cols = O_total / BN;
-  const int64_t tiles_ub = ts_cdiv(P, PS_BM) + K;
-  int64_t wgs = std::max<int64_t>(8, (int64_t)n_cu * occ / cols / 8 * 8);
-  wgs = std::min<int64_t>(wgs, (tiles_ub + 7) / 8 * 8);
-  dim3 grid((unsigned)wgs, (unsigned)cols);
-  pair_gemm_sp_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
-  TS_CHECK_LAUNCH("conv_pair_gemm (split, persistent)");
-  return TS_OK;
-}
-
 template <int BM, int BN, int WR, bool WT>
 static int launch_pair_gemm_s(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs,
                               int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
   const size_t lds = (size_t)3 * (BM * PS_AP + (WT ? BN * PS_AP : PS_BK * (BN + 8))) * 2;
   dim3 grid((unsigned)((ts_cdiv(P, BM) + K + 7) / 8 * 8), (unsigned)(O_total / BN));
-  const int2 *sched = (BM == 128 && g_ts_conv_impl == 9) ? g_ts_tile_sched : nullptr;
   if (g_ts_conv_impl == 8)    // tiles in launch order (A/B of the XCD remap)
-    pair_gemm_s_kernel<BM, BN, WR, WT, false><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z,
-                                                                          nullptr, 0, 0);
+    pair_gemm_s_kernel<BM, BN, WR, WT, false><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
   else
-    pair_gemm_s_kernel<BM, BN, WR, WT, true><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z,
-                                                                         sched, g_ts_tile_sched_n,
-                                                                         g_ts_conv_impl >= 16 ? g_ts_conv_impl - 16 : 0);
+    pair_gemm_s_kernel<BM, BN, WR, WT, true><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
   TS_CHECK_LAUNCH("conv_pair_gemm (split)");
   return TS_OK;
 }
@@ -526,24 +258,18 @@ static int launch_pair_gemm_s(const float *X, int R, const float *W, int O_total
 // 4x the workgroups, 4 per CU) are 0 - 10 % slower than the 128-row tiles - those layers are bound by the bytes each
 // tile pulls through L2, not by latency or occupancy - and so is launch order vs the XCD-contiguous tile order
 // (+-3 %).  ts_set_conv_impl(6) selects the small tiles, (8) launch-order tiles.
+// Round 2 (profiles/r02_experiments_pair_gemm.txt): an ablation shows the phases of a workgroup (gather + split + LDS 70 us,
+// MFMAs 85 us, Z stores 60 us of the 216 us stride-1 96 -> 96 launch) running back to back; tried against it and NOT
+// adopted: persistent workgroups with cross-tile prefetch (hipcc spills at 256 VGPRs: 1.3x slower), tiles launched in
+// spatial order for L2 reuse of the gathered rows (+8-15 % on the 32 / 64-wide layers, -0-12 % on the wide ones), 64- /
+// 32-column tiles for more workgroups per CU (+-3 %), an LDS-free kernel whose lanes load their MFMA fragments straight
+// from global memory at 4 waves per SIMD (bound by the L1 rate of the weight fragments: 1.4-1.9x slower).
 int ts_pair_gemm_split(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs, int K,
                        int64_t P, int gcol, float *Z, int bn, int wt, hipStream_t stream) {
 #define TS_PS(BM, BN, WR)                                                                                   \
   (wt ? launch_pair_gemm_s<BM, BN, WR, true>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream)       \
       : launch_pair_gemm_s<BM, BN, WR, false>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream))
   if (g_ts_conv_impl == 6 && O_total % 64 == 0) return TS_PS(64, 64, 2);
-#define TS_PSP(BN, WR)                                                                                     \
-  (wt ? launch_pair_gemm_sp<BN, WR, true>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream)         \
-      : launch_pair_gemm_sp<BN, WR, false>(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, stream))
-  if (g_ts_conv_impl == 10) {      // persistent, cross-tile pipelined (A/B: tools/sched_probe.py)
-    switch (bn) {
-      case 32: return TS_PSP(32, 4);
-      case 64: return TS_PSP(64, 2);
-      case 96: return TS_PSP(96, 2);
-      default: return TS_PSP(128, 2);
-    }
-  }
-#undef TS_PSP
   switch (bn) {
     case 32: return TS_PS(128, 32, 4);
     case 64: return TS_PS(128, 64, 2);
