@@ -1219,15 +1219,53 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
 thread_local float *g_ts_wgrad_part = nullptr;
 thread_local TsWgradPlan g_ts_wgrad_plan = {0, 0, 0};
 
+// Stand-alone ordered sum (1x1x1 convolutions, the class head, blocks without an input gradient): few output elements
+// (K * C_a * C_b / 4 float4 granules) but up to ~500 partial tiles each, so four thread groups sum a quarter of the
+// chunk range each and the quarters are added in a fixed order - still one summation order per element.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(TsWgradReduce job) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)job.K * job.cacb4) ts_wgrad_reduce_one(job, i);
+  __shared__ float4 red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+  const bool live = i < (int64_t)job.K * job.cacb4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const int k = (int)(i / job.cacb4);
+    const int64_t e = i - (int64_t)k * job.cacb4;
+    const int lo = job.nboffs[k], hi = job.nboffs[k + 1];
+    if (hi > lo) {
+      const int c0 = lo / job.chunk, c1 = (hi - 1) / job.chunk;
+      const int per = (c1 - c0 + 4) >> 2;
+      const int a = c0 + ty * per, b = min(c1 + 1, a + per);
+      const float4 *src = (const float4 *)job.part + ((int64_t)a + k) * job.cacb4 + e;
+#pragma unroll 4
+      for (int c = a; c < b; ++c, src += job.cacb4) {
+        const float4 v = *src;
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
+    }
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && live) {
+    float4 r = red[0][tx];
+#pragma unroll
+    for (int y = 1; y < 4; ++y) {
+      r.x += red[y][tx].x;
+      r.y += red[y][tx].y;
+      r.z += red[y][tx].z;
+      r.w += red[y][tx].w;
+    }
+    ((float4 *)job.dW)[i] = r;
+  }
 }
 
 int ts_wgrad_reduce(const TsWgradReduce &job, ts_stream_t stream_) {
   const int64_t n = (int64_t)job.K * job.cacb4;
   if (n == 0) return TS_OK;
-  wgrad_reduce_kernel<<<(unsigned)ts_cdiv(n, 256), 256, 0, (hipStream_t)stream_>>>(job);
+  wgrad_reduce_kernel<<<(unsigned)ts_cdiv(n, 64), 256, 0, (hipStream_t)stream_>>>(job);
   TS_CHECK_LAUNCH("wgrad_reduce");
   return TS_OK;
 }
