@@ -169,3 +169,39 @@ def test_install_as_dropin_binds_reference_import_names():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert "DROPIN_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_eval_helpers(tmp_path, g_eval_ms):
+    """taseg_amd/pcseg/eval.py against the reference's outputs stored in eval_ms.npz (vote sum / payload, R/train.py:474-503)
+    and against direct restatements of fast_hist_crop / per_class_iu / tta_remap's lookup"""
+    from taseg_amd.pcseg import eval as E
+    g = g_eval_ms
+    votes = int(g["votes"])
+    ret = {"point_predict_logits": [g[f"minkunet_ms_tta_point_predict_logits_{v}"] for v in range(votes)],
+           "point_predict": [g[f"minkunet_ms_tta_point_predict_{v}"] for v in range(votes)],
+           "point_labels": [g[f"minkunet_ms_tta_point_labels_{v}"] for v in range(votes)], "name": g["minkunet_ms_tta_name"].tolist()}
+    acc = E.accumulate_votes(ret, votes)
+    assert np.array_equal(acc, g["minkunet_ms_tta_sum"])                        # same fp32 additions in the same order
+    payload = E.vote_payload(acc, "semantickitti")
+    assert np.array_equal(payload, g["minkunet_ms_tta_label"]) and payload.dtype == np.uint32
+    with pytest.raises(ValueError):
+        E.accumulate_votes(ret, votes + 1)
+    path = E.write_prediction(str(tmp_path / "sequences" / "08" / "predictions" / "000000.label"), payload)
+    back = np.fromfile(path, dtype=np.uint32)
+    assert np.array_equal(back, payload.reshape(-1))
+    # tta_remap.py:103-154: class ids -> raw SemanticKITTI ids through learning_map_inv, instance bits kept
+    from taseg_amd.data.semantickitti import LEARNING_MAP_INV
+    lut = E.remap_lut(LEARNING_MAP_INV)
+    withinst = back | (np.arange(len(back), dtype=np.uint32) << 16)
+    out = E.remap_labels(withinst, lut)
+    assert np.array_equal(out & 0xFFFF, np.array([LEARNING_MAP_INV[int(c)] for c in back], dtype=np.uint32))
+    assert np.array_equal(out >> 16, np.arange(len(back), dtype=np.uint32) & 0xFFFF)
+    # validation metric: R/train.py:35-52
+    pred, lab = g["minkunet_ms_point_predict_0"], g["minkunet_ms_point_labels_0"]
+    uniq = np.arange(19)
+    h = E.fast_hist_crop(pred, lab, uniq)
+    full = O.fast_hist(pred, lab, 21)
+    assert np.array_equal(h, full[1:20, 1:20]) and h.shape == (19, 19)
+    assert np.allclose(E.per_class_iu(h), O.per_class_iu(h))
+    with pytest.raises(ValueError):
+        E.vote_payload(np.eye(4)[[0, 1]], "nuscenes")                          # class 0 in a nuScenes submission
