@@ -263,7 +263,10 @@ static int launch_pair_gemm_s(const float *X, int R, const float *W, int O_total
 // adopted: persistent workgroups with cross-tile prefetch (hipcc spills at 256 VGPRs: 1.3x slower), tiles launched in
 // spatial order for L2 reuse of the gathered rows (+8-15 % on the 32 / 64-wide layers, -0-12 % on the wide ones), 64- /
 // 32-column tiles for more workgroups per CU (+-3 %), an LDS-free kernel whose lanes load their MFMA fragments straight
-// from global memory at 4 waves per SIMD (bound by the L1 rate of the weight fragments: 1.4-1.9x slower).
+// from global memory at 4 waves per SIMD (bound by the L1 rate of the weight fragments: 1.4-1.9x slower), a producer /
+// consumer kernel (4 loader waves fill a double-buffered LDS stage a slice ahead of 4 MFMA waves, one barrier per slice,
+// one workgroup per CU: 1.1-1.4x slower).  With every gather served from cache the launch still takes 172 us, without Z
+// stores 156 us: compute pipeline (~115 us), Z stores (~75 us) and gather (~70 us) each overlap the others only partly.
 int ts_pair_gemm_split(const float *X, int R, const float *W, int O_total, const int2 *nbmaps, const int *nboffs, int K,
                        int64_t P, int gcol, float *Z, int bn, int wt, hipStream_t stream) {
 #define TS_PS(BM, BN, WR)                                                                                   \
