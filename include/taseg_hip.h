@@ -512,6 +512,16 @@ int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64_t n, const
 int ts_fuse_sweeps(const float *points, const int32_t *sweep_idx, int64_t n, const double *params, int32_t n_sweeps,
                    float *out, uint8_t *keep, ts_stream_t stream);
 
+/* TIAF camera projection of one scan (pcseg/data/dataset/semantickitti/semantickitti_ms_mm.py:411-461 get_fov_points,
+ * the per-point part): for point i = (x, y, z, .)
+ *   uvz = P . (x, y, z, 1)            P = P2 . Tr, 3x4 row-major float64; float64 FMA chain in k order (numpy's dgemm)
+ *   keep[i] = x > 0  &&  0 < u < img_w  &&  0 < v < img_h  (u = uvz0 / uvz2, v = uvz1 / uvz2, float64)
+ *                    &&  (int)v < crop_h  &&  (int)u < crop_w
+ *   pix[i]  = ( float((int)v) + row_offset , float((int)u) )        row_offset = crop_h * frame index in the image stack
+ * points [n,4] float32; pix [n,2] float32 (undefined where keep == 0); keep [n] uint8. */
+int ts_project_fov(const float *points, int64_t n, const double *proj, int32_t img_w, int32_t img_h, int32_t crop_h,
+                   int32_t crop_w, float row_offset, float *pix, uint8_t *keep, ts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

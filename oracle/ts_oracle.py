@@ -450,3 +450,47 @@ def nus_multiscan_fuse(seq, index, sample_list, points, pseudo, labels, steps):
         pseudos.append(ps)
         masks.append(m)
     return np.concatenate(raws, 0), np.concatenate(anns, 0), np.concatenate(pseudos, 0), np.concatenate(masks, 0)
+
+
+# --------------------------------------------------------------------------- TIAF data stage (camera side)
+def tiaf_fov_points(raw_data, proj_matrix, image_size, height, width, img_batch):
+    """R/pcseg/data/dataset/semantickitti/semantickitti_ms_mm.py:411-461 (get_fov_points) without the image arrays:
+    points in front of the camera whose projection falls inside the image and inside the (height, width) crop, with
+    their pixel (row + height * img_batch, col) appended.  raw_data [n,4] float32, proj_matrix [3,4] float64 (P2 @ Tr),
+    image_size = (W, H).  Returns (raw_fov [m,6] float32, keep [n] bool)."""
+    raw_data = np.asarray(raw_data, dtype=np.float32)
+    keep_mask = raw_data[:, 0] > 0
+    xyz1 = np.concatenate([raw_data[:, :3][keep_mask], np.ones([keep_mask.sum(), 1], dtype=np.float32)], axis=1)
+    uvz = (proj_matrix @ xyz1.T).T
+    uv = uvz[:, :2] / np.expand_dims(uvz[:, 2], axis=1)
+    frustum = (uv[:, 0] > 0) * (uv[:, 1] > 0) * (uv[:, 0] < image_size[0]) * (uv[:, 1] < image_size[1])
+    keep_mask[keep_mask] = frustum
+    uv = np.fliplr(uv)                                           # (row, col)
+    frustum_uv = uv[frustum].astype(dtype=int)
+    cropped = (frustum_uv[:, 0] < height) & (frustum_uv[:, 1] < width)
+    keep_mask[keep_mask.nonzero()[0][~cropped]] = False
+    frustum_uv = frustum_uv[cropped].astype(raw_data.dtype)
+    frustum_uv[:, 0] += (height * img_batch)
+    return np.concatenate([raw_data[keep_mask], frustum_uv], axis=-1), keep_mask
+
+
+def tiaf_crop_image(image_u8_rgb, height, width):
+    """semantickitti_ms_mm.py:432-447: float32, RGB -> BGR, / 255, top-left crop zero-padded to (height, width)."""
+    image = np.array(image_u8_rgb, dtype=np.float32)
+    image[..., [0, 1, 2]] = image[..., [2, 1, 0]]
+    image = image / 255.
+    r_max, c_max = min(height, image.shape[0]), min(width, image.shape[1])
+    out = np.zeros((height, width, image.shape[2]), dtype=image.dtype)
+    out[:r_max, :c_max] = image[:r_max, :c_max]
+    return out
+
+
+def kitti_ring_id(points):
+    """semantickitti_ms_mm.py:131-141: beam index from the azimuth wrap-arounds of the scan order, clipped to 63."""
+    scan_x, scan_y = points[:, 0], points[:, 1]
+    yaw = -np.arctan2(scan_y, -scan_x)
+    proj_x = 0.5 * (yaw / np.pi + 1.0)
+    new_raw = np.nonzero((proj_x[1:] < 0.2) * (proj_x[:-1] > 0.8))[0] + 1
+    proj_y = np.zeros_like(proj_x)
+    proj_y[new_raw] = 1
+    return np.clip(np.cumsum(proj_y), 0, 63)

@@ -19,7 +19,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
 
@@ -726,6 +726,24 @@ def fuse_sweeps(points, sweep_idx, params):
     L.check(L.load().ts_fuse_sweeps(L.ptr(points), L.ptr(sweep_idx), points.shape[0], L.ptr(params), params.shape[0],
                                     L.ptr(out), L.ptr(keep), L.stream()), "ts_fuse_sweeps")
     return out, keep.bool()
+
+
+def project_fov(points, proj, image_size, crop, row_offset=0.0):
+    """TIAF camera projection of one scan (semantickitti_ms_mm.py:411-461): points [n,4] float32, proj [3,4] float64
+    (P2 @ Tr), image_size = (width, height) of the camera image, crop = (HEIGHT, WIDTH) of the network input.
+    Returns (pix [n,2] float32 = (row + row_offset, col), keep [n] bool)."""
+    L.require_device(points, proj)
+    points = _f32(points, "points")
+    if proj.dtype != torch.float64 or tuple(proj.shape) != (3, 4):
+        raise TypeError("proj must be float64 [3, 4]")
+    proj = proj.contiguous()
+    assert points.ndim == 2 and points.shape[1] == 4, points.shape
+    n = points.shape[0]
+    pix = torch.empty((n, 2), dtype=torch.float32, device=points.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=points.device)
+    L.check(L.load().ts_project_fov(L.ptr(points), n, L.ptr(proj), int(image_size[0]), int(image_size[1]), int(crop[0]),
+                                    int(crop[1]), float(row_offset), L.ptr(pix), L.ptr(keep), L.stream()), "ts_project_fov")
+    return pix, keep.bool()
 
 
 def voxel_coords(points, voxel_size, batch_idx=None, n_batch=1, shift=None):

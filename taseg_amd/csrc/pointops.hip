@@ -408,6 +408,53 @@ extern "C" int ts_fuse_sweeps(const float *points, const int32_t *sweep_idx, int
   return TS_OK;
 }
 
+// TIAF camera projection (semantickitti_ms_mm.py:419-457): see include/taseg_hip.h
+__global__ __launch_bounds__(256) void project_fov_kernel(const float4 *__restrict__ pts, int64_t n,
+                                                          const double *__restrict__ proj, int img_w, int img_h,
+                                                          int crop_h, int crop_w, float row_offset,
+                                                          float2 *__restrict__ pix, uint8_t *__restrict__ keep) {
+#pragma clang fp contract(off)
+  double P[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) P[i] = proj[i];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float4 p = pts[i];
+    const double x = p.x, y = p.y, z = p.z;
+    double uvz[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)      // sum_k P[j][k] * (x, y, z, 1)[k], accumulated with FMAs in k order
+      uvz[j] = __builtin_fma(P[4 * j + 3], 1.0, __builtin_fma(P[4 * j + 2], z, __builtin_fma(P[4 * j + 1], y, P[4 * j] * x)));
+    const double u = uvz[0] / uvz[2], v = uvz[1] / uvz[2];
+    bool ok = p.x > 0.f && u > 0.0 && v > 0.0 && u < (double)img_w && v < (double)img_h;
+    int row = 0, col = 0;
+    if (ok) {
+      row = (int)v;                  // astype(int): truncation
+      col = (int)u;
+      ok = row < crop_h && col < crop_w;
+    }
+    keep[i] = ok ? 1 : 0;
+    pix[i] = make_float2(__fadd_rn((float)row, row_offset), (float)col);
+  }
+}
+
+extern "C" int ts_project_fov(const float *points, int64_t n, const double *proj, int32_t img_w, int32_t img_h,
+                              int32_t crop_h, int32_t crop_w, float row_offset, float *pix, uint8_t *keep,
+                              ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && img_w > 0 && img_h > 0 && crop_h > 0 && crop_w > 0, TS_ERR_INVALID_ARGUMENT, "ts_project_fov: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(points && proj && pix && keep, TS_ERR_INVALID_ARGUMENT, "ts_project_fov: null pointer");
+  TS_REQUIRE(((((uintptr_t)points) & 15) | (((uintptr_t)pix) & 7)) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_project_fov: points must be 16-byte, pix 8-byte aligned");
+  const int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
+  project_fov_kernel<<<grid, 256, 0, stream>>>((const float4 *)points, n, proj, img_w, img_h, crop_h, crop_w, row_offset,
+                                               (float2 *)pix, keep);
+  TS_CHECK_LAUNCH("ts_project_fov");
+  return TS_OK;
+}
+
 extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose, float *out,
                             ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

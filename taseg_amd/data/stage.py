@@ -100,7 +100,7 @@ def voxelize_sample(points, labels, voxel_size, name="") -> Dict:
             "num_points": torch.tensor([points.shape[0]])}
 
 
-def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name="", keep=None) -> Dict:
+def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name="", keep=None, return_shift=False) -> Dict:
     """Multi-scan sample (semantickitti_voxel_ms.py:121-187): both clouds voxelised, the single-frame one
     shifted by the fused cloud's minimum.  `keep` (optional bool mask over points_ms) is AND-ed with the clamp
     so the class-step filter and the clamp cost one compaction (one host read) instead of two."""
@@ -111,7 +111,9 @@ def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name=""
     points_ms, labels_ms = points_ms[clamp].contiguous(), labels_ms[clamp]
     pc_ms, mins_ms, inds_ms, inverse_ms = _quantize(points_ms, voxel_size)
     pc, _, inds, inverse = _quantize(points, voxel_size, shift=mins_ms)   # pc_ -= pc_ms_.min(0)  (:130)
+    extra = {"_shift": mins_ms} if return_shift else {}      # the fused cloud's minimum: further clouds of the sample share it
     return {
+        **extra,
         "name": name,
         "lidar": SparseTensor(points[inds], pc[inds]), "targets": SparseTensor(labels[inds], pc[inds]),
         "targets_mapped": SparseTensor(labels, pc), "inverse_map": SparseTensor(inverse, pc),

@@ -519,6 +519,99 @@ def gen_nus(fname="multiscan_nus.npz", multiscan=4, step=1.0):
           "voxels_ms", out["batch_lidar_ms_C"].shape)
 
 
+# ----------------------------------------------------------------------------------------- TIAF dataset stage
+def gen_tiaf_data(fname="tiaf_data.npz", T=8, multiscan=4, multiscan_image=8, step_image=4, height=60, width=192):
+    """The reference's TIAF dataset path on two synthetic sequences held in memory: SemantickittiMsMmDataset.__getitem__
+    (multiscan_fuse with camera frames, get_fov_points, ring ids; semantickitti_ms_mm.py:143-461) ->
+    SemkittiVoxelMsMmDataset.get_single_sample / collate_batch (semantickitti_voxel_ms_mm.py:79-266).  Camera images and
+    semantic maps are random arrays served through patched Image.open / np.load; the image is a little larger than the
+    (height, width) crop on one axis and smaller on the other, so that crop mask and zero padding both act."""
+    import types
+    from PIL import Image
+    sys.modules.setdefault("mmcv", types.ModuleType("mmcv"))
+    for alias, typ in (("int", int), ("bool", bool), ("float", float)):
+        if not hasattr(np, alias):
+            setattr(np, alias, typ)
+    _ref_env.setup_datasets()
+    from pcseg.data.dataset.semantickitti.semantickitti_ms_mm import SemantickittiMsMmDataset
+    from pcseg.data.dataset.semantickitti.semantickitti_voxel_ms_mm import SemkittiVoxelMsMmDataset
+    from pcseg.data.dataset.semantickitti.semantickitti_utils import LEARNING_MAP_INV
+    inv = np.array([LEARNING_MAP_INV[i] for i in range(20)], dtype=np.uint32)
+    img_h, img_w = 64, 180                       # rows: 64 > HEIGHT 60 (cropped); columns: 180 < WIDTH 192 (zero padded)
+    # KITTI-style calibration: camera looks along +x of the lidar (x_cam = -y, y_cam = -z, z_cam = x), pinhole P2
+    tr = np.array([[0.0, -1.0, 0.0, 0.02], [0.0, 0.0, -1.0, -0.07], [1.0, 0.0, 0.0, -0.27], [0.0, 0.0, 0.0, 1.0]])
+    p2 = np.array([[95.0, 0.0, 90.5, 4.5], [0.0, 95.0, 30.25, 0.2], [0.0, 0.0, 1.0, 0.003]])
+    proj = np.matmul(p2, tr)
+    out = {"backend": np.array(BACKEND_DESC), "T": np.array(T), "multiscan": np.array(multiscan),
+           "multiscan_image": np.array(multiscan_image), "step_image": np.array(step_image), "height": np.array(height),
+           "width": np.array(width), "proj": proj, "steps": np.array(FLEX_KITTI),
+           "learning_map_inv": inv.astype(np.int64)}
+    samples = []
+    for b, seed in enumerate([81, 82]):
+        files, poses = {}, []
+        rs = np.random.RandomState(900 + seed)
+        for t in range(T + 1):
+            pose = synth_pose(T - t)
+            pts, lab = small_scan(1000 * seed + t, pose=pose, scene_seed=seed)
+            raw = inv[lab].copy()
+            if t < T:
+                raw[:150] = 254                   # moving persons in the history: class 6 by learning_map, never aggregated
+            path = f"/data/sequences/00/velodyne/{t:06d}.bin"
+            files[path] = pts
+            files[path.replace("velodyne", "labels")[:-3] + "label"] = raw.reshape(-1, 1)
+            poses.append(pose)
+            out[f"b{b}_points_t{t}"] = pts
+            out[f"b{b}_rawlabels_t{t}"] = raw
+            out[f"b{b}_pose_t{t}"] = pose
+            if (T - t) % step_image == 0:
+                img = rs.randint(0, 256, size=(img_h, img_w, 3)).astype(np.uint8)
+                sem = rs.randint(0, 20, size=(img_h, img_w, 1)).astype(np.float32)
+                files[path.replace("velodyne", "image_2").replace(".bin", ".png")] = img
+                files[path.replace("velodyne", "semantic_map_dilate").replace(".bin", ".npy")] = sem
+                out[f"b{b}_image_t{t}"] = img
+                out[f"b{b}_semantic_t{t}"] = sem
+        ds = object.__new__(SemantickittiMsMmDataset)
+        ds.poses, ds.proj_matrix = {0: poses}, {0: proj}
+        ds.only_history, ds.split, ds.seq, ds.pseudo_mask, ds.trainval_seqs = True, "val", -1, "gt", ["00"]
+        ds.if_scribble, ds.augment, ds.dynamic_step, ds.fov_dist = False, "none", False, -1
+        ds.multiscan, ds.flexible_steps, ds.multiscan_image, ds.step_image = multiscan, FLEX_KITTI, multiscan_image, step_image
+        ds.height, ds.width, ds.image_jitter, ds.image_flip, ds.flip_ratio = height, width, False, False, 0.5
+        ds.annos = [f"/data/sequences/00/velodyne/{t:06d}.bin" for t in range(T + 1)]
+        ds.annos_another = list(ds.annos)
+        real_fromfile, real_load, real_open, real_array = np.fromfile, np.load, Image.open, np.array
+        np.fromfile = lambda path, dtype=None, **kw: files[path].copy()
+        np.load = lambda path, *a, **kw: files[path].copy()
+        Image.open = lambda path, *a, **kw: Image.fromarray(files[path])
+        # the reference is written against numpy 1.x, where np.array(..., copy=False) means "copy only if needed" (:428)
+        np.array = lambda obj, *a, copy=True, **kw: real_array(obj, *a, copy=(None if copy is False else copy), **kw)
+        try:
+            pc_data = ds[T]
+        finally:
+            np.fromfile, np.load, Image.open, np.array = real_fromfile, real_load, real_open, real_array
+        for k in ("xyzret", "xyzret_ms", "xyzret_fov_ms", "image_ms", "semantic_map_ms"):
+            out[f"b{b}_{k}"] = np.asarray(pc_data[k], dtype=np.float32) if k != "image_ms" else pc_data[k][..., ::1][:, ::3, ::3].copy()
+        out[f"b{b}_image_ms_shape"] = np.array(pc_data["image_ms"].shape)
+        out[f"b{b}_labels"] = pc_data["labels"].reshape(-1).astype(np.int64)
+        out[f"b{b}_labels_ms"] = pc_data["labels_ms"].reshape(-1).astype(np.int64)
+        vox = object.__new__(SemkittiVoxelMsMmDataset)
+        vox.point_cloud_dataset = [pc_data]
+        vox.in_feature_dim, vox.training, vox.if_tta, vox.voxel_size, vox.num_points = 5, False, False, VOXEL, 3000000
+        vox.eval_range = [0, 1000]
+        samples.append(vox.get_single_sample(0))
+    batch = SemkittiVoxelMsMmDataset.collate_batch(samples)
+    for key in BATCH_SPARSE + ("lidar_fov_ms",):
+        out[f"batch_{key}_C"] = batch[key].C.numpy()
+        out[f"batch_{key}_F"] = batch[key].F.numpy()
+    for key in BATCH_DENSE + ("offset_img",):
+        out[f"batch_{key}"] = batch[key].numpy()
+    out["batch_image_ms_sub"] = batch["image_ms"].numpy()[:, :, ::3, ::3].copy()      # NCHW, every 3rd pixel
+    out["batch_image_ms_shape"] = np.array(batch["image_ms"].shape)
+    out["batch_semantic_map_ms"] = batch["semantic_map_ms"].numpy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, os.path.getsize(os.path.join(HERE, fname)) // 1024, "KiB; fov points", [out[f"b{b}_xyzret_fov_ms"].shape for b in range(2)],
+          "fov voxels", out["batch_lidar_fov_ms_C"].shape, "images", out["batch_image_ms_shape"].tolist())
+
+
 if __name__ == "__main__":
     print("reference backend:", BACKEND_DESC)
     args = set(sys.argv[1:])
@@ -532,3 +625,5 @@ if __name__ == "__main__":
         gen_ckpt()
     if every or "--nus" in args:
         gen_nus()
+    if every or "--tiaf" in args:
+        gen_tiaf_data()
