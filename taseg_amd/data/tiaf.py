@@ -42,9 +42,20 @@ def fov_points(points: torch.Tensor, proj: torch.Tensor, image_size, crop, img_b
     return torch.cat([pts[keep], pix[keep]], 1)
 
 
+_lut = {}
+
+
 def crop_image(image_u8: torch.Tensor, crop) -> torch.Tensor:
-    """[h, w, 3] uint8 RGB -> float32 [HEIGHT, WIDTH, 3] BGR / 255, zero padded (semantickitti_ms_mm.py:432-447)."""
-    return _pad(image_u8.to(torch.float32).flip(2) / 255.0, crop)
+    """[h, w, 3] uint8 RGB -> float32 [HEIGHT, WIDTH, 3] BGR / 255, zero padded (semantickitti_ms_mm.py:432-447).  The 256
+    possible quotients come from a table of correctly rounded float32 divisions (numpy's `image / 255.`): the device's
+    division by a scalar is a multiplication by the reciprocal and differs in the last bit."""
+    if image_u8.dtype != torch.uint8:
+        raise TypeError("camera images must be uint8")
+    lut = _lut.get(image_u8.device)
+    if lut is None:
+        import numpy as np
+        lut = _lut[image_u8.device] = torch.from_numpy(np.arange(256, dtype=np.float32) / 255.).to(image_u8.device)
+    return _pad(lut[image_u8.flip(2).long()], crop)
 
 
 def build_tiaf_sample(frames: Dict[int, Dict], steps: Sequence[int], multiscan: int, step_image: int, proj: torch.Tensor,
