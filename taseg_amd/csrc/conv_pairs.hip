@@ -14,6 +14,8 @@
 // Reference algorithm: torchsparse backend/convolution/convolution_cuda.cu:101-164 runs, per offset, a
 // gather kernel, a cuBLAS GEMM and a read-modify-write scatter kernel (3 K launches, host-synchronised).
 // HBM traffic here: Z written once and read once (2 P C_out s bytes) + Y; the gathers hit L2 / Infinity Cache.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1216,6 +1218,12 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   return TS_OK;
 }
 
+static int wgrad_wgs_from_env() {
+  const char *e = getenv("TASEG_WGRAD_WGS");
+  const int v = e ? atoi(e) : 0;
+  return v >= 64 && v <= 8192 ? v : 512;
+}
+int g_ts_wgrad_wgs = wgrad_wgs_from_env();
 thread_local float *g_ts_wgrad_part = nullptr;
 thread_local TsWgradPlan g_ts_wgrad_plan = {0, 0, 0};
 

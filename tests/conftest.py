@@ -96,3 +96,20 @@ def nus_sample(g, b):
     labels = {d: (lm[g[f"{p}rawlabels_d{-d}"]] if f"{p}rawlabels_d{-d}" in g else np.zeros(len(pts[d]), dtype=np.int64))
               for d in offsets}
     return oseq, seq, int(g[p + "index"]), pts, pseudo, labels
+
+
+def dense_ops_inputs(n):
+    """Seeded inputs of tests/golden/ops_dense.npz (the fixture stores only the reference's outputs): submanifold k3
+    convolutions 32 -> 64 ("full") and 4 -> 20 ("ragged"), strided k2 32 -> 32 + transposed mirror ("t"), on `n` voxels."""
+    import torch
+    g = torch.Generator().manual_seed(9)
+    out = {}
+    for tag, (ci, co) in (("full", (32, 64)), ("ragged", (4, 20))):
+        out[f"{tag}_x"] = torch.randn(n, ci, generator=g)
+        out[f"{tag}_w"] = torch.randn(27, ci, co, generator=g) * 0.2
+        out[f"{tag}_gy"] = torch.randn(n, co, generator=g)
+    out["t_x"] = torch.randn(n, 32, generator=g)
+    out["t_wd"] = torch.randn(8, 32, 32, generator=g) * 0.2
+    out["t_wu"] = torch.randn(8, 32, 32, generator=g) * 0.2
+    out["t_gy"] = torch.randn(n, 32, generator=g)
+    return out

@@ -612,6 +612,50 @@ def gen_tiaf_data(fname="tiaf_data.npz", T=8, multiscan=4, multiscan_image=8, st
           "fov voxels", out["batch_lidar_fov_ms_C"].shape, "images", out["batch_image_ms_shape"].tolist())
 
 
+# ----------------------------------------------------------------------------------------- dense-rulebook op fixtures
+def gen_ops_dense(fname="ops_dense.npz"):
+    """Op-level convolution fixtures from the reference on a cloud with a DENSE rulebook (the round-1 ops.npz cloud has 1.08
+    pairs per voxel at stride 1): a 45 degree sector of a full-resolution scan, ~6.5 pairs per voxel - submanifold k3 with
+    full-tile channel counts (32 -> 64: the split-bf16 MFMA kernels) and a ragged one (4 -> 20), the strided k2 convolution
+    and its transposed mirror, forward + both gradients through the reference's autograd Function; rulebooks included."""
+    import torchsparse.nn.functional as F
+    from torchsparse.nn.utils import get_kernel_offsets
+    pts, lab = sector_scan(63, half_width_deg=15.0)
+    pc_, inds, _ = dataset_voxelize(pts)
+    coords = torch.from_numpy(np.concatenate([pc_[inds], np.zeros((len(inds), 1), np.int32)], 1)).int()
+    n = coords.shape[0]
+    out = {"backend": np.array(BACKEND_DESC), "coords": coords.numpy()}
+    refs = F.sphash(coords)
+    res = F.sphashquery(F.sphash(coords, get_kernel_offsets(3, 1, 1)), refs)
+    out["k3_nbsizes"] = torch.sum(res != -1, dim=1).numpy().astype(np.int32)
+    nb = torch.nonzero(res != -1)
+    nb[:, 0] = res.view(-1)[nb[:, 0] * res.size(1) + nb[:, 1]]
+    out["k3_nbmaps"] = nb.numpy().astype(np.int32)
+    # inputs are NOT stored: tests regenerate them from the same seeded torch CPU generator, in the same order
+    # (tests/conftest.py::dense_ops_inputs); outputs with one row per voxel are stored for every 4th voxel
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from conftest import dense_ops_inputs
+    inp = dense_ops_inputs(n)
+    for tag in ("full", "ragged"):
+        xin, w, gy = (inp[f"{tag}_{k}"].clone() for k in ("x", "w", "gy"))
+        xin.requires_grad_()
+        w.requires_grad_()
+        y = F.conv3d(SparseTensor(xin, coords, 1), w, 3)
+        y.F.backward(gy)
+        out.update({f"{tag}_y": y.F.detach().numpy()[::4], f"{tag}_gx": xin.grad.numpy()[::4], f"{tag}_gw": w.grad.numpy()})
+    xin, wd, wu = inp["t_x"].clone().requires_grad_(), inp["t_wd"].clone().requires_grad_(), inp["t_wu"].clone().requires_grad_()
+    st = SparseTensor(xin, coords, 1)
+    st.cmaps[st.stride] = coords
+    yd = F.conv3d(st, wd, 2, stride=2)
+    yu = F.conv3d(yd, wu, 2, stride=2, transposed=True)
+    yu.F.backward(inp["t_gy"])
+    out.update({"t_coords_d": yd.C.numpy(), "t_yd": yd.F.detach().numpy()[::2], "t_yu": yu.F.detach().numpy()[::4],
+                "t_gx": xin.grad.numpy()[::4], "t_gwd": wd.grad.numpy(), "t_gwu": wu.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, os.path.getsize(os.path.join(HERE, fname)) // 1024, "KiB;", n, "voxels,", len(out["k3_nbmaps"]), "pairs =",
+          round(len(out["k3_nbmaps"]) / n, 2), "per voxel")
+
+
 if __name__ == "__main__":
     print("reference backend:", BACKEND_DESC)
     args = set(sys.argv[1:])
@@ -627,3 +671,5 @@ if __name__ == "__main__":
         gen_nus()
     if every or "--tiaf" in args:
         gen_tiaf_data()
+    if every or "--ops-dense" in args:
+        gen_ops_dense()

@@ -804,3 +804,41 @@ def test_weight_gradient_is_deterministic_and_matches_atomic_form():
                 wanth[k] = ah64[sl[:, 0]].T @ bh64[sl[:, 1]]
                 p0 += sizes[k]
             assert np.abs(hr[0].cpu().numpy() - wanth).max() <= 2e-5 * scale
+
+
+def test_conv_dense_rulebook_reference_golden(B, F):
+    """the reference's own convolution results on a DENSE rulebook (6.3 pairs per voxel: tests/golden/ops_dense.npz, a 30
+    degree sector of a full-resolution scan): rulebook bit-exact; submanifold k3 with full-tile channels (split-bf16 MFMA
+    kernels) and ragged ones, strided k2 + transposed mirror - forward, input gradient, weight gradient"""
+    import os
+    from conftest import GOLDEN, dense_ops_inputs
+    from taseg_amd.torchsparse import SparseTensor
+    g = dict(np.load(os.path.join(GOLDEN, "ops_dense.npz"), allow_pickle=False))
+    coords = T(g["coords"])
+    n = coords.shape[0]
+    inp = dense_ops_inputs(n)
+    assert len(g["k3_nbmaps"]) / n > 5.0
+    for tag in ("full", "ragged"):
+        x = inp[f"{tag}_x"].to(DEV).requires_grad_()
+        w = inp[f"{tag}_w"].to(DEV).requires_grad_()
+        y = F.conv3d(SparseTensor(x, coords, 1), w, 3)
+        km = y.kmaps[((1, 1, 1), (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+        same(km.nbmaps.int(), g["k3_nbmaps"])
+        same(km.nbsizes.int(), g["k3_nbsizes"])
+        close(y.F[::4], g[f"{tag}_y"])
+        y.F.backward(inp[f"{tag}_gy"].to(DEV))
+        close(x.grad[::4], g[f"{tag}_gx"])
+        close(w.grad, g[f"{tag}_gw"])
+    x = inp["t_x"].to(DEV).requires_grad_()
+    wd, wu = inp["t_wd"].to(DEV).requires_grad_(), inp["t_wu"].to(DEV).requires_grad_()
+    st = SparseTensor(x, coords, 1)
+    st.cmaps[st.stride] = st.coords
+    yd = F.conv3d(st, wd, 2, stride=2)
+    same(yd.C, g["t_coords_d"])
+    close(yd.F[::2], g["t_yd"])
+    yu = F.conv3d(yd, wu, 2, stride=2, transposed=True)
+    close(yu.F[::4], g["t_yu"])
+    yu.F.backward(inp["t_gy"].to(DEV))
+    close(x.grad[::4], g["t_gx"])
+    close(wd.grad, g["t_gwd"])
+    close(wu.grad, g["t_gwu"])

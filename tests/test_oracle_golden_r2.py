@@ -46,3 +46,33 @@ def test_oracle_fp32_at_mk34_cr10(name, in_dim, fname, training):
         e_ours = np.linalg.norm(a - want64) / np.linalg.norm(want64)
         e_ref = np.linalg.norm(ref - want64) / np.linalg.norm(want64)
         assert e_ours <= max(2e-3, 2 * noise), (k, e_ours, e_ref, noise)
+
+
+def test_oracle_conv_on_dense_rulebook():
+    """oracle rulebook + convolution against the reference on a cloud with 6.6 pairs per voxel (ops_dense.npz)"""
+    from conftest import dense_ops_inputs
+    from oracle import ts_oracle as O
+    g = dict(np.load(os.path.join(GOLDEN, "ops_dense.npz"), allow_pickle=False))
+    c = g["coords"]
+    n = len(c)
+    inp = dense_ops_inputs(n)
+    _, nbmaps, nbsizes = O.build_kmap(c, c, O.get_kernel_offsets(3, 1, 1))
+    assert np.array_equal(nbmaps, g["k3_nbmaps"]) and np.array_equal(nbsizes, g["k3_nbsizes"])
+    for tag in ("full", "ragged"):
+        x, w, gy = (inp[f"{tag}_{k}"].numpy() for k in ("x", "w", "gy"))
+        y = O.conv_forward(x, w, nbmaps, nbsizes, (n, n))
+        gx, gw = O.conv_backward(x, w, gy, nbmaps, nbsizes)
+        for got, want in ((y[::4], g[f"{tag}_y"]), (gx[::4], g[f"{tag}_gx"]), (gw, g[f"{tag}_gw"])):
+            assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    down = O.spdownsample(c, 2, 2, 1)
+    assert np.array_equal(down, g["t_coords_d"])
+    _, nb2, ns2 = O.build_kmap(c, down, O.get_kernel_offsets(2, 1, 1))
+    x, wd, wu, gy = (inp[k].numpy() for k in ("t_x", "t_wd", "t_wu", "t_gy"))
+    yd = O.conv_forward(x, wd, nb2, ns2, (n, len(down)))
+    yu = O.conv_forward(yd, wu, nb2, ns2, (n, len(down)), transposed=True)
+    assert np.abs(yd[::2] - g["t_yd"]).max() <= 1e-5 * np.abs(g["t_yd"]).max()
+    assert np.abs(yu[::4] - g["t_yu"]).max() <= 1e-5 * np.abs(g["t_yu"]).max()
+    gyd, gwu = O.conv_backward(yd, wu, gy, nb2, ns2, transposed=True)
+    gx, gwd = O.conv_backward(x, wd, gyd, nb2, ns2)
+    for got, want in ((gx[::4], g["t_gx"]), (gwd, g["t_gwd"]), (gwu, g["t_gwu"])):
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
