@@ -625,6 +625,14 @@ def test_new_entry_points_accept_empty_inputs(B):
     pos = torch.full((27, 5), -1, dtype=torch.int32, device=dev)
     y = B.conv_gather_sum_f16(z, pos, 5)
     assert y.shape == (5, 32) and float(y.float().abs().sum()) == 0.0
+    # round-2 entry points: deterministic fp32 weight gradient with no pairs, nuScenes sweep fuse / TIAF projection with no points
+    gw32 = B.conv_wgrad(torch.randn(5, 32, device=dev), torch.randn(5, 32, device=dev), nb, offs, 27, 0, 0)
+    assert gw32.shape == (27, 32, 32) and float(gw32.abs().sum()) == 0.0
+    fused, keep = B.fuse_sweeps(torch.empty((0, 5), device=dev), torch.empty(0, dtype=torch.int32, device=dev),
+                                torch.zeros((1, 28), dtype=torch.float64, device=dev))
+    assert fused.shape == (0, 5) and keep.shape == (0,)
+    pix, keep = B.project_fov(e4, torch.eye(4, dtype=torch.float64, device=dev)[:3].contiguous(), (10, 10), (8, 8))
+    assert pix.shape == (0, 2) and keep.shape == (0,)
 
 
 # --------------------------------------------------------------------------- dense products on the pair-GEMM kernels
