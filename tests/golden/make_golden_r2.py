@@ -656,6 +656,61 @@ def gen_ops_dense(fname="ops_dense.npz"):
           round(len(out["k3_nbmaps"]) / n, 2), "per voxel")
 
 
+# ----------------------------------------------------------------------------------------- training-step trajectory
+def gen_train_steps(fname="train_steps_minkunet_ms.npz", steps=4):
+    """The reference's training step (R/train.py:398-416: zero_grad, forward, backward, clip_grad_norm_(10),
+    torch.optim.SGD(momentum 0.9, weight decay 1e-4) as R/pcseg/optim/__init__.py:15-21 builds it) repeated over
+    alternating batches with the reference's MinkUNetMs: losses per step, gradient norm before clipping, strided samples
+    of the parameters after the last step and of BatchNorm running statistics."""
+    from torch.nn.utils import clip_grad_norm_
+    cfg = make_model_cfg("MinkUNetMs", in_dim=5, cr=0.5, num_layer=[1] * 8)
+    torch.manual_seed(0)
+    model = fill_parameters(MinkUNetMs(cfg, 20), seed=5)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.02, weight_decay=1e-4, momentum=0.9)
+    batches = []
+    for seeds in ((91, 92), (93, 94)):
+        samples = []
+        for sd in seeds:
+            pts, lab = small_scan(sd, n=3000)
+            pc_, inds, _ = dataset_voxelize(pts)
+            feat = np.concatenate([pts, np.ones_like(pts[:, :1])], 1)
+            samples.append({"lidar": SparseTensor(feat[inds], pc_[inds]), "targets": SparseTensor(lab[inds], pc_[inds])})
+        batches.append(sparse_collate_fn(samples))
+    out = {"backend": np.array(BACKEND_DESC), "steps": np.array(steps), "lr": np.array(0.02), "momentum": np.array(0.9),
+           "weight_decay": np.array(1e-4), "max_norm": np.array(10.0)}
+    for i, bt in enumerate(batches):
+        out[f"coords{i}"] = bt["lidar"].C.int().numpy()
+        out[f"feats{i}"] = bt["lidar"].F.float().numpy()
+        out[f"labels{i}"] = bt["targets"].F.numpy().astype(np.int64)
+    losses, norms = [], []
+    for it in range(steps):
+        bt = batches[it % 2]
+        opt.zero_grad()
+        bd = {"lidar_ms": SparseTensor(bt["lidar"].F.float().clone(), bt["lidar"].C.int().clone()), "targets_ms": bt["targets"],
+              "offset_ms": torch.tensor([0])}
+        ret, _, _ = model(bd)
+        loss = ret["loss"].mean()
+        loss.backward()
+        norms.append(float(clip_grad_norm_(model.parameters(), 10.0)))
+        opt.step()
+        losses.append(float(loss))
+    out["losses"], out["grad_norms"] = np.array(losses), np.array(norms)
+    names = [n for n, _ in model.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["param_norms"] = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    for n, p in model.named_parameters():
+        if n in ("stem.0.kernel", "stage2.1.net.0.kernel", "stage4.1.net.3.kernel", "up2.1.0.net.0.kernel",
+                 "up4.1.0.net.3.kernel", "classifier.0.weight", "stem.1.weight", "up1.0.net.1.bias"):
+            out["param/" + n] = strided_sample(p.detach().numpy(), 2048)
+    for n, bbuf in model.named_buffers():
+        if n in ("stem.1.running_mean", "stem.1.running_var", "stage4.1.net.4.running_var", "up4.1.0.net.4.running_mean"):
+            out["stat/" + n] = bbuf.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, os.path.getsize(os.path.join(HERE, fname)) // 1024, "KiB; losses", [round(l, 5) for l in losses],
+          "grad norms", [round(n, 3) for n in norms])
+
+
 if __name__ == "__main__":
     print("reference backend:", BACKEND_DESC)
     args = set(sys.argv[1:])
@@ -673,3 +728,5 @@ if __name__ == "__main__":
         gen_tiaf_data()
     if every or "--ops-dense" in args:
         gen_ops_dense()
+    if every or "--train-steps" in args:
+        gen_train_steps()

@@ -205,3 +205,55 @@ def test_nuscenes_stage_on_device_matches_reference(g_multiscan_nus):
         assert np.array_equal(batch[key].F.cpu().numpy(), g[f"batch_{key}_F"]), key
     for key in ("num_points", "num_points_ms", "offset", "offset_ms", "point_mask"):
         assert np.array_equal(batch[key].cpu().numpy().reshape(-1), g[f"batch_{key}"].reshape(-1)), key
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "flat"])
+def test_training_steps_follow_the_reference(optimizer):
+    """Four SGD steps of the reference's training loop body (R/train.py:398-416: zero_grad, forward, backward,
+    clip_grad_norm_(10), SGD(momentum 0.9, wd 1e-4), alternating batches) with MinkUNetMs: per-step losses, gradient norms,
+    the parameters after the last step and BatchNorm running statistics against the trajectory of the REAL reference
+    (tests/golden/train_steps_minkunet_ms.npz) - with torch.optim.SGD and with the flat-bucket device optimizer."""
+    from taseg_amd.optim import FlatSGD
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    g = _load("train_steps_minkunet_ms.npz")
+    cfg = make_model_cfg("MinkUNetMs", in_dim=5, cr=0.5, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=5).cuda().train()
+    lr, mom, wd, clip = float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(g["max_norm"])
+    if optimizer == "flat":
+        opt = FlatSGD(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=clip)
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=lr, weight_decay=wd, momentum=mom)
+    batches = [(torch.from_numpy(g[f"coords{i}"]).cuda(), torch.from_numpy(g[f"feats{i}"]).cuda(),
+                torch.from_numpy(g[f"labels{i}"]).cuda()) for i in range(2)]
+    losses, norms = [], []
+    for it in range(int(g["steps"])):
+        c, f, l = batches[it % 2]
+        opt.zero_grad(set_to_none=True)
+        ret, _, _ = model({"lidar_ms": SparseTensor(f.clone(), c), "targets_ms": SparseTensor(l, c), "offset_ms": torch.tensor([0])})
+        loss = ret["loss"].mean()
+        loss.backward()
+        if optimizer == "flat":
+            opt.reducer.finish()
+            norms.append(float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in model.parameters()))))
+            opt.step()
+        else:
+            norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), clip)))
+            opt.step()
+        losses.append(float(loss))
+    dl = np.abs(np.array(losses) - g["losses"])
+    dn = np.abs(np.array(norms) - g["grad_norms"]) / g["grad_norms"]
+    names = g["param_names"].tolist()
+    params = dict(model.named_parameters())
+    pn = np.array([float(params[n].detach().double().norm()) for n in names])
+    dp = np.abs(pn - g["param_norms"]) / np.maximum(g["param_norms"], 1e-12)
+    worst = 0.0
+    for k in [k for k in g if k.startswith("param/")]:
+        got = strided_sample(params[k[6:]].detach().cpu().numpy(), 2048)
+        worst = max(worst, float(np.linalg.norm(got - g[k]) / np.linalg.norm(g[k])))
+    bufs = dict(model.named_buffers())
+    ds = max(float(np.abs(bufs[k[5:]].cpu().numpy() - g[k]).max() / max(np.abs(g[k]).max(), 1e-12)) for k in g if k.startswith("stat/"))
+    print(f"{optimizer}: |loss - reference| per step {np.round(dl, 6).tolist()}, gradient norm rel {np.round(dn, 6).tolist()}, parameter "
+          f"norms rel max {dp.max():.2e}, sampled parameters rel L2 max {worst:.2e}, running statistics rel max {ds:.2e}")
+    assert dl[0] <= 1e-4 and dl.max() <= 2e-3
+    assert dn.max() <= 5e-3 and dp.max() <= 1e-4 and worst <= 2e-3 and ds <= 1e-3
