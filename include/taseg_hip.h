@@ -464,8 +464,36 @@ int64_t ts_prof_collect(double *records, int64_t capacity);
  * 1 = scalar reference kernels (one thread per output element, atomics),
  * 2 = MFMA kernels with the guarded generic staging code even where the unguarded full-tile variants apply,
  * 3 / 4 = full-tile pair GEMM with one workgroup per tile everywhere / persistent workgroups everywhere
- *         (default: persistent for the forward weight layout only). */
+ *         (default: persistent for the forward weight layout only),
+ * 11 / 13 = with pre-split weight planes at hand (ts_conv_planes_hint) take the direct-rows pair GEMM on 96-column tiles
+ *         as well / never (default: on 128-column tiles). */
 void ts_set_conv_impl(int32_t impl);
+
+/* Pre-split weight planes for the fp32 pair GEMMs (csrc/conv_pairs_s.hip) - an optional accelerator of
+ * ts_conv_pair_gemm / ts_conv_block_forward / ts_conv_block_backward, no counterpart in the reference (its
+ * convolution_forward_cuda, backend/convolution/convolution_cuda.cu:101-164, multiplies fp32 operands in cuBLAS).
+ * The fp32 kernels evaluate a product on the bf16 matrix pipe through the exact split x = h + m + l of both operands;
+ * for a weight that split is the same in every workgroup of every launch until the optimizer changes the weight.
+ *   planes: 6 * K * c_in * c_out bf16 (16-byte aligned): h | m | l of W [K, c_in, c_out], then h | m | l of W^T
+ *           [K, c_out, c_in] (the input gradient reads those as a forward-layout product); c_in, c_out % 8 == 0.
+ *   ts_conv_split_planes[_batch]  write them (one launch per 16 weights): call after every update of the weight.
+ *   ts_conv_planes_hint           one-shot and per thread: the NEXT of the three calls above made by this thread may read
+ *           `planes` in place of `w` if its weight pointer is `w` and its shapes are (K, c_in, c_out); that call clears
+ *           the hint whether it used it or not.  Results are bit-identical with and without planes; keeping them in
+ *           step with the weight is the caller's contract (taseg_amd/planes.py does it for the modules). */
+typedef struct TsPlaneJob {
+  const float *w;
+  void *planes;
+  int32_t K, c_in, c_out;
+} TsPlaneJob;
+int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *planes, ts_stream_t stream);
+int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
+void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out);
+
+/* Diagnostic: while `stamps` (device memory, 16 x uint64 per workgroup, `capacity` workgroups) is set, the 96- / 128-
+ * column fp32 pair GEMMs run an instrumented instantiation whose workgroups leave shader-clock stamps of their phases
+ * (tools/phase_probe.py); NULL switches back to the product kernels. */
+void ts_debug_phase_stamps(unsigned long long *stamps, int64_t capacity);
 
 /* ------------------------------------------------------------------------ */
 /* 4. Host-side data stage moved on device                                   */

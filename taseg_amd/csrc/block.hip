@@ -116,6 +116,15 @@ extern "C" int64_t ts_prof_collect(double *records, int64_t capacity) {
   return n;
 }
 
+// The caller's one-shot hint of pre-split weight planes (ts_conv_planes_hint) belongs to the block call as a whole: taken
+// at entry, handed to the one fp32 pair GEMM of the call, gone when the call returns - whichever path it took.
+struct PlanesHintScope {
+  TsPlanesHint h;
+  PlanesHintScope() : h(g_ts_planes_hint) { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
+  void arm() const { g_ts_planes_hint = h; }
+  ~PlanesHintScope() { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
+};
+
 // out = act(BN(conv(feat)) [+ residual]).
 //   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
 //   `gather_col` and the position table pos [K, n_out] of the rows being produced (pos_out, or pos_in for a transposed
@@ -130,6 +139,7 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
                                      int32_t relu, int32_t half, void *comm, double *pack, void *conv_out, float *mean,
                                      float *invstd, void *out, uint8_t *mask, void *w16, void *ws, size_t ws_bytes,
                                      ts_stream_t stream) {
+  PlanesHintScope planes_hint;
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_forward: bad sizes");
   TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
@@ -164,6 +174,7 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   } else {
     {
       ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 4, 0);
+      planes_hint.arm();
       TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
                                (float *)z, c_out, stream));
     }
@@ -198,6 +209,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                       int32_t wgrad_col_a, void *grad_feat, void *grad_residual, float *grad_kernel,
                                       float *grad_bn_weight, float *grad_bn_bias, void *ws, size_t ws_bytes,
                                       ts_stream_t stream) {
+  PlanesHintScope planes_hint;
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_backward: bad sizes");
   TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
@@ -252,9 +264,11 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
       if (half)
         TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
                                      stream));
-      else
+      else {
+        planes_hint.arm();
         TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs,
                                  n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
+      }
     }
     {
       // the ordered weight-gradient sum riding on this launch reads its partial tiles and writes grad_kernel: real bytes

@@ -167,6 +167,14 @@ __device__ __forceinline__ void ts_wgrad_reduce_one(const TsWgradReduce &job, in
   ((float4 *)job.dW)[i] = acc;
 }
 
+// ---- pre-split weight planes (conv_pairs_s.hip) -------------------------------------------------------------------
+struct TsPlanesHint {
+  const float *w;                  // the weight the planes were split from
+  const unsigned short *planes;    // [6][K * c_in * c_out] bf16: h | m | l of W, then h | m | l of W^T
+  int K, c_in, c_out;
+};
+extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv_planes_hint, cleared by the call that reads it
+
 // Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can form the ordered sum
 // of the weight-gradient partials on the side (saves the reduce launch), and the atomic form of the weight gradient
 // can be told that its output is already zero.

@@ -29,6 +29,10 @@ int ts_pair_gemm_split(const float *X, int R, const float *W, int O_total, const
                        int64_t P, int gcol, float *Z, int bn, int wt, hipStream_t stream);
 int ts_wgrad_split(const float *A, int CA, const float *B, int CB, const int2 *nbmaps, const int *nboffs, int K,
                    int col_a, int64_t n_pairs, float *dW, int tm, int tn, hipStream_t stream);
+bool ts_pair_gemm_direct_ok(int bn);
+int ts_pair_gemm_direct(const float *X, int R, const unsigned short *planes, int64_t plane_n, int O_total,
+                        const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z, int bn,
+                        hipStream_t stream);
 
 // BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
 // Software pipeline: the (offset, C_in-slice) steps of a tile are flattened; the global loads of step s+1 are
@@ -672,7 +676,7 @@ static int launch_pair_gemm(const float *X, int R, const float *W, int O_total, 
   dim3 grid((unsigned)ts_cdiv(P, PG_BM), (unsigned)ts_cdiv(O_total, BN));
   const bool fast = (R % PG_BK == 0) && (O_total % BN == 0) && ((((uintptr_t)X) | ((uintptr_t)W)) & 15) == 0 &&
                     K <= 63 && g_ts_conv_impl != 2;
-  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 8)))   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
+  if (fast && (g_ts_conv_impl == 0 || (g_ts_conv_impl >= 6 && g_ts_conv_impl <= 8) || g_ts_conv_impl == 11 || g_ts_conv_impl == 13))   // default: fp32 operands on the bf16 matrix pipe (conv_pairs_s.hip)
     return ts_pair_gemm_split(X, R, W, O_total, nbmaps, nboffs, K, P, gcol, Z, BN, WT ? 1 : 0, stream);
   if (fast) {
     static bool fattr_set = false;
@@ -714,6 +718,18 @@ extern "C" int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in
   TS_REQUIRE(feat && kernel && nbmaps && nboffs && z, TS_ERR_INVALID_ARGUMENT, "ts_conv_pair_gemm: null pointer");
   const int2 *nm = (const int2 *)nbmaps;
   const int gc = gather_col ? 1 : 0;
+  {   // pre-split planes of this weight left by the caller (one-shot, common.h): the direct-rows kernel where it wins
+    const TsPlanesHint hint = g_ts_planes_hint;
+    g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0};
+    const int bn = c_out <= 32 ? 32 : c_out <= 64 ? 64 : c_out % 96 == 0 ? 96 : 128;
+    const bool shapes = weight_transposed ? (hint.c_in == c_out && hint.c_out == c_in) : (hint.c_in == c_in && hint.c_out == c_out);
+    if (hint.w == kernel && hint.planes && hint.K == K && shapes && K <= 63 && c_in % 32 == 0 && c_out % bn == 0 &&
+        ((((uintptr_t)feat) | ((uintptr_t)z) | ((uintptr_t)hint.planes)) & 15) == 0 && ts_pair_gemm_direct_ok(bn)) {
+      const int64_t n = (int64_t)K * c_in * c_out;
+      return ts_pair_gemm_direct(feat, c_in, hint.planes + (weight_transposed ? 3 * n : 0), n, c_out, nm, nboffs, K, n_pairs,
+                                 gc, z, bn, stream);
+    }
+  }
 #define TS_PG(BN, WR)                                                                                             \
   (weight_transposed                                                                                              \
        ? launch_pair_gemm<BN, WR, true>(feat, c_in, kernel, c_out, nm, nboffs, K, n_pairs, gc, z, stream)         \

@@ -72,12 +72,19 @@ __device__ __forceinline__ bf8 frag_tr(const unsigned short *img, int pitch, int
   } while (0)
 
 // X [*, R] fp32 rows; W = [K, R, O_total] (WT = false) or [K, O_total, R] (WT = true); Z [P, O_total] fp32
-template <int BM, int BN, int WR, bool WT, bool XCD>
+// PROBE: lane 0 of every workgroup leaves shader-clock stamps of its phases in `stamps` (ts_debug_phase_stamps;
+// tools/phase_probe.py) - a diagnostic instantiation, the product launches PROBE = false.
+#define TS_STAMP(i)                                                                     \
+  do {                                                                                  \
+    if (PROBE && tid == 0) stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+template <int BM, int BN, int WR, bool WT, bool XCD, bool PROBE = false>
 __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(const float *__restrict__ X, int R,
                                                           const float *__restrict__ W, int O_total,
                                                           const int2 *__restrict__ nbmaps,
                                                           const int *__restrict__ nboffs, int K, int gcol,
-                                                          float *__restrict__ Z) {
+                                                          float *__restrict__ Z,
+                                                          unsigned long long *__restrict__ stamps = nullptr) {
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
   constexpr int NI = (BN / 16) / WC;
@@ -97,6 +104,12 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
   const int tq = r16 >> 2, tp = lane & 3;
   const int wr = wave / WC, wc = wave % WC;
   const int o0 = blockIdx.y * BN;
+  if (PROBE && tid == 0) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = 0;
+    stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+  }
+  TS_STAMP(0);
 
   // tile -> (offset k, first pair, rows), as in pair_gemm_fast_kernel
   const int offv = nboffs[min(lane, K)];
@@ -116,6 +129,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
   const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
   const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
   const int np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  TS_STAMP(1);                                  // tile mapped (offset table arrived)
 
   // A slots: 8-float chunk (tid & 3) of tile row (tid >> 2) + 64 it
   const int arow0 = tid >> 2, acol = (tid & 3) << 3;
@@ -210,13 +224,34 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
     }
   };
 
+  if (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_STAMP(2);                                // pair indices arrived
+  }
   load_regs(0);
+  if (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_STAMP(3);                                // first slice arrived
+  }
   for (int c0 = 0; c0 < R; c0 += PS_BK) {
     if (c0) __syncthreads();          // the previous slice's fragments have been read
     store_lds();
     __syncthreads();
+    if (c0 == 0) TS_STAMP(4);                   // first slice split and staged
     if (c0 + PS_BK < R) load_regs(c0 + PS_BK);
     mma();
+    if (c0 == 0) TS_STAMP(5);                   // first MFMA block issued
+  }
+  TS_STAMP(6);                                  // all slices issued
+  if (PROBE) {
+    asm volatile("s_nop 0" ::: "memory");
+    float sink = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) sink += acc[mi][ni][0];
+    if (sink == 12345.678f) stamps[1] = 0;      // forces the accumulators: stamp 7 = MFMAs retired
+    TS_STAMP(7);
   }
   float *zt = Z + (int64_t)p0 * O_total + o0;
   if (np == BM) {
@@ -238,6 +273,336 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
           if (row < np) TS_ZSTORE(acc[mi][ni][q], &zt[(int64_t)row * O_total + (wc * NI + ni) * 16 + r16]);
         }
   }
+  TS_STAMP(8);                                  // Z stores issued
+  if (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_STAMP(9);                                // Z stores acknowledged
+    if (tid == 0) {
+      stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+      stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 11] =
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |      // XCC_ID
+          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                          // HW_ID (wave, simd, cu, sh, se)
+      stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 12] = (unsigned long long)np;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- pre-split weights
+// Planes of a convolution weight W [K, Ci, Co] (n = K * Ci * Co): six bf16 arrays of n elements,
+//     [0, 3n)  h | m | l of W itself            - the forward product reads them (slices along Ci)
+//     [3n, 6n) h | m | l of W^T = [K, Co, Ci]   - the input gradient runs as a forward-layout product on them
+// written once per optimizer step (ts_conv_split_planes[_batch]) and handed to the next convolution call of the
+// calling thread with ts_conv_planes_hint.  One workgroup row (blockIdx.y) per weight.
+struct TsPlaneJobs {
+  TsPlaneJob job[16];
+};
+__global__ __launch_bounds__(256) void split_planes_kernel(TsPlaneJobs jobs) {
+  const TsPlaneJob jb = jobs.job[blockIdx.y];
+  const float *__restrict__ w = jb.w;
+  unsigned short *__restrict__ planes = (unsigned short *)jb.planes;
+  const int64_t n = (int64_t)jb.K * jb.c_in * jb.c_out;
+  const int64_t n8 = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {      // W as it lies
+    u32x4 h, m, l;
+    split8(*(const f32x4 *)(w + 8 * i), *(const f32x4 *)(w + 8 * i + 4), h, m, l);
+    *(u32x4 *)(planes + 8 * i) = h;
+    *(u32x4 *)(planes + n + 8 * i) = m;
+    *(u32x4 *)(planes + 2 * n + 8 * i) = l;
+  }
+  // W^T: a thread takes 8 consecutive ci of one (k, co) - neighbouring threads neighbouring co, so the eight strided
+  // reads are coalesced across the wave; its 16-byte writes are Ci * 2 bytes apart
+  const int ci8 = jb.c_in >> 3;
+  unsigned short *__restrict__ pt = planes + 3 * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const int co = (int)(i % jb.c_out);
+    const int64_t r = i / jb.c_out;
+    const int c8 = (int)(r % ci8);
+    const int64_t k = r / ci8;
+    const float *src = w + (k * jb.c_in + 8 * c8) * jb.c_out + co;
+    f32x4 v0, v1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v0[j] = src[(int64_t)j * jb.c_out];
+      v1[j] = src[(int64_t)(j + 4) * jb.c_out];
+    }
+    u32x4 h, m, l;
+    split8(v0, v1, h, m, l);
+    const int64_t d = (k * jb.c_out + co) * jb.c_in + 8 * c8;
+    *(u32x4 *)(pt + d) = h;
+    *(u32x4 *)(pt + n + d) = m;
+    *(u32x4 *)(pt + 2 * n + d) = l;
+  }
+}
+
+extern "C" int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream) {
+  TS_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_split_planes_batch: bad arguments");
+  for (int32_t j0 = 0; j0 < n_jobs; j0 += 16) {
+    TsPlaneJobs chunk;
+    const int cnt = std::min(16, n_jobs - j0);
+    int64_t big = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const TsPlaneJob &jb = jobs[j0 + j];
+      TS_REQUIRE(jb.w && jb.planes && jb.K > 0 && jb.c_in > 0 && jb.c_out > 0 && jb.c_in % 8 == 0 && jb.c_out % 8 == 0 &&
+                     ((((uintptr_t)jb.w) | ((uintptr_t)jb.planes)) & 15) == 0,
+                 TS_ERR_INVALID_ARGUMENT, "ts_conv_split_planes_batch: job %d: null / misaligned pointer or channels not a multiple of 8",
+                 j0 + j);
+      chunk.job[j] = jb;
+      big = std::max<int64_t>(big, (int64_t)jb.K * jb.c_in * jb.c_out);
+    }
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ts_cdiv(big / 8, 256), 128)), (unsigned)cnt);
+    split_planes_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(chunk);
+    TS_CHECK_LAUNCH("ts_conv_split_planes_batch");
+  }
+  return TS_OK;
+}
+
+extern "C" int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *planes, ts_stream_t stream) {
+  TsPlaneJob jb = {w, planes, K, c_in, c_out};
+  return ts_conv_split_planes_batch(&jb, 1, stream);
+}
+
+// one-shot hint of the calling thread: the next ts_conv_pair_gemm / ts_conv_block_forward / ts_conv_block_backward whose
+// weight is `w` may read `planes` (layout above) instead of splitting the weight slice in every workgroup.  Any of these
+// calls clears it, whether it used it or not; a hint never outlives the call it was made for.
+thread_local TsPlanesHint g_ts_planes_hint = {nullptr, nullptr, 0, 0, 0};
+extern "C" void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out) {
+  g_ts_planes_hint = {w, (const unsigned short *)planes, K, c_in, c_out};
+}
+
+static unsigned long long *g_ts_phase_stamps = nullptr;
+static int64_t g_ts_phase_cap = 0;
+// ---------------------------------------------------------------------------------- pair GEMM, gathered rows direct
+// The gathered operand never touches LDS: lane (r16, g) of a wave loads the 8 consecutive floats of ITS MFMA fragment
+// (row r16 of a 16-row block, k = 8g .. 8g+7 of the slice) straight from the gathered row, splits them in registers and
+// feeds the matrix pipe; a wave owns 32 of the tile's 128 rows and all BN columns.  The weight slice arrives pre-split
+// (three bf16 planes in the fp32 weight's [K, R, O_total] layout, split_planes_kernel) and is the only thing staged in
+// LDS, double buffered: ONE barrier per slice, no split work for the weights, 40 - 52 KB of LDS and <= 168 VGPRs, i.e.
+// three workgroups per CU whose waves run their gather -> split -> MFMA chains independently between the barriers.
+template <int BN, bool PROBE>
+__global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__restrict__ X, int R,
+                                                             const unsigned short *__restrict__ Wp, int64_t wplane,
+                                                             int O_total, const int2 *__restrict__ nbmaps,
+                                                             const int *__restrict__ nboffs, int K, int gcol,
+                                                             float *__restrict__ Z,
+                                                             unsigned long long *__restrict__ stamps) {
+  constexpr int BM = 128, MI = 2, NI = BN / 16;
+  constexpr int BP = BN + 8;
+  constexpr int B_PLANE = PS_BK * BP;
+  constexpr int B_BUF = 3 * B_PLANE;
+  constexpr int B_CHUNKS = BN * (PS_BK / 8);
+  constexpr int B_IT = (B_CHUNKS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_d[];
+  unsigned short *Bp = smem_d;                                 // 2 buffers x 3 planes [32][BP]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = lane & 3;
+  const int o0 = blockIdx.y * BN;
+  if (PROBE && tid == 0) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = 0;
+    stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+  }
+  TS_STAMP(0);
+
+  const int offv = nboffs[min(lane, K)];
+  const int offn = nboffs[min(lane + 1, K)];
+  int incl = lane < K ? (offn - offv + BM - 1) / BM : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int tile = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  if (tile >= __builtin_amdgcn_readlane(incl, 63)) return;
+  const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= tile));
+  const int t_in_k = tile - (k ? __builtin_amdgcn_readlane(incl, max(k - 1, 0)) : 0);
+  const int p0 = __builtin_amdgcn_readlane(offv, k) + t_in_k * BM;
+  const int np = min(BM, __builtin_amdgcn_readlane(offv, k + 1) - p0);
+  TS_STAMP(1);
+
+  const float *aptr[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int2 pr = nbmaps[p0 + min(wave * 32 + mi * 16 + r16, np - 1)];   // rows past the tile repeat its last row; never stored
+    aptr[mi] = X + (int64_t)(gcol ? pr.y : pr.x) * R + 8 * g;
+  }
+  int boff[B_IT], bdst[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int e = min(tid + it * 256, B_CHUNKS - 1);
+    constexpr int q8 = BN >> 3;
+    const int kk = e / q8, c8 = (e - kk * q8) << 3;
+    boff[it] = kk * O_total + c8;
+    bdst[it] = kk * BP + c8;
+  }
+  const unsigned short *wkp = Wp + (int64_t)k * R * O_total + o0;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[MI][2];
+  u32x4 rp[B_IT][3];
+  bf8 a[MI][3];
+  auto load_a = [&](int c0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ra[mi][0] = *(const f32x4 *)(aptr[mi] + c0);
+      ra[mi][1] = *(const f32x4 *)(aptr[mi] + c0 + 4);
+    }
+  };
+  auto load_b = [&](int c0) {
+    const unsigned short *wb = wkp + (int64_t)c0 * O_total;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rp[it][pl] = *(const u32x4 *)(wb + pl * wplane + boff[it]);
+  };
+  auto write_b = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      if (B_IT * 256 == B_CHUNKS || tid + it * 256 < B_CHUNKS) {
+        unsigned short *dst = Bp + buf * B_BUF + bdst[it];
+        *(u32x4 *)dst = rp[it][0];
+        *(u32x4 *)(dst + B_PLANE) = rp[it][1];
+        *(u32x4 *)(dst + 2 * B_PLANE) = rp[it][2];
+      }
+    }
+  };
+  auto split_a = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      u32x4 h, m, l;
+      split8(ra[mi][0], ra[mi][1], h, m, l);
+      a[mi][0] = __builtin_bit_cast(bf8, h);
+      a[mi][1] = __builtin_bit_cast(bf8, m);
+      a[mi][2] = __builtin_bit_cast(bf8, l);
+    }
+  };
+  // (tried: weight fragment as the first matrix operand, so that a lane's four accumulator values are four consecutive
+  // channels of one pair row and leave as one 16-byte store - 7 - 10 % slower than the four 4-byte stores, and the
+  // matrix pipe does not round the two operand orders alike)
+  auto mma = [&](int buf) {
+    const unsigned short *bb = Bp + buf * B_BUF;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      bf8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = frag_tr(bb + p * B_PLANE, BP, 8 * g, ni * 16, tq, tp);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) TS_SPLIT_MMA(acc[mi][ni], a[mi], b);
+    }
+  };
+
+  if (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_STAMP(2);
+  }
+  const int S = R / PS_BK;
+  load_a(0);
+  load_b(0);
+  if (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_STAMP(3);
+  }
+  write_b(0);
+  split_a();
+  __syncthreads();
+  TS_STAMP(4);
+  // step s: the gathered fragments and the weights of slice s + 1 are issued, the MFMA block of slice s runs on the
+  // split fragments in registers and on LDS buffer s & 1, then the weights of s + 1 go to the other buffer, the raw
+  // fragments of s + 1 are split, and one barrier closes the step
+  for (int s = 0; s < S; ++s) {
+    const bool more = s + 1 < S;
+    if (more) {
+      load_a((s + 1) * PS_BK);
+      load_b((s + 1) * PS_BK);
+    }
+    mma(s & 1);
+    if (s == 0) TS_STAMP(5);
+    if (more) {
+      write_b((s + 1) & 1);
+      split_a();
+      __syncthreads();
+    }
+  }
+  TS_STAMP(6);
+  if (PROBE) {
+    float sink = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) sink += acc[mi][ni][0];
+    if (sink == 12345.678f) stamps[1] = 0;
+    TS_STAMP(7);
+  }
+  float *zt = Z + (int64_t)p0 * O_total + o0;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = wave * 32 + mi * 16 + 4 * g + q;
+      if (np == BM || row < np) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) TS_ZSTORE(acc[mi][ni][q], &zt[(int64_t)row * O_total + ni * 16 + r16]);
+      }
+    }
+  TS_STAMP(8);
+  if (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_STAMP(9);
+    if (tid == 0) {
+      stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+      stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 11] =
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+      stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 12] = (unsigned long long)np;
+    }
+  }
+}
+template <int BN>
+static int launch_pair_gemm_d(const float *X, int R, const unsigned short *planes, int64_t wplane, int O_total,
+                              const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z,
+                              unsigned long long *stamps, hipStream_t stream) {
+  const size_t lds = (size_t)2 * 3 * PS_BK * (BN + 8) * 2;
+  dim3 grid((unsigned)((ts_cdiv(P, 128) + K + 7) / 8 * 8), (unsigned)(O_total / BN));
+  if (stamps)
+    pair_gemm_d_kernel<BN, true><<<grid, 256, lds, stream>>>(X, R, planes, wplane, O_total, nbmaps, nboffs, K, gcol, Z, stamps);
+  else
+    pair_gemm_d_kernel<BN, false><<<grid, 256, lds, stream>>>(X, R, planes, wplane, O_total, nbmaps, nboffs, K, gcol, Z, nullptr);
+  TS_CHECK_LAUNCH("conv_pair_gemm (direct rows)");
+  return TS_OK;
+}
+
+
+// diagnostic: the next full-tile 128-row split pair GEMMs write 16 stamps per workgroup into `stamps` (device memory,
+// `capacity` workgroups); nullptr switches back to the product kernels.
+extern "C" void ts_debug_phase_stamps(unsigned long long *stamps, int64_t capacity) {
+  g_ts_phase_stamps = stamps;
+  g_ts_phase_cap = capacity;
+}
+
+// The direct-rows kernel on the planes that belong to THIS product in forward layout ([K, R, O_total]: the first half of
+// a weight's planes for the forward product, the W^T half for the input gradient), `plane_n` elements apart.  Taken by
+// ts_conv_pair_gemm when the caller left a hint (ts_conv_planes_hint) and ts_pair_gemm_direct_ok says the kernel wins:
+// 128-column tiles (3 instead of 2 workgroups per CU: 14 - 18 % on the stride-4 / 8 / 16 layers); on 96-column tiles
+// it ties with the LDS-staged kernel (ts_set_conv_impl(11) takes it there too, (13) never takes it).
+bool ts_pair_gemm_direct_ok(int bn) {
+  return g_ts_conv_impl == 11 ? (bn == 96 || bn == 128) : (g_ts_conv_impl == 0 && bn == 128);
+}
+int ts_pair_gemm_direct(const float *X, int R, const unsigned short *planes, int64_t plane_n, int O_total,
+                        const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z, int bn,
+                        hipStream_t stream) {
+  if (g_ts_phase_stamps)
+    TS_CHECK_HIP(hipMemsetAsync(g_ts_phase_stamps, 0, (size_t)g_ts_phase_cap * 16 * 8, stream), "phase stamps memset");
+  if (bn == 96)
+    return launch_pair_gemm_d<96>(X, R, planes, plane_n, O_total, nbmaps, nboffs, K, P, gcol, Z, g_ts_phase_stamps, stream);
+  return launch_pair_gemm_d<128>(X, R, planes, plane_n, O_total, nbmaps, nboffs, K, P, gcol, Z, g_ts_phase_stamps, stream);
 }
 
 template <int BM, int BN, int WR, bool WT>
@@ -245,7 +610,14 @@ static int launch_pair_gemm_s(const float *X, int R, const float *W, int O_total
                               int K, int64_t P, int gcol, float *Z, hipStream_t stream) {
   const size_t lds = (size_t)3 * (BM * PS_AP + (WT ? BN * PS_AP : PS_BK * (BN + 8))) * 2;
   dim3 grid((unsigned)((ts_cdiv(P, BM) + K + 7) / 8 * 8), (unsigned)(O_total / BN));
-  if (g_ts_conv_impl == 8)    // tiles in launch order (A/B of the XCD remap)
+  if (g_ts_phase_stamps && BM == 128 && BN >= 96) {
+    constexpr bool PB = BM == 128 && BN >= 96;
+    TS_REQUIRE((int64_t)grid.x * grid.y <= g_ts_phase_cap, TS_ERR_INVALID_ARGUMENT, "phase stamps: %lld workgroups, room for %lld",
+               (long long)grid.x * grid.y, (long long)g_ts_phase_cap);
+    TS_CHECK_HIP(hipMemsetAsync(g_ts_phase_stamps, 0, (size_t)g_ts_phase_cap * 16 * 8, stream), "phase stamps memset");
+    pair_gemm_s_kernel<BM, BN, WR, WT, true, PB><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol,
+                                                                              Z, g_ts_phase_stamps);
+  } else if (g_ts_conv_impl == 8)    // tiles in launch order (A/B of the XCD remap)
     pair_gemm_s_kernel<BM, BN, WR, WT, false><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);
   else
     pair_gemm_s_kernel<BM, BN, WR, WT, true><<<grid, 256, lds, stream>>>(X, R, W, O_total, nbmaps, nboffs, K, gcol, Z);

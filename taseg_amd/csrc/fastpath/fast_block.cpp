@@ -21,6 +21,7 @@ struct Api {
   decltype(&ts_conv_block_forward) forward = nullptr;
   decltype(&ts_conv_block_backward) backward = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
+  decltype(&ts_conv_planes_hint) planes_hint = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
   decltype(&ts_build_kmap_workspace_bytes) build_kmap_ws = nullptr;
@@ -62,7 +63,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const at::Tensor &pos_out, const at::Tensor &pos_in, int64_t n_in, int64_t n_out,
                             bool transposed, const c10::optional<at::Tensor> &running_mean,
                             const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt,
-                            double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream) {
+                            double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream,
+                            const c10::optional<at::Tensor> &planes) {
     const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
     const auto dt = half ? at::kHalf : at::kFloat;
     const int64_t rows = transposed ? n_in : n_out;
@@ -81,6 +83,9 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
     at::Tensor ws = workspace(nb, x, stream);
     float *st = stats.data_ptr<float>();
+    at::Tensor pl;                       // pre-split planes of the weight (taseg_amd/planes.py); fp32 blocks only
+    if (!half && planes.has_value() && planes->defined() && w32.data_ptr() == weight.data_ptr()) pl = *planes;
+    if (pl.defined()) api.planes_hint(w32.data_ptr<float>(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
     check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                       (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
                       (const int32_t *)table.data_ptr(), rows, (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(),
@@ -90,6 +95,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                       ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
           "ts_conv_block_forward");
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
+    ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
     ctx->saved_data["total"] = total;
     ctx->saved_data["n_in"] = n_in;
     ctx->saved_data["n_out"] = n_out;
@@ -131,6 +137,9 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor ws = workspace(nb, x, stream);
     const float *st = stats.data_ptr<float>();
     float *gw = gwb.data_ptr<float>();
+    const at::Tensor pl = ctx->saved_data["planes"].toTensor();
+    if (pl.defined() && !half && grad_feat.defined())
+      api.planes_hint((const float *)w.data_ptr(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
     check(api.backward(g.data_ptr(), (const uint8_t *)ptr(mask), conv_out.data_ptr(), st, st + c_out,
                        (const float *)bn_weight.data_ptr(), pack.defined() ? pack.data_ptr<double>() + 2 * c_out : nullptr,
                        (void *)comm, (double *)ptr(sums), rows, (int32_t)c_out, half ? 1 : 0, x.data_ptr(), x.size(0),
@@ -143,7 +152,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -157,7 +166,9 @@ void load_backend(const std::string &libpath) {
   api.forward = (decltype(api.forward))dlsym(h, "ts_conv_block_forward");
   api.backward = (decltype(api.backward))dlsym(h, "ts_conv_block_backward");
   api.last_error = (decltype(api.last_error))dlsym(h, "ts_last_error");
-  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward, "libtaseg_hip.so lacks the ts_conv_block_* entry points");
+  api.planes_hint = (decltype(api.planes_hint))dlsym(h, "ts_conv_planes_hint");
+  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.planes_hint,
+              "libtaseg_hip.so lacks the ts_conv_block_* / ts_conv_planes_hint entry points");
 #define TS_BIND(field, sym)                                      \
   api.field = (decltype(api.field))dlsym(h, sym);                \
   TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
@@ -178,10 +189,11 @@ at::Tensor conv_block(const at::Tensor &feats, const at::Tensor &weight, const c
                       const at::Tensor &nboffs, int64_t total, const at::Tensor &pos_out, const at::Tensor &pos_in,
                       int64_t n_in, int64_t n_out, bool transposed, const c10::optional<at::Tensor> &running_mean,
                       const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt, double momentum,
-                      double eps, bool relu, int64_t comm, bool half, int64_t stream) {
+                      double eps, bool relu, int64_t comm, bool half, int64_t stream,
+                      const c10::optional<at::Tensor> &planes) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
-                          transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream);
+                          transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes);
 }
 
 // ------------------------------------------------------------------------------------------------ index plan

@@ -17,6 +17,7 @@ all-reduce over ranks when there are several), whose buckets this optimizer shar
 import torch
 
 from . import _lib as L
+from . import planes as _planes
 from .parallel import GradBucketReducer
 
 __all__ = ["FlatSGD"]
@@ -82,3 +83,4 @@ class FlatSGD:
         # (a skipped very first step leaves the momentum buffers zero, which `first` = 0 then treats correctly:
         #  momentum * 0 + d = d)
         self._first = False
+        _planes.invalidate()       # ts_sgd_apply wrote the parameters through raw pointers: pre-split weights are stale

@@ -1,0 +1,106 @@
+"""Pre-split weight planes for the fp32 pair GEMMs (csrc/conv_pairs_s.hip, include/taseg_hip.h "Pre-split weight planes").
+
+The fp32 convolution kernels run on the bf16 matrix pipe through the exact split x = h + m + l of both operands.  For a
+weight that split is the same in every workgroup of every launch of a training step; `planes_for(weight)` keeps the six
+bf16 planes of a convolution weight (h | m | l of W and of W^T) next to it and re-splits them - all stale weights of
+the model in one batch of launches - when the weight has changed: a different `_version` (torch optimizers,
+`load_state_dict`, broadcasts), a different storage (`.to()`, FlatSGD's flat buckets) or an `invalidate()` from code
+that writes parameters behind torch's back (FlatSGD's ts_sgd_apply).  The planes are handed to the backend as a
+one-shot hint per call (ts_conv_planes_hint); results are bit-identical with and without them.
+
+TASEG_PRESPLIT=0 switches the mechanism off.
+"""
+import ctypes
+import os
+import weakref
+
+import torch
+
+from . import _lib as L
+
+__all__ = ["planes_for", "invalidate", "eligible", "hint", "stats"]
+
+_ENABLED = os.environ.get("TASEG_PRESPLIT", "1") != "0"
+_FREEZE = os.environ.get("TASEG_PRESPLIT_FREEZE", "0") == "1"      # timing experiment only: never re-split (stale planes!)
+_entries = {}          # id(weight) -> _Entry
+_epoch = 0
+stats = {"refreshes": 0, "launch_batches": 0}
+
+
+class TsPlaneJob(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("planes", ctypes.c_void_p), ("K", ctypes.c_int32), ("c_in", ctypes.c_int32),
+                ("c_out", ctypes.c_int32)]
+
+
+class _Entry:
+    __slots__ = ("ref", "planes", "ptr", "version", "epoch", "stream")
+
+    def __init__(self, weight):
+        self.ref = weakref.ref(weight)
+        self.planes = torch.empty(6 * weight.numel(), dtype=torch.int16, device=weight.device)
+        self.ptr = self.version = self.epoch = self.stream = None
+
+    def fresh(self, weight, stream):
+        if _FREEZE and self.ptr is not None:
+            return True
+        return self.ptr == weight.data_ptr() and self.version == weight._version and self.epoch == _epoch \
+            and self.stream == stream
+
+
+def invalidate():
+    """Every weight may have changed without a version bump (a kernel wrote the parameters through raw pointers)."""
+    global _epoch
+    _epoch += 1
+
+
+def _wide(c):
+    return c % 128 == 0 and c % 96 != 0      # the widths the direct-rows kernel takes (128-column tiles)
+
+
+def eligible(weight) -> bool:
+    """fp32 [K, C_in, C_out] weight on a ROCm device whose forward product or input gradient runs on 128-column tiles."""
+    return (_ENABLED and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 3 and weight.is_contiguous()
+            and weight.shape[0] <= 63 and weight.shape[1] % 32 == 0 and weight.shape[2] % 32 == 0
+            and (_wide(weight.shape[1]) or _wide(weight.shape[2])))
+
+
+def _refresh(stream):
+    """Re-split every registered weight that is stale (one launch per 16 weights) on `stream`."""
+    jobs, done = [], []
+    for key, e in list(_entries.items()):
+        w = e.ref()
+        if w is None:
+            del _entries[key]
+            continue
+        if not e.fresh(w, stream):
+            jobs.append((w.data_ptr(), e.planes.data_ptr(), w.shape[0], w.shape[1], w.shape[2]))
+            done.append((e, w))
+    if not jobs:
+        return
+    arr = (TsPlaneJob * len(jobs))(*[TsPlaneJob(*j) for j in jobs])
+    L.check(L.load().ts_conv_split_planes_batch(arr, len(jobs), stream), "ts_conv_split_planes_batch")
+    for e, w in done:
+        e.ptr, e.version, e.epoch, e.stream = w.data_ptr(), w._version, _epoch, stream
+    stats["refreshes"] += len(jobs)
+    stats["launch_batches"] += 1
+
+
+def planes_for(weight):
+    """The planes tensor of `weight` (int16 storage of 6 * numel bf16), in step with the weight on the current stream,
+    or None when the mechanism does not apply."""
+    if not eligible(weight):
+        return None
+    stream = L.stream()
+    e = _entries.get(id(weight))
+    if e is None or e.ref() is not weight:
+        e = _entries[id(weight)] = _Entry(weight)
+    if not e.fresh(weight, stream):
+        _refresh(stream)
+    return e.planes
+
+
+def hint(weight32, planes):
+    """One-shot: the next ts_conv_pair_gemm / ts_conv_block_* call of this thread on `weight32` may read `planes`."""
+    if planes is not None:
+        k, c_in, c_out = weight32.shape
+        L.load().ts_conv_planes_hint(weight32.data_ptr(), planes.data_ptr(), k, c_in, c_out)

@@ -17,6 +17,7 @@ import torch
 from torch.autograd import Function
 
 from ... import backend as B
+from ... import planes as _planes
 from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from .utils import get_kernel_offsets
@@ -287,7 +288,7 @@ class _SparseConv(Function):
     the weight gradient comes back in fp32."""
 
     @staticmethod
-    def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool):
+    def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool, planes=None):
         if feats.shape[1] != weight.shape[1]:
             raise ValueError("Input feature size and kernel size mismatch")
         n_in, n_out = kmap.sizes
@@ -308,12 +309,16 @@ class _SparseConv(Function):
             else:
                 # pass 1: z[p] = feats[source row of pair p] @ W[k(p)];  pass 2: out[row] = sum_k z[pos[k, row]]
                 f32, w32 = feats.contiguous().float(), weight.contiguous().float()
+                if w32.data_ptr() != weight.data_ptr():
+                    planes = None             # a converted copy: the planes belong to the parameter's own storage
+                _planes.hint(w32, planes)
                 z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
                 out = B.conv_gather_sum(z, table, rows)
                 ctx.save_for_backward(f32, w32)
                 if want_half:
                     out = out.half()          # stem (C_in = 4 / 5): fp32 kernels, half result like the reference
         ctx.kmap, ctx.transposed, ctx.half, ctx.in_dtype = kmap, transposed, half, feats.dtype
+        ctx.planes = None if half else planes
         return out
 
     @staticmethod
@@ -338,13 +343,14 @@ class _SparseConv(Function):
             else:
                 g32 = grad_out.contiguous().float()
                 if ctx.needs_input_grad[0]:
+                    _planes.hint(weight, ctx.planes)
                     z = B.conv_pair_gemm(g32, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol,
                                          weight_transposed=True)
                     grad_feats = B.conv_gather_sum(z, table, rows).to(ctx.in_dtype)
                 if ctx.needs_input_grad[1]:
                     grad_weight = B.conv_wgrad(feats, g32, kmap.nbmaps_buf, kmap.nboffs, k,
                                                col_a=1 if transposed else 0, max_pairs=kmap.total)
-        return grad_feats, grad_weight, None, None
+        return grad_feats, grad_weight, None, None, None
 
 
 def build_pyramid(x: SparseTensor, num_levels: int = 4, kernel_size: int = 3, down_kernel: int = 2) -> None:
@@ -539,7 +545,7 @@ def _identity_rows(n, dev):
 
 def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optional[torch.Tensor] = None,
            stride: Union[int, List[int], Tuple[int, ...]] = 1, dilation: Union[int, Tuple[int, ...]] = 1,
-           transposed: bool = False) -> SparseTensor:
+           transposed: bool = False, planes: Optional[torch.Tensor] = None) -> SparseTensor:
     """conv.py:122-205 - same coordinate / kernel-map caching protocol as the reference:
     `cmaps[stride]` holds coordinates, `kmaps[(in_stride, kernel, stride, dilation)]` the map,
     a transposed convolution reuses the map of its mirror strided convolution."""
@@ -556,7 +562,7 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optiona
             out_feats = input.feats.matmul(weight)   # plain dense GEMM -> rocBLAS/hipBLASLt
     else:
         kmap, out_coords, out_stride = conv_geometry(input, kernel_size, stride, dilation, transposed)
-        out_feats = _SparseConv.apply(input.feats, weight, kmap, transposed)
+        out_feats = _SparseConv.apply(input.feats, weight, kmap, transposed, planes)
     if bias is not None:
         out_feats = out_feats + bias
     return _conv_output(input, out_feats, out_coords, out_stride)
@@ -596,7 +602,7 @@ class _ConvBlock(Function):
     w.r.t. the convolution output and the transposed half weight live in the per-stream workspace."""
 
     @staticmethod
-    def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half):
+    def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half, planes=None):
         running_mean, running_var, nbt, momentum, eps = bn_state
         lib = B.L.load()
         L = B.L
@@ -616,6 +622,9 @@ class _ConvBlock(Function):
         pack = torch.empty(2 * c_out + 1, dtype=torch.float64, device=dev) if comm is not None else None
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+        if half or w32.data_ptr() != weight.data_ptr():
+            planes = None
+        _planes.hint(w32, planes)
         L.check(lib.ts_conv_block_forward(
             L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol,
             L.ptr(table), rows, c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
@@ -624,6 +633,7 @@ class _ConvBlock(Function):
             ws.numel(), L.stream()), "ts_conv_block_forward")
         ctx.save_for_backward(x, w16 if half else w32, conv_out, stats, mask, bn_weight)
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
+        ctx.planes = planes
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
         ctx.in_dtype, ctx.res_dtype = feats.dtype, (None if residual is None else residual.dtype)
         return out
@@ -650,6 +660,8 @@ class _ConvBlock(Function):
         sums = torch.empty((2, c_out), dtype=torch.float64, device=dev) if comm is not None else None
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+        if grad_feat is not None and not half:
+            _planes.hint(w, ctx.planes)
         L.check(lib.ts_conv_block_backward(
             L.ptr(g), L.ptr(mask), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn_weight),
             L.ptr(ctx.total_dev), comm, L.ptr(sums), rows, c_out, 1 if half else 0, L.ptr(x), x.shape[0], c_in, L.ptr(w), k,
@@ -660,7 +672,7 @@ class _ConvBlock(Function):
             grad_feat = grad_feat.to(ctx.in_dtype)
         if grad_res is not None and grad_res.dtype != ctx.res_dtype:
             grad_res = grad_res.to(ctx.res_dtype)
-        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None
+        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
 
 
 def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", residual, rows: int) -> bool:

@@ -10,6 +10,7 @@ from ..utils.misc import make_ntuple
 from . import functional as F
 from ... import backend as _B
 from ... import _fast
+from ... import planes as _planes
 from .utils import fapply
 
 __all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act", "conv_bn_act"]
@@ -62,7 +63,8 @@ class Conv3d(nn.Module):
 
     def forward(self, input: SparseTensor) -> SparseTensor:
         return F.conv3d(input, self.kernel, kernel_size=self.kernel_size, bias=self.bias, stride=self.stride,
-                        dilation=self.dilation, transposed=self.transposed)
+                        dilation=self.dilation, transposed=self.transposed,
+                        planes=None if F._amp_half(input.feats) else _planes.planes_for(self.kernel))
 
 
 def _bn_forward(mod, feats, torch_forward, group=None):
@@ -148,14 +150,16 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 state = (mod.running_mean if track else None, mod.running_var if track else None,
                          mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
                 fast = _fast.module()
+                half = F._amp_half(feats)
+                planes = None if half else _planes.planes_for(conv.kernel)      # pre-split weight (taseg_amd/planes.py)
                 if fast is not None:            # C++ autograd node, same two backend calls (csrc/fastpath)
                     out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
                                           kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
                                           state[1], state[2], float(mod.momentum), float(mod.eps), relu,
-                                          (comm.value or 0) if comm is not None else 0, F._amp_half(feats), _B.L.stream())
+                                          (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes)
                 else:
                     out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
-                                             relu, comm, F._amp_half(feats))
+                                             relu, comm, half, planes)
                 return F._conv_output(input, out, out_coords, out_stride)
     return bn_act(mod, conv(input), relu=relu, residual=residual)
 

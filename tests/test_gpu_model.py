@@ -445,3 +445,51 @@ def test_conv_block_paths_agree(g_minkunet):
             assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-7, mode
         for a, b in zip(bufs, ref[3]):                  # BatchNorm running statistics / counters
             assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), mode
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "flat"])
+def test_presplit_weight_planes_change_nothing(monkeypatch, optimizer):
+    """taseg_amd/planes.py: three SGD steps with the pre-split weight planes (the direct-rows pair GEMM reads them in the
+    128-wide layers, forward and input gradient; re-split after every optimizer step, FlatSGD announcing its raw-pointer
+    update) end in bit-identical losses and weights to three steps without them."""
+    from taseg_amd import planes
+    from taseg_amd.optim import FlatSGD
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    pts, lab = synth_scan(5, n_points=20000, n_beams=32, n_az=1000)
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+    coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+    feats, labels = torch.from_numpy(pts[idx]).cuda(), torch.from_numpy(lab[idx].astype(np.int64)).cuda()
+
+    def run(enabled):
+        monkeypatch.setattr(planes, "_ENABLED", enabled)
+        before = planes.stats["refreshes"]
+        cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
+        model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+        opt = FlatSGD(model, lr=0.05, momentum=0.9) if optimizer == "flat" else torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            ret, _, _ = model({"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords),
+                               "offset": torch.tensor([0])})
+            ret["loss"].backward()
+            opt.step()
+            losses.append(float(ret["loss"]))
+        model.eval()                      # the unfused path (Conv3d.forward -> conv3d) takes the planes as well
+        n = len(coords)
+        inv = SparseTensor(torch.arange(n, device="cuda"), coords)
+        with torch.no_grad():
+            out = model({"lidar": SparseTensor(feats, coords), "inverse_map": inv,
+                         "targets_mapped": SparseTensor(torch.zeros(n, dtype=torch.uint8, device="cuda"), coords),
+                         "num_points": torch.tensor([n]), "name": ["a"]})
+        return (losses, [p.detach().clone() for p in model.parameters()], np.asarray(out["point_predict_logits"][0]),
+                planes.stats["refreshes"] - before)
+
+    l0, w0, e0, n0 = run(False)
+    l1, w1, e1, n1 = run(True)
+    assert n0 == 0 and n1 >= 3 * 4, f"planes were split {n1} times: the mechanism did not engage"
+    assert l0 == l1 and all(torch.equal(a, b) for a, b in zip(w0, w1)), "pre-split planes changed the training steps"
+    assert np.array_equal(e0, e1), "pre-split planes changed the eval logits"

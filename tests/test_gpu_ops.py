@@ -850,3 +850,52 @@ def test_conv_dense_rulebook_reference_golden(B, F):
     close(x.grad[::4], g["t_gx"])
     close(wd.grad, g["t_gwd"])
     close(wu.grad, g["t_gwu"])
+
+
+@pytest.mark.parametrize("ci,co,impl", [(128, 128, 0), (256, 128, 0), (128, 256, 0), (64, 128, 0), (128, 64, 0),
+                                         (96, 96, 11), (192, 96, 11), (384, 256, 0)])
+def test_presplit_planes_give_the_same_bits(B, F, ci, co, impl):
+    """ts_conv_split_planes + ts_conv_planes_hint: the direct-rows pair GEMM on pre-split weight planes (forward product on
+    the planes of W, input gradient on those of W^T) returns bit for bit what the kernels that split the weight slice
+    themselves return; the hint is one-shot and a hint for another weight or other shapes is ignored."""
+    from taseg_amd import _lib as L
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    lib = L.load()
+    rs = np.random.RandomState(ci + 7 * co)
+    c = _blob(11, n=9000, extent=24)
+    km = B.build_kmap(T(c), T(c), get_kernel_offsets(3, 1, 1, device=DEV), want_inverse=True)
+    total = int(km["nboffs"][-1])
+    x, gy = T(rs.randn(len(c), ci).astype(np.float32)), T(rs.randn(len(c), co).astype(np.float32))
+    w = T((rs.randn(27, ci, co) / np.sqrt(27 * ci)).astype(np.float32))
+    planes = torch.empty(6 * w.numel(), dtype=torch.int16, device=DEV)
+    L.check(lib.ts_conv_split_planes(L.ptr(w), 27, ci, co, L.ptr(planes), L.stream()), "ts_conv_split_planes")
+    # the planes themselves: h + m + l == w exactly, in both layouts
+    pl = planes.view(torch.bfloat16).view(2, 3, -1).float()
+    assert torch.equal(pl[0].sum(0).view(27, ci, co), w) and torch.equal(pl[1].sum(0).view(27, co, ci), w.transpose(1, 2))
+    fwd = lambda: B.conv_pair_gemm(x, w, km["nbmaps"], km["nboffs"], total, 0)
+    dgr = lambda: B.conv_pair_gemm(gy, w, km["nbmaps"], km["nboffs"], total, 1, weight_transposed=True)
+    want_f, want_d = fwd(), dgr()
+    B.set_conv_impl(impl)
+    try:
+        lib.ts_conv_planes_hint(L.ptr(w), L.ptr(planes), 27, ci, co)
+        got_f = fwd()
+        lib.ts_conv_planes_hint(L.ptr(w), L.ptr(planes), 27, ci, co)
+        got_d = dgr()
+        assert torch.equal(got_f, want_f) and torch.equal(got_d, want_d)
+        # one-shot: poison the planes, the next call without a hint must not read them
+        junk = torch.zeros_like(planes)
+        lib.ts_conv_planes_hint(L.ptr(w), L.ptr(junk), 27, ci, co)
+        if co % 128 == 0 and co % 96 != 0 or impl == 11:
+            assert not torch.equal(fwd(), want_f), "the hinted call did not take the planes"
+        else:
+            fwd()                                                 # consumed (and ignored) all the same
+        assert torch.equal(fwd(), want_f), "a hint outlived its call"
+        # hints that do not fit this call are ignored: other weight pointer, other shapes
+        w2 = w.clone()
+        lib.ts_conv_planes_hint(L.ptr(w2), L.ptr(junk), 27, ci, co)
+        assert torch.equal(fwd(), want_f)
+        lib.ts_conv_planes_hint(L.ptr(w), L.ptr(junk), 27, co, ci + 32)
+        assert torch.equal(fwd(), want_f)
+    finally:
+        B.set_conv_impl(0)
+        lib.ts_conv_planes_hint(None, None, 0, 0, 0)
