@@ -474,8 +474,8 @@ void ts_set_conv_impl(int32_t impl);
  * convolution_forward_cuda, backend/convolution/convolution_cuda.cu:101-164, multiplies fp32 operands in cuBLAS).
  * The fp32 kernels evaluate a product on the bf16 matrix pipe through the exact split x = h + m + l of both operands;
  * for a weight that split is the same in every workgroup of every launch until the optimizer changes the weight.
- *   planes: 6 * K * c_in * c_out bf16 (16-byte aligned): h | m | l of W [K, c_in, c_out], then h | m | l of W^T
- *           [K, c_out, c_in] (the input gradient reads those as a forward-layout product); c_in, c_out % 8 == 0.
+ *   planes: 3 * K * c_in * c_out bf16 (16-byte aligned): h | m | l, each in the layout of W [K, c_in, c_out] (the forward
+ *           product and the input gradient read the same planes); c_in * c_out % 8 == 0.
  *   ts_conv_split_planes[_batch]  write them (one launch per 16 weights): call after every update of the weight.
  *   ts_conv_planes_hint           one-shot and per thread: the NEXT of the three calls above made by this thread may read
  *           `planes` in place of `w` if its weight pointer is `w` and its shapes are (K, c_in, c_out); that call clears

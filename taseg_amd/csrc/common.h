@@ -170,7 +170,7 @@ __device__ __forceinline__ void ts_wgrad_reduce_one(const TsWgradReduce &job, in
 // ---- pre-split weight planes (conv_pairs_s.hip) -------------------------------------------------------------------
 struct TsPlanesHint {
   const float *w;                  // the weight the planes were split from
-  const unsigned short *planes;    // [6][K * c_in * c_out] bf16: h | m | l of W, then h | m | l of W^T
+  const unsigned short *planes;    // [3][K * c_in * c_out] bf16: h | m | l, each in W's own layout
   int K, c_in, c_out;
 };
 extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv_planes_hint, cleared by the call that reads it

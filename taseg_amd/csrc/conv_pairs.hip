@@ -31,7 +31,7 @@ int ts_wgrad_split(const float *A, int CA, const float *B, int CB, const int2 *n
                    int col_a, int64_t n_pairs, float *dW, int tm, int tn, hipStream_t stream);
 bool ts_pair_gemm_direct_ok(int bn);
 int ts_pair_gemm_direct(const float *X, int R, const unsigned short *planes, int64_t plane_n, int O_total,
-                        const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z, int bn,
+                        const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z, int bn, int wt,
                         hipStream_t stream);
 
 // BN = output columns per workgroup, WR = waves along the pair (row) dimension (WC = 4 / WR along columns).
@@ -726,8 +726,8 @@ extern "C" int ts_conv_pair_gemm(const float *feat, int64_t n_rows, int32_t c_in
     if (hint.w == kernel && hint.planes && hint.K == K && shapes && K <= 63 && c_in % 32 == 0 && c_out % bn == 0 &&
         ((((uintptr_t)feat) | ((uintptr_t)z) | ((uintptr_t)hint.planes)) & 15) == 0 && ts_pair_gemm_direct_ok(bn)) {
       const int64_t n = (int64_t)K * c_in * c_out;
-      return ts_pair_gemm_direct(feat, c_in, hint.planes + (weight_transposed ? 3 * n : 0), n, c_out, nm, nboffs, K, n_pairs,
-                                 gc, z, bn, stream);
+      return ts_pair_gemm_direct(feat, c_in, hint.planes, n, c_out, nm, nboffs, K, n_pairs, gc, z, bn,
+                                 weight_transposed ? 1 : 0, stream);
     }
   }
 #define TS_PG(BN, WR)                                                                                             \

@@ -288,11 +288,13 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void pair_gemm_s_kernel(con
 }
 
 // ---------------------------------------------------------------------------------- pre-split weights
-// Planes of a convolution weight W [K, Ci, Co] (n = K * Ci * Co): six bf16 arrays of n elements,
-//     [0, 3n)  h | m | l of W itself            - the forward product reads them (slices along Ci)
-//     [3n, 6n) h | m | l of W^T = [K, Co, Ci]   - the input gradient runs as a forward-layout product on them
-// written once per optimizer step (ts_conv_split_planes[_batch]) and handed to the next convolution call of the
-// calling thread with ts_conv_planes_hint.  One workgroup row (blockIdx.y) per weight.
+// Planes of a convolution weight W [K, Ci, Co] (n = K * Ci * Co): three bf16 arrays of n elements, h | m | l, each in
+// the layout of W itself.  The forward product reads slices along Ci through transposing LDS loads, the input gradient
+// reads the same planes as [K, O = Ci, R = Co] rows (pair_gemm_d_kernel<.., WT>).  Written once per optimizer step
+// (ts_conv_split_planes[_batch]: a streaming pass, one workgroup row per weight, 16 weights per launch) and handed to
+// the next convolution call of the calling thread with ts_conv_planes_hint.  (A second set of planes of W^T, so that
+// the input gradient could run as a forward-layout product with two LDS buffers, made that kernel 4 % faster and the
+// split twice as expensive - more than it gained.)
 struct TsPlaneJobs {
   TsPlaneJob job[16];
 };
@@ -303,35 +305,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(TsPlaneJobs jobs) {
   const int64_t n = (int64_t)jb.K * jb.c_in * jb.c_out;
   const int64_t n8 = n >> 3;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {      // W as it lies
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
     u32x4 h, m, l;
     split8(*(const f32x4 *)(w + 8 * i), *(const f32x4 *)(w + 8 * i + 4), h, m, l);
     *(u32x4 *)(planes + 8 * i) = h;
     *(u32x4 *)(planes + n + 8 * i) = m;
     *(u32x4 *)(planes + 2 * n + 8 * i) = l;
-  }
-  // W^T: a thread takes 8 consecutive ci of one (k, co) - neighbouring threads neighbouring co, so the eight strided
-  // reads are coalesced across the wave; its 16-byte writes are Ci * 2 bytes apart
-  const int ci8 = jb.c_in >> 3;
-  unsigned short *__restrict__ pt = planes + 3 * n;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
-    const int co = (int)(i % jb.c_out);
-    const int64_t r = i / jb.c_out;
-    const int c8 = (int)(r % ci8);
-    const int64_t k = r / ci8;
-    const float *src = w + (k * jb.c_in + 8 * c8) * jb.c_out + co;
-    f32x4 v0, v1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v0[j] = src[(int64_t)j * jb.c_out];
-      v1[j] = src[(int64_t)(j + 4) * jb.c_out];
-    }
-    u32x4 h, m, l;
-    split8(v0, v1, h, m, l);
-    const int64_t d = (k * jb.c_out + co) * jb.c_in + 8 * c8;
-    *(u32x4 *)(pt + d) = h;
-    *(u32x4 *)(pt + n + d) = m;
-    *(u32x4 *)(pt + 2 * n + d) = l;
   }
 }
 
@@ -343,9 +322,9 @@ extern "C" int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs
     int64_t big = 0;
     for (int j = 0; j < cnt; ++j) {
       const TsPlaneJob &jb = jobs[j0 + j];
-      TS_REQUIRE(jb.w && jb.planes && jb.K > 0 && jb.c_in > 0 && jb.c_out > 0 && jb.c_in % 8 == 0 && jb.c_out % 8 == 0 &&
+      TS_REQUIRE(jb.w && jb.planes && jb.K > 0 && jb.c_in > 0 && jb.c_out > 0 && ((int64_t)jb.c_in * jb.c_out) % 8 == 0 &&
                      ((((uintptr_t)jb.w) | ((uintptr_t)jb.planes)) & 15) == 0,
-                 TS_ERR_INVALID_ARGUMENT, "ts_conv_split_planes_batch: job %d: null / misaligned pointer or channels not a multiple of 8",
+                 TS_ERR_INVALID_ARGUMENT, "ts_conv_split_planes_batch: job %d: null / misaligned pointer or C_in * C_out not a multiple of 8",
                  j0 + j);
       chunk.job[j] = jb;
       big = std::max<int64_t>(big, (int64_t)jb.K * jb.c_in * jb.c_out);
@@ -379,7 +358,11 @@ static int64_t g_ts_phase_cap = 0;
 // (three bf16 planes in the fp32 weight's [K, R, O_total] layout, split_planes_kernel) and is the only thing staged in
 // LDS, double buffered: ONE barrier per slice, no split work for the weights, 40 - 52 KB of LDS and <= 168 VGPRs, i.e.
 // three workgroups per CU whose waves run their gather -> split -> MFMA chains independently between the barriers.
-template <int BN, bool PROBE>
+// WT = false: planes of W [K, R, O_total], slices along its rows (forward product), transposing LDS reads, two LDS
+// buffers.  WT = true: the same planes read as [K, O_total, R] (input gradient: one image row per output column, the
+// slice contiguous along it), plain 16-byte fragment reads; that image takes 3 x BN x 80 bytes, so it is single buffered
+// (a second barrier per slice) to keep three workgroups on a CU.
+template <int BN, bool WT, bool PROBE>
 __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__restrict__ X, int R,
                                                              const unsigned short *__restrict__ Wp, int64_t wplane,
                                                              int O_total, const int2 *__restrict__ nbmaps,
@@ -388,12 +371,12 @@ __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__rest
                                                              unsigned long long *__restrict__ stamps) {
   constexpr int BM = 128, MI = 2, NI = BN / 16;
   constexpr int BP = BN + 8;
-  constexpr int B_PLANE = PS_BK * BP;
+  constexpr int B_PLANE = WT ? BN * PS_AP : PS_BK * BP;
   constexpr int B_BUF = 3 * B_PLANE;
   constexpr int B_CHUNKS = BN * (PS_BK / 8);
   constexpr int B_IT = (B_CHUNKS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_d[];
-  unsigned short *Bp = smem_d;                                 // 2 buffers x 3 planes [32][BP]
+  unsigned short *Bp = smem_d;                                 // (WT ? 1 : 2) buffers x 3 planes
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,12 +416,18 @@ __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__rest
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int e = min(tid + it * 256, B_CHUNKS - 1);
-    constexpr int q8 = BN >> 3;
-    const int kk = e / q8, c8 = (e - kk * q8) << 3;
-    boff[it] = kk * O_total + c8;
-    bdst[it] = kk * BP + c8;
+    if (WT) {
+      const int col = e >> 2, c8 = (e & 3) << 3;
+      boff[it] = col * R + c8;
+      bdst[it] = col * PS_AP + c8;
+    } else {
+      constexpr int q8 = BN >> 3;
+      const int kk = e / q8, c8 = (e - kk * q8) << 3;
+      boff[it] = kk * O_total + c8;
+      bdst[it] = kk * BP + c8;
+    }
   }
-  const unsigned short *wkp = Wp + (int64_t)k * R * O_total + o0;
+  const unsigned short *wkp = WT ? Wp + ((int64_t)k * O_total + o0) * R : Wp + (int64_t)k * R * O_total + o0;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -457,7 +446,7 @@ __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__rest
     }
   };
   auto load_b = [&](int c0) {
-    const unsigned short *wb = wkp + (int64_t)c0 * O_total;
+    const unsigned short *wb = WT ? wkp + c0 : wkp + (int64_t)c0 * O_total;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it)
 #pragma unroll
@@ -493,7 +482,12 @@ __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__rest
     for (int ni = 0; ni < NI; ++ni) {
       bf8 b[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[p] = frag_tr(bb + p * B_PLANE, BP, 8 * g, ni * 16, tq, tp);
+      for (int p = 0; p < 3; ++p) {
+        if (WT)
+          b[p] = *(const bf8 *)&bb[p * B_PLANE + (ni * 16 + r16) * PS_AP + 8 * g];
+        else
+          b[p] = frag_tr(bb + p * B_PLANE, BP, 8 * g, ni * 16, tq, tp);
+      }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) TS_SPLIT_MMA(acc[mi][ni], a[mi], b);
     }
@@ -523,10 +517,11 @@ __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__rest
       load_a((s + 1) * PS_BK);
       load_b((s + 1) * PS_BK);
     }
-    mma(s & 1);
+    mma(WT ? 0 : (s & 1));
     if (s == 0) TS_STAMP(5);
     if (more) {
-      write_b((s + 1) & 1);
+      if (WT) __syncthreads();        // single buffer: every wave has read the slice before it is overwritten
+      write_b(WT ? 0 : ((s + 1) & 1));
       split_a();
       __syncthreads();
     }
@@ -565,16 +560,16 @@ __global__ __launch_bounds__(256, 3) void pair_gemm_d_kernel(const float *__rest
     }
   }
 }
-template <int BN>
+template <int BN, bool WT>
 static int launch_pair_gemm_d(const float *X, int R, const unsigned short *planes, int64_t wplane, int O_total,
                               const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z,
                               unsigned long long *stamps, hipStream_t stream) {
-  const size_t lds = (size_t)2 * 3 * PS_BK * (BN + 8) * 2;
+  const size_t lds = WT ? (size_t)3 * BN * PS_AP * 2 : (size_t)2 * 3 * PS_BK * (BN + 8) * 2;
   dim3 grid((unsigned)((ts_cdiv(P, 128) + K + 7) / 8 * 8), (unsigned)(O_total / BN));
   if (stamps)
-    pair_gemm_d_kernel<BN, true><<<grid, 256, lds, stream>>>(X, R, planes, wplane, O_total, nbmaps, nboffs, K, gcol, Z, stamps);
+    pair_gemm_d_kernel<BN, WT, true><<<grid, 256, lds, stream>>>(X, R, planes, wplane, O_total, nbmaps, nboffs, K, gcol, Z, stamps);
   else
-    pair_gemm_d_kernel<BN, false><<<grid, 256, lds, stream>>>(X, R, planes, wplane, O_total, nbmaps, nboffs, K, gcol, Z, nullptr);
+    pair_gemm_d_kernel<BN, WT, false><<<grid, 256, lds, stream>>>(X, R, planes, wplane, O_total, nbmaps, nboffs, K, gcol, Z, nullptr);
   TS_CHECK_LAUNCH("conv_pair_gemm (direct rows)");
   return TS_OK;
 }
@@ -587,22 +582,23 @@ extern "C" void ts_debug_phase_stamps(unsigned long long *stamps, int64_t capaci
   g_ts_phase_cap = capacity;
 }
 
-// The direct-rows kernel on the planes that belong to THIS product in forward layout ([K, R, O_total]: the first half of
-// a weight's planes for the forward product, the W^T half for the input gradient), `plane_n` elements apart.  Taken by
-// ts_conv_pair_gemm when the caller left a hint (ts_conv_planes_hint) and ts_pair_gemm_direct_ok says the kernel wins:
-// 128-column tiles (3 instead of 2 workgroups per CU: 14 - 18 % on the stride-4 / 8 / 16 layers); on 96-column tiles
-// it ties with the LDS-staged kernel (ts_set_conv_impl(11) takes it there too, (13) never takes it).
+// The direct-rows kernel on the planes of the weight (`plane_n` elements apart), wt = 0: forward product, 1: input
+// gradient.  Taken by ts_conv_pair_gemm when the caller left a hint (ts_conv_planes_hint) and ts_pair_gemm_direct_ok says
+// the kernel wins: 128-column tiles (3 instead of 2 workgroups per CU: 12 - 18 % on the stride-4 / 8 / 16 layers); on
+// 96-column tiles it ties with the LDS-staged kernel (ts_set_conv_impl(11) takes it there too, (13) never takes it).
 bool ts_pair_gemm_direct_ok(int bn) {
   return g_ts_conv_impl == 11 ? (bn == 96 || bn == 128) : (g_ts_conv_impl == 0 && bn == 128);
 }
 int ts_pair_gemm_direct(const float *X, int R, const unsigned short *planes, int64_t plane_n, int O_total,
-                        const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z, int bn,
+                        const int2 *nbmaps, const int *nboffs, int K, int64_t P, int gcol, float *Z, int bn, int wt,
                         hipStream_t stream) {
   if (g_ts_phase_stamps)
     TS_CHECK_HIP(hipMemsetAsync(g_ts_phase_stamps, 0, (size_t)g_ts_phase_cap * 16 * 8, stream), "phase stamps memset");
-  if (bn == 96)
-    return launch_pair_gemm_d<96>(X, R, planes, plane_n, O_total, nbmaps, nboffs, K, P, gcol, Z, g_ts_phase_stamps, stream);
-  return launch_pair_gemm_d<128>(X, R, planes, plane_n, O_total, nbmaps, nboffs, K, P, gcol, Z, g_ts_phase_stamps, stream);
+#define TS_PD(BN)                                                                                                           \
+  (wt ? launch_pair_gemm_d<BN, true>(X, R, planes, plane_n, O_total, nbmaps, nboffs, K, P, gcol, Z, g_ts_phase_stamps, stream) \
+      : launch_pair_gemm_d<BN, false>(X, R, planes, plane_n, O_total, nbmaps, nboffs, K, P, gcol, Z, g_ts_phase_stamps, stream))
+  return bn == 96 ? TS_PD(96) : TS_PD(128);
+#undef TS_PD
 }
 
 template <int BM, int BN, int WR, bool WT>

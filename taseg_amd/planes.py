@@ -2,7 +2,7 @@
 
 The fp32 convolution kernels run on the bf16 matrix pipe through the exact split x = h + m + l of both operands.  For a
 weight that split is the same in every workgroup of every launch of a training step; `planes_for(weight)` keeps the six
-bf16 planes of a convolution weight (h | m | l of W and of W^T) next to it and re-splits them - all stale weights of
+bf16 planes of a convolution weight (h | m | l, each in the weight's own layout) next to it and re-splits them - all stale weights of
 the model in one batch of launches - when the weight has changed: a different `_version` (torch optimizers,
 `load_state_dict`, broadcasts), a different storage (`.to()`, FlatSGD's flat buckets) or an `invalidate()` from code
 that writes parameters behind torch's back (FlatSGD's ts_sgd_apply).  The planes are handed to the backend as a
@@ -37,7 +37,7 @@ class _Entry:
 
     def __init__(self, weight):
         self.ref = weakref.ref(weight)
-        self.planes = torch.empty(6 * weight.numel(), dtype=torch.int16, device=weight.device)
+        self.planes = torch.empty(3 * weight.numel(), dtype=torch.int16, device=weight.device)
         self.ptr = self.version = self.epoch = self.stream = None
 
     def fresh(self, weight, stream):
@@ -86,7 +86,7 @@ def _refresh(stream):
 
 
 def planes_for(weight):
-    """The planes tensor of `weight` (int16 storage of 6 * numel bf16), in step with the weight on the current stream,
+    """The planes tensor of `weight` (int16 storage of 3 * numel bf16), in step with the weight on the current stream,
     or None when the mechanism does not apply."""
     if not eligible(weight):
         return None

@@ -33,7 +33,7 @@ for spec in args.layers.split(","):
     n, P = km.sizes[0], km.total
     xf = torch.randn(n, ci, device="cuda")
     w = torch.randn(27, ci, co, device="cuda") * 0.05
-    planes = torch.empty(6 * w.numel(), dtype=torch.int16, device="cuda")
+    planes = torch.empty(3 * w.numel(), dtype=torch.int16, device="cuda")
     L.check(lib.ts_conv_split_planes(w.data_ptr(), 27, ci, co, planes.data_ptr(), L.stream()), "split")
     gy = torch.randn(n, co, device="cuda")
     for wt, pre in ((False, 0), (False, 2), (True, 0), (True, 2)):
