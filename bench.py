@@ -415,6 +415,7 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from taseg_amd import backend as B
+    from taseg_amd import planes as _planes
     from taseg_amd.data.synthetic import make_model_cfg
     from taseg_amd.pcseg.model import build_network
     from taseg_amd.torchsparse import SparseTensor
@@ -494,8 +495,11 @@ def main():
                                                         threaded=os.environ.get("TASEG_STAGE_THREAD", "0") == "1")
 
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
+    B.planes_in_use = _planes._ENABLED and not args.amp        # names the 128-column fp32 pair GEMM in the kernel table
 
-    def step():
+    opt_events = []
+
+    def step(time_optimizer=False):
         # one step = stage one batch (rulebooks / index plan; for minkunet_ms also the temporal aggregation and
         # voxelisation) + forward + loss + backward + clip + SGD.  With the prefetcher the batch staged inside
         # step i is the one step i+1 trains on (every timed step still stages exactly one batch).
@@ -508,15 +512,23 @@ def main():
         loss = ret["loss"].float().mean()
         if flat:
             (loss * opt.loss_scale()).backward()
-            opt.step()                   # reducer.finish() + grad stats + decide + apply, all on the device
         else:
             scaler.scale(loss).backward()
+        if time_optimizer:               # BASELINE's metric wants the optimizer's share stated: events on sampled steps
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if flat:
+            opt.step()                   # reducer.finish() + grad stats + decide + apply, all on the device
+        else:
             if reducer is not None:
                 reducer.finish()
             scaler.unscale_(opt)
             torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
             scaler.step(opt)
             scaler.update()
+        if time_optimizer:
+            ev[1].record()
+            opt_events.append(ev)
         if pf is not None:
             pf.prefetch()
         return ret["loss"]
@@ -541,7 +553,7 @@ def main():
     for i in range(args.steps):
         if not args.no_kernel_events:
             B.profile_pause(i % EVENT_EVERY != 0)      # HIP events around the conv kernels of every EVENT_EVERY-th timed step
-        loss = step()
+        loss = step(time_optimizer=not args.no_kernel_events and i % EVENT_EVERY == 0)
     fence()
     dt = time.perf_counter() - t0
     records = B.profile_end()
@@ -558,7 +570,7 @@ def main():
         dom = prof[0] if prof else None
         roofline = None
         if dom:
-            mfma_peak = MFMA_F16_PEAK_TF if args.amp else MFMA_SPLIT_PEAK_TF if "_s_kernel" in dom["kernel"] else MFMA_F32_PEAK_TF
+            mfma_peak = MFMA_F16_PEAK_TF if args.amp else MFMA_SPLIT_PEAK_TF if ("_s_kernel" in dom["kernel"] or "_d_kernel" in dom["kernel"]) else MFMA_F32_PEAK_TF
             t_mfma = dom["flops_per_launch"] / (mfma_peak * 1e12)
             t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
             if t_mfma >= t_hbm:
@@ -590,6 +602,8 @@ def main():
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}"},
             "loss": float(loss.detach()),
+            # inside ms_per_step; gradient clipping + SGD (world > 1: + the tail of the bucketed all-reduce it waits for)
+            "optimizer_ms_per_step": (sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events)) if opt_events else None,
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in prof[:8]],
             # the convolution kernels of one step: algorithmic bytes of the design as built (two passes: per-pair Z round

@@ -334,9 +334,15 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
     return dict(nbr=nbr, nbr_t=nbr_t, nbmaps=nbmaps, nbsizes=nbsizes, nboffs=nboffs, pos_out=pos_out, pos_in=pos_in)
 
 
+planes_in_use = False        # set by bench.py when the run's convolutions go through taseg_amd.planes (kernel naming only)
+
+
 def pair_gemm_kernel_name(c_out, weight_transposed=False, c_red=None):
     bn, wr = (32, 4) if c_out <= 32 else (64, 2) if c_out <= 64 else (96, 2) if c_out % 96 == 0 else (128, 2)
     fast = c_red is not None and c_red % 32 == 0 and c_out % bn == 0
+    if fast and _conv_impl == 0 and bn == 128 and planes_in_use:
+        # the block calls of a model run with pre-split weight planes (taseg_amd/planes.py): direct-rows kernel
+        return f"pair_gemm_d_kernel<128,{'true' if weight_transposed else 'false'}>"
     if fast and _conv_impl == 0:
         return f"pair_gemm_s_kernel<128,{bn},{wr},{'true' if weight_transposed else 'false'},true>"
     kind = "" if not fast else ("fast_" if weight_transposed else "persist_")
