@@ -564,6 +564,24 @@ def main():
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
     value = args.batch * world * args.steps / dt
+    bus = None
+    if dist is not None and world > 1:
+        # the achieved bus bandwidth of the step's one exchange, the gradient all-reduce, measured
+        # on its own after the timed region (a flat fp32 buffer of the model's size, bus = 2 (n - 1) / n * bytes / t)
+        n_par = sum(p.numel() for p in model.parameters())
+        buf = torch.zeros(n_par, dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            dist.all_reduce(buf)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t1) / 5], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bus = {"bytes": 4 * n_par, "ms": 1e3 * float(t.item()),
+               "bus_GBps": 2 * (world - 1) / world * 4 * n_par / float(t.item()) / 1e9}
+        del buf
 
     if rank == 0:
         prof = summarise_profile(records, profiled_steps)
@@ -603,6 +621,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "loss": float(loss.detach()),
             # inside ms_per_step; gradient clipping + SGD (world > 1: + the tail of the bucketed all-reduce it waits for)
+            "grad_allreduce": bus,
             "optimizer_ms_per_step": (sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events)) if opt_events else None,
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in prof[:8]],

@@ -131,3 +131,4 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     assert len(line) == 1, r.stdout
     rec = json.loads(line[0])
     assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and np.isfinite(rec["loss"])
+    assert rec["grad_allreduce"]["bytes"] > 100e6 and rec["grad_allreduce"]["bus_GBps"] > 0
