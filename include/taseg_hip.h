@@ -314,6 +314,23 @@ int ts_devoxelize_backward_runs_ld(const float *grad_out, int64_t go_ld, const i
 int ts_devoxelize_backward_csr_ld(const float *grad_out, int64_t go_ld, const float *weight, const int32_t *offsets,
                                   const int32_t *entries, int64_t n, int32_t c, int64_t m, float *grad_feat,
                                   ts_stream_t stream);
+
+/* Cell-reduced form of the same adjoint for coarse strides (stride 16: ~700 contributions per voxel).  No reference
+ * counterpart beyond devoxelize_backward_kernel (backend/devoxelize/devoxelize_cuda.cu:37-57), whose per-point
+ * atomicAdds it replaces.  Plan (coordinates only, built once per batch):
+ *   order      = ts_devox_order(idx): points of the same interpolation cell next to each other
+ *   flags      = ts_devox_segments(idx, order, n, max_len): 1 where a segment (equal 8-corner tuple, <= max_len points)
+ *                starts; seg_start = positions of the ones, then n
+ *   offsets / entries = ts_devox_csr on the segments' tuples [n_seg, 8] with weight 1 on the present corners
+ * ts_devoxelize_backward_cells_ld: stage 1 sums the weighted gradient rows of every segment per corner into part
+ * [n_seg * 8, c] (every gradient row is read once), stage 2 gathers those rows per voxel along the inverse map.  Fixed
+ * summation order, no atomics. */
+int ts_devox_segments(const int32_t *idx, const int32_t *order, int64_t n, int32_t max_len, int32_t *flags,
+                      ts_stream_t stream);
+int ts_devoxelize_backward_cells_ld(const float *grad_out, int64_t go_ld, const float *weight, const int32_t *order,
+                                    const int32_t *seg_start, int64_t n_seg, const int32_t *offsets,
+                                    const int32_t *entries, int64_t n, int32_t c, int64_t m, float *part,
+                                    float *grad_feat, ts_stream_t stream);
 size_t ts_devox_csr_workspace_bytes(int64_t n);
 int ts_devox_csr(const int32_t *idx, const float *weight, int64_t n, int64_t n_vox, int32_t *offsets, int32_t *entries,
                  void *ws, size_t ws_bytes, ts_stream_t stream);

@@ -165,7 +165,14 @@ def devoxelize_backward_from(grad, col, c, indices, weight, n_vox, order=None):
     n, ld = grad.shape
     out = torch.empty((int(n_vox), c), dtype=torch.float32, device=grad.device)
     lib = L.load()
-    if isinstance(order, tuple):
+    if isinstance(order, tuple) and isinstance(order[0], str):        # ("cells", ...): backend.devox_cells
+        _, walk, seg_start, off, ent = order
+        n_seg = seg_start.shape[0] - 1
+        part = torch.empty((max(8 * n_seg, 1), c), dtype=torch.float32, device=grad.device)
+        L.check(lib.ts_devoxelize_backward_cells_ld(grad.data_ptr() + 4 * col, ld, L.ptr(weight), L.ptr(walk), L.ptr(seg_start),
+                                                    n_seg, L.ptr(off), L.ptr(ent), n, c, int(n_vox), L.ptr(part), L.ptr(out),
+                                                    L.stream()), "ts_devoxelize_backward_cells_ld")
+    elif isinstance(order, tuple):
         off, ent = order
         L.check(lib.ts_devoxelize_backward_csr_ld(grad.data_ptr() + 4 * col, ld, L.ptr(weight), L.ptr(off), L.ptr(ent), n, c,
                                                   int(n_vox), L.ptr(out), L.stream()), "ts_devoxelize_backward_csr_ld")
@@ -190,8 +197,34 @@ def devox_csr(indices, weight, n_vox):
     return off, ent
 
 
+def devox_cells(indices, weight, n_vox, max_len=64):
+    """Plan of the cell-reduced devoxelize backward (include/taseg_hip.h, ts_devoxelize_backward_cells_ld) for a trilinear
+    map (indices, weight) [n, 8]: ("cells", walk order [n], seg_start [n_seg + 1], offsets [n_vox + 1], entries) - for
+    coarse strides, where many points share an interpolation cell.  Coordinates only; one host read (the segment
+    count) on the calling stream."""
+    L.require_device(indices, weight)
+    indices, weight = _i32(indices, "indices"), _f32(weight, "weight")
+    n = indices.shape[0]
+    walk = devox_order(indices, n_vox)
+    flags = torch.empty(max(n, 1), dtype=torch.int32, device=indices.device)
+    L.check(L.load().ts_devox_segments(L.ptr(indices), L.ptr(walk), n, int(max_len), L.ptr(flags), L.stream()),
+            "ts_devox_segments")
+    starts = torch.nonzero(flags[:n]).flatten().int()
+    seg_start = torch.cat([starts, torch.tensor([n], dtype=torch.int32, device=indices.device)])
+    first = walk[starts.long()].long()
+    tuples = indices[first].contiguous()                                   # [n_seg, 8]: the corner tuple of every segment
+    # a corner takes part if ANY point of the segment weighs on it; weight 1 on every present corner is a superset
+    # (rows of zeros add nothing) and keeps the plan free of a second pass over the weights
+    off, ent = devox_csr(tuples, (tuples >= 0).float(), n_vox)
+    return ("cells", walk, seg_start, off, ent)
+
+
 def devoxelize_backward_csr(top_grad, weight, csr, n):
-    """devoxelize_backward_cuda as a gather along the inverse map `csr` = devox_csr(...): no atomics, deterministic."""
+    """devoxelize_backward_cuda as a gather along the inverse map `csr` = devox_csr(...) (or the cell-reduced plan of
+    devox_cells): no atomics, deterministic."""
+    if isinstance(csr[0], str):
+        top_grad = _f32(top_grad, "top_grad")
+        return devoxelize_backward_from(top_grad, 0, top_grad.shape[1], csr[1], weight, n, csr)   # (indices unused by this plan)
     off, ent = csr
     L.require_device(top_grad, weight, off, ent)
     top_grad, weight = _f32(top_grad, "top_grad"), _f32(weight, "weight")

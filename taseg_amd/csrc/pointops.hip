@@ -503,6 +503,9 @@ extern "C" int ts_devoxelize_backward_runs_ld(const float *grad_out, int64_t go_
 // backward along the inverse map of ts_devox_csr: gfeat[v, :] = sum over the slots (point, corner) of voxel v of
 // weight[slot] * gout[point, :].  One group of c / 4 lanes per voxel, slots taken four at a time (independent loads);
 // every row is written exactly once (zeros for a voxel without slots): no fill, no atomics, fixed summation order.
+// SHIFT = 3: slot = point * 8 + corner, row = point, weighted by w[slot].  SHIFT = 0 (second stage of the cell-reduced
+// form below): slot = row of a matrix of partial sums, weight 1.
+template <int SHIFT>
 __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__restrict__ gout,
                                                                  const float *__restrict__ w,
                                                                  const int *__restrict__ off,
@@ -524,8 +527,8 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
     for (int u = 0; u < 4; ++u) s[u] = ent[e + u];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      wt[u] = w[s[u]];
-      g[u] = *(const float4 *)(gout + (int64_t)(s[u] >> 3) * go_ld + 4 * lane);
+      wt[u] = SHIFT ? w[s[u]] : 1.f;
+      g[u] = *(const float4 *)(gout + (int64_t)(s[u] >> SHIFT) * go_ld + 4 * lane);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -534,8 +537,8 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
   }
   for (; e < end; ++e) {
     const int s = ent[e];
-    const float wt = w[s];
-    const float4 g = *(const float4 *)(gout + (int64_t)(s >> 3) * go_ld + 4 * lane);
+    const float wt = SHIFT ? w[s] : 1.f;
+    const float4 g = *(const float4 *)(gout + (int64_t)(s >> SHIFT) * go_ld + 4 * lane);
     acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
   }
   *(float4 *)(gfeat + v * c + 4 * lane) = acc;
@@ -560,8 +563,118 @@ extern "C" int ts_devoxelize_backward_csr_ld(const float *grad_out, int64_t go_l
   TS_REQUIRE(((((uintptr_t)grad_out) | ((uintptr_t)grad_feat)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
              "ts_devoxelize_backward_csr: rows must be 16-byte aligned");
   const int groups = 256 / (c >> 2);
-  devoxelize_bwd_csr_kernel<<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(grad_out, weight, offsets, entries, m, c,
-                                                                             grad_feat, go_ld);
+  devoxelize_bwd_csr_kernel<3><<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(grad_out, weight, offsets, entries, m, c,
+                                                                                grad_feat, go_ld);
   TS_CHECK_LAUNCH("ts_devoxelize_backward_csr");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ cell-reduced backward (coarse strides)
+// At stride 16 a voxel collects ~700 (point, corner) contributions and a point feeds ~4 voxels: the inverse-map gather
+// above reads every gradient row once per live corner (8 x 246 MB per launch for 240k points x 256 channels).  Points of
+// the same interpolation cell share their 8-corner tuple, so the sum is split in two fixed-order stages:
+//   1. the points, walked in cell order (ts_devox_order), are cut into segments of equal tuple and at most 64 points
+//      (ts_devox_segments); a group of c / 4 lanes per segment forms the 8 weighted sums of its points' gradient rows -
+//      every row is read ONCE - and stores them as rows 8 s .. 8 s + 7 of `part`;
+//   2. the voxels gather the partial rows along the inverse map of the segments' corner tuples (ts_devox_csr on the
+//      [n_seg, 8] tuples): ~8x fewer rows than the point-wise gather.
+// No atomics, every output row written once, summation order fixed by the plan.
+__global__ __launch_bounds__(256) void devox_seg_flag_kernel(const int *__restrict__ idx, const int *__restrict__ order,
+                                                             int64_t n, int max_len, int *__restrict__ flags) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  bool cut = p == 0 || (p % max_len) == 0;
+  if (!cut) {
+    const int a = order[p], b = order[p - 1];
+    const int4 a0 = *(const int4 *)(idx + (int64_t)a * 8), a1 = *(const int4 *)(idx + (int64_t)a * 8 + 4);
+    const int4 b0 = *(const int4 *)(idx + (int64_t)b * 8), b1 = *(const int4 *)(idx + (int64_t)b * 8 + 4);
+    cut = a0.x != b0.x || a0.y != b0.y || a0.z != b0.z || a0.w != b0.w || a1.x != b1.x || a1.y != b1.y || a1.z != b1.z ||
+          a1.w != b1.w;
+  }
+  flags[p] = cut ? 1 : 0;
+}
+
+extern "C" int ts_devox_segments(const int32_t *idx, const int32_t *order, int64_t n, int32_t max_len, int32_t *flags,
+                                 ts_stream_t stream_) {
+  TS_REQUIRE(n >= 0 && max_len > 0, TS_ERR_INVALID_ARGUMENT, "ts_devox_segments: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(idx && order && flags && (((uintptr_t)idx) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devox_segments: null or misaligned pointer");
+  devox_seg_flag_kernel<<<(unsigned)ts_cdiv(n, 256), 256, 0, (hipStream_t)stream_>>>(idx, order, n, max_len, flags);
+  TS_CHECK_LAUNCH("ts_devox_segments");
+  return TS_OK;
+}
+
+__global__ __launch_bounds__(256) void devoxelize_bwd_cells_kernel(const float *__restrict__ gout,
+                                                                   const float *__restrict__ w,
+                                                                   const int *__restrict__ order,
+                                                                   const int *__restrict__ seg_start, int64_t n_seg,
+                                                                   int c, float *__restrict__ part, int64_t go_ld) {
+  const int cq = c >> 2, groups = 256 / cq;
+  const int grp = threadIdx.x / cq, lane = threadIdx.x - grp * cq;
+  if (grp >= groups) return;
+  const int64_t s = (int64_t)blockIdx.x * groups + grp;
+  if (s >= n_seg) return;
+  const int beg = seg_start[s], end = seg_start[s + 1];
+  float4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = beg;
+  for (; p + 2 <= end; p += 2) {                       // two rows in flight
+    const int i0 = order[p], i1 = order[p + 1];
+    const float4 g0 = *(const float4 *)(gout + (int64_t)i0 * go_ld + 4 * lane);
+    const float4 g1 = *(const float4 *)(gout + (int64_t)i1 * go_ld + 4 * lane);
+    const float4 wa0 = *(const float4 *)(w + (int64_t)i0 * 8), wb0 = *(const float4 *)(w + (int64_t)i0 * 8 + 4);
+    const float4 wa1 = *(const float4 *)(w + (int64_t)i1 * 8), wb1 = *(const float4 *)(w + (int64_t)i1 * 8 + 4);
+    const float w0[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w};
+    const float w1[8] = {wa1.x, wa1.y, wa1.z, wa1.w, wb1.x, wb1.y, wb1.z, wb1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[k].x += w0[k] * g0.x; acc[k].y += w0[k] * g0.y; acc[k].z += w0[k] * g0.z; acc[k].w += w0[k] * g0.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[k].x += w1[k] * g1.x; acc[k].y += w1[k] * g1.y; acc[k].z += w1[k] * g1.z; acc[k].w += w1[k] * g1.w;
+    }
+  }
+  for (; p < end; ++p) {
+    const int i0 = order[p];
+    const float4 g0 = *(const float4 *)(gout + (int64_t)i0 * go_ld + 4 * lane);
+    const float4 wa0 = *(const float4 *)(w + (int64_t)i0 * 8), wb0 = *(const float4 *)(w + (int64_t)i0 * 8 + 4);
+    const float w0[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[k].x += w0[k] * g0.x; acc[k].y += w0[k] * g0.y; acc[k].z += w0[k] * g0.z; acc[k].w += w0[k] * g0.w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) *(float4 *)(part + (s * 8 + k) * c + 4 * lane) = acc[k];
+}
+
+// grad_feat [m, c] = adjoint of the trilinear map (idx, weight) [n, 8] applied to grad_out [n, ld] through the plan
+// (order [n], seg_start [n_seg + 1], offsets [m + 1] / entries of ts_devox_csr on the segments' tuples); part = scratch
+// of n_seg * 8 * c floats
+extern "C" int ts_devoxelize_backward_cells_ld(const float *grad_out, int64_t go_ld, const float *weight,
+                                               const int32_t *order, const int32_t *seg_start, int64_t n_seg,
+                                               const int32_t *offsets, const int32_t *entries, int64_t n, int32_t c,
+                                               int64_t m, float *part, float *grad_feat, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && n_seg >= 0 && c > 0 && go_ld >= c && (go_ld & 3) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_cells: bad sizes");
+  TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_cells: C must be a multiple of 4, <= 1024");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(grad_feat && offsets && (n_seg == 0 || (grad_out && weight && order && seg_start && entries && part)),
+             TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_cells: null pointer");
+  TS_REQUIRE(((((uintptr_t)grad_out) | ((uintptr_t)grad_feat) | ((uintptr_t)part) | ((uintptr_t)weight)) & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_cells: rows must be 16-byte aligned");
+  const int groups = 256 / (c >> 2);
+  if (n_seg > 0) {
+    devoxelize_bwd_cells_kernel<<<(unsigned)ts_cdiv(n_seg, groups), 256, 0, stream>>>(grad_out, weight, order, seg_start,
+                                                                                     n_seg, c, part, go_ld);
+    TS_CHECK_LAUNCH("ts_devoxelize_backward_cells/partials");
+  }
+  devoxelize_bwd_csr_kernel<0><<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(part, nullptr, offsets, entries, m, c,
+                                                                                grad_feat, c);
+  TS_CHECK_LAUNCH("ts_devoxelize_backward_cells/gather");
   return TS_OK;
 }

@@ -23,6 +23,14 @@ __all__ = ["MinkUNet"]
 
 import os as _os
 _DEVOX_ATOMIC = _os.environ.get("TASEG_DEVOX_ATOMIC", "0") == "1"
+_DEVOX_CELLS = _os.environ.get("TASEG_DEVOX_CELLS", "1") != "0"     # stride-16 devoxelize backward: cell-reduced two-stage sum
+
+
+def _coarse_devox_plan(idx, w, n_vox):
+    """How the stride-16 devoxelize backward walks its map (~700 contributions per voxel, ~4 voxels per point): by default
+    the cell-reduced two-stage sum (every gradient row read once, backend.devox_cells); TASEG_DEVOX_CELLS=0: the plain
+    gather along the inverse map (every row read once per live corner)."""
+    return B.devox_cells(idx, w, n_vox) if _DEVOX_CELLS else B.devox_csr(idx, w, n_vox)
 
 
 class SyncBatchNorm(spnn.SyncBatchNorm):
@@ -256,7 +264,8 @@ class MinkUNetBackbone(BaseSegmentor):
             tri_idx, tri_w = dict(zip(keys, t_idx)), dict(zip(keys, t_w))
             tri_order = {keys[1]: orders[0]} if _DEVOX_ATOMIC else {}
             for key in (keys if not _DEVOX_ATOMIC else (keys[0], keys[2])):
-                tri_order[key] = B.devox_csr(tri_idx[key], tri_w[key], cmaps[key].shape[0])
+                plan = _coarse_devox_plan if key == keys[1] else B.devox_csr
+                tri_order[key] = plan(tri_idx[key], tri_w[key], cmaps[key].shape[0])
             return dict(coords=coords, point_coords=pc, cmaps=cmaps, kmaps=kmaps, tri_idx=tri_idx, tri_w=tri_w,
                         tri_order=tri_order, **extra)
         with torch.no_grad():
@@ -273,6 +282,8 @@ class MinkUNetBackbone(BaseSegmentor):
                 # every gradient row read once (147 vs 235 us per step, last-bit noise in the stage-4 gradients)
                 if s == 16 and _DEVOX_ATOMIC:
                     tri_order[key] = B.devox_order(tri_idx[key], probe.cmaps[key].shape[0])
+                elif s == 16:
+                    tri_order[key] = _coarse_devox_plan(tri_idx[key], tri_w[key], probe.cmaps[key].shape[0])
                 else:
                     tri_order[key] = B.devox_csr(tri_idx[key], tri_w[key], probe.cmaps[key].shape[0])
         return dict(coords=coords, point_coords=pc, cmaps=probe.cmaps, kmaps=probe.kmaps, tri_idx=tri_idx,

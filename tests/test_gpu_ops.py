@@ -899,3 +899,34 @@ def test_presplit_planes_give_the_same_bits(B, F, ci, co, impl):
     finally:
         B.set_conv_impl(0)
         lib.ts_conv_planes_hint(None, None, 0, 0, 0)
+
+
+@pytest.mark.parametrize("stride,c", [(16, 256), (16, 64), (4, 32)])
+def test_devoxelize_backward_cell_reduced(B, F, stride, c):
+    """backend.devox_cells + ts_devoxelize_backward_cells_ld: the two-stage sum over interpolation cells equals the
+    gather along the inverse map (and the oracle's scatter-add) up to summation order, twice gives the same bits, and
+    reads a column block of a wider gradient matrix in place."""
+    from taseg_amd.data.synthetic import synth_scan
+    pts, _ = synth_scan(3, n_points=60000, n_beams=64, n_az=1000)
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    coords = np.unique(np.concatenate([pc // stride * stride, np.zeros((len(pc), 1), np.int32)], 1), axis=0)
+    pcf = T(np.concatenate([pc.astype(np.float32), np.zeros((len(pc), 1), np.float32)], 1))
+    idx, w = B.trilinear_map(pcf, T(coords), stride)
+    m = len(coords)
+    rs = np.random.RandomState(stride + c)
+    g = T(rs.randn(len(pc), c + 32).astype(np.float32))
+    plan = B.devox_cells(idx, w, m)
+    assert plan[0] == "cells" and int(plan[2][-1]) == len(pc)
+    got = B.devoxelize_backward_from(g, 32, c, idx, w, m, plan)
+    again = B.devoxelize_backward_from(g, 32, c, idx, w, m, plan)
+    assert torch.equal(got, again)
+    ref = B.devoxelize_backward_from(g, 32, c, idx, w, m, B.devox_csr(idx, w, m))
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale
+    want = O.spdevoxelize_backward(g[:, 32:].cpu().numpy(), idx.cpu().numpy(), w.cpu().numpy(), m) \
+        if hasattr(O, "spdevoxelize_backward") else None
+    if want is not None:
+        close(got, want, 2e-5)
+    # the one-matrix form used by _Devoxelize.backward
+    close(B.devoxelize_backward_csr(g[:, 32:].contiguous(), w, plan, m), ref, 2e-5)
