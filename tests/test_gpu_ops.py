@@ -633,6 +633,13 @@ def test_new_entry_points_accept_empty_inputs(B):
     assert fused.shape == (0, 5) and keep.shape == (0,)
     pix, keep = B.project_fov(e4, torch.eye(4, dtype=torch.float64, device=dev)[:3].contiguous(), (10, 10), (8, 8))
     assert pix.shape == (0, 2) and keep.shape == (0,)
+    # cell-reduced devoxelize backward and the weight planes with nothing to do
+    plan = B.devox_cells(idx, w, 10)
+    assert plan[0] == "cells" and plan[2].tolist() == [0]
+    g = B.devoxelize_backward_from(torch.empty((0, 32), device=dev), 0, 32, idx, w, 10, plan)
+    assert g.shape == (10, 32) and float(g.abs().sum()) == 0.0
+    from taseg_amd import _lib as L
+    L.check(L.load().ts_conv_split_planes_batch(None, 0, L.stream()), "ts_conv_split_planes_batch")
 
 
 # --------------------------------------------------------------------------- dense products on the pair-GEMM kernels
