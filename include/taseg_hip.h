@@ -486,6 +486,21 @@ int64_t ts_prof_collect(double *records, int64_t capacity);
  *         as well / never (default: on 128-column tiles). */
 void ts_set_conv_impl(int32_t impl);
 
+/* Lovasz-softmax with classes = 'present' around ONE sort (R/tools/utils/common/lovasz_losses.py:158-227: lovasz_softmax_flat,
+ * lovasz_grad, flatten_probas' ignore handling), forward value and gradient in one pass.
+ *   ts_lovasz_errors  errors[c, p] = |(labels[p] == c) - probas[p, c]| where labels[p] != ignore, else 0 (class-major [C, P])
+ *   caller            errors_sorted, perm = sort(errors, dim 1, descending)            (perm int64, as torch.sort returns it)
+ *   ts_lovasz_grad    loss[0] = mean over the classes present of dot(errors_sorted_c, lovasz_grad(fg_sorted_c));
+ *                     grad_probas[p, c] = d loss / d probas[p, c] (every element written; rows with the ignored label 0)
+ * probas [P, C] float32 row-major, labels [P] int64 (`ignore` = a value no label takes when nothing is ignored),
+ * C <= 64.  ws >= ts_lovasz_workspace_bytes(P, C).  Rows with the ignored label keep their place with zero error and
+ * zero foreground (same value as dropping them, no host read of their number). */
+int ts_lovasz_errors(const float *probas, const int64_t *labels, int64_t ignore, int64_t n_points, int32_t n_classes,
+                     float *errors, ts_stream_t stream);
+size_t ts_lovasz_workspace_bytes(int64_t n_points, int32_t n_classes);
+int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, const int64_t *labels, int64_t ignore, int64_t n_points,
+                   int32_t n_classes, float *loss, float *grad_probas, void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* Pre-split weight planes for the fp32 pair GEMMs (csrc/conv_pairs_s.hip) - an optional accelerator of
  * ts_conv_pair_gemm / ts_conv_block_forward / ts_conv_block_backward, no counterpart in the reference (its
  * convolution_forward_cuda, backend/convolution/convolution_cuda.cu:101-164, multiplies fp32 operands in cuBLAS).

@@ -1,0 +1,218 @@
+// Lovasz-softmax on the device around ONE sort (reference: tools/utils/common/lovasz_losses.py:158-227, the authors'
+// per-class loop with classes = 'present'; taseg_amd/pcseg/loss/lovasz.py states the batched form this follows).
+//
+//   ts_lovasz_errors   err[c, p] = |fg(c, p) - probas[p, c]| for the rows that count (0 otherwise), class-major so that
+//                      the caller's sort runs along the contiguous dimension
+//   (caller)           errors_sorted, perm = sort(err, dim = 1, descending)
+//   ts_lovasz_grad     from the sorted order: foreground prefix sums (tile counts -> scan of the tile totals -> tile-local
+//                      scan), the Lovasz gradient g_i = J_i - J_(i-1) of the Jaccard extension, the per-class dot products
+//                      sum_i errors_sorted_i * g_i, the mean over the classes present, and - in the same pass - the
+//                      gradient w.r.t. the probabilities scattered back through the permutation:
+//                          d loss / d probas[perm_i, c] = sign_i * g_i * present_c / #present,
+//                      sign_i = -1 on foreground, +1 elsewhere, 0 where the error is 0 (torch's sign(0)).
+// The prefix sums are exact small integers in fp32 like the reference's cumsums; the summation order of the dot product
+// is fixed (tile by tile), so the value is run-to-run deterministic.
+#include "common.h"
+
+#define LV_TILE 1024          // elements per workgroup (256 threads x 4)
+
+__global__ __launch_bounds__(256) void lovasz_errors_kernel(const float *__restrict__ probas,
+                                                            const int64_t *__restrict__ labels, int64_t ignore,
+                                                            int64_t P, int C, float *__restrict__ err) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int64_t lab = labels[p];
+  const bool valid = lab != ignore;
+  for (int c = 0; c < C; ++c) {
+    const float pr = probas[p * C + c];
+    const float fg = (valid && lab == c) ? 1.f : 0.f;
+    err[(int64_t)c * P + p] = valid ? fabsf(fg - pr) : 0.f;
+  }
+}
+
+extern "C" int ts_lovasz_errors(const float *probas, const int64_t *labels, int64_t ignore, int64_t n_points,
+                                int32_t n_classes, float *errors, ts_stream_t stream) {
+  TS_REQUIRE(n_points >= 0 && n_classes > 0, TS_ERR_INVALID_ARGUMENT, "ts_lovasz_errors: bad sizes");
+  if (n_points == 0) return TS_OK;
+  TS_REQUIRE(probas && labels && errors, TS_ERR_INVALID_ARGUMENT, "ts_lovasz_errors: null pointer");
+  lovasz_errors_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, (hipStream_t)stream>>>(probas, labels, ignore, n_points,
+                                                                                          n_classes, errors);
+  TS_CHECK_LAUNCH("ts_lovasz_errors");
+  return TS_OK;
+}
+
+__device__ __forceinline__ int lv_fg(const int64_t *__restrict__ labels, int64_t ignore, int64_t src, int c) {
+  const int64_t lab = labels[src];
+  return (lab != ignore && lab == c) ? 1 : 0;
+}
+
+// foreground count of every tile of every class
+__global__ __launch_bounds__(256) void lovasz_tile_count_kernel(const int64_t *__restrict__ perm,
+                                                                const int64_t *__restrict__ labels, int64_t ignore,
+                                                                int64_t P, int tiles, int *__restrict__ tile_fg) {
+  __shared__ int red[4];
+  const int c = blockIdx.y, t = blockIdx.x;
+  const int64_t base = (int64_t)t * LV_TILE + threadIdx.x * 4;
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (base + u < P) cnt += lv_fg(labels, ignore, perm[(int64_t)c * P + base + u], c);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_fg[c * tiles + t] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup: exclusive scan of the tile counts per class, the class totals and the number of classes present
+__global__ __launch_bounds__(256) void lovasz_tile_scan_kernel(int *__restrict__ tile_fg, int C, int tiles,
+                                                               float *__restrict__ gts, float *__restrict__ n_present) {
+  __shared__ int carry;
+  __shared__ int wsum[4];
+  __shared__ int present;
+  if (threadIdx.x == 0) present = 0;
+  for (int c = 0; c < C; ++c) {
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < tiles; t0 += 256) {
+      const int t = t0 + threadIdx.x;
+      const int v = t < tiles ? tile_fg[c * tiles + t] : 0;
+      int inc = v;                                       // inclusive scan over the 256 threads
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(inc, d, 64);
+        if ((threadIdx.x & 63) >= d) inc += up;
+      }
+      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      int before = carry;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
+      if (t < tiles) tile_fg[c * tiles + t] = before + inc - v;      // exclusive prefix
+      __syncthreads();
+      if (threadIdx.x == 255) carry = before + inc;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      gts[c] = (float)carry;
+      if (carry > 0) present += 1;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_present = (float)present;
+}
+
+// tile-local scan + Lovasz gradient + partial dot product + gradient scatter
+__global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restrict__ errors_sorted,
+                                                          const int64_t *__restrict__ perm,
+                                                          const int64_t *__restrict__ labels, int64_t ignore, int64_t P,
+                                                          int C, int tiles, const int *__restrict__ tile_base,
+                                                          const float *__restrict__ gts,
+                                                          const float *__restrict__ n_present,
+                                                          float *__restrict__ tile_loss, float *__restrict__ dprob) {
+  __shared__ int wsum[4];
+  __shared__ float wred[4];
+  const int c = blockIdx.y, t = blockIdx.x;
+  const int64_t i0 = (int64_t)t * LV_TILE + threadIdx.x * 4;
+  int64_t src[4];
+  int fg[4];
+  float es[4];
+  int mine = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool in = i0 + u < P;
+    src[u] = in ? perm[(int64_t)c * P + i0 + u] : 0;
+    fg[u] = in ? lv_fg(labels, ignore, src[u], c) : 0;
+    es[u] = in ? errors_sorted[(int64_t)c * P + i0 + u] : 0.f;
+    mine += fg[u];
+  }
+  int inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc, d, 64);
+    if ((threadIdx.x & 63) >= d) inc += up;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  int before = tile_base[c * tiles + t];
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
+  int cum = before + inc - mine;                          // foreground in front of this thread's first element
+  const float g = gts[c];
+  const float np = *n_present;
+  const float scale = (g > 0.f && np > 0.f) ? 1.f / np : 0.f;     // present_c / #present
+  float part = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (i0 + u < P) {
+      const float rank = (float)(i0 + u + 1);
+      const float cum_prev = (float)cum;
+      cum += fg[u];
+      const float cum_i = (float)cum;
+      // jaccard_i = 1 - (gts - cum_i) / (gts + rank - cum_i); jaccard_(i-1) likewise with rank - 1 (0 in front of the row)
+      const float j_i = 1.f - (g - cum_i) / (g + (rank - cum_i));
+      const float j_p = (i0 + u == 0) ? 0.f : 1.f - (g - cum_prev) / (g + ((rank - 1.f) - cum_prev));
+      const float gr = j_i - j_p;
+      part += es[u] * gr;
+      const float sign = es[u] > 0.f ? (fg[u] ? -1.f : 1.f) : 0.f;
+      dprob[src[u] * C + c] = sign * gr * scale;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_loss[c * tiles + t] = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+}
+
+// loss = sum over the classes present of (sum of their tile partials, in tile order) / #present
+__global__ __launch_bounds__(64) void lovasz_finish_kernel(const float *__restrict__ tile_loss, const float *__restrict__ gts,
+                                                           const float *__restrict__ n_present, int C, int tiles,
+                                                           float *__restrict__ loss) {
+  const int c = threadIdx.x;
+  float v = 0.f;
+  if (c < C && gts[c] > 0.f)
+    for (int t = 0; t < tiles; ++t) v += tile_loss[c * tiles + t];
+  __shared__ float red[64];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += red[k];
+    const float np = *n_present;
+    *loss = np > 0.f ? s / np : 0.f;
+  }
+}
+
+extern "C" size_t ts_lovasz_workspace_bytes(int64_t n_points, int32_t n_classes) {
+  const size_t tiles = (size_t)ts_cdiv(std::max<int64_t>(n_points, 1), LV_TILE);
+  return ts_align_up(tiles * n_classes * 4, 256) * 2 + ts_align_up((size_t)n_classes * 4 + 4, 256);
+}
+
+// errors_sorted / perm [C, P] = sort(errors, descending) of ts_lovasz_errors' output; loss [1]; grad_probas [P, C]
+// (every element written).  ws >= ts_lovasz_workspace_bytes.
+extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, const int64_t *labels, int64_t ignore,
+                              int64_t n_points, int32_t n_classes, float *loss, float *grad_probas, void *ws,
+                              size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n_points > 0 && n_classes > 0 && n_classes <= 64, TS_ERR_INVALID_ARGUMENT,
+             "ts_lovasz_grad: need points and 1 .. 64 classes");
+  TS_REQUIRE(errors_sorted && perm && labels && loss && grad_probas && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_lovasz_grad: null pointer");
+  TS_REQUIRE(ws_bytes >= ts_lovasz_workspace_bytes(n_points, n_classes), TS_ERR_INVALID_ARGUMENT,
+             "ts_lovasz_grad: workspace too small");
+  const int tiles = (int)ts_cdiv(n_points, LV_TILE);
+  char *p = (char *)ws;
+  int *tile_fg = (int *)p;
+  p += ts_align_up((size_t)tiles * n_classes * 4, 256);
+  float *tile_loss = (float *)p;
+  p += ts_align_up((size_t)tiles * n_classes * 4, 256);
+  float *gts = (float *)p;
+  float *n_present = gts + n_classes;
+  dim3 grid((unsigned)tiles, (unsigned)n_classes);
+  lovasz_tile_count_kernel<<<grid, 256, 0, stream>>>(perm, labels, ignore, n_points, tiles, tile_fg);
+  lovasz_tile_scan_kernel<<<1, 256, 0, stream>>>(tile_fg, n_classes, tiles, gts, n_present);
+  lovasz_grad_kernel<<<grid, 256, 0, stream>>>(errors_sorted, perm, labels, ignore, n_points, n_classes, tiles, tile_fg,
+                                               gts, n_present, tile_loss, grad_probas);
+  lovasz_finish_kernel<<<1, 64, 0, stream>>>(tile_loss, gts, n_present, n_classes, tiles, loss);
+  TS_CHECK_LAUNCH("ts_lovasz_grad");
+  return TS_OK;
+}

@@ -5,9 +5,45 @@ Same value as the reference's per-class loop with classes='present', computed fo
 once: ONE batched descending sort of the [P, C] error matrix instead of C sorts, and no
 `fg.sum() == 0` host synchronisation per class.
 """
+import os
+
 import torch
 
 __all__ = ["lovasz_softmax", "lovasz_softmax_flat"]
+
+_FUSED = os.environ.get("TASEG_FUSED_LOVASZ", "1") != "0"
+_NO_IGNORE = -(1 << 62)          # a label value nothing takes
+
+
+class _LovaszPresent(torch.autograd.Function):
+    """classes = 'present' on the HIP kernels (csrc/loss.hip): the error matrix in one launch, torch's sort, then the
+    prefix sums, the Lovasz gradient, the per-class dot products, the mean over the classes present AND the gradient
+    w.r.t. the probabilities in four launches - the tensor-op form below takes ~40 launches forward and backward."""
+
+    @staticmethod
+    def forward(ctx, probas, labels, ignore):
+        from ... import _lib as L
+        lib = L.load()
+        p, c = probas.shape
+        prob = probas.contiguous().float()
+        lab = labels.contiguous().long()
+        ign = _NO_IGNORE if ignore is None else int(ignore)
+        err = torch.empty((c, p), dtype=torch.float32, device=prob.device)
+        L.check(lib.ts_lovasz_errors(L.ptr(prob), L.ptr(lab), ign, p, c, L.ptr(err), L.stream()), "ts_lovasz_errors")
+        es, perm = torch.sort(err, dim=1, descending=True)
+        loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+        dprob = torch.empty((p, c), dtype=torch.float32, device=prob.device)
+        ws = L.workspace(lib.ts_lovasz_workspace_bytes(p, c), prob.device)
+        L.check(lib.ts_lovasz_grad(L.ptr(es), L.ptr(perm), L.ptr(lab), ign, p, c, L.ptr(loss), L.ptr(dprob), L.ptr(ws),
+                                   ws.numel(), L.stream()), "ts_lovasz_grad")
+        ctx.save_for_backward(dprob)
+        ctx.in_dtype = probas.dtype
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dprob,) = ctx.saved_tensors
+        return (dprob * grad_out).to(ctx.in_dtype), None, None
 
 
 def _cumsum_rows(x: torch.Tensor, block: int = 2048) -> torch.Tensor:
@@ -79,5 +115,8 @@ def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=No
     if probas.dim() != 2:
         raise ValueError("lovasz_softmax here expects point-wise [P, C] probabilities")
     labels = labels.view(-1)
+    if (_FUSED and classes == "present" and probas.is_cuda and probas.shape[0] > 0 and probas.shape[1] <= 64
+            and probas.dtype in (torch.float32, torch.float16)):
+        return _LovaszPresent.apply(probas, labels, ignore)
     valid = (labels != ignore) if ignore is not None else None
     return lovasz_softmax_flat(probas, labels, classes=classes, valid=valid)

@@ -937,3 +937,39 @@ def test_devoxelize_backward_cell_reduced(B, F, stride, c):
         close(got, want, 2e-5)
     # the one-matrix form used by _Devoxelize.backward
     close(B.devoxelize_backward_csr(g[:, 32:].contiguous(), w, plan, m), ref, 2e-5)
+
+
+@pytest.mark.parametrize("p,c,ignore", [(70001, 20, 0), (4099, 17, 0), (1000, 20, None), (50000, 5, 3)])
+def test_lovasz_kernels_match_the_tensor_form_and_the_oracle(p, c, ignore):
+    """csrc/loss.hip (ts_lovasz_errors -> sort -> ts_lovasz_grad) against taseg_amd.pcseg.loss.lovasz.lovasz_softmax_flat
+    (torch ops) and the oracle's per-class loop (the reference's lovasz_losses.py restated): value and gradient, classes that
+    do not occur, ignored rows, a tile boundary inside the rows."""
+    from oracle import model as OM
+    from taseg_amd.pcseg.loss import lovasz as LV
+    rs = np.random.RandomState(p + c)
+    logits = torch.from_numpy(rs.randn(p, c).astype(np.float32) * 2).cuda()
+    labels = torch.from_numpy(rs.randint(0, c, size=p)).cuda()
+    labels[labels == c - 1] = 1                                   # the last class never occurs
+    labels[:17] = 0 if ignore is None else ignore
+    a = logits.clone().requires_grad_()
+    got = LV.lovasz_softmax(a.softmax(1), labels, ignore=ignore)
+    got.backward()
+    b = logits.clone().requires_grad_()
+    valid = (labels != ignore) if ignore is not None else None
+    want = LV.lovasz_softmax_flat(b.softmax(1), labels, valid=valid)
+    want.backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    assert float((a.grad - b.grad).abs().max()) <= 1e-7 + 1e-4 * float(b.grad.abs().max())
+    ref = OM.lovasz_softmax_ref(logits.cpu().softmax(1), labels.cpu(), ignore=-1 if ignore is None else ignore)
+    assert abs(float(got) - float(ref)) <= 5e-6 * max(1.0, abs(float(ref)))
+    # run-to-run identical
+    a2 = logits.clone().requires_grad_()
+    again = LV.lovasz_softmax(a2.softmax(1), labels, ignore=ignore)
+    again.backward()
+    assert float(again) == float(got) and torch.equal(a2.grad, a.grad)
+    # nothing but ignored rows: zero loss, zero gradient
+    if ignore is not None:
+        z = logits.clone().requires_grad_()
+        zero = LV.lovasz_softmax(z.softmax(1), torch.full_like(labels, ignore), ignore=ignore)
+        zero.backward()
+        assert float(zero) == 0.0 and float(z.grad.abs().max()) == 0.0
