@@ -501,6 +501,23 @@ size_t ts_lovasz_workspace_bytes(int64_t n_points, int32_t n_classes);
 int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, const int64_t *labels, int64_t ignore, int64_t n_points,
                    int32_t n_classes, float *loss, float *grad_probas, void *ws, size_t ws_bytes, ts_stream_t stream);
 
+/* The segmentors' training loss, CE + Lovasz (R/pcseg/loss/__init__.py:40-44, 118-133: nn.CrossEntropyLoss(ignore_index,
+ * label_smoothing) + lovasz_softmax(softmax(logits), ignore)), around the one sort:
+ *   ts_softmax_ce_forward  one pass over logits [P, C] (C <= 32): probas [P, C], the Lovasz error matrix [C, P] (what
+ *                          ts_lovasz_errors writes) and partials [ceil(P / 256), 3] doubles (sum -logp[y], sum -sum_c logp_c, rows)
+ *   ts_ce_lovasz_finish    out4 = { w_ce ce + w_lov lovasz, ce, lovasz, rows that count }; ce = (1 - eps) nll / n + eps smooth / (n C)
+ *                          (torch's label-smoothed mean over the rows whose label is not ignored); lovasz = ts_lovasz_grad's
+ *                          loss scalar (device pointer) or NULL
+ *   ts_ce_lovasz_backward  grad_logits [P, C] from probas, labels, grad_probas (= ts_lovasz_grad's, or NULL) and the
+ *                          upstream gradient scalar (device pointer) */
+int ts_softmax_ce_forward(const float *logits, const int64_t *labels, int64_t ignore, int64_t n_points, int32_t n_classes,
+                          float *probas, float *errors, double *partials, ts_stream_t stream);
+int ts_ce_lovasz_finish(const double *partials, int64_t n_points, int32_t n_classes, float smoothing, float w_ce, float w_lov,
+                        const float *lovasz, float *out4, ts_stream_t stream);
+int ts_ce_lovasz_backward(const float *probas, const int64_t *labels, int64_t ignore, const float *grad_probas,
+                          const float *out4, const float *grad_out, int64_t n_points, int32_t n_classes, float smoothing,
+                          float w_ce, float w_lov, float *grad_logits, ts_stream_t stream);
+
 /* Pre-split weight planes for the fp32 pair GEMMs (csrc/conv_pairs_s.hip) - an optional accelerator of
  * ts_conv_pair_gemm / ts_conv_block_forward / ts_conv_block_backward, no counterpart in the reference (its
  * convolution_forward_cuda, backend/convolution/convolution_cuda.cu:101-164, multiplies fp32 operands in cuBLAS).

@@ -216,3 +216,170 @@ extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, c
   TS_CHECK_LAUNCH("ts_lovasz_grad");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Cross entropy (ignore_index, label smoothing, reduction 'mean': torch/nn/functional.py cross_entropy as the reference's
+// nn.CrossEntropyLoss uses it, pcseg/loss/__init__.py:40-44) fused with the softmax the Lovasz term needs:
+//   ts_softmax_ce_forward   one pass over the logits: probas [P, C], the Lovasz error matrix [C, P] (ts_lovasz_errors'
+//                           output) and, per workgroup, the partial sums (sum_valid -logp[y], sum_valid -sum_c logp_c, #valid)
+//   ts_ce_lovasz_finish     loss = w_ce ((1 - eps) nll / n + eps smooth / (n C)) + w_lov lovasz       (partials in order)
+//   ts_ce_lovasz_backward   d loss / d logits from the saved probas, the labels and d lovasz / d probas:
+//                           go [ w_ce valid / n ((1 - eps)(p - onehot) + eps (p - 1 / C)) + w_lov p (dp - sum_c p_c dp_c) ]
+// C <= 32; one thread per row.
+#define CE_MAXC 32
+
+__global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float *__restrict__ logits,
+                                                             const int64_t *__restrict__ labels, int64_t ignore,
+                                                             int64_t P, int C, float *__restrict__ probas,
+                                                             float *__restrict__ err, double *__restrict__ part) {
+  __shared__ double red[3][4];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double nll = 0.0, smooth = 0.0, cnt = 0.0;
+  if (p < P) {
+    float v[CE_MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c)
+      if (c < C) {
+        v[c] = logits[p * C + c];
+        mx = fmaxf(mx, v[c]);
+      }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c)
+      if (c < C) {
+        v[c] = expf(v[c] - mx);
+        se += v[c];
+      }
+    const float lse = logf(se), inv = 1.f / se;
+    const int64_t lab = labels[p];
+    const bool valid = lab != ignore;
+    float sum_logp = 0.f, picked = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c)
+      if (c < C) {
+        const float lp = (logits[p * C + c] - mx) - lse;
+        sum_logp += lp;
+        if (lab == c) picked = lp;
+        const float pr = v[c] * inv;
+        probas[p * C + c] = pr;
+        const float fg = (valid && lab == c) ? 1.f : 0.f;
+        err[(int64_t)c * P + p] = valid ? fabsf(fg - pr) : 0.f;
+      }
+    if (valid) {
+      nll = -(double)picked;
+      smooth = -(double)sum_logp;
+      cnt = 1.0;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    nll += __shfl_down(nll, d, 64);
+    smooth += __shfl_down(smooth, d, 64);
+    cnt += __shfl_down(cnt, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = nll;
+    red[1][threadIdx.x >> 6] = smooth;
+    red[2][threadIdx.x >> 6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) part[(int64_t)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
+                                                                      (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+extern "C" int ts_softmax_ce_forward(const float *logits, const int64_t *labels, int64_t ignore, int64_t n_points,
+                                     int32_t n_classes, float *probas, float *errors, double *partials,
+                                     ts_stream_t stream) {
+  TS_REQUIRE(n_points > 0 && n_classes > 0 && n_classes <= CE_MAXC, TS_ERR_INVALID_ARGUMENT,
+             "ts_softmax_ce_forward: need points and 1 .. 32 classes");
+  TS_REQUIRE(logits && labels && probas && errors && partials, TS_ERR_INVALID_ARGUMENT, "ts_softmax_ce_forward: null pointer");
+  softmax_ce_fwd_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, (hipStream_t)stream>>>(logits, labels, ignore, n_points,
+                                                                                           n_classes, probas, errors, partials);
+  TS_CHECK_LAUNCH("ts_softmax_ce_forward");
+  return TS_OK;
+}
+
+// out[0] = total loss, out[1] = cross entropy, out[2] = lovasz, out[3] = number of rows that count
+__global__ __launch_bounds__(256) void ce_lovasz_finish_kernel(const double *__restrict__ part, int64_t blocks, int C,
+                                                               float smoothing, float w_ce, float w_lov,
+                                                               const float *__restrict__ lovasz, float *__restrict__ out) {
+  __shared__ double red[3][256];
+  double a = 0.0, b = 0.0, n = 0.0;
+  for (int64_t i = threadIdx.x; i < blocks; i += 256) {      // fixed assignment, fixed order
+    a += part[i * 3];
+    b += part[i * 3 + 1];
+    n += part[i * 3 + 2];
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  red[2][threadIdx.x] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double nll = 0.0, sm = 0.0, cnt = 0.0;
+    for (int k = 0; k < 256; ++k) {
+      nll += red[0][k];
+      sm += red[1][k];
+      cnt += red[2][k];
+    }
+    // no row counts: 0 / 0 = NaN, as torch's mean over nothing
+    const double ce = (1.0 - (double)smoothing) * (nll / cnt) + (double)smoothing * (sm / (cnt * C));
+    const float lov = lovasz ? *lovasz : 0.f;
+    out[0] = w_ce * (float)ce + w_lov * lov;
+    out[1] = (float)ce;
+    out[2] = lov;
+    out[3] = (float)cnt;
+  }
+}
+
+extern "C" int ts_ce_lovasz_finish(const double *partials, int64_t n_points, int32_t n_classes, float smoothing, float w_ce,
+                                   float w_lov, const float *lovasz, float *out4, ts_stream_t stream) {
+  TS_REQUIRE(n_points > 0 && n_classes > 0 && partials && out4, TS_ERR_INVALID_ARGUMENT, "ts_ce_lovasz_finish: bad arguments");
+  ce_lovasz_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials, ts_cdiv(n_points, 256), n_classes, smoothing, w_ce,
+                                                              w_lov, lovasz, out4);
+  TS_CHECK_LAUNCH("ts_ce_lovasz_finish");
+  return TS_OK;
+}
+
+__global__ __launch_bounds__(256) void ce_lovasz_bwd_kernel(const float *__restrict__ probas,
+                                                            const int64_t *__restrict__ labels, int64_t ignore,
+                                                            const float *__restrict__ dprob, const float *__restrict__ out4,
+                                                            const float *__restrict__ grad_out, int64_t P, int C,
+                                                            float smoothing, float w_ce, float w_lov,
+                                                            float *__restrict__ dlogits) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const float go = *grad_out;
+  const float n = out4[3];
+  const int64_t lab = labels[p];
+  const float kce = (lab != ignore) ? go * w_ce / n : 0.f;
+  float pr[CE_MAXC], dp[CE_MAXC];
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < CE_MAXC; ++c)
+    if (c < C) {
+      pr[c] = probas[p * C + c];
+      dp[c] = dprob ? dprob[p * C + c] : 0.f;
+      dot += pr[c] * dp[c];
+    }
+  const float klov = go * w_lov, invc = 1.f / (float)C;
+#pragma unroll
+  for (int c = 0; c < CE_MAXC; ++c)
+    if (c < C) {
+      const float onehot = lab == c ? 1.f : 0.f;
+      const float ce = (1.f - smoothing) * (pr[c] - onehot) + smoothing * (pr[c] - invc);
+      dlogits[p * C + c] = kce * ce + klov * pr[c] * (dp[c] - dot);
+    }
+}
+
+extern "C" int ts_ce_lovasz_backward(const float *probas, const int64_t *labels, int64_t ignore, const float *grad_probas,
+                                     const float *out4, const float *grad_out, int64_t n_points, int32_t n_classes,
+                                     float smoothing, float w_ce, float w_lov, float *grad_logits, ts_stream_t stream) {
+  TS_REQUIRE(n_points > 0 && n_classes > 0 && n_classes <= CE_MAXC, TS_ERR_INVALID_ARGUMENT,
+             "ts_ce_lovasz_backward: need points and 1 .. 32 classes");
+  TS_REQUIRE(probas && labels && out4 && grad_out && grad_logits, TS_ERR_INVALID_ARGUMENT, "ts_ce_lovasz_backward: null pointer");
+  ce_lovasz_bwd_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, (hipStream_t)stream>>>(
+      probas, labels, ignore, grad_probas, out4, grad_out, n_points, n_classes, smoothing, w_ce, w_lov, grad_logits);
+  TS_CHECK_LAUNCH("ts_ce_lovasz_backward");
+  return TS_OK;
+}

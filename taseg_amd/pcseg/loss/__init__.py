@@ -4,11 +4,61 @@ TASeg's configs use CE (label smoothing, ignore 0) + Lovasz-softmax
 (minkunet.py:344-348); those two are implemented.  The optional losses of the reference
 (Dice, ELL, WCE, Focal, EQLv2, GroupSoftmax) are dense torch code outside the path and raise.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import CrossEntropyLoss
 
-from .lovasz import lovasz_softmax
+from .lovasz import _NO_IGNORE, lovasz_softmax
+
+_FUSED = os.environ.get("TASEG_FUSED_LOSS", "1") != "0"
+
+
+class _CeLovasz(torch.autograd.Function):
+    """w_ce * CrossEntropy(ignore_index, label_smoothing) + w_lov * lovasz_softmax(softmax(logits), ignore) on the HIP
+    kernels of csrc/loss.hip: one pass over the logits (softmax, CE partial sums, Lovasz error matrix), torch's sort,
+    ts_lovasz_grad, a one-workgroup finish; the backward pass is ONE kernel from the saved probabilities.  The tensor-op
+    form (log_softmax, gathers, reductions, softmax and their autograd nodes) takes ~35 launches for the same numbers."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore, smoothing, w_ce, w_lov):
+        from ... import _lib as L
+        lib = L.load()
+        p, c = logits.shape
+        x = logits.contiguous().float()
+        lab = target.contiguous().long()
+        dev = x.device
+        ign = _NO_IGNORE if ignore is None else int(ignore)
+        probas = torch.empty((p, c), dtype=torch.float32, device=dev)
+        err = torch.empty((c, p), dtype=torch.float32, device=dev)
+        partials = torch.empty(((p + 255) // 256, 3), dtype=torch.float64, device=dev)
+        L.check(lib.ts_softmax_ce_forward(L.ptr(x), L.ptr(lab), ign, p, c, L.ptr(probas), L.ptr(err), L.ptr(partials),
+                                          L.stream()), "ts_softmax_ce_forward")
+        es, perm = torch.sort(err, dim=1, descending=True)
+        lov = torch.empty(1, dtype=torch.float32, device=dev)
+        dprob = torch.empty((p, c), dtype=torch.float32, device=dev)
+        ws = L.workspace(lib.ts_lovasz_workspace_bytes(p, c), dev)
+        L.check(lib.ts_lovasz_grad(L.ptr(es), L.ptr(perm), L.ptr(lab), ign, p, c, L.ptr(lov), L.ptr(dprob), L.ptr(ws),
+                                   ws.numel(), L.stream()), "ts_lovasz_grad")
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        L.check(lib.ts_ce_lovasz_finish(L.ptr(partials), p, c, float(smoothing), float(w_ce), float(w_lov), L.ptr(lov),
+                                        L.ptr(out4), L.stream()), "ts_ce_lovasz_finish")
+        ctx.save_for_backward(probas, lab, dprob, out4)
+        ctx.args = (ign, float(smoothing), float(w_ce), float(w_lov), logits.dtype)
+        return out4[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from ... import _lib as L
+        probas, lab, dprob, out4 = ctx.saved_tensors
+        ign, smoothing, w_ce, w_lov, dtype = ctx.args
+        p, c = probas.shape
+        go = grad_out.contiguous().float().reshape(1)
+        dlogits = torch.empty_like(probas)
+        L.check(L.load().ts_ce_lovasz_backward(L.ptr(probas), L.ptr(lab), ign, L.ptr(dprob), L.ptr(out4), L.ptr(go), p, c,
+                                               smoothing, w_ce, w_lov, L.ptr(dlogits), L.stream()), "ts_ce_lovasz_backward")
+        return dlogits.to(dtype), None, None, None, None, None
 
 __all__ = ["Losses", "lovasz_softmax"]
 
@@ -52,6 +102,12 @@ class Losses(nn.Module):
         self.lov_loss = lovasz_softmax
 
     def forward(self, input, target, xyz=None, offset=None):
+        if (_FUSED and sorted(self.loss_types) == ["CELoss", "LovLoss"] and self.class_weight is None and input.dim() == 2
+                and input.is_cuda and 0 < input.shape[1] <= 32 and input.shape[0] > 0
+                and input.dtype in (torch.float32, torch.float16) and target.dim() == 1):
+            return _CeLovasz.apply(input, target, self.ignore_index, self.label_smoothing,
+                                   self.loss_weights[self.loss_types.index("CELoss")],
+                                   self.loss_weights[self.loss_types.index("LovLoss")])
         total = 0
         if "CELoss" in self.loss_types:
             if self.class_weight is None and input.dim() == 2:

@@ -973,3 +973,33 @@ def test_lovasz_kernels_match_the_tensor_form_and_the_oracle(p, c, ignore):
         zero = LV.lovasz_softmax(z.softmax(1), torch.full_like(labels, ignore), ignore=ignore)
         zero.backward()
         assert float(zero) == 0.0 and float(z.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("p,c,smoothing,half", [(70001, 20, 0.0, False), (4099, 17, 0.1, False), (30000, 20, 0.05, True)])
+def test_fused_ce_lovasz_loss_matches_the_tensor_form_and_the_oracle(monkeypatch, p, c, smoothing, half):
+    """pcseg.loss.Losses on the csrc/loss.hip kernels (softmax + CE + Lovasz errors in one pass, one backward kernel) against
+    the same module on tensor ops and against the oracle's CE + Lovasz: value and gradient w.r.t. the logits."""
+    from oracle import model as OM
+    import taseg_amd.pcseg.loss as LS
+    rs = np.random.RandomState(p)
+    logits = torch.from_numpy(rs.randn(p, c).astype(np.float32) * 2).cuda()
+    if half:
+        logits = logits.half()
+    labels = torch.from_numpy(rs.randint(0, c, size=p)).cuda()
+    labels[labels == c - 1] = 1
+    crit = LS.Losses(["CELoss", "LovLoss"], [1.0, 0.7], ignore_index=0, label_smoothing=smoothing)
+    a = logits.clone().requires_grad_()
+    got = crit(a, labels)
+    (got * 3.0).backward()
+    monkeypatch.setattr(LS, "_FUSED", False)
+    b = logits.float().clone().requires_grad_()      # half logits: the kernels compute in fp32 like torch does under autocast
+    want = crit(b, labels)
+    (want * 3.0).backward()
+    tol = 2e-3 if half else 3e-6
+    assert abs(float(got) - float(want)) <= tol * max(1.0, abs(float(want)))
+    assert float((a.grad.float() - b.grad.float()).abs().max()) <= (2e-3 if half else 1e-4) * float(b.grad.float().abs().max()) + 1e-9
+    if not half:
+        ref = OM.loss_ce_lovasz(logits.cpu(), labels.cpu(), label_smoothing=smoothing)      # weights 1 / 1
+        monkeypatch.setattr(LS, "_FUSED", True)
+        one = LS.Losses(["CELoss", "LovLoss"], [1.0, 1.0], ignore_index=0, label_smoothing=smoothing)(logits, labels)
+        assert abs(float(one) - float(ref)) <= 5e-6 * max(1.0, abs(float(ref)))
