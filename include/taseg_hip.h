@@ -539,6 +539,13 @@ int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out,
 int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out);
 
+/* One-shot and per thread, like ts_conv_planes_hint: the NEXT ts_conv_block_backward of this thread adds `addend`
+ * ([n_dgrad_rows, c_in] in the storage type of grad_feat, 16-byte aligned) into its grad_feat store,
+ * grad_feat = (input gradient of the convolution) + addend, one rounding like a separate sum of the two.  For blocks whose
+ * input also feeds a shortcut (minkunet.py:117-129 ResidualBlock): the autograd node hands its input through as a second
+ * output, receives the shortcut's gradient with its own and lets it land here instead of in an add launch. */
+void ts_conv_block_addend_hint(const void *addend);
+
 /* Diagnostic: while `stamps` (device memory, 16 x uint64 per workgroup, `capacity` workgroups) is set, the 96- / 128-
  * column fp32 pair GEMMs run an instrumented instantiation whose workgroups leave shader-clock stamps of their phases
  * (tools/phase_probe.py); NULL switches back to the product kernels. */

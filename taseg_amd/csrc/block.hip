@@ -118,6 +118,11 @@ extern "C" int64_t ts_prof_collect(double *records, int64_t capacity) {
 
 // The caller's one-shot hint of pre-split weight planes (ts_conv_planes_hint) belongs to the block call as a whole: taken
 // at entry, handed to the one fp32 pair GEMM of the call, gone when the call returns - whichever path it took.
+// The gradient that reaches the block's input along another path (the shortcut of a residual block, when the block passes
+// its input through - see ts_conv_block_addend_hint): [n_dgrad_rows, c_in] in grad_feat's storage type, one-shot, per thread.
+thread_local const void *g_ts_block_addend = nullptr;
+extern "C" void ts_conv_block_addend_hint(const void *addend) { g_ts_block_addend = addend; }
+
 struct PlanesHintScope {
   TsPlanesHint h;
   PlanesHintScope() : h(g_ts_planes_hint) { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
@@ -210,8 +215,12 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                       float *grad_bn_weight, float *grad_bn_bias, void *ws, size_t ws_bytes,
                                       ts_stream_t stream) {
   PlanesHintScope planes_hint;
+  const void *addend = g_ts_block_addend;       // one-shot (ts_conv_block_addend_hint): added into grad_feat's store
+  g_ts_block_addend = nullptr;
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_backward: bad sizes");
+  TS_REQUIRE(!addend || (grad_feat && (((uintptr_t)addend) & 15) == 0), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_backward: an addend needs grad_feat and 16-byte alignment");
   TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_backward: workspace too small");
   const size_t es = half ? 2 : 4;
@@ -276,10 +285,10 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
       ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, side_bytes);
       if (half)
         TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, ride ? &job : nullptr,
-                                         stream));
+                                         addend, stream));
       else
         TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, (float *)grad_feat,
-                                     ride ? &job : nullptr, stream));
+                                     ride ? &job : nullptr, (const float *)addend, stream));
     }
   }
   if (det && !ride) TS_TRY(ts_wgrad_reduce(job, stream));

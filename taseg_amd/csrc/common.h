@@ -178,10 +178,13 @@ extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv
 // Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can form the ordered sum
 // of the weight-gradient partials on the side (saves the reduce launch), and the atomic form of the weight gradient
 // can be told that its output is already zero.
+// addend (optional, [n_rows, c] like out): out = (sum_k z rows) + addend - the gradient that reaches the block's input
+// along its other path (a residual connection) lands in the same store instead of a separate add launch
 int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                          float *out, const TsWgradReduce *side, ts_stream_t stream);
+                          float *out, const TsWgradReduce *side, const float *addend, ts_stream_t stream);
 int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                              void *out, const TsWgradReduce *side, ts_stream_t stream);
+                              void *out, const TsWgradReduce *side, const void *addend, ts_stream_t stream);
+extern thread_local const void *g_ts_block_addend;     // one-shot: set by ts_conv_block_addend_hint, taken by ts_conv_block_backward
 int ts_conv_wgrad_ex(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
                      const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
                      int32_t already_zero, ts_stream_t stream);

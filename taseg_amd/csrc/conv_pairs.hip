@@ -756,7 +756,7 @@ template <int VEC, int KT>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ Z, int C,
                                                          const int *__restrict__ pos, int K, int64_t n,
                                                          int64_t n_pairs, float *__restrict__ out,
-                                                         TsWgradReduce side) {
+                                                         TsWgradReduce side, const float *__restrict__ addend) {
   const int cv = C / VEC;
   const int64_t total = n * cv;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -803,6 +803,17 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
         }
       }
     }
+    if (addend) {          // one add per element after the sum over the offsets: the same bits as a separate a + b
+      if (VEC == 4) {
+        const float4 a = *(const float4 *)(addend + j * C + c);
+        acc[0] += a.x;
+        acc[1 % VEC] += a.y;
+        acc[2 % VEC] += a.z;
+        acc[3 % VEC] += a.w;
+      } else {
+        acc[0] += addend[j * C + c];
+      }
+    }
     if (VEC == 4) {
       *(float4 *)(out + j * C + c) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
     } else {
@@ -813,11 +824,11 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
 
 extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                   int64_t n_pairs, float *out, ts_stream_t stream_) {
-  return ts_conv_gather_sum_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, stream_);
+  return ts_conv_gather_sum_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, nullptr, stream_);
 }
 
 int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                          float *out, const TsWgradReduce *side_job, ts_stream_t stream_) {
+                          float *out, const TsWgradReduce *side_job, const float *addend, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TsWgradReduce side = {};
   if (side_job) side = *side_job;
@@ -831,14 +842,14 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
   if (vec) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 4), 256), 1 << 20);
     if (K == 27)
-      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
+      gather_sum_kernel<4, 27><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend);
     else if (K == 8)
-      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
+      gather_sum_kernel<4, 8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend);
     else
-      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
+      gather_sum_kernel<4, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend);
   } else {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * c, 256), 1 << 20);
-    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side);
+    gather_sum_kernel<1, 0><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend);
   }
   TS_CHECK_LAUNCH("conv_gather_sum");
   return TS_OK;

@@ -264,7 +264,8 @@ static int pair_gemm_f16_any(const void *feat, int64_t n_rows, int32_t c_red, co
 template <int KT>
 __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__restrict__ Z, int C,
                                                            const int *__restrict__ pos, int K, int64_t n_rows,
-                                                           _Float16 *__restrict__ out, TsWgradReduce side) {
+                                                           _Float16 *__restrict__ out, TsWgradReduce side,
+                                                           const _Float16 *__restrict__ addend) {
   const int c8n = C >> 3;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = n_rows * c8n, step = (int64_t)gridDim.x * blockDim.x;
@@ -296,6 +297,11 @@ __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__res
         }
       }
     }
+    if (addend) {
+      const h8 a = *(const h8 *)(addend + j * C + c8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += (float)a[i];
+    }
     h8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (_Float16)acc[i];
@@ -305,11 +311,11 @@ __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__res
 
 extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                       int64_t n_pairs, void *out, ts_stream_t stream_) {
-  return ts_conv_gather_sum_f16_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, stream_);
+  return ts_conv_gather_sum_f16_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, nullptr, stream_);
 }
 
 int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
-                              void *out, const TsWgradReduce *side_job, ts_stream_t stream_) {
+                              void *out, const TsWgradReduce *side_job, const void *addend, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TsWgradReduce side = {};
   if (side_job) side = *side_job;
@@ -325,11 +331,11 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
   const int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 8), 256), 1 << 20);
   const _Float16 *zz = (const _Float16 *)z;
   if (K == 27)
-    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side);
+    gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side, (const _Float16 *)addend);
   else if (K == 8)
-    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side);
+    gather_sum_h_kernel<8><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side, (const _Float16 *)addend);
   else
-    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side);
+    gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side, (const _Float16 *)addend);
   TS_CHECK_LAUNCH("ts_conv_gather_sum_f16");
   return TS_OK;
 }

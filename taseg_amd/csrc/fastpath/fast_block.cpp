@@ -22,6 +22,7 @@ struct Api {
   decltype(&ts_conv_block_backward) backward = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
   decltype(&ts_conv_planes_hint) planes_hint = nullptr;
+  decltype(&ts_conv_block_addend_hint) addend_hint = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
   decltype(&ts_build_kmap_workspace_bytes) build_kmap_ws = nullptr;
@@ -57,14 +58,14 @@ inline void *optr(const c10::optional<at::Tensor> &t) { return (t.has_value() &&
 
 class ConvBlock : public torch::autograd::Function<ConvBlock> {
  public:
-  static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &feats, const at::Tensor &weight,
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, const at::Tensor &feats, const at::Tensor &weight,
                             const c10::optional<at::Tensor> &residual, const at::Tensor &bn_weight,
                             const at::Tensor &bn_bias, const at::Tensor &nbmaps, const at::Tensor &nboffs, int64_t total,
                             const at::Tensor &pos_out, const at::Tensor &pos_in, int64_t n_in, int64_t n_out,
                             bool transposed, const c10::optional<at::Tensor> &running_mean,
                             const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt,
                             double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream,
-                            const c10::optional<at::Tensor> &planes) {
+                            const c10::optional<at::Tensor> &planes, bool passthrough) {
     const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
     const auto dt = half ? at::kHalf : at::kFloat;
     const int64_t rows = transposed ? n_in : n_out;
@@ -106,7 +107,10 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     ctx->saved_data["has_res"] = res.defined();
     ctx->saved_data["in_dtype"] = (int64_t)feats.scalar_type();
     ctx->saved_data["res_dtype"] = (int64_t)(res.defined() ? residual->scalar_type() : at::kFloat);
-    return out;
+    // passthrough: the input leaves the node a second time (autograd aliases it); whatever consumes THAT tensor - the
+    // shortcut of a residual block - sends its gradient back into this node, where it joins the input gradient's store
+    if (passthrough) return {out, feats};
+    return {out};
   }
 
   static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx,
@@ -123,6 +127,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const auto res_dtype = (at::ScalarType)ctx->saved_data["res_dtype"].toInt();
     const int64_t k = w.size(0), c_in = w.size(1), c_out = w.size(2), rows = conv_out.size(0);
     const int64_t stream = ctx->saved_data["stream"].toInt();   // the engine runs a node on its forward stream
+    TORCH_CHECK(grads[0].defined(), "conv_block: the block's output received no gradient");
     at::Tensor g = grads[0].contiguous().to(conv_out.scalar_type());
     const at::Tensor &table = transposed ? pos_out : pos_in;
     const int64_t drows = transposed ? n_out : n_in;
@@ -137,6 +142,12 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor ws = workspace(nb, x, stream);
     const float *st = stats.data_ptr<float>();
     float *gw = gwb.data_ptr<float>();
+    at::Tensor addend;                   // gradient of the passed-through input, in grad_feat's storage type
+    if (grads.size() > 1 && grads[1].defined() && grad_feat.defined()) {
+      addend = grads[1].contiguous().to(conv_out.scalar_type());
+      TORCH_CHECK(addend.sizes() == grad_feat.sizes(), "conv_block: pass-through gradient has the wrong shape");
+      api.addend_hint(addend.data_ptr());
+    }
     const at::Tensor pl = ctx->saved_data["planes"].toTensor();
     if (pl.defined() && !half && grad_feat.defined())
       api.planes_hint((const float *)w.data_ptr(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
@@ -152,7 +163,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -167,8 +178,9 @@ void load_backend(const std::string &libpath) {
   api.backward = (decltype(api.backward))dlsym(h, "ts_conv_block_backward");
   api.last_error = (decltype(api.last_error))dlsym(h, "ts_last_error");
   api.planes_hint = (decltype(api.planes_hint))dlsym(h, "ts_conv_planes_hint");
-  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.planes_hint,
-              "libtaseg_hip.so lacks the ts_conv_block_* / ts_conv_planes_hint entry points");
+  api.addend_hint = (decltype(api.addend_hint))dlsym(h, "ts_conv_block_addend_hint");
+  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.planes_hint && api.addend_hint,
+              "libtaseg_hip.so lacks the ts_conv_block_* / ts_conv_planes_hint / ts_conv_block_addend_hint entry points");
 #define TS_BIND(field, sym)                                      \
   api.field = (decltype(api.field))dlsym(h, sym);                \
   TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
@@ -184,16 +196,17 @@ void load_backend(const std::string &libpath) {
   api.handle = h;
 }
 
-at::Tensor conv_block(const at::Tensor &feats, const at::Tensor &weight, const c10::optional<at::Tensor> &residual,
+std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &weight, const c10::optional<at::Tensor> &residual,
                       const at::Tensor &bn_weight, const at::Tensor &bn_bias, const at::Tensor &nbmaps,
                       const at::Tensor &nboffs, int64_t total, const at::Tensor &pos_out, const at::Tensor &pos_in,
                       int64_t n_in, int64_t n_out, bool transposed, const c10::optional<at::Tensor> &running_mean,
                       const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt, double momentum,
                       double eps, bool relu, int64_t comm, bool half, int64_t stream,
-                      const c10::optional<at::Tensor> &planes) {
+                      const c10::optional<at::Tensor> &planes, bool passthrough) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
-                          transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes);
+                          transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
+                          passthrough);
 }
 
 // ------------------------------------------------------------------------------------------------ index plan

@@ -99,7 +99,8 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         # relu(net(x) + downsample(x)) with the BN / add / ReLU tails fused (same module parameters / buffers)
-        h = spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True)
+        # (the first block hands x through: the shortcut's gradient then lands in the store of conv1's input gradient)
+        h, x = spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True, passthrough=True)
         shortcut = x if isinstance(self.downsample, nn.Identity) else self.downsample(x)
         return spnn.conv_bn_act(self.net[3], self.net[4], h, relu=True, residual=shortcut)
 

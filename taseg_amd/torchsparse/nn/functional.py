@@ -602,7 +602,8 @@ class _ConvBlock(Function):
     w.r.t. the convolution output and the transposed half weight live in the per-stream workspace."""
 
     @staticmethod
-    def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half, planes=None):
+    def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half, planes=None,
+                passthrough=False):
         running_mean, running_var, nbt, momentum, eps = bn_state
         lib = B.L.load()
         L = B.L
@@ -636,10 +637,12 @@ class _ConvBlock(Function):
         ctx.planes = planes
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
         ctx.in_dtype, ctx.res_dtype = feats.dtype, (None if residual is None else residual.dtype)
-        return out
+        # passthrough: the input leaves the node a second time (autograd aliases it); the shortcut of a residual block
+        # consumes THAT tensor and its gradient comes back into this node, where it joins the input gradient's store
+        return (out, feats) if passthrough else out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_pass=None):
         x, w, conv_out, stats, mask, bn_weight = ctx.saved_tensors
         kmap, transposed, half, comm = ctx.kmap, ctx.transposed, ctx.half, ctx.comm
         lib = B.L.load()
@@ -662,6 +665,9 @@ class _ConvBlock(Function):
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
         if grad_feat is not None and not half:
             _planes.hint(w, ctx.planes)
+        if grad_pass is not None and grad_feat is not None:
+            addend = grad_pass.contiguous().to(dt)
+            lib.ts_conv_block_addend_hint(L.ptr(addend))
         L.check(lib.ts_conv_block_backward(
             L.ptr(g), L.ptr(mask), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn_weight),
             L.ptr(ctx.total_dev), comm, L.ptr(sums), rows, c_out, 1 if half else 0, L.ptr(x), x.shape[0], c_in, L.ptr(w), k,
@@ -672,7 +678,7 @@ class _ConvBlock(Function):
             grad_feat = grad_feat.to(ctx.in_dtype)
         if grad_res is not None and grad_res.dtype != ctx.res_dtype:
             grad_res = grad_res.to(ctx.res_dtype)
-        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None
+        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None, None
 
 
 def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", residual, rows: int) -> bool:

@@ -125,10 +125,16 @@ def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor =
     return input._like(out)
 
 
-def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None) -> SparseTensor:
+def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None,
+                passthrough: bool = False):
     """relu(BN(conv(input)) [+ residual]) for a Conv3d and its BatchNorm / SyncBatchNorm module: one autograd node and
     one backend call per direction when the block trains on the HIP path (functional._ConvBlock); otherwise exactly
-    `bn_act(mod, conv(input), relu, residual)`.  TASEG_FUSED_BLOCK=0 always takes the second form."""
+    `bn_act(mod, conv(input), relu, residual)`.  TASEG_FUSED_BLOCK=0 always takes the second form.
+
+    passthrough=True returns (output, input'): input' carries the input's features through the node, so that a second
+    consumer of the input (the shortcut of a residual block) sends its gradient back INTO the node, where it is added
+    in the store of the convolution's input gradient instead of by a separate add launch.  Use input' in place of
+    `input` downstream; on the unfused paths input' is `input` itself."""
     from ...rccl import direct_comm
     from .batchnorm import fast_path_ok  # noqa: F401  (same shape rules as the BatchNorm fast path)
     ones = (1, 1, 1)
@@ -156,12 +162,17 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                     out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
                                           kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
                                           state[1], state[2], float(mod.momentum), float(mod.eps), relu,
-                                          (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes)
+                                          (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
+                                          bool(passthrough))
+                    out, passed = (out[0], out[1]) if passthrough else (out[0], None)
                 else:
                     out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
-                                             relu, comm, half, planes)
-                return F._conv_output(input, out, out_coords, out_stride)
-    return bn_act(mod, conv(input), relu=relu, residual=residual)
+                                             relu, comm, half, planes, bool(passthrough))
+                    out, passed = out if passthrough else (out, None)
+                result = F._conv_output(input, out, out_coords, out_stride)
+                return (result, input._like(passed)) if passthrough else result
+    result = bn_act(mod, conv(input), relu=relu, residual=residual)
+    return (result, input) if passthrough else result
 
 
 class BatchNorm(nn.BatchNorm1d):

@@ -497,3 +497,51 @@ def test_presplit_weight_planes_change_nothing(monkeypatch, optimizer):
     assert n0 == 0 and n1 >= 3 * 4, f"planes were split {n1} times: the mechanism did not engage"
     assert l0 == l1 and all(torch.equal(a, b) for a, b in zip(w0, w1)), "pre-split planes changed the training steps"
     assert np.array_equal(e0, e1), "pre-split planes changed the eval logits"
+
+
+@pytest.mark.parametrize("node", ["native", "python"])
+@pytest.mark.parametrize("inc,outc", [(64, 64), (96, 64)])
+def test_residual_block_passes_its_input_through(monkeypatch, node, inc, outc):
+    """ResidualBlock hands its input through the first conv block's autograd node (conv_bn_act(passthrough=True)): the
+    shortcut's gradient - identity or 1x1x1 conv + BatchNorm - joins the store of conv1's input gradient
+    (ts_conv_block_addend_hint) instead of meeting it in an add launch.  Same bits as the separate add, on both nodes."""
+    from taseg_amd import _fast
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import ResidualBlock
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.nn import modules as M
+    if node == "native" and _fast.module() is None:
+        pytest.skip("taseg_amd/_fast_block.so has not been built")
+    if node == "python":
+        monkeypatch.setattr(_fast, "_mod", None)
+        monkeypatch.setattr(_fast, "_tried", True)
+    rs = np.random.RandomState(inc + outc)
+    c = np.unique(rs.randint(0, 24, size=(6000, 3)), axis=0).astype(np.int32)
+    coords = torch.from_numpy(np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)).cuda()
+    feats = torch.from_numpy(rs.randn(len(c), inc).astype(np.float32)).cuda()
+    gout = torch.from_numpy(rs.randn(len(c), outc).astype(np.float32)).cuda()
+
+    def run(passthrough):
+        torch.manual_seed(0)
+        block = ResidualBlock(inc, outc).cuda().train()
+        if not passthrough:
+            real = M.conv_bn_act
+
+            def separate(conv, mod, inp, relu=True, residual=None, passthrough=False):
+                out = real(conv, mod, inp, relu=relu, residual=residual)
+                return (out, inp) if passthrough else out
+            monkeypatch.setattr(M, "conv_bn_act", separate)
+            import taseg_amd.torchsparse.nn as spnn
+            monkeypatch.setattr(spnn, "conv_bn_act", separate)
+        x = feats.clone().requires_grad_()
+        y = block(SparseTensor(x, coords, 1))
+        y.F.backward(gout)
+        monkeypatch.undo()
+        if node == "python":
+            monkeypatch.setattr(_fast, "_mod", None)
+            monkeypatch.setattr(_fast, "_tried", True)
+        return y.F.detach().clone(), x.grad.clone(), [p.grad.clone() for p in block.parameters()]
+
+    ya, ga, pa = run(True)
+    yb, gb, pb = run(False)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
