@@ -64,41 +64,39 @@ __global__ __launch_bounds__(256) void lovasz_tile_count_kernel(const int64_t *_
   if (threadIdx.x == 0) tile_fg[c * tiles + t] = red[0] + red[1] + red[2] + red[3];
 }
 
-// one workgroup: exclusive scan of the tile counts per class, the class totals and the number of classes present
-__global__ __launch_bounds__(256) void lovasz_tile_scan_kernel(int *__restrict__ tile_fg, int C, int tiles,
-                                                               float *__restrict__ gts, float *__restrict__ n_present) {
+// one workgroup per class: exclusive scan of its tile counts and the class total
+__global__ __launch_bounds__(256) void lovasz_tile_scan_kernel(int *__restrict__ tile_fg, int tiles, float *__restrict__ gts) {
   __shared__ int carry;
   __shared__ int wsum[4];
-  __shared__ int present;
-  if (threadIdx.x == 0) present = 0;
-  for (int c = 0; c < C; ++c) {
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int t0 = 0; t0 < tiles; t0 += 256) {
-      const int t = t0 + threadIdx.x;
-      const int v = t < tiles ? tile_fg[c * tiles + t] : 0;
-      int inc = v;                                       // inclusive scan over the 256 threads
+  const int c = blockIdx.x;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < tiles; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const int v = t < tiles ? tile_fg[c * tiles + t] : 0;
+    int inc = v;                                       // inclusive scan over the 256 threads
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(inc, d, 64);
-        if ((threadIdx.x & 63) >= d) inc += up;
-      }
-      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
-      __syncthreads();
-      int before = carry;
-      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
-      if (t < tiles) tile_fg[c * tiles + t] = before + inc - v;      // exclusive prefix
-      __syncthreads();
-      if (threadIdx.x == 255) carry = before + inc;
-      __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d, 64);
+      if ((threadIdx.x & 63) >= d) inc += up;
     }
-    if (threadIdx.x == 0) {
-      gts[c] = (float)carry;
-      if (carry > 0) present += 1;
-    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
+    if (t < tiles) tile_fg[c * tiles + t] = before + inc - v;      // exclusive prefix
+    __syncthreads();
+    if (threadIdx.x == 255) carry = before + inc;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_present = (float)present;
+  if (threadIdx.x == 0) gts[c] = (float)carry;
+}
+
+// number of classes that occur (gts > 0), the same in every caller
+__device__ __forceinline__ float lv_present(const float *__restrict__ gts, int C) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(lane < C && gts[min(lane, C - 1)] > 0.f);
+  return (float)__builtin_popcountll(m);
 }
 
 // tile-local scan + Lovasz gradient + partial dot product + gradient scatter
@@ -107,7 +105,6 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restric
                                                           const int64_t *__restrict__ labels, int64_t ignore, int64_t P,
                                                           int C, int tiles, const int *__restrict__ tile_base,
                                                           const float *__restrict__ gts,
-                                                          const float *__restrict__ n_present,
                                                           float *__restrict__ tile_loss, float *__restrict__ dprob) {
   __shared__ int wsum[4];
   __shared__ float wred[4];
@@ -137,7 +134,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restric
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
   int cum = before + inc - mine;                          // foreground in front of this thread's first element
   const float g = gts[c];
-  const float np = *n_present;
+  const float np = lv_present(gts, C);
   const float scale = (g > 0.f && np > 0.f) ? 1.f / np : 0.f;     // present_c / #present
   float part = 0.f;
 #pragma unroll
@@ -163,21 +160,28 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restric
   if (threadIdx.x == 0) tile_loss[c * tiles + t] = (wred[0] + wred[1]) + (wred[2] + wred[3]);
 }
 
-// loss = sum over the classes present of (sum of their tile partials, in tile order) / #present
-__global__ __launch_bounds__(64) void lovasz_finish_kernel(const float *__restrict__ tile_loss, const float *__restrict__ gts,
-                                                           const float *__restrict__ n_present, int C, int tiles,
-                                                           float *__restrict__ loss) {
-  const int c = threadIdx.x;
-  float v = 0.f;
-  if (c < C && gts[c] > 0.f)
-    for (int t = 0; t < tiles; ++t) v += tile_loss[c * tiles + t];
-  __shared__ float red[64];
-  red[threadIdx.x] = v;
+// loss = sum over the classes present of (their tile partials: 32 lanes per class take the tiles lane, lane + 32, ...
+// in order, then the lanes are added in lane order) / #present.  One workgroup of 1024 threads: 32 classes x 32 lanes
+// per pass.
+__global__ __launch_bounds__(1024) void lovasz_finish_kernel(const float *__restrict__ tile_loss, const float *__restrict__ gts,
+                                                             int C, int tiles, float *__restrict__ loss) {
+  __shared__ float cls[64];
+  const int lane = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    const int c = c0 + slot;
+    float v = 0.f;
+    if (c < C && gts[c] > 0.f)
+      for (int t = lane; t < tiles; t += 32) v += tile_loss[c * tiles + t];
+    // lanes of one class sit in one half-wave: add them in lane order
+    float tot = 0.f;
+    for (int l = 0; l < 32; ++l) tot += __shfl(v, (threadIdx.x & 32) + l, 64);
+    if (lane == 0 && c < C) cls[c] = tot;
+  }
   __syncthreads();
+  const float np = lv_present(gts, C);          // a ballot: every lane of the wave takes part
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int k = 0; k < C; ++k) s += red[k];
-    const float np = *n_present;
+    for (int k = 0; k < C; ++k) s += cls[k];
     *loss = np > 0.f ? s / np : 0.f;
   }
 }
@@ -206,13 +210,12 @@ extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, c
   float *tile_loss = (float *)p;
   p += ts_align_up((size_t)tiles * n_classes * 4, 256);
   float *gts = (float *)p;
-  float *n_present = gts + n_classes;
   dim3 grid((unsigned)tiles, (unsigned)n_classes);
   lovasz_tile_count_kernel<<<grid, 256, 0, stream>>>(perm, labels, ignore, n_points, tiles, tile_fg);
-  lovasz_tile_scan_kernel<<<1, 256, 0, stream>>>(tile_fg, n_classes, tiles, gts, n_present);
+  lovasz_tile_scan_kernel<<<n_classes, 256, 0, stream>>>(tile_fg, tiles, gts);
   lovasz_grad_kernel<<<grid, 256, 0, stream>>>(errors_sorted, perm, labels, ignore, n_points, n_classes, tiles, tile_fg,
-                                               gts, n_present, tile_loss, grad_probas);
-  lovasz_finish_kernel<<<1, 64, 0, stream>>>(tile_loss, gts, n_present, n_classes, tiles, loss);
+                                               gts, tile_loss, grad_probas);
+  lovasz_finish_kernel<<<1, 1024, 0, stream>>>(tile_loss, gts, n_classes, tiles, loss);
   TS_CHECK_LAUNCH("ts_lovasz_grad");
   return TS_OK;
 }
