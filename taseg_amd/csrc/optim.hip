@@ -22,6 +22,16 @@ __global__ __launch_bounds__(256) void sgd_grad_stats_kernel(const float *__rest
   int bad = 0;
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int64_t step = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 * step + 3 < n; i += 4 * step) {       // four independent 16-byte loads in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(g + i + u * step);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc += (double)v[u].x * v[u].x + (double)v[u].y * v[u].y + (double)v[u].z * v[u].z + (double)v[u].w * v[u].w;
+      bad |= !(isfinite(v[u].x) && isfinite(v[u].y) && isfinite(v[u].z) && isfinite(v[u].w));
+    }
+  }
   for (; i + 3 < n; i += step) {
     const float4 v = *(const float4 *)(g + i);
     acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -92,7 +102,9 @@ extern "C" int ts_sgd_grad_stats(const float *grad, int64_t n, double *sumsq, in
   TS_REQUIRE(n >= 0 && sumsq && nonfinite, TS_ERR_INVALID_ARGUMENT, "ts_sgd_grad_stats: bad arguments");
   if (n == 0) return TS_OK;
   TS_REQUIRE(grad && (((uintptr_t)grad) & 15) == 0, TS_ERR_INVALID_ARGUMENT, "ts_sgd_grad_stats: grad must be 16-byte aligned");
-  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(n, 1024), 2048);
+  // few workgroups with long loops: every workgroup ends in ONE double atomic on the same address, and ~2000 of
+  // those took longer (18 us) than reading the bucket
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(n, 16384), 512);
   sgd_grad_stats_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad, n, sumsq, nonfinite);
   TS_CHECK_LAUNCH("ts_sgd_grad_stats");
   return TS_OK;
