@@ -281,7 +281,9 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     }
     {
       // the ordered weight-gradient sum riding on this launch reads its partial tiles and writes grad_kernel: real bytes
-      const double side_bytes = ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0;
+      // ... and so is the shortcut's gradient when it is added in this store (one more read of [n_dgrad_rows, c_in])
+      const double side_bytes = (ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0) +
+                                (addend ? es_d * (double)n_dgrad_rows * c_in : 0.0);
       ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, side_bytes);
       if (half)
         TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, ride ? &job : nullptr,
