@@ -104,7 +104,9 @@ def voxelize_sample_ms(points, labels, points_ms, labels_ms, voxel_size, name=""
     """Multi-scan sample (semantickitti_voxel_ms.py:121-187): both clouds voxelised, the single-frame one
     shifted by the fused cloud's minimum.  `keep` (optional bool mask over points_ms) is AND-ed with the clamp
     so the class-step filter and the clamp cost one compaction (one host read) instead of two."""
-    lo = points[:, :3].min(0).values
+    # (min over dim 0 of the [n, 3] slice runs in one of torch's slow few-column reductions: 175 us for 35k points;
+    #  the same minimum along the rows of the transposed copy takes ~10 us)
+    lo = points[:, :3].t().contiguous().min(1).values
     clamp = (points_ms[:, :3] >= lo).all(1)                               # :121-124
     if keep is not None:
         clamp = clamp & keep
