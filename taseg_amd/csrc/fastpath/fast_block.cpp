@@ -65,7 +65,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             bool transposed, const c10::optional<at::Tensor> &running_mean,
                             const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt,
                             double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream,
-                            const c10::optional<at::Tensor> &planes, bool passthrough) {
+                            const c10::optional<at::Tensor> &planes, bool passthrough,
+                            const c10::optional<at::Tensor> &grad_dest) {
     const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
     const auto dt = half ? at::kHalf : at::kFloat;
     const int64_t rows = transposed ? n_in : n_out;
@@ -97,6 +98,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
           "ts_conv_block_forward");
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
+    // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
+    ctx->saved_data["grad_dest"] = (grad_dest.has_value() && grad_dest->defined()) ? *grad_dest : at::Tensor();
     ctx->saved_data["total"] = total;
     ctx->saved_data["n_in"] = n_in;
     ctx->saved_data["n_out"] = n_out;
@@ -134,7 +137,14 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const auto opts = conv_out.options();
     at::Tensor grad_feat, grad_w, grad_res, sums;
     if (ctx->needs_input_grad(0)) grad_feat = at::empty({drows, c_in}, opts);
-    if (ctx->needs_input_grad(1)) grad_w = at::empty({k, c_in, c_out}, opts.dtype(at::kFloat));
+    if (ctx->needs_input_grad(1)) {
+      const at::Tensor dest = ctx->saved_data["grad_dest"].toTensor();
+      if (dest.defined() && dest.scalar_type() == at::kFloat && dest.is_contiguous() && dest.dim() == 3 && dest.size(0) == k &&
+          dest.size(1) == c_in && dest.size(2) == c_out && dest.device() == conv_out.device())
+        grad_w = dest.alias();             // a fresh alias of the bucket slot: autograd adopts it as p.grad, no copy
+      else
+        grad_w = at::empty({k, c_in, c_out}, opts.dtype(at::kFloat));
+    }
     if (has_res && ctx->needs_input_grad(2)) grad_res = at::empty_like(conv_out);
     at::Tensor gwb = at::empty({2, c_out}, opts.dtype(at::kFloat));
     if (comm) sums = at::empty({2, c_out}, opts.dtype(at::kDouble));
@@ -163,7 +173,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -202,11 +212,12 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       int64_t n_in, int64_t n_out, bool transposed, const c10::optional<at::Tensor> &running_mean,
                       const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt, double momentum,
                       double eps, bool relu, int64_t comm, bool half, int64_t stream,
-                      const c10::optional<at::Tensor> &planes, bool passthrough) {
+                      const c10::optional<at::Tensor> &planes, bool passthrough,
+                      const c10::optional<at::Tensor> &grad_dest) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
-                          passthrough);
+                          passthrough, grad_dest);
 }
 
 // ------------------------------------------------------------------------------------------------ index plan

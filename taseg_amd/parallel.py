@@ -116,6 +116,11 @@ class GradBucketReducer:
             off += -(-p.numel() // self.ALIGN) * self.ALIGN
         flat = torch.zeros(off, dtype=first.dtype, device=first.device)
         views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, params)]
+        for p, v in zip(params, views):
+            # producers that can write a gradient wherever they are told (the conv block nodes: their weight gradient is
+            # a full overwrite) put it straight into the bucket; _launch then finds p.grad already in place and copies
+            # nothing for it (the convolution weights are 99 % of the gradient bytes)
+            p._taseg_grad_dest = v
         self.buckets.append({"params": list(params), "flat": flat, "views": views, "offsets": offsets,
                              "pending": len(params), "launched": False, "unused": []})
 

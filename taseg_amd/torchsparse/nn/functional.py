@@ -603,7 +603,7 @@ class _ConvBlock(Function):
 
     @staticmethod
     def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half, planes=None,
-                passthrough=False):
+                passthrough=False, grad_dest=None):
         running_mean, running_var, nbt, momentum, eps = bn_state
         lib = B.L.load()
         L = B.L
@@ -635,6 +635,7 @@ class _ConvBlock(Function):
         ctx.save_for_backward(x, w16 if half else w32, conv_out, stats, mask, bn_weight)
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
         ctx.planes = planes
+        ctx.grad_dest = grad_dest        # where the weight gradient is wanted (a gradient bucket's view), or None
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
         ctx.in_dtype, ctx.res_dtype = feats.dtype, (None if residual is None else residual.dtype)
         # passthrough: the input leaves the node a second time (autograd aliases it); the shortcut of a residual block
@@ -657,7 +658,14 @@ class _ConvBlock(Function):
         table, drows = (kmap.pos_in, n_in) if not transposed else (kmap.pos_out, n_out)
         need = ctx.needs_input_grad
         grad_feat = torch.empty((drows, c_in), dtype=dt, device=dev) if need[0] else None
-        grad_w = torch.empty((k, c_in, c_out), dtype=torch.float32, device=dev) if need[1] else None
+        grad_w = None
+        if need[1]:
+            dest = ctx.grad_dest
+            if (dest is not None and dest.dtype == torch.float32 and dest.is_contiguous() and tuple(dest.shape) == (k, c_in, c_out)
+                    and dest.device == dev):
+                grad_w = dest.view_as(dest)      # a fresh alias of the bucket slot: autograd adopts it as p.grad, no copy
+            else:
+                grad_w = torch.empty((k, c_in, c_out), dtype=torch.float32, device=dev)
         grad_res = torch.empty_like(conv_out) if (ctx.res_dtype is not None and need[2]) else None
         gwb = torch.empty((2, c_out), dtype=torch.float32, device=dev)
         sums = torch.empty((2, c_out), dtype=torch.float64, device=dev) if comm is not None else None
@@ -678,7 +686,7 @@ class _ConvBlock(Function):
             grad_feat = grad_feat.to(ctx.in_dtype)
         if grad_res is not None and grad_res.dtype != ctx.res_dtype:
             grad_res = grad_res.to(ctx.res_dtype)
-        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None, None
+        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None, None, None
 
 
 def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", residual, rows: int) -> bool:

@@ -158,16 +158,17 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 fast = _fast.module()
                 half = F._amp_half(feats)
                 planes = None if half else _planes.planes_for(conv.kernel)      # pre-split weight (taseg_amd/planes.py)
+                dest = getattr(conv.kernel, "_taseg_grad_dest", None)           # bucket slot of the weight gradient (parallel.py)
                 if fast is not None:            # C++ autograd node, same two backend calls (csrc/fastpath)
                     out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
                                           kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
                                           state[1], state[2], float(mod.momentum), float(mod.eps), relu,
                                           (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
-                                          bool(passthrough))
+                                          bool(passthrough), dest)
                     out, passed = (out[0], out[1]) if passthrough else (out[0], None)
                 else:
                     out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
-                                             relu, comm, half, planes, bool(passthrough))
+                                             relu, comm, half, planes, bool(passthrough), dest)
                     out, passed = out if passthrough else (out, None)
                 result = F._conv_output(input, out, out_coords, out_stride)
                 return (result, input._like(passed)) if passthrough else result
