@@ -89,7 +89,7 @@ def build_tiaf_sample(frames: Dict[int, Dict], steps: Sequence[int], multiscan: 
         semantic.append(_pad(f["semantic"].float(), crop))
     fov = torch.cat(fov, 0)
     # FOV cloud: clamped to the current cloud's corner, rounded and shifted like the other two, grouped per voxel
-    lo = point[:, :3].min(0).values
+    lo = point[:, :3].t().contiguous().min(1).values       # (row-wise minimum of the transposed copy: see data/stage.py)
     fov = fov[(fov[:, :3] >= lo).all(1)].contiguous()
     shift = sample.pop("_shift")
     pc_fov, _, inds_fov, _ = _quantize(fov, voxel_size, shift=shift)
