@@ -492,7 +492,7 @@ def main():
     from taseg_amd.data.stage import DevicePrefetcher
     prepare = (lambda bd: bd.get("_plan") or model.prepare(bd)) if os.environ.get("TASEG_REUSE_PLAN") == "1" else model.prepare
     pf = None if args.no_prefetch else DevicePrefetcher(make_batch, prepare,
-                                                        threaded=os.environ.get("TASEG_STAGE_THREAD", "0") == "1")
+                                                        threaded=os.environ.get("TASEG_STAGE_THREAD", "1" if args.amp else "0") == "1")
 
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
     B.planes_in_use = _planes._ENABLED and not args.amp        # names the 128-column fp32 pair GEMM in the kernel table

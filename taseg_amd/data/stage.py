@@ -206,9 +206,10 @@ class DevicePrefetcher:
         self._staged = None          # (batch, ready_event) or a Future of it
         self._inflight = []          # [(batch, done_event)] handed out, possibly still read by the launch stream
         self._current = None
-        # threaded=True runs the stage on a worker thread (its host reads release the GIL while they wait).  Measured
-        # here it LOSES 6 % in the launch-bound AMP step - the stage's ~150 Python-level calls contend for the GIL with
-        # the training thread - so the default stays in-line.
+        # threaded=True runs the stage on a worker thread (its host reads release the GIL while they wait).  With the
+        # index plan built natively without the interpreter lock (csrc/fastpath) this takes ~2 ms of host time per step
+        # off the training thread: +4 ... 6 % where the step is host-bound (AMP at bs 2), nothing where it is device-bound;
+        # bench.py switches it on for --amp (TASEG_STAGE_THREAD overrides).  Same batches, same bits either way.
         self._pool = None
         if threaded:
             from concurrent.futures import ThreadPoolExecutor

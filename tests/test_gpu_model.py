@@ -285,7 +285,7 @@ def test_prefetched_batches_train_like_inline_ones():
         coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
         data.append((torch.from_numpy(pts[idx]).cuda(), coords, torch.from_numpy(lab[idx].astype(np.int64)).cuda()))
 
-    def run(prefetch):
+    def run(prefetch, threaded=False):
         cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5, num_layer=[1] * 8)
         model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
         opt = torch.optim.SGD(model.parameters(), lr=0.05)
@@ -296,7 +296,7 @@ def test_prefetched_batches_train_like_inline_ones():
             it[0] += 1
             return {"lidar": SparseTensor(f, c), "targets": SparseTensor(l, c), "offset": torch.tensor([0])}
 
-        pf = DevicePrefetcher(make_batch, model.prepare) if prefetch else None
+        pf = DevicePrefetcher(make_batch, model.prepare, threaded=threaded) if prefetch else None
         losses = []
         for _ in range(3):
             opt.zero_grad()
@@ -317,6 +317,8 @@ def test_prefetched_batches_train_like_inline_ones():
     # 2): identical runs give identical bits, and staging a batch early on another stream must not change a single one
     assert la == la2 and all(torch.equal(a, b) for a, b in zip(wa, wa2)), "two identical runs differ"
     assert la == lb and all(torch.equal(a, b) for a, b in zip(wa, wb)), "prefetched batches trained differently"
+    lc, wc = run(True, threaded=True)       # the stage on a worker thread (bench.py --amp)
+    assert la == lc and all(torch.equal(a, b) for a, b in zip(wa, wc)), "batches staged on a worker thread trained differently"
 
 
 def test_miou_parity_200_scans(g_miou):
