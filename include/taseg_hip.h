@@ -341,6 +341,19 @@ int ts_devox_order(const int32_t *idx, int64_t n, int64_t n_vox, int32_t *order,
                    ts_stream_t stream);
 int ts_devoxelize_backward_runs(const float *grad_out, const int32_t *idx, const float *weight, const int32_t *order,
                                 int64_t n, int32_t c, int64_t m, float *grad_feat, ts_stream_t stream);
+/* Half-storage forms for the AMP path (the reference's devoxelize op runs under `custom_fwd(cast_inputs=torch.half)`,
+ * nn/functional/devoxelize.py:54): `void *` rows are IEEE half, leading dimensions in elements, sums in float32 and ONE
+ * rounding at the store - the bits of the float32 entry points between a `.float()` of the inputs and a `.half()` of the
+ * result, without those two passes.  C % 4 == 0, rows 8-byte aligned; `part` stays float32. */
+int ts_devoxelize_forward_f16_ld(const void *feat, const int32_t *idx, const float *weight, int64_t n, int32_t c, int64_t m,
+                                 void *out, int64_t out_ld, ts_stream_t stream);
+int ts_devoxelize_backward_csr_f16_ld(const void *grad_out, int64_t go_ld, const float *weight, const int32_t *offsets,
+                                      const int32_t *entries, int64_t n, int32_t c, int64_t m, void *grad_feat,
+                                      ts_stream_t stream);
+int ts_devoxelize_backward_cells_f16_ld(const void *grad_out, int64_t go_ld, const float *weight, const int32_t *order,
+                                        const int32_t *seg_start, int64_t n_seg, const int32_t *offsets,
+                                        const int32_t *entries, int64_t n, int32_t c, int64_t m, float *part,
+                                        void *grad_feat, ts_stream_t stream);
 
 /* TIAF image -> point gather (R pcseg/model/segmentor/voxel/minkunet/unet2d.py:180-214) on the NCHW stack:
  *   out[n, c] = feat[first_frame(b_n) + row_n / H, c, (row_n % H) >> shift, col_n >> shift]

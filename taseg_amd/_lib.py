@@ -64,6 +64,9 @@ SIGNATURES = {
     "ts_devoxelize_backward_csr_ld": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "ts_devox_segments": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ts_devoxelize_backward_cells_ld": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "ts_devoxelize_forward_f16_ld": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp]),
+    "ts_devoxelize_backward_csr_f16_ld": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ts_devoxelize_backward_cells_f16_ld": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "ts_devox_csr_workspace_bytes": (_sz, [_i64]),
     "ts_devox_csr": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ts_devoxelize_backward_csr": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),

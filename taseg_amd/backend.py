@@ -144,40 +144,57 @@ def devox_order(indices, n_vox):
 
 
 def devoxelize_forward_into(feat, indices, weight, out, col):
-    """devoxelize_forward_cuda writing out[:, col : col + C] of a wider point matrix in place (no later torch.cat)."""
+    """devoxelize_forward_cuda writing out[:, col : col + C] of a wider point matrix in place (no later torch.cat).
+    feat and out both float32, or both float16 (half storage, float32 sums)."""
     L.require_device(feat, indices, weight, out)
-    feat, indices, weight = _f32(feat, "feat"), _i32(indices, "indices"), _f32(weight, "weight")
+    half = feat.dtype == torch.float16
+    feat = _f16(feat, "feat") if half else _f32(feat, "feat")
+    indices, weight = _i32(indices, "indices"), _f32(weight, "weight")
     m, c = feat.shape
     n = indices.shape[0]
-    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[0] != n or col + c > out.shape[1] or col % 4:
-        raise ValueError("devoxelize_forward_into: out must be a contiguous float32 [n, ld] matrix with room at `col`")
+    if out.dtype != feat.dtype or not out.is_contiguous() or out.shape[0] != n or col + c > out.shape[1] or col % 4 \
+            or (half and (c % 4 or out.shape[1] % 4)):
+        raise ValueError("devoxelize_forward_into: out must be a contiguous [n, ld] matrix of feat's dtype with room at `col`")
+    if half:
+        L.check(L.load().ts_devoxelize_forward_f16_ld(L.ptr(feat), L.ptr(indices), L.ptr(weight), n, c, m,
+                                                      out.data_ptr() + 2 * col, out.shape[1], L.stream()),
+                "ts_devoxelize_forward_f16_ld")
+        return
     L.check(L.load().ts_devoxelize_forward_ld(L.ptr(feat), L.ptr(indices), L.ptr(weight), n, c, m, out.data_ptr() + 4 * col,
                                               out.shape[1], L.stream()), "ts_devoxelize_forward_ld")
 
 
 def devoxelize_backward_from(grad, col, c, indices, weight, n_vox, order=None):
     """Adjoint of devoxelize_forward_into for the column block grad[:, col : col + c]; `order` = a walk order
-    (devox_order), an inverse map (devox_csr) or None."""
+    (devox_order), an inverse map (devox_csr), a cell plan (devox_cells) or None.  A float16 `grad` (inverse map or cell
+    plan only) gives a float16 result: float32 sums, one rounding."""
     L.require_device(grad, indices, weight)
     indices, weight = _i32(indices, "indices"), _f32(weight, "weight")
-    if grad.dtype != torch.float32 or not grad.is_contiguous() or col + c > grad.shape[1] or col % 4 or grad.shape[1] % 4:
-        raise ValueError("devoxelize_backward_from: grad must be a contiguous float32 [n, ld] matrix, ld and col % 4 == 0")
+    half = grad.dtype == torch.float16
+    if grad.dtype not in (torch.float32, torch.float16) or not grad.is_contiguous() or col + c > grad.shape[1] or col % 4 \
+            or grad.shape[1] % 4:
+        raise ValueError("devoxelize_backward_from: grad must be a contiguous float32 / float16 [n, ld] matrix, ld and col % 4 == 0")
+    if half and not isinstance(order, tuple):
+        raise TypeError("devoxelize_backward_from: float16 gradients need an inverse map or a cell plan")
     n, ld = grad.shape
-    out = torch.empty((int(n_vox), c), dtype=torch.float32, device=grad.device)
+    out = torch.empty((int(n_vox), c), dtype=grad.dtype, device=grad.device)
     lib = L.load()
+    base = grad.data_ptr() + grad.element_size() * col
     if isinstance(order, tuple) and isinstance(order[0], str):        # ("cells", ...): backend.devox_cells
         _, walk, seg_start, off, ent = order
         n_seg = seg_start.shape[0] - 1
         part = torch.empty((max(8 * n_seg, 1), c), dtype=torch.float32, device=grad.device)
-        L.check(lib.ts_devoxelize_backward_cells_ld(grad.data_ptr() + 4 * col, ld, L.ptr(weight), L.ptr(walk), L.ptr(seg_start),
-                                                    n_seg, L.ptr(off), L.ptr(ent), n, c, int(n_vox), L.ptr(part), L.ptr(out),
-                                                    L.stream()), "ts_devoxelize_backward_cells_ld")
+        fn, name = (lib.ts_devoxelize_backward_cells_f16_ld, "ts_devoxelize_backward_cells_f16_ld") if half else \
+            (lib.ts_devoxelize_backward_cells_ld, "ts_devoxelize_backward_cells_ld")
+        L.check(fn(base, ld, L.ptr(weight), L.ptr(walk), L.ptr(seg_start), n_seg, L.ptr(off), L.ptr(ent), n, c, int(n_vox),
+                   L.ptr(part), L.ptr(out), L.stream()), name)
     elif isinstance(order, tuple):
         off, ent = order
-        L.check(lib.ts_devoxelize_backward_csr_ld(grad.data_ptr() + 4 * col, ld, L.ptr(weight), L.ptr(off), L.ptr(ent), n, c,
-                                                  int(n_vox), L.ptr(out), L.stream()), "ts_devoxelize_backward_csr_ld")
+        fn, name = (lib.ts_devoxelize_backward_csr_f16_ld, "ts_devoxelize_backward_csr_f16_ld") if half else \
+            (lib.ts_devoxelize_backward_csr_ld, "ts_devoxelize_backward_csr_ld")
+        L.check(fn(base, ld, L.ptr(weight), L.ptr(off), L.ptr(ent), n, c, int(n_vox), L.ptr(out), L.stream()), name)
     else:
-        L.check(lib.ts_devoxelize_backward_runs_ld(grad.data_ptr() + 4 * col, ld, L.ptr(indices), L.ptr(weight),
+        L.check(lib.ts_devoxelize_backward_runs_ld(base, ld, L.ptr(indices), L.ptr(weight),
                                                    L.ptr(order), n, c, int(n_vox), L.ptr(out), L.stream()),
                 "ts_devoxelize_backward_runs_ld")
     return out

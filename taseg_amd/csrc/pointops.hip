@@ -8,6 +8,21 @@
 // row and walks its channels with 16-byte accesses where C % 4 == 0.
 #include "common.h"
 
+// four consecutive channels of a row stored as float32 or IEEE half; arithmetic is float32 either way and a half
+// result is rounded once at the store (what `.half()` of the float32 result gives)
+typedef _Float16 ts_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
+__device__ __forceinline__ float4 ld4(const _Float16 *p) {
+  const ts_h4 v = *(const ts_h4 *)p;
+  return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void st4(float *p, float4 v) { *(float4 *)p = v; }
+__device__ __forceinline__ void st4(_Float16 *p, float4 v) {
+  ts_h4 o;
+  o.x = (_Float16)v.x; o.y = (_Float16)v.y; o.z = (_Float16)v.z; o.w = (_Float16)v.w;
+  *(ts_h4 *)p = o;
+}
+
 // ------------------------------------------------------------------ voxelize
 // forward: out[idx[i]] += feat[i] / counts[idx[i]]   (float atomics, like the reference)
 __global__ __launch_bounds__(256) void voxelize_fwd_kernel(const float *__restrict__ feat,
@@ -80,11 +95,11 @@ extern "C" int ts_voxelize_backward(const float *grad_out, const int32_t *idx, c
 // forward: out[i, :] = sum_k w[i,k] * feat[idx[i,k], :], accumulated in k order
 // like the reference's `out += w * f` loop (devoxelize_cuda.cu:26-31).
 // VEC = 4: lane group of (c/4) lanes per point, float4 loads; VEC = 1 generic.
-template <int VEC>
-__global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const float *__restrict__ feat,
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const T *__restrict__ feat,
                                                              const int *__restrict__ idx,
                                                              const float *__restrict__ w, int64_t n, int c,
-                                                             float *__restrict__ out, int64_t out_ld) {
+                                                             T *__restrict__ out, int64_t out_ld) {
   const int cv = c / VEC;
   int64_t total = n * cv;
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,21 +118,21 @@ __global__ __launch_bounds__(256) void devoxelize_fwd_kernel(const float *__rest
       float wk = wp[k];
       if (VEC == 4) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0 && wk != 0.f) f = *(const float4 *)(feat + (int64_t)id * c + j);  // w == 0: nothing to fetch
+        if (id >= 0 && wk != 0.f) f = ld4(feat + (int64_t)id * c + j);  // w == 0: nothing to fetch
         acc[0] += wk * f.x;
         acc[1 % VEC] += wk * f.y;
         acc[2 % VEC] += wk * f.z;
         acc[3 % VEC] += wk * f.w;
       } else {
         float f = 0.f;
-        if (id >= 0 && wk != 0.f) f = feat[(int64_t)id * c + j];
+        if (id >= 0 && wk != 0.f) f = (float)feat[(int64_t)id * c + j];
         acc[0] += wk * f;
       }
     }
     if (VEC == 4) {
-      *(float4 *)(out + i * out_ld + j) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+      st4(out + i * out_ld + j, make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]));
     } else {
-      out[i * out_ld + j] = acc[0];
+      out[i * out_ld + j] = (T)acc[0];
     }
   }
 }
@@ -505,12 +520,12 @@ extern "C" int ts_devoxelize_backward_runs_ld(const float *grad_out, int64_t go_
 // every row is written exactly once (zeros for a voxel without slots): no fill, no atomics, fixed summation order.
 // SHIFT = 3: slot = point * 8 + corner, row = point, weighted by w[slot].  SHIFT = 0 (second stage of the cell-reduced
 // form below): slot = row of a matrix of partial sums, weight 1.
-template <int SHIFT>
-__global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__restrict__ gout,
+template <int SHIFT, typename TG = float, typename TO = float>
+__global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const TG *__restrict__ gout,
                                                                  const float *__restrict__ w,
                                                                  const int *__restrict__ off,
                                                                  const int *__restrict__ ent, int64_t m, int c,
-                                                                 float *__restrict__ gfeat, int64_t go_ld) {
+                                                                 TO *__restrict__ gfeat, int64_t go_ld) {
   const int cq = c >> 2, groups = 256 / cq;
   const int grp = threadIdx.x / cq, lane = threadIdx.x - grp * cq;
   if (grp >= groups) return;
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       wt[u] = SHIFT ? w[s[u]] : 1.f;
-      g[u] = *(const float4 *)(gout + (int64_t)(s[u] >> SHIFT) * go_ld + 4 * lane);
+      g[u] = ld4(gout + (int64_t)(s[u] >> SHIFT) * go_ld + 4 * lane);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -538,10 +553,10 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *__
   for (; e < end; ++e) {
     const int s = ent[e];
     const float wt = SHIFT ? w[s] : 1.f;
-    const float4 g = *(const float4 *)(gout + (int64_t)(s >> SHIFT) * go_ld + 4 * lane);
+    const float4 g = ld4(gout + (int64_t)(s >> SHIFT) * go_ld + 4 * lane);
     acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
   }
-  *(float4 *)(gfeat + v * c + 4 * lane) = acc;
+  st4(gfeat + v * c + 4 * lane, acc);
 }
 
 extern "C" int ts_devoxelize_backward_csr(const float *grad_out, const float *weight, const int32_t *offsets,
@@ -605,7 +620,8 @@ extern "C" int ts_devox_segments(const int32_t *idx, const int32_t *order, int64
   return TS_OK;
 }
 
-__global__ __launch_bounds__(256) void devoxelize_bwd_cells_kernel(const float *__restrict__ gout,
+template <typename TG>
+__global__ __launch_bounds__(256) void devoxelize_bwd_cells_kernel(const TG *__restrict__ gout,
                                                                    const float *__restrict__ w,
                                                                    const int *__restrict__ order,
                                                                    const int *__restrict__ seg_start, int64_t n_seg,
@@ -622,8 +638,8 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_cells_kernel(const float *
   int p = beg;
   for (; p + 2 <= end; p += 2) {                       // two rows in flight
     const int i0 = order[p], i1 = order[p + 1];
-    const float4 g0 = *(const float4 *)(gout + (int64_t)i0 * go_ld + 4 * lane);
-    const float4 g1 = *(const float4 *)(gout + (int64_t)i1 * go_ld + 4 * lane);
+    const float4 g0 = ld4(gout + (int64_t)i0 * go_ld + 4 * lane);
+    const float4 g1 = ld4(gout + (int64_t)i1 * go_ld + 4 * lane);
     const float4 wa0 = *(const float4 *)(w + (int64_t)i0 * 8), wb0 = *(const float4 *)(w + (int64_t)i0 * 8 + 4);
     const float4 wa1 = *(const float4 *)(w + (int64_t)i1 * 8), wb1 = *(const float4 *)(w + (int64_t)i1 * 8 + 4);
     const float w0[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w};
@@ -639,7 +655,7 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_cells_kernel(const float *
   }
   for (; p < end; ++p) {
     const int i0 = order[p];
-    const float4 g0 = *(const float4 *)(gout + (int64_t)i0 * go_ld + 4 * lane);
+    const float4 g0 = ld4(gout + (int64_t)i0 * go_ld + 4 * lane);
     const float4 wa0 = *(const float4 *)(w + (int64_t)i0 * 8), wb0 = *(const float4 *)(w + (int64_t)i0 * 8 + 4);
     const float w0[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w};
 #pragma unroll
@@ -669,12 +685,78 @@ extern "C" int ts_devoxelize_backward_cells_ld(const float *grad_out, int64_t go
              TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_cells: rows must be 16-byte aligned");
   const int groups = 256 / (c >> 2);
   if (n_seg > 0) {
-    devoxelize_bwd_cells_kernel<<<(unsigned)ts_cdiv(n_seg, groups), 256, 0, stream>>>(grad_out, weight, order, seg_start,
-                                                                                     n_seg, c, part, go_ld);
+    devoxelize_bwd_cells_kernel<float><<<(unsigned)ts_cdiv(n_seg, groups), 256, 0, stream>>>(grad_out, weight, order,
+                                                                                            seg_start, n_seg, c, part, go_ld);
     TS_CHECK_LAUNCH("ts_devoxelize_backward_cells/partials");
   }
   devoxelize_bwd_csr_kernel<0><<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(part, nullptr, offsets, entries, m, c,
                                                                                 grad_feat, c);
   TS_CHECK_LAUNCH("ts_devoxelize_backward_cells/gather");
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ half-storage forms (the AMP path)
+// Point / voxel feature rows and their gradients stored as IEEE half, every sum in float32, one rounding at the store:
+// bit for bit what the float32 entry points give between a `.float()` of the inputs and a `.half()` of the result -
+// without those two passes over the matrices and with half the bytes gathered.  `void *` = half arrays, leading
+// dimensions in elements.  C % 4 == 0, rows 8-byte aligned.
+extern "C" int ts_devoxelize_forward_f16_ld(const void *feat, const int32_t *idx, const float *weight, int64_t n, int32_t c,
+                                            int64_t m, void *out, int64_t out_ld, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0 && out_ld >= c, TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_forward_f16: bad sizes");
+  TS_REQUIRE((c & 3) == 0 && (out_ld & 3) == 0, TS_ERR_UNSUPPORTED, "ts_devoxelize_forward_f16: C and ld must be multiples of 4");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(out && idx && weight && (feat || m == 0), TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_forward_f16: null pointer");
+  TS_REQUIRE(((((uintptr_t)feat) | ((uintptr_t)out)) & 7) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_forward_f16: rows must be 8-byte aligned");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n * (c / 4), 256), 16384);
+  devoxelize_fwd_kernel<4, _Float16><<<grid, 256, 0, stream>>>((const _Float16 *)feat, idx, weight, n, c, (_Float16 *)out,
+                                                               out_ld);
+  TS_CHECK_LAUNCH("ts_devoxelize_forward_f16");
+  return TS_OK;
+}
+
+extern "C" int ts_devoxelize_backward_csr_f16_ld(const void *grad_out, int64_t go_ld, const float *weight,
+                                                 const int32_t *offsets, const int32_t *entries, int64_t n, int32_t c,
+                                                 int64_t m, void *grad_feat, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && c > 0 && go_ld >= c && (go_ld & 3) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_csr_f16: bad sizes");
+  TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_csr_f16: C must be a multiple of 4, <= 1024");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(grad_feat && offsets && (n == 0 || (grad_out && weight && entries)), TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_csr_f16: null pointer");
+  TS_REQUIRE(((((uintptr_t)grad_out) | ((uintptr_t)grad_feat)) & 7) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_csr_f16: rows must be 8-byte aligned");
+  const int groups = 256 / (c >> 2);
+  devoxelize_bwd_csr_kernel<3, _Float16, _Float16><<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(
+      (const _Float16 *)grad_out, weight, offsets, entries, m, c, (_Float16 *)grad_feat, go_ld);
+  TS_CHECK_LAUNCH("ts_devoxelize_backward_csr_f16");
+  return TS_OK;
+}
+
+// `part` stays float32 (n_seg * 8 * c floats): only the two ends of the two-stage sum are half
+extern "C" int ts_devoxelize_backward_cells_f16_ld(const void *grad_out, int64_t go_ld, const float *weight,
+                                                   const int32_t *order, const int32_t *seg_start, int64_t n_seg,
+                                                   const int32_t *offsets, const int32_t *entries, int64_t n, int32_t c,
+                                                   int64_t m, float *part, void *grad_feat, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && m >= 0 && n_seg >= 0 && c > 0 && go_ld >= c && (go_ld & 3) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_devoxelize_backward_cells_f16: bad sizes");
+  TS_REQUIRE((c & 3) == 0 && c <= 1024, TS_ERR_UNSUPPORTED, "ts_devoxelize_backward_cells_f16: C must be a multiple of 4, <= 1024");
+  if (m == 0) return TS_OK;
+  TS_REQUIRE(grad_feat && offsets && (n_seg == 0 || (grad_out && weight && order && seg_start && entries && part)),
+             TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_cells_f16: null pointer");
+  TS_REQUIRE(((((uintptr_t)grad_out) | ((uintptr_t)grad_feat)) & 7) == 0 && ((((uintptr_t)part) | ((uintptr_t)weight)) & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "ts_devoxelize_backward_cells_f16: misaligned rows");
+  const int groups = 256 / (c >> 2);
+  if (n_seg > 0) {
+    devoxelize_bwd_cells_kernel<_Float16><<<(unsigned)ts_cdiv(n_seg, groups), 256, 0, stream>>>(
+        (const _Float16 *)grad_out, weight, order, seg_start, n_seg, c, part, go_ld);
+    TS_CHECK_LAUNCH("ts_devoxelize_backward_cells_f16/partials");
+  }
+  devoxelize_bwd_csr_kernel<0, float, _Float16><<<(unsigned)ts_cdiv(m, groups), 256, 0, stream>>>(
+      part, nullptr, offsets, entries, m, c, (_Float16 *)grad_feat, c);
+  TS_CHECK_LAUNCH("ts_devoxelize_backward_cells_f16/gather");
   return TS_OK;
 }

@@ -79,20 +79,30 @@ def spvoxelize(feats: torch.Tensor, coords: torch.Tensor, counts: torch.Tensor) 
 
 
 class _Devoxelize(Function):
-    """fp32 kernels; half result under autocast / for half features (devoxelize.py:54), fp32 accumulation."""
+    """fp32 kernels; half result under autocast / for half features (devoxelize.py:54), fp32 accumulation.  Half features
+    with an inverse map or cell plan as `order` go through the half-storage kernels (same bits, no cast passes)."""
 
     @staticmethod
     def forward(ctx, feats, idx, weights, order=None):
         half = _amp_half(feats)
         idx = idx.int().contiguous()
         weights = weights.contiguous().float()
+        stored_half = half and feats.dtype == torch.float16 and isinstance(order, tuple) and feats.shape[1] % 4 == 0 \
+            and feats.shape[1] <= 1024
+        ctx.saved = (idx, weights, feats.shape[0], order, feats.dtype, stored_half)
+        if stored_half:
+            out = torch.empty((idx.shape[0], feats.shape[1]), dtype=torch.float16, device=feats.device)
+            B.devoxelize_forward_into(feats.contiguous(), idx, weights, out, 0)
+            return out
         out = B.devoxelize_forward_cuda(feats.contiguous().float(), idx, weights)
-        ctx.saved = (idx, weights, feats.shape[0], order, feats.dtype)
         return out.half() if half else out
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, weights, m, order, dtype = ctx.saved
+        idx, weights, m, order, dtype, stored_half = ctx.saved
+        if stored_half and grad_out.dtype == torch.float16:
+            g = grad_out.contiguous()
+            return B.devoxelize_backward_from(g, 0, g.shape[1], idx, weights, m, order).to(dtype), None, None, None
         grad_out = grad_out.contiguous().float()
         if isinstance(order, tuple) and grad_out.shape[1] % 4 == 0 and grad_out.shape[1] <= 1024:
             # `order` is the inverse map (offsets, entries) of backend.devox_csr: gather per voxel, no atomics
@@ -115,26 +125,32 @@ def spdevoxelize(feats: torch.Tensor, coords: torch.Tensor, weights: torch.Tenso
 class _DevoxelizeCat(Function):
     """torch.cat([spdevoxelize(f_i, idx_i, w_i) for i], dim=1) as one node: every source is interpolated straight into its
     column block of the [N, sum C_i] result and the backward pass reads the gradient blocks in place - no concatenation
-    copy, no contiguous copies of gradient slices (MinkUNet's z1 | z2 | z3 -> class head, minkunet.py:419-421)."""
+    copy, no contiguous copies of gradient slices (MinkUNet's z1 | z2 | z3 -> class head, minkunet.py:419-421).
+    Half features (the AMP path) stay half on both sides of the kernels - float32 sums, one rounding, the bits of the
+    float32 kernels between `.float()` and `.half()` - when every source has an inverse map or a cell plan."""
 
     @staticmethod
     def forward(ctx, maps, *feats):
         half = _amp_half(feats[0])
         n = maps[0][0].shape[0]
         cs = [f.shape[1] for f in feats]
-        out = torch.empty((n, sum(cs)), dtype=torch.float32, device=feats[0].device)
+        stored_half = half and all(f.dtype == torch.float16 for f in feats) and all(isinstance(o, tuple) for _, _, o in maps)
+        out = torch.empty((n, sum(cs)), dtype=torch.float16 if stored_half else torch.float32, device=feats[0].device)
         col = 0
         for f, (idx, w, _order), c in zip(feats, maps, cs):
-            B.devoxelize_forward_into(f.contiguous().float(), idx, w, out, col)
+            B.devoxelize_forward_into(f.contiguous() if stored_half else f.contiguous().float(), idx, w, out, col)
             col += c
         ctx.maps, ctx.cs = maps, cs
         ctx.rows = [f.shape[0] for f in feats]
         ctx.dtypes = [f.dtype for f in feats]
-        return out.half() if half else out
+        ctx.stored_half = stored_half
+        return out.half() if half and not stored_half else out
 
     @staticmethod
     def backward(ctx, grad_out):
-        g = grad_out.contiguous().float()
+        g = grad_out.contiguous()
+        if not (ctx.stored_half and g.dtype == torch.float16):
+            g = g.float()
         grads, col = [], 0
         for i, ((idx, w, order), c) in enumerate(zip(ctx.maps, ctx.cs)):
             if ctx.needs_input_grad[1 + i]:

@@ -131,3 +131,47 @@ def test_flat_sgd_matches_torch_sgd_clip_and_gradscaler(amp):
     # every tensor starts on a 64-byte boundary of its flat bucket (the 7-element bias must not misalign its successors:
     # the BatchNorm kernels take parameter pointers and require 16-byte alignment)
     assert all(p.data_ptr() % 64 == 0 and p.grad.data_ptr() % 64 == 0 for p in b.parameters())
+
+
+@pytest.mark.parametrize("stride,plan_kind", [(1, "csr"), (4, "csr"), (16, "cells")])
+def test_half_devoxelize_gives_the_bits_of_the_float_kernels(stride, plan_kind):
+    """ts_devoxelize_forward_f16_ld / ts_devoxelize_backward_{csr,cells}_f16_ld: half rows in and out, float32 sums, one
+    rounding - bit for bit the float32 kernels between `.float()` and `.half()`, for the single op and for the
+    concatenating node, forward and backward."""
+    from taseg_amd import backend as B
+    from taseg_amd.torchsparse.nn import functional as F
+    pts, _ = synth_scan(5, n_points=50000, n_beams=64, n_az=1000)
+    pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+    pc -= pc.min(0)
+    coords = np.unique(np.concatenate([pc // stride * stride, np.zeros((len(pc), 1), np.int32)], 1), axis=0)
+    pcf = torch.from_numpy(np.concatenate([pc.astype(np.float32), np.zeros((len(pc), 1), np.float32)], 1)).cuda()
+    idx, w = B.trilinear_map(pcf, torch.from_numpy(coords).cuda(), stride)
+    m, n = len(coords), len(pc)
+    plan = B.devox_cells(idx, w, m) if plan_kind == "cells" else B.devox_csr(idx, w, m)
+    rs = np.random.RandomState(stride)
+    for c in (32, 96):
+        feat = torch.from_numpy(rs.randn(m, c).astype(np.float32)).cuda().half()
+        gout = torch.from_numpy(rs.randn(n, c).astype(np.float32)).cuda().half()
+        # the float32 kernels around casts
+        want = B.devoxelize_forward_cuda(feat.float(), idx, w).half()
+        want_g = B.devoxelize_backward_from(gout.float(), 0, c, idx, w, m, plan).half()
+        a = feat.clone().requires_grad_()
+        got = F.spdevoxelize(a, idx, w, plan)
+        assert got.dtype == torch.float16 and torch.equal(got, want)
+        got.backward(gout)
+        assert a.grad.dtype == torch.float16 and torch.equal(a.grad, want_g)
+    # the concatenating node: two sources into one half matrix, gradient blocks read in place
+    f1 = torch.from_numpy(rs.randn(m, 32).astype(np.float32)).cuda().half().requires_grad_()
+    f2 = torch.from_numpy(rs.randn(m, 64).astype(np.float32)).cuda().half().requires_grad_()
+    out = F.spdevoxelize_cat([f1, f2], [(idx, w, plan), (idx, w, plan)])
+    assert out.dtype == torch.float16 and out.shape == (n, 96)
+    assert torch.equal(out[:, :32], B.devoxelize_forward_cuda(f1.detach().float(), idx, w).half())
+    assert torch.equal(out[:, 32:], B.devoxelize_forward_cuda(f2.detach().float(), idx, w).half())
+    g = torch.from_numpy(rs.randn(n, 96).astype(np.float32)).cuda().half()
+    out.backward(g)
+    assert torch.equal(f1.grad, B.devoxelize_backward_from(g.float(), 0, 32, idx, w, m, plan).half())
+    assert torch.equal(f2.grad, B.devoxelize_backward_from(g.float(), 32, 64, idx, w, m, plan).half())
+    # without a plan the op keeps the float kernels and still returns half
+    b = f1.detach().clone().requires_grad_()
+    plain = F.spdevoxelize(b, idx, w)
+    assert plain.dtype == torch.float16 and torch.equal(plain, out[:, :32])
