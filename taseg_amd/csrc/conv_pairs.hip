@@ -822,6 +822,79 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
   }
 }
 
+// Pass 2 with the live positions of a row compacted in LDS first: a workgroup owns 256 / (C / 4) whole rows; half-waves
+// load the K positions of a row (lane = offset), ballot the live ones and leave them - ascending offset, the fixed
+// summation order - as a list in LDS; then a lane walks its row's list with R independent 16-byte loads per round.
+// Against gather_sum_kernel<4, K>: one position load per lane instead of K, only live rows requested, R + a few instead
+// of 5 K registers (8 instead of 3 waves per SIMD).  Same additions in the same order: bit-identical sums.  K <= 32.
+template <int R>
+__global__ __launch_bounds__(256) void gather_list_kernel(const float *__restrict__ Z, int C,
+                                                          const int *__restrict__ pos, int K, int64_t n,
+                                                          int64_t n_pairs, float *__restrict__ out, TsWgradReduce side,
+                                                          const float *__restrict__ addend, int rpw) {
+  __shared__ int lst[64][33];
+  __shared__ int cnt[64];
+  const int tid = threadIdx.x;
+  {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + tid, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = e; i < (int64_t)side.K * side.cacb4; i += step) ts_wgrad_reduce_one(side, i);
+  }
+  const int64_t j0 = (int64_t)blockIdx.x * rpw;
+  const int hw = tid >> 5, l = tid & 31;
+  for (int base = 0; base < rpw; base += 8) {          // uniform trip count: the ballot below needs every lane
+    const int r = base + hw;
+    const int64_t j = j0 + r;
+    int p = -1;
+    if (r < rpw && j < n && l < K) p = pos[(int64_t)l * n + j];
+    const bool live = p >= 0 && p < n_pairs;
+    const unsigned long long m64 = __builtin_amdgcn_ballot_w64(live);
+    const unsigned m = (tid & 32) ? (unsigned)(m64 >> 32) : (unsigned)m64;
+    if (live) lst[r][__builtin_popcount(m & ((1u << l) - 1u))] = p;
+    if (l == 0 && r < rpw) cnt[r] = __builtin_popcount(m);
+  }
+  __syncthreads();
+  const int cv = C >> 2;
+  const int r = tid / cv;
+  const int64_t j = j0 + r;
+  if (r >= rpw || j >= n) return;
+  const int c = (tid - r * cv) << 2;
+  const int m = cnt[r];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = 0; b < m; b += R) {
+    float4 f[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      f[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b + i < m) f[i] = TS_ZLOAD((const float4 *)(Z + (int64_t)lst[r][b + i] * C + c));
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      acc.x += f[i].x;
+      acc.y += f[i].y;
+      acc.z += f[i].z;
+      acc.w += f[i].w;
+    }
+  }
+  if (addend) {
+    const float4 a = *(const float4 *)(addend + j * C + c);
+    acc.x += a.x;
+    acc.y += a.y;
+    acc.z += a.z;
+    acc.w += a.w;
+  }
+  *(float4 *)(out + j * C + c) = acc;
+}
+
+static int launch_gather_list(const float *z, int c, const int *pos, int K, int64_t n_rows, int64_t n_pairs, float *out,
+                              const TsWgradReduce &side, const float *addend, hipStream_t stream) {
+  const int cv = c >> 2, rpw = 256 / cv;
+  const unsigned grid = (unsigned)ts_cdiv(n_rows, rpw);
+  // R = 4 / 8 / 12 / 16 measured within 3 % of each other on every layer (profiles/r02_v9_gather_forms_probe.txt)
+  gather_list_kernel<8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend, rpw);
+  TS_CHECK_LAUNCH("conv_gather_sum (list)");
+  return TS_OK;
+}
+
 extern "C" int ts_conv_gather_sum(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                   int64_t n_pairs, float *out, ts_stream_t stream_) {
   return ts_conv_gather_sum_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, nullptr, stream_);
@@ -839,6 +912,11 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
   if (n_rows == 0) return TS_OK;
   TS_REQUIRE(pos && out && (z || n_pairs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum: null pointer");
   const bool vec = (c % 4 == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
+  // default: live positions compacted in LDS first (gather_list_kernel); TASEG_GATHER_POSITIONS=1 in the environment
+  // keeps the K-register form (A/B runs)
+  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  if (vec && K <= 32 && c >= 16 && c <= 1024 && !k_registers && g_ts_conv_impl != 1)
+    return launch_gather_list(z, c, pos, K, n_rows, n_pairs, out, side, addend, stream);
   if (vec) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 4), 256), 1 << 20);
     if (K == 27)

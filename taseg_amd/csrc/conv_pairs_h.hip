@@ -309,6 +309,64 @@ __global__ __launch_bounds__(256) void gather_sum_h_kernel(const _Float16 *__res
   }
 }
 
+// The list form of pass 2 (gather_list_kernel, conv_pairs.hip) for half rows: a workgroup owns 256 / (C / 8) whole rows,
+// half-waves compact the live positions of a row into LDS (lane = offset, ballot), a lane walks its row's list with R
+// independent 16-byte loads per round.  float32 sums in ascending offset order, one rounding: the bits of
+// gather_sum_h_kernel.  K <= 32, C >= 64.
+template <int R>
+__global__ __launch_bounds__(256) void gather_list_h_kernel(const _Float16 *__restrict__ Z, int C,
+                                                            const int *__restrict__ pos, int K, int64_t n,
+                                                            _Float16 *__restrict__ out, TsWgradReduce side,
+                                                            const _Float16 *__restrict__ addend, int rpw) {
+  __shared__ int lst[64][33];
+  __shared__ int cnt[64];
+  const int tid = threadIdx.x;
+  {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + tid, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = e; i < (int64_t)side.K * side.cacb4; i += step) ts_wgrad_reduce_one(side, i);
+  }
+  const int64_t j0 = (int64_t)blockIdx.x * rpw;
+  const int hw = tid >> 5, l = tid & 31;
+  for (int base = 0; base < rpw; base += 8) {          // uniform trip count: the ballot below needs every lane
+    const int r = base + hw;
+    const int64_t j = j0 + r;
+    int p = -1;
+    if (r < rpw && j < n && l < K) p = pos[(int64_t)l * n + j];
+    const bool live = p >= 0;
+    const unsigned long long m64 = __builtin_amdgcn_ballot_w64(live);
+    const unsigned m = (tid & 32) ? (unsigned)(m64 >> 32) : (unsigned)m64;
+    if (live) lst[r][__builtin_popcount(m & ((1u << l) - 1u))] = p;
+    if (l == 0 && r < rpw) cnt[r] = __builtin_popcount(m);
+  }
+  __syncthreads();
+  const int c8n = C >> 3;
+  const int r = tid / c8n;
+  const int64_t j = j0 + r;
+  if (r >= rpw || j >= n) return;
+  const int c8 = (tid - r * c8n) << 3;
+  const int m = cnt[r];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < m; b += R) {
+    h8 v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+      v[i] = b + i < m ? __builtin_nontemporal_load((const h8 *)(Z + (int64_t)lst[r][b + i] * C + c8)) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += (float)v[i][q];
+  }
+  if (addend) {
+    const h8 a = *(const h8 *)(addend + j * C + c8);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += (float)a[q];
+  }
+  h8 o;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) o[q] = (_Float16)acc[q];
+  *(h8 *)(out + j * C + c8) = o;
+}
+
 extern "C" int ts_conv_gather_sum_f16(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows,
                                       int64_t n_pairs, void *out, ts_stream_t stream_) {
   return ts_conv_gather_sum_f16_ex(z, c, pos, K, n_rows, n_pairs, out, nullptr, nullptr, stream_);
@@ -328,8 +386,17 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
   TS_REQUIRE(pos && out && (z || n_pairs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_gather_sum_f16: null pointer");
   TS_REQUIRE(((((uintptr_t)z) | ((uintptr_t)out)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_gather_sum_f16: pointers must be 16-byte aligned");
-  const int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 8), 256), 1 << 20);
   const _Float16 *zz = (const _Float16 *)z;
+  // default: live positions compacted in LDS first; TASEG_GATHER_POSITIONS=1 keeps the K-register form (A/B runs)
+  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  if (K <= 32 && c >= 64 && c <= 2048 && !k_registers) {   // 32 channels: 64 rows per workgroup, the list build costs more than it saves
+    const int rpw = 256 / (c >> 3);
+    gather_list_h_kernel<8><<<(unsigned)ts_cdiv(n_rows, rpw), 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side,
+                                                                                (const _Float16 *)addend, rpw);
+    TS_CHECK_LAUNCH("ts_conv_gather_sum_f16 (list)");
+    return TS_OK;
+  }
+  const int grid = (int)std::min<int64_t>(ts_cdiv(n_rows * (c / 8), 256), 1 << 20);
   if (K == 27)
     gather_sum_h_kernel<27><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side, (const _Float16 *)addend);
   else if (K == 8)
