@@ -557,6 +557,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     records = B.profile_end()
+    # what an event pair measures with nothing between its two records, after the timed region: the per-launch figures
+    # below are NOT corrected by it (in the flow of a step the bracket costs less: rocprofv3 puts the dominant kernel
+    # ~3 us below its event figure, the idle-stream bracket reads ~4.7 us) - it is reported as context for that gap
+    bracket_us = B.profile_empty_bracket_us() if records else 0.0
     profiled_steps = len(range(0, args.steps, EVENT_EVERY))
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -605,6 +609,7 @@ def main():
                 entry = json.load(open(tpath)).get(dom["kernel"])
                 traffic = entry["hbm_bytes_per_launch"] if entry else None
             roofline.update(traffic=traffic, kernel=dom["kernel"], avg_us=dom["avg_us"],
+                            event_bracket_us=bracket_us,
                             launches_per_step=dom["launches_per_step"],
                             algorithmic_bytes_per_launch=dom["bytes_per_launch"],
                             algorithmic_flops_per_launch=dom["flops_per_launch"])

@@ -488,6 +488,9 @@ int ts_conv_block_backward(const void *grad_out, const uint8_t *mask, const void
 void ts_prof_enable(int32_t on);
 int ts_prof_reserve(int64_t n_events);
 int64_t ts_prof_collect(double *records, int64_t capacity);
+/* microseconds an event pair measures with nothing between its two records (median of `reps` pairs back to back on
+ * `stream`): the bracket's own share of every per-launch figure above */
+int ts_prof_empty_bracket_us(int32_t reps, ts_stream_t stream, double *out_us);
 
 /* Debug / cross-check implementation selector: 0 = MFMA kernels (default; full-tile fp32 GEMMs run on the bf16 matrix
  * pipe through the exact three-way operand split of csrc/conv_pairs_s.hip), 5 = the same with v_mfma_f32_16x16x4_f32,

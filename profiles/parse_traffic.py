@@ -37,7 +37,7 @@ if __name__ == "__main__":
     write, n2 = collect(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("pair_gemm", "gather_sum", "wgrad_gemm", "wgrad_s", "bn_", "conv_nbr", "kmap_",
+        if not any(s in k for s in ("pair_gemm", "gather_sum", "gather_list", "wgrad_gemm", "wgrad_s", "bn_", "conv_nbr", "kmap_",
                                     "devoxelize", "voxelize", "trilinear", "table_", "hash_kernel", "devox_")):
             continue
         f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)

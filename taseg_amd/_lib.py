@@ -109,6 +109,7 @@ SIGNATURES = {
     "ts_prof_enable": (None, [_i32]),
     "ts_prof_reserve": (_i32, [_i64]),
     "ts_prof_collect": (_i64, [_vp, _i64]),
+    "ts_prof_empty_bracket_us": (_i32, [_i32, _vp, _vp]),
     "ts_set_conv_impl": (None, [_i32]),
     "ts_softmax_ce_forward": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ts_ce_lovasz_finish": (_i32, [_vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),

@@ -384,6 +384,18 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
     return dict(nbr=nbr, nbr_t=nbr_t, nbmaps=nbmaps, nbsizes=nbsizes, nboffs=nboffs, pos_out=pos_out, pos_in=pos_in)
 
 
+def gather_sum_kernel_name(c, k, half=False):
+    """The kernel ts_conv_gather_sum[_f16] launches for rows of c channels and K = k offsets (csrc/conv_pairs{,_h}.hip)."""
+    import os
+    lists = not os.environ.get("TASEG_GATHER_POSITIONS")
+    kt = k if k in (8, 27) else 0
+    if half:
+        return "gather_list_h_kernel<8>" if lists and k <= 32 and 64 <= c <= 2048 else f"gather_sum_h_kernel<{kt}>"
+    if c % 4:
+        return "gather_sum_kernel<1,0>"
+    return "gather_list_kernel<8>" if lists and k <= 32 and 16 <= c <= 1024 else f"gather_sum_kernel<4,{kt}>"
+
+
 planes_in_use = False        # set by bench.py when the run's convolutions go through taseg_amd.planes (kernel naming only)
 
 
@@ -428,7 +440,7 @@ def conv_gather_sum(z, pos, n_rows):
     if pos.shape != (k, n_rows):
         raise ValueError(f"position table shape {tuple(pos.shape)} != {(k, n_rows)}")
     out = torch.empty((n_rows, z.shape[1]), dtype=torch.float32, device=z.device)
-    with _Timed("gather_sum", name=(f"gather_sum_kernel<4,{k if k in (8, 27) else 0}>" if z.shape[1] % 4 == 0 else "gather_sum_kernel<1,0>"),
+    with _Timed("gather_sum", name=gather_sum_kernel_name(z.shape[1], k),
                 pairs=z.shape[0], c_red=0, c_out=z.shape[1], k=k, n_rows=n_rows):
         L.check(L.load().ts_conv_gather_sum(L.ptr(z), z.shape[1], L.ptr(pos), k, n_rows, z.shape[0], L.ptr(out),
                                             L.stream()), "ts_conv_gather_sum")
@@ -483,7 +495,7 @@ def conv_gather_sum_f16(z, pos, n_rows):
     if pos.shape != (k, n_rows):
         raise ValueError(f"position table shape {tuple(pos.shape)} != {(k, n_rows)}")
     out = torch.empty((n_rows, z.shape[1]), dtype=torch.float16, device=z.device)
-    with _Timed("gather_sum", name=f"gather_sum_h_kernel<{k if k in (8, 27) else 0}>", pairs=z.shape[0], c_red=0,
+    with _Timed("gather_sum", name=gather_sum_kernel_name(z.shape[1], k, half=True), pairs=z.shape[0], c_red=0,
                 c_out=z.shape[1], k=k, n_rows=n_rows, esize=2):
         L.check(L.load().ts_conv_gather_sum_f16(L.ptr(z), z.shape[1], L.ptr(pos), k, n_rows, z.shape[0], L.ptr(out),
                                                 L.stream()), "ts_conv_gather_sum_f16")
@@ -562,6 +574,15 @@ class _Ms:
         return self.ms
 
 
+def profile_empty_bracket_us(reps=200):
+    """Microseconds an event pair measures with nothing between its two records on the current stream (median of `reps`):
+    the bracket's own share of every per-launch figure profile_end() returns."""
+    import ctypes
+    out = ctypes.c_double(0.0)
+    L.check(L.load().ts_prof_empty_bracket_us(int(reps), L.stream(), ctypes.byref(out)), "ts_prof_empty_bracket_us")
+    return float(out.value)
+
+
 def profile_end():
     """[(kind, start, stop, meta)] of the bracketed launches: the Python wrappers' torch events and the records of the
     fused block calls (`ts_prof_collect`)."""
@@ -586,8 +607,7 @@ def profile_end():
             out.append(("pair_gemm", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k, esize=esize,
                                                          n_rows=rows)))
         elif int(kind) == 1:
-            name = (f"gather_sum_h_kernel<{k if k in (8, 27) else 0}>" if half else
-                    f"gather_sum_kernel<4,{k if k in (8, 27) else 0}>" if c_out % 4 == 0 else "gather_sum_kernel<1,0>")
+            name = gather_sum_kernel_name(c_out, k, half)
             out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,
                                                           esize=esize, side_bytes=float(wt))))
         else:

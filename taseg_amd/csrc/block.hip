@@ -116,6 +116,31 @@ extern "C" int64_t ts_prof_collect(double *records, int64_t capacity) {
   return n;
 }
 
+// what an event pair measures with NOTHING between its two records (microseconds, median of `reps` pairs recorded back
+// to back on `stream`): the part of every bracketed launch's elapsed time that is the bracket's own - bench.py subtracts
+// it from the per-launch figures and reports it next to them
+extern "C" int ts_prof_empty_bracket_us(int32_t reps, ts_stream_t stream_, double *out_us) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(reps > 0 && reps <= 4096 && out_us, TS_ERR_INVALID_ARGUMENT, "ts_prof_empty_bracket_us: bad arguments");
+  std::vector<hipEvent_t> ev(2 * (size_t)reps, nullptr);
+  for (auto &e : ev) {
+    e = prof_event();
+    TS_REQUIRE(e, TS_ERR_LAUNCH_FAILED, "ts_prof_empty_bracket_us: hipEventCreate failed");
+  }
+  for (auto &e : ev) TS_CHECK_HIP(hipEventRecord(e, stream), "hipEventRecord");
+  TS_CHECK_HIP(hipEventSynchronize(ev.back()), "hipEventSynchronize");
+  std::vector<double> us;
+  for (int i = 0; i < reps; ++i) {
+    float ms = 0.f;
+    TS_CHECK_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]), "hipEventElapsedTime");
+    us.push_back(1e3 * ms);
+  }
+  std::sort(us.begin(), us.end());
+  *out_us = us[us.size() / 2];
+  for (auto &e : ev) g_prof_pool.push_back(e);
+  return TS_OK;
+}
+
 // The caller's one-shot hint of pre-split weight planes (ts_conv_planes_hint) belongs to the block call as a whole: taken
 // at entry, handed to the one fp32 pair GEMM of the call, gone when the call returns - whichever path it took.
 // The gradient that reaches the block's input along another path (the shortcut of a residual block, when the block passes
