@@ -389,7 +389,7 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
   const _Float16 *zz = (const _Float16 *)z;
   // default: live positions compacted in LDS first; TASEG_GATHER_POSITIONS=1 keeps the K-register form (A/B runs)
   static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
-  if (K <= 32 && c >= 64 && c <= 2048 && !k_registers) {   // 32 channels: 64 rows per workgroup, the list build costs more than it saves
+  if (K <= 32 && c >= 64 && c <= 2048 && !k_registers && g_ts_conv_impl != 1) {   // 32 channels: 64 rows per workgroup, the list build costs more than it saves
     const int rpw = 256 / (c >> 3);
     gather_list_h_kernel<8><<<(unsigned)ts_cdiv(n_rows, rpw), 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side,
                                                                                 (const _Float16 *)addend, rpw);

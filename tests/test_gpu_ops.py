@@ -1003,3 +1003,37 @@ def test_fused_ce_lovasz_loss_matches_the_tensor_form_and_the_oracle(monkeypatch
         monkeypatch.setattr(LS, "_FUSED", True)
         one = LS.Losses(["CELoss", "LovLoss"], [1.0, 1.0], ignore_index=0, label_smoothing=smoothing)(logits, labels)
         assert abs(float(one) - float(ref)) <= 5e-6 * max(1.0, abs(float(ref)))
+
+
+@pytest.mark.parametrize("k,n,c", [(27, 10007, 96), (27, 4099, 128), (27, 257, 256), (8, 5003, 64), (27, 3001, 32), (27, 1500, 20),
+                                   (27, 700, 16), (1, 2000, 96), (27, 9, 1024)])
+def test_gather_sum_list_form_gives_the_bits_of_the_register_form(B, k, n, c):
+    """Pass 2 of the convolution: gather_list_kernel (live positions compacted in LDS, the default) against
+    gather_sum_kernel (K position registers per lane; what ts_set_conv_impl(1) keeps) - the same additions in the same
+    order, so the same bits; rows without any position, positions at both ends of Z, a ragged last workgroup; fp32 rows and
+    (C >= 64) half rows."""
+    rs = np.random.RandomState(k * 1000 + c)
+    p = int(0.3 * k * n) + 1
+    pos = np.full((k, n), -1, dtype=np.int32)
+    flat = rs.permutation(k * n)[:p]
+    pos.reshape(-1)[flat] = rs.permutation(p).astype(np.int32)          # every Z row used exactly once
+    pos[:, n // 2] = -1                                                   # a row with no neighbour at all
+    z = T(rs.randn(p, c).astype(np.float32))
+    pos_t = T(pos)
+    try:
+        B.set_conv_impl(1)
+        want = B.conv_gather_sum(z, pos_t, n)
+        want_h = B.conv_gather_sum_f16(z.half(), pos_t, n) if c % 8 == 0 else None
+    finally:
+        B.set_conv_impl(0)
+    got = B.conv_gather_sum(z, pos_t, n)
+    assert torch.equal(got, want)
+    assert float(got[n // 2].abs().max()) == 0.0 or bool((pos[:, n // 2] >= 0).any())
+    ref = np.zeros((n, c), np.float32)
+    zz = z.cpu().numpy()
+    for kk in range(k):
+        live = pos[kk] >= 0
+        ref[live] += zz[pos[kk][live]]
+    close(got, ref, 1e-5)
+    if want_h is not None:
+        assert torch.equal(B.conv_gather_sum_f16(z.half(), pos_t, n), want_h)
