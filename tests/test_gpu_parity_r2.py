@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, strided_sample  # noqa: E402
 
 LOGIT_TOL = 1e-3          # north_star: per-point logits within 1e-3 of the reference
+GRAD_TOL = 1e-3           # every parameter gradient (norm and sampled entries, relative L2) against the float64 evaluation
 
 
 def _load(name):
@@ -64,14 +65,13 @@ def test_mk34_cr10_vs_reference_and_fp64(name, in_dim, key, fname, training):
     n64, n32 = g["oracle64_" + tag + "gradnorms"], g["ref32_" + tag + "gradnorms"]
     ours = np.abs(norms - n64) / np.maximum(n64, 1e-30)
     refs = np.abs(n32 - n64) / np.maximum(n64, 1e-30)
-    # gradients (all 380 norms, 24 sampled tensors) within 2e-3 of the float64 evaluation - or, where that is larger,
-    # within twice the fp32 noise level of this network, measured as the REFERENCE's own worst distance to the float64
-    # gradients: train-mode BatchNorm over ~40 layers amplifies rounding differences of ANY fp32 evaluation chaotically
-    # (the reference is 1e-3 .. 8e-3 away on the early layers; on running statistics the level is 4e-5 and the 2e-3 bar
-    # applies as is)
+    # gradients (all 380 norms, 24 sampled tensors) within GRAD_TOL = 1e-3 of the float64 evaluation (measured: 3.7e-4 norms,
+    # 4.7e-4 sampled tensors, worst case, train mode).  For scale: the REFERENCE's own fp32 gradients sit 1e-3 .. 8e-3 from
+    # float64 on the early layers in train mode (train-mode BatchNorm over ~40 layers amplifies rounding differences of any
+    # fp32 evaluation) - `noise` below is printed as context, it no longer widens the bar
     noise = max(np.linalg.norm(g[k] - g[k.replace("ref32_", "oracle64_")]) / np.linalg.norm(g[k.replace("ref32_", "oracle64_")])
                 for k in g if k.startswith("ref32_" + tag + "grad/"))
-    assert (ours <= max(2e-3, 2 * noise)).all(), \
+    assert (ours <= GRAD_TOL).all(), \
         [(names[i], ours[i], refs[i]) for i in np.argsort(-ours)[:5]]
     worst = (0.0, 0.0, "")
     for k in [k for k in g if k.startswith("oracle64_" + tag + "grad/")]:
@@ -81,7 +81,7 @@ def test_mk34_cr10_vs_reference_and_fp64(name, in_dim, key, fname, training):
         e_ours = np.linalg.norm(got - want) / np.linalg.norm(want)
         e_ref = np.linalg.norm(ref - want) / np.linalg.norm(want)
         worst = max(worst, (e_ours, e_ref, pname))
-        assert e_ours <= max(2e-3, 2 * noise), (pname, e_ours, e_ref, noise)
+        assert e_ours <= GRAD_TOL, (pname, e_ours, e_ref, noise)
     if training:        # running statistics after one training-mode forward
         bufs = dict(model.named_buffers())
         for k in [k for k in g if k.startswith("ref32_train_stat/")]:
