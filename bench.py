@@ -280,7 +280,8 @@ def cpu_baseline(args, cfg_name, in_dim):
 
 def summarise_profile(records, steps):
     """Per kernel instantiation: launches, mean duration, algorithmic flops / bytes (SURVEY.md section 8(d):
-    flops = 2 P Cin Cout per pass; bytes = P (Cin s + 2 Cout s + 8) + K Cin Cout s, s = 4)."""
+    flops = 2 P Cin Cout per pass; bytes of a forward / input-gradient pass = P (Cin s + 2 Cout s + 8) + K Cin Cout s,
+    s = 4, split over its two launches; a weight gradient reads P (Cin + Cout) s + 8 P and writes K Cin Cout 4)."""
     pairs_cache = {}
     groups = {}
     for kind, e0, e1, m in records:
@@ -304,8 +305,10 @@ def summarise_profile(records, steps):
         elif kind == "gather_sum":   # Z read + output write + position table       (second half)
             flops = float(p * m["c_out"])
             byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4 + m.get("side_bytes", 0.0)
-        else:
-            byts = p * (m["c_red"] * es + 2 * m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+        elif kind == "conv_wgrad":   # both gathered operands + rulebook + the gradient written once (no scatter term)
+            byts = p * (m["c_red"] * es + m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+        else:                        # single-launch forms (conv_nbr, conv_os): gather read + output rows + table + weights
+            byts = p * (m["c_red"] * es + 8) + m.get("n_out", m.get("n_rows", 0)) * m["c_out"] * es + m["k"] * m["c_red"] * m["c_out"] * es
         # ideal-fused lower bound of the same launch: every feature row read / written once, the
         # rulebook and the weights once - no per-pair traffic (pair GEMM + gather-sum together make one convolution pass)
         rows = m.get("n_rows", 0)
@@ -334,6 +337,102 @@ def summarise_profile(records, steps):
     return out
 
 
+FAMILIES = (("pair_gemm", "pair GEMM (pass 1: gather -> per-offset GEMM -> Z)"),
+            ("gather", "gather-sum (pass 2: Z rows -> output rows)"),
+            ("wgrad", "weight gradient"),
+            ("conv_os", "output-stationary fused convolution"),
+            ("conv_nbr", "neighbour-table convolution"))
+
+
+def family_of(kernel):
+    for prefix, _ in FAMILIES:
+        if kernel.startswith(prefix):
+            return prefix
+    return kernel.split("<", 1)[0]
+
+
+def mfma_peak_of(kernel, amp):
+    """dense peak the instantiation's matrix instructions are priced against (MI355X_MICROARCH.md): f16 MFMA for the
+    half-storage kernels, 2500 / 6 for fp32 products as six bf16 MFMAs, the f32 MFMA otherwise"""
+    if amp or "_h_kernel" in kernel:
+        return MFMA_F16_PEAK_TF
+    if any(t in kernel for t in ("_s_kernel", "_d_kernel", "conv_os")):
+        return MFMA_SPLIT_PEAK_TF
+    return MFMA_F32_PEAK_TF
+
+
+def summarise_families(prof, amp, traffic_table):
+    """Instantiations grouped by kernel family: time share, launches, algorithmic flops and bytes, BOTH roofline
+    fractions (matrix pipe and HBM), PMC traffic where every member has a traffic.json entry."""
+    fams = {}
+    for r in prof:
+        f = fams.setdefault(family_of(r["kernel"]), {"ms_per_step": 0.0, "launches_per_step": 0.0, "flops": 0.0, "bytes": 0.0,
+                                                     "ideal": 0.0, "t_mfma": 0.0, "members": [], "traffic": 0.0, "traffic_ok": True})
+        f["ms_per_step"] += r["ms_per_step"]
+        f["launches_per_step"] += r["launches_per_step"]
+        f["flops"] += r["flops_per_launch"] * r["launches_per_step"]
+        f["bytes"] += r["bytes_per_step"]
+        f["ideal"] += r["ideal_fused_bytes_per_step"]
+        f["t_mfma"] += r["flops_per_launch"] * r["launches_per_step"] / (mfma_peak_of(r["kernel"], amp) * 1e12)
+        f["members"].append(r["kernel"])
+        entry = traffic_table.get(r["kernel"])
+        if entry is None:
+            f["traffic_ok"] = False
+        else:
+            f["traffic"] += entry["hbm_bytes_per_launch"] * r["launches_per_step"]
+    out = []
+    for name, f in fams.items():
+        sec = f["ms_per_step"] / 1e3
+        gemm = name not in ("gather",)
+        tf = f["flops"] / sec / 1e12
+        gbs = f["bytes"] / sec / 1e9
+        peak_tf = f["flops"] / f["t_mfma"] / 1e12 if f["t_mfma"] > 0 else None      # launch-weighted peak of the members
+        out.append({"family": name, "ms_per_step": f["ms_per_step"], "launches_per_step": f["launches_per_step"],
+                    "avg_us": 1e3 * f["ms_per_step"] / f["launches_per_step"],
+                    "flops_per_step": f["flops"], "bytes_per_step": f["bytes"], "ideal_fused_bytes_per_step": f["ideal"],
+                    "tflops": tf if gemm else None, "mfma_peak_tflops": peak_tf if gemm else None,
+                    "mfma_frac": (tf / peak_tf) if gemm and peak_tf else None,
+                    "gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                    "traffic_bytes_per_launch": (f["traffic"] / f["launches_per_step"]) if f["traffic_ok"] else None,
+                    "kernels": f["members"]})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def build_roofline(prof, amp, bracket_us):
+    """The `roofline` object of the JSON line: the kernel FAMILY with the largest share of the step's convolution time
+    (all its instantiations together), bound = the larger of its matrix-pipe and HBM times at peak, both fractions stated;
+    `families` lists the same for every family; `whole_step_lower_bound_ms` = max(ideal-fused bytes / HBM peak,
+    GEMM flops / matrix peak) of the step's convolution work."""
+    if not prof:
+        return None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    fams = summarise_families(prof, amp, table)
+    dom = fams[0]
+    per_launch_bytes = dom["bytes_per_step"] / dom["launches_per_step"]
+    per_launch_flops = dom["flops_per_step"] / dom["launches_per_step"]
+    t_hbm = dom["bytes_per_step"] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = dom["flops_per_step"] / (dom["mfma_peak_tflops"] * 1e12) if dom["mfma_peak_tflops"] else 0.0
+    if t_mfma >= t_hbm:
+        roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": dom["mfma_peak_tflops"], "unit": "TFLOP/s",
+                "frac": dom["mfma_frac"]}
+    else:
+        roof = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"]}
+    gemm_t = sum(f["flops_per_step"] / (f["mfma_peak_tflops"] * 1e12) for f in fams if f["mfma_peak_tflops"])
+    ideal = sum(f["ideal_fused_bytes_per_step"] for f in fams)
+    roof.update(traffic=dom["traffic_bytes_per_launch"], kernel=dom["family"], kernels=dom["kernels"], avg_us=dom["avg_us"],
+                ms_per_step=dom["ms_per_step"], launches_per_step=dom["launches_per_step"],
+                mfma_frac=dom["mfma_frac"], hbm_frac=dom["hbm_frac"], mfma_peak_tflops=dom["mfma_peak_tflops"],
+                event_bracket_us=bracket_us, algorithmic_bytes_per_launch=per_launch_bytes,
+                algorithmic_flops_per_launch=per_launch_flops,
+                families=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in f.items() if k != "kernels"} for f in fams],
+                whole_step_lower_bound_ms=1e3 * max(ideal / (HBM_PEAK_GBS * 1e9), gemm_t),
+                whole_step_lower_bound_terms_ms={"ideal_fused_bytes_at_hbm_peak": 1e3 * ideal / (HBM_PEAK_GBS * 1e9),
+                                                 "gemm_flops_at_matrix_peak": 1e3 * gemm_t})
+    return roof
+
+
 def secondary_runs(steps=10, warmup=3):
     """Short runs of the other BASELINE configurations (4-scan TFA, AMP, nuScenes shape + AMP) as CHILD processes after
     the headline measurement, so that the driver's default invocation observes them too.  Each entry is the child's
@@ -343,7 +442,7 @@ def secondary_runs(steps=10, warmup=3):
     for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"]):
         note("secondary run: " + " ".join(extra))
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
-               "--no-kernel-events", "--no-secondary"] + extra
+               "--no-secondary"] + extra           # per-launch events on the first timed step: every entry has its roofline
         entry = {"args": " ".join(extra)}
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -356,6 +455,13 @@ def secondary_runs(steps=10, warmup=3):
                 entry["error"] = (r.stderr or r.stdout)[-400:]
             else:
                 entry.update({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss")})
+                roof = rec.get("roofline") or {}
+                entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_us",
+                                                             "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
+                                                             "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
+                                                             "whole_step_lower_bound_ms")} if roof else None
+                entry["conv_bytes_per_step"] = rec.get("conv_bytes_per_step")
+                entry["ideal_fused_bytes_per_step"] = rec.get("ideal_fused_bytes_per_step")
         except Exception as exc:      # a failed side run must not lose the headline line
             entry["error"] = repr(exc)
         out.append(entry)
@@ -589,30 +695,7 @@ def main():
 
     if rank == 0:
         prof = summarise_profile(records, profiled_steps)
-        dom = prof[0] if prof else None
-        roofline = None
-        if dom:
-            mfma_peak = MFMA_F16_PEAK_TF if args.amp else MFMA_SPLIT_PEAK_TF if ("_s_kernel" in dom["kernel"] or "_d_kernel" in dom["kernel"]) else MFMA_F32_PEAK_TF
-            t_mfma = dom["flops_per_launch"] / (mfma_peak * 1e12)
-            t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
-            if t_mfma >= t_hbm:
-                roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": mfma_peak, "unit": "TFLOP/s",
-                            "frac": dom["tflops"] / mfma_peak}
-            else:
-                roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": dom["gbs"] / HBM_PEAK_GBS}
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-                # command (profiles/parse_traffic.py applies the gfx950 corrections)
-                entry = json.load(open(tpath)).get(dom["kernel"])
-                traffic = entry["hbm_bytes_per_launch"] if entry else None
-            roofline.update(traffic=traffic, kernel=dom["kernel"], avg_us=dom["avg_us"],
-                            event_bracket_us=bracket_us,
-                            launches_per_step=dom["launches_per_step"],
-                            algorithmic_bytes_per_launch=dom["bytes_per_launch"],
-                            algorithmic_flops_per_launch=dom["flops_per_launch"])
+        roofline = build_roofline(prof, args.amp, bracket_us)
         line = {
             "metric": "scans/sec (train fwd+bwd) at ~120k pts/scan" if not nusc else
             "scans/sec (train fwd+bwd), nuScenes-shaped sweeps", "value": value, "unit": "scans/s",

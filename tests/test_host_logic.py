@@ -205,3 +205,40 @@ def test_eval_helpers(tmp_path, g_eval_ms):
     assert np.allclose(E.per_class_iu(h), O.per_class_iu(h))
     with pytest.raises(ValueError):
         E.vote_payload(np.eye(4)[[0, 1]], "nuscenes")                          # class 0 in a nuScenes submission
+
+
+def test_bench_roofline_groups_by_family_and_prices_the_weight_gradient_without_a_scatter_term():
+    """bench.py's `roofline`: instantiations grouped by kernel family, the family with the largest time share reported
+    with BOTH fractions; weight-gradient bytes = P (Cin + Cout) s + 8 P + K Cin Cout 4 (no read-modify-write term)."""
+    import bench
+
+    class Ms:
+        def __init__(self, ms):
+            self.ms = ms
+
+        def elapsed_time(self, _):
+            return self.ms
+
+    p, k = 1_000_000, 27
+    recs = []
+    for name, ms in (("pair_gemm_s_kernel<128,96,2,false,true>", 0.20), ("pair_gemm_d_kernel<128,true>", 0.05)):
+        recs.append(("pair_gemm", Ms(ms), None, dict(name=name, pairs=p, c_red=96, c_out=96, k=k, esize=4, n_rows=150000)))
+    recs.append(("gather_sum", Ms(0.10), None, dict(name="gather_list_kernel<8>", pairs=p, c_red=0, c_out=96, k=k, n_rows=150000,
+                                                    esize=4, side_bytes=0.0)))
+    recs.append(("conv_wgrad", Ms(0.12), None, dict(name="wgrad_s_kernel<96,96>", pairs=p, c_red=96, c_out=96, k=k, esize=4,
+                                                    n_rows=150000, n_rows_b=150000)))
+    prof = bench.summarise_profile(recs, 1)
+    wg = [r for r in prof if r["kernel"].startswith("wgrad")][0]
+    assert wg["bytes_per_launch"] == p * (96 * 4 + 96 * 4 + 8) + k * 96 * 96 * 4
+    roof = bench.build_roofline(prof, False, 4.0)
+    assert roof["kernel"] == "pair_gemm" and len(roof["kernels"]) == 2 and roof["launches_per_step"] == 2
+    assert abs(roof["ms_per_step"] - 0.25) < 1e-12
+    flops = 2 * 2.0 * p * 96 * 96
+    assert abs(roof["mfma_frac"] - flops / 0.25e-3 / 1e12 / bench.MFMA_SPLIT_PEAK_TF) < 1e-9
+    byts = 2 * (p * (96 * 4 + 96 * 4 + 8) + k * 96 * 96 * 4)
+    assert abs(roof["hbm_frac"] - byts / 0.25e-3 / 1e9 / bench.HBM_PEAK_GBS) < 1e-9
+    assert roof["bound"] in ("mfma", "hbm") and roof["frac"] == (roof["mfma_frac"] if roof["bound"] == "mfma" else roof["hbm_frac"])
+    fams = {f["family"]: f for f in roof["families"]}
+    assert set(fams) == {"pair_gemm", "gather", "wgrad"} and fams["gather"]["mfma_frac"] is None
+    lb = roof["whole_step_lower_bound_terms_ms"]
+    assert roof["whole_step_lower_bound_ms"] == max(lb.values()) > 0
