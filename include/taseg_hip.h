@@ -562,6 +562,21 @@ void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t 
  * output, receives the shortcut's gradient with its own and lets it land here instead of in an add launch. */
 void ts_conv_block_addend_hint(const void *addend);
 
+/* Output-stationary (Z-free) form of a submanifold odd-kernel convolution pass for the wide shallow layers (csrc/conv_os.hip):
+ * one launch instead of ts_conv_pair_gemm + ts_conv_gather_sum, no per-pair product matrix in HBM.
+ *   out[j, :] = sum_k feat[nbr[wt ? K-1-k : k, j], :] @ (wt ? W_k^T : W_k)  [+ addend[j, :]]
+ * on the pre-split planes of W [K, c_in, c_out] (ts_conv_split_planes; `plane_n` elements between planes).  wt = 0: the
+ * forward product (c_red = c_in, reference convolution_cuda.cu:101-164 over all offsets); wt = 1: the input gradient
+ * (c_red = c_out of the layer, c_out = its c_in; :167-258) - valid where pair (i, j, k) of the rulebook implies pair
+ * (j, i, K-1-k), i.e. stride-1 odd kernels on one coordinate set, which is what `nbr` [K, n_rows] (the reference's `results`
+ * table, conv.py:160-166) then serves for both directions.  Bit-identical to the two-pass kernels.
+ * ts_conv_os_supported(c_red, c_out): 1 for the shapes built (96 -> 96, 128 -> 96, 96 -> 128). */
+int ts_conv_os(const float *feat, int32_t c_red, const void *planes, int64_t plane_n, int32_t K, int32_t c_out,
+               const int32_t *nbr, int64_t n_rows, int32_t wt, float *out, const float *addend, ts_stream_t stream);
+int32_t ts_conv_os_supported(int32_t c_red, int32_t c_out);
+/* diagnostic: ablation bits for tools/os_probe.py (wrong results, timing only); 0 = the product kernel */
+void ts_debug_conv_os(int32_t bits);
+
 /* Diagnostic: while `stamps` (device memory, 16 x uint64 per workgroup, `capacity` workgroups) is set, the 96- / 128-
  * column fp32 pair GEMMs run an instrumented instantiation whose workgroups leave shader-clock stamps of their phases
  * (tools/phase_probe.py); NULL switches back to the product kernels. */

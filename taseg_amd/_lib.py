@@ -121,6 +121,9 @@ SIGNATURES = {
     "ts_conv_split_planes_batch": (_i32, [_vp, _i32, _vp]),
     "ts_conv_planes_hint": (None, [_vp, _vp, _i32, _i32, _i32]),
     "ts_conv_block_addend_hint": (None, [_vp]),
+    "ts_conv_os": (_i32, [_vp, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "ts_conv_os_supported": (_i32, [_i32, _i32]),
+    "ts_debug_conv_os": (None, [_i32]),
     "ts_debug_phase_stamps": (None, [_vp, _i64]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),

@@ -856,3 +856,29 @@ def sparse_quantize(coords):
                                    ws.numel(), L.stream()), "ts_sparse_quantize")
     m = _count_to_host(cnt, "sparse_quantize")
     return index[:m], inverse[:n]
+
+
+def conv_os(feat, planes, kernel_shape, nbr, weight_transposed=False, addend=None):
+    """Output-stationary convolution pass (csrc/conv_os.hip): out[j] = sum_k feat[nbr[k', j]] @ (W_k or W_k^T) straight into
+    the output rows, no Z.  planes: taseg_amd.planes.planes_for(weight) (int16 storage of the three bf16 planes);
+    kernel_shape = weight.shape (K, c_in, c_out); weight_transposed: the input gradient (k' = K-1-k)."""
+    L.require_device(feat, planes, nbr, addend)
+    feat, nbr = _f32(feat, "feat"), _i32(nbr, "nbr")
+    k, c_in, c_out = (int(v) for v in kernel_shape)
+    c_red, c_o = (c_out, c_in) if weight_transposed else (c_in, c_out)
+    if feat.shape[1] != c_red:
+        raise ValueError("Input feature size and kernel size mismatch")
+    n = nbr.shape[1]
+    if nbr.shape[0] != k:
+        raise ValueError(f"neighbour table shape {tuple(nbr.shape)} != ({k}, n)")
+    if planes.numel() != 3 * k * c_in * c_out:
+        raise ValueError("planes do not belong to a weight of this shape")
+    if addend is not None:
+        addend = _f32(addend, "addend")
+    out = torch.empty((n, c_o), dtype=torch.float32, device=feat.device)
+    p = int((nbr >= 0).sum()) if _prof is not None else 0
+    with _Timed("conv_os", name=f"conv_os_kernel<{c_red},{c_o},{'true' if weight_transposed else 'false'}>", pairs=p, c_red=c_red,
+                c_out=c_o, k=k, n_rows=feat.shape[0], n_out=n):
+        L.check(L.load().ts_conv_os(L.ptr(feat), c_red, L.ptr(planes), k * c_in * c_out, k, c_o, L.ptr(nbr), n,
+                                    1 if weight_transposed else 0, L.ptr(out), L.ptr(addend), L.stream()), "ts_conv_os")
+    return out
