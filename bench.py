@@ -37,6 +37,36 @@ def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+class Watchdog:
+    """Per-rank hang guard.  A rank that makes no progress for `timeout` seconds (a collective some peer never entered, a
+    kernel that does not return) prints where it was and ends the PROCESS with exit code 3 - torch.distributed.run (or the
+    parent of `bench.py --gpus N`) then ends the other ranks and the launch fails loudly instead of sitting in a collective
+    until somebody's outer time limit.  beat(phase) marks progress; TASEG_BENCH_WATCHDOG_S (default 300, 0 = off)."""
+
+    def __init__(self, rank):
+        import threading
+        self.timeout = float(os.environ.get("TASEG_BENCH_WATCHDOG_S", "300"))
+        self.rank, self.phase, self.last = rank, "start", time.monotonic()
+        self._stop = threading.Event()
+        if self.timeout > 0:
+            threading.Thread(target=self._run, name="bench-watchdog", daemon=True).start()
+
+    def beat(self, phase):
+        self.phase, self.last = phase, time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(min(5.0, self.timeout / 4)):
+            idle = time.monotonic() - self.last
+            if idle > self.timeout:
+                print(f"[bench watchdog] rank {self.rank}: no progress for {idle:.0f} s in phase '{self.phase}' - giving up "
+                      f"(exit code 3); a peer rank stuck in another collective or a kernel that never returned",
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+
+
 def host_cores():
     """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands out a
     share of a large host - running one OpenMP thread per visible core of the HOST would oversubscribe the share)."""
@@ -505,6 +535,7 @@ def main():
     if world != args.gpus and not (args.gpus == 1 and world == 1):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or let "
                          f"`bench.py --gpus N` start the ranks itself)")
+    dog = Watchdog(rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the product path has no CPU fallback)")
     local %= max(torch.cuda.device_count(), 1)            # R/train.py:247-251: device_ids=[LOCAL_RANK % ngpu]
@@ -518,7 +549,9 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ["TASEG_SYNCBN_SINGLE_RANK"] = "1"
+        dog.beat("init_process_group")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    dog.beat("build model and inputs")
 
     from taseg_amd import backend as B
     from taseg_amd import planes as _planes
@@ -548,12 +581,16 @@ def main():
         # flat-bucket SGD (taseg_amd.optim): gradients land in flat buckets during backward (all-reduced over ranks on
         # their own communicator when N > 1), unscale + clip + SGD + loss-scale update in 3 launch kinds, no host read
         from taseg_amd.optim import FlatSGD
-        group = dist.new_group(backend=backend) if use_dist else None
+        from taseg_amd.rccl import single_communicator
+        # one communicator for everything (default, the reference's arrangement) or a dedicated one for the buckets
+        # beside SyncBatchNorm's library-owned communicator (TASEG_DIST_SINGLE_COMM=0; taseg_amd/rccl.py)
+        group = dist.new_group(backend=backend) if (use_dist and not single_communicator()) else None
         opt = FlatSGD(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=10.0, amp=args.amp, process_group=group)
     else:
         if use_dist and not args.torch_ddp:
             from taseg_amd.parallel import GradBucketReducer
-            reducer = GradBucketReducer(model, process_group=dist.new_group(backend=backend))
+            from taseg_amd.rccl import single_communicator
+            reducer = GradBucketReducer(model, process_group=None if single_communicator() else dist.new_group(backend=backend))
         elif use_dist:
             # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
@@ -647,8 +684,10 @@ def main():
 
     if rank == 0:
         note(f"{name} {args.workload}: {args.warmup} warm-up + {args.steps} timed steps on {world} rank(s)")
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        dog.beat(f"warm-up step {i}")
         step()
+    dog.beat("fence after warm-up")
     fence()
     if dist is not None:
         import ctypes
@@ -659,9 +698,12 @@ def main():
     for i in range(args.steps):
         if not args.no_kernel_events:
             B.profile_pause(i % EVENT_EVERY != 0)      # HIP events around the conv kernels of every EVENT_EVERY-th timed step
+        dog.beat(f"timed step {i}")           # (one attribute store: nothing the timed region notices)
         loss = step(time_optimizer=not args.no_kernel_events and i % EVENT_EVERY == 0)
+    dog.beat("fence after the timed steps")
     fence()
     dt = time.perf_counter() - t0
+    dog.beat("collect")
     records = B.profile_end()
     # what an event pair measures with nothing between its two records, after the timed region: the per-launch figures
     # below are NOT corrected by it (in the flow of a step the bracket costs less: rocprofv3 puts the dominant kernel
@@ -693,6 +735,7 @@ def main():
                "bus_GBps": 2 * (world - 1) / world * 4 * n_par / float(t.item()) / 1e9}
         del buf
 
+    dog.stop()                                # what follows is rank 0's reporting (CPU baseline legs, side runs: minutes, own limits)
     if rank == 0:
         prof = summarise_profile(records, profiled_steps)
         roofline = build_roofline(prof, args.amp, bracket_us)

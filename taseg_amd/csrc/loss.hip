@@ -270,7 +270,10 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float *__rest
         err[(int64_t)c * P + p] = valid ? fabsf(fg - pr) : 0.f;
       }
     if (valid) {
-      nll = -(double)picked;
+      // a label that is neither the ignore index nor a class: torch's CrossEntropyLoss (the reference,
+      // pcseg/loss/__init__.py:40-44) device-asserts; here the row poisons the sum - the loss comes out NaN instead of
+      // silently training on a wrong term (a mis-mapped raw id such as 255)
+      nll = (lab >= 0 && lab < C) ? -(double)picked : (double)NAN;
       smooth = -(double)sum_logp;
       cnt = 1.0;
     }

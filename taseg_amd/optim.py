@@ -56,6 +56,7 @@ class FlatSGD:
         for b in self.reducer.buckets:
             for p in b["params"]:
                 p.grad = None
+                p._taseg_dest_claimed = False
 
     def step(self):
         self.reducer.finish()                         # gradients sit in the flat buckets (reduced over ranks)
@@ -69,17 +70,25 @@ class FlatSGD:
         for b in self.reducer.buckets:
             # parameters that received no gradient on ANY rank this step (an unused head, a frozen branch): torch.optim.SGD
             # skips them entirely - no weight decay, no momentum update (R/pcseg/optim/__init__.py:15-21 builds that
-            # optimizer).  The flat update touches the whole bucket, so their slices are put back afterwards.
+            # optimizer).  The flat update touches the whole bucket, so their slices are put back afterwards.  b["unused"]
+            # is this rank's list; with several ranks the reducer's all-reduced flag of the parameter says whether some
+            # OTHER rank had a gradient for it - then the averaged gradient is applied here too (DDP's rule) and the
+            # replicas stay identical.  The flag is read on the device (torch.where), not on the host.
             keep = []
             for i in b.get("unused", ()):
                 off, n = b["offsets"][i], b["params"][i].numel()
-                keep.append((off, n, b["pflat"][off:off + n].clone(), b["mflat"][off:off + n].clone()))
+                used_elsewhere = (b["flags"][i] > 0) if self.reducer.world > 1 else None
+                keep.append((off, n, b["pflat"][off:off + n].clone(), b["mflat"][off:off + n].clone(), used_elsewhere))
             L.check(lib.ts_sgd_apply(L.ptr(b["pflat"]), L.ptr(b["flat"]), L.ptr(b["mflat"]), b["flat"].numel(),
                                      L.ptr(self.state), float(self.lr), float(self.momentum), float(self.weight_decay),
                                      1 if self._first else 0, st), "ts_sgd_apply")
-            for off, n, pv, mv in keep:
-                b["pflat"][off:off + n].copy_(pv)
-                b["mflat"][off:off + n].copy_(mv)
+            for off, n, pv, mv, used_elsewhere in keep:
+                if used_elsewhere is None:
+                    b["pflat"][off:off + n].copy_(pv)
+                    b["mflat"][off:off + n].copy_(mv)
+                else:
+                    b["pflat"][off:off + n].copy_(torch.where(used_elsewhere, b["pflat"][off:off + n], pv))
+                    b["mflat"][off:off + n].copy_(torch.where(used_elsewhere, b["mflat"][off:off + n], mv))
         # (a skipped very first step leaves the momentum buffers zero, which `first` = 0 then treats correctly:
         #  momentum * 0 + d = d)
         self._first = False

@@ -114,15 +114,18 @@ class GradBucketReducer:
         for p in params:
             offsets.append(off)
             off += -(-p.numel() // self.ALIGN) * self.ALIGN
-        flat = torch.zeros(off, dtype=first.dtype, device=first.device)
+        # [gradients (off elements) | one "this rank has a gradient" flag per parameter]: one buffer, one all-reduce
+        n_flags = -(-len(params) // self.ALIGN) * self.ALIGN
+        flat_all = torch.zeros(off + n_flags, dtype=first.dtype, device=first.device)
+        flat, flags = flat_all[:off], flat_all[off:off + len(params)]
         views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, params)]
         for p, v in zip(params, views):
             # producers that can write a gradient wherever they are told (the conv block nodes: their weight gradient is
             # a full overwrite) put it straight into the bucket; _launch then finds p.grad already in place and copies
             # nothing for it (the convolution weights are 99 % of the gradient bytes)
             p._taseg_grad_dest = v
-        self.buckets.append({"params": list(params), "flat": flat, "views": views, "offsets": offsets,
-                             "pending": len(params), "launched": False, "unused": []})
+        self.buckets.append({"params": list(params), "flat": flat, "flat_all": flat_all, "flags": flags, "views": views,
+                             "offsets": offsets, "pending": len(params), "launched": False, "unused": []})
 
     def _make_hook(self, bucket):
         def hook(_param):
@@ -151,8 +154,11 @@ class GradBucketReducer:
         for p, v in zip(bucket["params"], bucket["views"]):
             p.grad = v                               # the optimizer reads the reduced values in place
         if self.world > 1:
-            bucket["flat"].div_(self.world)
-            self._works.append(dist.all_reduce(bucket["flat"], group=self.group, async_op=True))
+            bucket["flags"].fill_(1.0)               # (the previous step's all-reduce left averages here)
+            for i in bucket["unused"]:
+                bucket["flags"][i] = 0.0
+            bucket["flat_all"].div_(self.world)
+            self._works.append(dist.all_reduce(bucket["flat_all"], group=self.group, async_op=True))
         bucket["launched"] = True
 
     def finish(self):
@@ -165,3 +171,5 @@ class GradBucketReducer:
         self._works = []
         for b in self.buckets:
             b["pending"], b["launched"] = len(b["params"]), False
+            for p in b["params"]:
+                p._taseg_dest_claimed = False        # the slots may be handed out again (nn/modules.py::_claim_grad_dest)

@@ -21,7 +21,6 @@ from . import _lib as L
 __all__ = ["planes_for", "invalidate", "eligible", "hint", "stats"]
 
 _ENABLED = os.environ.get("TASEG_PRESPLIT", "1") != "0"
-_FREEZE = os.environ.get("TASEG_PRESPLIT_FREEZE", "0") == "1"      # timing experiment only: never re-split (stale planes!)
 _entries = {}          # id(weight) -> _Entry
 _epoch = 0
 stats = {"refreshes": 0, "launch_batches": 0}
@@ -41,8 +40,6 @@ class _Entry:
         self.ptr = self.version = self.epoch = self.stream = None
 
     def fresh(self, weight, stream):
-        if _FREEZE and self.ptr is not None:
-            return True
         return self.ptr == weight.data_ptr() and self.version == weight._version and self.epoch == _epoch \
             and self.stream == stream
 
@@ -64,13 +61,17 @@ def eligible(weight) -> bool:
             and (_wide(weight.shape[1]) or _wide(weight.shape[2])))
 
 
-def _refresh(stream):
-    """Re-split every registered weight that is stale (one launch per 16 weights) on `stream`."""
+def _refresh(stream, device):
+    """Re-split every registered weight ON `device` that is stale (one launch per 16 weights) on `stream` - a stream of
+    that device: the caller's current one.  Weights of a second model on another GPU of the same process stay stale until
+    a convolution on their own device asks for them."""
     jobs, done = [], []
     for key, e in list(_entries.items()):
         w = e.ref()
         if w is None:
             del _entries[key]
+            continue
+        if w.device != device:
             continue
         if not e.fresh(w, stream):
             jobs.append((w.data_ptr(), e.planes.data_ptr(), w.shape[0], w.shape[1], w.shape[2]))
@@ -90,12 +91,16 @@ def planes_for(weight):
     or None when the mechanism does not apply."""
     if not eligible(weight):
         return None
+    if weight.device.index != torch.cuda.current_device():
+        # the split runs on the caller's current stream, which belongs to the current device: a weight that lives on
+        # another GPU goes without planes (the kernels then split in the workgroups, same bits)
+        return None
     stream = L.stream()
     e = _entries.get(id(weight))
-    if e is None or e.ref() is not weight:
+    if e is None or e.ref() is not weight or e.planes.device != weight.device:
         e = _entries[id(weight)] = _Entry(weight)
     if not e.fresh(weight, stream):
-        _refresh(stream)
+        _refresh(stream, weight.device)
     return e.planes
 
 

@@ -62,11 +62,25 @@ def _create(group):
     return comm
 
 
+def single_communicator() -> bool:
+    """TASEG_DIST_SINGLE_COMM (default 1): every collective of a training step - SyncBatchNorm statistics and the
+    gradient-bucket all-reduces - goes through ONE communicator, torch.distributed's default process group, in one
+    program order on one stream: the arrangement of the reference (DDP + nn.SyncBatchNorm on the default group,
+    R/train.py:247-251).  It is the default until the two-communicator arrangement (a library-owned RCCL communicator
+    for SyncBatchNorm on the compute stream beside c10d's for the buckets: ~1 ms per step faster on one rank) has run
+    with more than one rank on real devices - tests/test_gpu_dist.py::test_two_ranks_rccl needs two GPUs and has been
+    skipped on every box so far.  TASEG_DIST_SINGLE_COMM=0 selects the fast arrangement."""
+    return os.environ.get("TASEG_DIST_SINGLE_COMM", "1") != "0"
+
+
 def direct_comm(group):
-    """Communicator handle (ctypes.c_void_p) for `group`, created on first use; None = use dist.all_reduce."""
+    """Communicator handle (ctypes.c_void_p) for `group`, created on first use; None = use dist.all_reduce.
+    Off under TASEG_DIST_SINGLE_COMM (the default) unless TASEG_RCCL_DIRECT=1 asks for it explicitly."""
     key = id(group)
     if key not in _comms:
-        _comms[key] = None if os.environ.get("TASEG_RCCL_DIRECT", "1") == "0" else _create(group)
+        want = os.environ.get("TASEG_RCCL_DIRECT")
+        on = (want == "1") if want is not None else not single_communicator()
+        _comms[key] = _create(group) if on else None
     return _comms[key]
 
 

@@ -125,6 +125,21 @@ def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor =
     return input._like(out)
 
 
+def _claim_grad_dest(kernel):
+    """The gradient-bucket slot of `kernel` (parallel.GradBucketReducer) as the place the block's backward may write the
+    weight gradient STRAIGHT into - or None.  The slot is a full-overwrite target that autograd then adopts as p.grad, so it
+    is handed out only while nothing can have been accumulated for this step: p.grad is None (zero_grad(set_to_none=True)
+    semantics; a kept .grad aliases the slot itself and an overwrite followed by `grad += alias` would double the new
+    value) and no other use of the same weight since the last reducer.finish() / zero_grad() has claimed it (a weight
+    used twice in one graph: the second node gets a fresh tensor and autograd adds the two).  The claim is dropped by
+    GradBucketReducer.finish() and FlatSGD.zero_grad()."""
+    dest = getattr(kernel, "_taseg_grad_dest", None)
+    if dest is None or kernel.grad is not None or getattr(kernel, "_taseg_dest_claimed", False):
+        return None
+    kernel._taseg_dest_claimed = True
+    return dest
+
+
 def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None,
                 passthrough: bool = False):
     """relu(BN(conv(input)) [+ residual]) for a Conv3d and its BatchNorm / SyncBatchNorm module: one autograd node and
@@ -158,7 +173,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 fast = _fast.module()
                 half = F._amp_half(feats)
                 planes = None if half else _planes.planes_for(conv.kernel)      # pre-split weight (taseg_amd/planes.py)
-                dest = getattr(conv.kernel, "_taseg_grad_dest", None)           # bucket slot of the weight gradient (parallel.py)
+                dest = _claim_grad_dest(conv.kernel)                            # bucket slot of the weight gradient (parallel.py)
                 if fast is not None:            # C++ autograd node, same two backend calls (csrc/fastpath)
                     out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
                                           kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],

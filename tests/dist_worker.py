@@ -53,7 +53,7 @@ def scan_loss(logits, labels):
     return torch.nn.functional.cross_entropy(logits, labels, ignore_index=0)
 
 
-def one_step(model, batches, process_group=None):
+def one_step(model, batches, process_group=None, amp=False):
     """forward + backward over `batches` = [(coords, feats, labels)] (one per scan of this process); returns logits,
     gradients (after the bucketed all-reduce), BatchNorm running statistics"""
     from taseg_amd.optim import FlatSGD
@@ -64,16 +64,18 @@ def one_step(model, batches, process_group=None):
     labels = torch.from_numpy(np.concatenate([b[2] for b in batches])).cuda()
     grabbed = {}
     h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o))
-    model({"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": torch.tensor([0])})
+    with torch.autocast("cuda", dtype=torch.float16, enabled=amp):      # the reference's default mode (dist_train.sh --amp)
+        model({"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": torch.tensor([0])})
     h.remove()
-    logits = grabbed["logits"]
+    logits = grabbed["logits"].float()
     sizes = [len(b[0]) for b in batches]
     parts, lparts = torch.split(logits, sizes), torch.split(labels, sizes)
     loss = sum(scan_loss(a, b) for a, b in zip(parts, lparts)) / len(batches)
     opt.zero_grad()
-    loss.backward()
+    scale = 1024.0 if amp else 1.0          # static loss scale: half-storage gradients of the early layers would underflow
+    (loss * scale).backward()
     opt.reducer.finish()
-    grads = {n: p.grad.detach().float().cpu().numpy() for n, p in model.named_parameters()}
+    grads = {n: (p.grad.detach().float() / scale).cpu().numpy() for n, p in model.named_parameters()}
     stats = {n: b.detach().float().cpu().numpy() for n, b in model.named_buffers() if "running" in n}
     return logits.detach().float().cpu().numpy(), grads, stats, float(loss)
 
@@ -85,17 +87,49 @@ def pack(prefix, logits, grads, stats, loss):
     return out
 
 
+def unused_parameter_steps(rank, group):
+    """TASEG_WORKER_MODE=unused: FlatSGD over ranks where a parameter gets its gradient on rank 0 ONLY and another one on
+    no rank: three optimizer steps (momentum, weight decay), the parameters after each."""
+    from taseg_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 5)).cuda()
+    net.register_parameter("one_rank_only", torch.nn.Parameter(torch.ones(5, device="cuda")))
+    net.register_parameter("nobody", torch.nn.Parameter(torch.ones(3, device="cuda")))
+    opt = FlatSGD(net, lr=0.1, momentum=0.9, weight_decay=1e-2, max_norm=10.0, process_group=group)
+    out = {}
+    for step in range(3):
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(7 * step + rank)
+        x, y = torch.randn(6, 8, generator=g).cuda(), torch.randint(0, 5, (6,), generator=g).cuda()
+        logits = net[2](net[1](net[0](x)))
+        if rank == 0:
+            logits = logits + net.one_rank_only
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        opt.step()
+        for n, p in net.named_parameters():
+            out[f"step{step}/{n}"] = p.detach().cpu().numpy().copy()
+    return out
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("TASEG_DIST_BACKEND", "nccl")
     dev = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("TASEG_WORKER_MODE") == "unused":
+        np.savez(os.path.join(os.environ["OUT"], f"rank{rank}.npz"), **unused_parameter_steps(rank, dist.new_group(backend=backend)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     from taseg_amd import rccl
     out = {}
     scan = make_scan(41 + rank)
-    group = dist.new_group(backend=backend)
-    out.update(pack("", *one_step(build(True), [scan], group)))
+    amp = os.environ.get("TASEG_WORKER_AMP") == "1"
+    # TASEG_DIST_SINGLE_COMM (default): buckets and SyncBatchNorm share the default group, as in bench.py
+    from taseg_amd.rccl import single_communicator
+    group = None if single_communicator() else dist.new_group(backend=backend)
+    out.update(pack("", *one_step(build(True), [scan], group, amp=amp)))
     direct = rccl.direct_comm(dist.group.WORLD)
     out["direct_rccl"] = np.int64(1 if direct is not None else 0)
     if backend == "nccl" and world > 1:

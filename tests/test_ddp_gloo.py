@@ -129,3 +129,58 @@ def test_grad_bucket_reducer_two_ranks():
         want = [p.grad if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
         for got_a, got_b, w in zip(rows_a[step], rows_b[step], want):
             assert torch.allclose(torch.tensor(got_a), w, atol=1e-6) and torch.allclose(torch.tensor(got_b), w, atol=1e-6)
+
+
+def _flags_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    P.init_distributed(backend="gloo")
+    net = _net()
+    net.register_parameter("one_rank_only", torch.nn.Parameter(torch.ones(5)))     # rank 0 alone puts it into its loss
+    net.register_parameter("nobody", torch.nn.Parameter(torch.ones(3)))            # no rank ever uses it
+    red = P.GradBucketReducer(net, process_group=dist.new_group(backend="gloo"), bucket_mb=0.0002)
+    names = [n for n, _ in net.named_parameters()]
+    rows = []
+    for step in range(2):
+        for p in net.parameters():
+            p.grad = None
+        g = torch.Generator().manual_seed(7 * step + rank)
+        x, y = torch.randn(6, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+        logits = net[2](net[1](net[0](x)))
+        if rank == 0:
+            logits = logits + net.one_rank_only
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        red.finish()
+        flags, local_unused = {}, []
+        for b in red.buckets:
+            for i, p in enumerate(b["params"]):
+                name = names[[id(q) for q in net.parameters()].index(id(p))]
+                flags[name] = float(b["flags"][i])
+                if i in b["unused"]:
+                    local_unused.append(name)
+        rows.append((flags, sorted(local_unused), net.one_rank_only.grad.tolist(), net.nobody.grad.tolist()))
+    out.put((rank, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unused_parameter_decision_is_global():
+    """A parameter without a gradient on ONE rank only still takes the averaged gradient everywhere (DDP's
+    find_unused_parameters rule); the all-reduced flag that says so is identical on every rank, step after step."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_flags_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, rows0), (_, rows1) = res
+    for (f0, u0, g0, n0), (f1, u1, g1, n1) in zip(rows0, rows1):
+        assert f0 == f1                                            # the same decision on both ranks
+        assert f0["one_rank_only"] == 0.5 and f0["nobody"] == 0.0 and f0["0.weight"] == 1.0
+        assert u0 == ["nobody"] and u1 == ["nobody", "one_rank_only"]      # the rank-local lists differ ...
+        assert g0 == g1 and any(abs(v) > 0 for v in g0)                    # ... the averaged gradient does not
+        assert n0 == n1 == [0.0, 0.0, 0.0]

@@ -2,7 +2,7 @@
 ranks, gradients averaged by GradBucketReducer during backward - R/dist_train.sh:17-19, R/train.py:247-251) run by
 real rank processes on the real segmentor and HIP kernels, against ONE process on the concatenated batch.
 
-* test_two_ranks_share_one_device: 2 ranks on ONE card (the GPU box has one) with the gloo transport - everything but
+* test_ranks_share_one_device: 2 / 4 ranks on ONE card (the GPU box has one) with the gloo transport - everything but
   the RCCL wire: process-group set-up, weight broadcast, bucket hooks, SyncBatchNorm's packed all-reduce, finish().
 * test_two_ranks_rccl: needs >= 2 devices (skipped on the one-GPU box; runs wherever the driver has a multi-GPU
   node): RCCL transport, SyncBatchNorm on the library-owned communicator vs through torch.distributed, all-reduce
@@ -55,38 +55,65 @@ def _run_ranks(world, backend, out_dir, extra_env=None):
     return [dict(np.load(os.path.join(out_dir, f"rank{r}.npz"))) for r in range(world)], outs
 
 
-def _single_process(world):
+def _single_process(world, amp=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker as W
     batches = [W.make_scan(41 + r, batch_index=r) for r in range(world)]
-    logits, grads, stats, loss = W.one_step(W.build(False), batches)
+    logits, grads, stats, loss = W.one_step(W.build(False), batches, amp=amp)
     sizes = np.cumsum([0] + [len(b[0]) for b in batches])
     return [logits[sizes[r]:sizes[r + 1]] for r in range(world)], grads, stats, loss
 
 
-def _check_against_single(ranks, prefix=""):
+def _check_against_single(ranks, prefix="", amp=False):
+    """fp32: logits 1e-3, gradients 2e-3 relative L2.  amp: half storage rounds every activation (2^-11 relative) and the
+    per-rank / whole-batch runs round different partial sums - logits within 5e-2 + 4 half-precision ulps of the largest
+    logit; gradients within 0.2 relative L2 (cosine > 0.98, the bar of test_gpu_amp.py's AMP-vs-fp32 comparison): two
+    half-storage evaluations that round different partial sums differ from each other by as much as either differs from
+    fp32 - measured 8.7e-2 on stem.0.kernel, 1.25e-1 worst, whose output gradient has crossed ~40 half-rounded layers.  What the AMP case
+    pins exactly is the distributed property: every rank ends with bit-identical averaged gradients."""
     world = len(ranks)
-    want_logits, want_grads, want_stats, want_loss = _single_process(world)
+    want_logits, want_grads, want_stats, want_loss = _single_process(world, amp)
+    ltol, gtol, stol = (5e-2, 0.2, 2e-3) if amp else (1e-3, 2e-3, 1e-4)
     for r, got in enumerate(ranks):
-        # SyncBatchNorm statistics span both ranks: each rank's logits are its slice of the two-scan batch's logits
-        assert np.abs(got[prefix + "logits"] - want_logits[r]).max() <= 1e-3
-    assert abs(np.mean([float(g[prefix + "loss"]) for g in ranks]) - want_loss) <= 1e-4
+        # SyncBatchNorm statistics span the ranks: each rank's logits are its slice of the whole batch's logits
+        tol = ltol + (4 * 2.0 ** -11 * float(np.abs(want_logits[r]).max()) if amp else 0.0)
+        assert np.abs(got[prefix + "logits"] - want_logits[r]).max() <= tol
+    assert abs(np.mean([float(g[prefix + "loss"]) for g in ranks]) - want_loss) <= (5e-3 if amp else 1e-4)
     worst = 0.0
     for name, want in want_grads.items():
-        a, b = ranks[0][prefix + "grad/" + name], ranks[1][prefix + "grad/" + name]
-        assert np.array_equal(a, b), name                       # every rank holds the same averaged gradient
+        a = ranks[0][prefix + "grad/" + name]
+        for other in ranks[1:]:
+            assert np.array_equal(a, other[prefix + "grad/" + name]), name      # every rank holds the same averaged gradient
         err = np.linalg.norm(a - want) / max(np.linalg.norm(want), 1e-12)
         worst = max(worst, err)
-        assert err <= 2e-3, (name, err)
+        assert err <= gtol, (name, err)
     for name, want in want_stats.items():
-        assert np.allclose(ranks[0][prefix + "stat/" + name], want, rtol=1e-4, atol=1e-5), name
+        assert np.allclose(ranks[0][prefix + "stat/" + name], want, rtol=stol, atol=1e-5), name
     return worst
 
 
-def test_two_ranks_share_one_device(tmp_path):
-    ranks, _ = _run_ranks(2, "gloo", tmp_path, {"TASEG_RCCL_DIRECT": "0"})
-    worst = _check_against_single(ranks)
-    print(f"2 ranks (gloo, one device) vs one process on the concatenated batch: worst relative gradient error {worst:.2e}")
+@pytest.mark.parametrize("world,amp,single", [(2, False, "1"), (2, False, "0"), (4, False, "1"), (2, True, "1")])
+def test_ranks_share_one_device(tmp_path, world, amp, single):
+    """2 and 4 real rank processes on ONE card (gloo transport), fp32 and under autocast, with the step's collectives on one
+    communicator (the default, TASEG_DIST_SINGLE_COMM=1) and with a dedicated group for the gradient buckets"""
+    env = {"TASEG_RCCL_DIRECT": "0", "TASEG_DIST_SINGLE_COMM": single, "TASEG_WORKER_AMP": "1" if amp else "0"}
+    ranks, _ = _run_ranks(world, "gloo", tmp_path, env)
+    worst = _check_against_single(ranks, amp=amp)
+    print(f"{world} ranks (gloo, one device, {'AMP' if amp else 'fp32'}, single communicator {single}) vs one process on the "
+          f"concatenated batch: worst relative gradient error {worst:.2e}")
+
+
+def test_flat_sgd_unused_parameter_rule_is_global(tmp_path):
+    """A parameter with a gradient on rank 0 only: FlatSGD applies the averaged gradient on BOTH ranks (replicas stay
+    bit-identical, DDP's find_unused_parameters rule); a parameter unused on every rank is left untouched (torch.optim.SGD)."""
+    ranks, _ = _run_ranks(2, "gloo", tmp_path, {"TASEG_RCCL_DIRECT": "0", "TASEG_WORKER_MODE": "unused"})
+    a, b = ranks
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                       # no silent divergence of the replicas
+    assert np.array_equal(a["step2/nobody"], np.ones(3, np.float32))          # no weight decay, no momentum: untouched
+    moved = [float(np.abs(a[f"step{s}/one_rank_only"] - 1.0).max()) for s in range(3)]
+    assert moved[0] > 1e-4 and moved[2] > moved[0]                  # updated on both ranks, momentum building up
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two ROCm devices (RCCL refuses two ranks on one)")

@@ -547,3 +547,36 @@ def test_residual_block_passes_its_input_through(monkeypatch, node, inc, outc):
     yb, gb, pb = run(False)
     assert torch.equal(ya, yb) and torch.equal(ga, gb)
     assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+
+
+def test_weight_gradient_bucket_slot_is_handed_out_once_per_step():
+    """The conv block's backward writes its weight gradient straight into the parameter's gradient-bucket slot (a full
+    overwrite that autograd adopts as p.grad).  That is only sound while nothing has been accumulated for the step: a
+    weight used TWICE in one graph and a step WITHOUT zero_grad must still give old + new, not 2 x new."""
+    from taseg_amd.parallel import GradBucketReducer
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import BasicConvolutionBlock
+    from taseg_amd.torchsparse import SparseTensor
+    rs = np.random.RandomState(4)
+    c = np.unique(rs.randint(0, 20, size=(5000, 3)), axis=0).astype(np.int32)
+    coords = torch.from_numpy(np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)).cuda()
+    feats = torch.from_numpy(rs.randn(len(c), 64).astype(np.float32)).cuda()
+    gout = torch.from_numpy(rs.randn(len(c), 64).astype(np.float32)).cuda()
+
+    def grads(with_reducer, passes=1):
+        torch.manual_seed(0)
+        block = BasicConvolutionBlock(64, 64, ks=3).cuda().train()
+        red = GradBucketReducer(block) if with_reducer else None
+        for _ in range(passes):                                   # no zero_grad between the passes
+            y = block(block(SparseTensor(feats, coords, 1)))      # the same weight twice in one graph
+            y.F.backward(gout)
+            if red is not None:
+                red.finish()
+        return [p.grad.detach().clone() for p in block.parameters()]
+
+    want1, got1 = grads(False), grads(True)
+    for a, b in zip(got1, want1):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+    want2, got2 = grads(False, passes=2), grads(True, passes=2)
+    for a, b in zip(got2, want2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+    assert float((want2[0] - want1[0]).abs().max()) > 0           # the second pass really added something

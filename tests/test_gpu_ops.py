@@ -1005,6 +1005,19 @@ def test_fused_ce_lovasz_loss_matches_the_tensor_form_and_the_oracle(monkeypatch
         assert abs(float(one) - float(ref)) <= 5e-6 * max(1.0, abs(float(ref)))
 
 
+def test_fused_loss_fails_loudly_on_a_label_outside_the_classes():
+    """a label that is neither the ignore index nor in [0, C) - e.g. an unmapped raw id 255 - makes torch's CrossEntropyLoss
+    (the reference's) assert on the device; the fused kernels answer with a NaN loss instead of a silently wrong term"""
+    import taseg_amd.pcseg.loss as LS
+    rs = np.random.RandomState(1)
+    logits = torch.from_numpy(rs.randn(5000, 20).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rs.randint(0, 20, size=5000)).cuda()
+    crit = LS.Losses(["CELoss", "LovLoss"], [1.0, 1.0], ignore_index=0, label_smoothing=0.0)
+    assert np.isfinite(float(crit(logits, labels)))
+    labels[1234] = 255
+    assert np.isnan(float(crit(logits, labels)))
+
+
 @pytest.mark.parametrize("k,n,c", [(27, 10007, 96), (27, 4099, 128), (27, 257, 256), (8, 5003, 64), (27, 3001, 32), (27, 1500, 20),
                                    (27, 700, 16), (1, 2000, 96), (27, 9, 1024)])
 def test_gather_sum_list_form_gives_the_bits_of_the_register_form(B, k, n, c):

@@ -242,3 +242,21 @@ def test_bench_roofline_groups_by_family_and_prices_the_weight_gradient_without_
     assert set(fams) == {"pair_gemm", "gather", "wgrad"} and fams["gather"]["mfma_frac"] is None
     lb = roof["whole_step_lower_bound_terms_ms"]
     assert roof["whole_step_lower_bound_ms"] == max(lb.values()) > 0
+
+
+def test_bench_watchdog_ends_a_stuck_rank_with_exit_code_3():
+    """bench.Watchdog: a rank without progress for TASEG_BENCH_WATCHDOG_S seconds says where it was and exits 3 (the
+    launcher then ends its peers); a rank that keeps beating is left alone"""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; wd = bench.Watchdog(5); wd.beat('all-reduce of bucket 2');\n"
+            "t0 = time.time()\n"
+            "while time.time() - t0 < float(sys.argv[1]): time.sleep(0.1); (wd.beat('step') if sys.argv[2] == 'beat' else None)\n"
+            "wd.stop(); print('finished')" % ROOT)
+    env = dict(os.environ, TASEG_BENCH_WATCHDOG_S="1.0")
+    stuck = subprocess.run([sys.executable, "-c", code, "30", "stuck"], env=env, capture_output=True, text=True, timeout=120)
+    assert stuck.returncode == 3 and "rank 5" in stuck.stderr and "all-reduce of bucket 2" in stuck.stderr
+    alive = subprocess.run([sys.executable, "-c", code, "3", "beat"], env=env, capture_output=True, text=True, timeout=120)
+    assert alive.returncode == 0 and "finished" in alive.stdout
