@@ -637,6 +637,19 @@ int ts_fuse_sweeps(const float *points, const int32_t *sweep_idx, int64_t n, con
 int ts_project_fov(const float *points, int64_t n, const double *proj, int32_t img_w, int32_t img_h, int32_t crop_h,
                    int32_t crop_w, float row_offset, float *pix, uint8_t *keep, ts_stream_t stream);
 
+/* nuScenes TIAF camera projection (pcseg/data/dataset/nuscenes/nuscenes_ms_mm.py:349-398 get_fov_points, the per-point
+ * part): lidar frame -> ego -> global -> camera ego -> camera through the calibrated-sensor and ego-pose records of the lidar
+ * and camera sample_data entries, pinhole projection with nuscenes-devkit's view_points, half-resolution pixel.
+ *   cam[57] float64 = { M1[9] t1[3]  M2[9] t2[3]  t3[3] M3[9]  t4[3] M4[9]  K[9] }   (row-major 3x3; M3 / M4 = the TRANSPOSED
+ *                       rotations of the camera's ego pose / calibrated sensor, as the reference applies them)
+ *   p = M1 x + t1;  p = M2 p + t2;  p = M3 (p - t3);  p = M4 (p - t4)        every product an FMA chain in k order (dgemm)
+ *   (u, v) = f32( (K p)[0,1] / (K p)[2] )
+ *   keep[i] = p_z > 0  &&  0 < u < img_w  &&  0 < v < img_h  &&  ((int)v >> 1) >= crop_top
+ *   pix[i]  = ( float(((int)v >> 1) - crop_top) + row_offset , float((int)u >> 1) )    row_offset = HEIGHT * image index
+ * points [n,4] float32; pix [n,2] float32 (undefined where keep == 0); keep [n] uint8. */
+int ts_project_cam(const float *points, int64_t n, const double *cam, int32_t img_w, int32_t img_h, int32_t crop_top,
+                   float row_offset, float *pix, uint8_t *keep, ts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,3 +494,123 @@ def kitti_ring_id(points):
     proj_y = np.zeros_like(proj_x)
     proj_y[new_raw] = 1
     return np.clip(np.cumsum(proj_y), 0, 63)
+
+
+# --------------------------------------------------------------------------- nuScenes TIAF data stage (camera side)
+def view_points(points, view, normalize):
+    """`nuscenes.utils.geometry_utils.view_points` of nuscenes-devkit (a dependency the reference imports,
+    R/pcseg/data/dataset/nuscenes/nuscenes_ms_mm.py:15, without pinning a version; absent from /root/reference and from this
+    image - its published algorithm, unchanged since devkit 1.0, restated): pad the view matrix to 4x4, apply it to the
+    homogeneous points, keep three rows, divide by the third when `normalize`.  points [3, n]."""
+    viewpad = np.eye(4)
+    viewpad[:view.shape[0], :view.shape[1]] = view
+    nbr_points = points.shape[1]
+    points = np.concatenate((points, np.ones((1, nbr_points))))
+    points = np.dot(viewpad, points)
+    points = points[:3, :]
+    if normalize:
+        points = points / points[2:3, :].repeat(3, 0).reshape(3, nbr_points)
+    return points
+
+
+def nus_tiaf_fov_points(raw_data, annotated, cam, image_hw, height, img_batch, resize=0.5, crop_top=2):
+    """nuscenes_ms_mm.py:329-401 (get_fov_points) without the image arrays: lidar points of a keyframe -> ego -> global ->
+    camera ego -> camera (the calibrated-sensor and ego-pose records of the two sample_data entries), pinhole projection,
+    in-image test, pixel at half resolution, the top `crop_top` rows cut, the row shifted by height * img_batch.
+    raw_data [n,4] float32; cam = dict(lidar_cs_q, lidar_cs_t, lidar_pose_q, lidar_pose_t, cam_pose_q, cam_pose_t, cam_cs_q,
+    cam_cs_t, intrinsic [3,3]); image_hw = (H, W) of the full-size image.  Returns (raw_fov [m,6] float64: x, y, z,
+    intensity, row, col; labels [m]; keep [n])."""
+    raw_data = np.asarray(raw_data, dtype=np.float32)
+    pc = raw_data[:, :3].copy().T
+    pc = quaternion_rotation_matrix(cam["lidar_cs_q"]) @ pc
+    pc = pc + np.array(cam["lidar_cs_t"])[:, np.newaxis]
+    pc = quaternion_rotation_matrix(cam["lidar_pose_q"]) @ pc
+    pc = pc + np.array(cam["lidar_pose_t"])[:, np.newaxis]
+    pc = pc - np.array(cam["cam_pose_t"])[:, np.newaxis]
+    pc = quaternion_rotation_matrix(cam["cam_pose_q"]).T @ pc
+    pc = pc - np.array(cam["cam_cs_t"])[:, np.newaxis]
+    pc = quaternion_rotation_matrix(cam["cam_cs_q"]).T @ pc
+    depths = pc[2, :]
+    points = view_points(pc, np.array(cam["intrinsic"]), normalize=True).astype(np.float32)
+    keep = depths > 0
+    keep = np.logical_and(keep, points[0, :] > 0)
+    keep = np.logical_and(keep, points[0, :] < image_hw[1])
+    keep = np.logical_and(keep, points[1, :] > 0)
+    keep = np.logical_and(keep, points[1, :] < image_hw[0])
+    uv = points.T[:, :2][keep].astype(int)
+    uv = np.ascontiguousarray(np.fliplr(uv))                     # (row, col) at full resolution
+    uv[:, 0] = np.floor(resize * uv[:, 0])
+    uv[:, 1] = np.floor(resize * uv[:, 1])
+    crop = uv[:, 0] >= crop_top
+    keep[keep] = crop
+    uv = uv[crop]
+    uv[:, 0] -= crop_top
+    uv[:, 0] += height * img_batch
+    return np.concatenate([raw_data[keep], uv], axis=-1), np.asarray(annotated).reshape(-1)[keep], keep
+
+
+def nus_select_image_keyframes(keys, scene_of, index, multiscan_image, step_image, rng):
+    """nuscenes_ms_mm.py:204-236 (head of multiscan_fuse_fov): keyframe offsets whose camera images join the stack - walk
+    back over the KEYFRAME list of the scene until the lidar has travelled more than multiscan_image * step_image metres,
+    pick per multiple of step_image the nearest keyframe, fill up from the passed-over ones with `rng.sample` (the
+    reference uses the global `random.sample`), always add offset 0.  keys = list of pose dicts, scene_of[i] = scene of
+    keyframe i."""
+    if multiscan_image == 0:
+        return [0]
+    info0 = keys[index]
+    delta, total, dist = 0, [], []
+    while len(dist) == 0 or dist[-1] <= multiscan_image * step_image:
+        delta -= 1
+        if scene_of[index + delta] != scene_of[index]:
+            dist.append(1000)
+            break
+        origin = nus_transform_point(np.zeros((1, 5), dtype=float), info0, keys[index + delta])
+        total.append(delta)
+        dist.append(np.linalg.norm(origin.reshape(-1)[:2], ord=2))
+    cur, picked, passed = 1, [], []
+    for i in range(len(total)):
+        if dist[i] - cur * step_image > 0 or ((dist[i] < dist[i + 1]) and
+                                              (np.abs(dist[i] - cur * step_image) < np.abs(dist[i + 1] - cur * step_image))):
+            picked.append(total[i])
+            cur += 1
+        else:
+            passed.append(total[i])
+        if cur > multiscan_image:
+            break
+    if len(picked) < multiscan_image and len(passed) > 0:
+        picked += rng.sample(passed, min(multiscan_image - len(picked), len(passed)))
+    picked = list(set(picked))
+    picked.append(0)
+    picked.sort()
+    return picked
+
+
+def nus_tiaf_frame_cloud(keys, scene_of, stamps, index, delta, prev_delta, interval, points, labels, paint_dist):
+    """nuscenes_ms_mm.py:246-300: the cloud one image keyframe projects - its own points (ego box cut on the raw
+    coordinates, time delta to the current keyframe in column 4) plus those of up to `interval` earlier keyframes of the
+    scene (not reaching back to the previous image keyframe `prev_delta`), moved into ITS lidar frame; then the paint
+    radius.  points[i] / labels[i]: raw [n,5] float32 / mapped labels of keyframe i.  Returns (raw [m,5] float32, labels [m])."""
+    i = index + delta
+    raw = np.array(points[i], dtype=np.float32, copy=True).reshape(-1, 5)
+    no_ego = ~((np.abs(raw[:, 0]) < 1.0) & (np.abs(raw[:, 1]) < 1.5))
+    raw[:, 4] = stamps[index] / 1e6 - stamps[i] / 1e6
+    ann = np.asarray(labels[i]).reshape(-1, 1)
+    raw, ann = raw[no_ego], ann[no_ego]
+    for meta in range(-interval, 0):
+        j = i + meta
+        if j < 0 or j >= len(keys) or scene_of[j] != scene_of[index]:
+            continue
+        if prev_delta is not None and delta + meta <= prev_delta:
+            continue
+        raw1 = np.array(points[j], dtype=np.float32, copy=True).reshape(-1, 5)
+        no_ego1 = ~((np.abs(raw1[:, 0]) < 1.0) & (np.abs(raw1[:, 1]) < 1.5))
+        raw1[:, 4] = stamps[index] / 1e6 - stamps[j] / 1e6
+        ann1 = np.asarray(labels[j]).reshape(-1, 1)
+        raw1, ann1 = raw1[no_ego1], ann1[no_ego1]
+        raw1 = nus_transform_point(raw1, keys[i], keys[j])
+        raw = np.concatenate([raw, raw1], axis=0)
+        ann = np.concatenate([ann, ann1], axis=0)
+    if paint_dist > 0:
+        radius = np.linalg.norm(raw[:, :2], ord=2, axis=1, keepdims=False)
+        raw, ann = raw[radius <= paint_dist], ann[radius <= paint_dist]
+    return raw, ann.reshape(-1)

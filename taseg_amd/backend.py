@@ -822,6 +822,24 @@ def project_fov(points, proj, image_size, crop, row_offset=0.0):
     return pix, keep.bool()
 
 
+def project_cam(points, cam, image_size, crop_top, row_offset=0.0):
+    """nuScenes TIAF camera projection (nuscenes_ms_mm.py:349-398): points [n,4] float32 in the lidar frame, cam [57] float64
+    (taseg_amd.data.nuscenes_tiaf.camera_chain), image_size = (width, height) of the full-size camera image, crop_top rows cut
+    off the half-resolution image.  Returns (pix [n,2] float32 = (row + row_offset, col) at half resolution, keep [n] bool)."""
+    L.require_device(points, cam)
+    points = _f32(points, "points")
+    if cam.dtype != torch.float64 or cam.numel() != 57:
+        raise TypeError("cam must be 57 float64 values")
+    cam = cam.contiguous()
+    assert points.ndim == 2 and points.shape[1] == 4, points.shape
+    n = points.shape[0]
+    pix = torch.empty((n, 2), dtype=torch.float32, device=points.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=points.device)
+    L.check(L.load().ts_project_cam(L.ptr(points), n, L.ptr(cam), int(image_size[0]), int(image_size[1]), int(crop_top),
+                                    float(row_offset), L.ptr(pix), L.ptr(keep), L.stream()), "ts_project_cam")
+    return pix, keep.bool()
+
+
 def voxel_coords(points, voxel_size, batch_idx=None, n_batch=1, shift=None):
     """int32(round(xyz / voxel_size)) minus the per-scan minimum (or a given shift).
 

@@ -470,6 +470,72 @@ extern "C" int ts_project_fov(const float *points, int64_t n, const double *proj
   return TS_OK;
 }
 
+// nuScenes TIAF camera projection (nuscenes_ms_mm.py:349-398): see include/taseg_hip.h.  cam = 57 doubles:
+//   M1[9] t1[3] (lidar -> ego), M2[9] t2[3] (ego -> global), t3[3] M3[9] (global -> camera ego: subtract, then M3 =
+//   rotation^T), t4[3] M4[9] (camera ego -> camera), K[9] (intrinsic; the devkit pads it to 4 x 4 with a zero last column).
+// numpy evaluates every 3 x 3 product as an FMA chain over k in ascending order (dgemm), the additions separately.
+__global__ __launch_bounds__(256) void project_cam_kernel(const float4 *__restrict__ pts, int64_t n,
+                                                          const double *__restrict__ cam, int img_w, int img_h,
+                                                          int crop_top, float row_offset, float2 *__restrict__ pix,
+                                                          uint8_t *__restrict__ keep) {
+#pragma clang fp contract(off)
+  double C[57];
+#pragma unroll
+  for (int i = 0; i < 57; ++i) C[i] = cam[i];
+  auto mat = [](const double *M, const double *v, double *o) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = __builtin_fma(M[3 * j + 2], v[2], __builtin_fma(M[3 * j + 1], v[1], M[3 * j] * v[0]));
+  };
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float4 p = pts[i];
+    double a[3] = {(double)p.x, (double)p.y, (double)p.z}, b[3];
+    mat(C, a, b);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = b[j] + C[9 + j];
+    mat(C + 12, b, a);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[j] = (a[j] + C[21 + j]) - C[24 + j];
+    mat(C + 27, a, b);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = b[j] - C[36 + j];
+    mat(C + 39, b, a);
+    const double depth = a[2];
+    // viewpad @ (x, y, z, 1): the 4th column of the padded intrinsic is zero, fma(0, 1, acc) = acc + 0
+    double q[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      q[j] = __builtin_fma(0.0, 1.0, __builtin_fma(C[48 + 3 * j + 2], a[2], __builtin_fma(C[48 + 3 * j + 1], a[1], C[48 + 3 * j] * a[0])));
+    const float u = (float)(q[0] / q[2]), v = (float)(q[1] / q[2]);
+    bool ok = depth > 0.0 && u > 0.f && u < (float)img_w && v > 0.f && v < (float)img_h;
+    int row = 0, col = 0;
+    if (ok) {
+      row = ((int)v) >> 1;           // astype(int), then floor(0.5 * .) written back into the integer array
+      col = ((int)u) >> 1;
+      ok = row >= crop_top;
+      row -= crop_top;
+    }
+    keep[i] = ok ? 1 : 0;
+    pix[i] = make_float2(__fadd_rn((float)row, row_offset), (float)col);
+  }
+}
+
+extern "C" int ts_project_cam(const float *points, int64_t n, const double *cam, int32_t img_w, int32_t img_h,
+                              int32_t crop_top, float row_offset, float *pix, uint8_t *keep, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && img_w > 0 && img_h > 0 && crop_top >= 0, TS_ERR_INVALID_ARGUMENT, "ts_project_cam: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(points && cam && pix && keep, TS_ERR_INVALID_ARGUMENT, "ts_project_cam: null pointer");
+  TS_REQUIRE(((((uintptr_t)points) & 15) | (((uintptr_t)pix) & 7)) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_project_cam: points must be 16-byte, pix 8-byte aligned");
+  const int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
+  project_cam_kernel<<<grid, 256, 0, stream>>>((const float4 *)points, n, cam, img_w, img_h, crop_top, row_offset,
+                                               (float2 *)pix, keep);
+  TS_CHECK_LAUNCH("ts_project_cam");
+  return TS_OK;
+}
+
 extern "C" int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float *pose, float *out,
                             ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
