@@ -31,7 +31,7 @@ from make_golden_r2 import _ref_env, BACKEND_DESC, FLEX_NUS, nus_scene  # noqa: 
 
 VIEWS = ['CAM_FRONT', 'CAM_FRONT_RIGHT', 'CAM_BACK_RIGHT', 'CAM_BACK', 'CAM_BACK_LEFT', 'CAM_FRONT_LEFT']
 VIEW_YAW = [0.0, -55.0, -110.0, 180.0, 110.0, 55.0]            # degrees, ego frame (x forward, y left)
-IMG_H, IMG_W = 52, 96                                           # full-size camera image; half size minus 2 rows = 24 x 48
+IMG_H, IMG_W = 68, 96                                           # full-size camera image; half size minus 2 rows = 32 x 48 (UNet2D: multiples of 16)
 
 
 def _rot_to_quat(m):

@@ -14,7 +14,7 @@ from oracle import ts_oracle as O
 from taseg_amd.data import nuscenes_tiaf as T
 from taseg_amd.data.nuscenes import NuscSequence, select_sweeps, sweep_params
 
-IMG_H, IMG_W = 52, 96
+IMG_H, IMG_W = 68, 96
 
 
 @pytest.fixture(scope="module")
@@ -148,3 +148,20 @@ def test_device_stage_matches_the_reference(g):
         assert np.array_equal(batch[key].cpu().numpy().reshape(-1), g[f"batch_{key}"].reshape(-1)), key
     assert list(batch["depth_map_ms"].shape) == g["batch_depth_map_ms_shape"].tolist()
     assert list(batch["lidar_map_ms"].shape) == g["batch_lidar_map_ms_shape"].tolist()
+
+
+@pytest.mark.gpu
+def test_device_staged_batch_trains_the_nuscenes_tiaf_segmentor(g):
+    """the stage's batch_dict is what MinkUNetMsMmNus consumes (nuscenes/minkunet_mk34_cr10_fsa_tiaf.yaml:38-55: 17 classes,
+    IN_FEATURE_DIM 4, FOV losses on `targets_fov_ms`): one training step, five finite loss parts, gradients everywhere"""
+    from taseg_amd.data.synthetic import TIAF_CFG, fill_parameters, make_model_cfg
+    from taseg_amd.pcseg.model import build_network
+    batch = T.build_nusc_tiaf_batch([_device_sample(g, b) for b in range(2)])
+    cfg = make_model_cfg("MinkUNetMsMmNus", in_dim=4, cr=1.0, num_layer=[1] * 8, **TIAF_CFG)      # (the fusion head is cr 1.0 wide)
+    model = fill_parameters(build_network(cfg, 17), seed=3).cuda().train()
+    ret, tb, _ = model(batch)
+    assert np.isfinite(float(tb["loss"])) and len([k for k in tb if k.startswith("loss")]) >= 5
+    ret["loss"].backward()
+    missing = [n for n, p in model.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters())
