@@ -634,8 +634,10 @@ def main():
 
     from taseg_amd.data.stage import DevicePrefetcher
     prepare = (lambda bd: bd.get("_plan") or model.prepare(bd)) if os.environ.get("TASEG_REUSE_PLAN") == "1" else model.prepare
-    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, prepare,
-                                                        threaded=os.environ.get("TASEG_STAGE_THREAD", "1" if args.amp else "0") == "1")
+    threaded = os.environ.get("TASEG_STAGE_THREAD", "1" if args.amp else "0") == "1"
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, prepare, threaded=threaded)
+    # host-bound steps (the threaded stage is their mark) start staging batch i + 1 right after the forward pass of step i
+    early_stage = os.environ.get("TASEG_STAGE_EARLY", "1" if threaded else "0") == "1"
 
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
     B.planes_in_use = _planes._ENABLED and not args.amp        # names the 128-column fp32 pair GEMM in the kernel table
@@ -652,6 +654,8 @@ def main():
                 ret, _, _ = net(make_batch())
             else:
                 ret, _, _ = net(pf.next())
+        if pf is not None and early_stage:
+            pf.prefetch_early()          # the next batch is staged beside this step's backward pass (worker thread)
         loss = ret["loss"].float().mean()
         if flat:
             (loss * opt.loss_scale()).backward()

@@ -190,7 +190,9 @@ class DevicePrefetcher:
         pf = DevicePrefetcher(make_batch, model.prepare)
         for _ in range(steps):
             batch = pf.next()          # staged earlier; the current stream waits on its ready-event
-            ... forward / backward / optimizer step on `batch` ...
+            ... forward ...
+            pf.prefetch_early()        # (optional) stage the following batch beside the backward pass
+            ... backward / optimizer step on `batch` ...
             pf.prefetch()              # stage the following batch (optional: next() does it if needed)
 
     Memory: tensors of a staged batch are allocated on the side stream and consumed on the launch stream, so
@@ -223,6 +225,18 @@ class DevicePrefetcher:
             self._current = None
         self._inflight = [(b, e) for b, e in self._inflight if not e.query()]
 
+    def prefetch_early(self):
+        """Start staging the following batch while the CURRENT one is still in use (call it right after the forward pass has
+        been issued): the stage then runs beside the backward pass instead of between two steps - what matters when the
+        step is host-bound and the stage runs on a worker thread (`threaded=True`; measured: the AMP step at bs 2 waited
+        2.6 ms per step for a stage that was started at the end of the previous step).  The current batch is NOT retired
+        here; next() / prefetch() do that."""
+        if self._staged is not None:
+            return
+        if not self._inflight and self._current is None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._staged = self._pool.submit(self._stage) if self._pool is not None else self._stage()
+
     def prefetch(self):
         if self._staged is not None:
             return
@@ -246,6 +260,7 @@ class DevicePrefetcher:
         return batch, ready
 
     def next(self):
+        self._retire()               # the previous batch: every launch that reads it has been issued by now
         self.prefetch()
         staged = self._staged
         batch, ready = staged.result() if hasattr(staged, "result") else staged

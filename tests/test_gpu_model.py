@@ -264,7 +264,8 @@ rccl.shutdown()
 dist.destroy_process_group()
 print("SYNC_OK")
 '''
-    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    # TASEG_RCCL_DIRECT=1: the library-owned communicator is opt-in while TASEG_DIST_SINGLE_COMM is the default (taseg_amd/rccl.py)
+    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), TASEG_RCCL_DIRECT="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "SYNC_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
