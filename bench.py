@@ -406,6 +406,10 @@ def summarise_families(prof, amp, traffic_table):
         f["t_mfma"] += r["flops_per_launch"] * r["launches_per_step"] / (mfma_peak_of(r["kernel"], amp) * 1e12)
         f["members"].append(r["kernel"])
         entry = traffic_table.get(r["kernel"])
+        if entry is None:        # rocprofv3 prints every template argument (the trailing diagnostics flag too): match by prefix
+            stem = r["kernel"][:-1] if r["kernel"].endswith(">") else r["kernel"]
+            hits = [v for k, v in traffic_table.items() if k.startswith(stem + ",") or k == stem + ">"]
+            entry = hits[0] if len(hits) == 1 else None
         if entry is None:
             f["traffic_ok"] = False
         else:

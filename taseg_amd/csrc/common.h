@@ -109,6 +109,36 @@ __device__ __forceinline__ int ts_table_find(const TsTable &t, uint64_t key) {
   return -1;
 }
 
+// N look-ups at once: the first-slot key loads are independent and in flight together, then the value loads of the hits;
+// only a key whose first slot holds ANOTHER key (load factor <= 0.5) walks on sequentially.  Same results as N calls of
+// ts_table_find, which costs 2 dependent round trips per key, one key after the other.
+template <int N>
+__device__ __forceinline__ void ts_table_find_n(const TsTable &t, const unsigned long long (&want)[N], bool valid, int (&r)[N]) {
+  uint32_t slot[N];
+  unsigned long long got[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) slot[i] = ts_slot0(want[i], t.mask);
+#pragma unroll
+  for (int i = 0; i < N; ++i) got[i] = valid ? t.keys[slot[i]] : TS_EMPTY_KEY;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = (got[i] == want[i]) ? t.vals[slot[i]] : -1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (got[i] != want[i] && got[i] != TS_EMPTY_KEY) {
+      uint32_t s = (slot[i] + 1) & t.mask;
+      for (uint32_t probe = 0; probe < t.mask; ++probe) {
+        const unsigned long long kk = t.keys[s];
+        if (kk == want[i]) {
+          r[i] = t.vals[s];
+          break;
+        }
+        if (kk == TS_EMPTY_KEY) break;
+        s = (s + 1) & t.mask;
+      }
+    }
+  }
+}
+
 // Carve a table out of a workspace and reset it on `stream`.
 int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream,
                   size_t *used);
