@@ -462,7 +462,13 @@ int ts_bn_sync_backward(void *comm, const void *grad_out, const uint8_t *mask, c
  * (minkunet.py:31-129: BasicConvolutionBlock, BasicDeconvolutionBlock, the two halves of ResidualBlock).  Chains the
  * launches of ts_conv_pair_gemm / ts_conv_gather_sum (or the _f16 forms, half = 1) and ts_bn_act_train_* (comm == NULL)
  * or ts_bn_sync_* (comm = a ts_rccl_comm_init communicator) on `stream`; Z, the gradient w.r.t. the convolution output
- * and the transposed half weight live in `ws` (ts_conv_block_workspace_bytes).  Arguments: csrc/block.hip. */
+ * and the transposed half weight live in `ws` (ts_conv_block_workspace_bytes).  Arguments: csrc/block.hip.
+ * SyncBatchNorm with the all-reduce run by the CALLER (torch.distributed on its own communicator): comm = (void *)1 makes
+ * the call stop after the local sums (forward: convolution + `pack`; backward: `sums`), the caller all-reduces that buffer
+ * over its ranks and calls again with the same arguments and comm = (void *)2, which runs what is left (forward: statistics +
+ * elementwise pass; backward: elementwise pass + weight gradient + input gradient).  One-shot hints go with the second call
+ * of a backward pair and with the FIRST of a forward pair (the convolution runs there).  ts_bn_sync_forward / _backward take the
+ * same two values. */
 size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
                                      int32_t half);
 int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,

@@ -188,7 +188,9 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   }
   void *bn_ws = p;
   const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
-  if (half) {
+  if (comm == TS_COMM_CALLER_POST) {
+    // second half of a split call: conv_out and the all-reduced pack exist, statistics + elementwise pass are left
+  } else if (half) {
     // one half copy in the kernel's own layout serves both passes: the forward reads it through the transposing LDS
     // load (ts_conv_pair_gemm_f16_nat), the input gradient directly
     (void)w16t;
@@ -261,6 +263,8 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   if (comm) {
     TS_TRY(ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums,
                                grad_conv, grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));
+    // first half of a split call: the local sums are out, the caller all-reduces them (one-shot hints go with the second half)
+    if (comm == TS_COMM_CALLER_PRE) return TS_OK;
   } else if (half) {
     TS_TRY(ts_bn_act_train_backward_f16(grad_out, mask, conv_out, mean, invstd, bn_weight, n_out, c_out, grad_conv,
                                         grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));

@@ -197,6 +197,11 @@ __device__ __forceinline__ void ts_wgrad_reduce_one(const TsWgradReduce &job, in
   ((float4 *)job.dW)[i] = acc;
 }
 
+// Communicator sentinels of ts_bn_sync_* / ts_conv_block_* (include/taseg_hip.h): the CALLER owns the all-reduce and splits the
+// call in two around it - PRE stops after the local sums, POST starts behind the all-reduce.
+#define TS_COMM_CALLER_PRE ((void *)1)
+#define TS_COMM_CALLER_POST ((void *)2)
+
 // ---- pre-split weight planes (conv_pairs_s.hip) -------------------------------------------------------------------
 struct TsPlanesHint {
   const float *w;                  // the weight the planes were split from

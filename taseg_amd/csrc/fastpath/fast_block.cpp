@@ -6,6 +6,7 @@
 // bookkeeping and argument marshalling around ~25 us of launches.  PyTorch supplies memory, streams and the autograd
 // graph only.
 #include <dlfcn.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
 #include <mutex>
@@ -53,6 +54,25 @@ at::Tensor workspace(size_t nbytes, const at::Tensor &like, int64_t stream) {
   return it->second;
 }
 
+// SyncBatchNorm over torch.distributed: process groups registered from Python (register_group), addressed by index.  The
+// node then splits its backend call around ProcessGroup::allreduce on the group's own communicator (csrc/block.hip: comm
+// sentinels 1 / 2) - the C++ counterpart of functional._ConvBlock's split path, without the interpreter in between.
+std::mutex group_mutex;
+std::vector<c10::intrusive_ptr<c10d::ProcessGroup>> groups;
+
+void group_sum(int64_t id, at::Tensor buf) {
+  c10::intrusive_ptr<c10d::ProcessGroup> pg;
+  {
+    std::lock_guard<std::mutex> lock(group_mutex);
+    TORCH_CHECK(id >= 0 && id < (int64_t)groups.size(), "conv_block: unknown process group id ", id);
+    pg = groups[id];
+  }
+  std::vector<at::Tensor> v{std::move(buf)};
+  pg->allreduce(v, c10d::AllreduceOptions())->wait();      // the current stream waits for the collective; no host wait (NCCL)
+}
+
+void *const COMM_PRE = (void *)1, *const COMM_POST = (void *)2;
+
 inline void *ptr(const at::Tensor &t) { return t.defined() ? t.data_ptr() : nullptr; }
 inline void *optr(const c10::optional<at::Tensor> &t) { return (t.has_value() && t->defined()) ? t->data_ptr() : nullptr; }
 
@@ -66,8 +86,9 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt,
                             double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream,
                             const c10::optional<at::Tensor> &planes, bool passthrough,
-                            const c10::optional<at::Tensor> &grad_dest) {
+                            const c10::optional<at::Tensor> &grad_dest, int64_t group_id) {
     const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
+    const bool split = comm == 0 && group_id >= 0;
     const auto dt = half ? at::kHalf : at::kFloat;
     const int64_t rows = transposed ? n_in : n_out;
     const at::Tensor &table = transposed ? pos_in : pos_out;
@@ -81,21 +102,30 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor mask, w16, pack;
     if (relu) mask = at::empty({rows * (c_out / (half ? 8 : 4))}, opts.dtype(at::kByte));
     if (half) w16 = at::empty({k, c_in, c_out}, opts.dtype(at::kHalf));
-    if (comm) pack = at::empty({2 * c_out + 1}, opts.dtype(at::kDouble));
+    if (comm || split) pack = at::empty({2 * c_out + 1}, opts.dtype(at::kDouble));
     const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
     at::Tensor ws = workspace(nb, x, stream);
     float *st = stats.data_ptr<float>();
     at::Tensor pl;                       // pre-split planes of the weight (taseg_amd/planes.py); fp32 blocks only
     if (!half && planes.has_value() && planes->defined() && w32.data_ptr() == weight.data_ptr()) pl = *planes;
     if (pl.defined()) api.planes_hint(w32.data_ptr<float>(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
-    check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
-                      (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
-                      (const int32_t *)table.data_ptr(), rows, (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(),
-                      (const float *)bn_bias.data_ptr(), (float *)optr(running_mean), (float *)optr(running_var),
-                      (int64_t *)optr(nbt), (float)eps, (float)momentum, relu ? 1 : 0, half ? 1 : 0, (void *)comm,
-                      (double *)ptr(pack), conv_out.data_ptr(), st, st + c_out, out.data_ptr(), (uint8_t *)ptr(mask), ptr(w16),
-                      ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
-          "ts_conv_block_forward");
+    auto call = [&](void *c) {
+      check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
+                        (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
+                        (const int32_t *)table.data_ptr(), rows, (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(),
+                        (const float *)bn_bias.data_ptr(), (float *)optr(running_mean), (float *)optr(running_var),
+                        (int64_t *)optr(nbt), (float)eps, (float)momentum, relu ? 1 : 0, half ? 1 : 0, c,
+                        (double *)ptr(pack), conv_out.data_ptr(), st, st + c_out, out.data_ptr(), (uint8_t *)ptr(mask), ptr(w16),
+                        ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
+            "ts_conv_block_forward");
+    };
+    if (split) {
+      call(COMM_PRE);                    // convolution + this rank's sums (the planes hint is consumed here)
+      group_sum(group_id, pack);
+      call(COMM_POST);                   // statistics over all ranks + elementwise pass
+    } else {
+      call((void *)comm);
+    }
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
     // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
@@ -106,6 +136,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     ctx->saved_data["transposed"] = transposed;
     ctx->saved_data["half"] = half;
     ctx->saved_data["comm"] = comm;
+    ctx->saved_data["group_id"] = split ? group_id : (int64_t)-1;
     ctx->saved_data["stream"] = stream;
     ctx->saved_data["has_res"] = res.defined();
     ctx->saved_data["in_dtype"] = (int64_t)feats.scalar_type();
@@ -147,11 +178,27 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     }
     if (has_res && ctx->needs_input_grad(2)) grad_res = at::empty_like(conv_out);
     at::Tensor gwb = at::empty({2, c_out}, opts.dtype(at::kFloat));
-    if (comm) sums = at::empty({2, c_out}, opts.dtype(at::kDouble));
+    const int64_t group_id = ctx->saved_data["group_id"].toInt();
+    const bool split = group_id >= 0;
+    if (comm || split) sums = at::empty({2, c_out}, opts.dtype(at::kDouble));
     const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
     at::Tensor ws = workspace(nb, x, stream);
     const float *st = stats.data_ptr<float>();
     float *gw = gwb.data_ptr<float>();
+    auto call = [&](void *c) {
+      check(api.backward(g.data_ptr(), (const uint8_t *)ptr(mask), conv_out.data_ptr(), st, st + c_out,
+                         (const float *)bn_weight.data_ptr(), pack.defined() ? pack.data_ptr<double>() + 2 * c_out : nullptr,
+                         c, (double *)ptr(sums), rows, (int32_t)c_out, half ? 1 : 0, x.data_ptr(), x.size(0),
+                         (int32_t)c_in, w.data_ptr(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
+                         (const int32_t *)nboffs.data_ptr(), total, transposed ? 0 : 1, (const int32_t *)table.data_ptr(), drows,
+                         transposed ? 1 : 0, ptr(grad_feat), ptr(grad_res), (float *)ptr(grad_w), gw, gw + c_out, ws.data_ptr(),
+                         (size_t)ws.numel(), (ts_stream_t)stream),
+            "ts_conv_block_backward");
+    };
+    if (split) {
+      call(COMM_PRE);                    // this rank's sums of the BatchNorm backward
+      group_sum(group_id, sums.view({-1}));
+    }
     at::Tensor addend;                   // gradient of the passed-through input, in grad_feat's storage type
     if (grads.size() > 1 && grads[1].defined() && grad_feat.defined()) {
       addend = grads[1].contiguous().to(conv_out.scalar_type());
@@ -161,19 +208,12 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const at::Tensor pl = ctx->saved_data["planes"].toTensor();
     if (pl.defined() && !half && grad_feat.defined())
       api.planes_hint((const float *)w.data_ptr(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
-    check(api.backward(g.data_ptr(), (const uint8_t *)ptr(mask), conv_out.data_ptr(), st, st + c_out,
-                       (const float *)bn_weight.data_ptr(), pack.defined() ? pack.data_ptr<double>() + 2 * c_out : nullptr,
-                       (void *)comm, (double *)ptr(sums), rows, (int32_t)c_out, half ? 1 : 0, x.data_ptr(), x.size(0),
-                       (int32_t)c_in, w.data_ptr(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
-                       (const int32_t *)nboffs.data_ptr(), total, transposed ? 0 : 1, (const int32_t *)table.data_ptr(), drows,
-                       transposed ? 1 : 0, ptr(grad_feat), ptr(grad_res), (float *)ptr(grad_w), gw, gw + c_out, ws.data_ptr(),
-                       (size_t)ws.numel(), (ts_stream_t)stream),
-          "ts_conv_block_backward");
+    call(split ? COMM_POST : (void *)comm);
     if (grad_feat.defined() && grad_feat.scalar_type() != in_dtype) grad_feat = grad_feat.to(in_dtype);
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -213,11 +253,25 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt, double momentum,
                       double eps, bool relu, int64_t comm, bool half, int64_t stream,
                       const c10::optional<at::Tensor> &planes, bool passthrough,
-                      const c10::optional<at::Tensor> &grad_dest) {
+                      const c10::optional<at::Tensor> &grad_dest, int64_t group_id) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
-                          passthrough, grad_dest);
+                          passthrough, grad_dest, group_id);
+}
+
+// torch.distributed process group -> the index conv_block takes as `group_id` (SyncBatchNorm's all-reduce through c10d)
+int64_t register_group(const c10::intrusive_ptr<c10d::ProcessGroup> &pg) {
+  std::lock_guard<std::mutex> lock(group_mutex);
+  for (size_t i = 0; i < groups.size(); ++i)
+    if (groups[i].get() == pg.get()) return (int64_t)i;
+  groups.push_back(pg);
+  return (int64_t)groups.size() - 1;
+}
+
+void clear_groups() {
+  std::lock_guard<std::mutex> lock(group_mutex);
+  groups.clear();
 }
 
 // ------------------------------------------------------------------------------------------------ index plan
@@ -367,4 +421,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("index_plan", &index_plan, "coordinate pyramid + kernel maps + trilinear maps of a MinkUNet pass (releases the GIL)");
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");
   m.def("conv_block", &conv_block, "act(BN(conv(x)) [+ residual]) as one native autograd node");
+  m.def("register_group", &register_group, "process group -> id for conv_block's c10d SyncBatchNorm path");
+  m.def("clear_groups", &clear_groups, "drop the registered process groups (before destroy_process_group)");
 }

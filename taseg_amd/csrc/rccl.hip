@@ -109,12 +109,16 @@ extern "C" int ts_bn_sync_forward(void *comm, const void *x, const void *residua
                                   float *invstd, void *out, uint8_t *mask, void *ws, size_t ws_bytes,
                                   ts_stream_t stream) {
   TS_REQUIRE(pack, TS_ERR_INVALID_ARGUMENT, "ts_bn_sync_forward: null pointer");
-  if (num_batches_tracked) bn_count_batch_kernel<<<1, 1, 0, (hipStream_t)stream>>>(num_batches_tracked);
-  if (half)
-    TS_TRY(ts_bn_sync_stats_f16(x, n, c, pack, ws, ws_bytes, stream));
-  else
-    TS_TRY(ts_bn_sync_stats((const float *)x, n, c, pack, ws, ws_bytes, stream));
-  TS_TRY(ts_rccl_allreduce_f64(comm, pack, 2 * (int64_t)c + 1, stream));
+  // comm = TS_COMM_CALLER_PRE / _POST: the caller runs the all-reduce itself (torch.distributed) between two calls
+  if (comm != TS_COMM_CALLER_POST) {
+    if (num_batches_tracked) bn_count_batch_kernel<<<1, 1, 0, (hipStream_t)stream>>>(num_batches_tracked);
+    if (half)
+      TS_TRY(ts_bn_sync_stats_f16(x, n, c, pack, ws, ws_bytes, stream));
+    else
+      TS_TRY(ts_bn_sync_stats((const float *)x, n, c, pack, ws, ws_bytes, stream));
+    if (comm == TS_COMM_CALLER_PRE) return TS_OK;
+    TS_TRY(ts_rccl_allreduce_f64(comm, pack, 2 * (int64_t)c + 1, stream));
+  }
   TS_TRY(ts_bn_finalize(pack, pack + 2 * c, (double)n, c, eps, momentum, running_mean, running_var, mean, invstd, stream));
   if (half)
     return ts_bn_act_forward_f16(x, residual, mean, invstd, weight, bias, n, c, relu, out, mask, stream);
@@ -130,13 +134,16 @@ extern "C" int ts_bn_sync_backward(void *comm, const void *grad_out, const uint8
                                    void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias, void *ws,
                                    size_t ws_bytes, ts_stream_t stream) {
   TS_REQUIRE(sums && total_dev, TS_ERR_INVALID_ARGUMENT, "ts_bn_sync_backward: null pointer");
-  if (half)
-    TS_TRY(ts_bn_sync_backward_reduce_f16(grad_out, mask, x, mean, invstd, n, c, sums, grad_weight, grad_bias, ws, ws_bytes,
-                                          stream));
-  else
-    TS_TRY(ts_bn_sync_backward_reduce((const float *)grad_out, mask, (const float *)x, mean, invstd, n, c, sums,
-                                      grad_weight, grad_bias, ws, ws_bytes, stream));
-  TS_TRY(ts_rccl_allreduce_f64(comm, sums, 2 * (int64_t)c, stream));
+  if (comm != TS_COMM_CALLER_POST) {
+    if (half)
+      TS_TRY(ts_bn_sync_backward_reduce_f16(grad_out, mask, x, mean, invstd, n, c, sums, grad_weight, grad_bias, ws, ws_bytes,
+                                            stream));
+    else
+      TS_TRY(ts_bn_sync_backward_reduce((const float *)grad_out, mask, (const float *)x, mean, invstd, n, c, sums,
+                                        grad_weight, grad_bias, ws, ws_bytes, stream));
+    if (comm == TS_COMM_CALLER_PRE) return TS_OK;
+    TS_TRY(ts_rccl_allreduce_f64(comm, sums, 2 * (int64_t)c, stream));
+  }
   if (half)
     return ts_bn_act_backward_f16(grad_out, mask, x, mean, invstd, weight, sums, total_dev, (double)n, n, c, grad_x,
                                   grad_residual, ws, ws_bytes, stream);

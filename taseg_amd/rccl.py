@@ -84,8 +84,21 @@ def direct_comm(group):
     return _comms[key]
 
 
+def c10d_sum(buf, group):
+    """In-place sum of `buf` over the ranks of `group` on the group's own communicator; the current stream waits for the
+    collective (no host wait).  ProcessGroup.allreduce directly: torch.distributed.all_reduce adds ~10 us of argument
+    checking per call, and a SyncBatchNorm training step makes 126 of these."""
+    group.allreduce([buf]).wait()
+
+
 def shutdown():
-    """Destroy the communicators (call before dist.destroy_process_group())."""
+    """Destroy the communicators and drop the native node's process-group handles (call before
+    dist.destroy_process_group())."""
+    from . import _fast
+    from .torchsparse.nn import modules as _modules
+    if _fast._mod is not None:
+        _fast._mod.clear_groups()
+    _modules._group_ids.clear()
     lib = L.load()
     for key, comm in list(_comms.items()):
         if comm is not None and comm.value:

@@ -5,11 +5,10 @@ Single process: one backend call per direction (`ts_bn_act_train_*`, fp32 or hal
 sliced sums -> ONE all-reduce of [2C+1] (forward) / [2C] (backward) doubles -> elementwise kernels; torch's own
 SyncBatchNorm (torch/nn/modules/_functions.py) all-gathers per-rank mean / invstd / count instead."""
 import torch
-import torch.distributed as dist
 from torch.autograd import Function
 
 from ... import _lib as L
-from ...rccl import direct_comm
+from ...rccl import c10d_sum, direct_comm
 
 __all__ = ["batch_norm_train", "fast_path_ok"]
 
@@ -66,7 +65,7 @@ class _BatchNormActTrain(Function):
             pack = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
             L.check(getattr(lib, "ts_bn_sync_stats" + sfx)(L.ptr(x), n, c, L.ptr(pack), L.ptr(ws), ws.numel(),
                                                            L.stream()), "ts_bn_sync_stats" + sfx)
-            dist.all_reduce(pack, group=group)
+            c10d_sum(pack, group)
             total_dev = pack[2 * c:]
             L.check(lib.ts_bn_finalize(L.ptr(pack), L.ptr(total_dev), float(n), c, float(eps), float(momentum),
                                        L.ptr(running_mean), L.ptr(running_var), L.ptr(mean), L.ptr(invstd),
@@ -106,7 +105,7 @@ class _BatchNormActTrain(Function):
             L.check(getattr(lib, "ts_bn_sync_backward_reduce" + sfx)(
                 L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd), n, c, L.ptr(sums), L.ptr(gwb[0]),
                 L.ptr(gwb[1]), L.ptr(ws), ws.numel(), L.stream()), "ts_bn_sync_backward_reduce" + sfx)
-            dist.all_reduce(sums, group=ctx.group)
+            c10d_sum(sums, ctx.group)
             if ctx.half:
                 L.check(lib.ts_bn_act_backward_f16(L.ptr(grad_out), L.ptr(mask), L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                                    L.ptr(weight), L.ptr(sums), L.ptr(ctx.total_dev), float(n), n, c,

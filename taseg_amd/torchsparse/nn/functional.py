@@ -614,6 +614,14 @@ def _conv_output(input: SparseTensor, out_feats, out_coords, out_stride) -> Spar
     return output
 
 
+import ctypes as _ctypes
+
+_COMM_PRE, _COMM_POST = _ctypes.c_void_p(1), _ctypes.c_void_p(2)      # split-call sentinels (include/taseg_hip.h)
+
+
+from ...rccl import c10d_sum as _c10d_sum  # noqa: E402
+
+
 class _ConvBlock(Function):
     """act(BN(conv(x)) [+ residual]) in training mode as ONE autograd node and one backend call per direction
     (csrc/block.hip).  Same launches and arithmetic as `_SparseConv` followed by `_BatchNormActTrain`; Z, the gradient
@@ -621,7 +629,7 @@ class _ConvBlock(Function):
 
     @staticmethod
     def forward(ctx, feats, weight, residual, bn_weight, bn_bias, kmap, transposed, bn_state, relu, comm, half, planes=None,
-                passthrough=False, grad_dest=None):
+                passthrough=False, grad_dest=None, group=None):
         running_mean, running_var, nbt, momentum, eps = bn_state
         lib = B.L.load()
         L = B.L
@@ -638,20 +646,33 @@ class _ConvBlock(Function):
         stats = torch.empty((2, c_out), dtype=torch.float32, device=dev)
         mask = torch.empty(rows * (c_out // (8 if half else 4)), dtype=torch.uint8, device=dev) if relu else None
         w16 = torch.empty((k, c_in, c_out), dtype=torch.float16, device=dev) if half else None
-        pack = torch.empty(2 * c_out + 1, dtype=torch.float64, device=dev) if comm is not None else None
+        # SyncBatchNorm transports: `comm` = the library-owned RCCL communicator (collective inline on this stream), or - `group`
+        # given without one - torch.distributed runs the all-reduce between the two halves of a split call (csrc/block.hip)
+        split = comm is None and group is not None
+        pack = torch.empty(2 * c_out + 1, dtype=torch.float64, device=dev) if (comm is not None or split) else None
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
         if half or w32.data_ptr() != weight.data_ptr():
             planes = None
+
+        def call(c):
+            L.check(lib.ts_conv_block_forward(
+                L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol,
+                L.ptr(table), rows, c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
+                L.ptr(running_var), L.ptr(nbt), float(eps), float(momentum), 1 if relu else 0, 1 if half else 0, c,
+                L.ptr(pack), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(out), L.ptr(mask), L.ptr(w16), L.ptr(ws),
+                ws.numel(), L.stream()), "ts_conv_block_forward")
+
         _planes.hint(w32, planes)
-        L.check(lib.ts_conv_block_forward(
-            L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol,
-            L.ptr(table), rows, c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
-            L.ptr(running_var), L.ptr(nbt), float(eps), float(momentum), 1 if relu else 0, 1 if half else 0, comm,
-            L.ptr(pack), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(out), L.ptr(mask), L.ptr(w16), L.ptr(ws),
-            ws.numel(), L.stream()), "ts_conv_block_forward")
+        if split:
+            call(_COMM_PRE)                       # convolution + this rank's sums
+            _c10d_sum(pack, group)
+            call(_COMM_POST)                      # statistics over all ranks + elementwise pass
+        else:
+            call(comm)
         ctx.save_for_backward(x, w16 if half else w32, conv_out, stats, mask, bn_weight)
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
+        ctx.group = group if split else None
         ctx.planes = planes
         ctx.grad_dest = grad_dest        # where the weight gradient is wanted (a gradient bucket's view), or None
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
@@ -686,25 +707,33 @@ class _ConvBlock(Function):
                 grad_w = torch.empty((k, c_in, c_out), dtype=torch.float32, device=dev)
         grad_res = torch.empty_like(conv_out) if (ctx.res_dtype is not None and need[2]) else None
         gwb = torch.empty((2, c_out), dtype=torch.float32, device=dev)
-        sums = torch.empty((2, c_out), dtype=torch.float64, device=dev) if comm is not None else None
+        split = ctx.group is not None
+        sums = torch.empty((2, c_out), dtype=torch.float64, device=dev) if (comm is not None or split) else None
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+
+        def call(c):
+            L.check(lib.ts_conv_block_backward(
+                L.ptr(g), L.ptr(mask), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn_weight),
+                L.ptr(ctx.total_dev), c, L.ptr(sums), rows, c_out, 1 if half else 0, L.ptr(x), x.shape[0], c_in, L.ptr(w), k,
+                L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), drows, 1 if transposed else 0,
+                L.ptr(grad_feat), L.ptr(grad_res), L.ptr(grad_w), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(),
+                L.stream()), "ts_conv_block_backward")
+
+        if split:
+            call(_COMM_PRE)                       # this rank's sums of the BatchNorm backward
+            _c10d_sum(sums, ctx.group)
         if grad_feat is not None and not half:
             _planes.hint(w, ctx.planes)
         if grad_pass is not None and grad_feat is not None:
             addend = grad_pass.contiguous().to(dt)
             lib.ts_conv_block_addend_hint(L.ptr(addend))
-        L.check(lib.ts_conv_block_backward(
-            L.ptr(g), L.ptr(mask), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn_weight),
-            L.ptr(ctx.total_dev), comm, L.ptr(sums), rows, c_out, 1 if half else 0, L.ptr(x), x.shape[0], c_in, L.ptr(w), k,
-            L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), drows, 1 if transposed else 0,
-            L.ptr(grad_feat), L.ptr(grad_res), L.ptr(grad_w), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(),
-            L.stream()), "ts_conv_block_backward")
+        call(_COMM_POST if split else comm)
         if grad_feat is not None and grad_feat.dtype != ctx.in_dtype:
             grad_feat = grad_feat.to(ctx.in_dtype)
         if grad_res is not None and grad_res.dtype != ctx.res_dtype:
             grad_res = grad_res.to(ctx.res_dtype)
-        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None, None, None
+        return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None, None, None, None
 
 
 def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", residual, rows: int) -> bool:

@@ -125,6 +125,19 @@ def bn_act(mod, input: SparseTensor, relu: bool = True, residual: SparseTensor =
     return input._like(out)
 
 
+_group_ids = {}
+
+
+def _group_id(fast, group):
+    """index of a torch.distributed process group in the native node's registry (-1 = no c10d all-reduce in the block)"""
+    if group is None:
+        return -1
+    key = id(group)
+    if key not in _group_ids:
+        _group_ids[key] = fast.register_group(group)
+    return _group_ids[key]
+
+
 def _claim_grad_dest(kernel):
     """The gradient-bucket slot of `kernel` (parallel.GradBucketReducer) as the place the block's backward may write the
     weight gradient STRAIGHT into - or None.  The slot is a full-overwrite target that autograd then adopts as p.grad, so it
@@ -160,33 +173,34 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
         group = _sync_group(mod)
         _require_rows(input.feats, group)
         comm = None if group is None else direct_comm(group)
-        if group is None or comm is not None:
-            kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)
-            n_in, n_out = kmap.sizes
-            rows = n_in if conv.transposed else n_out
-            res = None if residual is None else residual.feats
-            feats = input.feats
-            if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
-                track = mod.track_running_stats
-                state = (mod.running_mean if track else None, mod.running_var if track else None,
-                         mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
-                fast = _fast.module()
-                half = F._amp_half(feats)
-                planes = None if half else _planes.planes_for(conv.kernel)      # pre-split weight (taseg_amd/planes.py)
-                dest = _claim_grad_dest(conv.kernel)                            # bucket slot of the weight gradient (parallel.py)
-                if fast is not None:            # C++ autograd node, same two backend calls (csrc/fastpath)
-                    out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
-                                          kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
-                                          state[1], state[2], float(mod.momentum), float(mod.eps), relu,
-                                          (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
-                                          bool(passthrough), dest)
-                    out, passed = (out[0], out[1]) if passthrough else (out[0], None)
-                else:
-                    out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
-                                             relu, comm, half, planes, bool(passthrough), dest)
-                    out, passed = out if passthrough else (out, None)
-                result = F._conv_output(input, out, out_coords, out_stride)
-                return (result, input._like(passed)) if passthrough else result
+        # SyncBatchNorm without the library-owned communicator: the Python node splits the block call around c10d's all-reduce
+        kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)
+        n_in, n_out = kmap.sizes
+        rows = n_in if conv.transposed else n_out
+        res = None if residual is None else residual.feats
+        feats = input.feats
+        if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
+            track = mod.track_running_stats
+            state = (mod.running_mean if track else None, mod.running_var if track else None,
+                     mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
+            fast = _fast.module()
+            half = F._amp_half(feats)
+            planes = None if half else _planes.planes_for(conv.kernel)      # pre-split weight (taseg_amd/planes.py)
+            dest = _claim_grad_dest(conv.kernel)                            # bucket slot of the weight gradient (parallel.py)
+            c10d_group = group if (group is not None and comm is None) else None
+            if fast is not None:                          # C++ autograd node, same backend calls (csrc/fastpath)
+                out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
+                                      kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
+                                      state[1], state[2], float(mod.momentum), float(mod.eps), relu,
+                                      (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
+                                      bool(passthrough), dest, _group_id(fast, c10d_group))
+                out, passed = (out[0], out[1]) if passthrough else (out[0], None)
+            else:
+                out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
+                                         relu, comm, half, planes, bool(passthrough), dest, c10d_group)
+                out, passed = out if passthrough else (out, None)
+            result = F._conv_output(input, out, out_coords, out_stride)
+            return (result, input._like(passed)) if passthrough else result
     result = bn_act(mod, conv(input), relu=relu, residual=residual)
     return (result, input) if passthrough else result
 
