@@ -68,7 +68,10 @@ void group_sum(int64_t id, at::Tensor buf) {
     pg = groups[id];
   }
   std::vector<at::Tensor> v{std::move(buf)};
-  pg->allreduce(v, c10d::AllreduceOptions())->wait();      // the current stream waits for the collective; no host wait (NCCL)
+  c10d::AllreduceOptions opts;
+  opts.asyncOp = false;                // as dist.all_reduce(async_op=False): ProcessGroupNCCL issues it on the CURRENT stream
+  auto work = pg->allreduce(v, opts);
+  if (work) work->wait();              // (ProcessGroupNCCL hands back no work object for a current-stream collective)
 }
 
 void *const COMM_PRE = (void *)1, *const COMM_POST = (void *)2;

@@ -87,8 +87,19 @@ def direct_comm(group):
 def c10d_sum(buf, group):
     """In-place sum of `buf` over the ranks of `group` on the group's own communicator; the current stream waits for the
     collective (no host wait).  ProcessGroup.allreduce directly: torch.distributed.all_reduce adds ~10 us of argument
-    checking per call, and a SyncBatchNorm training step makes 126 of these."""
-    group.allreduce([buf]).wait()
+    checking per call, and a SyncBatchNorm training step makes 126 of these.  asyncOp = False as in dist.all_reduce(...,
+    async_op=False): ProcessGroupNCCL then issues the collective on the CURRENT stream - no side stream, no pair of
+    cross-stream hand-overs per call."""
+    global _sync_opts
+    if _sync_opts is None:
+        _sync_opts = dist.AllreduceOptions()
+        _sync_opts.asyncOp = False
+    work = group.allreduce([buf], _sync_opts)
+    if work is not None:             # (ProcessGroupNCCL returns no work object for a current-stream collective)
+        work.wait()
+
+
+_sync_opts = None
 
 
 def shutdown():
