@@ -118,7 +118,16 @@ def test_flat_sgd_unused_parameter_rule_is_global(tmp_path):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two ROCm devices (RCCL refuses two ranks on one)")
 def test_two_ranks_rccl(tmp_path):
-    ranks, outs = _run_ranks(2, "nccl", tmp_path)
+    """the RCCL wire (needs two devices): first the DEFAULT arrangement - one communicator, SyncBatchNorm and gradient buckets
+    through torch.distributed's default group (TASEG_DIST_SINGLE_COMM=1) - then the library-owned communicator for
+    SyncBatchNorm beside a dedicated bucket group (TASEG_DIST_SINGLE_COMM=0), each against ONE process on the concatenated batch"""
+    (tmp_path / "single").mkdir()
+    (tmp_path / "direct").mkdir()
+    ranks, _ = _run_ranks(2, "nccl", tmp_path / "single")
+    assert int(ranks[0]["direct_rccl"]) == 0                   # the default keeps the library-owned communicator out
+    _check_against_single(ranks)
+    _check_against_single(ranks, "c10d/")
+    ranks, outs = _run_ranks(2, "nccl", tmp_path / "direct", {"TASEG_DIST_SINGLE_COMM": "0"})
     assert int(ranks[0]["direct_rccl"]) == 1, "the library-owned RCCL communicator was not created"
     _check_against_single(ranks)
     _check_against_single(ranks, "c10d/")
