@@ -560,6 +560,10 @@ typedef struct TsPlaneJob {
 int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *planes, ts_stream_t stream);
 int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out);
+/* The half-storage counterpart: job.planes = w16 [K, c_in, c_out] IEEE half (what ts_cast_weights_f16 writes), 16 weights
+ * per launch.  A ts_conv_block_forward(half = 1) call whose hint names (kernel, its own w16 argument) takes w16 as
+ * already cast and launches no cast of its own (torch.autocast casts the weight in every call: conv.py:19). */
+int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 
 /* One-shot and per thread, like ts_conv_planes_hint: the NEXT ts_conv_block_backward of this thread adds `addend`
  * ([n_dgrad_rows, c_in] in the storage type of grad_feat, 16-byte aligned) into its grad_feat store,

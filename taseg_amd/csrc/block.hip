@@ -193,8 +193,11 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   } else if (half) {
     // one half copy in the kernel's own layout serves both passes: the forward reads it through the transposing LDS
     // load (ts_conv_pair_gemm_f16_nat), the input gradient directly
+    // (the cast is skipped when the caller keeps w16 in step with the weight itself and says so: ts_conv_planes_hint(kernel, w16))
     (void)w16t;
-    TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
+    const TsPlanesHint &hw = planes_hint.h;
+    if (!(hw.w == kernel && (const void *)hw.planes == w16 && hw.K == K && hw.c_in == c_in && hw.c_out == c_out))
+      TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
     {
       ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 2, 0);
       TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));

@@ -139,9 +139,21 @@ __device__ __forceinline__ void ts_table_find_n(const TsTable &t, const unsigned
   }
 }
 
-// Carve a table out of a workspace and reset it on `stream`.
-int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream,
-                  size_t *used);
+// One launch that fills up to TS_FILL_MAX buffers with a 32-bit pattern each (pointers 4-byte aligned, sizes multiples of
+// 4 bytes; empty segments are skipped) - the index-plan builders clear their tables and counters with it instead of one
+// hipMemsetAsync per buffer.
+#define TS_FILL_MAX 6
+struct TsFillSeg {
+  void *p;
+  size_t bytes;
+  uint32_t word;
+};
+int ts_fill_segments(const TsFillSeg *segs, int n, hipStream_t stream);
+
+// Carve a table out of a workspace and reset it on `stream`.  `extra` (n_extra <= TS_FILL_MAX - 2 segments) is cleared by
+// the same launch.
+int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream, size_t *used,
+                  const TsFillSeg *extra = nullptr, int n_extra = 0);
 
 // ---- deterministic weight gradient ------------------------------------------------------------------------------
 // A weight-gradient workgroup = (chunk c of consecutive rulebook pairs, TM x TN tile).  Instead of adding its partial

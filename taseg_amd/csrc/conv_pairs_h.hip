@@ -53,6 +53,51 @@ extern "C" int ts_cast_weights_f16(const float *w, int32_t K, int32_t c_in, int3
   return TS_OK;
 }
 
+// Half copies of many weights in one launch (16 per launch, like ts_conv_split_planes_batch): job.planes = W16 [K, Ci, Co],
+// the layout both half pair GEMMs read.  taseg_amd/planes.py keeps these copies next to the parameters and refreshes the
+// stale ones once per optimizer step; ts_conv_block_forward then skips its own cast (ts_conv_planes_hint(w, w16, ..)).
+struct TsCastJobs {
+  TsPlaneJob job[16];
+};
+__global__ __launch_bounds__(256) void cast_weights_f16_batch_kernel(TsCastJobs jobs) {
+  const TsPlaneJob jb = jobs.job[blockIdx.y];
+  const float *__restrict__ w = jb.w;
+  _Float16 *__restrict__ w16 = (_Float16 *)jb.planes;
+  const int64_t n8 = ((int64_t)jb.K * jb.c_in * jb.c_out) >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = *(const f32x4 *)(w + 8 * i), b = *(const f32x4 *)(w + 8 * i + 4);
+    h8 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o[q] = (_Float16)a[q];
+      o[4 + q] = (_Float16)b[q];
+    }
+    *(h8 *)(w16 + 8 * i) = o;
+  }
+}
+
+extern "C" int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream) {
+  TS_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), TS_ERR_INVALID_ARGUMENT, "ts_cast_weights_f16_batch: bad arguments");
+  for (int32_t j0 = 0; j0 < n_jobs; j0 += 16) {
+    TsCastJobs chunk;
+    const int cnt = std::min(16, n_jobs - j0);
+    int64_t big = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const TsPlaneJob &jb = jobs[j0 + j];
+      TS_REQUIRE(jb.w && jb.planes && jb.K > 0 && jb.c_in > 0 && jb.c_out > 0 && ((int64_t)jb.c_in * jb.c_out) % 8 == 0 &&
+                     ((((uintptr_t)jb.w) | ((uintptr_t)jb.planes)) & 15) == 0,
+                 TS_ERR_INVALID_ARGUMENT,
+                 "ts_cast_weights_f16_batch: job %d: null / misaligned pointer or C_in * C_out not a multiple of 8", j0 + j);
+      chunk.job[j] = jb;
+      big = std::max<int64_t>(big, (int64_t)jb.K * jb.c_in * jb.c_out);
+    }
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ts_cdiv(big / 8, 256), 128)), (unsigned)cnt);
+    cast_weights_f16_batch_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(chunk);
+    TS_CHECK_LAUNCH("ts_cast_weights_f16_batch");
+  }
+  return TS_OK;
+}
+
 // fragment of a [k][col] image: 8 consecutive k rows of column c0 + (lane & 15) through the transposing LDS load
 // (lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3; as in wgrad_h_kernel below)
 typedef __fp16 hv4t __attribute__((__vector_size__(4 * sizeof(__fp16))));

@@ -323,28 +323,31 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
                              int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws,
                              size_t ws_bytes, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (pos_in && n_in > 0 && K > 0)
-    if (hipMemsetAsync(pos_in, 0xFF, (size_t)K * n_in * 4, stream) != hipSuccess) return TS_ERR_LAUNCH_FAILED;
   TS_REQUIRE(n_in >= 0 && n_out >= 0 && K > 0 && K <= 4096, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: bad sizes");
   TS_REQUIRE(n_in < (1LL << 30) && n_out < (1LL << 30) && (int64_t)K * n_out < (1LL << 31), TS_ERR_UNSUPPORTED,
              "ts_build_kmap: problem too large for int32 indexing");
   TS_REQUIRE(offsets && nbr, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: null pointer");
   TS_REQUIRE(ws_bytes >= ts_build_kmap_workspace_bytes(n_in, n_out, K), TS_ERR_WORKSPACE_TOO_SMALL,
              "ts_build_kmap: workspace %zu < %zu", ws_bytes, ts_build_kmap_workspace_bytes(n_in, n_out, K));
-  if (nbsizes) TS_CHECK_HIP(hipMemsetAsync(nbsizes, 0, (size_t)K * 4, stream), "kmap memset");
-  if (nboffs) TS_CHECK_HIP(hipMemsetAsync(nboffs, 0, (size_t)(K + 1) * 4, stream), "kmap memset");
-  if (nbr_t && n_in > 0) TS_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)K * n_in * 4, stream), "kmap memset");
-  if (n_out == 0) return TS_OK;
+  // the tables only the hits write (-1 = no pair): pos_in, nbr_t; one fill launch together with the hash table below
+  const TsFillSeg inverse[2] = {{pos_in, (size_t)K * n_in * 4, 0xFFFFFFFFu}, {nbr_t, (size_t)K * n_in * 4, 0xFFFFFFFFu}};
+  if (n_out == 0) {                              // no output rows: empty rulebook
+    const TsFillSeg empty[4] = {inverse[0], inverse[1], {nbsizes, (size_t)K * 4, 0u}, {nboffs, (size_t)(K + 1) * 4, 0u}};
+    return ts_fill_segments(empty, 4, stream);
+  }
   TS_REQUIRE(out_coords && (in_coords || n_in == 0), TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: null coords");
   TS_REQUIRE(((uintptr_t)in_coords & 15) == 0 && ((uintptr_t)out_coords & 15) == 0, TS_ERR_INVALID_ARGUMENT,
              "ts_build_kmap: coords must be 16-byte aligned");
   TsTable t;
-  size_t used = 0;
-  int rc = ts_table_init(&t, n_in, ws, ws_bytes, stream, &used);
-  if (rc != TS_OK) return rc;
   int nblk = (int)ts_cdiv(n_out, KM_BLOCK);
   size_t n_cnt = (size_t)K * nblk + 1;
   size_t cnt_bytes = ts_align_up(n_cnt * 4, 256);
+  size_t used = ts_table_bytes(n_in);
+  TS_REQUIRE(used <= ws_bytes, TS_ERR_WORKSPACE_TOO_SMALL, "ts_build_kmap: workspace too small");
+  // table keys / values, the two inverse tables and the closing element of the per-block counts: ONE fill launch
+  const TsFillSeg extra[3] = {inverse[0], inverse[1], {(unsigned *)((char *)ws + used) + (n_cnt - 1), 4, 0u}};
+  int rc = ts_table_init(&t, n_in, ws, ws_bytes, stream, &used, extra, 3);
+  if (rc != TS_OK) return rc;
   unsigned *blk_counts = (unsigned *)((char *)ws + used);
   unsigned *blk_offs = (unsigned *)((char *)ws + used + cnt_bytes);
   void *tmp = (char *)ws + used + 2 * cnt_bytes;
@@ -355,7 +358,6 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
     table_insert_coords_kernel<<<grid, 256, 0, stream>>>(t, (const int4 *)in_coords, n_in);
     TS_CHECK_LAUNCH("ts_build_kmap/insert");
   }
-  TS_CHECK_HIP(hipMemsetAsync(blk_counts + (n_cnt - 1), 0, 4, stream), "kmap memset");
   kmap_probe_kernel<<<nblk, KM_BLOCK, (size_t)K * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
                                                                blk_counts, nblk);
   TS_CHECK_LAUNCH("ts_build_kmap/probe");

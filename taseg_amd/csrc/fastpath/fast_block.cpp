@@ -104,14 +104,19 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor stats = at::empty({2, c_out}, opts.dtype(at::kFloat));
     at::Tensor mask, w16, pack;
     if (relu) mask = at::empty({rows * (c_out / (half ? 8 : 4))}, opts.dtype(at::kByte));
-    if (half) w16 = at::empty({k, c_in, c_out}, opts.dtype(at::kHalf));
+    const bool own_weight = w32.data_ptr() == weight.data_ptr();
+    const bool have = planes.has_value() && planes->defined() && own_weight;
+    // half storage: `planes` = the kept half copy of the weight (planes.half_for): w16 IS that tensor and the call casts nothing
+    const bool kept16 = half && have && planes->scalar_type() == at::kHalf && planes->numel() == k * c_in * c_out;
+    if (half) w16 = kept16 ? *planes : at::empty({k, c_in, c_out}, opts.dtype(at::kHalf));
     if (comm || split) pack = at::empty({2 * c_out + 1}, opts.dtype(at::kDouble));
     const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
     at::Tensor ws = workspace(nb, x, stream);
     float *st = stats.data_ptr<float>();
     at::Tensor pl;                       // pre-split planes of the weight (taseg_amd/planes.py); fp32 blocks only
-    if (!half && planes.has_value() && planes->defined() && w32.data_ptr() == weight.data_ptr()) pl = *planes;
+    if (!half && have && planes->scalar_type() == at::kShort) pl = *planes;
     if (pl.defined()) api.planes_hint(w32.data_ptr<float>(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
+    if (kept16) api.planes_hint(w32.data_ptr<float>(), w16.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,

@@ -18,9 +18,48 @@ void ts_set_error(const char *fmt, ...) {
 extern "C" const char *ts_last_error(void) { return g_err; }
 extern "C" const char *ts_version(void) { return "taseg_hip 0.1.0 gfx950"; }
 
+// ---------------------------------------------------------------- multi-buffer fill
+struct TsFillSegs {
+  TsFillSeg s[TS_FILL_MAX];
+};
+__global__ __launch_bounds__(256) void fill_segments_kernel(TsFillSegs a) {
+  const TsFillSeg sg = a.s[blockIdx.y];
+  uint32_t *p = (uint32_t *)sg.p;
+  const size_t nw = sg.bytes >> 2;
+  size_t head = ((16 - ((uintptr_t)p & 15)) & 15) >> 2;      // words up to the first 16-byte boundary
+  if (head > nw) head = nw;
+  const size_t nv = (nw - head) >> 2;
+  const uint4 v = make_uint4(sg.word, sg.word, sg.word, sg.word);
+  uint4 *pv = (uint4 *)(p + head);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) pv[i] = v;
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    if (threadIdx.x < head) p[threadIdx.x] = sg.word;
+    const size_t t0 = head + 4 * nv + threadIdx.x;
+    if (t0 < nw) p[t0] = sg.word;
+  }
+}
+
+int ts_fill_segments(const TsFillSeg *segs, int n, hipStream_t stream) {
+  TsFillSegs a;
+  int cnt = 0;
+  size_t big = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!segs[i].p || segs[i].bytes == 0) continue;
+    TS_REQUIRE(cnt < TS_FILL_MAX && (((uintptr_t)segs[i].p | segs[i].bytes) & 3) == 0, TS_ERR_INVALID_ARGUMENT,
+               "ts_fill_segments: more than %d segments or a segment that is not 4-byte granular", TS_FILL_MAX);
+    a.s[cnt++] = segs[i];
+    big = std::max(big, segs[i].bytes);
+  }
+  if (cnt == 0) return TS_OK;
+  dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>(ts_cdiv((int64_t)(big >> 4), 1024), 2048)), (unsigned)cnt);
+  fill_segments_kernel<<<grid, 256, 0, stream>>>(a);
+  TS_CHECK_LAUNCH("ts_fill_segments");
+  return TS_OK;
+}
+
 // ---------------------------------------------------------------- table init
-int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream,
-                  size_t *used) {
+int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t stream, size_t *used,
+                  const TsFillSeg *extra, int n_extra) {
   size_t cap = ts_table_capacity(n);
   size_t kb = ts_align_up(cap * 8, 256), vb = ts_align_up(cap * 4, 256);
   TS_REQUIRE(ws != nullptr && ws_bytes >= kb + vb, TS_ERR_WORKSPACE_TOO_SMALL,
@@ -29,10 +68,11 @@ int ts_table_init(TsTable *t, int64_t n, void *ws, size_t ws_bytes, hipStream_t 
   t->keys = (unsigned long long *)ws;
   t->vals = (int *)((char *)ws + kb);
   t->mask = (uint32_t)(cap - 1);
-  TS_CHECK_HIP(hipMemsetAsync(t->keys, 0xFF, cap * 8, stream), "table keys memset");
-  TS_CHECK_HIP(hipMemsetAsync(t->vals, 0x7F, cap * 4, stream), "table vals memset");
+  TS_REQUIRE(n_extra >= 0 && n_extra <= TS_FILL_MAX - 2, TS_ERR_INVALID_ARGUMENT, "hash table: too many extra fill segments");
+  TsFillSeg segs[TS_FILL_MAX] = {{t->keys, cap * 8, 0xFFFFFFFFu}, {t->vals, cap * 4, 0x7F7F7F7Fu}};
+  for (int i = 0; i < n_extra; ++i) segs[2 + i] = extra[i];
   if (used) *used = kb + vb;
-  return TS_OK;
+  return ts_fill_segments(segs, 2 + n_extra, stream);
 }
 
 // ---------------------------------------------------------------- K1: hash

@@ -18,10 +18,11 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["planes_for", "invalidate", "eligible", "hint", "stats"]
+__all__ = ["planes_for", "half_for", "invalidate", "eligible", "eligible_half", "hint", "stats"]
 
 _ENABLED = os.environ.get("TASEG_PRESPLIT", "1") != "0"
-_entries = {}          # id(weight) -> _Entry
+_entries = {}          # id(weight) -> _Entry (bf16 planes of the fp32 kernels)
+_half_entries = {}     # id(weight) -> _Entry (IEEE-half copy for the half-storage kernels)
 _epoch = 0
 stats = {"refreshes": 0, "launch_batches": 0}
 
@@ -34,9 +35,10 @@ class TsPlaneJob(ctypes.Structure):
 class _Entry:
     __slots__ = ("ref", "planes", "ptr", "version", "epoch", "stream")
 
-    def __init__(self, weight):
+    def __init__(self, weight, half=False):
         self.ref = weakref.ref(weight)
-        self.planes = torch.empty(3 * weight.numel(), dtype=torch.int16, device=weight.device)
+        self.planes = (torch.empty(weight.shape, dtype=torch.float16, device=weight.device) if half else
+                       torch.empty(3 * weight.numel(), dtype=torch.int16, device=weight.device))
         self.ptr = self.version = self.epoch = self.stream = None
 
     def fresh(self, weight, stream):
@@ -61,15 +63,16 @@ def eligible(weight) -> bool:
             and (_wide(weight.shape[1]) or _wide(weight.shape[2])))
 
 
-def _refresh(stream, device):
+def _refresh(stream, device, entries=None, fn="ts_conv_split_planes_batch"):
     """Re-split every registered weight ON `device` that is stale (one launch per 16 weights) on `stream` - a stream of
     that device: the caller's current one.  Weights of a second model on another GPU of the same process stay stale until
     a convolution on their own device asks for them."""
+    entries = _entries if entries is None else entries
     jobs, done = [], []
-    for key, e in list(_entries.items()):
+    for key, e in list(entries.items()):
         w = e.ref()
         if w is None:
-            del _entries[key]
+            del entries[key]
             continue
         if w.device != device:
             continue
@@ -79,7 +82,7 @@ def _refresh(stream, device):
     if not jobs:
         return
     arr = (TsPlaneJob * len(jobs))(*[TsPlaneJob(*j) for j in jobs])
-    L.check(L.load().ts_conv_split_planes_batch(arr, len(jobs), stream), "ts_conv_split_planes_batch")
+    L.check(getattr(L.load(), fn)(arr, len(jobs), stream), fn)
     for e, w in done:
         e.ptr, e.version, e.epoch, e.stream = w.data_ptr(), w._version, _epoch, stream
     stats["refreshes"] += len(jobs)
@@ -101,6 +104,28 @@ def planes_for(weight):
         e = _entries[id(weight)] = _Entry(weight)
     if not e.fresh(weight, stream):
         _refresh(stream, weight.device)
+    return e.planes
+
+
+def eligible_half(weight) -> bool:
+    """fp32 [K, C_in, C_out] parameter on a ROCm device that the half-storage block call can take a kept copy of."""
+    return (_ENABLED and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 3 and weight.is_contiguous()
+            and (weight.shape[1] * weight.shape[2]) % 8 == 0 and weight.data_ptr() % 16 == 0)
+
+
+def half_for(weight):
+    """The IEEE-half copy [K, C_in, C_out] of `weight` that the half-storage convolutions read (autocast's cast of the
+    weight, conv.py:19, done once per optimizer step for ALL weights of the model - 16 per launch - instead of once per
+    convolution call), in step with the weight on the current stream; None when the mechanism does not apply.  Hand it to
+    the block call as its w16 buffer and name it in `hint(weight, w16)`: the call then launches no cast."""
+    if not eligible_half(weight) or weight.device.index != torch.cuda.current_device():
+        return None
+    stream = L.stream()
+    e = _half_entries.get(id(weight))
+    if e is None or e.ref() is not weight or e.planes.device != weight.device or e.planes.shape != weight.shape:
+        e = _half_entries[id(weight)] = _Entry(weight, half=True)
+    if not e.fresh(weight, stream):
+        _refresh(stream, weight.device, _half_entries, "ts_cast_weights_f16_batch")
     return e.planes
 
 

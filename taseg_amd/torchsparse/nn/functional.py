@@ -645,16 +645,16 @@ class _ConvBlock(Function):
         out = torch.empty((rows, c_out), dtype=dt, device=dev)
         stats = torch.empty((2, c_out), dtype=torch.float32, device=dev)
         mask = torch.empty(rows * (c_out // (8 if half else 4)), dtype=torch.uint8, device=dev) if relu else None
-        w16 = torch.empty((k, c_in, c_out), dtype=torch.float16, device=dev) if half else None
+        if w32.data_ptr() != weight.data_ptr() or (planes is not None and planes.dtype != (torch.float16 if half else torch.int16)):
+            planes = None                         # a converted copy: planes / half copy belong to the parameter's own storage
+        # half storage: `planes` = the kept half copy of the weight (planes.half_for) - the call casts nothing
+        w16 = (planes if planes is not None else torch.empty((k, c_in, c_out), dtype=torch.float16, device=dev)) if half else None
         # SyncBatchNorm transports: `comm` = the library-owned RCCL communicator (collective inline on this stream), or - `group`
         # given without one - torch.distributed runs the all-reduce between the two halves of a split call (csrc/block.hip)
         split = comm is None and group is not None
         pack = torch.empty(2 * c_out + 1, dtype=torch.float64, device=dev) if (comm is not None or split) else None
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
-        if half or w32.data_ptr() != weight.data_ptr():
-            planes = None
-
         def call(c):
             L.check(lib.ts_conv_block_forward(
                 L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol,
@@ -673,7 +673,7 @@ class _ConvBlock(Function):
         ctx.save_for_backward(x, w16 if half else w32, conv_out, stats, mask, bn_weight)
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
         ctx.group = group if split else None
-        ctx.planes = planes
+        ctx.planes = None if half else planes
         ctx.grad_dest = grad_dest        # where the weight gradient is wanted (a gradient bucket's view), or None
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
         ctx.in_dtype, ctx.res_dtype = feats.dtype, (None if residual is None else residual.dtype)

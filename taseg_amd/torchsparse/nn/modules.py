@@ -185,7 +185,8 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                      mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
             fast = _fast.module()
             half = F._amp_half(feats)
-            planes = None if half else _planes.planes_for(conv.kernel)      # pre-split weight (taseg_amd/planes.py)
+            # fp32: pre-split bf16 planes of the weight; half storage: its kept half copy (taseg_amd/planes.py)
+            planes = _planes.half_for(conv.kernel) if half else _planes.planes_for(conv.kernel)
             dest = _claim_grad_dest(conv.kernel)                            # bucket slot of the weight gradient (parallel.py)
             c10d_group = group if (group is not None and comm is None) else None
             if fast is not None:                          # C++ autograd node, same backend calls (csrc/fastpath)

@@ -175,3 +175,61 @@ def test_half_devoxelize_gives_the_bits_of_the_float_kernels(stride, plan_kind):
     b = f1.detach().clone().requires_grad_()
     plain = F.spdevoxelize(b, idx, w)
     assert plain.dtype == torch.float16 and torch.equal(plain, out[:, :32])
+
+
+def test_kept_half_copy_of_the_weights_follows_the_optimizer():
+    """planes.half_for: the half copy the half-storage block calls read in place of a cast per call.  It equals
+    weight.half() bit for bit, is refreshed for ALL registered weights by the first request after a version bump
+    (torch optimizers) or an invalidate() (FlatSGD's raw-pointer update), 16 weights per launch, and the block call
+    that is handed the copy gives the bits of the call that casts for itself."""
+    from taseg_amd import planes as P
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse import nn as spnn
+    from taseg_amd.torchsparse.nn import modules as M
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(27, ci, co, device="cuda") * 0.1) for ci, co in ((32, 32), (32, 64), (96, 96)) for _ in range(7)]
+    before = dict(P.stats)
+    hs = [P.half_for(w) for w in ws]
+    for w, h in zip(ws, hs):
+        assert h.dtype == torch.float16 and torch.equal(h, w.detach().half())
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)                                   # version bump, same storage
+    assert not torch.equal(hs[3], ws[3].detach().half())     # stale until asked for
+    batches = P.stats["launch_batches"]
+    h0 = P.half_for(ws[0])
+    assert h0 is hs[0] and P.stats["launch_batches"] == batches + 1      # one request refreshed every stale weight ...
+    for w, h in zip(ws, hs):
+        assert torch.equal(h, w.detach().half())
+    assert P.half_for(ws[5]) is hs[5] and P.stats["launch_batches"] == batches + 1   # ... and nothing is left to do
+    ws[2].data.add_(1.0)                                  # .data writes do not bump the version: invalidate() is the contract
+    P.invalidate()
+    assert torch.equal(P.half_for(ws[2]), ws[2].detach().half())
+    assert P.stats["refreshes"] > before["refreshes"]
+
+    # a conv + BN + ReLU block under autocast: kept copy vs the call's own cast
+    rs = np.random.RandomState(0)
+    c = np.unique(rs.randint(0, 24, (6000, 3)), axis=0).astype(np.int32)
+    coords = torch.from_numpy(np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)).cuda()
+    feats = torch.randn(len(c), 32, device="cuda")
+    conv, bn = spnn.Conv3d(32, 64, 3).cuda(), spnn.BatchNorm(64).cuda()
+
+    def run(kept):
+        saved = P.half_for
+        if not kept:
+            P.half_for = lambda w: None
+        try:
+            bn.reset_running_stats()
+            conv.zero_grad(set_to_none=True)
+            x = SparseTensor(feats.clone().requires_grad_(True), coords, 1)
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = M.conv_bn_act(conv, bn, x)
+            y.feats.float().square().sum().backward()
+            return y.feats.detach().clone(), x.feats.grad.clone(), conv.kernel.grad.clone()
+        finally:
+            P.half_for = saved
+
+    a, b = run(True), run(False)
+    assert a[0].dtype == torch.float16
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

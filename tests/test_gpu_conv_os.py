@@ -81,3 +81,22 @@ def test_output_stationary_kernel_at_bench_size():
     assert torch.equal(B.conv_os(x, pl, w.shape, km["nbr"]), y2)
     gx2 = B.conv_gather_sum(B.conv_pair_gemm(gy, w, km["nbmaps"], km["nboffs"], total, 1, weight_transposed=True), km["pos_in"], n)
     assert torch.equal(B.conv_os(gy, pl, w.shape, km["nbr"], weight_transposed=True), gx2)
+
+
+def test_output_stationary_kernel_walks_a_dense_tile_in_batches():
+    """a near-full voxel grid (~23 pairs per voxel): the lists of a 192-row tile exceed the LDS capacity and the kernel takes
+    the offsets in several batches - same bits as the two passes"""
+    from taseg_amd import backend as B
+    rs = np.random.RandomState(5)
+    grid = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(-1, 3)
+    keep = rs.rand(len(grid)) < 0.9
+    c = np.concatenate([grid[keep], np.zeros((int(keep.sum()), 1), np.int64)], 1).astype(np.int32)
+    c = c[rs.permutation(len(c))]
+    km, x, gy, w, _ = _case(c, 96, 96, seed=3)
+    total = int(km["nboffs"][-1])
+    assert total > 20 * len(c)
+    pl = _planes(w)
+    y2 = B.conv_gather_sum(B.conv_pair_gemm(x, w, km["nbmaps"], km["nboffs"], total, 0), km["pos_out"], len(c))
+    assert torch.equal(B.conv_os(x, pl, w.shape, km["nbr"]), y2)
+    gx2 = B.conv_gather_sum(B.conv_pair_gemm(gy, w, km["nbmaps"], km["nboffs"], total, 1, weight_transposed=True), km["pos_in"], len(c))
+    assert torch.equal(B.conv_os(gy, pl, w.shape, km["nbr"], weight_transposed=True), gx2)
