@@ -409,7 +409,9 @@ def summarise_families(prof, amp, traffic_table):
         if entry is None:        # rocprofv3 prints every template argument (the trailing diagnostics flag too): match by prefix
             stem = r["kernel"][:-1] if r["kernel"].endswith(">") else r["kernel"]
             hits = [v for k, v in traffic_table.items() if k.startswith(stem + ",") or k == stem + ">"]
-            entry = hits[0] if len(hits) == 1 else None
+            if hits:             # several instantiations behind one label (forward / transposed): weighted by the launches sampled
+                w = [max(1, h.get("launches_sampled", 1)) for h in hits]
+                entry = {"hbm_bytes_per_launch": sum(h["hbm_bytes_per_launch"] * x for h, x in zip(hits, w)) / sum(w)}
         if entry is None:
             f["traffic_ok"] = False
         else:

@@ -11,8 +11,10 @@ $RP -d $OUT/trace_amp -- python3 bench.py --amp --no-cpu-baseline --no-secondary
 $RP -d $OUT/trace_nus_amp -- python3 bench.py --workload nuscenes_ms --amp --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $OUT/bench_nus_amp_under_rocprof.json 2> $OUT/trace_nus_amp.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 bench.py --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_amp -o f -- python3 bench.py --amp --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_fetch_amp.json 2> $OUT/pmc_fetch_amp.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_amp -o w -- python3 bench.py --amp --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_write_amp.json 2> $OUT/pmc_write_amp.err
 for t in default amp nus_amp; do python tools/kstats.py $OUT/trace_$t 25 45 > $OUT/kstats_$t.txt; done
-python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") > $OUT/traffic.txt
+python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $(find $OUT/pmc_fetch_amp -name "*counter_collection.csv") $(find $OUT/pmc_write_amp -name "*counter_collection.csv") > $OUT/traffic.txt
 cp profiles/traffic.json $OUT/traffic.json
 for w in "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist"; do
   tag=$(echo $w | tr -d ' -'); python bench.py $w --no-cpu-baseline --no-secondary --steps 30 --warmup 5 > $OUT/bench_$tag.json 2> /dev/null; done
