@@ -326,7 +326,7 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
   TS_REQUIRE(n_in >= 0 && n_out >= 0 && K > 0 && K <= 4096, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: bad sizes");
   TS_REQUIRE(n_in < (1LL << 30) && n_out < (1LL << 30) && (int64_t)K * n_out < (1LL << 31), TS_ERR_UNSUPPORTED,
              "ts_build_kmap: problem too large for int32 indexing");
-  TS_REQUIRE(offsets && nbr, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: null pointer");
+  TS_REQUIRE(offsets && (nbr || n_out == 0), TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: null pointer");
   TS_REQUIRE(ws_bytes >= ts_build_kmap_workspace_bytes(n_in, n_out, K), TS_ERR_WORKSPACE_TOO_SMALL,
              "ts_build_kmap: workspace %zu < %zu", ws_bytes, ts_build_kmap_workspace_bytes(n_in, n_out, K));
   // the tables only the hits write (-1 = no pair): pos_in, nbr_t; one fill launch together with the hash table below

@@ -148,6 +148,40 @@ def test_kmap_dense_blob_vs_oracle(B, F):
     same(F.spdownsample(T(c), 2, 2, 1), down)
 
 
+def test_kmap_tables_are_cleared_by_the_build(B, F):
+    """ts_build_kmap clears its hash table, the inverse tables (nbr_t, pos_in: -1 where an input row has no partner) and its
+    block counter with one fill launch (ts_fill_segments): recycled, garbage-filled outputs of odd sizes - 1, 3, 5, 257
+    rows, so that the fill's unaligned head / tail paths run - must come back exactly as the oracle's tables; an empty
+    output set gives an empty rulebook and all-(-1) inverse tables."""
+    offs = O.get_kernel_offsets(3, 1, 1)
+    rs = np.random.RandomState(3)
+    for n in (1, 3, 5, 257, 1000):
+        c = np.unique(rs.randint(0, 7 if n < 300 else 12, (4 * n, 3)), axis=0)[:n].astype(np.int32)
+        c = np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)
+        out = c[rs.permutation(len(c))[: max(1, len(c) // 2)]]            # a subset in another order: some inputs have no partner
+        junk = torch.full((64 * 1024,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)     # dirty the caching allocator's blocks
+        del junk
+        km = B.build_kmap(T(c), T(out), T(offs.astype(np.int32)), want_inverse=True)
+        res, ref_maps, ref_sizes = O.build_kmap(c, out, offs)
+        sizes = km["nbsizes"].cpu().numpy()
+        assert (sizes == ref_sizes).all()
+        total = int(sizes.sum())
+        assert (km["nbr"].cpu().numpy() == res).all()
+        assert (km["nbmaps"][:total].cpu().numpy() == ref_maps).all()
+        nbr_t = np.full((len(offs), len(c)), -1, np.int32)
+        pos_in = np.full((len(offs), len(c)), -1, np.int32)
+        o = np.concatenate([[0], np.cumsum(ref_sizes)])
+        for k in range(len(offs)):
+            seg = ref_maps[o[k]:o[k + 1]]
+            nbr_t[k, seg[:, 0]] = seg[:, 1]
+            pos_in[k, seg[:, 0]] = np.arange(o[k], o[k + 1])
+        assert (km["nbr_t"].cpu().numpy() == nbr_t).all()
+        assert (km["pos_in"].cpu().numpy() == pos_in).all()
+    km = B.build_kmap(T(c), T(np.zeros((0, 4), np.int32)), T(offs.astype(np.int32)), want_inverse=True)
+    assert int(km["nbsizes"].sum()) == 0 and int(km["nboffs"].abs().sum()) == 0
+    assert (km["nbr_t"] == -1).all() and (km["pos_in"] == -1).all()
+
+
 def test_downsample_negative_and_range(B, F):
     c = _blob(4, n=3000, extent=30)
     c[:, :3] -= 15                       # negative coordinates: trunc toward zero, like the reference

@@ -32,7 +32,7 @@ rec = B.profile_end()
 tab = collections.defaultdict(lambda: [0, 0.0])
 cache = {}
 for kind, e0, e1, m in rec:
-    if kind == "conv_wgrad":
+    if kind == "conv_wgrad" and "nboffs" in m:
         key = m["nboffs"].data_ptr()
         if key not in cache:
             cache[key] = int(m["nboffs"][-1])
