@@ -492,7 +492,7 @@ def secondary_runs(steps=10, warmup=3):
             else:
                 entry.update({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss")})
                 roof = rec.get("roofline") or {}
-                entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_us",
+                entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us",
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
                                                              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
                                                              "whole_step_lower_bound_ms")} if roof else None
