@@ -49,7 +49,7 @@ def timed(fn, label, fl=None, byts=None):
     us = e0.elapsed_time(e1) / args.iters * 1e3
     extra = f"  {fl / us / 1e6:7.1f} TF/s" if fl else ""
     extra += f"  {byts / us / 1e3:7.1f} GB/s" if byts else ""
-    print(f"{label:8s} {us:9.1f} us{extra}")
+    print(f"{label:28s} {us:9.1f} us{extra}")
 
 
 what = args.what.split(",")
@@ -59,6 +59,15 @@ if "dgrad" in what:
     timed(lambda: B.conv_pair_gemm(gy, w, km.nbmaps_buf, km.nboffs, P, 1, weight_transposed=True), "dgrad", flops)
 if "wgrad" in what:
     timed(lambda: B.conv_wgrad(xf, gy, km.nbmaps_buf, km.nboffs, 27, col_a=0, max_pairs=P), "wgrad", flops)
+if "shared" in what:
+    # what sharing the gathered dY rows between the input gradient and the weight gradient could save at most: the same launches
+    # with the dY column of the rulebook pointed at row 0 (those gathers come from cache), and with both columns at row 0
+    m0 = km.nbmaps_buf.clone()
+    m0[:, 1] = 0
+    m00 = torch.zeros_like(km.nbmaps_buf)
+    timed(lambda: B.conv_pair_gemm(gy, w, m0, km.nboffs, P, 1, weight_transposed=True), "dgrad, dY rows from cache", flops)
+    timed(lambda: B.conv_wgrad(xf, gy, m0, km.nboffs, 27, col_a=0, max_pairs=P), "wgrad, dY rows from cache", flops)
+    timed(lambda: B.conv_wgrad(xf, gy, m00, km.nboffs, 27, col_a=0, max_pairs=P), "wgrad, all rows from cache", flops)
 if "f16" in what:
     w16, w16t = B.cast_weights_f16(w)
     xh, gyh = xf.half(), gy.half()
