@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_os.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip"]
+EXPERIMENTS = {"conv_pairs_x.hip": "libtaseg_x.so"}      # three-product IEEE-half split pair GEMM (tools/x_probe.py)
 LIB = os.path.join(PKG, "libtaseg_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -57,6 +58,13 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
+    # measured-and-shelved kernels: their own small library next to the objects, loaded only by tools/
+    for src_name, lib_name in EXPERIMENTS.items():
+        src, obj = os.path.join(HERE, src_name), os.path.join(OBJ_DIR, src_name.replace(".hip", ".o"))
+        out = os.path.join(OBJ_DIR, lib_name)
+        if os.path.exists(src) and (force or _newer(src, out) or any(_newer(d, out) for d in _deps())):
+            run([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, os.path.join(OBJ_DIR, "hash.o"), "-ldl"])
     return LIB
 
 
