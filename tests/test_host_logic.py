@@ -260,3 +260,27 @@ def test_bench_watchdog_ends_a_stuck_rank_with_exit_code_3():
     assert stuck.returncode == 3 and "rank 5" in stuck.stderr and "all-reduce of bucket 2" in stuck.stderr
     alive = subprocess.run([sys.executable, "-c", code, "3", "beat"], env=env, capture_output=True, text=True, timeout=120)
     assert alive.returncode == 0 and "finished" in alive.stdout
+
+
+def test_traffic_parser_recovers_names_rocprofv3_leaves_mangled():
+    """profiles/parse_traffic.py: rocprofv3's demangler does not know _Float16 (DF16_), so the half kernels arrive mangled; the
+    table keys must still be `name<template arguments>` - what bench.py's family roofline looks its members up by."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("parse_traffic", os.path.join(root, "profiles", "parse_traffic.py"))
+    pt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pt)
+    assert pt.short("_Z20gather_list_h_kernelILi8EEvPKDF16_iPKiilPDF16_13TsWgradReduceS1_i") == "gather_list_h_kernel<8>"
+    assert pt.short("_Z18pair_gemm_h_kernelILi128ELi2ELb1EEvPKDF16_iS1_iPK15HIP_vector_typeIiLj2EEPKiiiPDF16_") == \
+        "pair_gemm_h_kernel<128,2,true>"
+    assert pt.short("_Z21devoxelize_fwd_kernelILi4EDF16_EvPKT0_PKiPKfliPS0_l") == "devoxelize_fwd_kernel<4,_Float16>"
+    assert pt.short("_Z24bn_act_bwd_coef_h_kernelPKDv8_DF16_PKhS1_PKfS5_S5_S5_liPS_S6_") == "bn_act_bwd_coef_h_kernel"
+    assert pt.short("void wgrad_s_kernel<96, 96>(float const*, int)") == "wgrad_s_kernel<96,96>"
+    import bench
+    table = {"pair_gemm_h_kernel<128,2,true>": {"hbm_bytes_per_launch": 80e6, "launches_sampled": 100},
+             "pair_gemm_h_kernel<128,2,false>": {"hbm_bytes_per_launch": 60e6, "launches_sampled": 300}}
+    prof = [{"kernel": "pair_gemm_h_kernel<128>", "ms_per_step": 1.0, "launches_per_step": 10.0, "flops_per_launch": 1e9,
+             "bytes_per_step": 1e9, "ideal_fused_bytes_per_step": 1e8}]
+    fam = bench.summarise_families(prof, True, table)[0]
+    assert abs(fam["traffic_bytes_per_launch"] - 65e6) < 1.0          # launch-weighted over the two instantiations
