@@ -565,6 +565,28 @@ void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t 
  * already cast and launches no cast of its own (torch.autocast casts the weight in every call: conv.py:19). */
 int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 
+/* Class-sorted implicit GEMM (csrc/conv_class.hip) - pass 1 of a submanifold 3x3x3 convolution with the sums of up to nine
+ * offsets kept in the accumulators: Z' has one row per (output row, z-plane of offsets) instead of one per rulebook pair
+ * (about 2 N instead of 6.5 N rows on a LiDAR scan), pass 2 is ts_conv_gather_sum with K = 3 and the plan's position table.
+ * Same product as convolution_forward_cuda / convolution_backward_cuda (backend/convolution/convolution_cuda.cu:101-278) on the
+ * rulebook ts_build_kmap gave; another summation order than ts_conv_pair_gemm + ts_conv_gather_sum (1e-6-close, deterministic).
+ *   ts_conv_class_rows(n)   m_pad = 3 * roundup(n, 128): rows of src / Z'
+ *   ts_conv_class_plan      nbr [27][n] (in == out) -> src [9][m_pad] (input row of (group offset, sorted row) or -1),
+ *                           tile_info [m_pad / 128][2], n_tiles [1] (device), pos [3][n] (row of Z' per (group, output) or -1)
+ *   ts_conv_class_gemm      zp [m_pad, c_out]; wt = 0 forward (kernel [27, c_red, c_out]), wt = 1 input gradient (feat = output
+ *                           gradients, kernel [27, c_out, c_red] as stored: the mirrored offset's slice, transposed)
+ *   ts_conv_class_hint      one-shot, per thread: the NEXT ts_conv_block_forward / _backward of this thread may run its forward
+ *                           product / input gradient on this plan (fp32, K = 27, n rows in and out; it clears the hint) */
+int64_t ts_conv_class_rows(int64_t n);
+size_t ts_conv_class_plan_workspace_bytes(int64_t n);
+int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t *src, int32_t *tile_info, int32_t *n_tiles,
+                       int32_t *pos, void *ws, size_t ws_bytes, ts_stream_t stream);
+int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
+int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t c_out, const int32_t *src,
+                       int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt, float *zp,
+                       ts_stream_t stream);
+void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos, int64_t n);
+
 /* One-shot and per thread, like ts_conv_planes_hint: the NEXT ts_conv_block_backward of this thread adds `addend`
  * ([n_dgrad_rows, c_in] in the storage type of grad_feat, 16-byte aligned) into its grad_feat store,
  * grad_feat = (input gradient of the convolution) + addend, one rounding like a separate sum of the two.  For blocks whose

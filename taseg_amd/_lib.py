@@ -120,6 +120,12 @@ SIGNATURES = {
     "ts_conv_split_planes": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ts_conv_split_planes_batch": (_i32, [_vp, _i32, _vp]),
     "ts_cast_weights_f16_batch": (_i32, [_vp, _i32, _vp]),
+    "ts_conv_class_rows": (_i64, [_i64]),
+    "ts_conv_class_plan_workspace_bytes": (_sz, [_i64]),
+    "ts_conv_class_plan": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_conv_class_supported": (_i32, [_i32, _i32]),
+    "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "ts_conv_class_hint": (None, [_vp, _vp, _vp, _vp, _i64]),
     "ts_conv_planes_hint": (None, [_vp, _vp, _i32, _i32, _i32]),
     "ts_conv_block_addend_hint": (None, [_vp]),
     "ts_conv_os": (_i32, [_vp, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),

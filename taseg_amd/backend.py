@@ -18,7 +18,7 @@ __all__ = [
     "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs", "devox_csr",
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
-    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad",
+    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm",
     "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
@@ -874,6 +874,41 @@ def sparse_quantize(coords):
                                    ws.numel(), L.stream()), "ts_sparse_quantize")
     m = _count_to_host(cnt, "sparse_quantize")
     return index[:m], inverse[:n]
+
+
+def conv_class_plan(nbr):
+    """Plan of the class-sorted implicit GEMM (csrc/conv_class.hip) for a submanifold 3x3x3 map: nbr [27, n] (build_kmap with
+    in == out) -> dict(src [9, m_pad], tile_info [m_pad / 128, 2], n_tiles [1] (device), pos [3, n], m_pad, n).  No host sync."""
+    L.require_device(nbr)
+    nbr = _i32(nbr, "nbr")
+    k, n = nbr.shape
+    lib = L.load()
+    m_pad = int(lib.ts_conv_class_rows(n))
+    dev = nbr.device
+    src = torch.empty((9, m_pad), dtype=torch.int32, device=dev)
+    tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
+    n_tiles = torch.empty(1, dtype=torch.int32, device=dev)
+    pos = torch.empty((3, n), dtype=torch.int32, device=dev)
+    ws = L.workspace(lib.ts_conv_class_plan_workspace_bytes(n), dev)
+    L.check(lib.ts_conv_class_plan(L.ptr(nbr), n, k, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles), L.ptr(pos), L.ptr(ws),
+                                   ws.numel(), L.stream()), "ts_conv_class_plan")
+    return dict(src=src, tile_info=tile_info, n_tiles=n_tiles, pos=pos, m_pad=m_pad, n=n)
+
+
+def conv_class_gemm(feat, kernel, plan, weight_transposed=False):
+    """Pass 1 on a class plan: z' [m_pad, C] with one row per (output row, z-plane of offsets); the convolution is
+    conv_gather_sum(z', plan["pos"], n).  weight_transposed: the input gradient (feat = output gradients, kernel as stored)."""
+    L.require_device(feat, kernel)
+    feat, kernel = _f32(feat, "feat"), _f32(kernel, "kernel")
+    k, c_in, c_out = kernel.shape
+    c_red, cols = (c_out, c_in) if weight_transposed else (c_in, c_out)
+    if feat.shape[1] != c_red:
+        raise ValueError(f"conv_class_gemm: feat has {feat.shape[1]} channels, the product reduces over {c_red}")
+    zp = torch.empty((plan["m_pad"], cols), dtype=torch.float32, device=feat.device)
+    L.check(L.load().ts_conv_class_gemm(L.ptr(feat), c_red, L.ptr(kernel), k, cols, L.ptr(plan["src"]), plan["m_pad"],
+                                        L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
+                                        L.ptr(zp), L.stream()), "ts_conv_class_gemm")
+    return zp
 
 
 def conv_os(feat, planes, kernel_shape, nbr, weight_transposed=False, addend=None):

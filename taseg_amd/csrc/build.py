@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_os.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip"]
+SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_os.hip", "conv_class.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip"]
 EXPERIMENTS = {"conv_pairs_x.hip": "libtaseg_x.so"}      # three-product IEEE-half split pair GEMM (tools/x_probe.py)
 LIB = os.path.join(PKG, "libtaseg_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")

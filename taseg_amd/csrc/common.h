@@ -222,6 +222,13 @@ struct TsPlanesHint {
 };
 extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv_planes_hint, cleared by the call that reads it
 
+// class-sorted implicit GEMM (csrc/conv_class.hip): the plan of a submanifold 3x3x3 map over n rows, as a one-shot hint
+struct TsClassHint {
+  const int32_t *src, *tile_info, *n_tiles, *pos;
+  int64_t n;
+};
+extern thread_local TsClassHint g_ts_class_hint;      // set by ts_conv_class_hint, cleared by the block call that reads it
+
 // Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can form the ordered sum
 // of the weight-gradient partials on the side (saves the reduce launch), and the atomic form of the weight gradient
 // can be told that its output is already zero.

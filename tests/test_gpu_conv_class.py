@@ -1,0 +1,94 @@
+"""Class-sorted implicit GEMM (csrc/conv_class.hip): plan properties, and the convolution / input gradient it computes against
+the float64 oracle and the two-pass kernels (same product, another summation order: 1e-6-close, not bit-identical)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ts_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _cloud(seed, n, extent, batch=2):
+    rs = np.random.RandomState(seed)
+    c = np.unique(np.concatenate([rs.randint(0, extent, (n, 3)), rs.randint(0, batch, (n, 1))], 1), axis=0)
+    return c[rs.permutation(len(c))].astype(np.int32)
+
+
+def _T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("n,extent", [(1, 4), (100, 3), (127, 40), (129, 6), (5000, 14), (40000, 40)])
+def test_class_plan_lists_every_pair_once(n, extent):
+    """every (output row, offset) pair of the rulebook appears exactly once in src, at the row pos names; dead rows and the
+    padding carry -1; the tile list holds every tile with a live row, longest first, with the union of its rows' masks"""
+    from taseg_amd import backend as B
+    c = _cloud(n, n, extent)
+    offs = O.get_kernel_offsets(3, 1, 1)
+    km = B.build_kmap(_T(c), _T(c), _T(offs))
+    plan = B.conv_class_plan(km["nbr"])
+    nbr = km["nbr"].cpu().numpy()
+    nn = nbr.shape[1]
+    src, pos = plan["src"].cpu().numpy(), plan["pos"].cpu().numpy()
+    m_pad = plan["m_pad"]
+    assert m_pad == 3 * ((nn + 127) // 128 * 128) and src.shape == (9, m_pad)
+    got = np.full_like(nbr, -1)
+    for g in range(3):
+        live = np.nonzero(pos[g] >= 0)[0]
+        assert len(np.unique(pos[g][live])) == len(live)                      # one Z' row per (row, group)
+        assert np.all((pos[g][live] >= g * (m_pad // 3)) & (pos[g][live] < (g + 1) * (m_pad // 3)))
+        got[9 * g:9 * g + 9][:, live] = src[:, pos[g][live]]
+        dead = np.nonzero(pos[g] < 0)[0]
+        assert np.all(nbr[9 * g:9 * g + 9][:, dead] < 0)                        # rows without a neighbour in the group
+    assert np.array_equal(got, nbr)
+    used = np.zeros(m_pad, bool)
+    used[pos[pos >= 0]] = True
+    assert np.all(src[:, ~used] == -1)
+    nt = int(plan["n_tiles"].item())
+    info = plan["tile_info"].cpu().numpy()[:nt]
+    tiles = info[:, 0] >> 2
+    assert len(np.unique(tiles)) == nt
+    live_tiles = np.unique(np.nonzero(used)[0] // 128)
+    assert np.array_equal(np.sort(tiles), live_tiles)
+    masks = ((src >= 0).reshape(9, -1, 128).any(2) * (1 << np.arange(9))[:, None]).sum(0)
+    assert np.array_equal(info[:, 1], masks[tiles]) and np.array_equal(info[:, 0] & 3, tiles // (m_pad // 3 // 128))
+    pop = np.array([bin(int(v)).count("1") for v in info[:, 1]])
+    assert np.all(pop[:-1] >= pop[1:])                                           # longest first
+
+
+@pytest.mark.parametrize("ci,co", [(32, 32), (32, 64), (64, 64), (96, 96), (128, 96), (96, 128), (256, 128)])
+def test_class_gemm_is_the_convolution(ci, co):
+    from taseg_amd import backend as B
+    c = _cloud(7, 20000, 30)
+    offs = O.get_kernel_offsets(3, 1, 1)
+    km = B.build_kmap(_T(c), _T(c), _T(offs))
+    plan = B.conv_class_plan(km["nbr"])
+    _, nbmaps, nbsizes = O.build_kmap(c, c, offs)
+    total = len(nbmaps)
+    rs = np.random.RandomState(1)
+    x = rs.randn(len(c), ci).astype(np.float32)
+    x[::9] *= 1e-3
+    w = (rs.randn(27, ci, co) / np.sqrt(ci)).astype(np.float32)
+    gy = rs.randn(len(c), co).astype(np.float32)
+    y64 = O.conv_forward(x.astype(np.float64), w.astype(np.float64), nbmaps, nbsizes, (len(c), len(c)))
+    gx64, _ = O.conv_backward(x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64), nbmaps, nbsizes)
+    xt, wt, gt = _T(x), _T(w), _T(gy)
+    y = B.conv_gather_sum(B.conv_class_gemm(xt, wt, plan), plan["pos"], len(c))
+    gx = B.conv_gather_sum(B.conv_class_gemm(gt, wt, plan, weight_transposed=True), plan["pos"], len(c))
+    y2 = B.conv_gather_sum(B.conv_pair_gemm(xt, wt, km["nbmaps"], km["nboffs"], total, 0), km["pos_out"], len(c))
+    gx2 = B.conv_gather_sum(B.conv_pair_gemm(gt, wt, km["nbmaps"], km["nboffs"], total, 1, weight_transposed=True),
+                            km["pos_in"], len(c))
+
+    def rel(a, b):
+        b = np.asarray(b, dtype=np.float64)
+        return float(np.abs(a.double().cpu().numpy() - b).max()) / float(np.abs(b).max())
+
+    assert rel(y, y64) <= 1e-5 and rel(gx, gx64) <= 1e-5
+    assert rel(y, y2.double().cpu().numpy()) <= 2e-6 and rel(gx, gx2.double().cpu().numpy()) <= 2e-6
+    # deterministic: the same launch twice gives the same bits (tile order varies, results do not)
+    plan_b = B.conv_class_plan(km["nbr"])
+    y_b = B.conv_gather_sum(B.conv_class_gemm(xt, wt, plan_b), plan_b["pos"], len(c))
+    assert torch.equal(y, y_b)
