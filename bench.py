@@ -332,6 +332,8 @@ def summarise_profile(records, steps):
         es = m.get("esize", 4)       # bytes per stored feature element (2 on the half-storage path)
         if kind == "pair_gemm":      # gather read + Z write + rulebook + weights  (first half of the 8(d) figure)
             byts = p * (m["c_red"] * es + m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * es
+        elif kind == "class_gemm":   # gather read + Z' write (<= 3 rows per output) + the plan's neighbour table + weights
+            byts = p * m["c_red"] * es + m["z_rows"] * (m["c_out"] * es + 36) + m["k"] * m["c_red"] * m["c_out"] * es
         elif kind == "gather_sum":   # Z read + output write + position table       (second half)
             flops = float(p * m["c_out"])
             byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4 + m.get("side_bytes", 0.0)
@@ -342,7 +344,7 @@ def summarise_profile(records, steps):
         # ideal-fused lower bound of the same launch: every feature row read / written once, the
         # rulebook and the weights once - no per-pair traffic (pair GEMM + gather-sum together make one convolution pass)
         rows = m.get("n_rows", 0)
-        if kind == "pair_gemm":
+        if kind in ("pair_gemm", "class_gemm"):
             ideal = rows * m["c_red"] * es + 8 * p + m["k"] * m["c_red"] * m["c_out"] * es
         elif kind == "gather_sum":
             ideal = rows * m["c_out"] * es
@@ -367,7 +369,8 @@ def summarise_profile(records, steps):
     return out
 
 
-FAMILIES = (("pair_gemm", "pair GEMM (pass 1: gather -> per-offset GEMM -> Z)"),
+FAMILIES = (("class_gemm", "class-sorted implicit GEMM (pass 1 with the sums of a z-plane of offsets in the accumulators)"),
+            ("pair_gemm", "pair GEMM (pass 1: gather -> per-offset GEMM -> Z)"),
             ("gather", "gather-sum (pass 2: Z rows -> output rows)"),
             ("wgrad", "weight gradient"),
             ("conv_os", "output-stationary fused convolution"),
@@ -386,7 +389,7 @@ def mfma_peak_of(kernel, amp):
     half-storage kernels, 2500 / 6 for fp32 products as six bf16 MFMAs, the f32 MFMA otherwise"""
     if amp or "_h_kernel" in kernel:
         return MFMA_F16_PEAK_TF
-    if any(t in kernel for t in ("_s_kernel", "_d_kernel", "conv_os")):
+    if any(t in kernel for t in ("_s_kernel", "_d_kernel", "conv_os", "class_gemm")):
         return MFMA_SPLIT_PEAK_TF
     return MFMA_F32_PEAK_TF
 

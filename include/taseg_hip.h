@@ -576,7 +576,8 @@ int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_
  *   ts_conv_class_gemm      zp [m_pad, c_out]; wt = 0 forward (kernel [27, c_red, c_out]), wt = 1 input gradient (feat = output
  *                           gradients, kernel [27, c_out, c_red] as stored: the mirrored offset's slice, transposed)
  *   ts_conv_class_hint      one-shot, per thread: the NEXT ts_conv_block_forward / _backward of this thread may run its forward
- *                           product / input gradient on this plan (fp32, K = 27, n rows in and out; it clears the hint) */
+ *                           product / input gradient on this plan (fp32, K = 27, n rows in and out; it clears the hint);
+ *                           z_rows = the caller's host copy of 128 * n_tiles (profile records only), or 0 */
 int64_t ts_conv_class_rows(int64_t n);
 size_t ts_conv_class_plan_workspace_bytes(int64_t n);
 int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t *src, int32_t *tile_info, int32_t *n_tiles,
@@ -585,7 +586,8 @@ int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
 int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t c_out, const int32_t *src,
                        int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt, float *zp,
                        ts_stream_t stream);
-void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos, int64_t n);
+void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos, int64_t n,
+                        int64_t z_rows);
 
 /* One-shot and per thread, like ts_conv_planes_hint: the NEXT ts_conv_block_backward of this thread adds `addend`
  * ([n_dgrad_rows, c_in] in the storage type of grad_feat, 16-byte aligned) into its grad_feat store,

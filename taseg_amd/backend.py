@@ -606,6 +606,9 @@ def profile_end():
             name = f"pair_gemm_h_kernel<{pick(c_out)}>" if half else pair_gemm_kernel_name(c_out, bool(wt), c_red)
             out.append(("pair_gemm", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k, esize=esize,
                                                          n_rows=rows)))
+        elif int(kind) == 3:      # class-sorted implicit GEMM (csrc/conv_class.hip): `wt` carries the rows of Z'
+            out.append(("class_gemm", _Ms(ms), None, dict(name=f"class_gemm_kernel<{pick(c_out)}>", pairs=pairs, c_red=c_red,
+                                                          c_out=c_out, k=k, esize=esize, n_rows=rows, z_rows=int(wt))))
         elif int(kind) == 1:
             name = gather_sum_kernel_name(c_out, k, half)
             out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,

@@ -155,6 +155,18 @@ struct PlanesHintScope {
   ~PlanesHintScope() { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
 };
 
+// the class plan of the block's kernel map (csrc/conv_class.hip), one-shot like the planes hint
+struct ClassHintScope {
+  TsClassHint h;
+  ClassHintScope() : h(g_ts_class_hint) { g_ts_class_hint = TsClassHint{nullptr, nullptr, nullptr, nullptr, 0, 0}; }
+  double z_rows() const { return (double)(h.z_rows > 0 ? h.z_rows : ts_conv_class_rows(h.n)); }
+  // fp32 submanifold 3x3x3 product over the plan's rows, Z' fits where Z would have gone
+  bool fits(int32_t K, int64_t n_rows_a, int64_t n_rows_b, int32_t c_red, int32_t c_out, int64_t n_pairs, int32_t half) const {
+    return h.src && !half && K == 27 && n_rows_a == h.n && n_rows_b == h.n && ts_conv_class_supported(c_red, c_out) &&
+           ts_conv_class_rows(h.n) <= n_pairs && g_ts_conv_impl == 0;
+  }
+};
+
 // out = act(BN(conv(feat)) [+ residual]).
 //   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
 //   `gather_col` and the position table pos [K, n_out] of the rows being produced (pos_out, or pos_in for a transposed
@@ -170,6 +182,7 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
                                      float *invstd, void *out, uint8_t *mask, void *w16, void *ws, size_t ws_bytes,
                                      ts_stream_t stream) {
   PlanesHintScope planes_hint;
+  ClassHintScope class_hint;
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_forward: bad sizes");
   TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
@@ -205,6 +218,19 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
     {
       ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 2, 0);
       TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
+    }
+  } else if (gather_col == 0 && class_hint.fits(K, n_feat_rows, n_out, c_in, c_out, n_pairs, half)) {
+    // class-sorted implicit GEMM: the sums of a z-plane of offsets stay in the accumulators, Z' has <= 3 rows per output
+    const TsClassHint &ch = class_hint.h;
+    const int64_t m_pad = ts_conv_class_rows(ch.n);
+    {
+      ProfScope ps(3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 4, class_hint.z_rows());
+      TS_TRY(ts_conv_class_gemm((const float *)feat, c_in, kernel, K, c_out, ch.src, m_pad, ch.tile_info, ch.n_tiles, 0,
+                                (float *)z, stream));
+    }
+    {
+      ProfScope ps(1, stream, class_hint.z_rows(), 0, c_out, 3, (double)n_out, 4, 0);
+      TS_TRY(ts_conv_gather_sum((const float *)z, c_out, ch.pos, 3, n_out, m_pad, (float *)conv_out, stream));
     }
   } else {
     {
@@ -245,6 +271,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                       float *grad_bn_weight, float *grad_bn_bias, void *ws, size_t ws_bytes,
                                       ts_stream_t stream) {
   PlanesHintScope planes_hint;
+  ClassHintScope class_hint;
   const void *addend = g_ts_block_addend;       // one-shot (ts_conv_block_addend_hint): added into grad_feat's store
   g_ts_block_addend = nullptr;
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
@@ -299,7 +326,23 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     if (det) job = TsWgradReduce{part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
   }
   const bool ride = det && grad_feat && n_dgrad_rows > 0;
-  if (grad_feat) {
+  if (grad_feat && dgrad_gather_col == 1 && class_hint.fits(K, n_out, n_dgrad_rows, c_out, c_in, n_pairs, half)) {
+    // input gradient on the class plan: gy rows through W_{26-k}^T, the sums of a z-plane of offsets in the accumulators
+    const TsClassHint &ch = class_hint.h;
+    const int64_t m_pad = ts_conv_class_rows(ch.n);
+    {
+      ProfScope ps(3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, 4, class_hint.z_rows());
+      TS_TRY(ts_conv_class_gemm((const float *)grad_conv, c_out, (const float *)weights, K, c_in, ch.src, m_pad, ch.tile_info,
+                                ch.n_tiles, 1, (float *)z, stream));
+    }
+    {
+      const double side_bytes = (ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0) +
+                                (addend ? es_d * (double)n_dgrad_rows * c_in : 0.0);
+      ProfScope ps(1, stream, class_hint.z_rows(), 0, c_in, 3, (double)n_dgrad_rows, es_d, side_bytes);
+      TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, ch.pos, 3, n_dgrad_rows, m_pad, (float *)grad_feat,
+                                   ride ? &job : nullptr, (const float *)addend, stream));
+    }
+  } else if (grad_feat) {
     {
       ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, 1);
       if (half)

@@ -226,6 +226,7 @@ extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv
 struct TsClassHint {
   const int32_t *src, *tile_info, *n_tiles, *pos;
   int64_t n;
+  int64_t z_rows;      // rows of Z' the live tiles cover (host copy of 128 * n_tiles, for the profile records), or 0
 };
 extern thread_local TsClassHint g_ts_class_hint;      // set by ts_conv_class_hint, cleared by the block call that reads it
 

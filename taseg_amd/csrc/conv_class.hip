@@ -249,11 +249,14 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
     }
   }
 
-  f32x4 acc[MI][NI];
+  // acc: the product of the offset being walked (what a Z row of the two-pass form holds); tot: the offsets finished so far,
+  // added with ordinary fp32 adds.  Keeping ONE accumulator across the offsets would chain 3.7x more terms through the matrix
+  // pipe's internal adder and doubles the rounding noise of the result (measured against float64).
+  f32x4 acc[MI][NI], tot[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = tot[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float *aptr[A_IT];
   bool alive[A_IT];
@@ -356,6 +359,13 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
       }
       mma();
     }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        tot[mi][ni] += acc[mi][ni];
+        acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     if (!mask) break;
     mask &= mask - 1;
   }
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        zt[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * O_total + (wc * NI + ni) * 16 + r16] = acc[mi][ni][q];
+        zt[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * O_total + (wc * NI + ni) * 16 + r16] = tot[mi][ni][q];
 }
 
 template <int BN, int WR, bool WT>
@@ -414,8 +424,8 @@ extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float 
 
 // One-shot and per thread (like ts_conv_planes_hint): the NEXT ts_conv_block_forward / ts_conv_block_backward of this thread
 // may run its forward product / input gradient on this plan when the block is a submanifold 3x3x3 convolution over `n` rows.
-thread_local TsClassHint g_ts_class_hint = {nullptr, nullptr, nullptr, nullptr, 0};
+thread_local TsClassHint g_ts_class_hint = {nullptr, nullptr, nullptr, nullptr, 0, 0};
 extern "C" void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos,
-                                   int64_t n) {
-  g_ts_class_hint = TsClassHint{src, tile_info, n_tiles, pos, n};
+                                   int64_t n, int64_t z_rows) {
+  g_ts_class_hint = TsClassHint{src, tile_info, n_tiles, pos, n, z_rows};
 }

@@ -23,6 +23,7 @@ struct Api {
   decltype(&ts_conv_block_backward) backward = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
   decltype(&ts_conv_planes_hint) planes_hint = nullptr;
+  decltype(&ts_conv_class_hint) class_hint = nullptr;
   decltype(&ts_conv_block_addend_hint) addend_hint = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
@@ -89,7 +90,10 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt,
                             double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream,
                             const c10::optional<at::Tensor> &planes, bool passthrough,
-                            const c10::optional<at::Tensor> &grad_dest, int64_t group_id) {
+                            const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
+                            const c10::optional<at::Tensor> &cls_src, const c10::optional<at::Tensor> &cls_tiles,
+                            const c10::optional<at::Tensor> &cls_count, const c10::optional<at::Tensor> &cls_pos,
+                            int64_t cls_rows) {
     const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
     const bool split = comm == 0 && group_id >= 0;
     const auto dt = half ? at::kHalf : at::kFloat;
@@ -117,6 +121,12 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (!half && have && planes->scalar_type() == at::kShort) pl = *planes;
     if (pl.defined()) api.planes_hint(w32.data_ptr<float>(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
     if (kept16) api.planes_hint(w32.data_ptr<float>(), w16.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
+    // plan of the class-sorted implicit GEMM of this block's kernel map (csrc/conv_class.hip), if the caller wants it used
+    const bool cls = !half && !transposed && cls_src.has_value() && cls_src->defined() && cls_tiles.has_value() &&
+                     cls_count.has_value() && cls_pos.has_value();
+    if (cls)
+      api.class_hint((const int32_t *)cls_src->data_ptr(), (const int32_t *)cls_tiles->data_ptr(),
+                     (const int32_t *)cls_count->data_ptr(), (const int32_t *)cls_pos->data_ptr(), cls_pos->size(1), cls_rows);
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
@@ -136,6 +146,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     }
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
+    ctx->saved_data["cls"] = cls ? c10::List<at::Tensor>({*cls_src, *cls_tiles, *cls_count, *cls_pos}) : c10::List<at::Tensor>();
+    ctx->saved_data["cls_rows"] = cls_rows;
     // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
     ctx->saved_data["grad_dest"] = (grad_dest.has_value() && grad_dest->defined()) ? *grad_dest : at::Tensor();
     ctx->saved_data["total"] = total;
@@ -216,12 +228,18 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const at::Tensor pl = ctx->saved_data["planes"].toTensor();
     if (pl.defined() && !half && grad_feat.defined())
       api.planes_hint((const float *)w.data_ptr(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
+    const auto cls = ctx->saved_data["cls"].toTensorList();
+    if (cls.size() == 4 && grad_feat.defined()) {
+      const at::Tensor c0 = cls.get(0), c1 = cls.get(1), c2 = cls.get(2), c3 = cls.get(3);
+      api.class_hint((const int32_t *)c0.data_ptr(), (const int32_t *)c1.data_ptr(), (const int32_t *)c2.data_ptr(),
+                     (const int32_t *)c3.data_ptr(), c3.size(1), ctx->saved_data["cls_rows"].toInt());
+    }
     call(split ? COMM_POST : (void *)comm);
     if (grad_feat.defined() && grad_feat.scalar_type() != in_dtype) grad_feat = grad_feat.to(in_dtype);
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -236,8 +254,9 @@ void load_backend(const std::string &libpath) {
   api.backward = (decltype(api.backward))dlsym(h, "ts_conv_block_backward");
   api.last_error = (decltype(api.last_error))dlsym(h, "ts_last_error");
   api.planes_hint = (decltype(api.planes_hint))dlsym(h, "ts_conv_planes_hint");
+  api.class_hint = (decltype(api.class_hint))dlsym(h, "ts_conv_class_hint");
   api.addend_hint = (decltype(api.addend_hint))dlsym(h, "ts_conv_block_addend_hint");
-  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.planes_hint && api.addend_hint,
+  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.planes_hint && api.addend_hint && api.class_hint,
               "libtaseg_hip.so lacks the ts_conv_block_* / ts_conv_planes_hint / ts_conv_block_addend_hint entry points");
 #define TS_BIND(field, sym)                                      \
   api.field = (decltype(api.field))dlsym(h, sym);                \
@@ -261,11 +280,13 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       const c10::optional<at::Tensor> &running_var, const c10::optional<at::Tensor> &nbt, double momentum,
                       double eps, bool relu, int64_t comm, bool half, int64_t stream,
                       const c10::optional<at::Tensor> &planes, bool passthrough,
-                      const c10::optional<at::Tensor> &grad_dest, int64_t group_id) {
+                      const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
+                      const c10::optional<at::Tensor> &cls_src, const c10::optional<at::Tensor> &cls_tiles,
+                      const c10::optional<at::Tensor> &cls_count, const c10::optional<at::Tensor> &cls_pos, int64_t cls_rows) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
-                          passthrough, grad_dest, group_id);
+                          passthrough, grad_dest, group_id, cls_src, cls_tiles, cls_count, cls_pos, cls_rows);
 }
 
 // torch.distributed process group -> the index conv_block takes as `group_id` (SyncBatchNorm's all-reduce through c10d)

@@ -256,6 +256,7 @@ class MinkUNetBackbone(BaseSegmentor):
                 s = 1 << lvl
                 km = spF.KernelMap(dict(zip(names, sub_t[lvl])), (cm[lvl].shape[0], cm[lvl].shape[0]))
                 km._total = int(totals[2 * lvl])
+                km.build_class_plan()                 # large maps: plan of the class-sorted implicit GEMM (csrc/conv_class.hip)
                 kmaps[((s, s, s), (3, 3, 3), (1, 1, 1), (1, 1, 1))] = km
                 if lvl < 4:
                     km = spF.KernelMap(dict(zip(names, down_t[lvl])), (cm[lvl].shape[0], cm[lvl + 1].shape[0]))
@@ -272,6 +273,9 @@ class MinkUNetBackbone(BaseSegmentor):
         with torch.no_grad():
             probe = SparseTensor(None, coords, 1)
             spF.build_pyramid(probe, num_levels=4)
+            for key, km in probe.kmaps.items():
+                if key[1] == (3, 3, 3) and key[2] == (1, 1, 1):
+                    km.build_class_plan()
             tri_idx, tri_w, tri_order = {}, {}, {}
             pc = point_coords.contiguous()
             for s in (1, 16, 4):

@@ -11,6 +11,7 @@ what differs is how the work is scheduled on the device:
 * `nbmaps` / `nbsizes` with the reference's exact contents and order are still produced
   (and are what the weight-gradient kernel walks), so rulebooks can be compared bit for bit.
 """
+import os
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -227,6 +228,22 @@ class KernelMap:
         self.sizes = sizes
         self._nbmaps = None
         self._total = None
+        self.cls = None                       # plan of the class-sorted implicit GEMM (csrc/conv_class.hip), large 3x3x3 maps
+
+    def build_class_plan(self):
+        """Plan of the class-sorted implicit GEMM for a SUBMANIFOLD 3x3x3 map (in == out; the caller knows): rows sorted by
+        the neighbour mask of each z-plane of offsets.  Built with the map, on the stream that builds it; maps too small to
+        gain (class_gemm_pays) go without."""
+        if (_CLASS_GEMM and self.cls is None and self.nbr.shape[0] == 27 and self.sizes[0] == self.sizes[1]
+                and self.sizes[0] >= _CLASS_MIN_ROWS):
+            self.cls = B.conv_class_plan(self.nbr)
+            self.cls["z_rows"] = 0            # host copy of 128 * n_tiles: class_rows() reads it once, when a profile asks
+        return self.cls
+
+    def class_rows(self) -> int:
+        if self.cls is not None and not self.cls["z_rows"]:
+            self.cls["z_rows"] = 128 * int(self.cls["n_tiles"].item())
+        return 0 if self.cls is None else self.cls["z_rows"]
 
     @property
     def total(self) -> int:
@@ -255,6 +272,31 @@ class KernelMap:
 
     def __len__(self):
         return 3
+
+
+# Class-sorted implicit GEMM (csrc/conv_class.hip) - where it beats pair GEMM + gather-sum (profiles/r03_class_gemm_layers.txt):
+# 1.4-1.65x on the 178k-voxel stride-1 maps and the 32 / 64-wide stride-2 layers, 1.1-1.3x on the 84k-voxel 96-wide ones,
+# 1.1x on 30k voxels x 64 channels, a loss on 30k x 128 and below.  TASEG_CLASS_GEMM=0 keeps every block on the two passes.
+_CLASS_GEMM = os.environ.get("TASEG_CLASS_GEMM", "1") != "0"
+_CLASS_MIN_ROWS = 16384
+
+
+def class_gemm_pays(n_rows: int, c_in: int, c_out: int) -> bool:
+    if max(c_in, c_out) <= 64:
+        return n_rows >= _CLASS_MIN_ROWS
+    cols128 = any(c % 128 == 0 and c % 96 != 0 for c in (c_in, c_out))       # a direction on 128-column tiles (direct-rows pair GEMM)
+    return n_rows >= (100000 if cols128 else 48000)
+
+
+def class_hint(kmap, c_in: int, c_out: int, profiling: bool = False) -> bool:
+    """One-shot: let the NEXT block call of this thread run its product / input gradient on kmap's class plan."""
+    cls = kmap.cls
+    if cls is None or not class_gemm_pays(cls["n"], c_in, c_out):
+        return False
+    z_rows = kmap.class_rows() if profiling else cls["z_rows"]
+    B.L.load().ts_conv_class_hint(cls["src"].data_ptr(), cls["tile_info"].data_ptr(), cls["n_tiles"].data_ptr(),
+                                  cls["pos"].data_ptr(), cls["n"], z_rows)
+    return True
 
 
 def build_kernel_map(in_coords, out_coords, kernel_size, tensor_stride, dilation=1) -> KernelMap:
@@ -664,6 +706,8 @@ class _ConvBlock(Function):
                 ws.numel(), L.stream()), "ts_conv_block_forward")
 
         _planes.hint(w32, planes)
+        if not half and not transposed:
+            class_hint(kmap, c_in, c_out, B._prof is not None)      # large submanifold maps: class-sorted implicit GEMM
         if split:
             call(_COMM_PRE)                       # convolution + this rank's sums
             _c10d_sum(pack, group)
@@ -725,6 +769,8 @@ class _ConvBlock(Function):
             _c10d_sum(sums, ctx.group)
         if grad_feat is not None and not half:
             _planes.hint(w, ctx.planes)
+            if not transposed:
+                class_hint(kmap, c_in, c_out, B._prof is not None)
         if grad_pass is not None and grad_feat is not None:
             addend = grad_pass.contiguous().to(dt)
             lib.ts_conv_block_addend_hint(L.ptr(addend))

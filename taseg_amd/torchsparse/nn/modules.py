@@ -153,6 +153,18 @@ def _claim_grad_dest(kernel):
     return dest
 
 
+_NO_CLASS = (None, None, None, None, 0)
+
+
+def _class_args(kmap, conv, half):
+    """(src, tile_info, n_tiles, pos, z_rows) of kmap's class plan when this fp32 submanifold block gains from the class-sorted
+    implicit GEMM (functional.class_gemm_pays), else five placeholders - the C++ node hands them on as ts_conv_class_hint"""
+    cls = kmap.cls
+    if cls is None or half or conv.transposed or not F.class_gemm_pays(cls["n"], conv.kernel.shape[1], conv.kernel.shape[2]):
+        return _NO_CLASS
+    return cls["src"], cls["tile_info"], cls["n_tiles"], cls["pos"], (kmap.class_rows() if _B._prof is not None else cls["z_rows"])
+
+
 def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None,
                 passthrough: bool = False):
     """relu(BN(conv(input)) [+ residual]) for a Conv3d and its BatchNorm / SyncBatchNorm module: one autograd node and
@@ -194,7 +206,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                                       kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
                                       state[1], state[2], float(mod.momentum), float(mod.eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
-                                      bool(passthrough), dest, _group_id(fast, c10d_group))
+                                      bool(passthrough), dest, _group_id(fast, c10d_group), *_class_args(kmap, conv, half))
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
                 out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
