@@ -586,6 +586,10 @@ int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
 int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t c_out, const int32_t *src,
                        int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt, float *zp,
                        ts_stream_t stream);
+/* half storage (torch.autocast): feat / zp IEEE half, w = the half weight [27, C_in, C_out] as stored */
+int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t c_out, const int32_t *src,
+                           int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt, void *zp,
+                           ts_stream_t stream);
 void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos, int64_t n,
                         int64_t z_rows);
 

@@ -125,6 +125,7 @@ SIGNATURES = {
     "ts_conv_class_plan": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_conv_class_supported": (_i32, [_i32, _i32]),
     "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "ts_conv_class_gemm_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
     "ts_conv_class_hint": (None, [_vp, _vp, _vp, _vp, _i64, _i64]),
     "ts_conv_planes_hint": (None, [_vp, _vp, _i32, _i32, _i32]),
     "ts_conv_block_addend_hint": (None, [_vp]),

@@ -18,7 +18,7 @@ __all__ = [
     "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs", "devox_csr",
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
-    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm",
+    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16",
     "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
@@ -911,6 +911,23 @@ def conv_class_gemm(feat, kernel, plan, weight_transposed=False):
     L.check(L.load().ts_conv_class_gemm(L.ptr(feat), c_red, L.ptr(kernel), k, cols, L.ptr(plan["src"]), plan["m_pad"],
                                         L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
                                         L.ptr(zp), L.stream()), "ts_conv_class_gemm")
+    return zp
+
+
+def conv_class_gemm_f16(feat, w16, plan, weight_transposed=False):
+    """conv_class_gemm for IEEE-half rows: w16 = the half weight [27, C_in, C_out] as stored; z' half (fp32 sums)."""
+    L.require_device(feat, w16)
+    if feat.dtype != torch.float16 or w16.dtype != torch.float16:
+        raise TypeError("conv_class_gemm_f16: half tensors expected")
+    feat, w16 = feat.contiguous(), w16.contiguous()
+    k, c_in, c_out = w16.shape
+    c_red, cols = (c_out, c_in) if weight_transposed else (c_in, c_out)
+    if feat.shape[1] != c_red:
+        raise ValueError(f"conv_class_gemm_f16: feat has {feat.shape[1]} channels, the product reduces over {c_red}")
+    zp = torch.empty((plan["m_pad"], cols), dtype=torch.float16, device=feat.device)
+    L.check(L.load().ts_conv_class_gemm_f16(L.ptr(feat), c_red, L.ptr(w16), k, cols, L.ptr(plan["src"]), plan["m_pad"],
+                                            L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
+                                            L.ptr(zp), L.stream()), "ts_conv_class_gemm_f16")
     return zp
 
 

@@ -160,9 +160,10 @@ struct ClassHintScope {
   TsClassHint h;
   ClassHintScope() : h(g_ts_class_hint) { g_ts_class_hint = TsClassHint{nullptr, nullptr, nullptr, nullptr, 0, 0}; }
   double z_rows() const { return (double)(h.z_rows > 0 ? h.z_rows : ts_conv_class_rows(h.n)); }
-  // fp32 submanifold 3x3x3 product over the plan's rows, Z' fits where Z would have gone
+  // submanifold 3x3x3 product over the plan's rows, Z' fits where Z would have gone
   bool fits(int32_t K, int64_t n_rows_a, int64_t n_rows_b, int32_t c_red, int32_t c_out, int64_t n_pairs, int32_t half) const {
-    return h.src && !half && K == 27 && n_rows_a == h.n && n_rows_b == h.n && ts_conv_class_supported(c_red, c_out) &&
+    (void)half;        // both storage types have the kernel
+    return h.src && K == 27 && n_rows_a == h.n && n_rows_b == h.n && ts_conv_class_supported(c_red, c_out) &&
            ts_conv_class_rows(h.n) <= n_pairs && g_ts_conv_impl == 0;
   }
 };
@@ -203,6 +204,21 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
   if (comm == TS_COMM_CALLER_POST) {
     // second half of a split call: conv_out and the all-reduced pack exist, statistics + elementwise pass are left
+  } else if (half && gather_col == 0 && class_hint.fits(K, n_feat_rows, n_out, c_in, c_out, n_pairs, half)) {
+    // half storage on the class plan (csrc/conv_class.hip): Z' rows are rounded to half once per (row, z-plane of offsets)
+    const TsPlanesHint &hw = planes_hint.h;
+    if (!(hw.w == kernel && (const void *)hw.planes == w16 && hw.K == K && hw.c_in == c_in && hw.c_out == c_out))
+      TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
+    const TsClassHint &ch = class_hint.h;
+    const int64_t m_pad = ts_conv_class_rows(ch.n);
+    {
+      ProfScope ps(3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 2, class_hint.z_rows());
+      TS_TRY(ts_conv_class_gemm_f16(feat, c_in, w16, K, c_out, ch.src, m_pad, ch.tile_info, ch.n_tiles, 0, z, stream));
+    }
+    {
+      ProfScope ps(1, stream, class_hint.z_rows(), 0, c_out, 3, (double)n_out, 2, 0);
+      TS_TRY(ts_conv_gather_sum_f16(z, c_out, ch.pos, 3, n_out, m_pad, conv_out, stream));
+    }
   } else if (half) {
     // one half copy in the kernel's own layout serves both passes: the forward reads it through the transposing LDS
     // load (ts_conv_pair_gemm_f16_nat), the input gradient directly
@@ -331,16 +347,23 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     const TsClassHint &ch = class_hint.h;
     const int64_t m_pad = ts_conv_class_rows(ch.n);
     {
-      ProfScope ps(3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, 4, class_hint.z_rows());
-      TS_TRY(ts_conv_class_gemm((const float *)grad_conv, c_out, (const float *)weights, K, c_in, ch.src, m_pad, ch.tile_info,
-                                ch.n_tiles, 1, (float *)z, stream));
+      ProfScope ps(3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, class_hint.z_rows());
+      if (half)
+        TS_TRY(ts_conv_class_gemm_f16(grad_conv, c_out, weights, K, c_in, ch.src, m_pad, ch.tile_info, ch.n_tiles, 1, z, stream));
+      else
+        TS_TRY(ts_conv_class_gemm((const float *)grad_conv, c_out, (const float *)weights, K, c_in, ch.src, m_pad,
+                                  ch.tile_info, ch.n_tiles, 1, (float *)z, stream));
     }
     {
       const double side_bytes = (ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0) +
                                 (addend ? es_d * (double)n_dgrad_rows * c_in : 0.0);
       ProfScope ps(1, stream, class_hint.z_rows(), 0, c_in, 3, (double)n_dgrad_rows, es_d, side_bytes);
-      TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, ch.pos, 3, n_dgrad_rows, m_pad, (float *)grad_feat,
-                                   ride ? &job : nullptr, (const float *)addend, stream));
+      if (half)
+        TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, ch.pos, 3, n_dgrad_rows, m_pad, grad_feat, ride ? &job : nullptr, addend,
+                                         stream));
+      else
+        TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, ch.pos, 3, n_dgrad_rows, m_pad, (float *)grad_feat,
+                                     ride ? &job : nullptr, (const float *)addend, stream));
     }
   } else if (grad_feat) {
     {

@@ -281,8 +281,10 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
   auto load_regs = [&](int c0) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      ra[it][0] = *(const f32x4 *)(aptr[it] + c0);
-      ra[it][1] = *(const f32x4 *)(aptr[it] + c0 + 4);
+      if (alive[it]) {                   // a row without this neighbour loads nothing (11 % of the (row, offset) slots of a tile)
+        ra[it][0] = *(const f32x4 *)(aptr[it] + c0);
+        ra[it][1] = *(const f32x4 *)(aptr[it] + c0 + 4);
+      }
       rlive[it] = alive[it];
     }
     const float *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
@@ -420,6 +422,216 @@ extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float 
     default: return CG_GO(32, 4);
   }
 #undef CG_GO
+}
+
+// ------------------------------------------------------------------------------------------- half storage
+// The same walk for IEEE-half rows (torch.autocast; conv_pairs_h.hip): one v_mfma_f32_16x16x32_f16 per product, fp32 sums, the
+// gathered operand and the weight slice double-buffered in LDS (one barrier per slice), Z' rows rounded to half ONCE per
+// (row, group) - the two-pass form rounds every pair's Z row.
+typedef _Float16 ch8 __attribute__((ext_vector_type(8)));
+typedef __fp16 chv4t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ ch8 cgh_frag_tr(const _Float16 *img, int pitch, int r0, int c0, int tq, int tp) {
+  typedef chv4t __attribute__((address_space(3))) * lds_hv4;
+  const chv4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + tq) * pitch + c0 + 4 * tp));
+  const chv4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + 4 + tq) * pitch + c0 + 4 * tp));
+  ch8 v;
+  v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+  v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+  return v;
+}
+
+template <int BN, int WR, bool WT>
+__global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__restrict__ X, int R,
+                                                             const _Float16 *__restrict__ W, int O_total,
+                                                             const int *__restrict__ src, int64_t m_pad,
+                                                             const int2 *__restrict__ tile_info,
+                                                             const int *__restrict__ n_tiles, int K,
+                                                             _Float16 *__restrict__ Zp) {
+  constexpr int BM = CG_BM;
+  constexpr int WC = 4 / WR;
+  constexpr int MI = (BM / 16) / WR;
+  constexpr int NI = (BN / 16) / WC;
+  constexpr int A_HALVES = BM * CG_AP;
+  constexpr int BP = BN + 8;
+  constexpr int B_HALVES = WT ? BN * CG_AP : CG_BK * BP;
+  constexpr int A_IT = BM * (CG_BK / 8) / 256;
+  constexpr int B_IT = (BN * (CG_BK / 8) + 255) / 256;
+  constexpr int ZP = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_cgh[];
+  _Float16 *Abuf = smem_cgh;
+  _Float16 *Bbuf = Abuf + 2 * A_HALVES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = lane & 3;
+  const int wr = wave / WC, wc = wave % WC;
+  const int o0 = blockIdx.y * BN;
+  const int tile = (int)blockIdx.x;
+  if (tile >= *n_tiles) return;
+  const int2 info = tile_info[tile];
+  const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
+  int mask = __builtin_amdgcn_readfirstlane(info.y);
+  const int64_t row0 = (int64_t)(__builtin_amdgcn_readfirstlane(info.x) >> 2) * BM;
+
+  const int arow0 = tid >> 2, acol = (tid & 3) << 3;
+  int boff[B_IT], bdst[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int e = min(tid + it * 256, BN * 4 - 1);
+    if (WT) {
+      const int col = e >> 2, c8 = (e & 3) << 3;
+      boff[it] = col * R + c8;
+      bdst[it] = col * CG_AP + c8;
+    } else {
+      constexpr int q8 = BN >> 3;
+      const int kk = e / q8, c8 = (e - kk * q8) << 3;
+      boff[it] = kk * O_total + c8;
+      bdst[it] = kk * BP + c8;
+    }
+  }
+  f32x4 acc[MI][NI], tot[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = tot[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const _Float16 *aptr[A_IT];
+  bool alive[A_IT];
+  const _Float16 *wk = W;
+  int nsrc[A_IT];
+  auto fetch = [&](int kl) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) nsrc[it] = src[(int64_t)kl * m_pad + row0 + arow0 + 64 * it];
+  };
+  auto bind = [&](int kl) {
+    const int k = CG_GK * grp + kl;
+    const int kw = WT ? (K - 1 - k) : k;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      alive[it] = nsrc[it] >= 0;
+      aptr[it] = X + (int64_t)max(nsrc[it], 0) * R + acol;
+    }
+    wk = WT ? W + ((int64_t)kw * O_total + o0) * R : W + (int64_t)kw * R * O_total + o0;
+  };
+  ch8 ra[A_IT], rb[B_IT];
+  auto load_regs = [&](int c0) {
+    const ch8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      ra[it] = zero;
+      if (alive[it]) ra[it] = *(const ch8 *)(aptr[it] + c0);
+    }
+    const _Float16 *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const ch8 *)(wb + boff[it]);
+  };
+  auto store_lds = [&](_Float16 *At, _Float16 *Bt) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) *(ch8 *)&At[(arow0 + 64 * it) * CG_AP + acol] = ra[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      if (B_IT * 256 == BN * 4 || tid + it * 256 < BN * 4) *(ch8 *)&Bt[bdst[it]] = rb[it];
+  };
+  auto mma = [&](const _Float16 *At, const _Float16 *Bt) {
+    ch8 a[MI], b[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *(const ch8 *)&At[((wr * MI + mi) * 16 + r16) * CG_AP + 8 * g];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      b[ni] = WT ? *(const ch8 *)&Bt[((wc * NI + ni) * 16 + r16) * CG_AP + 8 * g]
+                 : cgh_frag_tr(Bt, BP, 8 * g, (wc * NI + ni) * 16, tq, tp);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  fetch(__builtin_ctz(mask));
+  bind(__builtin_ctz(mask));
+  mask &= mask - 1;
+  load_regs(0);
+  int t = 0;
+  while (true) {
+    if (mask) fetch(__builtin_ctz(mask));
+    for (int c0 = 0; c0 < R; c0 += CG_BK, ++t) {
+      _Float16 *At = Abuf + (t & 1) * A_HALVES, *Bt = Bbuf + (t & 1) * B_HALVES;
+      store_lds(At, Bt);
+      __syncthreads();
+      if (c0 + CG_BK < R) {
+        load_regs(c0 + CG_BK);
+      } else if (mask) {
+        bind(__builtin_ctz(mask));
+        load_regs(0);
+      }
+      mma(At, Bt);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        tot[mi][ni] += acc[mi][ni];
+        acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    if (!mask) break;
+    mask &= mask - 1;
+  }
+  // Z' tile: sums -> half -> LDS image [row][col] -> 16-byte chunks of whole rows
+  __syncthreads();
+  _Float16 *Zt = smem_cgh;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        Zt[((wr * MI + mi) * 16 + 4 * g + q) * ZP + (wc * NI + ni) * 16 + r16] = (_Float16)tot[mi][ni][q];
+  __syncthreads();
+  constexpr int CH = BN / 8;
+  for (int e = tid; e < BM * CH; e += 256) {
+    const int row = e / CH, ch = e - row * CH;
+    *(ch8 *)(Zp + (row0 + row) * O_total + o0 + ch * 8) = *(const ch8 *)&Zt[row * ZP + ch * 8];
+  }
+}
+
+template <int BN, int WR, bool WT>
+static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_total, const int *src, int64_t m_pad,
+                          const int2 *tile_info, const int *n_tiles, int K, _Float16 *Zp, hipStream_t stream) {
+  const size_t stage = (size_t)2 * (CG_BM * CG_AP + (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
+  const size_t ztile = (size_t)CG_BM * (BN + 8) * 2;
+  dim3 grid((unsigned)(m_pad / CG_BM), (unsigned)(O_total / BN));
+  class_gemm_h_kernel<BN, WR, WT><<<grid, 256, std::max(stage, ztile), stream>>>(X, R, W, O_total, src, m_pad, tile_info, n_tiles, K, Zp);
+  TS_CHECK_LAUNCH("ts_conv_class_gemm_f16");
+  return TS_OK;
+}
+
+// half rows: feat / zp IEEE half, w = the half weight [27, C_in, C_out] as stored (wt = 0: forward, read in place through the
+// transposing LDS load; wt = 1: input gradient, rows of the mirrored offset's slice = result columns)
+extern "C" int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t c_out,
+                                      const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles,
+                                      int32_t wt, void *zp, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(K == CG_GROUPS * CG_GK, TS_ERR_UNSUPPORTED, "ts_conv_class_gemm_f16: 27 offsets (3x3x3) only");
+  TS_REQUIRE(ts_conv_class_supported(c_red, c_out), TS_ERR_UNSUPPORTED,
+             "ts_conv_class_gemm_f16: channel counts must be multiples of 32 (got %d, %d)", c_red, c_out);
+  TS_REQUIRE(feat && w && src && tile_info && n_tiles && zp, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_gemm_f16: null pointer");
+  TS_REQUIRE(m_pad > 0 && m_pad % (CG_GROUPS * CG_BM) == 0 && m_pad < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_class_gemm_f16: m_pad must be ts_conv_class_rows(n)");
+  TS_REQUIRE(((((uintptr_t)feat) | ((uintptr_t)w) | ((uintptr_t)zp)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_class_gemm_f16: pointers must be 16-byte aligned");
+  const int2 *ti = (const int2 *)tile_info;
+  const _Float16 *x = (const _Float16 *)feat, *wh = (const _Float16 *)w;
+#define CGH_GO(BN, WR)                                                                                                  \
+  (wt ? launch_class_h<BN, WR, true>(x, c_red, wh, c_out, src, m_pad, ti, n_tiles, K, (_Float16 *)zp, stream)          \
+      : launch_class_h<BN, WR, false>(x, c_red, wh, c_out, src, m_pad, ti, n_tiles, K, (_Float16 *)zp, stream))
+  switch (cg_tile_columns(c_out)) {
+    case 128: return CGH_GO(128, 2);
+    case 96: return CGH_GO(96, 2);
+    case 64: return CGH_GO(64, 2);
+    default: return CGH_GO(32, 4);
+  }
+#undef CGH_GO
 }
 
 // One-shot and per thread (like ts_conv_planes_hint): the NEXT ts_conv_block_forward / ts_conv_block_backward of this thread

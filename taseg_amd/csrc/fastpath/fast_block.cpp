@@ -122,7 +122,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (pl.defined()) api.planes_hint(w32.data_ptr<float>(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
     if (kept16) api.planes_hint(w32.data_ptr<float>(), w16.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
     // plan of the class-sorted implicit GEMM of this block's kernel map (csrc/conv_class.hip), if the caller wants it used
-    const bool cls = !half && !transposed && cls_src.has_value() && cls_src->defined() && cls_tiles.has_value() &&
+    const bool cls = !transposed && cls_src.has_value() && cls_src->defined() && cls_tiles.has_value() &&
                      cls_count.has_value() && cls_pos.has_value();
     if (cls)
       api.class_hint((const int32_t *)cls_src->data_ptr(), (const int32_t *)cls_tiles->data_ptr(),

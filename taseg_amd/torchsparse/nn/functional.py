@@ -279,19 +279,22 @@ class KernelMap:
 # 1.1x on 30k voxels x 64 channels, a loss on 30k x 128 and below.  TASEG_CLASS_GEMM=0 keeps every block on the two passes.
 _CLASS_GEMM = os.environ.get("TASEG_CLASS_GEMM", "1") != "0"
 _CLASS_MIN_ROWS = 16384
+_CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
 
 
-def class_gemm_pays(n_rows: int, c_in: int, c_out: int) -> bool:
+def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> bool:
+    if half:
+        return n_rows >= _CLASS_MIN_ROWS_HALF
     if max(c_in, c_out) <= 64:
         return n_rows >= _CLASS_MIN_ROWS
     cols128 = any(c % 128 == 0 and c % 96 != 0 for c in (c_in, c_out))       # a direction on 128-column tiles (direct-rows pair GEMM)
     return n_rows >= (100000 if cols128 else 48000)
 
 
-def class_hint(kmap, c_in: int, c_out: int, profiling: bool = False) -> bool:
+def class_hint(kmap, c_in: int, c_out: int, profiling: bool = False, half: bool = False) -> bool:
     """One-shot: let the NEXT block call of this thread run its product / input gradient on kmap's class plan."""
     cls = kmap.cls
-    if cls is None or not class_gemm_pays(cls["n"], c_in, c_out):
+    if cls is None or not class_gemm_pays(cls["n"], c_in, c_out, half):
         return False
     z_rows = kmap.class_rows() if profiling else cls["z_rows"]
     B.L.load().ts_conv_class_hint(cls["src"].data_ptr(), cls["tile_info"].data_ptr(), cls["n_tiles"].data_ptr(),
@@ -706,8 +709,8 @@ class _ConvBlock(Function):
                 ws.numel(), L.stream()), "ts_conv_block_forward")
 
         _planes.hint(w32, planes)
-        if not half and not transposed:
-            class_hint(kmap, c_in, c_out, B._prof is not None)      # large submanifold maps: class-sorted implicit GEMM
+        if not transposed:
+            class_hint(kmap, c_in, c_out, B._prof is not None, half)      # large submanifold maps: class-sorted implicit GEMM
         if split:
             call(_COMM_PRE)                       # convolution + this rank's sums
             _c10d_sum(pack, group)
@@ -769,8 +772,8 @@ class _ConvBlock(Function):
             _c10d_sum(sums, ctx.group)
         if grad_feat is not None and not half:
             _planes.hint(w, ctx.planes)
-            if not transposed:
-                class_hint(kmap, c_in, c_out, B._prof is not None)
+        if grad_feat is not None and not transposed:
+            class_hint(kmap, c_in, c_out, B._prof is not None, half)
         if grad_pass is not None and grad_feat is not None:
             addend = grad_pass.contiguous().to(dt)
             lib.ts_conv_block_addend_hint(L.ptr(addend))

@@ -157,10 +157,10 @@ _NO_CLASS = (None, None, None, None, 0)
 
 
 def _class_args(kmap, conv, half):
-    """(src, tile_info, n_tiles, pos, z_rows) of kmap's class plan when this fp32 submanifold block gains from the class-sorted
-    implicit GEMM (functional.class_gemm_pays), else five placeholders - the C++ node hands them on as ts_conv_class_hint"""
+    """(src, tile_info, n_tiles, pos, z_rows) of kmap's class plan when this submanifold block gains from the class-sorted
+    implicit GEMM (functional.class_gemm_pays; fp32 and half storage), else five placeholders - the C++ node hands them on as ts_conv_class_hint"""
     cls = kmap.cls
-    if cls is None or half or conv.transposed or not F.class_gemm_pays(cls["n"], conv.kernel.shape[1], conv.kernel.shape[2]):
+    if cls is None or conv.transposed or not F.class_gemm_pays(cls["n"], conv.kernel.shape[1], conv.kernel.shape[2], half):
         return _NO_CLASS
     return cls["src"], cls["tile_info"], cls["n_tiles"], cls["pos"], (kmap.class_rows() if _B._prof is not None else cls["z_rows"])
 

@@ -92,3 +92,34 @@ def test_class_gemm_is_the_convolution(ci, co):
     plan_b = B.conv_class_plan(km["nbr"])
     y_b = B.conv_gather_sum(B.conv_class_gemm(xt, wt, plan_b), plan_b["pos"], len(c))
     assert torch.equal(y, y_b)
+
+
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 96), (128, 96), (96, 128)])
+def test_class_gemm_half_storage(ci, co):
+    """IEEE-half rows: the class path rounds a Z' row once per (row, z-plane), the two-pass form once per pair - both within
+    half precision of the fp32 evaluation"""
+    from taseg_amd import backend as B
+    c = _cloud(11, 20000, 30)
+    offs = O.get_kernel_offsets(3, 1, 1)
+    km = B.build_kmap(_T(c), _T(c), _T(offs))
+    plan = B.conv_class_plan(km["nbr"])
+    total = int(km["nboffs"][-1])
+    rs = np.random.RandomState(2)
+    x = _T(rs.randn(len(c), ci).astype(np.float32))
+    gy = _T(rs.randn(len(c), co).astype(np.float32))
+    w = _T((rs.randn(27, ci, co) / np.sqrt(ci)).astype(np.float32))
+    xh, gh, wh = x.half(), gy.half(), w.half()
+    y32 = B.conv_gather_sum(B.conv_class_gemm(xh.float(), wh.float(), plan), plan["pos"], len(c))
+    g32 = B.conv_gather_sum(B.conv_class_gemm(gh.float(), wh.float(), plan, weight_transposed=True), plan["pos"], len(c))
+    y = B.conv_gather_sum_f16(B.conv_class_gemm_f16(xh, wh, plan), plan["pos"], len(c))
+    g = B.conv_gather_sum_f16(B.conv_class_gemm_f16(gh, wh, plan, weight_transposed=True), plan["pos"], len(c))
+    y2 = B.conv_gather_sum_f16(B.conv_pair_gemm_f16(xh, wh, km["nbmaps"], km["nboffs"], total, 0, natural=True), km["pos_out"], len(c))
+    g2 = B.conv_gather_sum_f16(B.conv_pair_gemm_f16(gh, wh, km["nbmaps"], km["nboffs"], total, 1), km["pos_in"], len(c))
+    assert y.dtype == torch.float16 and g.dtype == torch.float16
+
+    def err(a, b):
+        return float((a.float() - b).abs().max()) / float(b.abs().max())
+
+    for got, two, ref in ((y, y2, y32), (g, g2, g32)):
+        assert err(got, ref) <= 2e-3                                   # a few half ulps of the tensor's scale
+        assert err(got, ref) <= 1.5 * err(two, ref) + 2e-4       # same error budget: 3 roundings of group sums vs 6.5 of pair products

@@ -14,6 +14,7 @@ ap.add_argument("--stride", type=int, default=1)
 ap.add_argument("--cin", type=int, default=96)
 ap.add_argument("--cout", type=int, default=96)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--half", action="store_true", help="IEEE-half rows (the autocast path)")
 args = ap.parse_args()
 coords, feats, labels, _ = bench.make_scans(0, 2, 120000, "minkunet")
 x = SparseTensor(None, coords, 1)
@@ -57,24 +58,33 @@ def class_gemm(feat, wt, c_out):
     holder = {}
 
     def go():
-        holder["z"] = B.conv_class_gemm(feat, w, plan, weight_transposed=bool(wt))
+        holder["z"] = (B.conv_class_gemm_f16(feat, w, plan, weight_transposed=bool(wt)) if args.half else
+                       B.conv_class_gemm(feat, w, plan, weight_transposed=bool(wt)))
     go()
     return go, holder["z"]
 
 
+if args.half:
+    xf, gy, w = xf.half(), gy.half(), w.half()
+gsum = B.conv_gather_sum_f16 if args.half else B.conv_gather_sum
+
+
 for wt, name, feat, c_out in ((0, "fwd", xf, args.cout), (1, "dgrad", gy, args.cin)):
+    feat = gy if wt else xf
     if wt:
-        two1 = lambda: B.conv_pair_gemm(gy, w, km.nbmaps_buf, km.nboffs, P, 1, weight_transposed=True)
+        two1 = ((lambda: B.conv_pair_gemm_f16(gy, w, km.nbmaps_buf, km.nboffs, P, 1)) if args.half else
+                (lambda: B.conv_pair_gemm(gy, w, km.nbmaps_buf, km.nboffs, P, 1, weight_transposed=True)))
         table = km.pos_in
     else:
-        two1 = lambda: B.conv_pair_gemm(xf, w, km.nbmaps_buf, km.nboffs, P, 0)
+        two1 = ((lambda: B.conv_pair_gemm_f16(xf, w, km.nbmaps_buf, km.nboffs, P, 0, natural=True)) if args.half else
+                (lambda: B.conv_pair_gemm(xf, w, km.nbmaps_buf, km.nboffs, P, 0)))
         table = km.pos_out
     z = two1()
-    y2 = B.conv_gather_sum(z, table, n)
+    y2 = gsum(z, table, n)
     go, zp = class_gemm(feat, wt, c_out)
     go()
-    y1 = B.conv_gather_sum(zp, pos, n)
-    err = float((y1 - y2).abs().max()) / float(y2.abs().max())
+    y1 = gsum(zp, pos, n)
+    err = float((y1.float() - y2.float()).abs().max()) / float(y2.float().abs().max())
     sel = torch.randperm(n, device="cuda")[:20000]
     ref = torch.zeros((len(sel), c_out), dtype=torch.float64, device="cuda")
     for k in range(27):
@@ -83,8 +93,8 @@ for wt, name, feat, c_out in ((0, "fwd", xf, args.cout), (1, "dgrad", gy, args.c
         wk = (w[26 - k].double().t() if wt else w[k].double())
         ref[ok] += feat[src_rows[ok]].double() @ wk
     e64 = [float((y[sel].double() - ref).abs().max()) / float(ref.abs().max()) for y in (y2, y1)]
-    t_a, t_b = timed(two1), timed(lambda: B.conv_gather_sum(z, table, n))
-    t_c, t_d = timed(go), timed(lambda: B.conv_gather_sum(zp, pos, n))
+    t_a, t_b = timed(two1), timed(lambda: gsum(z, table, n))
+    t_c, t_d = timed(go), timed(lambda: gsum(zp, pos, n))
     if t_plan is None:
         t_plan = timed(lambda: B.conv_class_plan(nbr))
         print(f"plan build {t_plan:.1f} us (once per batch and stride, staging stream)")
