@@ -249,6 +249,19 @@ def test_convolution_at_bench_size_vs_float64_oracle(bench_maps, tag, ci, co):
     # run-to-run identical
     z2 = B.conv_pair_gemm(xd, wd, km["nbmaps"], km["nboffs"], total, gather_col=0)
     assert torch.equal(B.conv_gather_sum(z2, km["pos_out"], n_out), y)
+    if tag == "s1k3":
+        # the class-sorted implicit GEMM the training step takes on a map of this size (csrc/conv_class.hip): same bar against
+        # float64, every pair of the rulebook on the plan, Z' under a third of Z, results independent of the tile order
+        plan = B.conv_class_plan(km["nbr"])
+        yc = B.conv_gather_sum(B.conv_class_gemm(xd, wd, plan), plan["pos"], n_out)
+        gxc = B.conv_gather_sum(B.conv_class_gemm(gyd, wd, plan, weight_transposed=True), plan["pos"], n_in)
+        ec = (_rel(yc, want_y), _rel(gxc, want_gx))
+        z_rows = 128 * int(plan["n_tiles"])
+        print(f"   class-sorted: y {ec[0]:.2e}, grad_x {ec[1]:.2e}; Z' rows {z_rows} = {z_rows / n_out:.2f} N against {total / n_out:.2f} N pairs")
+        assert max(ec) <= 1e-5 and z_rows * 3 <= total
+        assert int((plan["src"] >= 0).sum()) == total
+        plan2 = B.conv_class_plan(km["nbr"])
+        assert torch.equal(B.conv_gather_sum(B.conv_class_gemm(xd, wd, plan2), plan2["pos"], n_out), yc)
 
 
 def test_nuscenes_config_autocast_vs_fp32_at_bench_size():
