@@ -79,7 +79,7 @@ if __name__ == "__main__":
             write.setdefault(k, w_[k])
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("pair_gemm", "gather_sum", "gather_list", "wgrad_gemm", "wgrad_s", "bn_", "conv_nbr", "kmap_",
+        if not any(s in k for s in ("pair_gemm", "class_gemm", "class_", "gather_sum", "gather_list", "wgrad_gemm", "wgrad_s", "wgrad_h", "bn_", "conv_nbr", "kmap_",
                                     "devoxelize", "voxelize", "trilinear", "table_", "hash_kernel", "devox_")):
             continue
         f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
