@@ -229,236 +229,3 @@ extern "C" int ts_debug_pair_gemm_x(const float *X, int32_t R, const float *W, i
   return wt ? launch_x<96, true>(X, R, W, O_total, nm, nboffs, K, P, gcol, sx, sw, Z, stream)
             : launch_x<96, false>(X, R, W, O_total, nm, nboffs, K, P, gcol, sx, sw, Z, stream);
 }
-
-// =====================================================================================================================
-// EXPERIMENT 2: class-sorted implicit GEMM.  The 27 offsets are cut into three groups (k / 9: the offsets of one z-plane);
-// per group the output rows that have at least one neighbour in it are sorted by their 9-bit neighbour mask and cut into
-// 128-row tiles.  A workgroup owns one tile: for every offset of the tile's union mask it gathers the 128 neighbour rows
-// (absent: zero) and multiplies them with W_k exactly like a pair-GEMM tile, but keeps the 128 x BN sums in its accumulators
-// across the offsets and stores them ONCE - Z' has one row per (output row, group) instead of one per pair (1.98 N instead of
-// 6.5 N rows on the bench rulebook), pass 2 adds three rows per output instead of 6.5.  Six-product bf16 split as in
-// conv_pairs_s.hip.  src [9][m_pad]: input row of (group offset kl, sorted row i) or -1; tile_info[t] = (group, union mask).
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pk_bf16x(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf2));
-}
-__device__ __forceinline__ void split8b(const f32x4 &v0, const f32x4 &v1, u32x4 &h, u32x4 &m, u32x4 &l) {
-  const float a[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x0 = a[2 * i], x1 = a[2 * i + 1];
-    const unsigned hh = pk_bf16x(x0, x1);
-    const float r0 = x0 - __uint_as_float(hh << 16), r1 = x1 - __uint_as_float(hh & 0xffff0000u);
-    const unsigned mm = pk_bf16x(r0, r1);
-    const float s0 = r0 - __uint_as_float(mm << 16), s1 = r1 - __uint_as_float(mm & 0xffff0000u);
-    h[i] = hh;
-    m[i] = mm;
-    l[i] = pk_bf16x(s0, s1);
-  }
-}
-#define CX_MMA(ACC, A, B)                                                               \
-  do {                                                                                  \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[2], (B)[0], ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[0], (B)[2], ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[1], (B)[1], ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[1], (B)[0], ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[0], (B)[1], ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[0], (B)[0], ACC, 0, 0, 0);        \
-  } while (0)
-
-template <int BN, int WR, bool WT>
-__global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restrict__ X, int R, const float *__restrict__ W,
-                                                           int O_total, const int *__restrict__ src, int64_t m_pad,
-                                                           const int2 *__restrict__ tile_info, int n_tiles, int K,
-                                                           float *__restrict__ Zp) {
-  constexpr int BM = PX_BM;
-  constexpr int WC = 4 / WR;
-  constexpr int MI = (BM / 16) / WR;
-  constexpr int NI = (BN / 16) / WC;
-  constexpr int BP = BN + 8;
-  constexpr int A_PLANE = BM * PX_AP;
-  constexpr int B_PLANE = WT ? BN * PX_AP : PX_BK * BP;
-  constexpr int A_IT = BM * (PX_BK / 8) / 256;
-  constexpr int B_CHUNKS = BN * (PX_BK / 8);
-  constexpr int B_IT = (B_CHUNKS + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem_x[];
-  unsigned short *Ap = smem_x;
-  unsigned short *Bp = Ap + 3 * A_PLANE;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, g = lane >> 4;
-  const int tq = r16 >> 2, tp = lane & 3;
-  const int wr = wave / WC, wc = wave % WC;
-  const int o0 = blockIdx.y * BN;
-  const int tile = (int)blockIdx.x;             // launch order = list order (longest first): every XCD gets tiles of every length
-  if (tile >= n_tiles) return;
-  const int2 info = tile_info[tile];           // x = group + 4 * (row tile of Z' / src), y = union mask; tiles come longest first
-  const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
-  int mask = __builtin_amdgcn_readfirstlane(info.y);
-  const int64_t row0 = (int64_t)(__builtin_amdgcn_readfirstlane(info.x) >> 2) * BM;
-
-  const int arow0 = tid >> 2, acol = (tid & 3) << 3;
-  int boff[B_IT], bdst[B_IT];
-#pragma unroll
-  for (int it = 0; it < B_IT; ++it) {
-    const int e = min(tid + it * 256, B_CHUNKS - 1);
-    if (WT) {
-      const int col = e >> 2, c8 = (e & 3) << 3;
-      boff[it] = col * R + c8;
-      bdst[it] = col * PX_AP + c8;
-    } else {
-      constexpr int q8 = BN >> 3;
-      const int kk = e / q8, c8 = (e - kk * q8) << 3;
-      boff[it] = kk * O_total + c8;
-      bdst[it] = kk * BP + c8;
-    }
-  }
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float *aptr[A_IT];
-  bool alive[A_IT];
-  const float *wk = W;
-  int nsrc[A_IT];                       // input rows of the NEXT offset of the mask, fetched an offset ahead
-  auto fetch = [&](int kl) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) nsrc[it] = src[(int64_t)kl * m_pad + row0 + arow0 + 64 * it];
-  };
-  auto bind = [&](int kl) {             // operand pointers of group offset kl: k = 9 grp + kl; WT (input gradient): W of the mirrored offset
-    const int k = 9 * grp + kl;
-    const int kw = WT ? (K - 1 - k) : k;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      alive[it] = nsrc[it] >= 0;
-      aptr[it] = X + (int64_t)max(nsrc[it], 0) * R + acol;
-    }
-    wk = WT ? W + ((int64_t)kw * O_total + o0) * R : W + (int64_t)kw * R * O_total + o0;
-  };
-  f32x4 ra[A_IT][2], rb[B_IT][2];
-  bool rlive[A_IT];
-  auto load_regs = [&](int c0) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      ra[it][0] = *(const f32x4 *)(aptr[it] + c0);
-      ra[it][1] = *(const f32x4 *)(aptr[it] + c0 + 4);
-      rlive[it] = alive[it];
-    }
-    const float *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      rb[it][0] = *(const f32x4 *)(wb + boff[it]);
-      rb[it][1] = *(const f32x4 *)(wb + boff[it] + 4);
-    }
-  };
-  auto store_lds = [&]() {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int rr = arow0 + 64 * it;
-      u32x4 h, m, l;
-      split8b(rlive[it] ? ra[it][0] : zero, rlive[it] ? ra[it][1] : zero, h, m, l);
-      unsigned short *dst = Ap + rr * PX_AP + acol;
-      *(u32x4 *)dst = h;
-      *(u32x4 *)(dst + A_PLANE) = m;
-      *(u32x4 *)(dst + 2 * A_PLANE) = l;
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      if (B_IT * 256 == B_CHUNKS || tid + it * 256 < B_CHUNKS) {
-        u32x4 h, m, l;
-        split8b(rb[it][0], rb[it][1], h, m, l);
-        unsigned short *dst = Bp + bdst[it];
-        *(u32x4 *)dst = h;
-        *(u32x4 *)(dst + B_PLANE) = m;
-        *(u32x4 *)(dst + 2 * B_PLANE) = l;
-      }
-    }
-  };
-  auto mma = [&]() {
-    bf8 a[MI][3];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[mi][p] = *(const bf8 *)&Ap[p * A_PLANE + ((wr * MI + mi) * 16 + r16) * PX_AP + 8 * g];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      bf8 b[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        if (WT)
-          b[p] = *(const bf8 *)&Bp[p * B_PLANE + ((wc * NI + ni) * 16 + r16) * PX_AP + 8 * g];
-        else
-          b[p] = __builtin_bit_cast(bf8, frag_tr_x(Bp + p * B_PLANE, BP, 8 * g, (wc * NI + ni) * 16, tq, tp));
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) CX_MMA(acc[mi][ni], a[mi], b);
-    }
-  };
-
-  if (mask) {
-    fetch(__builtin_ctz(mask));
-    bind(__builtin_ctz(mask));
-    mask &= mask - 1;
-    load_regs(0);
-    bool first = true;
-    while (true) {
-      if (mask) fetch(__builtin_ctz(mask));  // rows of the next offset: needed only when this offset's last slice is staged
-      for (int c0 = 0; c0 < R; c0 += PX_BK) {
-        if (!first) __syncthreads();
-        first = false;
-        store_lds();
-        __syncthreads();
-        if (c0 + PX_BK < R) {
-          load_regs(c0 + PX_BK);
-        } else if (mask) {
-          bind(__builtin_ctz(mask));         // first slice of the next offset, in flight behind this slice's MFMAs
-          load_regs(0);
-        }
-        mma();
-      }
-      if (!mask) break;
-      mask &= mask - 1;
-    }
-  }
-  float *zt = Zp + row0 * O_total + o0;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        zt[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * O_total + (wc * NI + ni) * 16 + r16] = acc[mi][ni][q];
-}
-
-template <int BN, bool WT>
-static int launch_class(const float *X, int R, const float *W, int O_total, const int *src, int64_t m_pad, const int2 *tile_info,
-                        int n_tiles, int K, float *Zp, hipStream_t stream) {
-  const size_t lds = (size_t)3 * (PX_BM * PX_AP + (WT ? BN * PX_AP : PX_BK * (BN + 8))) * 2;
-  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)(O_total / BN));
-  class_gemm_kernel<BN, 2, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, src, m_pad, tile_info, n_tiles, K, Zp);
-  TS_CHECK_LAUNCH("ts_debug_class_gemm");
-  return TS_OK;
-}
-
-extern "C" int ts_debug_class_gemm(const float *X, int32_t R, const float *W, int32_t O_total, const int32_t *src, int64_t m_pad,
-                                   const int32_t *tile_info, int32_t n_tiles, int32_t K, int32_t wt, float *Zp,
-                                   ts_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(X && W && src && tile_info && Zp && n_tiles > 0 && m_pad == (int64_t)n_tiles * PX_BM && R % 32 == 0 && K == 27,
-             TS_ERR_INVALID_ARGUMENT, "ts_debug_class_gemm: bad arguments");
-  TS_REQUIRE(O_total % 96 == 0 || O_total % 128 == 0, TS_ERR_UNSUPPORTED, "ts_debug_class_gemm: 96- or 128-column tiles only");
-  const int2 *ti = (const int2 *)tile_info;
-  if (O_total % 128 == 0)
-    return wt ? launch_class<128, true>(X, R, W, O_total, src, m_pad, ti, n_tiles, K, Zp, stream)
-              : launch_class<128, false>(X, R, W, O_total, src, m_pad, ti, n_tiles, K, Zp, stream);
-  return wt ? launch_class<96, true>(X, R, W, O_total, src, m_pad, ti, n_tiles, K, Zp, stream)
-            : launch_class<96, false>(X, R, W, O_total, src, m_pad, ti, n_tiles, K, Zp, stream);
-}
