@@ -15,8 +15,13 @@ ap.add_argument("--cin", type=int, default=96)
 ap.add_argument("--cout", type=int, default=96)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--half", action="store_true", help="IEEE-half rows (the autocast path)")
+ap.add_argument("--ms", action="store_true", help="lexicographic stride-1 order (the multi-scan models' voxel order) instead of hash order")
 args = ap.parse_args()
 coords, feats, labels, _ = bench.make_scans(0, 2, 120000, "minkunet")
+if args.ms:
+    import numpy as np
+    c = coords.cpu().numpy()
+    coords = torch.from_numpy(c[np.lexsort((c[:, 2], c[:, 1], c[:, 0], c[:, 3]))]).cuda()
 x = SparseTensor(None, coords, 1)
 spF.build_pyramid(x, 4)
 s = args.stride
