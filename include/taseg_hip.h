@@ -572,7 +572,9 @@ int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_
  * rulebook ts_build_kmap gave; another summation order than ts_conv_pair_gemm + ts_conv_gather_sum (1e-6-close, deterministic).
  *   ts_conv_class_rows(n)   m_pad = 3 * roundup(n, 128): rows of src / Z'
  *   ts_conv_class_plan      nbr [27][n] (in == out) -> src [9][m_pad] (input row of (group offset, sorted row) or -1),
- *                           tile_info [m_pad / 128][2], n_tiles [1] (device), pos [3][n] (row of Z' per (group, output) or -1)
+ *                           tile_info [m_pad / 128][2], n_tiles [2] (device: live tiles, and their (tile, offset) steps - 128 *
+ *                           steps row-products against the rulebook's P pairs says what the plan costs: mask-sorted LiDAR rows
+ *                           give ~1.1 P, rows with unrelated masks up to 3.7 P), pos [3][n] (row of Z' per (group, output) or -1)
  *   ts_conv_class_gemm      zp [m_pad, c_out]; wt = 0 forward (kernel [27, c_red, c_out]), wt = 1 input gradient (feat = output
  *                           gradients, kernel [27, c_out, c_red] as stored: the mirrored offset's slice, transposed)
  *   ts_conv_class_hint      one-shot, per thread: the NEXT ts_conv_block_forward / _backward of this thread may run its forward

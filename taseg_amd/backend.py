@@ -881,7 +881,8 @@ def sparse_quantize(coords):
 
 def conv_class_plan(nbr):
     """Plan of the class-sorted implicit GEMM (csrc/conv_class.hip) for a submanifold 3x3x3 map: nbr [27, n] (build_kmap with
-    in == out) -> dict(src [9, m_pad], tile_info [m_pad / 128, 2], n_tiles [1] (device), pos [3, n], m_pad, n).  No host sync."""
+    in == out) -> dict(src [9, m_pad], tile_info [m_pad / 128, 2], n_tiles [2] (device: live tiles, (tile, offset) steps),
+    pos [3, n], m_pad, n).  No host sync."""
     L.require_device(nbr)
     nbr = _i32(nbr, "nbr")
     k, n = nbr.shape
@@ -890,7 +891,7 @@ def conv_class_plan(nbr):
     dev = nbr.device
     src = torch.empty((9, m_pad), dtype=torch.int32, device=dev)
     tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
-    n_tiles = torch.empty(1, dtype=torch.int32, device=dev)
+    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)          # (live tiles, (tile, offset) steps)
     pos = torch.empty((3, n), dtype=torch.int32, device=dev)
     ws = L.workspace(lib.ts_conv_class_plan_workspace_bytes(n), dev)
     L.check(lib.ts_conv_class_plan(L.ptr(nbr), n, k, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles), L.ptr(pos), L.ptr(ws),

@@ -103,12 +103,14 @@ __global__ __launch_bounds__(1024) void class_tiles_kernel(const int *__restrict
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int run = 0;
+    int run = 0, steps = 0;
     for (int c = CG_GK; c >= 1; --c) {
       base[c] = run;
       run += cnt[c];
+      steps += c * cnt[c];
     }
-    *n_tiles = run;
+    n_tiles[0] = run;
+    n_tiles[1] = steps;        // (tile, offset) steps of the plan: 128 * steps row-products against the rulebook's pairs
   }
   __syncthreads();
   const int tiles_per_group = (int)(npad / CG_BM);
@@ -132,7 +134,7 @@ extern "C" size_t ts_conv_class_plan_workspace_bytes(int64_t n) {
 }
 
 // nbr [27][n] (ts_build_kmap of a submanifold 3x3x3 map: in == out) -> src [9][m_pad], tile_info [m_pad / 128] (x, y) pairs,
-// n_tiles [1], pos [3][n];  m_pad = ts_conv_class_rows(n)
+// n_tiles [2] = (live tiles, their (tile, offset) steps), pos [3][n];  m_pad = ts_conv_class_rows(n)
 extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t *src, int32_t *tile_info, int32_t *n_tiles,
                                   int32_t *pos, void *ws, size_t ws_bytes, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -236,13 +236,17 @@ class KernelMap:
         gain (class_gemm_pays) go without."""
         if (_CLASS_GEMM and self.cls is None and self.nbr.shape[0] == 27 and self.sizes[0] == self.sizes[1]
                 and self.sizes[0] >= _CLASS_MIN_ROWS):
-            self.cls = B.conv_class_plan(self.nbr)
-            self.cls["z_rows"] = 0            # host copy of 128 * n_tiles: class_rows() reads it once, when a profile asks
+            cls = B.conv_class_plan(self.nbr)
+            # one host read (the map's builder has just read the pair total the same way): is the plan worth walking?  Rows with
+            # LiDAR-like neighbour masks sort into near-uniform tiles (128 * steps ~ 1.1 P); rows with unrelated masks would make
+            # every tile walk all nine offsets of its group with most rows absent (up to 3.7 P row-products): two passes then
+            tiles, steps = cls["n_tiles"].tolist()
+            cls["z_rows"], cls["steps"] = 128 * tiles, steps
+            if 128 * steps <= _CLASS_MAX_WORK * self.total:
+                self.cls = cls
         return self.cls
 
     def class_rows(self) -> int:
-        if self.cls is not None and not self.cls["z_rows"]:
-            self.cls["z_rows"] = 128 * int(self.cls["n_tiles"].item())
         return 0 if self.cls is None else self.cls["z_rows"]
 
     @property
@@ -279,6 +283,7 @@ class KernelMap:
 # 1.1x on 30k voxels x 64 channels, a loss on 30k x 128 and below.  TASEG_CLASS_GEMM=0 keeps every block on the two passes.
 _CLASS_GEMM = os.environ.get("TASEG_CLASS_GEMM", "1") != "0"
 _CLASS_MIN_ROWS = 16384
+_CLASS_MAX_WORK = 1.6        # a class plan is used while its row-products stay under 1.6x the rulebook's pairs
 _CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
 
 

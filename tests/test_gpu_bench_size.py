@@ -256,7 +256,7 @@ def test_convolution_at_bench_size_vs_float64_oracle(bench_maps, tag, ci, co):
         yc = B.conv_gather_sum(B.conv_class_gemm(xd, wd, plan), plan["pos"], n_out)
         gxc = B.conv_gather_sum(B.conv_class_gemm(gyd, wd, plan, weight_transposed=True), plan["pos"], n_in)
         ec = (_rel(yc, want_y), _rel(gxc, want_gx))
-        z_rows = 128 * int(plan["n_tiles"])
+        z_rows = 128 * int(plan["n_tiles"][0])
         print(f"   class-sorted: y {ec[0]:.2e}, grad_x {ec[1]:.2e}; Z' rows {z_rows} = {z_rows / n_out:.2f} N against {total / n_out:.2f} N pairs")
         assert max(ec) <= 1e-5 and z_rows * 3 <= total
         assert int((plan["src"] >= 0).sum()) == total

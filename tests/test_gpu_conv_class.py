@@ -47,7 +47,7 @@ def test_class_plan_lists_every_pair_once(n, extent):
     used = np.zeros(m_pad, bool)
     used[pos[pos >= 0]] = True
     assert np.all(src[:, ~used] == -1)
-    nt = int(plan["n_tiles"].item())
+    nt = int(plan["n_tiles"][0])
     info = plan["tile_info"].cpu().numpy()[:nt]
     tiles = info[:, 0] >> 2
     assert len(np.unique(tiles)) == nt
@@ -57,6 +57,7 @@ def test_class_plan_lists_every_pair_once(n, extent):
     assert np.array_equal(info[:, 1], masks[tiles]) and np.array_equal(info[:, 0] & 3, tiles // (m_pad // 3 // 128))
     pop = np.array([bin(int(v)).count("1") for v in info[:, 1]])
     assert np.all(pop[:-1] >= pop[1:])                                           # longest first
+    assert int(plan["n_tiles"][1]) == int(pop.sum())                             # the plan's (tile, offset) steps
 
 
 @pytest.mark.parametrize("ci,co", [(32, 32), (32, 64), (64, 64), (96, 96), (128, 96), (96, 128), (256, 128)])
@@ -123,3 +124,33 @@ def test_class_gemm_half_storage(ci, co):
     for got, two, ref in ((y, y2, y32), (g, g2, g32)):
         assert err(got, ref) <= 2e-3                                   # a few half ulps of the tensor's scale
         assert err(got, ref) <= 1.5 * err(two, ref) + 2e-4       # same error budget: 3 roundings of group sums vs 6.5 of pair products
+
+
+def test_class_plan_is_kept_only_while_its_work_stays_near_the_pairs(monkeypatch):
+    """KernelMap.build_class_plan reads the plan's (tile, offset) steps and keeps the plan only while 128 * steps stays under
+    _CLASS_MAX_WORK x the rulebook's pairs.  Sorting by mask makes that easy to meet - a LiDAR-like surface gives 1.03, even 35 %
+    of a dense box chosen at random 1.46 - so the guard is exercised here with a tighter bound: the surface map keeps its plan,
+    the random one goes back to the two passes."""
+    from taseg_amd import backend as B
+    from taseg_amd.torchsparse.nn import functional as F
+    rs = np.random.RandomState(0)
+    u, v = np.meshgrid(np.arange(150), np.arange(150), indexing="ij")
+    plane = np.stack([u.ravel(), v.ravel(), (u.ravel() // 7) % 3], 1)
+    wall = np.stack([u.ravel(), np.full(u.size, 60), v.ravel() % 40], 1)
+    surf = np.unique(np.concatenate([plane, wall]), axis=0)
+    surf = np.concatenate([surf, np.zeros((len(surf), 1), np.int64)], 1).astype(np.int32)
+    box = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(40), indexing="ij"), -1).reshape(-1, 3)
+    noise = box[rs.rand(len(box)) < 0.35]
+    noise = np.concatenate([noise, np.zeros((len(noise), 1), np.int64)], 1).astype(np.int32)
+    monkeypatch.setattr(F, "_CLASS_MAX_WORK", 1.2)
+    got = {}
+    for name, c in (("surface", surf), ("noise", noise)):
+        assert len(c) >= 16384
+        km = F.build_kernel_map(_T(c), _T(c), 3, 1)
+        plan = km.build_class_plan()
+        tiles, steps = B.conv_class_plan(km.nbr)["n_tiles"].tolist()
+        got[name] = (plan is not None, 128 * steps / km.total)
+        if plan is not None:
+            assert plan["z_rows"] == 128 * tiles and km.class_rows() == 128 * tiles
+    assert got["surface"][0] and got["surface"][1] < 1.2, got
+    assert not got["noise"][0] and 1.2 < got["noise"][1] < 1.6, got

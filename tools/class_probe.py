@@ -38,7 +38,7 @@ flops = 2.0 * P * args.cin * args.cout
 plan = B.conv_class_plan(nbr)
 torch.cuda.synchronize()
 pos, m_pad = plan["pos"], plan["m_pad"]
-n_tiles = int(plan["n_tiles"].item())
+n_tiles = int(plan["n_tiles"][0])
 info = plan["tile_info"][:n_tiles]
 steps = int(sum(bin(int(v)).count("1") for v in info[:, 1].tolist()))
 print(f"stride {s}: {n} voxels, {P} pairs, {args.cin} -> {args.cout}; Z' rows {n_tiles * 128} ({n_tiles * 128 / n:.2f} N), {n_tiles} tiles, "
