@@ -650,7 +650,10 @@ def conv_geometry(input: SparseTensor, kernel_size, stride, dilation, transposed
             out_coords = spdownsample(input.coords, stride, kernel_size, input.stride)
         key = (input.stride, kernel_size, stride, dilation)
         if key not in input.kmaps:
-            input.kmaps[key] = build_kernel_map(input.coords, out_coords, kernel_size, input.stride, dilation)
+            km = build_kernel_map(input.coords, out_coords, kernel_size, input.stride, dilation)
+            if stride == ones and tuple(kernel_size) == (3, 3, 3):
+                km.build_class_plan()     # a map made on demand (UNet3D of the TIAF models, user code): large ones get their class plan
+            input.kmaps[key] = km
         return input.kmaps[key], out_coords, out_stride
     out_stride = tuple(input.stride[k] // stride[k] for k in range(3))
     return input.kmaps[(out_stride, kernel_size, stride, dilation)], input.cmaps[out_stride], out_stride
