@@ -365,26 +365,36 @@ class _SparseConv(Function):
         want_half = _amp_half(feats)
         half = want_half and _half_ok(weight.shape[1], weight.shape[2])
         gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
+        # large submanifold 3x3x3 maps: class-sorted implicit GEMM (csrc/conv_class.hip) in place of pair GEMM + 27-way pass 2
+        cls = kmap.cls if (not transposed and kmap.cls is not None and _dense_ok(weight.shape[1], weight.shape[2]) and
+                           class_gemm_pays(kmap.cls["n"], weight.shape[1], weight.shape[2], half)) else None
         with _no_autocast():
             if half:
                 fh = feats.contiguous().half()
                 w16, _ = B.cast_weights_f16(weight.detach().float(), want=(True, False))
-                z = B.conv_pair_gemm_f16(fh, w16, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol, natural=True)
-                out = B.conv_gather_sum_f16(z, table, rows)
+                if cls is not None:
+                    out = B.conv_gather_sum_f16(B.conv_class_gemm_f16(fh, w16, cls), cls["pos"], rows)
+                else:
+                    z = B.conv_pair_gemm_f16(fh, w16, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol, natural=True)
+                    out = B.conv_gather_sum_f16(z, table, rows)
                 ctx.save_for_backward(fh, w16)
             else:
                 # pass 1: z[p] = feats[source row of pair p] @ W[k(p)];  pass 2: out[row] = sum_k z[pos[k, row]]
                 f32, w32 = feats.contiguous().float(), weight.contiguous().float()
                 if w32.data_ptr() != weight.data_ptr():
                     planes = None             # a converted copy: the planes belong to the parameter's own storage
-                _planes.hint(w32, planes)
-                z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
-                out = B.conv_gather_sum(z, table, rows)
+                if cls is not None:
+                    out = B.conv_gather_sum(B.conv_class_gemm(f32, w32, cls), cls["pos"], rows)
+                else:
+                    _planes.hint(w32, planes)
+                    z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
+                    out = B.conv_gather_sum(z, table, rows)
                 ctx.save_for_backward(f32, w32)
                 if want_half:
                     out = out.half()          # stem (C_in = 4 / 5): fp32 kernels, half result like the reference
         ctx.kmap, ctx.transposed, ctx.half, ctx.in_dtype = kmap, transposed, half, feats.dtype
         ctx.planes = None if half else planes
+        ctx.cls = cls
         return out
 
     @staticmethod
@@ -399,7 +409,10 @@ class _SparseConv(Function):
         with _no_autocast():
             if ctx.half:
                 gh = grad_out.contiguous().half()
-                if ctx.needs_input_grad[0]:
+                if ctx.needs_input_grad[0] and ctx.cls is not None:
+                    z = B.conv_class_gemm_f16(gh, weight, ctx.cls, weight_transposed=True)
+                    grad_feats = B.conv_gather_sum_f16(z, ctx.cls["pos"], rows).to(ctx.in_dtype)
+                elif ctx.needs_input_grad[0]:
                     # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T: rows of W_k (= w16) are the output columns
                     z = B.conv_pair_gemm_f16(gh, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
                     grad_feats = B.conv_gather_sum_f16(z, table, rows).to(ctx.in_dtype)
@@ -408,7 +421,10 @@ class _SparseConv(Function):
                                                    col_a=1 if transposed else 0, max_pairs=kmap.total)
             else:
                 g32 = grad_out.contiguous().float()
-                if ctx.needs_input_grad[0]:
+                if ctx.needs_input_grad[0] and ctx.cls is not None:
+                    z = B.conv_class_gemm(g32, weight, ctx.cls, weight_transposed=True)
+                    grad_feats = B.conv_gather_sum(z, ctx.cls["pos"], rows).to(ctx.in_dtype)
+                elif ctx.needs_input_grad[0]:
                     _planes.hint(weight, ctx.planes)
                     z = B.conv_pair_gemm(g32, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol,
                                          weight_transposed=True)
