@@ -472,7 +472,7 @@ def build_roofline(prof, amp, bracket_us):
     return roof
 
 
-def secondary_runs(steps=10, warmup=3):
+def secondary_runs(steps=30, warmup=8):
     """Short runs of the other BASELINE configurations (4-scan TFA, AMP, nuScenes shape + AMP) as CHILD processes after
     the headline measurement, so that the driver's default invocation observes them too.  Each entry is the child's
     own JSON line cut down to value / ms_per_step / dtype / config."""
