@@ -283,6 +283,7 @@ class KernelMap:
 # 1.1x on 30k voxels x 64 channels, a loss on 30k x 128 and below.  TASEG_CLASS_GEMM=0 keeps every block on the two passes.
 _CLASS_GEMM = os.environ.get("TASEG_CLASS_GEMM", "1") != "0"
 _CLASS_MIN_ROWS = 16384
+_CLASS_MIN_ROWS_128 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_128", "60000"))
 _CLASS_MAX_WORK = 1.6        # a class plan is used while its row-products stay under 1.6x the rulebook's pairs
 _CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
 
@@ -293,7 +294,7 @@ def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> b
     if max(c_in, c_out) <= 64:
         return n_rows >= _CLASS_MIN_ROWS
     cols128 = any(c % 128 == 0 and c % 96 != 0 for c in (c_in, c_out))       # a direction on 128-column tiles (direct-rows pair GEMM)
-    return n_rows >= (100000 if cols128 else 48000)
+    return n_rows >= (_CLASS_MIN_ROWS_128 if cols128 else 48000)
 
 
 def class_hint(kmap, c_in: int, c_out: int, profiling: bool = False, half: bool = False) -> bool:
