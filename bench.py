@@ -332,8 +332,10 @@ def summarise_profile(records, steps):
         es = m.get("esize", 4)       # bytes per stored feature element (2 on the half-storage path)
         if kind == "pair_gemm":      # gather read + Z write + rulebook + weights  (first half of the 8(d) figure)
             byts = p * (m["c_red"] * es + m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * es
-        elif kind == "class_gemm":   # gather read + Z' write (<= 3 rows per output) + the plan's neighbour table + weights
-            byts = p * m["c_red"] * es + m["z_rows"] * (m["c_out"] * es + 36) + m["k"] * m["c_red"] * m["c_out"] * es
+        elif kind == "class_gemm":   # gather read + Z' write (<= 3 rows per output; direct plans: the result rows) + the plan's
+            # neighbour table + weights
+            byts = (p * m["c_red"] * es + m["z_rows"] * (m["c_out"] * es + 36) + m.get("out_rows", 0) * (m["c_out"] * es + 4 * 8)
+                    + m["k"] * m["c_red"] * m["c_out"] * es)
         elif kind == "gather_sum":   # Z read + output write + position table       (second half)
             flops = float(p * m["c_out"])
             byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4 + m.get("side_bytes", 0.0)
@@ -590,16 +592,14 @@ def main():
         # flat-bucket SGD (taseg_amd.optim): gradients land in flat buckets during backward (all-reduced over ranks on
         # their own communicator when N > 1), unscale + clip + SGD + loss-scale update in 3 launch kinds, no host read
         from taseg_amd.optim import FlatSGD
-        from taseg_amd.rccl import single_communicator
-        # one communicator for everything (default, the reference's arrangement) or a dedicated one for the buckets
-        # beside SyncBatchNorm's library-owned communicator (TASEG_DIST_SINGLE_COMM=0; taseg_amd/rccl.py)
-        group = dist.new_group(backend=backend) if (use_dist and not single_communicator()) else None
+        # the buckets always get a communicator of their own (launched in bucket-index order on every rank); SyncBatchNorm's
+        # statistics go through the default group (TASEG_DIST_SINGLE_COMM=1, default) or the library-owned communicator
+        group = dist.new_group(backend=backend) if use_dist else None
         opt = FlatSGD(model, lr=lr, momentum=mom, weight_decay=wd, max_norm=10.0, amp=args.amp, process_group=group)
     else:
         if use_dist and not args.torch_ddp:
             from taseg_amd.parallel import GradBucketReducer
-            from taseg_amd.rccl import single_communicator
-            reducer = GradBucketReducer(model, process_group=None if single_communicator() else dist.new_group(backend=backend))
+            reducer = GradBucketReducer(model, process_group=dist.new_group(backend=backend))
         elif use_dist:
             # buffers (BN running statistics) are identical on every rank by construction (SyncBatchNorm): no broadcast
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,

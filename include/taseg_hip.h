@@ -466,9 +466,39 @@ int ts_bn_sync_backward(void *comm, const void *grad_out, const uint8_t *mask, c
  * SyncBatchNorm with the all-reduce run by the CALLER (torch.distributed on its own communicator): comm = (void *)1 makes
  * the call stop after the local sums (forward: convolution + `pack`; backward: `sums`), the caller all-reduces that buffer
  * over its ranks and calls again with the same arguments and comm = (void *)2, which runs what is left (forward: statistics +
- * elementwise pass; backward: elementwise pass + weight gradient + input gradient).  One-shot hints go with the second call
- * of a backward pair and with the FIRST of a forward pair (the convolution runs there).  ts_bn_sync_forward / _backward take the
- * same two values. */
+ * elementwise pass; backward: elementwise pass + weight gradient + input gradient).  ts_bn_sync_forward / _backward take the
+ * same two values.
+ *
+ * `opts` (may be NULL) names everything a block call may use beyond the rulebook - explicitly, per call (round 4: it replaces
+ * the thread-local one-shot hints ts_conv_class_hint / ts_conv_block_addend_hint and, for the block calls, ts_conv_planes_hint;
+ * nothing a call leaves behind can steer another call):
+ *   fwd_plan / dgrad_plan  class-sorted plans of THIS block's kernel map (ts_conv_class_plan) for the forward product and the
+ *                          input gradient, or NULL for pair GEMM + pass 2.  A plan is used only if it fits the call: K, its row
+ *                          count = the rows the product writes, channel counts the class kernels take, and map_id == the
+ *                          call's nboffs pointer (the identity of the kernel map it was built from) - otherwise the two passes.
+ *                          Plans with `rows` (direct, one group: the 2x2x2 strided / transposed maps) store the result rows
+ *                          themselves: no Z, no pass 2.  Submanifold 3x3x3 maps use ONE plan for both directions (mirror = 1:
+ *                          the input gradient takes the slice of offset K-1-k).
+ *   planes                 fp32: the pre-split bf16 planes of `kernel` (ts_conv_split_planes), kept in step by the caller
+ *   w16_current            half: the w16 buffer already holds the cast of `kernel` (the call casts nothing)
+ *   addend                 backward only: [n_dgrad_rows, c_in] in grad_feat's storage type, 16-byte aligned, added in the
+ *                          grad_feat store (the gradient reaching the block's input along a residual connection,
+ *                          minkunet.py:117-129) - one rounding like a separate sum of the two */
+typedef struct TsClassPlan {
+  const int32_t *src, *tile_info, *n_tiles;
+  const int32_t *pos;      /* [groups][n]: pass-2 plans */
+  const int32_t *rows;     /* [m_pad]: direct plans (groups == 1) */
+  int64_t n, m_pad;
+  int64_t z_rows;          /* host copy of 128 * listed tiles (profile records only), or 0 */
+  int32_t K, groups, mirror;
+  const void *map_id;      /* nboffs pointer of the kernel map the plan was built from */
+} TsClassPlan;
+typedef struct TsConvBlockOpts {
+  const TsClassPlan *fwd_plan, *dgrad_plan;
+  const void *planes;
+  int32_t w16_current;
+  const void *addend;
+} TsConvBlockOpts;
 size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
                                      int32_t half);
 int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
@@ -476,15 +506,15 @@ int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, c
                           const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight,
                           const float *bn_bias, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                           float eps, float momentum, int32_t relu, int32_t half, void *comm, double *pack, void *conv_out,
-                          float *mean, float *invstd, void *out, uint8_t *mask, void *w16, void *ws, size_t ws_bytes,
-                          ts_stream_t stream);
+                          float *mean, float *invstd, void *out, uint8_t *mask, void *w16, const TsConvBlockOpts *opts,
+                          void *ws, size_t ws_bytes, ts_stream_t stream);
 int ts_conv_block_backward(const void *grad_out, const uint8_t *mask, const void *conv_out, const float *mean,
                            const float *invstd, const float *bn_weight, const double *total_dev, void *comm, double *sums,
                            int64_t n_out, int32_t c_out, int32_t half, const void *feat, int64_t n_feat_rows, int32_t c_in,
                            const void *weights, int32_t K, const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs,
                            int32_t dgrad_gather_col, const int32_t *pos_dgrad, int64_t n_dgrad_rows, int32_t wgrad_col_a,
                            void *grad_feat, void *grad_residual, float *grad_kernel, float *grad_bn_weight,
-                           float *grad_bn_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
+                           float *grad_bn_bias, const TsConvBlockOpts *opts, void *ws, size_t ws_bytes, ts_stream_t stream);
 
 /* Per-launch timing inside ts_conv_block_*: while enabled, every pair-GEMM / gather-sum / weight-gradient launch of the
  * block calls is bracketed by HIP events on the caller's stream.  ts_prof_collect waits for them and writes one record
@@ -541,16 +571,16 @@ int ts_ce_lovasz_backward(const float *probas, const int64_t *labels, int64_t ig
                           float w_ce, float w_lov, float *grad_logits, ts_stream_t stream);
 
 /* Pre-split weight planes for the fp32 pair GEMMs (csrc/conv_pairs_s.hip) - an optional accelerator of
- * ts_conv_pair_gemm / ts_conv_block_forward / ts_conv_block_backward, no counterpart in the reference (its
+ * ts_conv_pair_gemm (one-shot hint below) and ts_conv_block_forward / _backward (TsConvBlockOpts.planes), no counterpart in the reference (its
  * convolution_forward_cuda, backend/convolution/convolution_cuda.cu:101-164, multiplies fp32 operands in cuBLAS).
  * The fp32 kernels evaluate a product on the bf16 matrix pipe through the exact split x = h + m + l of both operands;
  * for a weight that split is the same in every workgroup of every launch until the optimizer changes the weight.
  *   planes: 3 * K * c_in * c_out bf16 (16-byte aligned): h | m | l, each in the layout of W [K, c_in, c_out] (the forward
  *           product and the input gradient read the same planes); c_in * c_out % 8 == 0.
  *   ts_conv_split_planes[_batch]  write them (one launch per 16 weights): call after every update of the weight.
- *   ts_conv_planes_hint           one-shot and per thread: the NEXT of the three calls above made by this thread may read
+ *   ts_conv_planes_hint           one-shot and per thread: the NEXT ts_conv_pair_gemm made by this thread may read
  *           `planes` in place of `w` if its weight pointer is `w` and its shapes are (K, c_in, c_out); that call clears
- *           the hint whether it used it or not.  Results are bit-identical with and without planes; keeping them in
+ *           the hint whether it used it or not (the block calls take their planes as an argument and clear any hint).  Results are bit-identical with and without planes; keeping them in
  *           step with the weight is the caller's contract (taseg_amd/planes.py does it for the modules). */
 typedef struct TsPlaneJob {
   const float *w;
@@ -561,61 +591,49 @@ int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out,
 int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out);
 /* The half-storage counterpart: job.planes = w16 [K, c_in, c_out] IEEE half (what ts_cast_weights_f16 writes), 16 weights
- * per launch.  A ts_conv_block_forward(half = 1) call whose hint names (kernel, its own w16 argument) takes w16 as
- * already cast and launches no cast of its own (torch.autocast casts the weight in every call: conv.py:19). */
+ * per launch.  A ts_conv_block_forward(half = 1) call with opts->w16_current takes its w16 argument as already cast and
+ * launches no cast of its own (torch.autocast casts the weight in every call: conv.py:19). */
 int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 
-/* Class-sorted implicit GEMM (csrc/conv_class.hip) - pass 1 of a submanifold 3x3x3 convolution with the sums of up to nine
- * offsets kept in the accumulators: Z' has one row per (output row, z-plane of offsets) instead of one per rulebook pair
- * (about 2 N instead of 6.5 N rows on a LiDAR scan), pass 2 is ts_conv_gather_sum with K = 3 and the plan's position table.
+/* Class-sorted implicit GEMM (csrc/conv_class.hip) - pass 1 of a convolution with the sums of up to nine offsets kept in the
+ * accumulators.  The K offsets are cut into `groups` groups of K / groups <= 9; per group the destination rows are sorted by
+ * their neighbour mask and cut into 128-row tiles; a workgroup owns a tile and walks the offsets of the tile's union mask.
  * Same product as convolution_forward_cuda / convolution_backward_cuda (backend/convolution/convolution_cuda.cu:101-278) on the
  * rulebook ts_build_kmap gave; another summation order than ts_conv_pair_gemm + ts_conv_gather_sum (1e-6-close, deterministic).
- *   ts_conv_class_rows(n)   m_pad = 3 * roundup(n, 128): rows of src / Z'
- *   ts_conv_class_plan      nbr [27][n] (in == out) -> src [9][m_pad] (input row of (group offset, sorted row) or -1),
- *                           tile_info [m_pad / 128][2], n_tiles [2] (device: live tiles, and their (tile, offset) steps - 128 *
- *                           steps row-products against the rulebook's P pairs says what the plan costs: mask-sorted LiDAR rows
- *                           give ~1.1 P, rows with unrelated masks up to 3.7 P), pos [3][n] (row of Z' per (group, output) or -1)
- *   ts_conv_class_gemm      zp [m_pad, c_out]; wt = 0 forward (kernel [27, c_red, c_out]), wt = 1 input gradient (feat = output
- *                           gradients, kernel [27, c_out, c_red] as stored: the mirrored offset's slice, transposed)
- *   ts_conv_class_hint      one-shot, per thread: the NEXT ts_conv_block_forward / _backward of this thread may run its forward
- *                           product / input gradient on this plan (fp32, K = 27, n rows in and out; it clears the hint);
- *                           z_rows = the caller's host copy of 128 * n_tiles (profile records only), or 0 */
+ *   submanifold 3x3x3 maps: groups = 3 (one z-plane of the kernel each): Z' has one row per (output row, z-plane) instead of one
+ *     per rulebook pair (about 2 N instead of 6.5 N rows on a LiDAR scan), pass 2 is ts_conv_gather_sum with K = 3 and the
+ *     plan's position table `pos`.  The map is its own transpose with the offsets reversed, so the SAME plan serves the input
+ *     gradient (wt = 1, mirror = 1: slice K-1-k, transposed).
+ *   2x2x2 strided maps (and their transposed use, convolution_cuda.cu:21,34): groups = 1, a DIRECT plan (`rows` instead of `pos`):
+ *     all offsets of a destination row sit in one tile, the sums ARE the result and are stored straight into the destination
+ *     rows - no Z, no pass 2.  Two plans per map: destination = coarse rows (nbr = the map's own table: strided forward,
+ *     transposed input gradient) and destination = fine rows (nbr = ts_conv_nbr_transposed: transposed forward, strided input
+ *     gradient; every fine row has exactly one pair); mirror = 0.  Rows without any neighbour are written as zeros.
+ *   ts_conv_class_rows2(n, groups)  m_pad = groups * roundup(n, 128): slots of src / rows of Z' (ts_conv_class_rows: groups = 3)
+ *   ts_conv_class_plan      nbr [K][n] -> src [K / groups][m_pad] (input row of (group offset, slot) or -1), tile_info
+ *                           [m_pad / 128][2], n_tiles [2] (device: listed tiles, and their (tile, offset) steps - 128 * steps
+ *                           row-products against the rulebook's P pairs says what the plan costs: mask-sorted LiDAR rows give
+ *                           ~1.1 P, rows with unrelated masks up to 3.7 P), and exactly one of pos [groups][n] (row of Z' per
+ *                           (group, destination) or -1) and rows [m_pad] (destination row per slot or -1; groups == 1)
+ *   ts_conv_nbr_transposed  nbr_t [K][n_in] of a kernel map from its pos_in table and rulebook
+ *   ts_conv_class_gemm      wt = 0: feat = input rows, kernel [K, c_red, c_out]; wt = 1: the transposed product (feat = output
+ *                           gradients [*, c_red], kernel [K, c_out, c_red] as stored; mirror selects the slice K-1-k);
+ *                           rows == NULL: zp [m_pad, c_out]; rows != NULL: zp [n, c_out] = the result */
 int64_t ts_conv_class_rows(int64_t n);
+int64_t ts_conv_class_rows2(int64_t n, int32_t groups);
 size_t ts_conv_class_plan_workspace_bytes(int64_t n);
-int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t *src, int32_t *tile_info, int32_t *n_tiles,
-                       int32_t *pos, void *ws, size_t ws_bytes, ts_stream_t stream);
-int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
-int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t c_out, const int32_t *src,
-                       int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt, float *zp,
-                       ts_stream_t stream);
-/* half storage (torch.autocast): feat / zp IEEE half, w = the half weight [27, C_in, C_out] as stored */
-int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t c_out, const int32_t *src,
-                           int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt, void *zp,
+int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t groups, int32_t *src, int32_t *tile_info,
+                       int32_t *n_tiles, int32_t *pos, int32_t *rows, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_conv_nbr_transposed(const int32_t *pos_in, const int32_t *nbmaps, int32_t K, int64_t n_in, int32_t *nbr_t,
                            ts_stream_t stream);
-void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos, int64_t n,
-                        int64_t z_rows);
-
-/* One-shot and per thread, like ts_conv_planes_hint: the NEXT ts_conv_block_backward of this thread adds `addend`
- * ([n_dgrad_rows, c_in] in the storage type of grad_feat, 16-byte aligned) into its grad_feat store,
- * grad_feat = (input gradient of the convolution) + addend, one rounding like a separate sum of the two.  For blocks whose
- * input also feeds a shortcut (minkunet.py:117-129 ResidualBlock): the autograd node hands its input through as a second
- * output, receives the shortcut's gradient with its own and lets it land here instead of in an add launch. */
-void ts_conv_block_addend_hint(const void *addend);
-
-/* Output-stationary (Z-free) form of a submanifold odd-kernel convolution pass for the wide shallow layers (csrc/conv_os.hip):
- * one launch instead of ts_conv_pair_gemm + ts_conv_gather_sum, no per-pair product matrix in HBM.
- *   out[j, :] = sum_k feat[nbr[wt ? K-1-k : k, j], :] @ (wt ? W_k^T : W_k)  [+ addend[j, :]]
- * on the pre-split planes of W [K, c_in, c_out] (ts_conv_split_planes; `plane_n` elements between planes).  wt = 0: the
- * forward product (c_red = c_in, reference convolution_cuda.cu:101-164 over all offsets); wt = 1: the input gradient
- * (c_red = c_out of the layer, c_out = its c_in; :167-258) - valid where pair (i, j, k) of the rulebook implies pair
- * (j, i, K-1-k), i.e. stride-1 odd kernels on one coordinate set, which is what `nbr` [K, n_rows] (the reference's `results`
- * table, conv.py:160-166) then serves for both directions.  Bit-identical to the two-pass kernels.
- * ts_conv_os_supported(c_red, c_out): 1 for the shapes built (96 -> 96, 128 -> 96, 96 -> 128). */
-int ts_conv_os(const float *feat, int32_t c_red, const void *planes, int64_t plane_n, int32_t K, int32_t c_out,
-               const int32_t *nbr, int64_t n_rows, int32_t wt, float *out, const float *addend, ts_stream_t stream);
-int32_t ts_conv_os_supported(int32_t c_red, int32_t c_out);
-/* diagnostic: ablation bits for tools/os_probe.py (wrong results, timing only); 0 = the product kernel */
-void ts_debug_conv_os(int32_t bits);
+int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
+int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                       const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                       int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream);
+/* half storage (torch.autocast): feat / zp IEEE half, w = the half weight [K, C_in, C_out] as stored */
+int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
+                           const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                           int32_t mirror, const int32_t *rows, void *zp, ts_stream_t stream);
 
 /* Diagnostic: while `stamps` (device memory, 16 x uint64 per workgroup, `capacity` workgroups) is set, the 96- / 128-
  * column fp32 pair GEMMs run an instrumented instantiation whose workgroups leave shader-clock stamps of their phases

@@ -103,9 +103,10 @@ SIGNATURES = {
     "ts_conv_block_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "ts_conv_block_forward": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                     _vp, _sz, _vp]),
+                                     _vp, _vp, _sz, _vp]),
     "ts_conv_block_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp,
-                                      _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                      _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                      _vp]),
     "ts_prof_enable": (None, [_i32]),
     "ts_prof_reserve": (_i32, [_i64]),
     "ts_prof_collect": (_i64, [_vp, _i64]),
@@ -121,17 +122,14 @@ SIGNATURES = {
     "ts_conv_split_planes_batch": (_i32, [_vp, _i32, _vp]),
     "ts_cast_weights_f16_batch": (_i32, [_vp, _i32, _vp]),
     "ts_conv_class_rows": (_i64, [_i64]),
+    "ts_conv_class_rows2": (_i64, [_i64, _i32]),
     "ts_conv_class_plan_workspace_bytes": (_sz, [_i64]),
-    "ts_conv_class_plan": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_conv_class_plan": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_conv_nbr_transposed": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "ts_conv_class_supported": (_i32, [_i32, _i32]),
-    "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
-    "ts_conv_class_gemm_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
-    "ts_conv_class_hint": (None, [_vp, _vp, _vp, _vp, _i64, _i64]),
+    "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "ts_conv_class_gemm_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_planes_hint": (None, [_vp, _vp, _i32, _i32, _i32]),
-    "ts_conv_block_addend_hint": (None, [_vp]),
-    "ts_conv_os": (_i32, [_vp, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
-    "ts_conv_os_supported": (_i32, [_i32, _i32]),
-    "ts_debug_conv_os": (None, [_i32]),
     "ts_debug_phase_stamps": (None, [_vp, _i64]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
@@ -142,6 +140,20 @@ SIGNATURES = {
     "ts_sparse_quantize": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_voxel_coords": (_i32, [_vp, _i64, _i32, _c.c_float, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
+
+
+
+class TsClassPlan(_c.Structure):
+    """include/taseg_hip.h: a class-sorted plan of one kernel map, by reference"""
+    _fields_ = [("src", _vp), ("tile_info", _vp), ("n_tiles", _vp), ("pos", _vp), ("rows", _vp), ("n", _i64), ("m_pad", _i64),
+                ("z_rows", _i64), ("K", _i32), ("groups", _i32), ("mirror", _i32), ("map_id", _vp)]
+
+
+class TsConvBlockOpts(_c.Structure):
+    """include/taseg_hip.h: what a ts_conv_block_* call may use beyond the rulebook"""
+    _fields_ = [("fwd_plan", _c.POINTER(TsClassPlan)), ("dgrad_plan", _c.POINTER(TsClassPlan)), ("planes", _vp),
+                ("w16_current", _i32), ("addend", _vp)]
+
 
 _lib = None
 _lock = threading.Lock()

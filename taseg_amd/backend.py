@@ -607,8 +607,10 @@ def profile_end():
             out.append(("pair_gemm", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=c_red, c_out=c_out, k=k, esize=esize,
                                                          n_rows=rows)))
         elif int(kind) == 3:      # class-sorted implicit GEMM (csrc/conv_class.hip): `wt` carries the rows of Z'
+            # (`wt` >= 0: rows of Z' of a pass-2 plan; < 0: minus the result rows a direct plan stores)
             out.append(("class_gemm", _Ms(ms), None, dict(name=f"class_gemm_kernel<{pick(c_out)}>", pairs=pairs, c_red=c_red,
-                                                          c_out=c_out, k=k, esize=esize, n_rows=rows, z_rows=int(wt))))
+                                                          c_out=c_out, k=k, esize=esize, n_rows=rows, z_rows=max(int(wt), 0),
+                                                          out_rows=max(-int(wt), 0))))
         elif int(kind) == 1:
             name = gather_sum_kernel_name(c_out, k, half)
             out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,
@@ -879,44 +881,86 @@ def sparse_quantize(coords):
     return index[:m], inverse[:n]
 
 
-def conv_class_plan(nbr):
-    """Plan of the class-sorted implicit GEMM (csrc/conv_class.hip) for a submanifold 3x3x3 map: nbr [27, n] (build_kmap with
-    in == out) -> dict(src [9, m_pad], tile_info [m_pad / 128, 2], n_tiles [2] (device: live tiles, (tile, offset) steps),
-    pos [3, n], m_pad, n).  No host sync."""
+def _tile_cols(c):
+    return 128 if c % 128 == 0 else 96 if c % 96 == 0 else 64 if c % 64 == 0 else 32
+
+
+def conv_class_plan(nbr, groups=3, direct=False):
+    """Plan of the class-sorted implicit GEMM (csrc/conv_class.hip) for the table nbr [K, n] (input row feeding destination row j
+    through offset k, or -1): the K offsets in `groups` groups of <= 9, destination rows sorted by their neighbour mask per group.
+    groups = 3: submanifold 3x3x3 maps (build_kmap with in == out), pass 2 adds the three group rows through plan["pos"];
+    direct (groups = 1): 2x2x2 strided maps, the sums are stored straight into the rows plan["rows"] names - no Z, no pass 2.
+    Returns dict(src [K / groups, m_pad], tile_info [m_pad / 128, 2], n_tiles [2] (device: listed tiles, (tile, offset) steps),
+    pos | rows, m_pad, n, K, groups, mirror).  No host sync."""
     L.require_device(nbr)
     nbr = _i32(nbr, "nbr")
     k, n = nbr.shape
+    if direct:
+        groups = 1
     lib = L.load()
-    m_pad = int(lib.ts_conv_class_rows(n))
+    m_pad = int(lib.ts_conv_class_rows2(n, groups))
     dev = nbr.device
-    src = torch.empty((9, m_pad), dtype=torch.int32, device=dev)
+    src = torch.empty((k // groups, m_pad), dtype=torch.int32, device=dev)
     tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
-    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)          # (live tiles, (tile, offset) steps)
-    pos = torch.empty((3, n), dtype=torch.int32, device=dev)
+    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)          # (listed tiles, (tile, offset) steps)
+    pos = None if direct else torch.empty((groups, n), dtype=torch.int32, device=dev)
+    rows = torch.empty(m_pad, dtype=torch.int32, device=dev) if direct else None
     ws = L.workspace(lib.ts_conv_class_plan_workspace_bytes(n), dev)
-    L.check(lib.ts_conv_class_plan(L.ptr(nbr), n, k, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles), L.ptr(pos), L.ptr(ws),
-                                   ws.numel(), L.stream()), "ts_conv_class_plan")
-    return dict(src=src, tile_info=tile_info, n_tiles=n_tiles, pos=pos, m_pad=m_pad, n=n)
+    L.check(lib.ts_conv_class_plan(L.ptr(nbr), n, k, groups, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles), L.ptr(pos), L.ptr(rows),
+                                   L.ptr(ws), ws.numel(), L.stream()), "ts_conv_class_plan")
+    # mirror: the transposed product takes the slice of offset K-1-k (the submanifold map is its own transpose with the offsets
+    # reversed); direct plans are built per direction
+    return dict(src=src, tile_info=tile_info, n_tiles=n_tiles, pos=pos, rows=rows, m_pad=m_pad, n=n, K=k, groups=groups,
+                mirror=0 if direct else 1, z_rows=0, map_id=None)
+
+
+def conv_nbr_transposed(pos_in, nbmaps, k):
+    """nbr_t [K, n_in]: the output row fed by input row i through offset k, or -1 (the table of a kernel map's transposed use)"""
+    L.require_device(pos_in, nbmaps)
+    pos_in, nbmaps = _i32(pos_in, "pos_in"), _i32(nbmaps, "nbmaps")
+    n_in = pos_in.shape[1]
+    out = torch.empty((k, n_in), dtype=torch.int32, device=pos_in.device)
+    L.check(L.load().ts_conv_nbr_transposed(L.ptr(pos_in), L.ptr(nbmaps), k, n_in, L.ptr(out), L.stream()),
+            "ts_conv_nbr_transposed")
+    return out
+
+
+def class_plan_struct(plan):
+    """the TsClassPlan (include/taseg_hip.h) of a plan dict, cached in it (the dict keeps the tensors alive)"""
+    st = plan.get("_struct")
+    if st is None:
+        mid = plan.get("map_id")
+        st = L.TsClassPlan(L.ptr(plan["src"]), L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), L.ptr(plan["pos"]),
+                           L.ptr(plan["rows"]), plan["n"], plan["m_pad"], int(plan.get("z_rows") or 0), plan["K"], plan["groups"],
+                           plan["mirror"], None if mid is None else mid.data_ptr())
+        plan["_struct"] = st
+    return st
 
 
 def conv_class_gemm(feat, kernel, plan, weight_transposed=False):
-    """Pass 1 on a class plan: z' [m_pad, C] with one row per (output row, z-plane of offsets); the convolution is
-    conv_gather_sum(z', plan["pos"], n).  weight_transposed: the input gradient (feat = output gradients, kernel as stored)."""
+    """The product on a class plan.  Pass-2 plans: z' [m_pad, C] with one row per (destination row, group of offsets); the
+    convolution is conv_gather_sum(z', plan["pos"], n).  Direct plans: the result [n, C] itself.  weight_transposed: the
+    transposed product (feat = output gradients, kernel as stored)."""
     L.require_device(feat, kernel)
     feat, kernel = _f32(feat, "feat"), _f32(kernel, "kernel")
     k, c_in, c_out = kernel.shape
     c_red, cols = (c_out, c_in) if weight_transposed else (c_in, c_out)
     if feat.shape[1] != c_red:
         raise ValueError(f"conv_class_gemm: feat has {feat.shape[1]} channels, the product reduces over {c_red}")
-    zp = torch.empty((plan["m_pad"], cols), dtype=torch.float32, device=feat.device)
-    L.check(L.load().ts_conv_class_gemm(L.ptr(feat), c_red, L.ptr(kernel), k, cols, L.ptr(plan["src"]), plan["m_pad"],
-                                        L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
-                                        L.ptr(zp), L.stream()), "ts_conv_class_gemm")
+    direct = plan["rows"] is not None
+    zp = torch.empty((plan["n"] if direct else plan["m_pad"], cols), dtype=torch.float32, device=feat.device)
+    with _Timed("class_gemm", name=f"class_gemm_kernel<{_tile_cols(cols)}>", pairs=int(plan.get("pairs", 0)), c_red=c_red,
+                c_out=cols, k=k, esize=4, n_rows=feat.shape[0], z_rows=0 if direct else int(plan.get("z_rows") or plan["m_pad"]),
+                out_rows=plan["n"] if direct else 0):
+        L.check(L.load().ts_conv_class_gemm(L.ptr(feat), c_red, L.ptr(kernel), k, plan["groups"], cols, L.ptr(plan["src"]),
+                                            plan["m_pad"], L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]),
+                                            1 if weight_transposed else 0, plan["mirror"], L.ptr(plan["rows"]), L.ptr(zp),
+                                            L.stream()), "ts_conv_class_gemm")
     return zp
 
 
 def conv_class_gemm_f16(feat, w16, plan, weight_transposed=False):
-    """conv_class_gemm for IEEE-half rows: w16 = the half weight [27, C_in, C_out] as stored; z' half (fp32 sums)."""
+    """conv_class_gemm for IEEE-half rows: w16 = the half weight [K, C_in, C_out] as stored; result half (fp32 sums)."""
     L.require_device(feat, w16)
     if feat.dtype != torch.float16 or w16.dtype != torch.float16:
         raise TypeError("conv_class_gemm_f16: half tensors expected")
@@ -925,34 +969,13 @@ def conv_class_gemm_f16(feat, w16, plan, weight_transposed=False):
     c_red, cols = (c_out, c_in) if weight_transposed else (c_in, c_out)
     if feat.shape[1] != c_red:
         raise ValueError(f"conv_class_gemm_f16: feat has {feat.shape[1]} channels, the product reduces over {c_red}")
-    zp = torch.empty((plan["m_pad"], cols), dtype=torch.float16, device=feat.device)
-    L.check(L.load().ts_conv_class_gemm_f16(L.ptr(feat), c_red, L.ptr(w16), k, cols, L.ptr(plan["src"]), plan["m_pad"],
-                                            L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
-                                            L.ptr(zp), L.stream()), "ts_conv_class_gemm_f16")
+    direct = plan["rows"] is not None
+    zp = torch.empty((plan["n"] if direct else plan["m_pad"], cols), dtype=torch.float16, device=feat.device)
+    with _Timed("class_gemm", name=f"class_gemm_kernel<{_tile_cols(cols)}>", pairs=int(plan.get("pairs", 0)), c_red=c_red,
+                c_out=cols, k=k, esize=2, n_rows=feat.shape[0], z_rows=0 if direct else int(plan.get("z_rows") or plan["m_pad"]),
+                out_rows=plan["n"] if direct else 0):
+        L.check(L.load().ts_conv_class_gemm_f16(L.ptr(feat), c_red, L.ptr(w16), k, plan["groups"], cols, L.ptr(plan["src"]),
+                                                plan["m_pad"], L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]),
+                                                1 if weight_transposed else 0, plan["mirror"], L.ptr(plan["rows"]), L.ptr(zp),
+                                                L.stream()), "ts_conv_class_gemm_f16")
     return zp
-
-
-def conv_os(feat, planes, kernel_shape, nbr, weight_transposed=False, addend=None):
-    """Output-stationary convolution pass (csrc/conv_os.hip): out[j] = sum_k feat[nbr[k', j]] @ (W_k or W_k^T) straight into
-    the output rows, no Z.  planes: taseg_amd.planes.planes_for(weight) (int16 storage of the three bf16 planes);
-    kernel_shape = weight.shape (K, c_in, c_out); weight_transposed: the input gradient (k' = K-1-k)."""
-    L.require_device(feat, planes, nbr, addend)
-    feat, nbr = _f32(feat, "feat"), _i32(nbr, "nbr")
-    k, c_in, c_out = (int(v) for v in kernel_shape)
-    c_red, c_o = (c_out, c_in) if weight_transposed else (c_in, c_out)
-    if feat.shape[1] != c_red:
-        raise ValueError("Input feature size and kernel size mismatch")
-    n = nbr.shape[1]
-    if nbr.shape[0] != k:
-        raise ValueError(f"neighbour table shape {tuple(nbr.shape)} != ({k}, n)")
-    if planes.numel() != 3 * k * c_in * c_out:
-        raise ValueError("planes do not belong to a weight of this shape")
-    if addend is not None:
-        addend = _f32(addend, "addend")
-    out = torch.empty((n, c_o), dtype=torch.float32, device=feat.device)
-    p = int((nbr >= 0).sum()) if _prof is not None else 0
-    with _Timed("conv_os", name=f"conv_os_kernel<{c_red},{c_o},{'true' if weight_transposed else 'false'}>", pairs=p, c_red=c_red,
-                c_out=c_o, k=k, n_rows=feat.shape[0], n_out=n):
-        L.check(L.load().ts_conv_os(L.ptr(feat), c_red, L.ptr(planes), k * c_in * c_out, k, c_o, L.ptr(nbr), n,
-                                    1 if weight_transposed else 0, L.ptr(out), L.ptr(addend), L.stream()), "ts_conv_os")
-    return out

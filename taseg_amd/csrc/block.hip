@@ -141,32 +141,30 @@ extern "C" int ts_prof_empty_bracket_us(int32_t reps, ts_stream_t stream_, doubl
   return TS_OK;
 }
 
-// The caller's one-shot hint of pre-split weight planes (ts_conv_planes_hint) belongs to the block call as a whole: taken
-// at entry, handed to the one fp32 pair GEMM of the call, gone when the call returns - whichever path it took.
-// The gradient that reaches the block's input along another path (the shortcut of a residual block, when the block passes
-// its input through - see ts_conv_block_addend_hint): [n_dgrad_rows, c_in] in grad_feat's storage type, one-shot, per thread.
-thread_local const void *g_ts_block_addend = nullptr;
-extern "C" void ts_conv_block_addend_hint(const void *addend) { g_ts_block_addend = addend; }
-
-struct PlanesHintScope {
+// Everything a block call may use beyond the rulebook arrives in TsConvBlockOpts (include/taseg_hip.h) - nothing is taken
+// from, or left in, thread-local state: a stale ts_conv_planes_hint of the calling thread is cleared on entry and the planes
+// of THIS call are armed right before its one fp32 pair GEMM.
+struct PlanesScope {
   TsPlanesHint h;
-  PlanesHintScope() : h(g_ts_planes_hint) { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
+  PlanesScope(const float *w, const void *planes, int K, int c_in, int c_out)
+      : h{planes ? w : nullptr, (const unsigned short *)planes, K, c_in, c_out} {
+    g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0};
+  }
   void arm() const { g_ts_planes_hint = h; }
-  ~PlanesHintScope() { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
+  ~PlanesScope() { g_ts_planes_hint = TsPlanesHint{nullptr, nullptr, 0, 0, 0}; }
 };
 
-// the class plan of the block's kernel map (csrc/conv_class.hip), one-shot like the planes hint
-struct ClassHintScope {
-  TsClassHint h;
-  ClassHintScope() : h(g_ts_class_hint) { g_ts_class_hint = TsClassHint{nullptr, nullptr, nullptr, nullptr, 0, 0}; }
-  double z_rows() const { return (double)(h.z_rows > 0 ? h.z_rows : ts_conv_class_rows(h.n)); }
-  // submanifold 3x3x3 product over the plan's rows, Z' fits where Z would have gone
-  bool fits(int32_t K, int64_t n_rows_a, int64_t n_rows_b, int32_t c_red, int32_t c_out, int64_t n_pairs, int32_t half) const {
-    (void)half;        // both storage types have the kernel
-    return h.src && K == 27 && n_rows_a == h.n && n_rows_b == h.n && ts_conv_class_supported(c_red, c_out) &&
-           ts_conv_class_rows(h.n) <= n_pairs && g_ts_conv_impl == 0;
-  }
-};
+// may this call run a product on `p`?  K offsets over `n_dest` destination rows, plan built from THIS kernel map (map_id), shapes
+// the class kernels take; pass-2 plans also need Z' to fit where Z would have gone
+static bool plan_fits(const TsClassPlan *p, int32_t K, int64_t n_dest, int32_t c_red, int32_t c_out, int64_t n_pairs,
+                      const int32_t *nboffs) {
+  if (!p || !p->src || !p->tile_info || !p->n_tiles || g_ts_conv_impl != 0) return false;
+  if (p->K != K || p->n != n_dest || p->map_id != (const void *)nboffs || !ts_conv_class_supported(c_red, c_out)) return false;
+  if (p->groups < 1 || K % p->groups != 0 || p->m_pad != ts_conv_class_rows2(n_dest, p->groups)) return false;
+  if (p->rows) return p->groups == 1 && !p->pos;
+  return p->pos && p->m_pad <= n_pairs;
+}
+static double plan_z_rows(const TsClassPlan *p) { return (double)(p->z_rows > 0 ? p->z_rows : p->m_pad); }
 
 // out = act(BN(conv(feat)) [+ residual]).
 //   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
@@ -180,10 +178,11 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
                                      const float *bn_weight, const float *bn_bias, float *running_mean,
                                      float *running_var, int64_t *num_batches_tracked, float eps, float momentum,
                                      int32_t relu, int32_t half, void *comm, double *pack, void *conv_out, float *mean,
-                                     float *invstd, void *out, uint8_t *mask, void *w16, void *ws, size_t ws_bytes,
-                                     ts_stream_t stream) {
-  PlanesHintScope planes_hint;
-  ClassHintScope class_hint;
+                                     float *invstd, void *out, uint8_t *mask, void *w16, const TsConvBlockOpts *opts, void *ws,
+                                     size_t ws_bytes, ts_stream_t stream) {
+  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts &o = opts ? *opts : none;
+  PlanesScope planes(kernel, half ? nullptr : o.planes, K, c_in, c_out);
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_forward: bad sizes");
   TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
@@ -195,69 +194,58 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   void *z = p;
   p += blk_align((size_t)n_pairs * cmax * es);
   p += blk_align((size_t)n_out * cmax * es);
-  void *w16t = nullptr;
-  if (half) {
-    w16t = p;
-    p += blk_align((size_t)K * c_in * c_out * 2);
-  }
+  if (half) p += blk_align((size_t)K * c_in * c_out * 2);
   void *bn_ws = p;
   const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+  const TsClassPlan *cp = plan_fits(o.fwd_plan, K, n_out, c_in, c_out, n_pairs, nboffs) ? o.fwd_plan : nullptr;
   if (comm == TS_COMM_CALLER_POST) {
     // second half of a split call: conv_out and the all-reduced pack exist, statistics + elementwise pass are left
-  } else if (half && gather_col == 0 && class_hint.fits(K, n_feat_rows, n_out, c_in, c_out, n_pairs, half)) {
-    // half storage on the class plan (csrc/conv_class.hip): Z' rows are rounded to half once per (row, z-plane of offsets)
-    const TsPlanesHint &hw = planes_hint.h;
-    if (!(hw.w == kernel && (const void *)hw.planes == w16 && hw.K == K && hw.c_in == c_in && hw.c_out == c_out))
-      TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
-    const TsClassHint &ch = class_hint.h;
-    const int64_t m_pad = ts_conv_class_rows(ch.n);
-    {
-      ProfScope ps(3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 2, class_hint.z_rows());
-      TS_TRY(ts_conv_class_gemm_f16(feat, c_in, w16, K, c_out, ch.src, m_pad, ch.tile_info, ch.n_tiles, 0, z, stream));
-    }
-    {
-      ProfScope ps(1, stream, class_hint.z_rows(), 0, c_out, 3, (double)n_out, 2, 0);
-      TS_TRY(ts_conv_gather_sum_f16(z, c_out, ch.pos, 3, n_out, m_pad, conv_out, stream));
-    }
-  } else if (half) {
-    // one half copy in the kernel's own layout serves both passes: the forward reads it through the transposing LDS
-    // load (ts_conv_pair_gemm_f16_nat), the input gradient directly
-    // (the cast is skipped when the caller keeps w16 in step with the weight itself and says so: ts_conv_planes_hint(kernel, w16))
-    (void)w16t;
-    const TsPlanesHint &hw = planes_hint.h;
-    if (!(hw.w == kernel && (const void *)hw.planes == w16 && hw.K == K && hw.c_in == c_in && hw.c_out == c_out))
-      TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
-    {
-      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 2, 0);
-      TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
-    }
-    {
-      ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 2, 0);
-      TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
-    }
-  } else if (gather_col == 0 && class_hint.fits(K, n_feat_rows, n_out, c_in, c_out, n_pairs, half)) {
-    // class-sorted implicit GEMM: the sums of a z-plane of offsets stay in the accumulators, Z' has <= 3 rows per output
-    const TsClassHint &ch = class_hint.h;
-    const int64_t m_pad = ts_conv_class_rows(ch.n);
-    {
-      ProfScope ps(3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 4, class_hint.z_rows());
-      TS_TRY(ts_conv_class_gemm((const float *)feat, c_in, kernel, K, c_out, ch.src, m_pad, ch.tile_info, ch.n_tiles, 0,
-                                (float *)z, stream));
-    }
-    {
-      ProfScope ps(1, stream, class_hint.z_rows(), 0, c_out, 3, (double)n_out, 4, 0);
-      TS_TRY(ts_conv_gather_sum((const float *)z, c_out, ch.pos, 3, n_out, m_pad, (float *)conv_out, stream));
-    }
   } else {
-    {
-      ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 4, 0);
-      planes_hint.arm();
-      TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
-                               (float *)z, c_out, stream));
-    }
-    {
-      ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 4, 0);
-      TS_TRY(ts_conv_gather_sum((const float *)z, c_out, pos, K, n_out, n_pairs, (float *)conv_out, stream));
+    // half storage: one half copy in the kernel's own layout serves both passes (the forward reads it through the transposing
+    // LDS load, the input gradient directly); the cast is skipped when the caller keeps w16 in step with the weight itself
+    if (half && !o.w16_current) TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
+    const double es_d = (double)es;
+    if (cp) {
+      // class-sorted implicit GEMM: the sums of a group of offsets stay in the accumulators; a direct plan (2x2x2 maps) stores
+      // the result rows themselves, a pass-2 plan leaves <= 3 rows of Z' per output
+      void *dst = cp->rows ? conv_out : z;
+      {
+        // (last field: rows of Z' a pass-2 plan writes, or minus the result rows a direct plan writes)
+        ProfScope ps(3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, cp->rows ? -(double)n_out : plan_z_rows(cp));
+        if (half)
+          TS_TRY(ts_conv_class_gemm_f16_ex(feat, c_in, w16, K, cp->groups, c_out, cp->src, cp->m_pad, cp->tile_info, cp->n_tiles,
+                                           0, 0, cp->rows, dst, nullptr, stream));
+        else
+          TS_TRY(ts_conv_class_gemm_ex((const float *)feat, c_in, kernel, K, cp->groups, c_out, cp->src, cp->m_pad, cp->tile_info,
+                                       cp->n_tiles, 0, 0, cp->rows, (float *)dst, nullptr, stream));
+      }
+      if (!cp->rows) {
+        ProfScope ps(1, stream, plan_z_rows(cp), 0, c_out, cp->groups, (double)n_out, es_d, 0);
+        if (half)
+          TS_TRY(ts_conv_gather_sum_f16(z, c_out, cp->pos, cp->groups, n_out, cp->m_pad, conv_out, stream));
+        else
+          TS_TRY(ts_conv_gather_sum((const float *)z, c_out, cp->pos, cp->groups, n_out, cp->m_pad, (float *)conv_out, stream));
+      }
+    } else if (half) {
+      {
+        ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 2, 0);
+        TS_TRY(ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, z, c_out, stream));
+      }
+      {
+        ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 2, 0);
+        TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
+      }
+    } else {
+      {
+        ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, 4, 0);
+        planes.arm();
+        TS_TRY(ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
+                                 (float *)z, c_out, stream));
+      }
+      {
+        ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 4, 0);
+        TS_TRY(ts_conv_gather_sum((const float *)z, c_out, pos, K, n_out, n_pairs, (float *)conv_out, stream));
+      }
     }
   }
   if (comm)
@@ -284,12 +272,12 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                       const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs,
                                       int32_t dgrad_gather_col, const int32_t *pos_dgrad, int64_t n_dgrad_rows,
                                       int32_t wgrad_col_a, void *grad_feat, void *grad_residual, float *grad_kernel,
-                                      float *grad_bn_weight, float *grad_bn_bias, void *ws, size_t ws_bytes,
-                                      ts_stream_t stream) {
-  PlanesHintScope planes_hint;
-  ClassHintScope class_hint;
-  const void *addend = g_ts_block_addend;       // one-shot (ts_conv_block_addend_hint): added into grad_feat's store
-  g_ts_block_addend = nullptr;
+                                      float *grad_bn_weight, float *grad_bn_bias, const TsConvBlockOpts *opts, void *ws,
+                                      size_t ws_bytes, ts_stream_t stream) {
+  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts &o = opts ? *opts : none;
+  PlanesScope planes((const float *)weights, half ? nullptr : o.planes, K, c_in, c_out);
+  const void *addend = o.addend;                // added into grad_feat's store
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_backward: bad sizes");
   TS_REQUIRE(!addend || (grad_feat && (((uintptr_t)addend) & 15) == 0), TS_ERR_INVALID_ARGUMENT,
@@ -309,7 +297,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   if (comm) {
     TS_TRY(ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums,
                                grad_conv, grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));
-    // first half of a split call: the local sums are out, the caller all-reduces them (one-shot hints go with the second half)
+    // first half of a split call: the local sums are out, the caller all-reduces them
     if (comm == TS_COMM_CALLER_PRE) return TS_OK;
   } else if (half) {
     TS_TRY(ts_bn_act_train_backward_f16(grad_out, mask, conv_out, mean, invstd, bn_weight, n_out, c_out, grad_conv,
@@ -319,9 +307,9 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                     c_out, (float *)grad_conv, (float *)grad_residual, grad_bn_weight, grad_bn_bias, bn_ws,
                                     bn_ws_bytes, stream));
   }
-  // Weight gradient first, as partial tiles (deterministic form, common.h): their ordered sum then rides on the
-  // gather-sum launch of the input gradient - no reduce launch, no fill of grad_kernel, no float atomics.  A block
-  // without an input gradient (the first layer) sums with a launch of its own.
+  // Weight gradient first, as partial tiles (deterministic form, common.h): their ordered sum then rides on the launch that
+  // finishes the input gradient (pass 2, or the direct class GEMM) - no reduce launch, no fill of grad_kernel, no float
+  // atomics.  A block without an input gradient (the first layer) sums with a launch of its own.
   const double es_d = half ? 2 : 4;
   float *part = (float *)(((char *)bn_ws) + blk_align(bn_ws_bytes));
   const bool det = grad_kernel && ((int64_t)c_in * c_out) % 4 == 0 && (((uintptr_t)grad_kernel) & 15) == 0 &&
@@ -342,27 +330,35 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     if (det) job = TsWgradReduce{part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
   }
   const bool ride = det && grad_feat && n_dgrad_rows > 0;
-  if (grad_feat && dgrad_gather_col == 1 && class_hint.fits(K, n_out, n_dgrad_rows, c_out, c_in, n_pairs, half)) {
-    // input gradient on the class plan: gy rows through W_{26-k}^T, the sums of a z-plane of offsets in the accumulators
-    const TsClassHint &ch = class_hint.h;
-    const int64_t m_pad = ts_conv_class_rows(ch.n);
+  const TsClassPlan *cp = (grad_feat && plan_fits(o.dgrad_plan, K, n_dgrad_rows, c_out, c_in, n_pairs, nboffs) &&
+                           !(o.dgrad_plan->rows && addend))
+                              ? o.dgrad_plan
+                              : nullptr;
+  // the ordered weight-gradient sum riding on a launch reads its partial tiles and writes grad_kernel: real bytes
+  // ... and so is the shortcut's gradient when it is added in the store (one more read of [n_dgrad_rows, c_in])
+  const double side_bytes = (ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0) +
+                            (addend ? es_d * (double)n_dgrad_rows * c_in : 0.0);
+  if (cp) {
+    // input gradient on the class plan: gy rows through W_k^T (mirror: W_{K-1-k}^T), the sums of a group of offsets in the
+    // accumulators; a direct plan writes grad_feat itself and carries the weight-gradient sum
+    void *dst = cp->rows ? grad_feat : z;
     {
-      ProfScope ps(3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, class_hint.z_rows());
+      ProfScope ps(3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, cp->rows ? -(double)n_dgrad_rows : plan_z_rows(cp));
+      const TsWgradReduce *side = (cp->rows && ride) ? &job : nullptr;
       if (half)
-        TS_TRY(ts_conv_class_gemm_f16(grad_conv, c_out, weights, K, c_in, ch.src, m_pad, ch.tile_info, ch.n_tiles, 1, z, stream));
+        TS_TRY(ts_conv_class_gemm_f16_ex(grad_conv, c_out, weights, K, cp->groups, c_in, cp->src, cp->m_pad, cp->tile_info,
+                                         cp->n_tiles, 1, cp->mirror, cp->rows, dst, side, stream));
       else
-        TS_TRY(ts_conv_class_gemm((const float *)grad_conv, c_out, (const float *)weights, K, c_in, ch.src, m_pad,
-                                  ch.tile_info, ch.n_tiles, 1, (float *)z, stream));
+        TS_TRY(ts_conv_class_gemm_ex((const float *)grad_conv, c_out, (const float *)weights, K, cp->groups, c_in, cp->src,
+                                     cp->m_pad, cp->tile_info, cp->n_tiles, 1, cp->mirror, cp->rows, (float *)dst, side, stream));
     }
-    {
-      const double side_bytes = (ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0) +
-                                (addend ? es_d * (double)n_dgrad_rows * c_in : 0.0);
-      ProfScope ps(1, stream, class_hint.z_rows(), 0, c_in, 3, (double)n_dgrad_rows, es_d, side_bytes);
+    if (!cp->rows) {
+      ProfScope ps(1, stream, plan_z_rows(cp), 0, c_in, cp->groups, (double)n_dgrad_rows, es_d, side_bytes);
       if (half)
-        TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, ch.pos, 3, n_dgrad_rows, m_pad, grad_feat, ride ? &job : nullptr, addend,
-                                         stream));
+        TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, cp->pos, cp->groups, n_dgrad_rows, cp->m_pad, grad_feat, ride ? &job : nullptr,
+                                         addend, stream));
       else
-        TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, ch.pos, 3, n_dgrad_rows, m_pad, (float *)grad_feat,
+        TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, cp->pos, cp->groups, n_dgrad_rows, cp->m_pad, (float *)grad_feat,
                                      ride ? &job : nullptr, (const float *)addend, stream));
     }
   } else if (grad_feat) {
@@ -372,16 +368,12 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
         TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, z, c_in,
                                      stream));
       else {
-        planes_hint.arm();
+        planes.arm();
         TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs,
                                  n_pairs, dgrad_gather_col, (float *)z, c_in, stream));
       }
     }
     {
-      // the ordered weight-gradient sum riding on this launch reads its partial tiles and writes grad_kernel: real bytes
-      // ... and so is the shortcut's gradient when it is added in this store (one more read of [n_dgrad_rows, c_in])
-      const double side_bytes = (ride ? 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K) : 0.0) +
-                                (addend ? es_d * (double)n_dgrad_rows * c_in : 0.0);
       ProfScope ps(1, stream, (double)n_pairs, 0, c_in, K, (double)n_dgrad_rows, es_d, side_bytes);
       if (half)
         TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, pos_dgrad, K, n_dgrad_rows, n_pairs, grad_feat, ride ? &job : nullptr,

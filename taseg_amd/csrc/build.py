@@ -13,8 +13,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_os.hip", "conv_class.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip"]
-EXPERIMENTS = {"conv_pairs_x.hip": "libtaseg_x.so"}      # three-product IEEE-half split pair GEMM (tools/x_probe.py)
+SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_class.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip"]
+# measured-and-shelved kernels live in tools/experiments/ and are NOT part of libtaseg_hip.so:
+# `python -m taseg_amd.csrc.build --experiments` builds them into tools/experiments/build/libtaseg_exp.so for the probes there
+EXP_DIR = os.path.join(ROOT, "tools", "experiments")
+EXPERIMENTS = ["conv_os.hip", "conv_pairs_x.hip"]
 LIB = os.path.join(PKG, "libtaseg_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -58,15 +61,27 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
-    # measured-and-shelved kernels: their own small library next to the objects, loaded only by tools/
-    for src_name, lib_name in EXPERIMENTS.items():
-        src, obj = os.path.join(HERE, src_name), os.path.join(OBJ_DIR, src_name.replace(".hip", ".o"))
-        out = os.path.join(OBJ_DIR, lib_name)
-        if os.path.exists(src) and (force or _newer(src, out) or any(_newer(d, out) for d in _deps())):
-            run([HIPCC, *FLAGS, "-c", src, "-o", obj])
-            run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, os.path.join(OBJ_DIR, "hash.o"), "-ldl"])
     return LIB
 
 
+def build_experiments(verbose=True):
+    """tools/experiments/*.hip -> tools/experiments/build/libtaseg_exp.so (links the product library's hash.o for ts_set_error)"""
+    build(verbose=verbose)
+    out_dir = os.path.join(EXP_DIR, "build")
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for name in EXPERIMENTS:
+        src, obj = os.path.join(EXP_DIR, name), os.path.join(out_dir, name.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-I", HERE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    out = os.path.join(out_dir, "libtaseg_exp.so")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, os.path.join(OBJ_DIR, "hash.o"),
+                    os.path.join(OBJ_DIR, "conv_pairs.o"), "-ldl"], check=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_experiments() if "--experiments" in sys.argv else build(force="--force" in sys.argv))

@@ -222,13 +222,13 @@ struct TsPlanesHint {
 };
 extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv_planes_hint, cleared by the call that reads it
 
-// class-sorted implicit GEMM (csrc/conv_class.hip): the plan of a submanifold 3x3x3 map over n rows, as a one-shot hint
-struct TsClassHint {
-  const int32_t *src, *tile_info, *n_tiles, *pos;
-  int64_t n;
-  int64_t z_rows;      // rows of Z' the live tiles cover (host copy of 128 * n_tiles, for the profile records), or 0
-};
-extern thread_local TsClassHint g_ts_class_hint;      // set by ts_conv_class_hint, cleared by the block call that reads it
+// class-sorted implicit GEMM (csrc/conv_class.hip), library-internal forms: + the ordered weight-gradient sum riding on the launch
+int ts_conv_class_gemm_ex(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                          const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                          int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, ts_stream_t stream);
+int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
+                              const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                              int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, ts_stream_t stream);
 
 // Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can form the ordered sum
 // of the weight-gradient partials on the side (saves the reduce launch), and the atomic form of the weight gradient
@@ -239,7 +239,6 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
                           float *out, const TsWgradReduce *side, const float *addend, ts_stream_t stream);
 int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
                               void *out, const TsWgradReduce *side, const void *addend, ts_stream_t stream);
-extern thread_local const void *g_ts_block_addend;     // one-shot: set by ts_conv_block_addend_hint, taken by ts_conv_block_backward
 int ts_conv_wgrad_ex(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
                      const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
                      int32_t already_zero, ts_stream_t stream);

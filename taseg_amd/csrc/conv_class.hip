@@ -45,32 +45,36 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static inline int64_t cg_npad(int64_t n) { return (n + CG_BM - 1) / CG_BM * CG_BM; }
 
 extern "C" int64_t ts_conv_class_rows(int64_t n) { return n < 0 ? 0 : CG_GROUPS * cg_npad(n); }
+extern "C" int64_t ts_conv_class_rows2(int64_t n, int32_t groups) { return (n < 0 || groups < 1) ? 0 : groups * cg_npad(n); }
 
 // key = group * 512 + (511 - mask): inside a group, rows with more / higher neighbour bits first, rows without a neighbour in
-// the group (and the padding up to a multiple of 128) last; value = row (-1: padding)
-__global__ __launch_bounds__(256) void class_keys_kernel(const int *__restrict__ nbr, int64_t n, int64_t npad,
+// the group (and the padding up to a multiple of 128) last; value = row (-1: padding).  gk = offsets per group (<= 9).
+__global__ __launch_bounds__(256) void class_keys_kernel(const int *__restrict__ nbr, int64_t n, int64_t npad, int groups, int gk,
                                                         unsigned short *__restrict__ keys, int *__restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= CG_GROUPS * npad) return;
+  if (i >= groups * npad) return;
   const int g = (int)(i / npad);
   const int64_t j = i - (int64_t)g * npad;
   unsigned bits = 0;
   if (j < n) {
 #pragma unroll
-    for (int kl = 0; kl < CG_GK; ++kl) bits |= (unsigned)(nbr[(int64_t)(CG_GK * g + kl) * n + j] >= 0) << kl;
+    for (int kl = 0; kl < CG_GK; ++kl)
+      if (kl < gk) bits |= (unsigned)(nbr[(int64_t)(gk * g + kl) * n + j] >= 0) << kl;
   }
   keys[i] = (unsigned short)(g * 512 + (511 - bits));
   vals[i] = j < n ? (int)j : -1;
 }
 
 // one 128-thread workgroup per tile of the sorted list: the neighbour table in sorted order (src), the position of every row in
-// the list (pos), the union mask of the tile
-__global__ __launch_bounds__(CG_BM) void class_fill_kernel(const int *__restrict__ nbr, int64_t n, int64_t npad,
-                                                          const unsigned short *__restrict__ keys,
+// the list (pos; plans with pass 2) or the row of every list slot (rows; direct plans: the product is stored straight into the
+// destination rows), the union mask of the tile (bit 30: the tile holds at least one real row)
+__global__ __launch_bounds__(CG_BM) void class_fill_kernel(const int *__restrict__ nbr, int64_t n, int64_t npad, int groups,
+                                                          int gk, const unsigned short *__restrict__ keys,
                                                           const int *__restrict__ vals, int *__restrict__ src,
-                                                          int *__restrict__ pos, int *__restrict__ tile_mask) {
+                                                          int *__restrict__ pos, int *__restrict__ rows,
+                                                          int *__restrict__ tile_mask) {
   __shared__ unsigned wmask[CG_BM / 64];
-  const int64_t m_pad = CG_GROUPS * npad;
+  const int64_t m_pad = groups * npad;
   const int64_t i = (int64_t)blockIdx.x * CG_BM + threadIdx.x;
   const int key = keys[i];
   const int g = key >> 9;
@@ -79,9 +83,10 @@ __global__ __launch_bounds__(CG_BM) void class_fill_kernel(const int *__restrict
   const bool live = j >= 0 && bits != 0;
 #pragma unroll
   for (int kl = 0; kl < CG_GK; ++kl)
-    src[(int64_t)kl * m_pad + i] = (live && ((bits >> kl) & 1)) ? nbr[(int64_t)(CG_GK * g + kl) * n + j] : -1;
-  if (j >= 0) pos[(int64_t)g * n + j] = live ? (int)i : -1;
-  unsigned m = live ? bits : 0u;
+    if (kl < gk) src[(int64_t)kl * m_pad + i] = (live && ((bits >> kl) & 1)) ? nbr[(int64_t)(gk * g + kl) * n + j] : -1;
+  if (pos && j >= 0) pos[(int64_t)g * n + j] = live ? (int)i : -1;
+  if (rows) rows[i] = j;
+  unsigned m = (live ? bits : 0u) | (j >= 0 ? (1u << 30) : 0u);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, 64);
   if ((threadIdx.x & 63) == 0) wmask[threadIdx.x >> 6] = m;
@@ -91,20 +96,21 @@ __global__ __launch_bounds__(CG_BM) void class_fill_kernel(const int *__restrict
 
 // live tiles, longest (most offsets) first: tile_info[t] = (group + 4 * tile, union mask); one workgroup (<= 70k tiles at the
 // 3e6-voxel cap).  The order inside a length class follows the arrival of the LDS atomics - every tile owns its Z' rows, so
-// the order of the list changes the schedule, never a result.
-__global__ __launch_bounds__(1024) void class_tiles_kernel(const int *__restrict__ tile_mask, int n_all, int64_t npad,
+// the order of the list changes the schedule, never a result.  direct: tiles of rows WITHOUT any neighbour are listed too (last,
+// with mask 0): their destination rows must be written (zeros).
+__global__ __launch_bounds__(1024) void class_tiles_kernel(const int *__restrict__ tile_mask, int n_all, int64_t npad, int direct,
                                                            int2 *__restrict__ tile_info, int *__restrict__ n_tiles) {
   __shared__ int cnt[CG_GK + 1], base[CG_GK + 1];
   if (threadIdx.x <= CG_GK) cnt[threadIdx.x] = 0;
   __syncthreads();
   for (int t = threadIdx.x; t < n_all; t += 1024) {
     const int m = tile_mask[t];
-    if (m) atomicAdd(&cnt[__builtin_popcount(m)], 1);
+    if ((m & 511) || (direct && (m >> 30))) atomicAdd(&cnt[__builtin_popcount(m & 511)], 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0, steps = 0;
-    for (int c = CG_GK; c >= 1; --c) {
+    for (int c = CG_GK; c >= 0; --c) {
       base[c] = run;
       run += cnt[c];
       steps += c * cnt[c];
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(1024) void class_tiles_kernel(const int *__restrict
   const int tiles_per_group = (int)(npad / CG_BM);
   for (int t = threadIdx.x; t < n_all; t += 1024) {
     const int m = tile_mask[t];
-    if (m) {
-      const int at = atomicAdd(&base[__builtin_popcount(m)], 1);
-      tile_info[at] = make_int2(t / tiles_per_group + 4 * t, m);
+    if ((m & 511) || (direct && (m >> 30))) {
+      const int at = atomicAdd(&base[__builtin_popcount(m & 511)], 1);
+      tile_info[at] = make_int2(t / tiles_per_group + 4 * t, m & 511);
     }
   }
 }
@@ -133,16 +139,23 @@ extern "C" size_t ts_conv_class_plan_workspace_bytes(int64_t n) {
          ts_align_up(sort_bytes, 256) + 256;
 }
 
-// nbr [27][n] (ts_build_kmap of a submanifold 3x3x3 map: in == out) -> src [9][m_pad], tile_info [m_pad / 128] (x, y) pairs,
-// n_tiles [2] = (live tiles, their (tile, offset) steps), pos [3][n];  m_pad = ts_conv_class_rows(n)
-extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t *src, int32_t *tile_info, int32_t *n_tiles,
-                                  int32_t *pos, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+// nbr [K][n] = input row feeding destination row j through offset k, or -1 (ts_build_kmap's `nbr` table; for the transposed
+// direction of a strided map the table of the inverse map) -> src [K / groups][m_pad], tile_info [m_pad / 128] (x, y) pairs,
+// n_tiles [2] = (listed tiles, their (tile, offset) steps), and either pos [groups][n] (pass 2 adds the groups' rows) or - direct
+// plans, groups == 1 - rows [m_pad] (destination row of every list slot, -1 = padding);  m_pad = ts_conv_class_rows2(n, groups)
+extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t groups, int32_t *src, int32_t *tile_info,
+                                  int32_t *n_tiles, int32_t *pos, int32_t *rows, void *ws, size_t ws_bytes, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(K == CG_GROUPS * CG_GK, TS_ERR_UNSUPPORTED, "ts_conv_class_plan: 27 offsets (3x3x3) only");
+  TS_REQUIRE(groups >= 1 && groups <= CG_GROUPS && K > 0 && K % groups == 0 && K / groups <= CG_GK, TS_ERR_UNSUPPORTED,
+             "ts_conv_class_plan: K offsets must split into 1-3 groups of <= 9 (got K %d, groups %d)", K, groups);
   TS_REQUIRE(n > 0 && n < (1LL << 28), TS_ERR_INVALID_ARGUMENT, "ts_conv_class_plan: bad n");
-  TS_REQUIRE(nbr && src && tile_info && n_tiles && pos && ws, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_plan: null pointer");
+  TS_REQUIRE(nbr && src && tile_info && n_tiles && ws, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_plan: null pointer");
+  TS_REQUIRE((pos != nullptr) != (rows != nullptr), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_class_plan: exactly one of pos (pass-2 plan) and rows (direct plan) must be given");
+  TS_REQUIRE(!rows || groups == 1, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_plan: a direct plan has one group");
   TS_REQUIRE(ws_bytes >= ts_conv_class_plan_workspace_bytes(n), TS_ERR_WORKSPACE_TOO_SMALL, "ts_conv_class_plan: workspace too small");
-  const int64_t npad = cg_npad(n), m = CG_GROUPS * npad;
+  const int gk = K / groups;
+  const int64_t npad = cg_npad(n), m = groups * npad;
   char *p = (char *)ws;
   unsigned short *k0 = (unsigned short *)p;
   p += ts_align_up((size_t)m * 2, 256);
@@ -155,13 +168,34 @@ extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int3
   int *tmask = (int *)p;
   p += ts_align_up((size_t)(m / CG_BM) * 4, 256);
   size_t sort_bytes = ws_bytes - (size_t)(p - (char *)ws);
-  class_keys_kernel<<<(unsigned)ts_cdiv(m, 256), 256, 0, stream>>>(nbr, n, npad, k0, v0);
+  class_keys_kernel<<<(unsigned)ts_cdiv(m, 256), 256, 0, stream>>>(nbr, n, npad, groups, gk, k0, v0);
   TS_CHECK_LAUNCH("ts_conv_class_plan/keys");
   TS_CHECK_HIP(rocprim::radix_sort_pairs(p, sort_bytes, k0, k1, v0, v1, (size_t)m, 0, 11, stream), "ts_conv_class_plan/sort");
-  class_fill_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>(nbr, n, npad, k1, v1, src, pos, tmask);
+  class_fill_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>(nbr, n, npad, groups, gk, k1, v1, src, pos, rows, tmask);
   TS_CHECK_LAUNCH("ts_conv_class_plan/fill");
-  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), npad, (int2 *)tile_info, n_tiles);
+  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), npad, rows ? 1 : 0, (int2 *)tile_info, n_tiles);
   TS_CHECK_LAUNCH("ts_conv_class_plan/tiles");
+  return TS_OK;
+}
+
+// inverse table of a kernel map for the plans of its transposed direction: nbr_t[k][i] = output row fed by input row i through
+// offset k (nbmaps[pos_in[k][i]].y) or -1
+__global__ __launch_bounds__(256) void class_nbr_t_kernel(const int *__restrict__ pos_in, const int2 *__restrict__ nbmaps,
+                                                         int64_t total, int *__restrict__ nbr_t) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int p = pos_in[e];
+  nbr_t[e] = p >= 0 ? nbmaps[p].y : -1;
+}
+
+extern "C" int ts_conv_nbr_transposed(const int32_t *pos_in, const int32_t *nbmaps, int32_t K, int64_t n_in, int32_t *nbr_t,
+                                      ts_stream_t stream) {
+  TS_REQUIRE(K > 0 && n_in >= 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_nbr_transposed: bad sizes");
+  if (n_in == 0) return TS_OK;
+  TS_REQUIRE(pos_in && nbmaps && nbr_t, TS_ERR_INVALID_ARGUMENT, "ts_conv_nbr_transposed: null pointer");
+  const int64_t total = (int64_t)K * n_in;
+  class_nbr_t_kernel<<<(unsigned)ts_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(pos_in, (const int2 *)nbmaps, total, nbr_t);
+  TS_CHECK_LAUNCH("ts_conv_nbr_transposed");
   return TS_OK;
 }
 
@@ -202,11 +236,18 @@ __device__ __forceinline__ bf8 cg_frag_tr(const unsigned short *img, int pitch, 
 
 // X [n, R] fp32 rows; W [K, R, O_total] (WT = false: forward) or [K, O_total, R] (WT = true: the input gradient multiplies with
 // the transposed slice of the MIRRORED offset); Zp [m_pad, O_total].  grid (upper bound of the tile count, O_total / BN).
+// gk offsets per group (k = gk * group + kl); mirror: the transposed product takes the slice of offset K-1-k (submanifold maps: the
+// map is its own transpose with the offsets reversed) instead of k (direct plans of a strided map: built for that direction);
+// rows != NULL (direct plans): list slot i is stored into row rows[i] of Zp (= the result itself), -1 = padding.
+// Workgroups with blockIdx.x >= tile_blocks (launched when side.K > 0) form the ordered sum of the weight-gradient partials of the
+// launch before this one (common.h) - the job that rides on pass 2 where there is one.
 template <int BN, int WR, bool WT>
 __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restrict__ X, int R, const float *__restrict__ W,
                                                            int O_total, const int *__restrict__ src, int64_t m_pad,
                                                            const int2 *__restrict__ tile_info,
-                                                           const int *__restrict__ n_tiles, int K, float *__restrict__ Zp) {
+                                                           const int *__restrict__ n_tiles, int K, int gk, int mirror,
+                                                           const int *__restrict__ rows, float *__restrict__ Zp,
+                                                           TsWgradReduce side, int tile_blocks) {
   constexpr int BM = CG_BM;
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
@@ -228,11 +269,27 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
   const int wr = wave / WC, wc = wave % WC;
   const int o0 = blockIdx.y * BN;
   const int tile = (int)blockIdx.x;             // launch order = list order (longest first): every XCD gets tiles of every length
+  if (tile >= tile_blocks) {                    // side job: ordered sum of the weight-gradient partials
+    if (blockIdx.y == 0) {
+      const int64_t step = (int64_t)(gridDim.x - tile_blocks) * 256;
+      for (int64_t i = (int64_t)(tile - tile_blocks) * 256 + tid; i < (int64_t)side.K * side.cacb4; i += step)
+        ts_wgrad_reduce_one(side, i);
+    }
+    return;
+  }
   if (tile >= *n_tiles) return;
   const int2 info = tile_info[tile];
   const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
   int mask = __builtin_amdgcn_readfirstlane(info.y);
   const int64_t row0 = (int64_t)(__builtin_amdgcn_readfirstlane(info.x) >> 2) * BM;
+  if (mask == 0) {                              // direct plans: a tile of rows without any neighbour - their result is zero
+    for (int e = tid; e < BM * (BN / 4); e += 256) {
+      const int r = e / (BN / 4), c4 = e - r * (BN / 4);
+      const int dst = rows ? rows[row0 + r] : (int)(row0 + r);
+      if (dst >= 0) *(f32x4 *)(Zp + (int64_t)dst * O_total + o0 + 4 * c4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
 
   const int arow0 = tid >> 2, acol = (tid & 3) << 3;
   int boff[B_IT], bdst[B_IT];
@@ -268,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) nsrc[it] = src[(int64_t)kl * m_pad + row0 + arow0 + 64 * it];
   };
-  auto bind = [&](int kl) {             // operand pointers of group offset kl: k = 9 grp + kl
-    const int k = CG_GK * grp + kl;
-    const int kw = WT ? (K - 1 - k) : k;
+  auto bind = [&](int kl) {             // operand pointers of group offset kl: k = gk grp + kl
+    const int k = gk * grp + kl;
+    const int kw = (WT && mirror) ? (K - 1 - k) : k;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       alive[it] = nsrc[it] >= 0;
@@ -373,6 +430,20 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
     if (!mask) break;
     mask &= mask - 1;
   }
+  if (rows) {                                   // direct plan: the sums ARE the result rows
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dst = rows[row0 + (wr * MI + mi) * 16 + 4 * g + q];
+        if (dst >= 0) {
+          float *zr = Zp + (int64_t)dst * O_total + o0 + r16;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) zr[(wc * NI + ni) * 16] = tot[mi][ni][q];
+        }
+      }
+    return;
+  }
   float *zt = Zp + row0 * O_total + o0;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -383,12 +454,23 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
         zt[(int64_t)((wr * MI + mi) * 16 + 4 * g + q) * O_total + (wc * NI + ni) * 16 + r16] = tot[mi][ni][q];
 }
 
+struct CgArgs {          // what a class-GEMM launch takes beyond operands and result
+  const int *src;
+  int64_t m_pad;
+  const int2 *tile_info;
+  const int *n_tiles;
+  int K, gk, mirror;
+  const int *rows;
+  TsWgradReduce side;    // side.K == 0: none
+};
+
 template <int BN, int WR, bool WT>
-static int launch_class(const float *X, int R, const float *W, int O_total, const int *src, int64_t m_pad, const int2 *tile_info,
-                        const int *n_tiles, int K, float *Zp, hipStream_t stream) {
+static int launch_class(const float *X, int R, const float *W, int O_total, const CgArgs &a, float *Zp, hipStream_t stream) {
   const size_t lds = (size_t)3 * (CG_BM * CG_AP + (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
-  dim3 grid((unsigned)(m_pad / CG_BM), (unsigned)(O_total / BN));
-  class_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, src, m_pad, tile_info, n_tiles, K, Zp);
+  const unsigned tiles = (unsigned)(a.m_pad / CG_BM);
+  dim3 grid(tiles + (a.side.K > 0 ? 64u : 0u), (unsigned)(O_total / BN));
+  class_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K, a.gk,
+                                                            a.mirror, a.rows, Zp, a.side, (int)tiles);
   TS_CHECK_LAUNCH("ts_conv_class_gemm");
   return TS_OK;
 }
@@ -399,24 +481,32 @@ extern "C" int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out) {
   return c_red > 0 && c_red % CG_BK == 0 && cg_tile_columns(c_out) != 0;
 }
 
-// zp [m_pad, c_out] = pass 1 of the convolution on the plan (wt = 0: feat = input rows, kernel [27, c_red, c_out]; wt = 1: input
-// gradient, feat = output-gradient rows [n, c_red], kernel [27, c_out, c_red] as stored, result columns = c_out = C_in)
-extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t c_out,
-                                  const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                                  float *zp, ts_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(K == CG_GROUPS * CG_GK, TS_ERR_UNSUPPORTED, "ts_conv_class_gemm: 27 offsets (3x3x3) only");
+static int cg_check(const char *what, int K, int groups, int c_red, int c_out, int64_t m_pad, const void *a, const void *b,
+                    const void *c, const void *src, const void *ti, const void *nt) {
+  TS_REQUIRE(groups >= 1 && groups <= CG_GROUPS && K > 0 && K % groups == 0 && K / groups <= CG_GK, TS_ERR_UNSUPPORTED,
+             "%s: K offsets must split into 1-3 groups of <= 9 (got K %d, groups %d)", what, K, groups);
   TS_REQUIRE(ts_conv_class_supported(c_red, c_out), TS_ERR_UNSUPPORTED,
-             "ts_conv_class_gemm: C_red must be a multiple of 32 and C_out of 32 (got %d, %d)", c_red, c_out);
-  TS_REQUIRE(feat && kernel && src && tile_info && n_tiles && zp, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_gemm: null pointer");
-  TS_REQUIRE(m_pad > 0 && m_pad % (CG_GROUPS * CG_BM) == 0 && m_pad < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_class_gemm: m_pad must be ts_conv_class_rows(n)");
-  TS_REQUIRE(((((uintptr_t)feat) | ((uintptr_t)kernel) | ((uintptr_t)zp)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_class_gemm: pointers must be 16-byte aligned");
-  const int2 *ti = (const int2 *)tile_info;
-#define CG_GO(BN, WR)                                                                                             \
-  (wt ? launch_class<BN, WR, true>(feat, c_red, kernel, c_out, src, m_pad, ti, n_tiles, K, zp, stream)            \
-      : launch_class<BN, WR, false>(feat, c_red, kernel, c_out, src, m_pad, ti, n_tiles, K, zp, stream))
+             "%s: C_red must be a multiple of 32 and C_out of 32 (got %d, %d)", what, c_red, c_out);
+  TS_REQUIRE(a && b && c && src && ti && nt, TS_ERR_INVALID_ARGUMENT, "%s: null pointer", what);
+  TS_REQUIRE(m_pad > 0 && m_pad % ((int64_t)groups * CG_BM) == 0 && m_pad < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
+             "%s: m_pad must be ts_conv_class_rows2(n, groups)", what);
+  TS_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "%s: pointers must be 16-byte aligned", what);
+  return TS_OK;
+}
+
+// library-internal form (csrc/block.hip): + the weight-gradient sum riding on the launch
+int ts_conv_class_gemm_ex(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                          const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                          int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = cg_check("ts_conv_class_gemm", K, groups, c_red, c_out, m_pad, feat, kernel, zp, src, tile_info, n_tiles);
+  if (rc != TS_OK) return rc;
+  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}};
+  if (side) a.side = *side;
+#define CG_GO(BN, WR)                                                                  \
+  (wt ? launch_class<BN, WR, true>(feat, c_red, kernel, c_out, a, zp, stream)          \
+      : launch_class<BN, WR, false>(feat, c_red, kernel, c_out, a, zp, stream))
   switch (cg_tile_columns(c_out)) {
     case 128: return CG_GO(128, 2);
     case 96: return CG_GO(96, 2);
@@ -424,6 +514,17 @@ extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float 
     default: return CG_GO(32, 4);
   }
 #undef CG_GO
+}
+
+// zp = pass 1 of the convolution on the plan (wt = 0: feat = input rows, kernel [K, c_red, c_out]; wt = 1: the transposed product,
+// feat = output-gradient rows [n, c_red], kernel [K, c_out, c_red] as stored, result columns = c_out = C_in; mirror = 1 takes the
+// slice of offset K-1-k: submanifold maps).  rows == NULL: zp [m_pad, c_out], one row per (destination row, group) - pass 2 is
+// ts_conv_gather_sum(zp, pos, groups); rows != NULL (direct plan, groups == 1): zp [n, c_out] IS the result.
+extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                                  const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                                  int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream) {
+  return ts_conv_class_gemm_ex(feat, c_red, kernel, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, rows, zp, nullptr,
+                               stream);
 }
 
 // ------------------------------------------------------------------------------------------- half storage
@@ -447,8 +548,9 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__
                                                              const _Float16 *__restrict__ W, int O_total,
                                                              const int *__restrict__ src, int64_t m_pad,
                                                              const int2 *__restrict__ tile_info,
-                                                             const int *__restrict__ n_tiles, int K,
-                                                             _Float16 *__restrict__ Zp) {
+                                                             const int *__restrict__ n_tiles, int K, int gk, int mirror,
+                                                             const int *__restrict__ rows, _Float16 *__restrict__ Zp,
+                                                             TsWgradReduce side, int tile_blocks) {
   constexpr int BM = CG_BM;
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
@@ -470,11 +572,28 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__
   const int wr = wave / WC, wc = wave % WC;
   const int o0 = blockIdx.y * BN;
   const int tile = (int)blockIdx.x;
+  if (tile >= tile_blocks) {                    // side job: ordered sum of the weight-gradient partials
+    if (blockIdx.y == 0) {
+      const int64_t step = (int64_t)(gridDim.x - tile_blocks) * 256;
+      for (int64_t i = (int64_t)(tile - tile_blocks) * 256 + tid; i < (int64_t)side.K * side.cacb4; i += step)
+        ts_wgrad_reduce_one(side, i);
+    }
+    return;
+  }
   if (tile >= *n_tiles) return;
   const int2 info = tile_info[tile];
   const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
   int mask = __builtin_amdgcn_readfirstlane(info.y);
   const int64_t row0 = (int64_t)(__builtin_amdgcn_readfirstlane(info.x) >> 2) * BM;
+  if (mask == 0) {                              // direct plans: rows without any neighbour
+    const ch8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < BM * (BN / 8); e += 256) {
+      const int r = e / (BN / 8), c8 = e - r * (BN / 8);
+      const int dst = rows ? rows[row0 + r] : (int)(row0 + r);
+      if (dst >= 0) *(ch8 *)(Zp + (int64_t)dst * O_total + o0 + 8 * c8) = zero;
+    }
+    return;
+  }
 
   const int arow0 = tid >> 2, acol = (tid & 3) << 3;
   int boff[B_IT], bdst[B_IT];
@@ -507,8 +626,8 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__
     for (int it = 0; it < A_IT; ++it) nsrc[it] = src[(int64_t)kl * m_pad + row0 + arow0 + 64 * it];
   };
   auto bind = [&](int kl) {
-    const int k = CG_GK * grp + kl;
-    const int kw = WT ? (K - 1 - k) : k;
+    const int k = gk * grp + kl;
+    const int kw = (WT && mirror) ? (K - 1 - k) : k;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       alive[it] = nsrc[it] >= 0;
@@ -593,40 +712,37 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__
   constexpr int CH = BN / 8;
   for (int e = tid; e < BM * CH; e += 256) {
     const int row = e / CH, ch = e - row * CH;
-    *(ch8 *)(Zp + (row0 + row) * O_total + o0 + ch * 8) = *(const ch8 *)&Zt[row * ZP + ch * 8];
+    const int64_t dst = rows ? (int64_t)rows[row0 + row] : row0 + row;      // direct plan: the destination row of the slot
+    if (dst >= 0) *(ch8 *)(Zp + dst * O_total + o0 + ch * 8) = *(const ch8 *)&Zt[row * ZP + ch * 8];
   }
 }
 
 template <int BN, int WR, bool WT>
-static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_total, const int *src, int64_t m_pad,
-                          const int2 *tile_info, const int *n_tiles, int K, _Float16 *Zp, hipStream_t stream) {
+static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_total, const CgArgs &a, _Float16 *Zp,
+                          hipStream_t stream) {
   const size_t stage = (size_t)2 * (CG_BM * CG_AP + (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
   const size_t ztile = (size_t)CG_BM * (BN + 8) * 2;
-  dim3 grid((unsigned)(m_pad / CG_BM), (unsigned)(O_total / BN));
-  class_gemm_h_kernel<BN, WR, WT><<<grid, 256, std::max(stage, ztile), stream>>>(X, R, W, O_total, src, m_pad, tile_info, n_tiles, K, Zp);
+  const unsigned tiles = (unsigned)(a.m_pad / CG_BM);
+  dim3 grid(tiles + (a.side.K > 0 ? 64u : 0u), (unsigned)(O_total / BN));
+  class_gemm_h_kernel<BN, WR, WT><<<grid, 256, std::max(stage, ztile), stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info,
+                                                                                 a.n_tiles, a.K, a.gk, a.mirror, a.rows, Zp,
+                                                                                 a.side, (int)tiles);
   TS_CHECK_LAUNCH("ts_conv_class_gemm_f16");
   return TS_OK;
 }
 
-// half rows: feat / zp IEEE half, w = the half weight [27, C_in, C_out] as stored (wt = 0: forward, read in place through the
-// transposing LDS load; wt = 1: input gradient, rows of the mirrored offset's slice = result columns)
-extern "C" int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t c_out,
-                                      const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles,
-                                      int32_t wt, void *zp, ts_stream_t stream_) {
+int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
+                              const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                              int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(K == CG_GROUPS * CG_GK, TS_ERR_UNSUPPORTED, "ts_conv_class_gemm_f16: 27 offsets (3x3x3) only");
-  TS_REQUIRE(ts_conv_class_supported(c_red, c_out), TS_ERR_UNSUPPORTED,
-             "ts_conv_class_gemm_f16: channel counts must be multiples of 32 (got %d, %d)", c_red, c_out);
-  TS_REQUIRE(feat && w && src && tile_info && n_tiles && zp, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_gemm_f16: null pointer");
-  TS_REQUIRE(m_pad > 0 && m_pad % (CG_GROUPS * CG_BM) == 0 && m_pad < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_class_gemm_f16: m_pad must be ts_conv_class_rows(n)");
-  TS_REQUIRE(((((uintptr_t)feat) | ((uintptr_t)w) | ((uintptr_t)zp)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_class_gemm_f16: pointers must be 16-byte aligned");
-  const int2 *ti = (const int2 *)tile_info;
+  const int rc = cg_check("ts_conv_class_gemm_f16", K, groups, c_red, c_out, m_pad, feat, w, zp, src, tile_info, n_tiles);
+  if (rc != TS_OK) return rc;
+  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}};
+  if (side) a.side = *side;
   const _Float16 *x = (const _Float16 *)feat, *wh = (const _Float16 *)w;
-#define CGH_GO(BN, WR)                                                                                                  \
-  (wt ? launch_class_h<BN, WR, true>(x, c_red, wh, c_out, src, m_pad, ti, n_tiles, K, (_Float16 *)zp, stream)          \
-      : launch_class_h<BN, WR, false>(x, c_red, wh, c_out, src, m_pad, ti, n_tiles, K, (_Float16 *)zp, stream))
+#define CGH_GO(BN, WR)                                                                         \
+  (wt ? launch_class_h<BN, WR, true>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)           \
+      : launch_class_h<BN, WR, false>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))
   switch (cg_tile_columns(c_out)) {
     case 128: return CGH_GO(128, 2);
     case 96: return CGH_GO(96, 2);
@@ -636,10 +752,11 @@ extern "C" int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const voi
 #undef CGH_GO
 }
 
-// One-shot and per thread (like ts_conv_planes_hint): the NEXT ts_conv_block_forward / ts_conv_block_backward of this thread
-// may run its forward product / input gradient on this plan when the block is a submanifold 3x3x3 convolution over `n` rows.
-thread_local TsClassHint g_ts_class_hint = {nullptr, nullptr, nullptr, nullptr, 0, 0};
-extern "C" void ts_conv_class_hint(const int32_t *src, const int32_t *tile_info, const int32_t *n_tiles, const int32_t *pos,
-                                   int64_t n, int64_t z_rows) {
-  g_ts_class_hint = TsClassHint{src, tile_info, n_tiles, pos, n, z_rows};
+// half rows: feat / zp IEEE half, w = the half weight [K, C_in, C_out] as stored (wt = 0: forward, read in place through the
+// transposing LDS load; wt = 1: the transposed product, rows of the (mirrored) offset's slice = result columns)
+extern "C" int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
+                                      const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles,
+                                      int32_t wt, int32_t mirror, const int32_t *rows, void *zp, ts_stream_t stream) {
+  return ts_conv_class_gemm_f16_ex(feat, c_red, w, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, rows, zp, nullptr,
+                                   stream);
 }

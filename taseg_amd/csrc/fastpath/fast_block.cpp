@@ -22,9 +22,6 @@ struct Api {
   decltype(&ts_conv_block_forward) forward = nullptr;
   decltype(&ts_conv_block_backward) backward = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
-  decltype(&ts_conv_planes_hint) planes_hint = nullptr;
-  decltype(&ts_conv_class_hint) class_hint = nullptr;
-  decltype(&ts_conv_block_addend_hint) addend_hint = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
   decltype(&ts_build_kmap_workspace_bytes) build_kmap_ws = nullptr;
@@ -80,6 +77,32 @@ void *const COMM_PRE = (void *)1, *const COMM_POST = (void *)2;
 inline void *ptr(const at::Tensor &t) { return t.defined() ? t.data_ptr() : nullptr; }
 inline void *optr(const c10::optional<at::Tensor> &t) { return (t.has_value() && t->defined()) ? t->data_ptr() : nullptr; }
 
+// A class plan of the block's kernel map as it crosses from Python: tensors (src, tile_info, n_tiles, pos | rows) and
+// meta (n, m_pad, z_rows, K, groups, mirror, direct); empty vectors = no plan.  map_id = the map's nboffs (plans are attributes
+// of the KernelMap object they were built from, taseg_amd/torchsparse/nn/functional.py).
+struct PlanRef {
+  TsClassPlan plan;
+  bool live = false;
+  PlanRef(const std::vector<at::Tensor> &t, const std::vector<int64_t> &m, const at::Tensor &nboffs) {
+    if (t.size() != 4 || m.size() != 7) return;
+    const bool direct = m[6] != 0;
+    plan.src = (const int32_t *)t[0].data_ptr();
+    plan.tile_info = (const int32_t *)t[1].data_ptr();
+    plan.n_tiles = (const int32_t *)t[2].data_ptr();
+    plan.pos = direct ? nullptr : (const int32_t *)t[3].data_ptr();
+    plan.rows = direct ? (const int32_t *)t[3].data_ptr() : nullptr;
+    plan.n = m[0];
+    plan.m_pad = m[1];
+    plan.z_rows = m[2];
+    plan.K = (int32_t)m[3];
+    plan.groups = (int32_t)m[4];
+    plan.mirror = (int32_t)m[5];
+    plan.map_id = nboffs.data_ptr();
+    live = true;
+  }
+  const TsClassPlan *get() const { return live ? &plan : nullptr; }
+};
+
 class ConvBlock : public torch::autograd::Function<ConvBlock> {
  public:
   static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, const at::Tensor &feats, const at::Tensor &weight,
@@ -91,9 +114,15 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             double momentum, double eps, bool relu, int64_t comm, bool half, int64_t stream,
                             const c10::optional<at::Tensor> &planes, bool passthrough,
                             const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
-                            const c10::optional<at::Tensor> &cls_src, const c10::optional<at::Tensor> &cls_tiles,
-                            const c10::optional<at::Tensor> &cls_count, const c10::optional<at::Tensor> &cls_pos,
-                            int64_t cls_rows) {
+                            const c10::optional<at::Tensor> &pf0, const c10::optional<at::Tensor> &pf1,
+                            const c10::optional<at::Tensor> &pf2, const c10::optional<at::Tensor> &pf3,
+                            const std::vector<int64_t> &plan_f_meta, const c10::optional<at::Tensor> &pd0,
+                            const c10::optional<at::Tensor> &pd1, const c10::optional<at::Tensor> &pd2,
+                            const c10::optional<at::Tensor> &pd3, const std::vector<int64_t> &plan_d_meta) {
+    // (the plans cross the autograd boundary as four optional tensors + their meta each: a fixed number of node inputs)
+    std::vector<at::Tensor> plan_f, plan_d;
+    if (pf0.has_value() && pf0->defined()) plan_f = {*pf0, *pf1, *pf2, *pf3};
+    if (pd0.has_value() && pd0->defined()) plan_d = {*pd0, *pd1, *pd2, *pd3};
     const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
     const bool split = comm == 0 && group_id >= 0;
     const auto dt = half ? at::kHalf : at::kFloat;
@@ -119,14 +148,10 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     float *st = stats.data_ptr<float>();
     at::Tensor pl;                       // pre-split planes of the weight (taseg_amd/planes.py); fp32 blocks only
     if (!half && have && planes->scalar_type() == at::kShort) pl = *planes;
-    if (pl.defined()) api.planes_hint(w32.data_ptr<float>(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
-    if (kept16) api.planes_hint(w32.data_ptr<float>(), w16.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
-    // plan of the class-sorted implicit GEMM of this block's kernel map (csrc/conv_class.hip), if the caller wants it used
-    const bool cls = !transposed && cls_src.has_value() && cls_src->defined() && cls_tiles.has_value() &&
-                     cls_count.has_value() && cls_pos.has_value();
-    if (cls)
-      api.class_hint((const int32_t *)cls_src->data_ptr(), (const int32_t *)cls_tiles->data_ptr(),
-                     (const int32_t *)cls_count->data_ptr(), (const int32_t *)cls_pos->data_ptr(), cls_pos->size(1), cls_rows);
+    // everything the call may use beyond the rulebook, explicitly (TsConvBlockOpts): the class plans of this block's kernel map
+    // (csrc/conv_class.hip), the pre-split planes / the kept half copy of the weight
+    const PlanRef pf(plan_f, plan_f_meta, nboffs);
+    TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr};
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
@@ -134,7 +159,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                         (const float *)bn_bias.data_ptr(), (float *)optr(running_mean), (float *)optr(running_var),
                         (int64_t *)optr(nbt), (float)eps, (float)momentum, relu ? 1 : 0, half ? 1 : 0, c,
                         (double *)ptr(pack), conv_out.data_ptr(), st, st + c_out, out.data_ptr(), (uint8_t *)ptr(mask), ptr(w16),
-                        ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
+                        &bopts, ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
             "ts_conv_block_forward");
     };
     if (split) {
@@ -146,8 +171,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     }
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
-    ctx->saved_data["cls"] = cls ? c10::List<at::Tensor>({*cls_src, *cls_tiles, *cls_count, *cls_pos}) : c10::List<at::Tensor>();
-    ctx->saved_data["cls_rows"] = cls_rows;
+    ctx->saved_data["plan_d"] = c10::List<at::Tensor>(plan_d);        // the input gradient's plan (tensors + meta)
+    ctx->saved_data["plan_d_meta"] = c10::List<int64_t>(plan_d_meta);
     // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
     ctx->saved_data["grad_dest"] = (grad_dest.has_value() && grad_dest->defined()) ? *grad_dest : at::Tensor();
     ctx->saved_data["total"] = total;
@@ -205,14 +230,19 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor ws = workspace(nb, x, stream);
     const float *st = stats.data_ptr<float>();
     float *gw = gwb.data_ptr<float>();
+    const at::Tensor pl = ctx->saved_data["planes"].toTensor();
+    const std::vector<at::Tensor> plan_d = ctx->saved_data["plan_d"].toTensorVector();
+    const std::vector<int64_t> plan_d_meta = ctx->saved_data["plan_d_meta"].toIntVector();
+    const PlanRef pd(grad_feat.defined() ? plan_d : std::vector<at::Tensor>(), plan_d_meta, nboffs);
+    TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr};
     auto call = [&](void *c) {
       check(api.backward(g.data_ptr(), (const uint8_t *)ptr(mask), conv_out.data_ptr(), st, st + c_out,
                          (const float *)bn_weight.data_ptr(), pack.defined() ? pack.data_ptr<double>() + 2 * c_out : nullptr,
                          c, (double *)ptr(sums), rows, (int32_t)c_out, half ? 1 : 0, x.data_ptr(), x.size(0),
                          (int32_t)c_in, w.data_ptr(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
                          (const int32_t *)nboffs.data_ptr(), total, transposed ? 0 : 1, (const int32_t *)table.data_ptr(), drows,
-                         transposed ? 1 : 0, ptr(grad_feat), ptr(grad_res), (float *)ptr(grad_w), gw, gw + c_out, ws.data_ptr(),
-                         (size_t)ws.numel(), (ts_stream_t)stream),
+                         transposed ? 1 : 0, ptr(grad_feat), ptr(grad_res), (float *)ptr(grad_w), gw, gw + c_out, &bopts,
+                         ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
             "ts_conv_block_backward");
     };
     if (split) {
@@ -223,23 +253,15 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (grads.size() > 1 && grads[1].defined() && grad_feat.defined()) {
       addend = grads[1].contiguous().to(conv_out.scalar_type());
       TORCH_CHECK(addend.sizes() == grad_feat.sizes(), "conv_block: pass-through gradient has the wrong shape");
-      api.addend_hint(addend.data_ptr());
-    }
-    const at::Tensor pl = ctx->saved_data["planes"].toTensor();
-    if (pl.defined() && !half && grad_feat.defined())
-      api.planes_hint((const float *)w.data_ptr(), pl.data_ptr(), (int32_t)k, (int32_t)c_in, (int32_t)c_out);
-    const auto cls = ctx->saved_data["cls"].toTensorList();
-    if (cls.size() == 4 && grad_feat.defined()) {
-      const at::Tensor c0 = cls.get(0), c1 = cls.get(1), c2 = cls.get(2), c3 = cls.get(3);
-      api.class_hint((const int32_t *)c0.data_ptr(), (const int32_t *)c1.data_ptr(), (const int32_t *)c2.data_ptr(),
-                     (const int32_t *)c3.data_ptr(), c3.size(1), ctx->saved_data["cls_rows"].toInt());
+      bopts.addend = addend.data_ptr();
     }
     call(split ? COMM_POST : (void *)comm);
     if (grad_feat.defined() && grad_feat.scalar_type() != in_dtype) grad_feat = grad_feat.to(in_dtype);
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none,
+            none, none, none, none, none, none};
   }
 };
 
@@ -253,11 +275,7 @@ void load_backend(const std::string &libpath) {
   api.forward = (decltype(api.forward))dlsym(h, "ts_conv_block_forward");
   api.backward = (decltype(api.backward))dlsym(h, "ts_conv_block_backward");
   api.last_error = (decltype(api.last_error))dlsym(h, "ts_last_error");
-  api.planes_hint = (decltype(api.planes_hint))dlsym(h, "ts_conv_planes_hint");
-  api.class_hint = (decltype(api.class_hint))dlsym(h, "ts_conv_class_hint");
-  api.addend_hint = (decltype(api.addend_hint))dlsym(h, "ts_conv_block_addend_hint");
-  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.planes_hint && api.addend_hint && api.class_hint,
-              "libtaseg_hip.so lacks the ts_conv_block_* / ts_conv_planes_hint / ts_conv_block_addend_hint entry points");
+  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward, "libtaseg_hip.so lacks the ts_conv_block_* entry points");
 #define TS_BIND(field, sym)                                      \
   api.field = (decltype(api.field))dlsym(h, sym);                \
   TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
@@ -281,12 +299,16 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       double eps, bool relu, int64_t comm, bool half, int64_t stream,
                       const c10::optional<at::Tensor> &planes, bool passthrough,
                       const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
-                      const c10::optional<at::Tensor> &cls_src, const c10::optional<at::Tensor> &cls_tiles,
-                      const c10::optional<at::Tensor> &cls_count, const c10::optional<at::Tensor> &cls_pos, int64_t cls_rows) {
+                      const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta,
+                      const std::vector<at::Tensor> &plan_d, const std::vector<int64_t> &plan_d_meta) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  TORCH_CHECK((plan_f.empty() || plan_f.size() == 4) && (plan_d.empty() || plan_d.size() == 4),
+              "conv_block: a plan is (src, tile_info, n_tiles, pos | rows)");
+  auto at_ = [](const std::vector<at::Tensor> &v, size_t i) { return v.size() == 4 ? c10::optional<at::Tensor>(v[i]) : c10::nullopt; };
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
-                          passthrough, grad_dest, group_id, cls_src, cls_tiles, cls_count, cls_pos, cls_rows);
+                          passthrough, grad_dest, group_id, at_(plan_f, 0), at_(plan_f, 1), at_(plan_f, 2), at_(plan_f, 3),
+                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta);
 }
 
 // torch.distributed process group -> the index conv_block takes as `group_id` (SyncBatchNorm's all-reduce through c10d)

@@ -374,7 +374,10 @@ __global__ __launch_bounds__(256) void ce_lovasz_bwd_kernel(const float *__restr
     if (c < C) {
       const float onehot = lab == c ? 1.f : 0.f;
       const float ce = (1.f - smoothing) * (pr[c] - onehot) + smoothing * (pr[c] - invc);
-      dlogits[p * C + c] = kce * ce + klov * pr[c] * (dp[c] - dot);
+      // a label outside [0, C) that is not the ignore index poisons the row's gradient like it poisons the forward loss (the
+      // reference device-asserts, R/pcseg/loss/__init__.py:40-44 -> F.cross_entropy): the optimizer must not step on it
+      const bool bad = lab != ignore && (lab < 0 || lab >= C);
+      dlogits[p * C + c] = bad ? __builtin_nanf("") : kce * ce + klov * pr[c] * (dp[c] - dot);
     }
 }
 

@@ -72,17 +72,27 @@ class GradBucketReducer:
         loss.backward()                               # hooks launch a bucket's all-reduce when it is complete
         reducer.finish()                              # before clip / optimizer.step(): wait for the collectives
 
-    Pass a dedicated `process_group` (dist.new_group()) when other small collectives (SyncBatchNorm) run during
-    backward: collectives of one communicator execute in order on one stream.
+    The buckets' all-reduces run on a communicator of their OWN: `process_group`, or - when none is given and there is
+    more than one rank - a group created here (every rank constructs its reducer, so every rank makes the collective
+    `dist.new_group()` call).  SyncBatchNorm's statistics all-reduces run during backward on the default group / the
+    library-owned communicator; sharing one communicator would make the program order of bucket and statistics
+    collectives depend on when each rank's gradients happen to be complete.
+    Launch order is the bucket index on every rank: bucket i is launched only after buckets 0..i-1 (a bucket that is
+    complete earlier waits; what backward leaves incomplete - parameters unused on this rank - is launched by finish()
+    in index order).  Which parameters receive a gradient may differ between ranks; the sequence of collectives may not.
     Buckets follow reverse registration order (roughly the order gradients appear).  Parameters that received no
     gradient in a step are reduced as zeros (every rank must contribute the same buffer) and listed in
     bucket["unused"] so that the optimizer can leave them untouched like torch.optim.SGD does.  Contract: ONE backward
     pass per finish(); a second one raises.  Works with any backend (RCCL on GPU, gloo in the CPU tests)."""
 
     def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: float = 32.0, broadcast: bool = True):
-        self.group = process_group
         # also usable without a process group (one process): the buckets then only flatten the gradients
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if live else 1
+        if live and process_group is None and self.world > 1 and os.environ.get("TASEG_DIST_BUCKETS_ON_DEFAULT_GROUP") != "1":
+            process_group = dist.new_group(backend=dist.get_backend())
+        self.group = process_group
+        self._next = 0              # index of the next bucket to launch (launch order = index order on every rank)
         params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []
         cur, cur_bytes = [], 0
@@ -136,8 +146,10 @@ class GradBucketReducer:
                 raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket whose all-reduce was already "
                                    "launched - exactly one backward pass per finish() / optimizer step is supported")
             bucket["pending"] -= 1
-            if bucket["pending"] == 0:
-                self._launch(bucket)
+            # in index order only: a complete bucket behind an incomplete one waits for it (or for finish())
+            while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+                self._launch(self.buckets[self._next])
+                self._next += 1
         return hook
 
     def _launch(self, bucket):
@@ -163,9 +175,10 @@ class GradBucketReducer:
 
     def finish(self):
         """Launch what backward left incomplete (unused parameters), wait for every collective, re-arm."""
-        for b in self.buckets:
+        for b in self.buckets[self._next:]:          # index order, like the launches during backward
             if not b["launched"]:
                 self._launch(b)
+        self._next = 0
         for w in self._works:
             w.wait()
         self._works = []

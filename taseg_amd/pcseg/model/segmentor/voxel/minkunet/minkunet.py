@@ -261,6 +261,7 @@ class MinkUNetBackbone(BaseSegmentor):
                 if lvl < 4:
                     km = spF.KernelMap(dict(zip(names, down_t[lvl])), (cm[lvl].shape[0], cm[lvl + 1].shape[0]))
                     km._total = int(totals[2 * lvl + 1])
+                    km.build_direct_plans()               # 2x2x2 strided map: one-pass plans of its two directions
                     kmaps[((s, s, s), (2, 2, 2), (2, 2, 2), (1, 1, 1))] = km
             keys = ((1, 1, 1), (16, 16, 16), (4, 4, 4))
             tri_idx, tri_w = dict(zip(keys, t_idx)), dict(zip(keys, t_w))
@@ -276,6 +277,8 @@ class MinkUNetBackbone(BaseSegmentor):
             for key, km in probe.kmaps.items():
                 if key[1] == (3, 3, 3) and key[2] == (1, 1, 1):
                     km.build_class_plan()
+                elif key[1] == key[2] == (2, 2, 2):
+                    km.build_direct_plans()
             tri_idx, tri_w, tri_order = {}, {}, {}
             pc = point_coords.contiguous()
             for s in (1, 16, 4):

@@ -63,13 +63,12 @@ def _create(group):
 
 
 def single_communicator() -> bool:
-    """TASEG_DIST_SINGLE_COMM (default 1): every collective of a training step - SyncBatchNorm statistics and the
-    gradient-bucket all-reduces - goes through ONE communicator, torch.distributed's default process group, in one
-    program order on one stream: the arrangement of the reference (DDP + nn.SyncBatchNorm on the default group,
-    R/train.py:247-251).  It is the default until the two-communicator arrangement (a library-owned RCCL communicator
-    for SyncBatchNorm on the compute stream beside c10d's for the buckets: ~1 ms per step faster on one rank) has run
-    with more than one rank on real devices - tests/test_gpu_dist.py::test_two_ranks_rccl needs two GPUs and has been
-    skipped on every box so far.  TASEG_DIST_SINGLE_COMM=0 selects the fast arrangement."""
+    """TASEG_DIST_SINGLE_COMM (default 1): SyncBatchNorm's statistics all-reduces go through torch.distributed's default
+    process group (c10d, on the compute stream) like nn.SyncBatchNorm under DDP in the reference (R/train.py:247-251); the
+    gradient buckets always use a communicator of their own (parallel.GradBucketReducer), launched in bucket-index order.
+    TASEG_DIST_SINGLE_COMM=0 moves the statistics onto a library-owned RCCL communicator inline on the compute stream
+    (~1 ms per step faster on one rank) - not the default until it has run with more than one rank on real devices
+    (tests/test_gpu_dist.py::test_two_ranks_rccl needs two GPUs and has been skipped on every box so far)."""
     return os.environ.get("TASEG_DIST_SINGLE_COMM", "1") != "0"
 
 

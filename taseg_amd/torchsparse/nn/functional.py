@@ -229,6 +229,7 @@ class KernelMap:
         self._nbmaps = None
         self._total = None
         self.cls = None                       # plan of the class-sorted implicit GEMM (csrc/conv_class.hip), large 3x3x3 maps
+        self.direct = None                    # {"down", "up"}: direct plans of a 2x2x2 strided map (no Z, no pass 2)
 
     def build_class_plan(self):
         """Plan of the class-sorted implicit GEMM for a SUBMANIFOLD 3x3x3 map (in == out; the caller knows): rows sorted by
@@ -242,9 +243,38 @@ class KernelMap:
             # every tile walk all nine offsets of its group with most rows absent (up to 3.7 P row-products): two passes then
             tiles, steps = cls["n_tiles"].tolist()
             cls["z_rows"], cls["steps"] = 128 * tiles, steps
+            cls["map_id"], cls["pairs"] = self.nboffs, self.total          # the identity of the map the plan belongs to
             if 128 * steps <= _CLASS_MAX_WORK * self.total:
                 self.cls = cls
         return self.cls
+
+    def build_direct_plans(self):
+        """The two DIRECT plans of a 2x2x2 strided map (csrc/conv_class.hip): every destination row holds all its offsets in one
+        tile, so the class GEMM stores the result rows themselves - no Z, no pass 2.  "down": destination = the map's output
+        (coarse) rows, fed by its input (fine) rows - the strided forward and the transposed convolution's input gradient;
+        "up": destination = the fine rows (each has exactly one pair) - the transposed forward and the strided
+        convolution's input gradient (convolution_cuda.cu:21,34: transpose swaps the map's columns).  No host read."""
+        k = self.nbr.shape[0]
+        if _DIRECT_CONV and self.direct is None and k <= 9 and min(self.sizes) >= _DIRECT_MIN_ROWS and self.total > 0:
+            down = B.conv_class_plan(self.nbr, direct=True)
+            up = B.conv_class_plan(B.conv_nbr_transposed(self.pos_in, self.nbmaps_buf, k), direct=True)
+            for plan in (down, up):
+                plan["map_id"], plan["pairs"] = self.nboffs, self.total
+            self.direct = {"down": down, "up": up}
+        return self.direct
+
+    def plans_for(self, transposed: bool, c_in: int, c_out: int, half: bool):
+        """(forward plan, input-gradient plan) of a convolution over this map with these channel counts - either may be None
+        (pair GEMM + pass 2).  Submanifold 3x3x3: the one mirrored plan for both where class_gemm_pays; 2x2x2 strided: the direct
+        plans of the two directions."""
+        if not _dense_ok(c_in, c_out):
+            return None, None
+        if self.cls is not None and not transposed and class_gemm_pays(self.cls["n"], c_in, c_out, half):
+            return self.cls, self.cls
+        if self.direct is not None:
+            d = self.direct
+            return (d["up"], d["down"]) if transposed else (d["down"], d["up"])
+        return None, None
 
     def class_rows(self) -> int:
         return 0 if self.cls is None else self.cls["z_rows"]
@@ -282,10 +312,14 @@ class KernelMap:
 # 1.4-1.65x on the 178k-voxel stride-1 maps and the 32 / 64-wide stride-2 layers, 1.1-1.3x on the 84k-voxel 96-wide ones,
 # 1.1x on 30k voxels x 64 channels, a loss on 30k x 128 and below.  TASEG_CLASS_GEMM=0 keeps every block on the two passes.
 _CLASS_GEMM = os.environ.get("TASEG_CLASS_GEMM", "1") != "0"
-_CLASS_MIN_ROWS = 16384
+_CLASS_MIN_ROWS = 16384          # <= 64 channels (module attributes: tests force them down to pin the class path at model level)
+_CLASS_MIN_ROWS_96 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_96", "48000"))
 _CLASS_MIN_ROWS_128 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_128", "60000"))
 _CLASS_MAX_WORK = 1.6        # a class plan is used while its row-products stay under 1.6x the rulebook's pairs
 _CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
+# one-pass 2x2x2 strided / transposed convolutions on direct class plans (TASEG_DIRECT_CONV=0: pair GEMM + pass 2)
+_DIRECT_CONV = os.environ.get("TASEG_DIRECT_CONV", "1") != "0"
+_DIRECT_MIN_ROWS = int(os.environ.get("TASEG_DIRECT_MIN_ROWS", "0"))
 
 
 def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> bool:
@@ -294,18 +328,7 @@ def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> b
     if max(c_in, c_out) <= 64:
         return n_rows >= _CLASS_MIN_ROWS
     cols128 = any(c % 128 == 0 and c % 96 != 0 for c in (c_in, c_out))       # a direction on 128-column tiles (direct-rows pair GEMM)
-    return n_rows >= (_CLASS_MIN_ROWS_128 if cols128 else 48000)
-
-
-def class_hint(kmap, c_in: int, c_out: int, profiling: bool = False, half: bool = False) -> bool:
-    """One-shot: let the NEXT block call of this thread run its product / input gradient on kmap's class plan."""
-    cls = kmap.cls
-    if cls is None or not class_gemm_pays(cls["n"], c_in, c_out, half):
-        return False
-    z_rows = kmap.class_rows() if profiling else cls["z_rows"]
-    B.L.load().ts_conv_class_hint(cls["src"].data_ptr(), cls["tile_info"].data_ptr(), cls["n_tiles"].data_ptr(),
-                                  cls["pos"].data_ptr(), cls["n"], z_rows)
-    return True
+    return n_rows >= (_CLASS_MIN_ROWS_128 if cols128 else _CLASS_MIN_ROWS_96)
 
 
 def build_kernel_map(in_coords, out_coords, kernel_size, tensor_stride, dilation=1) -> KernelMap:
@@ -366,15 +389,21 @@ class _SparseConv(Function):
         want_half = _amp_half(feats)
         half = want_half and _half_ok(weight.shape[1], weight.shape[2])
         gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
-        # large submanifold 3x3x3 maps: class-sorted implicit GEMM (csrc/conv_class.hip) in place of pair GEMM + 27-way pass 2
-        cls = kmap.cls if (not transposed and kmap.cls is not None and _dense_ok(weight.shape[1], weight.shape[2]) and
-                           class_gemm_pays(kmap.cls["n"], weight.shape[1], weight.shape[2], half)) else None
+        # class plans (csrc/conv_class.hip): large submanifold 3x3x3 maps in place of pair GEMM + 27-way pass 2; 2x2x2 strided /
+        # transposed maps in ONE pass (direct plans)
+        cls, cls_d = kmap.plans_for(transposed, weight.shape[1], weight.shape[2], half)
+
+        def finish(z, plan, n_rows, f16):
+            if plan["rows"] is not None:
+                return z                          # direct plan: the product IS the result
+            return (B.conv_gather_sum_f16 if f16 else B.conv_gather_sum)(z, plan["pos"], n_rows)
+
         with _no_autocast():
             if half:
                 fh = feats.contiguous().half()
                 w16, _ = B.cast_weights_f16(weight.detach().float(), want=(True, False))
                 if cls is not None:
-                    out = B.conv_gather_sum_f16(B.conv_class_gemm_f16(fh, w16, cls), cls["pos"], rows)
+                    out = finish(B.conv_class_gemm_f16(fh, w16, cls), cls, rows, True)
                 else:
                     z = B.conv_pair_gemm_f16(fh, w16, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol, natural=True)
                     out = B.conv_gather_sum_f16(z, table, rows)
@@ -385,7 +414,7 @@ class _SparseConv(Function):
                 if w32.data_ptr() != weight.data_ptr():
                     planes = None             # a converted copy: the planes belong to the parameter's own storage
                 if cls is not None:
-                    out = B.conv_gather_sum(B.conv_class_gemm(f32, w32, cls), cls["pos"], rows)
+                    out = finish(B.conv_class_gemm(f32, w32, cls), cls, rows, False)
                 else:
                     _planes.hint(w32, planes)
                     z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
@@ -395,7 +424,7 @@ class _SparseConv(Function):
                     out = out.half()          # stem (C_in = 4 / 5): fp32 kernels, half result like the reference
         ctx.kmap, ctx.transposed, ctx.half, ctx.in_dtype = kmap, transposed, half, feats.dtype
         ctx.planes = None if half else planes
-        ctx.cls = cls
+        ctx.cls = cls_d
         return out
 
     @staticmethod
@@ -412,7 +441,7 @@ class _SparseConv(Function):
                 gh = grad_out.contiguous().half()
                 if ctx.needs_input_grad[0] and ctx.cls is not None:
                     z = B.conv_class_gemm_f16(gh, weight, ctx.cls, weight_transposed=True)
-                    grad_feats = B.conv_gather_sum_f16(z, ctx.cls["pos"], rows).to(ctx.in_dtype)
+                    grad_feats = (z if ctx.cls["rows"] is not None else B.conv_gather_sum_f16(z, ctx.cls["pos"], rows)).to(ctx.in_dtype)
                 elif ctx.needs_input_grad[0]:
                     # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T: rows of W_k (= w16) are the output columns
                     z = B.conv_pair_gemm_f16(gh, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
@@ -424,7 +453,7 @@ class _SparseConv(Function):
                 g32 = grad_out.contiguous().float()
                 if ctx.needs_input_grad[0] and ctx.cls is not None:
                     z = B.conv_class_gemm(g32, weight, ctx.cls, weight_transposed=True)
-                    grad_feats = B.conv_gather_sum(z, ctx.cls["pos"], rows).to(ctx.in_dtype)
+                    grad_feats = (z if ctx.cls["rows"] is not None else B.conv_gather_sum(z, ctx.cls["pos"], rows)).to(ctx.in_dtype)
                 elif ctx.needs_input_grad[0]:
                     _planes.hint(weight, ctx.planes)
                     z = B.conv_pair_gemm(g32, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol,
@@ -668,8 +697,12 @@ def conv_geometry(input: SparseTensor, kernel_size, stride, dilation, transposed
         key = (input.stride, kernel_size, stride, dilation)
         if key not in input.kmaps:
             km = build_kernel_map(input.coords, out_coords, kernel_size, input.stride, dilation)
-            if stride == ones and tuple(kernel_size) == (3, 3, 3):
+            # (a class plan's input gradient relies on the map being its own transpose: only for a map over ONE coordinate set -
+            # equal row counts of a user-provided cmaps entry do not make it one)
+            if stride == ones and tuple(kernel_size) == (3, 3, 3) and out_coords.data_ptr() == input.coords.data_ptr():
                 km.build_class_plan()     # a map made on demand (UNet3D of the TIAF models, user code): large ones get their class plan
+            elif tuple(stride) == tuple(kernel_size) == (2, 2, 2):
+                km.build_direct_plans()   # 2x2x2 strided map: one-pass plans of its two directions
             input.kmaps[key] = km
         return input.kmaps[key], out_coords, out_stride
     out_stride = tuple(input.stride[k] // stride[k] for k in range(3))
@@ -690,6 +723,14 @@ _COMM_PRE, _COMM_POST = _ctypes.c_void_p(1), _ctypes.c_void_p(2)      # split-ca
 
 
 from ...rccl import c10d_sum as _c10d_sum  # noqa: E402
+
+
+def _block_opts(plan_f, plan_d, planes, w16_current, addend):
+    """TsConvBlockOpts of one block call (the struct only holds pointers: the caller keeps the tensors alive over the call)"""
+    LB = B.L
+    pf = None if plan_f is None else _ctypes.pointer(B.class_plan_struct(plan_f))
+    pd = None if plan_d is None else _ctypes.pointer(B.class_plan_struct(plan_d))
+    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend))
 
 
 class _ConvBlock(Function):
@@ -725,17 +766,20 @@ class _ConvBlock(Function):
         pack = torch.empty(2 * c_out + 1, dtype=torch.float64, device=dev) if (comm is not None or split) else None
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+        # everything the call may use beyond the rulebook, explicitly (include/taseg_hip.h TsConvBlockOpts): the class plans of
+        # THIS kernel map (large submanifold maps: class-sorted implicit GEMM; 2x2x2 maps: direct one-pass plans), the pre-split
+        # planes / the kept half copy of the weight
+        plan_f, plan_d = kmap.plans_for(transposed, c_in, c_out, half)
+        opts = _block_opts(plan_f, plan_d, None if half else planes, half and planes is not None, None)
+
         def call(c):
             L.check(lib.ts_conv_block_forward(
                 L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol,
                 L.ptr(table), rows, c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
                 L.ptr(running_var), L.ptr(nbt), float(eps), float(momentum), 1 if relu else 0, 1 if half else 0, c,
-                L.ptr(pack), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(out), L.ptr(mask), L.ptr(w16), L.ptr(ws),
-                ws.numel(), L.stream()), "ts_conv_block_forward")
+                L.ptr(pack), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(out), L.ptr(mask), L.ptr(w16),
+                _ctypes.byref(opts), L.ptr(ws), ws.numel(), L.stream()), "ts_conv_block_forward")
 
-        _planes.hint(w32, planes)
-        if not transposed:
-            class_hint(kmap, c_in, c_out, B._prof is not None, half)      # large submanifold maps: class-sorted implicit GEMM
         if split:
             call(_COMM_PRE)                       # convolution + this rank's sums
             _c10d_sum(pack, group)
@@ -746,6 +790,7 @@ class _ConvBlock(Function):
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
         ctx.group = group if split else None
         ctx.planes = None if half else planes
+        ctx.plan_d = plan_d
         ctx.grad_dest = grad_dest        # where the weight gradient is wanted (a gradient bucket's view), or None
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
         ctx.in_dtype, ctx.res_dtype = feats.dtype, (None if residual is None else residual.dtype)
@@ -784,24 +829,20 @@ class _ConvBlock(Function):
         total = kmap.total
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
 
+        addend = grad_pass.contiguous().to(dt) if (grad_pass is not None and grad_feat is not None) else None
+        opts = _block_opts(None, ctx.plan_d if grad_feat is not None else None, None if half else ctx.planes, False, addend)
+
         def call(c):
             L.check(lib.ts_conv_block_backward(
                 L.ptr(g), L.ptr(mask), L.ptr(conv_out), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn_weight),
                 L.ptr(ctx.total_dev), c, L.ptr(sums), rows, c_out, 1 if half else 0, L.ptr(x), x.shape[0], c_in, L.ptr(w), k,
                 L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), drows, 1 if transposed else 0,
-                L.ptr(grad_feat), L.ptr(grad_res), L.ptr(grad_w), L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), ws.numel(),
-                L.stream()), "ts_conv_block_backward")
+                L.ptr(grad_feat), L.ptr(grad_res), L.ptr(grad_w), L.ptr(gwb[0]), L.ptr(gwb[1]), _ctypes.byref(opts), L.ptr(ws),
+                ws.numel(), L.stream()), "ts_conv_block_backward")
 
         if split:
             call(_COMM_PRE)                       # this rank's sums of the BatchNorm backward
             _c10d_sum(sums, ctx.group)
-        if grad_feat is not None and not half:
-            _planes.hint(w, ctx.planes)
-        if grad_feat is not None and not transposed:
-            class_hint(kmap, c_in, c_out, B._prof is not None, half)
-        if grad_pass is not None and grad_feat is not None:
-            addend = grad_pass.contiguous().to(dt)
-            lib.ts_conv_block_addend_hint(L.ptr(addend))
         call(_COMM_POST if split else comm)
         if grad_feat is not None and grad_feat.dtype != ctx.in_dtype:
             grad_feat = grad_feat.to(ctx.in_dtype)

@@ -153,16 +153,17 @@ def _claim_grad_dest(kernel):
     return dest
 
 
-_NO_CLASS = (None, None, None, None, 0)
+_NO_PLAN = ([], [])
 
 
-def _class_args(kmap, conv, half):
-    """(src, tile_info, n_tiles, pos, z_rows) of kmap's class plan when this submanifold block gains from the class-sorted
-    implicit GEMM (functional.class_gemm_pays; fp32 and half storage), else five placeholders - the C++ node hands them on as ts_conv_class_hint"""
-    cls = kmap.cls
-    if cls is None or conv.transposed or not F.class_gemm_pays(cls["n"], conv.kernel.shape[1], conv.kernel.shape[2], half):
-        return _NO_CLASS
-    return cls["src"], cls["tile_info"], cls["n_tiles"], cls["pos"], (kmap.class_rows() if _B._prof is not None else cls["z_rows"])
+def _plan_args(plan):
+    """(tensors, meta) of a class plan for the C++ node: (src, tile_info, n_tiles, pos | rows) and (n, m_pad, z_rows, K, groups,
+    mirror, direct) - or two empty lists"""
+    if plan is None:
+        return _NO_PLAN
+    direct = plan["rows"] is not None
+    return ([plan["src"], plan["tile_info"], plan["n_tiles"], plan["rows"] if direct else plan["pos"]],
+            [plan["n"], plan["m_pad"], int(plan.get("z_rows") or 0), plan["K"], plan["groups"], plan["mirror"], 1 if direct else 0])
 
 
 def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None,
@@ -201,12 +202,14 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
             planes = _planes.half_for(conv.kernel) if half else _planes.planes_for(conv.kernel)
             dest = _claim_grad_dest(conv.kernel)                            # bucket slot of the weight gradient (parallel.py)
             c10d_group = group if (group is not None and comm is None) else None
+            # class plans of this kernel map for the forward product / the input gradient (functional.KernelMap.plans_for)
+            plan_f, plan_d = kmap.plans_for(conv.transposed, conv.kernel.shape[1], conv.kernel.shape[2], half)
             if fast is not None:                          # C++ autograd node, same backend calls (csrc/fastpath)
                 out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
                                       kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
                                       state[1], state[2], float(mod.momentum), float(mod.eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
-                                      bool(passthrough), dest, _group_id(fast, c10d_group), *_class_args(kmap, conv, half))
+                                      bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d))
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
                 out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,

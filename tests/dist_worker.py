@@ -127,8 +127,7 @@ def main():
     scan = make_scan(41 + rank)
     amp = os.environ.get("TASEG_WORKER_AMP") == "1"
     # TASEG_DIST_SINGLE_COMM (default): buckets and SyncBatchNorm share the default group, as in bench.py
-    from taseg_amd.rccl import single_communicator
-    group = None if single_communicator() else dist.new_group(backend=backend)
+    group = dist.new_group(backend=backend)      # the buckets' own communicator, as bench.py passes it
     out.update(pack("", *one_step(build(True), [scan], group, amp=amp)))
     direct = rccl.direct_comm(dist.group.WORLD)
     out["direct_rccl"] = np.int64(1 if direct is not None else 0)

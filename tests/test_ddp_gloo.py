@@ -184,3 +184,60 @@ def test_unused_parameter_decision_is_global():
         assert u0 == ["nobody"] and u1 == ["nobody", "one_rank_only"]      # the rank-local lists differ ...
         assert g0 == g1 and any(abs(v) > 0 for v in g0)                    # ... the averaged gradient does not
         assert n0 == n1 == [0.0, 0.0, 0.0]
+
+
+def _order_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    P.init_distributed(backend="gloo")
+    net = _net()
+    # registered LAST = first bucket (reverse registration order): rank 0 alone uses it, so on rank 0 the bucket is complete
+    # early in backward while rank 1 only completes it in finish()
+    tail = torch.nn.Module()
+    tail.register_parameter("one_rank_only", torch.nn.Parameter(torch.ones(5)))
+    net.add_module("tail", tail)                    # (a module's own parameters come FIRST in parameters(), a child's last)
+    # ONE parameter per bucket and NO process group given: the reducer makes its own; buckets of equal padded size exist
+    # (two biases of 16-element slots), so a rank-local launch order would pair different buckets across ranks
+    red = P.GradBucketReducer(net, bucket_mb=1e-7)
+    assert red.group is not None and len(red.buckets) == len(list(net.parameters()))
+    order, launch = [], red._launch
+    ids = [id(b) for b in red.buckets]
+    red._launch = lambda b: (order.append(ids.index(id(b))), launch(b))[1]
+    rows = []
+    for step in range(2):
+        for p in net.parameters():
+            p.grad = None
+        g = torch.Generator().manual_seed(11 * step + rank)
+        x, y = torch.randn(6, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+        logits = net[2](net[1](net[0](x)))
+        if rank == 0:
+            logits = logits + tail.one_rank_only
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        during = list(order)
+        red.finish()
+        rows.append((during, list(order), [p.grad.clone().tolist() for p in net.parameters()]))
+        order.clear()
+    out.put((rank, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_launch_order_is_the_same_on_every_rank():
+    """One parameter per bucket, one parameter used by rank 0 only (round-3 advice): the all-reduces must still pair up -
+    every rank launches its buckets in index order, whatever the order in which its gradients became complete."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, rows0), (_, rows1) = res
+    for (during0, all0, g0), (during1, all1, g1) in zip(rows0, rows1):
+        assert all0 == all1 == sorted(all0)                 # index order on both ranks
+        assert len(during0) > len(during1) == 0             # rank 1 could launch nothing before finish(): bucket 0 was incomplete
+        assert g0 == g1                                     # the same averaged gradients
+        assert any(abs(v) > 0 for v in g0[-1])              # one_rank_only (last parameter, bucket 0) took rank 0's gradient / 2

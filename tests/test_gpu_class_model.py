@@ -1,0 +1,162 @@
+"""The class-sorted implicit GEMM (csrc/conv_class.hip) pinned at MODEL level (-m gpu).
+
+The training step takes the class path only above row thresholds (functional.class_gemm_pays: 16 384 rows for <= 64
+channels, 48 000 for the 96-column layers, 60 000 with a 128-column direction, 48 000 for half storage), so the largest
+golden model (44 238 voxels) never reached `class_gemm_kernel<96|128>` nor any `class_gemm_h_kernel` inside a network.  Here:
+
+* the mk34 cr 1.0 comparison against the REAL reference's logits / loss / running statistics and the float64 gradients
+  (tests/golden/model_mk34_*.npz, bars of test_gpu_parity_r2: logits 1e-3, gradients 1e-3 of float64) is repeated with every
+  threshold forced to 1 row - all submanifold 3x3x3 blocks whose plan passes the work guard go through the fused block call
+  + class plan + C++ node, forward and input gradient; the per-launch records prove which kernels ran;
+* the same under torch.autocast: half-storage class kernels against the reference's fp32 logits at SURVEY 8(d)'s fp16 gate
+  and against the two-pass half path at its rounding noise;
+* ONE bench scan (seed 0, 120 000 points, ~89k voxels, mk34 cr 1.0, running-statistics BatchNorm) forward-only against
+  OracleMinkUNet on the reference's own CPU kernels (oracle/_ref): logits within 1e-3 at the size bench.py runs
+  (convolution_cuda.cu:101-165, minkunet.py:385-434).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity_r2 import MK34, mk34_vs_reference_and_fp64  # noqa: E402
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg  # noqa: E402
+
+
+def _force_class_path(monkeypatch):
+    from taseg_amd.torchsparse.nn import functional as F
+    for name in ("_CLASS_MIN_ROWS", "_CLASS_MIN_ROWS_96", "_CLASS_MIN_ROWS_128", "_CLASS_MIN_ROWS_HALF"):
+        monkeypatch.setattr(F, name, 1)
+
+
+def _class_launches(records):
+    """{(columns, half)} of the class-GEMM launches among backend.profile_end() records"""
+    return {(r[3]["c_out"], r[3]["esize"] == 2) for r in records if r[0] == "class_gemm"}
+
+
+@pytest.mark.parametrize("name,in_dim,key,fname", MK34)
+@pytest.mark.parametrize("training", [True, False])
+def test_mk34_on_the_class_path_vs_reference_and_fp64(monkeypatch, name, in_dim, key, fname, training):
+    from taseg_amd import backend as B
+    _force_class_path(monkeypatch)
+    B.profile_begin()
+    try:
+        mk34_vs_reference_and_fp64(name, in_dim, key, fname, training)
+    finally:
+        recs = B.profile_end()
+    ran = _class_launches(recs)
+    cols = {c for c, half in ran if not half}
+    # 32 / 64 / 96 / 128-column tiles, forward (c_out) and input gradient (c_in as columns), all inside the network
+    assert {32, 64, 96, 128} <= {128 if c % 128 == 0 else 96 if c % 96 == 0 else 64 if c % 64 == 0 else 32 for c in cols}, ran
+    n_class = sum(1 for r in recs if r[0] == "class_gemm")
+    n_pair = sum(1 for r in recs if r[0] == "pair_gemm" and r[3]["k"] == 27)
+    print(f"{name} training={training}: {n_class} class-GEMM launches, {n_pair} 27-offset pair-GEMM launches left")
+    assert n_class >= 60
+
+
+def _amp_step(model, g, key, amp=True):
+    from taseg_amd.torchsparse import SparseTensor
+    coords = torch.from_numpy(g["coords"]).cuda()
+    sfx = "" if key == "lidar" else "_ms"
+    bd = {key: SparseTensor(torch.from_numpy(g["feats"]).cuda(), coords),
+          "targets" + sfx: SparseTensor(torch.from_numpy(g["labels"]).cuda(), coords),
+          "offset" + sfx: torch.tensor([0], device="cuda")}
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach().float()))
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        ret, tb, _ = model(bd)
+    h.remove()
+    ret["loss"].float().backward()
+    grads = {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.reset_running_stats()
+    return grabbed["logits"], float(ret["loss"]), grads
+
+
+@pytest.mark.parametrize("name,in_dim,key,fname", MK34[:1])
+def test_mk34_half_storage_class_path_vs_reference(monkeypatch, name, in_dim, key, fname):
+    """class_gemm_h_kernel inside the network (fused block call, kept half weights, C++ node): against the reference's fp32
+    logits at the fp16 gate of SURVEY 8(d) (deviation reported, arg-max agreement >= 99 %), and against the two-pass half
+    path - same storage type, another summation order and ONE rounding per (row, z-plane) instead of one per pair"""
+    from taseg_amd import backend as B
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse.nn import functional as F
+    g = dict(np.load(os.path.join(GOLDEN, fname), allow_pickle=False))
+    cfg = make_model_cfg(name, in_dim=in_dim, cr=1.0)
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+    monkeypatch.setattr(F, "_CLASS_GEMM", False)
+    l_two, loss_two, g_two = _amp_step(model, g, key)
+    monkeypatch.setattr(F, "_CLASS_GEMM", True)
+    _force_class_path(monkeypatch)
+    B.profile_begin()
+    try:
+        l_cls, loss_cls, g_cls = _amp_step(model, g, key)
+    finally:
+        recs = B.profile_end()
+    ran = _class_launches(recs)
+    assert {c for c, half in ran if half} >= {32, 64, 96, 128, 256}, ran
+    ref = torch.from_numpy(g["ref32_train_logits"]).cuda()
+    d_ref = (l_cls[::8] - ref).abs()
+    d_two = (l_two[::8] - ref).abs()
+    agree = float((l_cls[::8].argmax(1) == ref.argmax(1)).float().mean())
+    d_paths = (l_cls - l_two).abs()
+    print(f"{name} AMP class path: |logit - reference fp32| max {float(d_ref.max()):.4f} mean {float(d_ref.mean()):.5f} (two-pass half "
+          f"path: {float(d_two.max()):.4f} / {float(d_two.mean()):.5f}), arg-max agreement {100 * agree:.2f} %, loss "
+          f"{loss_cls:.5f} vs reference {float(g['ref32_train_loss']):.5f}; class vs two-pass max {float(d_paths.max()):.4f}")
+    assert agree >= 0.99 and float(d_ref.mean()) < 0.02 and float(d_ref.max()) < 0.25
+    assert float(d_ref.mean()) <= 1.5 * float(d_two.mean()) + 1e-3            # no worse than the path it replaces
+    assert abs(loss_cls - float(g["ref32_train_loss"])) < 2e-2
+    for k in ("stem.0.kernel", "stage2.1.net.0.kernel", "stage4.1.net.3.kernel", "up4.1.1.net.3.kernel", "classifier.0.weight"):
+        cos = float(torch.nn.functional.cosine_similarity(g_cls[k].flatten(), g_two[k].flatten(), dim=0))
+        assert cos > 0.99, (k, cos)
+
+
+def test_bench_scan_forward_vs_reference_cpu_kernels():
+    """One scan of the default bench workload (bench.make_scans seed 0: 120 000 points) through MinkUNet mk34 cr 1.0 with
+    running-statistics BatchNorm: HIP logits (class path at its PRODUCTION thresholds: this is the size they are set for)
+    against the oracle model driven by the reference's own C++ kernels (oracle/_ref) - 1e-3, north_star's bar"""
+    import bench
+    from oracle import model as OM
+    from taseg_amd import backend as B
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    coords, feats, labels, npts = bench.make_scans(0, 1, 120000, "minkunet")
+    cfg = make_model_cfg("MinkUNet", in_dim=4, cr=1.0)
+    model = fill_parameters(build_network(cfg, 20), seed=7).cuda().train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach()))
+    B.profile_begin()
+    try:
+        model({"lidar": SparseTensor(feats.clone(), coords), "targets": SparseTensor(labels, coords),
+               "offset": torch.tensor([len(coords)], device="cuda", dtype=torch.int32)})
+    finally:
+        recs = B.profile_end()
+    h.remove()
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    backend = "ref" if os.path.exists(os.path.join(os.path.dirname(OM.__file__), "_ref", "ts_ref_backend.so")) else "numpy"
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)          # the reference's CPU kernels are fastest on one thread (OpenMP on the inner channel loop)
+    try:
+        om = OM.OracleMinkUNet(params, cfg, backend=backend, training=False)
+        with torch.no_grad():
+            want = om.forward_minkunet(coords.cpu().numpy(), feats.cpu())
+    finally:
+        torch.set_num_threads(threads)
+    got = grabbed["logits"].float().cpu()
+    err = float((got - want).abs().max())
+    ran = _class_launches(recs)
+    print(f"bench scan: {npts} points -> {got.shape[0]} voxels, oracle backend {backend}: max |logit - oracle| {err:.2e}; class "
+          f"launches {sorted(ran)}")
+    assert got.shape[0] > 80000
+    assert err <= 1e-3
+    assert {c for c, _ in ran} >= {32, 96}          # the stride-1 / stride-2 layers of this very size run on the class path

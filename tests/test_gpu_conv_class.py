@@ -154,3 +154,127 @@ def test_class_plan_is_kept_only_while_its_work_stays_near_the_pairs(monkeypatch
             assert plan["z_rows"] == 128 * tiles and km.class_rows() == 128 * tiles
     assert got["surface"][0] and got["surface"][1] < 1.2, got
     assert not got["noise"][0] and 1.2 < got["noise"][1] < 1.6, got
+
+
+# ---------------------------------------------------------------------------------------------- direct plans (2x2x2 maps)
+def _strided_map(seed, n, extent, stride=1):
+    from taseg_amd import backend as B
+    fine = _cloud(seed, n, extent) * np.array([stride, stride, stride, 1], np.int32)
+    coarse = O.spdownsample(fine, 2, 2, stride)
+    offs = O.get_kernel_offsets(2, stride, 1)
+    km = B.build_kmap(_T(fine), _T(coarse), _T(offs))
+    _, nbmaps, nbsizes = O.build_kmap(fine, coarse, offs)
+    return fine, coarse, km, nbmaps, nbsizes
+
+
+@pytest.mark.parametrize("n,extent", [(1, 4), (300, 5), (129, 40), (6000, 24)])
+def test_direct_plans_hold_every_pair_of_a_strided_map(n, extent):
+    """the two direct plans of a 2x2x2 / stride-2 map (conv.py:184-192, SURVEY App. A: every fine voxel has exactly one
+    parent): destination = coarse rows ("down") lists each coarse row once with all its children, destination = fine rows
+    ("up") lists each fine row once with its one parent; padding slots carry -1"""
+    from taseg_amd import backend as B
+    fine, coarse, km, nbmaps, nbsizes = _strided_map(n, n, extent)
+    nbr = km["nbr"].cpu().numpy()                                                # [8, n_coarse]: fine row per (offset, coarse row)
+    down = B.conv_class_plan(km["nbr"], direct=True)
+    nbr_t = B.conv_nbr_transposed(km["pos_in"], km["nbmaps"], 8)
+    up = B.conv_class_plan(nbr_t, direct=True)
+    want_t = np.full((8, len(fine)), -1, np.int64)
+    kk = np.repeat(np.arange(8), nbsizes)
+    want_t[kk, nbmaps[:, 0]] = nbmaps[:, 1]
+    assert np.array_equal(nbr_t.cpu().numpy(), want_t) and np.all((want_t >= 0).sum(0) == 1)
+    for plan, table, n_dest in ((down, nbr, len(coarse)), (up, want_t, len(fine))):
+        src, rows = plan["src"].cpu().numpy(), plan["rows"].cpu().numpy()
+        assert plan["pos"] is None and plan["groups"] == 1 and plan["mirror"] == 0
+        assert plan["m_pad"] == (n_dest + 127) // 128 * 128 and src.shape == (8, plan["m_pad"])
+        live = rows >= 0
+        assert np.array_equal(np.sort(rows[live]), np.arange(n_dest))             # every destination row exactly once
+        assert np.array_equal(src[:, live], table[:, rows[live]]) and np.all(src[:, ~live] == -1)
+        nt = int(plan["n_tiles"][0])
+        info = plan["tile_info"].cpu().numpy()[:nt]
+        assert nt == plan["m_pad"] // 128 and np.array_equal(np.sort(info[:, 0] >> 2), np.arange(nt))
+        masks = ((src >= 0).reshape(8, -1, 128).any(2) * (1 << np.arange(8))[:, None]).sum(0)
+        assert np.array_equal(info[:, 1], masks[info[:, 0] >> 2])
+
+
+@pytest.mark.parametrize("ci,co", [(32, 32), (64, 64), (128, 96), (96, 96), (256, 128), (128, 128)])
+@pytest.mark.parametrize("half", [False, True])
+def test_direct_plans_are_the_strided_and_transposed_convolution(ci, co, half):
+    """ONE pass, no Z: strided forward / its input gradient and the transposed convolution's forward / input gradient on the
+    direct plans against the float64 oracle (convolution_cuda.cu:101-278 with transpose = 0 / 1) and against pair GEMM +
+    pass 2 - the same products added in the same order (k ascending), so the same bits in fp32"""
+    from taseg_amd import backend as B
+    fine, coarse, km, nbmaps, nbsizes = _strided_map(5, 20000, 36)
+    nf, nc, total = len(fine), len(coarse), len(nbmaps)
+    down = B.conv_class_plan(km["nbr"], direct=True)
+    up = B.conv_class_plan(B.conv_nbr_transposed(km["pos_in"], km["nbmaps"], 8), direct=True)
+    rs = np.random.RandomState(3)
+    xf = rs.randn(nf, ci).astype(np.float32)           # features on the fine rows
+    xc = rs.randn(nc, ci).astype(np.float32)           # ... on the coarse rows (transposed convolution input)
+    gc = rs.randn(nc, co).astype(np.float32)
+    gf = rs.randn(nf, co).astype(np.float32)
+    w = (rs.randn(8, ci, co) / np.sqrt(ci)).astype(np.float32)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    want = {
+        "strided forward": O.conv_forward(f64(xf), f64(w), nbmaps, nbsizes, (nf, nc)),
+        "strided input gradient": O.conv_backward(f64(xf), f64(w), f64(gc), nbmaps, nbsizes)[0],
+        "transposed forward": O.conv_forward(f64(xc), f64(w), nbmaps, nbsizes, (nf, nc), transposed=True),
+        "transposed input gradient": O.conv_backward(f64(xc), f64(w), f64(gf), nbmaps, nbsizes, transposed=True)[0],
+    }
+    T = (lambda a: _T(a).half()) if half else _T
+    wt = T(w)
+    cg = B.conv_class_gemm_f16 if half else B.conv_class_gemm
+    pg = B.conv_pair_gemm_f16 if half else B.conv_pair_gemm
+    gs = B.conv_gather_sum_f16 if half else B.conv_gather_sum
+    nat = dict(natural=True) if half else {}
+    wtr = {} if half else dict(weight_transposed=True)
+    got = {
+        "strided forward": cg(T(xf), wt, down),
+        "strided input gradient": cg(T(gc), wt, up, weight_transposed=True),
+        "transposed forward": cg(T(xc), wt, up),
+        "transposed input gradient": cg(T(gf), wt, down, weight_transposed=True),
+    }
+    two = {
+        "strided forward": gs(pg(T(xf), wt, km["nbmaps"], km["nboffs"], total, 0, **nat), km["pos_out"], nc),
+        "strided input gradient": gs(pg(T(gc), wt, km["nbmaps"], km["nboffs"], total, 1, **wtr), km["pos_in"], nf),
+        "transposed forward": gs(pg(T(xc), wt, km["nbmaps"], km["nboffs"], total, 1, **nat), km["pos_in"], nf),
+        "transposed input gradient": gs(pg(T(gf), wt, km["nbmaps"], km["nboffs"], total, 0, **wtr), km["pos_out"], nc),
+    }
+    for name, y in got.items():
+        ref = want[name]
+        assert tuple(y.shape) == ref.shape, name
+        err = float(np.abs(y.double().cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+        err2 = float(np.abs(two[name].double().cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+        same = bool(torch.equal(y, two[name]))
+        print(f"{'half' if half else 'fp32'} {ci}->{co} {name}: rel err vs fp64 {err:.2e} (two passes {err2:.2e}), bit-identical to the two passes: {same}")
+        if half:
+            assert err <= 2e-3 and err <= 1.5 * err2 + 2e-4, name
+        else:
+            assert err <= 1e-5, name
+            if "fine" in name or name in ("strided input gradient", "transposed forward"):
+                assert same, name              # one pair per destination row: nothing is added, the product is the result
+    y_again = cg(T(xf), wt, B.conv_class_plan(km["nbr"], direct=True))
+    assert torch.equal(y_again, got["strided forward"])                       # deterministic across plan builds
+
+
+def test_direct_plan_writes_zero_rows_without_neighbours():
+    """a destination row no pair reaches must come out as zeros (the direct store is the only writer of the result)"""
+    from taseg_amd import backend as B
+    rs = np.random.RandomState(0)
+    n, k = 1000, 8
+    nbr = np.full((k, n), -1, np.int32)
+    livecols = rs.permutation(n)[:600]
+    for j in livecols:
+        ks = rs.permutation(k)[:rs.randint(1, 4)]
+        nbr[ks, j] = rs.randint(0, 700, size=len(ks))
+    plan = B.conv_class_plan(_T(nbr), direct=True)
+    x = _T(rs.randn(700, 32).astype(np.float32))
+    w = _T(rs.randn(k, 32, 64).astype(np.float32))
+    y = B.conv_class_gemm(x, w, plan)
+    want = np.zeros((n, 64))
+    xn, wn = x.double().cpu().numpy(), w.double().cpu().numpy()
+    for kk in range(k):
+        j = np.nonzero(nbr[kk] >= 0)[0]
+        want[j] += xn[nbr[kk, j]] @ wn[kk]
+    assert float(np.abs(y.double().cpu().numpy() - want).max()) <= 1e-4
+    dead = np.setdiff1d(np.arange(n), livecols)
+    assert len(dead) > 300 and bool((y[_T(dead).long()] == 0).all())

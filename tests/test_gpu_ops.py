@@ -561,7 +561,9 @@ def test_device_multiscan_stage_golden(g_multiscan):
         same(batch[key].to(torch.from_numpy(g[f"batch_{key}"]).dtype), g[f"batch_{key}"])
 
 
-@pytest.mark.parametrize("n,c", [(5000, 32), (20011, 96), (777, 256), (3, 16)])
+# rows: the one-launch column kernels (csrc/bn.hip: register form up to 12 chunks of 1024 rows, streaming form up to 24k rows)
+# and the three-launch path above that
+@pytest.mark.parametrize("n,c", [(5000, 32), (20011, 96), (777, 256), (3, 16), (12001, 128), (13000, 256), (30011, 64)])
 def test_batchnorm_train_matches_torch(n, c):
     """our reductions + torch's elementwise halves == nn.BatchNorm1d (training): output, grads, running stats"""
     from taseg_amd.torchsparse import SparseTensor
@@ -1049,7 +1051,11 @@ def test_fused_loss_fails_loudly_on_a_label_outside_the_classes():
     crit = LS.Losses(["CELoss", "LovLoss"], [1.0, 1.0], ignore_index=0, label_smoothing=0.0)
     assert np.isfinite(float(crit(logits, labels)))
     labels[1234] = 255
-    assert np.isnan(float(crit(logits, labels)))
+    a = logits.clone().requires_grad_()
+    loss = crit(a, labels)
+    assert np.isnan(float(loss))
+    loss.backward()                  # ... and the gradient of that row is poisoned too: no optimizer step on a wrong gradient
+    assert bool(torch.isnan(a.grad[1234]).all())
 
 
 @pytest.mark.parametrize("k,n,c", [(27, 10007, 96), (27, 4099, 128), (27, 257, 256), (8, 5003, 64), (27, 3001, 32), (27, 1500, 20),

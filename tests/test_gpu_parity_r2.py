@@ -28,10 +28,17 @@ def _load(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
 
-@pytest.mark.parametrize("name,in_dim,key,fname", [("MinkUNet", 4, "lidar", "model_mk34_minkunet.npz"),
-                                                   ("MinkUNetMs", 5, "lidar_ms", "model_mk34_minkunet_ms.npz")])
+MK34 = [("MinkUNet", 4, "lidar", "model_mk34_minkunet.npz"), ("MinkUNetMs", 5, "lidar_ms", "model_mk34_minkunet_ms.npz")]
+
+
+@pytest.mark.parametrize("name,in_dim,key,fname", MK34)
 @pytest.mark.parametrize("training", [True, False])
 def test_mk34_cr10_vs_reference_and_fp64(name, in_dim, key, fname, training):
+    mk34_vs_reference_and_fp64(name, in_dim, key, fname, training)
+
+
+def mk34_vs_reference_and_fp64(name, in_dim, key, fname, training):
+    """the comparison itself (also run with the class-path thresholds forced down: tests/test_gpu_class_model.py)"""
     from taseg_amd.pcseg.model import build_network
     from taseg_amd.torchsparse import SparseTensor
     g = _load(fname)
