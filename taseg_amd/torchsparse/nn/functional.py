@@ -266,14 +266,17 @@ class KernelMap:
     def plans_for(self, transposed: bool, c_in: int, c_out: int, half: bool):
         """(forward plan, input-gradient plan) of a convolution over this map with these channel counts - either may be None
         (pair GEMM + pass 2).  Submanifold 3x3x3: the one mirrored plan for both where class_gemm_pays; 2x2x2 strided: the direct
-        plans of the two directions."""
+        plans of the two directions where direct_conv_pays."""
         if not _dense_ok(c_in, c_out):
             return None, None
         if self.cls is not None and not transposed and class_gemm_pays(self.cls["n"], c_in, c_out, half):
             return self.cls, self.cls
         if self.direct is not None:
             d = self.direct
-            return (d["up"], d["down"]) if transposed else (d["down"], d["up"])
+            fwd, dgrad = (d["up"], d["down"]) if transposed else (d["down"], d["up"])
+            # (forward: reduces over c_in, writes c_out columns; input gradient: the other way round)
+            return (fwd if direct_conv_pays(fwd is d["up"], fwd["n"], c_in, c_out, half) else None,
+                    dgrad if direct_conv_pays(dgrad is d["up"], dgrad["n"], c_out, c_in, half) else None)
         return None, None
 
     def class_rows(self) -> int:
@@ -320,6 +323,7 @@ _CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
 # one-pass 2x2x2 strided / transposed convolutions on direct class plans (TASEG_DIRECT_CONV=0: pair GEMM + pass 2)
 _DIRECT_CONV = os.environ.get("TASEG_DIRECT_CONV", "1") != "0"
 _DIRECT_MIN_ROWS = int(os.environ.get("TASEG_DIRECT_MIN_ROWS", "0"))
+_DIRECT_FORCE = os.environ.get("TASEG_DIRECT_CONV") == "force"        # every fitting 2x2x2 product on its direct plan (tests, probes)
 
 
 def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> bool:
@@ -329,6 +333,23 @@ def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> b
         return n_rows >= _CLASS_MIN_ROWS
     cols128 = any(c % 128 == 0 and c % 96 != 0 for c in (c_in, c_out))       # a direction on 128-column tiles (direct-rows pair GEMM)
     return n_rows >= (_CLASS_MIN_ROWS_128 if cols128 else _CLASS_MIN_ROWS_96)
+
+
+def direct_conv_pays(up: bool, n_dest: int, c_red: int, c_cols: int, half: bool) -> bool:
+    """Does the one-pass class GEMM on a direct plan beat pair GEMM + pass 2 for this product?  (tools/direct_probe.py on the bench
+    rulebooks, profiles/r04_direct_conv_probe.txt.)  "up" plans (destination = fine rows, ONE offset per tile: a pair GEMM whose
+    rows land in place) win 1.15-2.05x in fp32 down to ~30k destination rows of <= 64 channels / ~60k rows of wide ones and
+    1.26-2.09x everywhere in half storage; "down" plans (destination = coarse rows, a tile walks up to 8 offsets) win 1.4-3.0x
+    where tiles are many and rows narrow, and lose (0.2-0.9x) on the few, wide tiles of the deep levels - a coarse level has 128
+    x fewer workgroups than its pairs have rows."""
+    if _DIRECT_FORCE:
+        return True
+    wide = max(c_red, c_cols) > 64
+    if up:
+        return True if half else n_dest >= (60000 if wide else 20000)
+    if half:
+        return n_dest >= (60000 if wide else 8000) and max(c_red, c_cols) <= 96
+    return (not wide) and n_dest >= 20000
 
 
 def build_kernel_map(in_coords, out_coords, kernel_size, tensor_stride, dilation=1) -> KernelMap:

@@ -10,7 +10,6 @@ from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, synth_scan
 
 
 @pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
-# rows: one-launch register form (<= 8 chunks of 1024 rows), its streaming form (<= 24k rows), the three-launch path beyond
 @pytest.mark.parametrize("n,c", [(20011, 96), (4097, 32), (900, 256), (7000, 128), (30011, 64)])
 def test_bn_act_half_matches_fp32_kernels(n, c, with_res, relu):
     from taseg_amd.torchsparse.nn.batchnorm import batch_norm_act_train

@@ -113,9 +113,20 @@ def test_mk34_half_storage_class_path_vs_reference(monkeypatch, name, in_dim, ke
     assert agree >= 0.99 and float(d_ref.mean()) < 0.02 and float(d_ref.max()) < 0.25
     assert float(d_ref.mean()) <= 1.5 * float(d_two.mean()) + 1e-3            # no worse than the path it replaces
     assert abs(loss_cls - float(g["ref32_train_loss"])) < 2e-2
-    for k in ("stem.0.kernel", "stage2.1.net.0.kernel", "stage4.1.net.3.kernel", "up4.1.1.net.3.kernel", "classifier.0.weight"):
-        cos = float(torch.nn.functional.cosine_similarity(g_cls[k].flatten(), g_two[k].flatten(), dim=0))
-        assert cos > 0.99, (k, cos)
+    # gradients: both half paths against the float64 evaluation of the same network (the golden's sampled tensors) - the class
+    # path must sit in the same noise band as the path it replaces (two half evaluations of a 40-layer train-mode BatchNorm chain
+    # differ from EACH OTHER by more than either differs from fp32: stem.0.kernel cos 0.98 between them)
+    from taseg_amd.data.synthetic import strided_sample
+    worst = (0.0, 0.0, "")
+    for k in [k for k in g if k.startswith("oracle64_train_grad/")]:
+        pname = k.split("/", 1)[1]
+        want = torch.from_numpy(g[k]).double()
+        e_cls, e_two = (float((torch.from_numpy(strided_sample(t[pname].cpu().numpy(), 2048)).double() - want).norm() / want.norm())
+                        for t in (g_cls, g_two))
+        worst = max(worst, (e_cls, e_two, pname))
+        assert e_cls <= 1.5 * e_two + 0.02, (pname, e_cls, e_two)
+    print(f"   worst sampled gradient vs fp64 (relative L2): class path {worst[0]:.3f}, two-pass half path {worst[1]:.3f} ({worst[2]})")
+    assert worst[0] < 0.3
 
 
 def test_bench_scan_forward_vs_reference_cpu_kernels():

@@ -561,8 +561,6 @@ def test_device_multiscan_stage_golden(g_multiscan):
         same(batch[key].to(torch.from_numpy(g[f"batch_{key}"]).dtype), g[f"batch_{key}"])
 
 
-# rows: the one-launch column kernels (csrc/bn.hip: register form up to 12 chunks of 1024 rows, streaming form up to 24k rows)
-# and the three-launch path above that
 @pytest.mark.parametrize("n,c", [(5000, 32), (20011, 96), (777, 256), (3, 16), (12001, 128), (13000, 256), (30011, 64)])
 def test_batchnorm_train_matches_torch(n, c):
     """our reductions + torch's elementwise halves == nn.BatchNorm1d (training): output, grads, running stats"""
