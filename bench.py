@@ -131,6 +131,9 @@ def parse():
     ap.add_argument("--cpu-leg", type=int, default=0,
                     help="(internal) run ONE CPU-baseline leg with this many threads, print its JSON record and exit")
     ap.add_argument("--cpu-leg-timeout", type=float, default=100.0, help="seconds before a CPU-baseline leg is abandoned")
+    ap.add_argument("--eval", action="store_true",
+                    help="evaluation pass instead of a training step: eval-mode forward on the index plan + un-voxelisation + "
+                         "arg-max per point, as the segmentors' eval branch returns it (minkunet.py:435-455, R/train.py:452-540)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short runs of the other workloads (minkunet_ms, --amp, nuscenes_ms --amp) that the "
                          "default N=1 run appends as `secondary`")
@@ -480,7 +483,7 @@ def secondary_runs(steps=30, warmup=8):
     own JSON line cut down to value / ms_per_step / dtype / config."""
     import subprocess
     out = []
-    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"]):
+    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"], ["--eval"], ["--eval", "--amp"]):
         note("secondary run: " + " ".join(extra))
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
                "--no-secondary"] + extra           # per-launch events on the first timed step: every entry has its roofline
@@ -495,7 +498,7 @@ def secondary_runs(steps=30, warmup=8):
             if r.returncode != 0 or rec is None:
                 entry["error"] = (r.stderr or r.stdout)[-400:]
             else:
-                entry.update({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss")})
+                entry.update({k: rec.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss")})
                 roof = rec.get("roofline") or {}
                 entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us",
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
@@ -530,8 +533,55 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def eval_run(args):
+    """`--eval`: K timed evaluation passes of the default workload (MinkUNet mk34 cr 1.0, bs 2, 120 000 points per scan) after W
+    warm-up passes; one pass = index plan of the batch + eval-mode forward (running-statistics BatchNorm, no graph) + the eval
+    branch's un-voxelisation through inverse_map + arg-max per point, returned as numpy arrays like the reference does
+    (minkunet.py:435-455).  One JSON line; value = scans per second."""
+    from taseg_amd.data.synthetic import fill_parameters, make_model_cfg
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    torch.cuda.set_device(0)
+    batch = args.batch or 2
+    points = args.points or 120000
+    model = fill_parameters(build_network(make_model_cfg("MinkUNet", in_dim=4, cr=1.0), 20), seed=1).cuda().eval()
+    coords, feats, labels, npts = make_scans(0, batch, points, "minkunet")
+    offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
+    counts = torch.bincount(coords[:, 3].long())
+    # one voxel per point after the dataset's sparse_quantize: the inverse map of scene b is the identity on its voxels
+    inv = torch.cat([torch.arange(int(c), device="cuda") for c in counts])
+    names = [f"scan{b}" for b in range(batch)]
+
+    def one_pass():
+        bd = {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset,
+              "targets_mapped": SparseTensor(labels, coords), "inverse_map": SparseTensor(inv, coords), "num_points": counts,
+              "name": names}
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            return model(bd)
+
+    for _ in range(args.warmup):
+        out = one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(out["point_predict"]) == batch and out["point_predict"][0].shape[0] == int(counts[0])
+    ms = 1e3 * dt / args.steps
+    print(json.dumps({
+        "metric": "scans/sec (eval forward + un-voxelisation + arg-max per point)", "value": batch * args.steps / dt, "unit": "scans/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16-storage/f32-accumulate" if args.amp else "f32", "data": "synthetic", "loss": None,
+        "config": {"workload": f"MinkUNet mk34 cr1.0 evaluation pass (eval-mode BatchNorm, no graph), bs={batch}, voxel 0.05 m, "
+                               f"{'autocast fp16' if args.amp else 'fp32'}, index plan + forward + un-voxelisation + arg-max",
+                   "points_per_step_per_gpu": int(npts), "voxels_per_step_per_gpu": int(coords.shape[0])}}), flush=True)
+
+
 def main():
     args = parse()
+    if getattr(args, "eval", False):
+        return eval_run(args)
     if args.cpu_leg:                       # child of cpu_baseline(): no GPU, one timed CPU pass, one JSON record
         from taseg_amd.data.synthetic import make_model_cfg
         ms = args.workload in ("minkunet_ms", "nuscenes_ms")

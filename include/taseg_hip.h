@@ -508,6 +508,14 @@ int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, c
                           float eps, float momentum, int32_t relu, int32_t half, void *comm, double *pack, void *conv_out,
                           float *mean, float *invstd, void *out, uint8_t *mask, void *w16, const TsConvBlockOpts *opts,
                           void *ws, size_t ws_bytes, ts_stream_t stream);
+/* evaluation form (module in eval mode, no graph): out = act((conv(feat) - mean) * invstd * bn_weight + bn_bias [+ residual]) with the
+ * caller's mean / invstd (running_mean, 1 / sqrt(running_var + eps)); the same convolution as the training forward (opts->fwd_plan,
+ * planes, w16_current), then one elementwise pass - no statistics, nothing kept for a backward pass */
+int ts_conv_block_eval(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
+                       const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, const int32_t *pos,
+                       int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight, const float *bn_bias,
+                       const float *mean, const float *invstd, int32_t relu, int32_t half, void *out, void *w16,
+                       const TsConvBlockOpts *opts, void *ws, size_t ws_bytes, ts_stream_t stream);
 int ts_conv_block_backward(const void *grad_out, const uint8_t *mask, const void *conv_out, const float *mean,
                            const float *invstd, const float *bn_weight, const double *total_dev, void *comm, double *sums,
                            int64_t n_out, int32_t c_out, int32_t half, const void *feat, int64_t n_feat_rows, int32_t c_in,

@@ -166,45 +166,18 @@ static bool plan_fits(const TsClassPlan *p, int32_t K, int64_t n_dest, int32_t c
 }
 static double plan_z_rows(const TsClassPlan *p) { return (double)(p->z_rows > 0 ? p->z_rows : p->m_pad); }
 
-// out = act(BN(conv(feat)) [+ residual]).
-//   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
-//   `gather_col` and the position table pos [K, n_out] of the rows being produced (pos_out, or pos_in for a transposed
-//   convolution); conv_out [n_out, c_out] is kept for the backward pass (BatchNorm input), as are mean / invstd / mask
-//   and - half storage - w16 [K, c_in, c_out].  comm != NULL: SyncBatchNorm on that communicator (pack [2 c_out + 1]
-//   doubles; pack[2 c_out] = global row count afterwards).
-extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
-                                     const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
-                                     const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual,
-                                     const float *bn_weight, const float *bn_bias, float *running_mean,
-                                     float *running_var, int64_t *num_batches_tracked, float eps, float momentum,
-                                     int32_t relu, int32_t half, void *comm, double *pack, void *conv_out, float *mean,
-                                     float *invstd, void *out, uint8_t *mask, void *w16, const TsConvBlockOpts *opts, void *ws,
-                                     size_t ws_bytes, ts_stream_t stream) {
-  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
-  const TsConvBlockOpts &o = opts ? *opts : none;
-  PlanesScope planes(kernel, half ? nullptr : o.planes, K, c_in, c_out);
-  TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_block_forward: bad sizes");
-  TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
-             "ts_conv_block_forward: workspace too small");
-  TS_REQUIRE(!half || w16, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_forward: half storage needs the w16 buffer");
-  const size_t es = half ? 2 : 4;
-  const size_t cmax = (size_t)std::max(c_in, c_out);
-  char *p = (char *)ws;
-  void *z = p;
-  p += blk_align((size_t)n_pairs * cmax * es);
-  p += blk_align((size_t)n_out * cmax * es);
-  if (half) p += blk_align((size_t)K * c_in * c_out * 2);
-  void *bn_ws = p;
-  const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+// The convolution of a block: conv_out [n_out, c_out] = sum over the rulebook, on the class plan of opts (where it fits) or as pair
+// GEMM + pass 2 through z.  Shared by the training forward and the evaluation forward.
+static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K, const int32_t *nbmaps,
+                      const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, const int32_t *pos, int64_t n_out, int32_t c_out,
+                      int32_t half, void *conv_out, void *w16, const TsConvBlockOpts &o, const PlanesScope &planes, void *z,
+                      ts_stream_t stream) {
   const TsClassPlan *cp = plan_fits(o.fwd_plan, K, n_out, c_in, c_out, n_pairs, nboffs) ? o.fwd_plan : nullptr;
-  if (comm == TS_COMM_CALLER_POST) {
-    // second half of a split call: conv_out and the all-reduced pack exist, statistics + elementwise pass are left
-  } else {
+  {
     // half storage: one half copy in the kernel's own layout serves both passes (the forward reads it through the transposing
     // LDS load, the input gradient directly); the cast is skipped when the caller keeps w16 in step with the weight itself
     if (half && !o.w16_current) TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
-    const double es_d = (double)es;
+    const double es_d = half ? 2 : 4;
     if (cp) {
       // class-sorted implicit GEMM: the sums of a group of offsets stay in the accumulators; a direct plan (2x2x2 maps) stores
       // the result rows themselves, a pass-2 plan leaves <= 3 rows of Z' per output
@@ -248,6 +221,46 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
       }
     }
   }
+  return TS_OK;
+}
+
+// out = act(BN(conv(feat)) [+ residual]).
+//   feat [n_feat_rows, c_in]; kernel fp32 [K, c_in, c_out]; rulebook (nbmaps, nboffs, n_pairs) with the gathered column
+//   `gather_col` and the position table pos [K, n_out] of the rows being produced (pos_out, or pos_in for a transposed
+//   convolution); conv_out [n_out, c_out] is kept for the backward pass (BatchNorm input), as are mean / invstd / mask
+//   and - half storage - w16 [K, c_in, c_out].  comm != NULL: SyncBatchNorm on that communicator (pack [2 c_out + 1]
+//   doubles; pack[2 c_out] = global row count afterwards).
+extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
+                                     const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
+                                     const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual,
+                                     const float *bn_weight, const float *bn_bias, float *running_mean,
+                                     float *running_var, int64_t *num_batches_tracked, float eps, float momentum,
+                                     int32_t relu, int32_t half, void *comm, double *pack, void *conv_out, float *mean,
+                                     float *invstd, void *out, uint8_t *mask, void *w16, const TsConvBlockOpts *opts, void *ws,
+                                     size_t ws_bytes, ts_stream_t stream) {
+  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts &o = opts ? *opts : none;
+  PlanesScope planes(kernel, half ? nullptr : o.planes, K, c_in, c_out);
+  TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_forward: bad sizes");
+  TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_forward: workspace too small");
+  TS_REQUIRE(!half || w16, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_forward: half storage needs the w16 buffer");
+  const size_t es = half ? 2 : 4;
+  const size_t cmax = (size_t)std::max(c_in, c_out);
+  char *p = (char *)ws;
+  void *z = p;
+  p += blk_align((size_t)n_pairs * cmax * es);
+  p += blk_align((size_t)n_out * cmax * es);
+  if (half) p += blk_align((size_t)K * c_in * c_out * 2);
+  void *bn_ws = p;
+  const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+  if (comm == TS_COMM_CALLER_POST) {
+    // second half of a split call: conv_out and the all-reduced pack exist, statistics + elementwise pass are left
+  } else {
+    TS_TRY(block_conv(feat, n_feat_rows, c_in, kernel, K, nbmaps, nboffs, n_pairs, gather_col, pos, n_out, c_out, half, conv_out,
+                      w16, o, planes, z, stream));
+  }
   if (comm)
     return ts_bn_sync_forward(comm, conv_out, residual, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked,
                               n_out, c_out, eps, momentum, relu, half, pack, mean, invstd, out, mask, bn_ws, bn_ws_bytes,
@@ -259,6 +272,38 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
   return ts_bn_act_train_forward((const float *)conv_out, (const float *)residual, bn_weight, bn_bias, running_mean,
                                  running_var, num_batches_tracked, n_out, c_out, eps, momentum, relu, mean, invstd,
                                  (float *)out, mask, bn_ws, bn_ws_bytes, stream);
+}
+
+// Evaluation form of the block (module in eval mode, minkunet.py:435-455 / train.py:452-540: running statistics, no graph):
+// out = act((conv(feat) - mean) * invstd * bn_weight + bn_bias [+ residual]) with the caller's mean / invstd (running_mean,
+// 1 / sqrt(running_var + eps)) - convolution as in the training forward (class plans included), then ONE elementwise pass; the
+// convolution output lives in the workspace.
+extern "C" int ts_conv_block_eval(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
+                                  const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
+                                  const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight,
+                                  const float *bn_bias, const float *mean, const float *invstd, int32_t relu, int32_t half,
+                                  void *out, void *w16, const TsConvBlockOpts *opts, void *ws, size_t ws_bytes,
+                                  ts_stream_t stream) {
+  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts &o = opts ? *opts : none;
+  PlanesScope planes(kernel, half ? nullptr : o.planes, K, c_in, c_out);
+  TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_eval: bad sizes");
+  TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_eval: workspace too small");
+  TS_REQUIRE(!half || w16, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_eval: half storage needs the w16 buffer");
+  TS_REQUIRE(mean && invstd && bn_weight && bn_bias && out, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_eval: null pointer");
+  const size_t es = half ? 2 : 4;
+  const size_t cmax = (size_t)std::max(c_in, c_out);
+  char *p = (char *)ws;
+  void *z = p;
+  p += blk_align((size_t)n_pairs * cmax * es);
+  void *conv_out = p;
+  TS_TRY(block_conv(feat, n_feat_rows, c_in, kernel, K, nbmaps, nboffs, n_pairs, gather_col, pos, n_out, c_out, half, conv_out, w16, o,
+                    planes, z, stream));
+  if (half)
+    return ts_bn_act_forward_f16(conv_out, residual, mean, invstd, bn_weight, bn_bias, n_out, c_out, relu, out, nullptr, stream);
+  return ts_bn_act_forward((const float *)conv_out, (const float *)residual, mean, invstd, bn_weight, bn_bias, n_out, c_out, relu,
+                           (float *)out, nullptr, stream);
 }
 
 // Backward of ts_conv_block_forward.  weights = the fp32 kernel, or (half storage) the w16 buffer the forward filled.

@@ -23,7 +23,7 @@ from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from .utils import get_kernel_offsets
 
-__all__ = ["conv3d", "conv_geometry", "conv_block_ok", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "spdevoxelize_cat", "calc_ti_weights",
+__all__ = ["conv3d", "conv_geometry", "conv_block_ok", "conv_block_eval", "sphash", "sphashquery", "spcount", "spvoxelize", "spdevoxelize", "spdevoxelize_cat", "calc_ti_weights",
            "spdownsample", "KernelMap", "build_kernel_map", "build_pyramid", "point_linear"]
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -872,9 +872,39 @@ class _ConvBlock(Function):
         return grad_feat, grad_w, grad_res, gwb[0], gwb[1], None, None, None, None, None, None, None, None, None, None
 
 
+def conv_block_eval(feats, weight, residual, bn_weight, bn_bias, mean, invstd, kmap, transposed, relu, half, planes=None):
+    """act(BN_eval(conv(x)) [+ residual]) without a graph: ONE backend call (ts_conv_block_eval, csrc/block.hip) - the convolution
+    of the training forward (class plans, pre-split planes / kept half weights) followed by one elementwise pass on the running
+    statistics (mean, invstd = 1 / sqrt(running_var + eps)).  The evaluation branch of the segmentors runs 63 of these per pass
+    (minkunet.py:435-455; ten passes per scan under test-time augmentation, R/train.py:474-503)."""
+    lib = B.L.load()
+    L = B.L
+    n_in, n_out = kmap.sizes
+    k, c_in, c_out = weight.shape
+    gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
+    dt = torch.float16 if half else torch.float32
+    x = feats.contiguous().to(dt)
+    w32 = weight.detach().contiguous().float()
+    res = None if residual is None else residual.contiguous().to(dt)
+    dev = x.device
+    out = torch.empty((rows, c_out), dtype=dt, device=dev)
+    if w32.data_ptr() != weight.data_ptr() or (planes is not None and planes.dtype != (torch.float16 if half else torch.int16)):
+        planes = None
+    w16 = (planes if planes is not None else torch.empty((k, c_in, c_out), dtype=torch.float16, device=dev)) if half else None
+    total = kmap.total
+    ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
+    plan_f, _ = kmap.plans_for(transposed, c_in, c_out, half)
+    opts = _block_opts(plan_f, None, None if half else planes, half and planes is not None, None)
+    L.check(lib.ts_conv_block_eval(
+        L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), rows,
+        c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(mean), L.ptr(invstd), 1 if relu else 0, 1 if half else 0,
+        L.ptr(out), L.ptr(w16), _ctypes.byref(opts), L.ptr(ws), ws.numel(), L.stream()), "ts_conv_block_eval")
+    return out
+
+
 def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", residual, rows: int) -> bool:
     """Can `_ConvBlock` serve this convolution + training BatchNorm?  (else: conv3d followed by bn_act)"""
-    if not (feats.is_cuda and weight.dim() == 3 and feats.dim() == 2 and torch.is_grad_enabled()):
+    if not (feats.is_cuda and weight.dim() == 3 and feats.dim() == 2):
         return False
     half = _amp_half(feats)
     c_in, c_out = weight.shape[1], weight.shape[2]

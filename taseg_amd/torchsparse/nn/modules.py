@@ -166,6 +166,17 @@ def _plan_args(plan):
             [plan["n"], plan["m_pad"], int(plan.get("z_rows") or 0), plan["K"], plan["groups"], plan["mirror"], 1 if direct else 0])
 
 
+def _eval_invstd(mod):
+    """1 / sqrt(running_var + eps) of a BatchNorm module, kept until the buffer changes (63 modules x 10 TTA votes per scan)"""
+    rv = mod.running_var
+    hit = getattr(mod, "_taseg_eval_invstd", None)
+    if hit is None or hit[0] != rv._version or hit[1] is not rv or hit[2].device != rv.device:
+        with torch.no_grad():
+            hit = (rv._version, rv, torch.rsqrt(rv.float() + mod.eps))
+        mod._taseg_eval_invstd = hit
+    return hit[2]
+
+
 def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None,
                 passthrough: bool = False):
     """relu(BN(conv(input)) [+ residual]) for a Conv3d and its BatchNorm / SyncBatchNorm module: one autograd node and
@@ -181,8 +192,24 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     ones = (1, 1, 1)
     ks, stride = conv.kernel_size, conv.stride
     dil = make_ntuple(conv.dilation, ndim=3)
-    if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and mod.momentum is not None and mod.affine \
-            and not (conv._forward_hooks or conv._forward_pre_hooks):      # hooks on the conv module must still fire
+    if _FUSED_BLOCK and conv.bias is None and ks != ones and not mod.training and not torch.is_grad_enabled() and mod.affine \
+            and mod.track_running_stats and mod.running_var is not None \
+            and not (conv._forward_hooks or conv._forward_pre_hooks or mod._forward_hooks or mod._forward_pre_hooks):
+        # evaluation (eval-mode BatchNorm, no graph): one backend call per block on the running statistics
+        kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)
+        n_in, n_out = kmap.sizes
+        rows = n_in if conv.transposed else n_out
+        res = None if residual is None else residual.feats
+        feats = input.feats
+        if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
+            half = F._amp_half(feats)
+            planes = _planes.half_for(conv.kernel) if half else _planes.planes_for(conv.kernel)
+            out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), kmap,
+                                    conv.transposed, relu, half, planes)
+            result = F._conv_output(input, out, out_coords, out_stride)
+            return (result, input) if passthrough else result
+    if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and torch.is_grad_enabled() and mod.momentum is not None \
+            and mod.affine and not (conv._forward_hooks or conv._forward_pre_hooks):      # hooks on the conv module must still fire
         group = _sync_group(mod)
         _require_rows(input.feats, group)
         comm = None if group is None else direct_comm(group)

@@ -137,6 +137,41 @@ def test_eval_branch_unvoxelises(g_minkunet):
     assert n == sum(per_scan)
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_eval_block_call_equals_the_module_chain(g_minkunet, monkeypatch, amp):
+    """evaluation (eval-mode BatchNorm, no graph): the one-call block path (ts_conv_block_eval: convolution + one elementwise pass
+    on the running statistics) against conv3d -> nn.BatchNorm1d(eval) -> add -> relu chained like the reference's modules
+    (minkunet.py:42-51, 117-129); and a BatchNorm buffer that changes is picked up (no stale 1 / sqrt(var + eps))"""
+    from taseg_amd.torchsparse.nn import modules as M
+    cfg, model = _build("MinkUNet", 4)
+    model.train()                       # (the training branch of forward: no inverse maps needed; the BatchNorms are what matters)
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    outs = []
+    for fused in (True, False, True):
+        monkeypatch.setattr(M, "_FUSED_BLOCK", fused)
+        grabbed = {}
+        h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach().float()))
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            model(_batch(g_minkunet, "lidar"))
+        h.remove()
+        outs.append(grabbed["logits"])
+        if len(outs) == 2:          # new running statistics: the fused path must follow
+            with torch.no_grad():
+                model.stem[1].running_var.mul_(1.7)
+                model.stage2[1].net[1].running_mean.add_(0.05)
+    tol = 3e-2 if amp else 2e-5
+    assert float((outs[0] - outs[1]).abs().max()) <= tol * max(1.0, float(outs[1].abs().max()))
+    assert float((outs[2] - outs[1]).abs().max()) > 10 * tol           # the changed buffers changed the logits ...
+    monkeypatch.setattr(M, "_FUSED_BLOCK", False)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach().float()))
+        model(_batch(g_minkunet, "lidar"))
+        h.remove()
+    assert float((outs[2] - grabbed["logits"]).abs().max()) <= tol * max(1.0, float(outs[2].abs().max()))      # ... the same way
+
+
 def test_dropout_does_not_touch_devoxelised_features():
     """DROPOUT_P > 0 (the default when the key is absent is 0.3): z1 / z2 are devoxelised from the features BEFORE
     dropout (minkunet.py:400-412).  The concat path collects its sources before the dropout call, so with the same
