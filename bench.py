@@ -123,14 +123,16 @@ def parse():
                          "one rank - a single-GPU check of what `--gpus N` executes")
     ap.add_argument("--conv-impl", type=int, default=0,
                     help="ts_set_conv_impl: 0 = default (full-tile fp32 GEMMs as split-bf16 MFMAs), 5 = v_mfma_f32_16x16x4_f32")
-    ap.add_argument("--cpu-sector-deg", type=float, default=180.0,
-                    help="azimuth sector of one scan the 1-thread CPU baseline leg runs on (360 = the whole scan, ~15 s)")
+    ap.add_argument("--cpu-sector-deg", type=float, default=360.0,
+                    help="azimuth sector of one scan the 1-thread CPU baseline leg runs on (360 = the whole scan, ~15 s per pass)")
+    ap.add_argument("--cpu-passes", type=int, default=3, help="timed passes of the 1-thread CPU leg (value = their median)")
+    ap.add_argument("--cpu-warmup", type=int, default=1, help="un-timed passes of the 1-thread CPU leg")
     ap.add_argument("--cpu-sector-deg-all", type=float, default=45.0,
                     help="sector of the all-cores leg (the reference's CPU convolution gets SLOWER with threads: its "
                          "OpenMP pragma is on the inner channel loop; 0 = skip the leg)")
     ap.add_argument("--cpu-leg", type=int, default=0,
                     help="(internal) run ONE CPU-baseline leg with this many threads, print its JSON record and exit")
-    ap.add_argument("--cpu-leg-timeout", type=float, default=100.0, help="seconds before a CPU-baseline leg is abandoned")
+    ap.add_argument("--cpu-leg-timeout", type=float, default=240.0, help="seconds before the 1-thread CPU-baseline leg is abandoned")
     ap.add_argument("--eval", action="store_true",
                     help="evaluation pass instead of a training step: eval-mode forward on the index plan + un-voxelisation + "
                          "arg-max per point, as the segmentors' eval branch returns it (minkunet.py:435-455, R/train.py:452-540)")
@@ -224,10 +226,10 @@ def make_nusc_samples(rank, batch, points, multiscan=15, step=1.0):
     return samples, npts, len(offsets)
 
 
-def _cpu_leg(cfg, points, sector_deg, threads):
-    """One timed pass (forward + CE/Lovasz loss + backward) of the reference CPU path over an azimuth sector of scan
-    seed 0 with `threads` OpenMP / BLAS threads: the oracle model driven by the reference's own compiled CPU kernels
-    (oracle/_ref) when present, else the numpy port."""
+def _cpu_leg(cfg, points, sector_deg, threads, passes=1, warmup=0):
+    """Timed passes (forward + CE/Lovasz loss + backward) of the reference CPU path over scan seed 0 (an azimuth sector of it for
+    sector_deg < 360) with `threads` OpenMP / BLAS threads: the oracle model driven by the reference's own compiled CPU kernels
+    (oracle/_ref) when present, else the numpy port.  value = scans per second at the MEDIAN timed pass."""
     from oracle import model as OM
     from taseg_amd.data.synthetic import fill_parameters, synth_scan
     from taseg_amd.pcseg.model import build_network
@@ -254,16 +256,23 @@ def _cpu_leg(cfg, points, sector_deg, threads):
     learn = {k for k, _ in model.named_parameters()}
     params = {k: v.clone().requires_grad_(k in learn) for k, v in model.state_dict().items()}
     om = OM.OracleMinkUNet(params, cfg, backend="ref" if kind == "reference" else "numpy", training=True)
-    t0 = time.time()
     fwd = om.forward_minkunet if cfg.NAME == "MinkUNet" else om.forward_minkunet_ms
-    logits = fwd(coords, feats)
-    loss = OM.loss_ce_lovasz(logits, labels)
-    loss.backward()
-    dt = time.time() - t0
+    times = []
+    for i in range(warmup + passes):          # 1 warm-up, median of >= 3 timed steps
+        for v in params.values():
+            v.grad = None
+        t0 = time.time()
+        logits = fwd(coords, feats)
+        loss = OM.loss_ce_lovasz(logits, labels)
+        loss.backward()
+        if i >= warmup:
+            times.append(time.time() - t0)
+    dt = float(np.median(times))
     frac = float(keep.sum()) / float(points)
-    return {"value": frac / dt, "unit": "scans/s", "threads": threads, "kind": kind,
-            "sample": f"{sector_deg:g} deg azimuth sector of one scan: {int(keep.sum())} pts -> {len(idx)} voxels "
-                      f"({frac:.3f} scan), fwd+bwd {dt:.1f} s, fp32, {threads} thread(s)"}
+    what = "one whole scan" if sector_deg >= 360 else f"{sector_deg:g} deg azimuth sector of one scan"
+    return {"value": frac / dt, "unit": "scans/s", "threads": threads, "kind": kind, "passes_s": [round(t, 2) for t in times],
+            "sample": f"{what}: {int(keep.sum())} pts -> {len(idx)} voxels ({frac:.3f} scan), fwd+bwd median {dt:.1f} s of "
+                      f"{passes} timed pass(es) after {warmup} warm-up, fp32, {threads} thread(s)"}
 
 
 def cpu_baseline(args, cfg_name, in_dim):
@@ -284,15 +293,19 @@ def cpu_baseline(args, cfg_name, in_dim):
     except OSError:
         pass
     legs = []
-    plan = [(1, args.cpu_sector_deg)] + ([(nproc, args.cpu_sector_deg_all)] if nproc > 1 and args.cpu_sector_deg_all > 0 else [])
-    for threads, sector in plan:
-        note(f"cpu_baseline leg: {threads} thread(s), {sector:g} deg sector")
+    # 1 thread: a WHOLE scan, 1 warm-up pass + the median of 3 timed passes; all cores: one un-warmed pass
+    # over a 45 deg sector - with one thread per core the reference's convolution is ~20x slower and a whole scan would not finish
+    # inside the bench's time budget
+    plan = [(1, args.cpu_sector_deg, args.cpu_passes, args.cpu_warmup, args.cpu_leg_timeout)] + \
+           ([(nproc, args.cpu_sector_deg_all, 1, 0, 100.0)] if nproc > 1 and args.cpu_sector_deg_all > 0 else [])
+    for threads, sector, passes, warm, limit in plan:
+        note(f"cpu_baseline leg: {threads} thread(s), {sector:g} deg sector, {warm} warm-up + {passes} timed pass(es)")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--cpu-sector-deg", str(sector),
-               "--points", str(args.points), "--workload", args.workload]
+               "--cpu-passes", str(passes), "--cpu-warmup", str(warm), "--points", str(args.points), "--workload", args.workload]
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
         rec = {"threads": threads, "value": None, "unit": "scans/s"}
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_leg_timeout)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode == 0 and line:
                 rec = json.loads(line[-1])
@@ -300,7 +313,7 @@ def cpu_baseline(args, cfg_name, in_dim):
                 rec["error"] = (r.stderr or r.stdout)[-300:]
         except subprocess.TimeoutExpired:
             rec["sample"] = (f"{sector:g} deg azimuth sector of one scan did not finish fwd+bwd within "
-                             f"{args.cpu_leg_timeout:g} s at {threads} threads")
+                             f"{limit:g} s at {threads} threads")
         legs.append(rec)
     done = [r for r in legs if r.get("value")]
     if not done:
@@ -453,6 +466,16 @@ def build_roofline(prof, amp, bracket_us):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     table = json.load(open(tpath)) if os.path.exists(tpath) else {}
     fams = summarise_families(prof, amp, table)
+    # rocprofv3-equivalent figures next to the event-bracketed ones: an event pair spans the launch gap (`event_bracket_us`, measured
+    # with nothing between the two records); avg_us_net = avg_us - event_bracket_us is what `rocprofv3 --kernel-trace --stats`
+    # reports as the average duration (profiles/), and the *_net fractions are priced with it.  Nothing is subtracted from
+    # `achieved` / `frac`.
+    for f in fams:
+        net = max(f["avg_us"] - (bracket_us or 0.0), 1e-3)
+        k = f["avg_us"] / net
+        f["avg_us_net"] = net
+        f["hbm_frac_net"] = f["hbm_frac"] * k
+        f["mfma_frac_net"] = f["mfma_frac"] * k if f["mfma_frac"] is not None else None
     dom = fams[0]
     per_launch_bytes = dom["bytes_per_step"] / dom["launches_per_step"]
     per_launch_flops = dom["flops_per_step"] / dom["launches_per_step"]
@@ -468,7 +491,8 @@ def build_roofline(prof, amp, bracket_us):
     roof.update(traffic=dom["traffic_bytes_per_launch"], kernel=dom["family"], kernels=dom["kernels"], avg_us=dom["avg_us"],
                 ms_per_step=dom["ms_per_step"], launches_per_step=dom["launches_per_step"],
                 mfma_frac=dom["mfma_frac"], hbm_frac=dom["hbm_frac"], mfma_peak_tflops=dom["mfma_peak_tflops"],
-                event_bracket_us=bracket_us, algorithmic_bytes_per_launch=per_launch_bytes,
+                event_bracket_us=bracket_us, avg_us_net=dom["avg_us_net"], hbm_frac_net=dom["hbm_frac_net"],
+                mfma_frac_net=dom["mfma_frac_net"], algorithmic_bytes_per_launch=per_launch_bytes,
                 algorithmic_flops_per_launch=per_launch_flops,
                 families=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in f.items() if k != "kernels"} for f in fams],
                 whole_step_lower_bound_ms=1e3 * max(ideal / (HBM_PEAK_GBS * 1e9), gemm_t),
@@ -500,7 +524,7 @@ def secondary_runs(steps=30, warmup=8):
             else:
                 entry.update({k: rec.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss")})
                 roof = rec.get("roofline") or {}
-                entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us",
+                entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us", "avg_us_net", "hbm_frac_net", "mfma_frac_net",
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
                                                              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
                                                              "whole_step_lower_bound_ms")} if roof else None
@@ -586,7 +610,8 @@ def main():
         from taseg_amd.data.synthetic import make_model_cfg
         ms = args.workload in ("minkunet_ms", "nuscenes_ms")
         cfg = make_model_cfg("MinkUNetMs" if ms else "MinkUNet", in_dim=5 if ms else 4, cr=1.0)
-        print(json.dumps(_cpu_leg(cfg, args.points or 120000, args.cpu_sector_deg, args.cpu_leg)), flush=True)
+        print(json.dumps(_cpu_leg(cfg, args.points or 120000, args.cpu_sector_deg, args.cpu_leg, args.cpu_passes,
+                                  args.cpu_warmup)), flush=True)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
