@@ -576,10 +576,22 @@ def eval_run(args):
     inv = torch.cat([torch.arange(int(c), device="cuda") for c in counts])
     names = [f"scan{b}" for b in range(batch)]
 
+    def make_batch():
+        return {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset,
+                "targets_mapped": SparseTensor(labels, coords), "inverse_map": SparseTensor(inv, coords), "num_points": counts,
+                "name": names}
+
+    # the index plan of batch i + 1 (coordinates only) is staged on a second stream / worker thread while batch i runs - the role
+    # of the reference's DataLoader workers; --no-prefetch builds it inline
+    from taseg_amd.data.stage import DevicePrefetcher
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare, threaded=True)
+
     def one_pass():
-        bd = {"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset,
-              "targets_mapped": SparseTensor(labels, coords), "inverse_map": SparseTensor(inv, coords), "num_points": counts,
-              "name": names}
+        if pf is None:
+            bd = make_batch()
+        else:
+            bd = pf.next()
+            pf.prefetch_early()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             return model(bd)
 

@@ -19,7 +19,7 @@ from taseg_amd import backend as B
 from taseg_amd import _fast
 from .utils import voxel_to_point, voxelize_index
 
-__all__ = ["MinkUNet"]
+__all__ = ["MinkUNet", "unvoxelise_predictions"]
 
 import os as _os
 _DEVOX_ATOMIC = _os.environ.get("TASEG_DEVOX_ATOMIC", "0") == "1"
@@ -360,6 +360,61 @@ class MinkUNetBackbone(BaseSegmentor):
         return {"loss": loss}, {"loss": lazy}, {"loss": lazy}
 
 
+def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_probs, point_mask=None, num_points_ms=None,
+                           names=None):
+    """The evaluation tail of the segmentors (minkunet.py:435-455, minkunet_ms.py:433-458) for the WHOLE batch at once: per scene
+    `out[scene][inverse_map of the scene]` (Ms: `[point_mask of the scene]`), trimmed to the scan's own point count; arg-max and
+    logits (or the soft-max under return_logit / return_tta) and the mapped labels as numpy arrays, scene by scene - what the
+    reference's per-scene loop of boolean masks returns, with three stable sorts, one gather and a handful of device -> host
+    copies instead of ~12 launches and 6 host reads per scene."""
+    dev = out.device
+    b_vox, b_pts, b_lab = vox_batch.long(), invs.C[:, -1].long(), all_labels.C[:, -1].long()
+    cnt_v, cnt_p, cnt_l = torch.bincount(b_vox), torch.bincount(b_pts), torch.bincount(b_lab)
+    order_v = torch.sort(b_vox, stable=True)[1]            # out[scene] = out[order_v[start : start + count]] (original order kept)
+    bp_sorted, order_p = torch.sort(b_pts, stable=True)
+    order_l = torch.sort(b_lab, stable=True)[1]
+    start_v = torch.cumsum(cnt_v, 0) - cnt_v
+    start_v = torch.nn.functional.pad(start_v, (0, max(0, int(cnt_p.shape[0]) - int(start_v.shape[0]))))
+    local = invs.F[order_p].long()
+    cnt_v_pad = torch.nn.functional.pad(cnt_v, (0, max(0, int(cnt_p.shape[0]) - int(cnt_v.shape[0]))))
+    bad = ((local < 0) | (local >= cnt_v_pad[bp_sorted])).any()       # read below with the counts (the reference's indexing raises)
+    rows = order_v[(start_v[bp_sorted] + local).clamp_(0, max(int(order_v.shape[0]) - 1, 0))]
+    mapped = out[rows]                                      # [points, classes], scene-major, the scene's own point order
+    kept_scene = bp_sorted
+    if point_mask is not None:
+        keep = point_mask.to(dev).bool()
+        mapped, kept_scene = mapped[keep], bp_sorted[keep]
+    cnt_k = torch.bincount(kept_scene, minlength=int(cnt_p.shape[0]))
+    result = mapped.softmax(1) if want_probs else mapped.argmax(1)
+    labels_sorted = all_labels.F[order_l]
+    # device -> host: everything the per-scene slicing needs
+    n_scenes = int(cnt_p.shape[0])
+    cnt_p_h, cnt_k_h, cnt_l_h = cnt_p.tolist(), cnt_k.tolist(), cnt_l.tolist() + [0] * n_scenes
+    if bool(bad):
+        raise IndexError("inverse_map names a voxel outside its scene")
+    n_cur_h = [int(v) for v in torch.as_tensor(num_points).reshape(-1).tolist()]
+    if num_points_ms is not None:
+        n_ms_h = [int(v) for v in torch.as_tensor(num_points_ms).reshape(-1).tolist()]
+        if n_ms_h[:n_scenes] != cnt_p_h:
+            raise IndexError(f"num_points_ms {n_ms_h[:n_scenes]} does not match the inverse map's points per scene {cnt_p_h}")
+    result_h = result.cpu().numpy()
+    mapped_h = None if want_probs else mapped.cpu().numpy()
+    labels_h = labels_sorted.cpu().numpy()
+    point_predict, point_labels, point_predict_logits = [], [], []
+    at_k = at_l = 0
+    for b in range(n_scenes):
+        n_cur = n_cur_h[b]
+        seg = slice(at_k, at_k + min(cnt_k_h[b], n_cur))
+        point_predict.append(result_h[seg].copy())
+        if mapped_h is not None:
+            point_predict_logits.append(mapped_h[seg].copy())
+        point_labels.append(labels_h[at_l: at_l + min(cnt_l_h[b], n_cur)].copy())
+        at_k += cnt_k_h[b]
+        at_l += cnt_l_h[b]
+    return {"point_predict": point_predict, "point_labels": point_labels, "name": names,
+            "point_predict_logits": point_predict_logits}
+
+
 class MinkUNet(MinkUNetBackbone):
     """Single-frame model: re-voxelises `batch_dict['lidar']` on device, then the U-Net
     (minkunet.py:385-455)."""
@@ -383,22 +438,8 @@ class MinkUNet(MinkUNetBackbone):
             target = batch_dict["targets"].F.long().cuda(non_blocking=True)
             return self._train_outputs(out, target, batch_dict["lidar"].C[:, :3].float(), batch_dict["offset"])
 
-        invs = batch_dict["inverse_map"]
-        all_labels = batch_dict["targets_mapped"]
-        point_predict, point_labels, point_predict_logits = [], [], []
-        for idx in range(int(invs.C[:, -1].max()) + 1):
-            scene = x.C[:, -1] == idx
-            cur_inv = invs.F[invs.C[:, -1] == idx]
-            mapped = out[scene][cur_inv]
-            n_cur = int(batch_dict["num_points"][idx])
-            if return_logit or return_tta:
-                point_predict.append(mapped.softmax(1)[:n_cur].cpu().numpy())
-            else:
-                point_predict.append(mapped.argmax(1)[:n_cur].cpu().numpy())
-                point_predict_logits.append(mapped[:n_cur].cpu().numpy())
-            point_labels.append(all_labels.F[all_labels.C[:, -1] == idx][:n_cur].cpu().numpy())
-        return {"point_predict": point_predict, "point_labels": point_labels, "name": batch_dict["name"],
-                "point_predict_logits": point_predict_logits}
+        return unvoxelise_predictions(out, x.C[:, -1], batch_dict["inverse_map"], batch_dict["targets_mapped"],
+                                      batch_dict["num_points"], return_logit or return_tta, names=batch_dict["name"])
 
     def forward_ensemble(self, batch_dict):
         return self.forward(batch_dict, return_tta=True)

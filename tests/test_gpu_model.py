@@ -163,7 +163,7 @@ def test_eval_block_call_equals_the_module_chain(g_minkunet, monkeypatch, amp):
                 model.stage2[1].net[1].running_mean.add_(0.05)
     tol = 3e-2 if amp else 2e-5
     assert float((outs[0] - outs[1]).abs().max()) <= tol * max(1.0, float(outs[1].abs().max()))
-    assert float((outs[2] - outs[1]).abs().max()) > 10 * tol           # the changed buffers changed the logits ...
+    assert float((outs[2] - outs[1]).abs().max()) > 5e-3               # the changed buffers changed the logits ...
     monkeypatch.setattr(M, "_FUSED_BLOCK", False)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
         h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach().float()))
