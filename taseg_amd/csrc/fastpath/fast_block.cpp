@@ -21,6 +21,7 @@ struct Api {
   decltype(&ts_conv_block_workspace_bytes) workspace_bytes = nullptr;
   decltype(&ts_conv_block_forward) forward = nullptr;
   decltype(&ts_conv_block_backward) backward = nullptr;
+  decltype(&ts_conv_block_eval) eval = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
@@ -274,8 +275,9 @@ void load_backend(const std::string &libpath) {
   api.workspace_bytes = (decltype(api.workspace_bytes))dlsym(h, "ts_conv_block_workspace_bytes");
   api.forward = (decltype(api.forward))dlsym(h, "ts_conv_block_forward");
   api.backward = (decltype(api.backward))dlsym(h, "ts_conv_block_backward");
+  api.eval = (decltype(api.eval))dlsym(h, "ts_conv_block_eval");
   api.last_error = (decltype(api.last_error))dlsym(h, "ts_last_error");
-  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward, "libtaseg_hip.so lacks the ts_conv_block_* entry points");
+  TORCH_CHECK(api.workspace_bytes && api.forward && api.backward && api.eval, "libtaseg_hip.so lacks the ts_conv_block_* entry points");
 #define TS_BIND(field, sym)                                      \
   api.field = (decltype(api.field))dlsym(h, sym);                \
   TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
@@ -309,6 +311,45 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
                           passthrough, grad_dest, group_id, at_(plan_f, 0), at_(plan_f, 1), at_(plan_f, 2), at_(plan_f, 3),
                           plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta);
+}
+
+// Evaluation form of the block (eval-mode BatchNorm on its running statistics, no graph): ts_conv_block_eval without the
+// interpreter around it - the Python wrapper (functional.conv_block_eval) costs ~70 us per block, 63 blocks per pass, which made
+// the evaluation forward host-bound (tools/eval_probe.py: 4.9 ms for ~3.5 ms of kernels).
+at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, const c10::optional<at::Tensor> &residual,
+                           const at::Tensor &bn_weight, const at::Tensor &bn_bias, const at::Tensor &mean,
+                           const at::Tensor &invstd, const at::Tensor &nbmaps, const at::Tensor &nboffs, int64_t total,
+                           const at::Tensor &pos_out, const at::Tensor &pos_in, int64_t n_in, int64_t n_out, bool transposed,
+                           bool relu, bool half, int64_t stream, const c10::optional<at::Tensor> &planes,
+                           const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta) {
+  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  at::NoGradGuard nograd;
+  const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
+  const auto dt = half ? at::kHalf : at::kFloat;
+  const int64_t rows = transposed ? n_in : n_out;
+  const at::Tensor &table = transposed ? pos_in : pos_out;
+  at::Tensor x = feats.contiguous().to(dt);
+  at::Tensor w32 = weight.detach().contiguous().to(at::kFloat);
+  at::Tensor res;
+  if (residual.has_value() && residual->defined()) res = residual->contiguous().to(dt);
+  at::Tensor out = at::empty({rows, c_out}, x.options());
+  const bool own_weight = w32.data_ptr() == weight.data_ptr();
+  const bool have = planes.has_value() && planes->defined() && own_weight;
+  const bool kept16 = half && have && planes->scalar_type() == at::kHalf && planes->numel() == k * c_in * c_out;
+  at::Tensor w16, pl;
+  if (half) w16 = kept16 ? *planes : at::empty({k, c_in, c_out}, x.options().dtype(at::kHalf));
+  if (!half && have && planes->scalar_type() == at::kShort) pl = *planes;
+  const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
+  at::Tensor ws = workspace(nb, x, stream);
+  const PlanRef pf(plan_f, plan_f_meta, nboffs);
+  TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr};
+  check(api.eval(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
+                 (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0, (const int32_t *)table.data_ptr(), rows,
+                 (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(), (const float *)bn_bias.data_ptr(),
+                 (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(), relu ? 1 : 0, half ? 1 : 0, out.data_ptr(),
+                 ptr(w16), &bopts, ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
+        "ts_conv_block_eval");
+  return out;
 }
 
 // torch.distributed process group -> the index conv_block takes as `group_id` (SyncBatchNorm's all-reduce through c10d)
@@ -472,6 +513,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("index_plan", &index_plan, "coordinate pyramid + kernel maps + trilinear maps of a MinkUNet pass (releases the GIL)");
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");
   m.def("conv_block", &conv_block, "act(BN(conv(x)) [+ residual]) as one native autograd node");
+  m.def("conv_block_eval", &conv_block_eval, "act(BN_eval(conv(x)) [+ residual]) on the running statistics, no graph");
   m.def("register_group", &register_group, "process group -> id for conv_block's c10d SyncBatchNorm path");
   m.def("clear_groups", &clear_groups, "drop the registered process groups (before destroy_process_group)");
 }

@@ -405,10 +405,10 @@ def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_pr
     for b in range(n_scenes):
         n_cur = n_cur_h[b]
         seg = slice(at_k, at_k + min(cnt_k_h[b], n_cur))
-        point_predict.append(result_h[seg].copy())
+        point_predict.append(result_h[seg])                 # (views of the batch's arrays: no second host copy)
         if mapped_h is not None:
-            point_predict_logits.append(mapped_h[seg].copy())
-        point_labels.append(labels_h[at_l: at_l + min(cnt_l_h[b], n_cur)].copy())
+            point_predict_logits.append(mapped_h[seg])
+        point_labels.append(labels_h[at_l: at_l + min(cnt_l_h[b], n_cur)])
         at_k += cnt_k_h[b]
         at_l += cnt_l_h[b]
     return {"point_predict": point_predict, "point_labels": point_labels, "name": names,

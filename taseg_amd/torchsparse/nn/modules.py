@@ -204,8 +204,15 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
         if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
             half = F._amp_half(feats)
             planes = _planes.half_for(conv.kernel) if half else _planes.planes_for(conv.kernel)
-            out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), kmap,
-                                    conv.transposed, relu, half, planes)
+            fast = _fast.module()
+            if fast is not None and mod.running_mean.dtype == torch.float32 and mod.weight.dtype == torch.float32:
+                plan_f, _ = kmap.plans_for(conv.transposed, conv.kernel.shape[1], conv.kernel.shape[2], half)
+                out = fast.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod),
+                                           kmap.nbmaps_buf, kmap.nboffs, kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out,
+                                           conv.transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f))
+            else:
+                out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), kmap,
+                                        conv.transposed, relu, half, planes)
             result = F._conv_output(input, out, out_coords, out_stride)
             return (result, input) if passthrough else result
     if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and torch.is_grad_enabled() and mod.momentum is not None \

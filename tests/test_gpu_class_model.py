@@ -47,11 +47,11 @@ def test_mk34_on_the_class_path_vs_reference_and_fp64(monkeypatch, name, in_dim,
     B.profile_begin()
     try:
         # every map down to the ~800-voxel stride-16 level takes the class path here, a configuration production never runs
-        # (class_gemm_pays starts at 16k rows).  Logits / loss / running statistics keep their bars; a gradient tensor may sit at
-        # 1.5x the REFERENCE's own fp32 distance to float64 where that is above 1e-3: with train-mode statistics over a few hundred
-        # deep voxels any other summation order moves up1.0.net.0.kernel by 1-2e-3 (the reference itself: 1.2-1.9e-3; measured
-        # here 1.06e-3 / 2.3e-3; at production thresholds the same tensor sits at 4.7e-4 - test_gpu_parity_r2)
-        mk34_vs_reference_and_fp64(name, in_dim, key, fname, training, ref_slack=1.5)
+        # (class_gemm_pays starts at 16k rows).  Logits / loss / running statistics keep their bars; gradients get round 2's bar,
+        # max(2e-3, 2 x the REFERENCE's own fp32 distance to float64 on that tensor): with train-mode statistics over a few hundred
+        # deep voxels any other summation order moves the up1 kernels by 1-2e-3 (the reference itself: 1.0-1.9e-3; measured here
+        # 1.1 / 1.5 / 2.3e-3; at production thresholds the same tensors sit at <= 4.7e-4 - test_gpu_parity_r2, bar 1e-3)
+        mk34_vs_reference_and_fp64(name, in_dim, key, fname, training, ref_slack=2.0, grad_tol=2e-3)
     finally:
         recs = B.profile_end()
     ran = _class_launches(recs)

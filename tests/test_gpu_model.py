@@ -170,6 +170,17 @@ def test_eval_block_call_equals_the_module_chain(g_minkunet, monkeypatch, amp):
         model(_batch(g_minkunet, "lidar"))
         h.remove()
     assert float((outs[2] - grabbed["logits"]).abs().max()) <= tol * max(1.0, float(outs[2].abs().max()))      # ... the same way
+    # the Python wrapper of the same backend call (taken when taseg_amd/_fast_block.so is absent) gives the same bits
+    from taseg_amd import _fast
+    if _fast.module() is not None:
+        monkeypatch.setattr(M, "_FUSED_BLOCK", True)
+        monkeypatch.setattr(_fast, "_mod", None)
+        monkeypatch.setattr(_fast, "_tried", True)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("py", o.detach().float()))
+            model(_batch(g_minkunet, "lidar"))
+            h.remove()
+        assert torch.equal(grabbed["py"], outs[2])
 
 
 def test_dropout_does_not_touch_devoxelised_features():
