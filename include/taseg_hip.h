@@ -680,6 +680,10 @@ int ts_fuse_scan(const float *points, int64_t n, const float *pose0, const float
  * (poses [n_scans, 4, 4] row-major).  Bit-identical to n_scans calls of ts_fuse_scan. */
 int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64_t n, const float *pose0, const float *poses,
                   int32_t n_scans, float *out, ts_stream_t stream);
+/* the same for the history scans of a whole BATCH of samples: pose0s [n_scans, 4, 4] = the current-frame pose of the sample the
+ * scan belongs to (one launch per batch instead of one per sample) */
+int ts_fuse_scans_batch(const float *points, const int32_t *scan_idx, int64_t n, const float *pose0s, const float *poses,
+                        int32_t n_scans, float *out, ts_stream_t stream);
 
 /* nuScenes multi-scan fuse (pcseg/data/dataset/nuscenes/nuscenes_ms.py:280-318 per selected sweep, :348-373
  * transform_point): for point i of the concatenated sweeps, with s = sweep_idx[i] and params[s] = 28 doubles

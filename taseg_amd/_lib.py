@@ -135,6 +135,7 @@ SIGNATURES = {
     "ts_debug_phase_stamps": (None, [_vp, _i64]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_fuse_scans": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "ts_fuse_scans_batch": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
     "ts_fuse_sweeps": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "ts_project_fov": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _c.c_float, _vp, _vp, _vp]),
     "ts_project_cam": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _c.c_float, _vp, _vp, _vp]),

@@ -792,6 +792,20 @@ def fuse_scans(points, scan_idx, pose0, poses):
     return out
 
 
+def fuse_scans_batch(points, scan_idx, pose0s, poses):
+    """fuse_scans for the history scans of a whole batch: point i is transformed with poses[scan_idx[i]] and the current-frame
+    pose pose0s[scan_idx[i]] of its own sample (both [S, 4, 4])."""
+    L.require_device(points, scan_idx, pose0s, poses)
+    points, pose0s, poses = _f32(points, "points"), _f32(pose0s, "pose0s"), _f32(poses, "poses")
+    scan_idx = _i32(scan_idx, "scan_idx")
+    assert points.ndim == 2 and points.shape[1] == 4 and pose0s.shape == poses.shape and poses.shape[1:] == (4, 4)
+    out = torch.empty_like(points)
+    if points.shape[0]:
+        L.check(L.load().ts_fuse_scans_batch(L.ptr(points), L.ptr(scan_idx), points.shape[0], L.ptr(pose0s), L.ptr(poses),
+                                             poses.shape[0], L.ptr(out), L.stream()), "ts_fuse_scans_batch")
+    return out
+
+
 def fuse_sweeps(points, sweep_idx, params):
     """nuScenes multi-scan fuse for the concatenated selected sweeps of one sample (nuscenes_ms.py:280-318, 348-373):
     points [n,5] float32, sweep_idx [n] int32, params [S,28] float64 (taseg_amd.data.nuscenes.sweep_params).

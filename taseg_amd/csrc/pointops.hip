@@ -311,6 +311,9 @@ __global__ __launch_bounds__(256) void fuse_scan_kernel(const float4 *__restrict
 }
 
 // All history scans of a sample in one launch: point i uses poses[scan_idx[i]].  Same arithmetic, same order.
+// PER_SCAN: pose0 is a table too (pose0[scan_idx[i]]) - the history scans of a whole BATCH of samples in one launch, every scan
+// with the current-frame pose of its own sample.
+template <bool PER_SCAN>
 __global__ __launch_bounds__(256) void fuse_scans_kernel(const float4 *__restrict__ pts,
                                                          const int *__restrict__ scan_idx, int64_t n,
                                                          const float *__restrict__ pose0,
@@ -319,13 +322,17 @@ __global__ __launch_bounds__(256) void fuse_scans_kernel(const float4 *__restric
 #pragma clang fp contract(off)
   float Q[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) Q[i] = pose0[i];
+  for (int i = 0; i < 16; ++i) Q[i] = PER_SCAN ? 0.f : pose0[i];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
     const float4 p = pts[i];
     const int sidx = min(max(scan_idx[i], 0), n_scans - 1);
     const float *P = poses + 16 * sidx;
+    if (PER_SCAN) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Q[q] = pose0[16 * sidx + q];
+    }
     const float h[4] = {p.x, p.y, p.z, 1.0f};
     float nw[3];
 #pragma unroll
@@ -357,9 +364,25 @@ extern "C" int ts_fuse_scans(const float *points, const int32_t *scan_idx, int64
   TS_REQUIRE(((uintptr_t)points & 15) == 0 && ((uintptr_t)out & 15) == 0, TS_ERR_INVALID_ARGUMENT,
              "ts_fuse_scans: points/out must be 16-byte aligned");
   int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
-  fuse_scans_kernel<<<grid, 256, 0, stream>>>((const float4 *)points, scan_idx, n, pose0, poses, n_scans,
-                                              (float4 *)out);
+  fuse_scans_kernel<false><<<grid, 256, 0, stream>>>((const float4 *)points, scan_idx, n, pose0, poses, n_scans,
+                                                     (float4 *)out);
   TS_CHECK_LAUNCH("ts_fuse_scans");
+  return TS_OK;
+}
+
+// the history scans of a whole batch: pose0s [n_scans, 16] = the current-frame pose of the sample scan s belongs to
+extern "C" int ts_fuse_scans_batch(const float *points, const int32_t *scan_idx, int64_t n, const float *pose0s,
+                                   const float *poses, int32_t n_scans, float *out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n >= 0 && n_scans > 0, TS_ERR_INVALID_ARGUMENT, "ts_fuse_scans_batch: bad sizes");
+  if (n == 0) return TS_OK;
+  TS_REQUIRE(points && scan_idx && pose0s && poses && out, TS_ERR_INVALID_ARGUMENT, "ts_fuse_scans_batch: null pointer");
+  TS_REQUIRE(((uintptr_t)points & 15) == 0 && ((uintptr_t)out & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_fuse_scans_batch: points/out must be 16-byte aligned");
+  int grid = (int)std::min<int64_t>(ts_cdiv(n, 256), 4096);
+  fuse_scans_kernel<true><<<grid, 256, 0, stream>>>((const float4 *)points, scan_idx, n, pose0s, poses, n_scans,
+                                                    (float4 *)out);
+  TS_CHECK_LAUNCH("ts_fuse_scans_batch");
   return TS_OK;
 }
 
