@@ -172,7 +172,63 @@ def fuse_sweeps(cur_pts, cur_lab, hist_pts: List[torch.Tensor], hist_lab: List[t
 def build_nuscenes_batch(samples: List[Dict], voxel_size: float, steps: Sequence[int], in_feature_dim: int = 4) -> Dict:
     """samples[b] = dict(points [n,5], labels [n], hist_points [..], hist_labels [..], hist_pseudo [..],
     params [S,28] float64 tensor, name).  Returns the collated batch_dict MinkUNetMs consumes
-    (nuscenes_voxel_ms.py:77-212 == the SemanticKITTI stage on the first `in_feature_dim` columns)."""
+    (nuscenes_voxel_ms.py:77-212 == the SemanticKITTI stage on the first `in_feature_dim` columns).
+    The whole batch goes through ONE chain of launches: one ts_fuse_sweeps over every sweep point of every sample (ego box,
+    sensor -> keyframe -> current-frame transforms, time delta), the class-step rule as one table lookup, then
+    stage.voxelize_batch_ms (one compaction, one batch-keyed voxelisation per cloud kind)."""
+    from . import stage as _stage
+    if not _stage._BATCHED or not samples:
+        return build_nuscenes_batch_per_sample(samples, voxel_size, steps, in_feature_dim)
+    dev = samples[0]["points"].device
+    f = in_feature_dim
+    n_cls = len(steps)
+    cur_all = torch.cat([s["points"] for s in samples], 0)          # (a fresh tensor: the resident scans stay untouched)
+    cur_all[:, 4] = 0                                                 # time column of the current keyframe (:109)
+    n_cur = [int(s["points"].shape[0]) for s in samples]
+    cur_f = cur_all[:, :f].contiguous()
+    cuts = [0]
+    for n in n_cur:
+        cuts.append(cuts[-1] + n)
+    cur_list = [cur_f[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    lab_list = [s["labels"].long() for s in samples]
+    hp, hl, hs, lengths, sample_of_sweep, rows, params = [], [], [], [], [], [], []
+    for b, s in enumerate(samples):
+        for pos, p in enumerate(s["hist_points"]):
+            hp.append(p)
+            lengths.append(int(p.shape[0]))
+            sample_of_sweep.append(b)
+            rows.append([bool(st) and (pos + 1) % st == 0 for st in steps])           # nuscenes_ms.py:320-328
+        hl += list(s["hist_labels"])
+        hs += list(s["hist_pseudo"])
+        if len(s["hist_points"]):
+            params.append(s["params"])
+    if hp:
+        stack = torch.cat(hp, 0).contiguous()
+        pseudo = torch.cat(hs, 0).long()
+        lab_h = torch.cat(hl, 0).long()
+        sweep_g = _stage.rows_index(lengths, dev)
+        key = ("nusc-table", tuple(map(tuple, rows)), tuple(sample_of_sweep), str(dev))
+        hit = _tables.get(key)
+        if hit is None:
+            if len(_tables) >= 64:
+                _tables.pop(next(iter(_tables)))
+            hit = (torch.tensor(rows, dtype=torch.bool).to(dev), torch.tensor(sample_of_sweep, dtype=torch.int64).to(dev))
+            _tables[key] = hit
+        table, sample_of = hit
+        fused, no_ego = B.fuse_sweeps(stack, sweep_g.int(), torch.cat(params, 0) if len(params) > 1 else params[0])
+        keep = no_ego & table.view(-1)[sweep_g * n_cls + pseudo]
+        hist_ms, hist_b = fused[:, :f].contiguous(), sample_of[sweep_g]
+    else:
+        hist_ms = torch.empty((0, f), dtype=cur_f.dtype, device=dev)
+        lab_h = torch.empty(0, dtype=torch.int64, device=dev)
+        keep = torch.empty(0, dtype=torch.bool, device=dev)
+        hist_b = torch.empty(0, dtype=torch.int64, device=dev)
+    return _stage.voxelize_batch_ms(cur_list, lab_list, cur_f, hist_ms, lab_h, keep, hist_b, voxel_size,
+                                    [s.get("name", "") for s in samples])
+
+
+def build_nuscenes_batch_per_sample(samples: List[Dict], voxel_size: float, steps: Sequence[int], in_feature_dim: int = 4) -> Dict:
+    """build_nuscenes_batch sample by sample (the form the batched stage replaced; its cross-check and TASEG_STAGE_BATCHED=0)"""
     out = []
     for s in samples:
         raw, lab, keep = fuse_sweeps(s["points"], s["labels"], s["hist_points"], s["hist_labels"], s["hist_pseudo"],

@@ -21,7 +21,7 @@ from .. import backend as B
 from ..torchsparse import SparseTensor
 
 __all__ = ["fuse_multiscan", "voxelize_sample_ms", "voxelize_sample", "collate_batch", "build_multiscan_batch",
-           "DevicePrefetcher"]
+           "build_multiscan_batch_per_sample", "voxelize_batch_ms", "rows_index", "DevicePrefetcher"]
 
 
 _static_cache = {}
@@ -161,10 +161,9 @@ def collate_batch(samples: List[Dict]) -> Dict:
     return out
 
 
-def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[int]) -> Dict:
-    """scans[b] = dict(points=[T+1 tensors, current LAST], labels=[...], poses=[...], name=str
-    [, deltas=[frame offsets of the history scans], pseudo=[pseudo classes of the history scans, see _fuse_history]]).
-    Returns the collated batch_dict MinkUNetMs consumes."""
+def build_multiscan_batch_per_sample(scans: List[Dict], voxel_size: float, steps: Sequence[int]) -> Dict:
+    """build_multiscan_batch sample by sample (fuse, clamp, two voxelisations and ~55 launches per sample, then collate): the
+    form the batched stage below replaced; kept as its cross-check (tests) and for TASEG_STAGE_BATCHED=0."""
     samples = []
     for s in scans:
         pts, lab, poses = s["points"], s["labels"], s["poses"]
@@ -175,6 +174,148 @@ def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[
         samples.append(voxelize_sample_ms(pts[t], lab[t].long(), raw_all, lab_all, voxel_size, s.get("name", ""),
                                           keep=keep))
     return collate_batch(samples)
+
+
+import os as _os
+
+_BATCHED = _os.environ.get("TASEG_STAGE_BATCHED", "1") != "0"
+_rows_cache = {}
+
+
+def rows_index(lengths: Sequence[int], device) -> torch.Tensor:
+    """int64 [sum(lengths)]: the index of the segment every concatenated row belongs to (built on the device from the lengths;
+    a few layouts are kept - resident synthetic scans repeat theirs every step)"""
+    key = (tuple(lengths), str(device))
+    hit = _rows_cache.get(key)
+    if hit is None:
+        if len(_rows_cache) >= 64:
+            _rows_cache.pop(next(iter(_rows_cache)))
+        total = int(sum(lengths))
+        lens = torch.tensor(list(lengths), dtype=torch.int64).to(device, non_blocking=True)
+        hit = torch.repeat_interleave(torch.arange(len(lengths), dtype=torch.int64, device=device), lens, output_size=total)
+        _rows_cache[key] = hit
+    return hit
+
+
+def voxelize_batch_ms(cur_list: List[torch.Tensor], lab_list: List[torch.Tensor], cur_ms: torch.Tensor, hist_pts: torch.Tensor,
+                      hist_lab: torch.Tensor, hist_keep: torch.Tensor, hist_b: torch.Tensor, voxel_size: float,
+                      names: List[str]) -> Dict:
+    """collate_batch([voxelize_sample_ms(...) for every sample]) for the WHOLE batch in one chain of launches
+    (semantickitti_voxel_ms.py:121-212 / nuscenes_voxel_ms.py:77-212): clamp of the fused clouds to their current scan's minimum
+    + class-step filter -> ONE compaction; the fused clouds laid out sample-major, current scan first (one stable sort on the
+    sample index); ONE voxelisation of all fused clouds (per-sample minima, batch-keyed radix sort: voxel order (b, x, y, z),
+    representative = first point, inverse map) and ONE of the current scans shifted by their fused cloud's minimum; gathers on
+    the whole batch.  Four host reads per batch (kept points, points per fused cloud, the two voxel counts) instead of three per
+    sample.  Same tensors, bit for bit, as the per-sample path.
+
+    cur_list[b] [n_b, F] / lab_list[b]: the current scans (single-frame cloud);  cur_ms [sum n_b, Fm]: the same points as they
+    appear in the fused clouds (time flag / time column);  hist_*: the transformed history points of all samples, sample-major
+    (hist_b ascending): points [Nh, Fm], labels [Nh] int64, keep flags [Nh] bool (class-step rule, ego box), sample index [Nh]."""
+    dev = cur_ms.device
+    nb = len(cur_list)
+    n_cur = [int(c.shape[0]) for c in cur_list]
+    cur = torch.cat(cur_list, 0).contiguous()
+    cur_lab = torch.cat(lab_list, 0)
+    cur_b = rows_index(n_cur, dev)
+    # minimum of every current scan (the reference clamps the fused cloud to it, :121-124): float min is exact in any order
+    lo = torch.full((nb, 3), float("inf"), dtype=cur.dtype, device=dev)
+    lo.scatter_reduce_(0, cur_b[:, None].expand(-1, 3), cur[:, :3], "amin", include_self=True)
+    if hist_pts.shape[0]:
+        sel = hist_keep & (hist_pts[:, :3] >= lo[hist_b]).all(1)
+        idx = sel.nonzero().squeeze(1)                                  # host read 1 (the compaction's size)
+        kept_pts, kept_lab, kept_b = hist_pts[idx], hist_lab[idx], hist_b[idx]
+        all_b = torch.cat([cur_b, kept_b])
+        ms_b, order = torch.sort(all_b, stable=True)                    # sample-major; inside a sample: current scan, then history
+        ms_pts = torch.cat([cur_ms, kept_pts], 0)[order].contiguous()
+        ms_lab = torch.cat([cur_lab, kept_lab], 0)[order]
+        point_mask = order < cur.shape[0]
+    else:
+        ms_b, ms_pts, ms_lab = cur_b, cur_ms.contiguous(), cur_lab
+        point_mask = torch.ones(cur.shape[0], dtype=torch.bool, device=dev)
+    edges = torch.arange(nb + 1, device=dev)
+    ms_start = torch.searchsorted(ms_b, edges)                          # first fused-cloud row of every sample (+ the total)
+    n_ms = (ms_start[1:] - ms_start[:-1]).tolist()                      # host read 2
+    coords_ms, mins = B.voxel_coords(ms_pts, voxel_size, batch_idx=ms_b.int(), n_batch=nb)
+    index_ms, inverse_ms = B.sparse_quantize(coords_ms)                 # host read 3 (voxels of the fused clouds)
+    coords_c, _ = B.voxel_coords(cur, voxel_size, batch_idx=cur_b.int(), n_batch=nb, shift=mins)    # pc_ -= pc_ms_.min(0)  (:130)
+    index_c, inverse_c = B.sparse_quantize(coords_c)                    # host read 4 (voxels of the current scans)
+    index_ms, index_c = index_ms.long(), index_c.long()
+
+    def per_sample(coords4, index, inverse, row_b):
+        vox = coords4[index].contiguous()                               # [m, 4] = x, y, z, sample: sorted by (sample, x, y, z)
+        vox_start = torch.searchsorted(vox[:, 3].contiguous().long(), edges)
+        return vox, vox_start[1:].int(), inverse.long() - vox_start[row_b]     # local voxel index of every point
+
+    vox_ms, offset_ms, inv_ms = per_sample(coords_ms, index_ms, inverse_ms, ms_b)
+    vox_c, offset_c, inv_c = per_sample(coords_c, index_c, inverse_c, cur_b)
+    return {
+        "name": list(names),
+        "lidar": SparseTensor(cur[index_c], vox_c), "targets": SparseTensor(cur_lab[index_c], vox_c),
+        "targets_mapped": SparseTensor(cur_lab, coords_c), "inverse_map": SparseTensor(inv_c, coords_c),
+        "num_points": torch.tensor(n_cur).view(-1, 1),
+        "lidar_ms": SparseTensor(ms_pts[index_ms], vox_ms), "targets_ms": SparseTensor(ms_lab[index_ms], vox_ms),
+        "targets_mapped_ms": SparseTensor(ms_lab, coords_ms), "inverse_map_ms": SparseTensor(inv_ms, coords_ms),
+        "num_points_ms": torch.tensor(n_ms).view(-1, 1),
+        "offset": offset_c, "offset_ms": offset_ms, "point_mask": point_mask,
+    }
+
+
+def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[int]) -> Dict:
+    """scans[b] = dict(points=[T+1 tensors, current LAST], labels=[...], poses=[...], name=str
+    [, deltas=[frame offsets of the history scans], pseudo=[pseudo classes of the history scans, see _fuse_history]]).
+    Returns the collated batch_dict MinkUNetMs consumes.  The whole batch goes through ONE chain of launches: one pose-fuse
+    launch over every history point of every sample (ts_fuse_scans_batch), the class-step rule as one table lookup, then
+    voxelize_batch_ms."""
+    if not _BATCHED or not scans:
+        return build_multiscan_batch_per_sample(scans, voxel_size, steps)
+    dev = scans[0]["points"][-1].device
+    n_cls = len(steps)
+    cur_list, lab_list, hist_pts, hist_lab, hist_ps, lengths, scan_sample, pose0s, poses, rows = [], [], [], [], [], [], [], [], [], []
+    for b, s in enumerate(scans):
+        pts, lab, ps = s["points"], s["labels"], s["poses"]
+        t = len(pts) - 1
+        deltas = s.get("deltas") or [i - t for i in range(t)]
+        cur_list.append(pts[t][:, :4] if pts[t].shape[1] != 4 else pts[t])
+        lab_list.append(lab[t].long())
+        pseudo = s.get("pseudo")
+        for i in range(t):
+            hist_pts.append(pts[i][:, :4])
+            hist_lab.append(lab[i])
+            hist_ps.append(lab[i] if pseudo is None else pseudo[i])
+            lengths.append(int(pts[i].shape[0]))
+            scan_sample.append(b)
+            pose0s.append(ps[t])
+            poses.append(ps[i])
+            # semantickitti_ms.py:303-308: class c is aggregated from the scan delta frames away iff steps[c] != 0 and
+            # |delta| % steps[c] == 0; last column: pseudo class -1 (no class's canonical raw id): never kept
+            rows.append([bool(st) and abs(deltas[i]) % st == 0 for st in steps] + [False])
+    cur4 = torch.cat(cur_list, 0)
+    cur_ms = torch.cat([cur4, torch.ones((cur4.shape[0], 1), dtype=cur4.dtype, device=dev)], 1)      # append_time_flag (:253-257)
+    if hist_pts:
+        hp = torch.cat(hist_pts, 0).contiguous()
+        hl = torch.cat(hist_lab, 0).long()
+        hps = hl if all(s.get("pseudo") is None for s in scans) else torch.cat(hist_ps, 0).long()
+        scan_g = rows_index(lengths, dev)
+        key = ("kitti-table", tuple(map(tuple, rows)), tuple(scan_sample), str(dev))
+        hit = _static_cache.get(key)
+        if hit is None:
+            if len(_static_cache) >= 64:
+                _static_cache.pop(next(iter(_static_cache)))
+            hit = (torch.tensor(rows, dtype=torch.bool).to(dev), torch.tensor(scan_sample, dtype=torch.int64).to(dev))
+            _static_cache[key] = hit
+        table, sample_of_scan = hit
+        fused = B.fuse_scans_batch(hp, scan_g.int(), torch.stack(pose0s, 0), torch.stack(poses, 0))
+        hps = torch.where(hps < 0, torch.full_like(hps, n_cls), hps)
+        keep = table.view(-1)[scan_g * (n_cls + 1) + hps]
+        hist_ms = torch.cat([fused, torch.zeros((fused.shape[0], 1), dtype=fused.dtype, device=dev)], 1)
+        hist_b = sample_of_scan[scan_g]
+    else:
+        hist_ms = torch.empty((0, 5), dtype=cur4.dtype, device=dev)
+        hl = torch.empty(0, dtype=torch.int64, device=dev)
+        keep = torch.empty(0, dtype=torch.bool, device=dev)
+        hist_b = torch.empty(0, dtype=torch.int64, device=dev)
+    return voxelize_batch_ms([s["points"][-1] for s in scans], lab_list, cur_ms, hist_ms, hl, keep, hist_b, voxel_size,
+                             [s.get("name", "") for s in scans])
 
 
 class DevicePrefetcher:

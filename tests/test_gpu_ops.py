@@ -561,6 +561,51 @@ def test_device_multiscan_stage_golden(g_multiscan):
         same(batch[key].to(torch.from_numpy(g[f"batch_{key}"]).dtype), g[f"batch_{key}"])
 
 
+def _same_batches(a, b):
+    from taseg_amd.torchsparse import SparseTensor
+    assert list(a) == list(b) or set(a) == set(b)
+    for key, v in a.items():
+        w = b[key]
+        if isinstance(v, SparseTensor):
+            assert v.C.dtype == w.C.dtype and v.F.dtype == w.F.dtype and torch.equal(v.C, w.C) and torch.equal(v.F, w.F), key
+        elif isinstance(v, torch.Tensor):
+            assert v.dtype == w.dtype and v.shape == w.shape and v.device == w.device and torch.equal(v, w), key
+        else:
+            assert v == w, key
+
+
+def test_batched_multiscan_stage_equals_the_per_sample_stage(g_multiscan):
+    """stage.build_multiscan_batch (ONE chain of launches for the batch: one pose fuse, one compaction, one batch-keyed
+    voxelisation per cloud kind) against the per-sample form it replaced (semantickitti_voxel_ms.py:121-212 sample by sample +
+    collate): every tensor of the batch_dict bit for bit, dtypes and devices included - on the golden scans, on a batch whose
+    second sample has NO history, with unequal history lengths, and with pseudo classes that are never aggregated (-1)"""
+    from taseg_amd.data import stage as S
+    g = g_multiscan
+    Tn = int(g["T"])
+    lm = g["learning_map"]
+    steps = g["steps"].tolist()
+
+    def scan(b, keep_hist=None, cut=None, pseudo=False):
+        ts = list(range(Tn + 1)) if keep_hist is None else keep_hist + [Tn]
+        pts = [T(g[f"b{b}_points_t{t}"]) for t in ts]
+        lab = [T(lm[g[f"b{b}_rawlabels_t{t}"]]) for t in ts]
+        if cut:
+            pts[0], lab[0] = pts[0][:cut].contiguous(), lab[0][:cut].contiguous()
+        d = {"points": pts, "labels": lab, "poses": [T(g[f"b{b}_pose_t{t}"]) for t in ts], "name": f"s{b}",
+             "deltas": [t - Tn for t in ts[:-1]]}
+        if pseudo:
+            ps = [l.long().clone() for l in lab[:-1]]
+            for p in ps:
+                p[::7] = -1
+            d["pseudo"] = ps
+        return d
+
+    cases = [[scan(0), scan(1)], [scan(0), scan(1, keep_hist=[])], [scan(1, keep_hist=[1, 3], cut=1000), scan(0), scan(0, keep_hist=[2])],
+             [scan(0, pseudo=True), scan(1)]]
+    for scans in cases:
+        _same_batches(S.build_multiscan_batch(scans, 0.05, steps), S.build_multiscan_batch_per_sample(scans, 0.05, steps))
+
+
 @pytest.mark.parametrize("n,c", [(5000, 32), (20011, 96), (777, 256), (3, 16), (12001, 128), (13000, 256), (30011, 64)])
 def test_batchnorm_train_matches_torch(n, c):
     """our reductions + torch's elementwise halves == nn.BatchNorm1d (training): output, grads, running stats"""

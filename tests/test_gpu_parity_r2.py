@@ -207,6 +207,13 @@ def test_nuscenes_stage_on_device_matches_reference(g_multiscan_nus):
         samples.append(dict(points=cur, labels=cur_lab, hist_points=hp, hist_labels=hl, hist_pseudo=hs, params=params,
                             name=f"s{b}"))
     batch = N.build_nuscenes_batch(samples, 0.1, steps)
+    # the batched stage (one chain of launches per batch) against the per-sample form it replaced: every tensor, bit for bit -
+    # also with a sample that has no sweeps at all
+    from test_gpu_ops import _same_batches
+    _same_batches(batch, N.build_nuscenes_batch_per_sample(samples, 0.1, steps))
+    bare = dict(samples[1], hist_points=[], hist_labels=[], hist_pseudo=[], params=samples[1]["params"][:0])
+    _same_batches(N.build_nuscenes_batch([samples[0], bare, samples[1]], 0.1, steps),
+                  N.build_nuscenes_batch_per_sample([samples[0], bare, samples[1]], 0.1, steps))
     for key in ("lidar", "lidar_ms", "inverse_map", "inverse_map_ms", "targets", "targets_ms", "targets_mapped",
                 "targets_mapped_ms"):
         assert np.array_equal(batch[key].C.cpu().numpy(), g[f"batch_{key}_C"]), key
