@@ -666,6 +666,11 @@ int ts_voxel_coords(const float *points, int64_t n, int32_t point_stride, float 
  *   out_index   [<=n] : for voxel v (ascending (b,x,y,z)) the index of its FIRST point in input order;
  *   out_inverse [n]   : voxel id of every point (global over the batch);
  *   *out_count        : number of voxels (-1 if a coordinate is outside [-2^17, 2^17) or b >= 1024). */
+/* out [n_seg, 3] = per-segment minimum of (x, y, z) of points [n, point_stride] whose segment index is seg[i] (int64, 0 ..
+ * n_seg - 1 <= 63): the current scan's minimum every fused cloud of a batch is clamped to (semantickitti_voxel_ms.py:121-124),
+ * all samples in one launch */
+int ts_segment_min3(const float *points, int64_t n, int32_t point_stride, const int64_t *seg, int32_t n_seg, float *out,
+                    ts_stream_t stream);
 size_t ts_quantize_workspace_bytes(int64_t n);
 int ts_sparse_quantize(const int32_t *coords, int64_t n, int32_t *out_index, int32_t *out_inverse,
                        int32_t *out_count, void *ws, size_t ws_bytes, ts_stream_t stream);

@@ -879,6 +879,19 @@ def voxel_coords(points, voxel_size, batch_idx=None, n_batch=1, shift=None):
     return out, (mins if shift is None else shift)
 
 
+def segment_min3(points, seg, n_seg):
+    """[n_seg, 3] float32: per-segment minimum of the first three columns of points [n, F]; seg [n] int64 segment index"""
+    L.require_device(points, seg)
+    points = _f32(points, "points")
+    if seg.dtype != torch.int64:
+        seg = seg.long()
+    seg = seg.contiguous()
+    out = torch.empty((int(n_seg), 3), dtype=torch.float32, device=points.device)
+    L.check(L.load().ts_segment_min3(L.ptr(points), points.shape[0], points.shape[1], L.ptr(seg), int(n_seg), L.ptr(out),
+                                     L.stream()), "ts_segment_min3")
+    return out
+
+
 def sparse_quantize(coords):
     """np.unique-style voxel grouping of int coords [n,4]: (index [m], inverse [n]) int32, m via one sync."""
     L.require_device(coords)

@@ -218,23 +218,37 @@ def voxelize_batch_ms(cur_list: List[torch.Tensor], lab_list: List[torch.Tensor]
     cur_lab = torch.cat(lab_list, 0)
     cur_b = rows_index(n_cur, dev)
     # minimum of every current scan (the reference clamps the fused cloud to it, :121-124): float min is exact in any order
-    lo = torch.full((nb, 3), float("inf"), dtype=cur.dtype, device=dev)
-    lo.scatter_reduce_(0, cur_b[:, None].expand(-1, 3), cur[:, :3], "amin", include_self=True)
+    lo = B.segment_min3(cur, cur_b, nb) if nb <= 64 else torch.stack([c[:, :3].t().contiguous().min(1).values for c in cur_list])
+    edges = torch.arange(nb + 1, device=dev)
+    n_c = cur.shape[0]
     if hist_pts.shape[0]:
         sel = hist_keep & (hist_pts[:, :3] >= lo[hist_b]).all(1)
         idx = sel.nonzero().squeeze(1)                                  # host read 1 (the compaction's size)
         kept_pts, kept_lab, kept_b = hist_pts[idx], hist_lab[idx], hist_b[idx]
-        all_b = torch.cat([cur_b, kept_b])
-        ms_b, order = torch.sort(all_b, stable=True)                    # sample-major; inside a sample: current scan, then history
-        ms_pts = torch.cat([cur_ms, kept_pts], 0)[order].contiguous()
-        ms_lab = torch.cat([cur_lab, kept_lab], 0)[order]
-        point_mask = order < cur.shape[0]
+        n_k = int(idx.shape[0])
+        # the fused clouds sample-major, current scan first, history behind it in its own order - written straight to their rows
+        # (no sort): current point i of sample b lands kept_start[b] rows further down, kept history point j cur_start[b + 1]
+        cur_start = torch.tensor([0] + list(torch.tensor(n_cur).cumsum(0).tolist()), dtype=torch.int64).to(dev, non_blocking=True)
+        kept_start = torch.searchsorted(kept_b, edges)
+        dest_cur = torch.arange(n_c, device=dev) + kept_start[cur_b]
+        dest_hist = torch.arange(n_k, device=dev) + cur_start[kept_b + 1]
+        ms_pts = torch.empty((n_c + n_k, cur_ms.shape[1]), dtype=cur_ms.dtype, device=dev)
+        ms_pts[dest_cur] = cur_ms
+        ms_pts[dest_hist] = kept_pts
+        ms_lab = torch.empty(n_c + n_k, dtype=cur_lab.dtype, device=dev)
+        ms_lab[dest_cur] = cur_lab
+        ms_lab[dest_hist] = kept_lab
+        ms_b = torch.empty(n_c + n_k, dtype=torch.int64, device=dev)
+        ms_b[dest_cur] = cur_b
+        ms_b[dest_hist] = kept_b
+        point_mask = torch.zeros(n_c + n_k, dtype=torch.bool, device=dev)
+        point_mask[dest_cur] = True
+        kept = (kept_start[1:] - kept_start[:-1]).tolist()              # host read 2 (kept history points per sample)
+        n_ms = [a + k for a, k in zip(n_cur, kept)]
     else:
         ms_b, ms_pts, ms_lab = cur_b, cur_ms.contiguous(), cur_lab
-        point_mask = torch.ones(cur.shape[0], dtype=torch.bool, device=dev)
-    edges = torch.arange(nb + 1, device=dev)
-    ms_start = torch.searchsorted(ms_b, edges)                          # first fused-cloud row of every sample (+ the total)
-    n_ms = (ms_start[1:] - ms_start[:-1]).tolist()                      # host read 2
+        point_mask = torch.ones(n_c, dtype=torch.bool, device=dev)
+        n_ms = list(n_cur)
     coords_ms, mins = B.voxel_coords(ms_pts, voxel_size, batch_idx=ms_b.int(), n_batch=nb)
     index_ms, inverse_ms = B.sparse_quantize(coords_ms)                 # host read 3 (voxels of the fused clouds)
     coords_c, _ = B.voxel_coords(cur, voxel_size, batch_idx=cur_b.int(), n_batch=nb, shift=mins)    # pc_ -= pc_ms_.min(0)  (:130)
