@@ -230,6 +230,7 @@ class KernelMap:
         self._total = None
         self.cls = None                       # plan of the class-sorted implicit GEMM (csrc/conv_class.hip), large 3x3x3 maps
         self.direct = None                    # {"down", "up"}: direct plans of a 2x2x2 strided map (no Z, no pass 2)
+        self._plans = {}                      # plans_for() answers (dropped when a plan is built)
 
     def build_class_plan(self):
         """Plan of the class-sorted implicit GEMM for a SUBMANIFOLD 3x3x3 map (in == out; the caller knows): rows sorted by
@@ -246,6 +247,7 @@ class KernelMap:
             cls["map_id"], cls["pairs"] = self.nboffs, self.total          # the identity of the map the plan belongs to
             if 128 * steps <= _CLASS_MAX_WORK * self.total:
                 self.cls = cls
+                self._plans.clear()
         return self.cls
 
     def build_direct_plans(self):
@@ -261,12 +263,21 @@ class KernelMap:
             for plan in (down, up):
                 plan["map_id"], plan["pairs"] = self.nboffs, self.total
             self.direct = {"down": down, "up": up}
+            self._plans.clear()
         return self.direct
 
     def plans_for(self, transposed: bool, c_in: int, c_out: int, half: bool):
         """(forward plan, input-gradient plan) of a convolution over this map with these channel counts - either may be None
         (pair GEMM + pass 2).  Submanifold 3x3x3: the one mirrored plan for both where class_gemm_pays; 2x2x2 strided: the direct
         plans of the two directions where direct_conv_pays."""
+        key = (transposed, c_in, c_out, half)
+        hit = self._plans.get(key)            # (asked ~4 times per block and step: the answer only depends on the key)
+        if hit is None:
+            hit = self._choose_plans(transposed, c_in, c_out, half)
+            self._plans[key] = hit
+        return hit
+
+    def _choose_plans(self, transposed, c_in, c_out, half):
         if not _dense_ok(c_in, c_out):
             return None, None
         if self.cls is not None and not transposed and class_gemm_pays(self.cls["n"], c_in, c_out, half):

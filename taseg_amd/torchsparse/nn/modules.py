@@ -161,9 +161,13 @@ def _plan_args(plan):
     mirror, direct) - or two empty lists"""
     if plan is None:
         return _NO_PLAN
-    direct = plan["rows"] is not None
-    return ([plan["src"], plan["tile_info"], plan["n_tiles"], plan["rows"] if direct else plan["pos"]],
-            [plan["n"], plan["m_pad"], int(plan.get("z_rows") or 0), plan["K"], plan["groups"], plan["mirror"], 1 if direct else 0])
+    hit = plan.get("_args")
+    if hit is None:
+        direct = plan["rows"] is not None
+        hit = ([plan["src"], plan["tile_info"], plan["n_tiles"], plan["rows"] if direct else plan["pos"]],
+               [plan["n"], plan["m_pad"], int(plan.get("z_rows") or 0), plan["K"], plan["groups"], plan["mirror"], 1 if direct else 0])
+        plan["_args"] = hit
+    return hit
 
 
 def _eval_invstd(mod):

@@ -553,7 +553,7 @@ def test_presplit_weight_planes_change_nothing(monkeypatch, optimizer):
 def test_residual_block_passes_its_input_through(monkeypatch, node, inc, outc):
     """ResidualBlock hands its input through the first conv block's autograd node (conv_bn_act(passthrough=True)): the
     shortcut's gradient - identity or 1x1x1 conv + BatchNorm - joins the store of conv1's input gradient
-    (ts_conv_block_addend_hint) instead of meeting it in an add launch.  Same bits as the separate add, on both nodes."""
+    (TsConvBlockOpts.addend) instead of meeting it in an add launch.  Same bits as the separate add, on both nodes."""
     from taseg_amd import _fast
     from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import ResidualBlock
     from taseg_amd.torchsparse import SparseTensor
@@ -627,3 +627,71 @@ def test_weight_gradient_bucket_slot_is_handed_out_once_per_step():
     for a, b in zip(got2, want2):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
     assert float((want2[0] - want1[0]).abs().max()) > 0           # the second pass really added something
+
+
+def test_block_call_options_are_explicit_and_checked(monkeypatch):
+    """Round 4: what a block call may use beyond its rulebook arrives as an argument (TsConvBlockOpts), nothing is taken from or
+    left in thread-local state.  (a) a stale ts_conv_planes_hint of the calling thread does not steer a block call; (b) a class
+    plan built from ANOTHER kernel map with the same row count (same K, same n - what the round-3 hint accepted) is ignored: the
+    call runs pair GEMM + pass 2 and gives the bits of a call without any plan; (c) the block's own plan is taken (other bits,
+    1e-6-close)."""
+    from taseg_amd import backend as B
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse import nn as spnn
+    from taseg_amd.torchsparse.nn import functional as F
+    from taseg_amd import _fast
+    monkeypatch.setattr(_fast, "_mod", None)            # the Python node: it builds the options struct from the KernelMap's plans
+    monkeypatch.setattr(_fast, "_tried", True)
+    for name in ("_CLASS_MIN_ROWS", "_CLASS_MIN_ROWS_96", "_CLASS_MIN_ROWS_128", "_CLASS_MIN_ROWS_HALF"):
+        monkeypatch.setattr(F, name, 1)
+    rs = np.random.RandomState(5)
+
+    def cloud(seed):                 # a two-voxel-thick random surface: LiDAR-like neighbour masks (the plan's work guard keeps it)
+        r = np.random.RandomState(seed)
+        xs, ys = np.meshgrid(np.arange(46), np.arange(46), indexing="ij")
+        h = np.cumsum(r.randint(-1, 2, size=(46, 46)), axis=1) + 30
+        c = np.stack([np.concatenate([xs.ravel(), xs.ravel()]), np.concatenate([ys.ravel(), ys.ravel()]),
+                      np.concatenate([h.ravel(), h.ravel() + 1])], 1).astype(np.int32)[:4000]
+        return torch.from_numpy(np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)).cuda()
+
+    ca, cb = cloud(1), cloud(2)
+    assert ca.shape == cb.shape and not torch.equal(ca, cb)
+    feats = torch.from_numpy(rs.randn(ca.shape[0], 64).astype(np.float32)).cuda()
+    gout = torch.from_numpy(rs.randn(ca.shape[0], 64).astype(np.float32)).cuda()
+    torch.manual_seed(0)
+    conv, bn = spnn.Conv3d(64, 64, 3).cuda(), spnn.BatchNorm(64).cuda().train()
+
+    def run(plan_from=None, own_plan=False, stale_hint=False):
+        x = SparseTensor(feats.clone().requires_grad_(), ca, 1)
+        F.build_pyramid(x, num_levels=0)
+        km = x.kmaps[((1, 1, 1), (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+        if own_plan:
+            assert km.build_class_plan() is not None
+        if plan_from is not None:                                       # the plan of another cloud's map, forced onto this one
+            other = SparseTensor(None, plan_from, 1)
+            F.build_pyramid(other, num_levels=0)
+            okm = other.kmaps[((1, 1, 1), (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+            assert okm.build_class_plan() is not None
+            km.cls = okm.cls
+            km._plans.clear()
+        if stale_hint:
+            junk = torch.zeros(3 * conv.kernel.numel(), dtype=torch.int16, device="cuda")
+            B.L.load().ts_conv_planes_hint(B.L.ptr(conv.kernel), B.L.ptr(junk), 27, 64, 64)
+        for m in (conv, bn):
+            m.zero_grad()
+        bn.reset_running_stats()
+        y = spnn.conv_bn_act(conv, bn, x, relu=True)
+        y.F.backward(gout)
+        return y.F.detach().clone(), x.F.grad.clone(), conv.kernel.grad.clone()
+
+    monkeypatch.setattr(F, "_CLASS_GEMM", False)
+    base = run()
+    hinted = run(stale_hint=True)
+    assert all(torch.equal(a, b) for a, b in zip(base, hinted))          # (a)
+    monkeypatch.setattr(F, "_CLASS_GEMM", True)
+    foreign = run(plan_from=cb)
+    assert all(torch.equal(a, b) for a, b in zip(base, foreign))         # (b): the foreign plan was not used
+    own = run(own_plan=True)
+    assert not torch.equal(own[0], base[0])                              # (c): the class path ran ...
+    for a, b in zip(own, base):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))       # ... and computes the same block
