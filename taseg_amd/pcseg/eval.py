@@ -95,18 +95,39 @@ def scan_confusions(ret_dict: Dict, unique_label: Sequence[int]) -> np.ndarray:
     return total
 
 
+def _staged(model, batches: Iterable[Dict], prefetch: bool):
+    """the batches with their index plan (coordinates only: coordinate pyramid, kernel maps, class plans, trilinear maps) built one
+    batch AHEAD on a second stream / worker thread (data.stage.DevicePrefetcher) - the role of the reference's DataLoader workers;
+    an evaluation pass then is forward + un-voxelisation only (bench.py --eval: 5.2 + 1.2 ms instead of 2.9 + 5.2 + 1.2 per batch)"""
+    prepare = getattr(model, "prepare", None)
+    if not prefetch or prepare is None:
+        yield from batches
+        return
+    from ..data.stage import DevicePrefetcher
+    it = iter(batches)
+    done = object()
+    pf = DevicePrefetcher(lambda: next(it, done), lambda b: b if b is done else prepare(b), threaded=True)
+    while True:
+        batch = pf.next()
+        if batch is done:
+            return
+        pf.prefetch_early()
+        yield batch
+
+
 def evaluate(model, batches: Iterable[Dict], num_class: int, tta_votes: int = 0, dataset: str = "semantickitti",
-             save_dir: str = None) -> Dict:
+             save_dir: str = None, prefetch: bool = True) -> Dict:
     """The loop body of Trainer.evaluate (R/train.py:465-540) over already collated, device-resident batches: validation
     (mIoU over the classes 1 .. num_class - 1) or, with tta_votes > 0, vote accumulation and optional writing of one
-    prediction file per scan.  Returns {"iou", "miou", "hist"} or {"predictions": [...]}."""
+    prediction file per scan.  Returns {"iou", "miou", "hist"} or {"predictions": [...]}.  prefetch: stage the index plan of the
+    next batch while this one runs (same results)."""
     import torch
     unique_label = np.arange(num_class - 1)
     hist, preds = np.zeros((num_class - 1, num_class - 1), dtype=np.int64), []
     was_training = model.training
     model.eval()
     try:
-        for batch in batches:
+        for batch in _staged(model, batches, prefetch):
             with torch.no_grad():
                 ret = model(batch)
             if tta_votes:

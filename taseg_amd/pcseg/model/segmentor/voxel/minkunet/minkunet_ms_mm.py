@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from taseg_amd.torchsparse import PointTensor
-from .minkunet import LazyScalar, MinkUNetBackbone
+from .minkunet import LazyScalar, MinkUNetBackbone, unvoxelise_predictions
 from .unet2d import UNet2D
 from .unet3d import UNet3D
 from .utils import voxel_to_point_fov
@@ -130,27 +130,10 @@ class MinkUNetMsMm(MinkUNetBackbone):
         if self.ensemble_type == "replace":
             out_ms = out_ms.clone()
             out_ms[overlap] = out_fusion
-        invs_ms = batch_dict["inverse_map_ms"]
-        all_labels = batch_dict["targets_mapped"]
-        point_mask = batch_dict["point_mask"]
-        num_points_ms = batch_dict["num_points_ms"]
-        point_predict, point_labels, point_predict_logits = [], [], []
-        cursor = 0
-        for idx in range(int(invs_ms.C[:, -1].max()) + 1):
-            scene = x_ms.C[:, -1] == idx
-            cur_inv = invs_ms.F[invs_ms.C[:, -1] == idx]
-            n_ms = int(num_points_ms[idx])
-            mapped = out_ms[scene][cur_inv][point_mask[cursor: cursor + n_ms]]
-            n_cur = int(batch_dict["num_points"][idx])
-            if return_logit or return_tta:
-                point_predict.append(mapped.softmax(1)[:n_cur].cpu().numpy())
-            else:
-                point_predict.append(mapped.argmax(1)[:n_cur].cpu().numpy())
-                point_predict_logits.append(mapped[:n_cur].cpu().numpy())
-            point_labels.append(all_labels.F[all_labels.C[:, -1] == idx][:n_cur].cpu().numpy())
-            cursor += n_ms
-        return {"point_predict": point_predict, "point_labels": point_labels, "name": batch_dict["name"],
-                "point_predict_logits": point_predict_logits}
+        # the evaluation tail of MinkUNetMs for the whole batch at once (minkunet.unvoxelise_predictions)
+        return unvoxelise_predictions(out_ms, x_ms.C[:, -1], batch_dict["inverse_map_ms"], batch_dict["targets_mapped"],
+                                      batch_dict["num_points"], return_logit or return_tta, point_mask=batch_dict["point_mask"],
+                                      num_points_ms=batch_dict["num_points_ms"], names=batch_dict["name"])
 
     def forward_ensemble(self, batch_dict):
         return self.forward(batch_dict, return_tta=True)

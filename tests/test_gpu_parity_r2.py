@@ -150,6 +150,28 @@ def test_eval_dictionary_and_tta_votes(g_eval_ms, tag, name, in_dim):
     assert hist.shape == (19, 19) and np.abs(hist - want).sum() <= 4
 
 
+def test_evaluate_loop_with_and_without_the_staged_index_plan(g_eval_ms):
+    """pcseg.eval.evaluate (the loop body of Trainer.evaluate, R/train.py:465-540): the same confusion matrix / mIoU whether the
+    index plan of the next batch is staged ahead on a second stream (the default) or built inline, equal to the matrices of the
+    reference's own predictions on these batches (up to arg-max flips on 1e-3 near-ties); the TTA branch returns one payload per
+    batch"""
+    from taseg_amd.pcseg import eval as E
+    from taseg_amd.pcseg.model import build_network
+    g = g_eval_ms
+    cfg = make_model_cfg("MinkUNetMs", in_dim=5, cr=0.5, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().train()
+    batches = lambda: (_eval_batch(g, "batch_") for _ in range(3))  # noqa: E731
+    a = E.evaluate(model, batches(), 20)
+    b = E.evaluate(model, batches(), 20, prefetch=False)
+    assert model.training                                            # the mode the caller had is restored
+    assert np.array_equal(a["hist"], b["hist"]) and a["miou"] == b["miou"]
+    want = 3 * sum(E.fast_hist_crop(g[f"minkunet_ms_point_predict_{i}"], g[f"minkunet_ms_point_labels_{i}"], np.arange(19)) for i in range(2))
+    assert a["hist"].shape == (19, 19) and np.abs(a["hist"] - want).sum() <= 12
+    tta = E.evaluate(model, (_eval_batch(g, "tta_") for _ in range(2)), 20, tta_votes=int(g["votes"]))
+    assert len(tta["predictions"]) == 2 and np.array_equal(tta["predictions"][0], tta["predictions"][1])
+    assert (tta["predictions"][0] == g["minkunet_ms_tta_label"]).mean() >= 0.999
+
+
 def test_reference_format_checkpoint_loads(tmp_path):
     """R/train.py:319-342 checkpoint layout, DDP-prefixed keys: load_params_from_file (base_segmentors.py:16-37), then
     the loaded model reproduces the reference model's eval logits"""

@@ -16,6 +16,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_
 for t in default amp nus_amp; do python tools/kstats.py $OUT/trace_$t 25 45 > $OUT/kstats_$t.txt; done
 python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $(find $OUT/pmc_fetch_amp -name "*counter_collection.csv") $(find $OUT/pmc_write_amp -name "*counter_collection.csv") > $OUT/traffic.txt
 cp profiles/traffic.json $OUT/traffic.json
+# the data stage alone under the profiler: launches and GPU time per batch = totals / 23 batches (3 warm-up + 20 timed) per form
+for wl in minkunet_ms nuscenes_ms; do for form in batched per_sample; do
+  $RP -d $OUT/trace_stage_${wl}_$form -- python3 tools/stage_probe.py --workload $wl --only $form --reps 20 > $OUT/stage_${wl}_$form.txt 2> /dev/null
+  python tools/kstats.py $OUT/trace_stage_${wl}_$form 23 12 > $OUT/kstats_stage_${wl}_$form.txt; done; done
+python tools/stage_probe.py > $OUT/stage_probe.txt 2> /dev/null
+for w in "--eval" "--eval --amp"; do tag=$(echo $w | tr -d ' -'); python bench.py $w --no-cpu-baseline --no-secondary --steps 40 --warmup 8 > $OUT/bench_$tag.json 2> /dev/null; done
+python tools/eval_probe.py > $OUT/eval_probe.txt 2> /dev/null; python tools/eval_probe.py --amp >> $OUT/eval_probe.txt 2> /dev/null
 for w in "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist"; do
   tag=$(echo $w | tr -d ' -'); python bench.py $w --no-cpu-baseline --no-secondary --steps 30 --warmup 5 > $OUT/bench_$tag.json 2> /dev/null; done
 tail -c 400 $OUT/bench_default.json
