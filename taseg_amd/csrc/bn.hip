@@ -9,6 +9,8 @@
 //     (ts_bn_act_train_forward / _backward, fp32 and half storage);
 //   * the SyncBatchNorm reduction halves whose double sums the host all-reduces (ts_bn_sync_*).
 // Accumulation: float per lane over one slice (<= ~350 rows), double across slices.
+#include <stdlib.h>
+
 #include "common.h"
 
 // mean / invstd from the double sums + running-statistics update (nn.BatchNorm1d semantics: biased variance
@@ -340,6 +342,17 @@ static inline int bn_rows_per_slice(int64_t n, int c) {
   return (int)rows;
 }
 
+// TASEG_DEBUG_BN_ABLATE (diagnostic, WRONG results, timing only; fp32 path): bit 0 skips the forward statistics pass
+// (bn_partial<0>) - what "statistics in the epilogue of the pass that produces y" could save at most; bit 1 skips the forward
+// elementwise pass of the blocks without a residual - the most "normalise where the consumer gathers the row" could save.
+static int bn_debug_ablate() {
+  static const int v = [] {
+    const char *e = getenv("TASEG_DEBUG_BN_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 extern "C" size_t ts_bn_train_workspace_bytes(int32_t c) {
   // float partials [BN_MAX_SLICES][2][C] + float coefficients [2][C]
   return ((size_t)BN_MAX_SLICES * 2 * c + 2 * (size_t)c) * sizeof(float);
@@ -363,14 +376,16 @@ extern "C" int ts_bn_act_train_forward(const float *x, const float *residual, co
   float *part = (float *)ws;
   const int rows = bn_rows_per_slice(n, c);
   const int slices = (int)ts_cdiv(n, rows);
-  bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);
+  const int ablate = bn_debug_ablate();       // diagnostic (wrong results, timing only): upper bounds of two fusions, see below
+  if (!(ablate & 1)) bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);
   bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum,
                                                                      running_mean, running_var, mean, invstd,
                                                                      num_batches_tracked);
   const int64_t total4 = n * (c / 4);
   const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
-  bn_act_fwd_kernel<<<grid, 256, 0, stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd, weight, bias,
-                                              total4, c / 4, relu, (float4 *)out, mask);
+  if (!((ablate & 2) && !residual && relu))
+    bn_act_fwd_kernel<<<grid, 256, 0, stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd, weight, bias,
+                                                total4, c / 4, relu, (float4 *)out, mask);
   TS_CHECK_LAUNCH("ts_bn_act_train_forward");
   return TS_OK;
 }

@@ -13,13 +13,18 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 bench.py --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_amp -o f -- python3 bench.py --amp --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_fetch_amp.json 2> $OUT/pmc_fetch_amp.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_amp -o w -- python3 bench.py --amp --no-cpu-baseline --no-secondary --no-kernel-events --steps 2 --warmup 1 > $OUT/pmc_write_amp.json 2> $OUT/pmc_write_amp.err
+# keep the summaries (kernel_stats.csv per run), drop the per-dispatch traces: gpurun copies back at most 64 MiB
+keep_stats() { f=$(find $OUT/$1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/$2_kernel_stats.csv; rm -rf $OUT/$1; }
 for t in default amp nus_amp; do python tools/kstats.py $OUT/trace_$t 25 45 > $OUT/kstats_$t.txt; done
+keep_stats trace_default bench; keep_stats trace_amp bench_amp; keep_stats trace_nus_amp bench_nuscenes_amp
 python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $(find $OUT/pmc_fetch_amp -name "*counter_collection.csv") $(find $OUT/pmc_write_amp -name "*counter_collection.csv") > $OUT/traffic.txt
 cp profiles/traffic.json $OUT/traffic.json
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_amp $OUT/pmc_write_amp
 # the data stage alone under the profiler: launches and GPU time per batch = totals / 23 batches (3 warm-up + 20 timed) per form
 for wl in minkunet_ms nuscenes_ms; do for form in batched per_sample; do
   $RP -d $OUT/trace_stage_${wl}_$form -- python3 tools/stage_probe.py --workload $wl --only $form --reps 20 > $OUT/stage_${wl}_$form.txt 2> /dev/null
-  python tools/kstats.py $OUT/trace_stage_${wl}_$form 23 12 > $OUT/kstats_stage_${wl}_$form.txt; done; done
+  python tools/kstats.py $OUT/trace_stage_${wl}_$form 23 12 > $OUT/kstats_stage_${wl}_$form.txt
+  keep_stats trace_stage_${wl}_$form stage_${wl}_$form; done; done
 python tools/stage_probe.py > $OUT/stage_probe.txt 2> /dev/null
 for w in "--eval" "--eval --amp"; do tag=$(echo $w | tr -d ' -'); python bench.py $w --no-cpu-baseline --no-secondary --steps 40 --warmup 8 > $OUT/bench_$tag.json 2> /dev/null; done
 python tools/eval_probe.py > $OUT/eval_probe.txt 2> /dev/null; python tools/eval_probe.py --amp >> $OUT/eval_probe.txt 2> /dev/null
