@@ -632,6 +632,10 @@ int64_t ts_conv_class_rows2(int64_t n, int32_t groups);
 size_t ts_conv_class_plan_workspace_bytes(int64_t n);
 int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t groups, int32_t *src, int32_t *tile_info,
                        int32_t *n_tiles, int32_t *pos, int32_t *rows, void *ws, size_t ws_bytes, ts_stream_t stream);
+/* the direct plan of a strided map's one-pair-per-destination direction (destination = its input rows) straight from the rulebook,
+ * without a sort (slot p = pair p; needs n_pairs == number of destination rows); ws >= 4 * ceil(n_pairs / 128) bytes */
+int ts_conv_class_plan_pairs(const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int64_t n_pairs, int32_t *src,
+                             int32_t *tile_info, int32_t *n_tiles, int32_t *rows, void *ws, size_t ws_bytes, ts_stream_t stream);
 int ts_conv_nbr_transposed(const int32_t *pos_in, const int32_t *nbmaps, int32_t K, int64_t n_in, int32_t *nbr_t,
                            ts_stream_t stream);
 int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);

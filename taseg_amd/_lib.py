@@ -127,6 +127,7 @@ SIGNATURES = {
     "ts_conv_class_rows2": (_i64, [_i64, _i32]),
     "ts_conv_class_plan_workspace_bytes": (_sz, [_i64]),
     "ts_conv_class_plan": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_conv_class_plan_pairs": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_conv_nbr_transposed": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "ts_conv_class_supported": (_i32, [_i32, _i32]),
     "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

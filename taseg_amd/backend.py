@@ -941,6 +941,27 @@ def conv_class_plan(nbr, groups=3, direct=False):
                 mirror=0 if direct else 1, z_rows=0, map_id=None)
 
 
+def conv_class_plan_pairs(nbmaps, nboffs, k, n_pairs):
+    """Direct plan of the one-pair-per-destination direction of a strided map (destination = the map's INPUT rows: transposed
+    forward, strided input gradient) straight from its rulebook - no sort, 2 launches.  n_pairs must equal the number of
+    destination rows (every input row in exactly one pair)."""
+    L.require_device(nbmaps, nboffs)
+    nbmaps, nboffs = _i32(nbmaps, "nbmaps"), _i32(nboffs, "nboffs")
+    lib = L.load()
+    n = int(n_pairs)
+    m_pad = int(lib.ts_conv_class_rows2(n, 1))
+    dev = nbmaps.device
+    src = torch.empty((k, m_pad), dtype=torch.int32, device=dev)
+    tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
+    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)
+    rows = torch.empty(m_pad, dtype=torch.int32, device=dev)
+    ws = L.workspace(4 * (m_pad // 128) + 256, dev)
+    L.check(lib.ts_conv_class_plan_pairs(L.ptr(nbmaps), L.ptr(nboffs), k, n, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles),
+                                         L.ptr(rows), L.ptr(ws), ws.numel(), L.stream()), "ts_conv_class_plan_pairs")
+    return dict(src=src, tile_info=tile_info, n_tiles=n_tiles, pos=None, rows=rows, m_pad=m_pad, n=n, K=k, groups=1, mirror=0,
+                z_rows=0, map_id=None)
+
+
 def conv_nbr_transposed(pos_in, nbmaps, k):
     """nbr_t [K, n_in]: the output row fed by input row i through offset k, or -1 (the table of a kernel map's transposed use)"""
     L.require_device(pos_in, nbmaps)

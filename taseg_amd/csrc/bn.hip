@@ -342,9 +342,11 @@ static inline int bn_rows_per_slice(int64_t n, int c) {
   return (int)rows;
 }
 
-// TASEG_DEBUG_BN_ABLATE (diagnostic, WRONG results, timing only; fp32 path): bit 0 skips the forward statistics pass
-// (bn_partial<0>) - what "statistics in the epilogue of the pass that produces y" could save at most; bit 1 skips the forward
-// elementwise pass of the blocks without a residual - the most "normalise where the consumer gathers the row" could save.
+// TASEG_DEBUG_BN_ABLATE (diagnostic, fp32 path).  Bits 0 / 1 (WRONG results, timing only): skip the forward statistics pass
+// (bn_partial<0>) / the forward elementwise pass of the blocks without a residual.  Garbage activations also change what the
+// chip draws, so the CLEAN measurement is bits 2 / 3: run the same pass TWICE (same results) - the step's slow-down is what one such
+// pass costs in the step, launch gap included: the most "statistics in the epilogue of the pass that produces y" / "normalise where
+// the consumer gathers the row" could save.
 static int bn_debug_ablate() {
   static const int v = [] {
     const char *e = getenv("TASEG_DEBUG_BN_ABLATE");
@@ -378,12 +380,16 @@ extern "C" int ts_bn_act_train_forward(const float *x, const float *residual, co
   const int slices = (int)ts_cdiv(n, rows);
   const int ablate = bn_debug_ablate();       // diagnostic (wrong results, timing only): upper bounds of two fusions, see below
   if (!(ablate & 1)) bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);
+  if (ablate & 4) bn_partial_kernel<0><<<slices, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, n, c, rows, part);   // the pass once more
   bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum,
                                                                      running_mean, running_var, mean, invstd,
                                                                      num_batches_tracked);
   const int64_t total4 = n * (c / 4);
   const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total4, 256), 1 << 16);
   if (!((ablate & 2) && !residual && relu))
+    bn_act_fwd_kernel<<<grid, 256, 0, stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd, weight, bias,
+                                                total4, c / 4, relu, (float4 *)out, mask);
+  if ((ablate & 8) && !residual && relu)          // the same pass once more (same results)
     bn_act_fwd_kernel<<<grid, 256, 0, stream>>>((const float4 *)x, (const float4 *)residual, mean, invstd, weight, bias,
                                                 total4, c / 4, relu, (float4 *)out, mask);
   TS_CHECK_LAUNCH("ts_bn_act_train_forward");

@@ -178,6 +178,55 @@ extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int3
   return TS_OK;
 }
 
+// Direct plan of the ONE-PAIR-PER-DESTINATION direction of a strided map (destination = its fine / input rows: the transposed
+// forward and the strided input gradient) straight from the rulebook, without a sort: the pairs are ordered by offset already, so
+// slot p = pair p, rows[p] = its input row, src[k(p)][p] = its output row - tiles of 128 consecutive pairs hold one offset (two
+// where they straddle an offset boundary).  Needs every destination row in exactly one pair (n_pairs == n: 2x2x2 / stride-2 maps,
+// SURVEY App. A); 2 launches instead of the ~10 of the sorted builder.
+__global__ __launch_bounds__(CG_BM) void class_fill_pairs_kernel(const int2 *__restrict__ nbmaps, const int *__restrict__ nboffs,
+                                                                int K, int64_t n_pairs, int64_t m_pad, int *__restrict__ src,
+                                                                int *__restrict__ rows, int *__restrict__ tile_mask) {
+  __shared__ unsigned wmask[CG_BM / 64];
+  const int64_t i = (int64_t)blockIdx.x * CG_BM + threadIdx.x;
+  int k = -1;
+  int2 pr = make_int2(-1, -1);
+  if (i < n_pairs) {
+    pr = nbmaps[i];
+#pragma unroll
+    for (int kk = 0; kk < CG_GK; ++kk)
+      if (kk < K && i >= nboffs[kk]) k = kk;
+  }
+#pragma unroll
+  for (int kl = 0; kl < CG_GK; ++kl)
+    if (kl < K) src[(int64_t)kl * m_pad + i] = (kl == k) ? pr.y : -1;
+  rows[i] = k >= 0 ? pr.x : -1;
+  unsigned m = k >= 0 ? ((1u << k) | (1u << 30)) : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, 64);
+  if ((threadIdx.x & 63) == 0) wmask[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_mask[blockIdx.x] = (int)(wmask[0] | wmask[1]);
+}
+
+extern "C" int ts_conv_class_plan_pairs(const int32_t *nbmaps, const int32_t *nboffs, int32_t K, int64_t n_pairs, int32_t *src,
+                                        int32_t *tile_info, int32_t *n_tiles, int32_t *rows, void *ws, size_t ws_bytes,
+                                        ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(K > 0 && K <= CG_GK, TS_ERR_UNSUPPORTED, "ts_conv_class_plan_pairs: 1 .. 9 offsets (got %d)", K);
+  TS_REQUIRE(n_pairs > 0 && n_pairs < (1LL << 28), TS_ERR_INVALID_ARGUMENT, "ts_conv_class_plan_pairs: bad pair count");
+  TS_REQUIRE(nbmaps && nboffs && src && tile_info && n_tiles && rows && ws, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_class_plan_pairs: null pointer");
+  const int64_t m = cg_npad(n_pairs);
+  TS_REQUIRE(ws_bytes >= ts_align_up((size_t)(m / CG_BM) * 4, 256), TS_ERR_WORKSPACE_TOO_SMALL,
+             "ts_conv_class_plan_pairs: workspace too small");
+  int *tmask = (int *)ws;
+  class_fill_pairs_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>((const int2 *)nbmaps, nboffs, K, n_pairs, m, src, rows, tmask);
+  TS_CHECK_LAUNCH("ts_conv_class_plan_pairs/fill");
+  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), m, 1, (int2 *)tile_info, n_tiles);
+  TS_CHECK_LAUNCH("ts_conv_class_plan_pairs/tiles");
+  return TS_OK;
+}
+
 // inverse table of a kernel map for the plans of its transposed direction: nbr_t[k][i] = output row fed by input row i through
 // offset k (nbmaps[pos_in[k][i]].y) or -1
 __global__ __launch_bounds__(256) void class_nbr_t_kernel(const int *__restrict__ pos_in, const int2 *__restrict__ nbmaps,

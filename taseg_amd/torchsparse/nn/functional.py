@@ -258,10 +258,19 @@ class KernelMap:
         convolution's input gradient (convolution_cuda.cu:21,34: transpose swaps the map's columns).  No host read."""
         k = self.nbr.shape[0]
         if _DIRECT_CONV and self.direct is None and k <= 9 and min(self.sizes) >= _DIRECT_MIN_ROWS and self.total > 0:
-            down = B.conv_class_plan(self.nbr, direct=True)
-            up = B.conv_class_plan(B.conv_nbr_transposed(self.pos_in, self.nbmaps_buf, k), direct=True)
+            n_in, n_out = self.sizes
+            # "up": every input row sits in exactly one pair (total == n_in): the plan IS the rulebook order, no sort (2 launches);
+            # otherwise the sorted builder on the inverse table.  "down" is only ever chosen above _DIRECT_DOWN_MIN_ROWS
+            # destination rows (direct_conv_pays): smaller maps go without (the builder is a radix sort + 3 kernels per plan, on
+            # the staging stream beside the training step)
+            if self.total == n_in:
+                up = B.conv_class_plan_pairs(self.nbmaps_buf, self.nboffs, k, self.total)
+            else:
+                up = B.conv_class_plan(B.conv_nbr_transposed(self.pos_in, self.nbmaps_buf, k), direct=True)
+            down = B.conv_class_plan(self.nbr, direct=True) if (n_out >= _DIRECT_DOWN_MIN_ROWS or _DIRECT_FORCE) else None
             for plan in (down, up):
-                plan["map_id"], plan["pairs"] = self.nboffs, self.total
+                if plan is not None:
+                    plan["map_id"], plan["pairs"] = self.nboffs, self.total
             self.direct = {"down": down, "up": up}
             self._plans.clear()
         return self.direct
@@ -286,8 +295,8 @@ class KernelMap:
             d = self.direct
             fwd, dgrad = (d["up"], d["down"]) if transposed else (d["down"], d["up"])
             # (forward: reduces over c_in, writes c_out columns; input gradient: the other way round)
-            return (fwd if direct_conv_pays(fwd is d["up"], fwd["n"], c_in, c_out, half) else None,
-                    dgrad if direct_conv_pays(dgrad is d["up"], dgrad["n"], c_out, c_in, half) else None)
+            return (fwd if fwd is not None and direct_conv_pays(fwd is d["up"], fwd["n"], c_in, c_out, half) else None,
+                    dgrad if dgrad is not None and direct_conv_pays(dgrad is d["up"], dgrad["n"], c_out, c_in, half) else None)
         return None, None
 
     def class_rows(self) -> int:
@@ -334,6 +343,7 @@ _CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
 # one-pass 2x2x2 strided / transposed convolutions on direct class plans (TASEG_DIRECT_CONV=0: pair GEMM + pass 2)
 _DIRECT_CONV = os.environ.get("TASEG_DIRECT_CONV", "1") != "0"
 _DIRECT_MIN_ROWS = int(os.environ.get("TASEG_DIRECT_MIN_ROWS", "0"))
+_DIRECT_DOWN_MIN_ROWS = 8000        # smallest destination-row count any "down" plan is chosen at (direct_conv_pays)
 _DIRECT_FORCE = os.environ.get("TASEG_DIRECT_CONV") == "force"        # every fitting 2x2x2 product on its direct plan (tests, probes)
 
 

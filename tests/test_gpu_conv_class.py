@@ -254,6 +254,13 @@ def test_direct_plans_are_the_strided_and_transposed_convolution(ci, co, half):
                 assert same, name              # one pair per destination row: nothing is added, the product is the result
     y_again = cg(T(xf), wt, B.conv_class_plan(km["nbr"], direct=True))
     assert torch.equal(y_again, got["strided forward"])                       # deterministic across plan builds
+    # the sort-free "up" plan (slot = rulebook pair: ts_conv_class_plan_pairs) computes the same rows, bit for bit
+    up2 = B.conv_class_plan_pairs(km["nbmaps"], km["nboffs"], 8, total)
+    assert total == nf and up2["m_pad"] == up["m_pad"]
+    r2 = up2["rows"].cpu().numpy()
+    assert np.array_equal(np.sort(r2[r2 >= 0]), np.arange(nf)) and np.array_equal(r2[:total], nbmaps[:, 0])
+    assert torch.equal(cg(T(gc), wt, up2, weight_transposed=True), got["strided input gradient"])
+    assert torch.equal(cg(T(xc), wt, up2), got["transposed forward"])
 
 
 def test_direct_plan_writes_zero_rows_without_neighbours():

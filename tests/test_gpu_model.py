@@ -648,10 +648,10 @@ def test_block_call_options_are_explicit_and_checked(monkeypatch):
 
     def cloud(seed):                 # a two-voxel-thick random surface: LiDAR-like neighbour masks (the plan's work guard keeps it)
         r = np.random.RandomState(seed)
-        xs, ys = np.meshgrid(np.arange(46), np.arange(46), indexing="ij")
-        h = np.cumsum(r.randint(-1, 2, size=(46, 46)), axis=1) + 30
+        xs, ys = np.meshgrid(np.arange(150), np.arange(140), indexing="ij")
+        h = np.cumsum(r.randint(-1, 2, size=(150, 140)) * (r.rand(150, 140) < 0.2), axis=1) + 60
         c = np.stack([np.concatenate([xs.ravel(), xs.ravel()]), np.concatenate([ys.ravel(), ys.ravel()]),
-                      np.concatenate([h.ravel(), h.ravel() + 1])], 1).astype(np.int32)[:4000]
+                      np.concatenate([h.ravel(), h.ravel() + 1])], 1).astype(np.int32)[:40000]
         return torch.from_numpy(np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)).cuda()
 
     ca, cb = cloud(1), cloud(2)
