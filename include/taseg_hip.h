@@ -675,6 +675,26 @@ int ts_voxel_coords(const float *points, int64_t n, int32_t point_stride, float 
  * all samples in one launch */
 int ts_segment_min3(const float *points, int64_t n, int32_t point_stride, const int64_t *seg, int32_t n_seg, float *out,
                     ts_stream_t stream);
+/* The batched data stage (csrc/stage.hip, taseg_amd/data/stage.py::voxelize_batch_ms): the per-point decisions and the layout of
+ * the fused clouds of a WHOLE batch (semantickitti_ms.py:303-308, semantickitti_voxel_ms.py:121-212; nuscenes_ms.py:320-328).
+ *   ts_stage_keep_flags   keep[i] = pre_keep[i] (optional) AND table[scan_idx[i]][cls[i] (neg_col where cls[i] < 0)] AND
+ *                         xyz(i) >= lo[sample] ; sample[i] = sample_of_scan[scan_idx[i]]  (table [n_scans, table_cols] bytes)
+ *   ts_stage_layout       the fused clouds sample-major, current scan first: pts [n_cur + n_kept, f], lab, sample (int64 and
+ *                         int32), is_cur, from the current points (cur_b ascending, cur_start [B + 1] their cumulative counts), the
+ *                         history rows and the ascending indices idx [n_kept] of the kept ones (kept_start [B + 1] cumulative)
+ *   ts_stage_split_voxels after ts_sparse_quantize on the batch: vox [m, 4] = coords4[index], start [B + 1] first voxel of every
+ *                         sample, offset [B] cumulative voxel counts, inverse_local[i] = inverse[i] - start[row_sample[i]] */
+int ts_stage_keep_flags(const float *points, int64_t n, int32_t point_stride, const uint8_t *pre_keep, const int32_t *scan_idx,
+                        const int64_t *cls, const uint8_t *table, int32_t n_scans, int32_t table_cols, int32_t neg_col,
+                        const int64_t *sample_of_scan, const float *lo, int32_t n_samples, uint8_t *keep, int64_t *sample,
+                        ts_stream_t stream);
+int ts_stage_layout(const float *cur, const int64_t *cur_lab, const int64_t *cur_b, int64_t n_cur, const float *hist,
+                    const int64_t *hist_lab, const int64_t *hist_b, const int64_t *idx, int64_t n_kept, int32_t f,
+                    const int64_t *cur_start, const int64_t *kept_start, float *pts, int64_t *lab, int64_t *sample, int32_t *sample32,
+                    uint8_t *is_cur, ts_stream_t stream);
+int ts_stage_split_voxels(const int32_t *coords4, const int32_t *index, int64_t m, const int32_t *inverse,
+                          const int64_t *row_sample, int64_t n, int32_t n_samples, int32_t *vox, int64_t *start, int32_t *offset,
+                          int64_t *inverse_local, ts_stream_t stream);
 size_t ts_quantize_workspace_bytes(int64_t n);
 int ts_sparse_quantize(const int32_t *coords, int64_t n, int32_t *out_index, int32_t *out_inverse,
                        int32_t *out_count, void *ws, size_t ws_bytes, ts_stream_t stream);

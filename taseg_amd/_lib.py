@@ -141,6 +141,9 @@ SIGNATURES = {
     "ts_project_fov": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _c.c_float, _vp, _vp, _vp]),
     "ts_project_cam": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _c.c_float, _vp, _vp, _vp]),
     "ts_segment_min3": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "ts_stage_keep_flags": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ts_stage_layout": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ts_stage_split_voxels": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ts_quantize_workspace_bytes": (_sz, [_i64]),
     "ts_sparse_quantize": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_voxel_coords": (_i32, [_vp, _i64, _i32, _c.c_float, _vp, _i32, _vp, _vp, _vp, _vp]),

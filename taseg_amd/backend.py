@@ -892,6 +892,67 @@ def segment_min3(points, seg, n_seg):
     return out
 
 
+def stage_keep_flags(points, scan_idx, cls, table, sample_of_scan, lo, pre_keep=None, neg_col=-1):
+    """csrc/stage.hip: (keep [n] bool, sample [n] int64) of the history points of a batch - class-step table AND the optional
+    pre-filter AND the clamp to the sample's current-scan minimum.  points [n, F] float32, scan_idx [n] int32, cls [n] int64,
+    table [S, C] bool, sample_of_scan [S] int64, lo [B, 3] float32."""
+    L.require_device(points, scan_idx, cls, table, sample_of_scan, lo, pre_keep)
+    points, scan_idx, lo = _f32(points, "points"), _i32(scan_idx, "scan_idx"), _f32(lo, "lo")
+    cls, sample_of_scan = cls.long().contiguous(), sample_of_scan.long().contiguous()
+    table = table.contiguous()
+    if table.dtype not in (torch.bool, torch.uint8) or table.ndim != 2:
+        raise TypeError("table must be a bool / uint8 matrix")
+    if pre_keep is not None:
+        pre_keep = pre_keep.contiguous()
+        if pre_keep.dtype not in (torch.bool, torch.uint8):
+            raise TypeError("pre_keep must be bool / uint8")
+    n = points.shape[0]
+    keep = torch.empty(n, dtype=torch.bool, device=points.device)
+    sample = torch.empty(n, dtype=torch.int64, device=points.device)
+    L.check(L.load().ts_stage_keep_flags(L.ptr(points), n, points.shape[1], L.ptr(pre_keep), L.ptr(scan_idx), L.ptr(cls),
+                                         L.ptr(table), table.shape[0], table.shape[1], int(neg_col), L.ptr(sample_of_scan),
+                                         L.ptr(lo), lo.shape[0], L.ptr(keep), L.ptr(sample), L.stream()), "ts_stage_keep_flags")
+    return keep, sample
+
+
+def stage_layout(cur, cur_lab, cur_b, hist, hist_lab, hist_b, idx, cur_start, kept_start):
+    """csrc/stage.hip: the fused clouds of a batch sample-major, current scan first -> (pts [Nc + Nk, F], labels int64, sample
+    int64, sample int32, is_current bool)."""
+    L.require_device(cur, cur_lab, cur_b, hist, hist_lab, hist_b, idx, cur_start, kept_start)
+    cur, hist = _f32(cur, "cur"), _f32(hist, "hist")
+    n_cur, n_kept, f = cur.shape[0], idx.shape[0], cur.shape[1]
+    assert hist.shape[1] == f and cur_lab.dtype == hist_lab.dtype == torch.int64
+    dev = cur.device
+    pts = torch.empty((n_cur + n_kept, f), dtype=torch.float32, device=dev)
+    lab = torch.empty(n_cur + n_kept, dtype=torch.int64, device=dev)
+    sample = torch.empty(n_cur + n_kept, dtype=torch.int64, device=dev)
+    sample32 = torch.empty(n_cur + n_kept, dtype=torch.int32, device=dev)
+    is_cur = torch.empty(n_cur + n_kept, dtype=torch.bool, device=dev)
+    L.check(L.load().ts_stage_layout(L.ptr(cur), L.ptr(cur_lab.contiguous()), L.ptr(cur_b.contiguous()), n_cur, L.ptr(hist),
+                                     L.ptr(hist_lab.contiguous()), L.ptr(hist_b.contiguous()), L.ptr(idx.contiguous()), n_kept, f,
+                                     L.ptr(cur_start.contiguous()), L.ptr(kept_start.contiguous()), L.ptr(pts), L.ptr(lab),
+                                     L.ptr(sample), L.ptr(sample32), L.ptr(is_cur), L.stream()), "ts_stage_layout")
+    return pts, lab, sample, sample32, is_cur
+
+
+def stage_split_voxels(coords4, index, inverse, row_sample, n_samples):
+    """csrc/stage.hip: after sparse_quantize on a whole batch -> (vox [m, 4] int32 = coords4[index], offset [B] int32 cumulative
+    voxel counts, inverse_local [n] int64 = voxel index inside the point's own sample)."""
+    L.require_device(coords4, index, inverse, row_sample)
+    coords4, index, inverse = _i32(coords4, "coords4"), _i32(index, "index"), _i32(inverse, "inverse")
+    row_sample = row_sample.long().contiguous()
+    m, n = index.shape[0], inverse.shape[0]
+    dev = coords4.device
+    vox = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    start = torch.empty(n_samples + 1, dtype=torch.int64, device=dev)
+    offset = torch.empty(n_samples, dtype=torch.int32, device=dev)
+    local = torch.empty(n, dtype=torch.int64, device=dev)
+    L.check(L.load().ts_stage_split_voxels(L.ptr(coords4), L.ptr(index), m, L.ptr(inverse), L.ptr(row_sample), n, int(n_samples),
+                                           L.ptr(vox), L.ptr(start), L.ptr(offset), L.ptr(local), L.stream()),
+            "ts_stage_split_voxels")
+    return vox, offset, local
+
+
 def sparse_quantize(coords):
     """np.unique-style voxel grouping of int coords [n,4]: (index [m], inverse [n]) int32, m via one sync."""
     L.require_device(coords)

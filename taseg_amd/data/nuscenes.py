@@ -177,7 +177,7 @@ def build_nuscenes_batch(samples: List[Dict], voxel_size: float, steps: Sequence
     sensor -> keyframe -> current-frame transforms, time delta), the class-step rule as one table lookup, then
     stage.voxelize_batch_ms (one compaction, one batch-keyed voxelisation per cloud kind)."""
     from . import stage as _stage
-    if not _stage._BATCHED or not samples:
+    if not _stage._BATCHED or not samples or len(samples) > 64:
         return build_nuscenes_batch_per_sample(samples, voxel_size, steps, in_feature_dim)
     dev = samples[0]["points"].device
     f = in_feature_dim
@@ -206,7 +206,7 @@ def build_nuscenes_batch(samples: List[Dict], voxel_size: float, steps: Sequence
         stack = torch.cat(hp, 0).contiguous()
         pseudo = torch.cat(hs, 0).long()
         lab_h = torch.cat(hl, 0).long()
-        sweep_g = _stage.rows_index(lengths, dev)
+        sweep32 = _stage.rows_index32(lengths, dev)
         key = ("nusc-table", tuple(map(tuple, rows)), tuple(sample_of_sweep), str(dev))
         hit = _tables.get(key)
         if hit is None:
@@ -215,16 +215,17 @@ def build_nuscenes_batch(samples: List[Dict], voxel_size: float, steps: Sequence
             hit = (torch.tensor(rows, dtype=torch.bool).to(dev), torch.tensor(sample_of_sweep, dtype=torch.int64).to(dev))
             _tables[key] = hit
         table, sample_of = hit
-        fused, no_ego = B.fuse_sweeps(stack, sweep_g.int(), torch.cat(params, 0) if len(params) > 1 else params[0])
-        keep = no_ego & table.view(-1)[sweep_g * n_cls + pseudo]
-        hist_ms, hist_b = fused[:, :f].contiguous(), sample_of[sweep_g]
+        fused, no_ego = B.fuse_sweeps(stack, sweep32, torch.cat(params, 0) if len(params) > 1 else params[0])
+        hist_ms = fused[:, :f].contiguous()
     else:
         hist_ms = torch.empty((0, f), dtype=cur_f.dtype, device=dev)
-        lab_h = torch.empty(0, dtype=torch.int64, device=dev)
-        keep = torch.empty(0, dtype=torch.bool, device=dev)
-        hist_b = torch.empty(0, dtype=torch.int64, device=dev)
-    return _stage.voxelize_batch_ms(cur_list, lab_list, cur_f, hist_ms, lab_h, keep, hist_b, voxel_size,
-                                    [s.get("name", "") for s in samples])
+        lab_h = pseudo = torch.empty(0, dtype=torch.int64, device=dev)
+        sweep32 = torch.empty(0, dtype=torch.int32, device=dev)
+        no_ego = None
+        table = torch.zeros((1, n_cls), dtype=torch.bool, device=dev)
+        sample_of = torch.zeros(1, dtype=torch.int64, device=dev)
+    return _stage.voxelize_batch_ms(cur_list, lab_list, cur_f, hist_ms, lab_h, sweep32, pseudo, table, sample_of, voxel_size,
+                                    [s.get("name", "") for s in samples], pre_keep=no_ego)
 
 
 def build_nuscenes_batch_per_sample(samples: List[Dict], voxel_size: float, steps: Sequence[int], in_feature_dim: int = 4) -> Dict:

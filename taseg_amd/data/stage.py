@@ -198,70 +198,54 @@ def rows_index(lengths: Sequence[int], device) -> torch.Tensor:
 
 
 def voxelize_batch_ms(cur_list: List[torch.Tensor], lab_list: List[torch.Tensor], cur_ms: torch.Tensor, hist_pts: torch.Tensor,
-                      hist_lab: torch.Tensor, hist_keep: torch.Tensor, hist_b: torch.Tensor, voxel_size: float,
-                      names: List[str]) -> Dict:
+                      hist_lab: torch.Tensor, hist_scan: torch.Tensor, hist_cls: torch.Tensor, table: torch.Tensor,
+                      sample_of_scan: torch.Tensor, voxel_size: float, names: List[str], pre_keep=None, neg_col: int = -1) -> Dict:
     """collate_batch([voxelize_sample_ms(...) for every sample]) for the WHOLE batch in one chain of launches
-    (semantickitti_voxel_ms.py:121-212 / nuscenes_voxel_ms.py:77-212): clamp of the fused clouds to their current scan's minimum
-    + class-step filter -> ONE compaction; the fused clouds laid out sample-major, current scan first (one stable sort on the
-    sample index); ONE voxelisation of all fused clouds (per-sample minima, batch-keyed radix sort: voxel order (b, x, y, z),
-    representative = first point, inverse map) and ONE of the current scans shifted by their fused cloud's minimum; gathers on
-    the whole batch.  Four host reads per batch (kept points, points per fused cloud, the two voxel counts) instead of three per
+    (semantickitti_voxel_ms.py:121-212 / nuscenes_voxel_ms.py:77-212): the per-sample clamp minima in one launch, the class-step
+    rule + pre-filter + clamp in one launch (csrc/stage.hip), ONE compaction, the fused clouds written sample-major with the current
+    scan first (no sort), ONE voxelisation of all fused clouds (per-sample minima, batch-keyed radix sort: voxel order (b, x, y, z),
+    representative = first point, inverse map) and ONE of the current scans shifted by their fused cloud's minimum, gathers on the
+    whole batch.  Four host reads per batch (kept points, kept points per sample, the two voxel counts) instead of three per
     sample.  Same tensors, bit for bit, as the per-sample path.
 
-    cur_list[b] [n_b, F] / lab_list[b]: the current scans (single-frame cloud);  cur_ms [sum n_b, Fm]: the same points as they
-    appear in the fused clouds (time flag / time column);  hist_*: the transformed history points of all samples, sample-major
-    (hist_b ascending): points [Nh, Fm], labels [Nh] int64, keep flags [Nh] bool (class-step rule, ego box), sample index [Nh]."""
+    cur_list[b] [n_b, F] / lab_list[b] int64: the current scans (single-frame cloud);  cur_ms [sum n_b, Fm]: the same points as
+    they appear in the fused clouds (time flag / time column);  hist_*: the transformed history points of all samples, sample-major:
+    points [Nh, Fm], labels [Nh] int64, global scan / sweep index [Nh] int32, pseudo class [Nh] int64 (neg_col: the table column of
+    a negative class), table [S, C] bool (is class c taken from scan s), sample_of_scan [S] int64; pre_keep [Nh] bool (optional:
+    the ego-box filter)."""
     dev = cur_ms.device
     nb = len(cur_list)
+    if nb > 64:
+        raise ValueError("voxelize_batch_ms: at most 64 samples per batch")
     n_cur = [int(c.shape[0]) for c in cur_list]
     cur = torch.cat(cur_list, 0).contiguous()
     cur_lab = torch.cat(lab_list, 0)
     cur_b = rows_index(n_cur, dev)
-    # minimum of every current scan (the reference clamps the fused cloud to it, :121-124): float min is exact in any order
-    lo = B.segment_min3(cur, cur_b, nb) if nb <= 64 else torch.stack([c[:, :3].t().contiguous().min(1).values for c in cur_list])
-    edges = torch.arange(nb + 1, device=dev)
     n_c = cur.shape[0]
     if hist_pts.shape[0]:
-        sel = hist_keep & (hist_pts[:, :3] >= lo[hist_b]).all(1)
-        idx = sel.nonzero().squeeze(1)                                  # host read 1 (the compaction's size)
-        kept_pts, kept_lab, kept_b = hist_pts[idx], hist_lab[idx], hist_b[idx]
-        n_k = int(idx.shape[0])
-        # the fused clouds sample-major, current scan first, history behind it in its own order - written straight to their rows
-        # (no sort): current point i of sample b lands kept_start[b] rows further down, kept history point j cur_start[b + 1]
-        cur_start = torch.tensor([0] + list(torch.tensor(n_cur).cumsum(0).tolist()), dtype=torch.int64).to(dev, non_blocking=True)
-        kept_start = torch.searchsorted(kept_b, edges)
-        dest_cur = torch.arange(n_c, device=dev) + kept_start[cur_b]
-        dest_hist = torch.arange(n_k, device=dev) + cur_start[kept_b + 1]
-        ms_pts = torch.empty((n_c + n_k, cur_ms.shape[1]), dtype=cur_ms.dtype, device=dev)
-        ms_pts[dest_cur] = cur_ms
-        ms_pts[dest_hist] = kept_pts
-        ms_lab = torch.empty(n_c + n_k, dtype=cur_lab.dtype, device=dev)
-        ms_lab[dest_cur] = cur_lab
-        ms_lab[dest_hist] = kept_lab
-        ms_b = torch.empty(n_c + n_k, dtype=torch.int64, device=dev)
-        ms_b[dest_cur] = cur_b
-        ms_b[dest_hist] = kept_b
-        point_mask = torch.zeros(n_c + n_k, dtype=torch.bool, device=dev)
-        point_mask[dest_cur] = True
+        lo = B.segment_min3(cur, cur_b, nb)        # minimum of every current scan: the fused cloud is clamped to it (:121-124)
+        keep, hist_b = B.stage_keep_flags(hist_pts, hist_scan, hist_cls, table, sample_of_scan, lo, pre_keep=pre_keep, neg_col=neg_col)
+        idx = keep.nonzero().squeeze(1)                                 # host read 1 (the compaction's size)
+        cuts = [0]
+        for n in n_cur:
+            cuts.append(cuts[-1] + n)
+        cur_start = torch.tensor(cuts, dtype=torch.int64).to(dev, non_blocking=True)
+        kept_start = torch.searchsorted(hist_b[idx], torch.arange(nb + 1, device=dev))
+        ms_pts, ms_lab, ms_b, ms_b32, point_mask = B.stage_layout(cur_ms, cur_lab, cur_b, hist_pts, hist_lab, hist_b, idx, cur_start,
+                                                                  kept_start)
         kept = (kept_start[1:] - kept_start[:-1]).tolist()              # host read 2 (kept history points per sample)
         n_ms = [a + k for a, k in zip(n_cur, kept)]
     else:
-        ms_b, ms_pts, ms_lab = cur_b, cur_ms.contiguous(), cur_lab
+        ms_b, ms_b32, ms_pts, ms_lab = cur_b, cur_b.int(), cur_ms.contiguous(), cur_lab
         point_mask = torch.ones(n_c, dtype=torch.bool, device=dev)
         n_ms = list(n_cur)
-    coords_ms, mins = B.voxel_coords(ms_pts, voxel_size, batch_idx=ms_b.int(), n_batch=nb)
+    coords_ms, mins = B.voxel_coords(ms_pts, voxel_size, batch_idx=ms_b32, n_batch=nb)
     index_ms, inverse_ms = B.sparse_quantize(coords_ms)                 # host read 3 (voxels of the fused clouds)
-    coords_c, _ = B.voxel_coords(cur, voxel_size, batch_idx=cur_b.int(), n_batch=nb, shift=mins)    # pc_ -= pc_ms_.min(0)  (:130)
+    coords_c, _ = B.voxel_coords(cur, voxel_size, batch_idx=rows_index32(n_cur, dev), n_batch=nb, shift=mins)   # pc_ -= pc_ms_.min(0) (:130)
     index_c, inverse_c = B.sparse_quantize(coords_c)                    # host read 4 (voxels of the current scans)
+    vox_ms, offset_ms, inv_ms = B.stage_split_voxels(coords_ms, index_ms, inverse_ms, ms_b, nb)
+    vox_c, offset_c, inv_c = B.stage_split_voxels(coords_c, index_c, inverse_c, cur_b, nb)
     index_ms, index_c = index_ms.long(), index_c.long()
-
-    def per_sample(coords4, index, inverse, row_b):
-        vox = coords4[index].contiguous()                               # [m, 4] = x, y, z, sample: sorted by (sample, x, y, z)
-        vox_start = torch.searchsorted(vox[:, 3].contiguous().long(), edges)
-        return vox, vox_start[1:].int(), inverse.long() - vox_start[row_b]     # local voxel index of every point
-
-    vox_ms, offset_ms, inv_ms = per_sample(coords_ms, index_ms, inverse_ms, ms_b)
-    vox_c, offset_c, inv_c = per_sample(coords_c, index_c, inverse_c, cur_b)
     return {
         "name": list(names),
         "lidar": SparseTensor(cur[index_c], vox_c), "targets": SparseTensor(cur_lab[index_c], vox_c),
@@ -274,13 +258,23 @@ def voxelize_batch_ms(cur_list: List[torch.Tensor], lab_list: List[torch.Tensor]
     }
 
 
+def rows_index32(lengths: Sequence[int], device) -> torch.Tensor:
+    """rows_index as int32 (what ts_voxel_coords takes), cached beside it"""
+    key = ("i32", tuple(lengths), str(device))
+    hit = _rows_cache.get(key)
+    if hit is None:
+        hit = rows_index(lengths, device).int()
+        _rows_cache[key] = hit
+    return hit
+
+
 def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[int]) -> Dict:
     """scans[b] = dict(points=[T+1 tensors, current LAST], labels=[...], poses=[...], name=str
     [, deltas=[frame offsets of the history scans], pseudo=[pseudo classes of the history scans, see _fuse_history]]).
     Returns the collated batch_dict MinkUNetMs consumes.  The whole batch goes through ONE chain of launches: one pose-fuse
     launch over every history point of every sample (ts_fuse_scans_batch), the class-step rule as one table lookup, then
     voxelize_batch_ms."""
-    if not _BATCHED or not scans:
+    if not _BATCHED or not scans or len(scans) > 64:
         return build_multiscan_batch_per_sample(scans, voxel_size, steps)
     dev = scans[0]["points"][-1].device
     n_cls = len(steps)
@@ -309,7 +303,6 @@ def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[
         hp = torch.cat(hist_pts, 0).contiguous()
         hl = torch.cat(hist_lab, 0).long()
         hps = hl if all(s.get("pseudo") is None for s in scans) else torch.cat(hist_ps, 0).long()
-        scan_g = rows_index(lengths, dev)
         key = ("kitti-table", tuple(map(tuple, rows)), tuple(scan_sample), str(dev))
         hit = _static_cache.get(key)
         if hit is None:
@@ -318,18 +311,17 @@ def build_multiscan_batch(scans: List[Dict], voxel_size: float, steps: Sequence[
             hit = (torch.tensor(rows, dtype=torch.bool).to(dev), torch.tensor(scan_sample, dtype=torch.int64).to(dev))
             _static_cache[key] = hit
         table, sample_of_scan = hit
-        fused = B.fuse_scans_batch(hp, scan_g.int(), torch.stack(pose0s, 0), torch.stack(poses, 0))
-        hps = torch.where(hps < 0, torch.full_like(hps, n_cls), hps)
-        keep = table.view(-1)[scan_g * (n_cls + 1) + hps]
+        scan32 = rows_index32(lengths, dev)
+        fused = B.fuse_scans_batch(hp, scan32, torch.stack(pose0s, 0), torch.stack(poses, 0))
         hist_ms = torch.cat([fused, torch.zeros((fused.shape[0], 1), dtype=fused.dtype, device=dev)], 1)
-        hist_b = sample_of_scan[scan_g]
     else:
         hist_ms = torch.empty((0, 5), dtype=cur4.dtype, device=dev)
-        hl = torch.empty(0, dtype=torch.int64, device=dev)
-        keep = torch.empty(0, dtype=torch.bool, device=dev)
-        hist_b = torch.empty(0, dtype=torch.int64, device=dev)
-    return voxelize_batch_ms([s["points"][-1] for s in scans], lab_list, cur_ms, hist_ms, hl, keep, hist_b, voxel_size,
-                             [s.get("name", "") for s in scans])
+        hl = hps = torch.empty(0, dtype=torch.int64, device=dev)
+        scan32 = torch.empty(0, dtype=torch.int32, device=dev)
+        table = torch.zeros((1, n_cls + 1), dtype=torch.bool, device=dev)
+        sample_of_scan = torch.zeros(1, dtype=torch.int64, device=dev)
+    return voxelize_batch_ms([s["points"][-1] for s in scans], lab_list, cur_ms, hist_ms, hl, scan32, hps, table, sample_of_scan,
+                             voxel_size, [s.get("name", "") for s in scans], neg_col=n_cls)
 
 
 class DevicePrefetcher:
