@@ -42,6 +42,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CG_GK 9              // offsets per group
 
 // ---------------------------------------------------------------------------------------------------------- plan
+// compute units of the current device (persistent launches size their grid from it); 256 when the query fails
+static int ts_cu_count() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 256;
+  return cus;
+}
 static inline int64_t cg_npad(int64_t n) { return (n + CG_BM - 1) / CG_BM * CG_BM; }
 
 extern "C" int64_t ts_conv_class_rows(int64_t n) { return n < 0 ? 0 : CG_GROUPS * cg_npad(n); }
@@ -766,6 +773,270 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__
   }
 }
 
+// Whole-row, persistent form of the half kernel.  A step = (tile, offset of the tile's mask, RC-column chunk of the rows).
+// The slice form above keeps ONE 32-column slice (8 KB of gathered rows per workgroup) in flight and a workgroup lives for the
+// 3.7 offsets of its tile: every workgroup pays the chain tile entry -> row indices -> rows -> LDS before its first MFMA, and
+// every slice a fabric round trip (3.2 TB/s on the stride-1 96 -> 96 layer).  Here
+//   * the WHOLE [128 x RC] block of gathered rows and the [RC x BN] weight block of step s + 1 are in flight (registers) while
+//     step s multiplies from LDS (16-byte pieces of a row on consecutive lanes: full lines per request), the row indices of the
+//     offset after that are fetched a step earlier still, the entry of the next tile a tile ahead;
+//   * a workgroup walks the tile list (tile = round * G + its slot, the slot order reversed every other round: the list is sorted
+//     longest first), so the stream of steps does not stop at a tile's end - the finished tile's sums leave through LDS while the
+//     next tile's first block is already in flight.
+// One accumulator set across the offsets of a tile (the sums are rounded to half once, at the end; the fp32 kernel's second set
+// buys nothing at half precision).  Same Z' / direct-row stores, same side job.
+struct CgCursor {          // walks (tile, offset) in list order for one workgroup; everything wave-uniform
+  int tile, round, slot, G, n_tiles;
+  int rest;                // offsets of the current tile not handed out yet
+  int row0, grp;
+  int2 ahead;              // entry of the tile after the current one (loaded a tile ahead)
+};
+struct CgStep {
+  int row0, grp, kl, last;  // last: the tile's last offset
+};
+
+template <int BN, int WR, bool WT, int RC>
+__global__ __launch_bounds__(256, 2) void class_gemm_h2_kernel(
+    const _Float16 *__restrict__ X, int R, const _Float16 *__restrict__ W, int O_total, const int *__restrict__ src, int64_t m_pad,
+    const int2 *__restrict__ tile_info, const int *__restrict__ n_tiles_p, int K, int gk, int mirror, const int *__restrict__ rows,
+    _Float16 *__restrict__ Zp, TsWgradReduce side, int G) {
+  constexpr int BM = CG_BM;
+  constexpr int WC = 4 / WR;
+  constexpr int MI = (BM / 16) / WR;
+  constexpr int NI = (BN / 16) / WC;
+  constexpr int AP = RC + 8;                       // pitch of the row block (and of the WT weight block) in halves
+  constexpr int BP = BN + 8;
+  constexpr int A_HALVES = BM * AP;
+  constexpr int RQ = RC / 8;                       // 16-byte pieces per row chunk
+  constexpr int A_IT = BM * RQ / 256;
+  constexpr int B_CHUNKS = RC * BN / 8;
+  constexpr int B_IT = (B_CHUNKS + 255) / 256;
+  constexpr int KB = RC / 32;
+  constexpr int ZP = BN + 8;
+  constexpr int CH = BN / 8;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_cgh[];
+  _Float16 *At = smem_cgh;
+  _Float16 *Bt = At + A_HALVES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = lane & 3;
+  const int wr = wave / WC, wc = wave % WC;
+  const int o0 = blockIdx.y * BN;
+  if ((int)blockIdx.x >= G) {                   // side job: ordered sum of the weight-gradient partials
+    if (blockIdx.y == 0) {
+      const int64_t step = (int64_t)(gridDim.x - G) * 256;
+      for (int64_t i = (int64_t)((int)blockIdx.x - G) * 256 + tid; i < (int64_t)side.K * side.cacb4; i += step)
+        ts_wgrad_reduce_one(side, i);
+    }
+    return;
+  }
+
+  CgCursor cur;
+  cur.G = G;
+  cur.slot = (int)blockIdx.x;
+  cur.round = 0;
+  cur.n_tiles = __builtin_amdgcn_readfirstlane(*n_tiles_p);
+  cur.tile = cur.slot;
+  cur.rest = 0;
+  cur.row0 = cur.grp = 0;
+  cur.ahead = make_int2(0, 0);
+  auto tile_of = [&](int round) { return round * G + ((round & 1) ? G - 1 - cur.slot : cur.slot); };
+  auto load_entry = [&](int t) -> int2 {
+    int2 e = make_int2(0, 0);
+    if (t < cur.n_tiles) e = tile_info[t];
+    return make_int2(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y));
+  };
+  auto zero_tile = [&](int row0) {               // direct plans: a tile of rows without any neighbour - their result is zero
+    const ch8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < BM * CH; e += 256) {
+      const int r = e / CH, c8 = e - r * CH;
+      const int dst = rows ? rows[row0 + r] : (int)(row0 + r);
+      if (dst >= 0) *(ch8 *)(Zp + (int64_t)dst * O_total + o0 + 8 * c8) = zero;
+    }
+  };
+  bool opened = false;
+  auto next_step = [&](CgStep &st) -> bool {     // false: this workgroup's list is finished
+    while (cur.rest == 0) {
+      int2 e;
+      if (!opened) {
+        e = load_entry(cur.tile);
+        opened = true;
+      } else {
+        cur.round += 1;
+        cur.tile = tile_of(cur.round);
+        e = cur.ahead;
+      }
+      if (cur.tile >= cur.n_tiles) return false;
+      cur.ahead = load_entry(tile_of(cur.round + 1));
+      cur.grp = e.x & 3;
+      cur.row0 = (e.x >> 2) * BM;
+      cur.rest = e.y;
+      if (cur.rest == 0) zero_tile(cur.row0);
+    }
+    st.kl = __builtin_ctz(cur.rest);
+    cur.rest &= cur.rest - 1;
+    st.row0 = cur.row0;
+    st.grp = cur.grp;
+    st.last = cur.rest == 0;
+    return true;
+  };
+
+  // piece e = it * 256 + tid of the row block: row e / RQ, 16-byte piece e % RQ (consecutive lanes = consecutive pieces of a row)
+  int arow[A_IT], acol[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int e = it * 256 + tid;
+    arow[it] = e / RQ;
+    acol[it] = (e - arow[it] * RQ) << 3;
+  }
+  int boff[B_IT], bdst[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int e = min(tid + it * 256, B_CHUNKS - 1);
+    if (WT) {
+      const int col = e / RQ, c8 = (e - col * RQ) << 3;
+      boff[it] = col * R + c8;
+      bdst[it] = col * AP + c8;
+    } else {
+      constexpr int q8 = BN >> 3;
+      const int kk = e / q8, c8 = (e - kk * q8) << 3;
+      boff[it] = kk * O_total + c8;
+      bdst[it] = kk * BP + c8;
+    }
+  }
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int sa[A_IT], sb[A_IT];                // input rows of the offset being loaded / of the offset after it
+  auto fetch = [&](const CgStep &st, int (&dst)[A_IT]) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) dst[it] = src[(int64_t)st.kl * m_pad + st.row0 + arow[it]];
+  };
+  ch8 ra[A_IT], rb[B_IT];
+  auto load_regs = [&](const CgStep &st, int c0) {
+    const ch8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      ra[it] = zero;
+      if (sa[it] >= 0) ra[it] = *(const ch8 *)(X + (int64_t)sa[it] * R + c0 + acol[it]);
+    }
+    const int k = gk * st.grp + st.kl;
+    const int kw = (WT && mirror) ? (K - 1 - k) : k;
+    const _Float16 *wb = WT ? W + ((int64_t)kw * O_total + o0) * R + c0 : W + ((int64_t)kw * R + c0) * O_total + o0;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const ch8 *)(wb + boff[it]);
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) *(ch8 *)&At[arow[it] * AP + acol[it]] = ra[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      if (B_IT * 256 == B_CHUNKS || tid + it * 256 < B_CHUNKS) *(ch8 *)&Bt[bdst[it]] = rb[it];
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      ch8 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const ch8 *)&At[((wr * MI + mi) * 16 + r16) * AP + 32 * kb + 8 * g];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = WT ? *(const ch8 *)&Bt[((wc * NI + ni) * 16 + r16) * AP + 32 * kb + 8 * g]
+                   : cgh_frag_tr(Bt, BP, 32 * kb + 8 * g, (wc * NI + ni) * 16, tq, tp);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  // the finished tile: sums -> half -> LDS image [row][col] -> 16-byte chunks of whole rows (Z' rows, or the destination rows of a
+  // direct plan); called between two barriers' worth of LDS use (every wave has read the last block)
+  auto flush_tile = [&](int row0) {
+    _Float16 *Zt = smem_cgh;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Zt[((wr * MI + mi) * 16 + 4 * g + q) * ZP + (wc * NI + ni) * 16 + r16] = (_Float16)acc[mi][ni][q];
+          acc[mi][ni][q] = 0.f;
+        }
+    __syncthreads();
+    for (int e = tid; e < BM * CH; e += 256) {
+      const int row = e / CH, ch = e - row * CH;
+      const int64_t dst = rows ? (int64_t)rows[row0 + row] : (int64_t)row0 + row;
+      if (dst >= 0) *(ch8 *)(Zp + dst * O_total + o0 + ch * 8) = *(const ch8 *)&Zt[row * ZP + ch * 8];
+    }
+  };
+
+  CgStep sl, sf, sm;                      // the step being loaded, the one whose row indices are fetched, the one multiplying
+  if (!next_step(sl)) return;
+  fetch(sl, sa);
+  bool has_f = next_step(sf);
+  if (has_f) fetch(sf, sb);
+  load_regs(sl, 0);
+  int c0 = 0;
+  while (true) {
+    store_lds();                           // the block of this step (waits for its loads)
+    __syncthreads();
+    sm = sl;
+    const bool tile_done = sm.last && c0 + RC >= R;
+    bool more = true;
+    if (c0 + RC < R) {
+      c0 += RC;
+    } else if (has_f) {
+      c0 = 0;
+      sl = sf;
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) sa[it] = sb[it];
+      has_f = next_step(sf);
+      if (has_f) fetch(sf, sb);
+    } else {
+      more = false;
+    }
+    if (more) load_regs(sl, c0);           // the next step's block, in flight behind this step's MFMAs (and the tile's flush)
+    mma();
+    __syncthreads();                       // every wave has read this step's block
+    if (tile_done) {
+      flush_tile(sm.row0);
+      __syncthreads();
+    }
+    if (!more) break;
+  }
+}
+
+template <int BN, int WR, bool WT, int RC>
+static int launch_class_h2(const _Float16 *X, int R, const _Float16 *W, int O_total, const CgArgs &a, _Float16 *Zp,
+                           hipStream_t stream) {
+  const size_t stage = (size_t)(CG_BM * (RC + 8) + (WT ? BN * (RC + 8) : RC * (BN + 8))) * 2;
+  const size_t ztile = (size_t)CG_BM * (BN + 8) * 2;
+  const size_t lds = std::max(stage, ztile);
+  const int64_t tiles = a.m_pad / CG_BM;
+  static const int cus = ts_cu_count();
+  // one resident workgroup per slot the kernel can hold on the chip (registers and LDS of THIS instantiation), each walking the list
+  static const int per_cu = [&] {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, class_gemm_h2_kernel<BN, WR, WT, RC>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+  }();
+  const int ny = O_total / BN;
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cus * per_cu / ny));
+  dim3 grid((unsigned)G + (a.side.K > 0 ? 64u : 0u), (unsigned)ny);
+  class_gemm_h2_kernel<BN, WR, WT, RC><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K,
+                                                                    a.gk, a.mirror, a.rows, Zp, a.side, G);
+  TS_CHECK_LAUNCH("ts_conv_class_gemm_f16 (whole rows)");
+  return TS_OK;
+}
+// row chunk of the deep-prefetch form: the largest of 128 / 96 / 64 / 32 that divides the reduction width
+static int cgh_row_chunk(int c_red) { return c_red % 128 == 0 ? 128 : c_red % 96 == 0 ? 96 : c_red % 64 == 0 ? 64 : c_red % 32 == 0 ? 32 : 0; }
+
 template <int BN, int WR, bool WT>
 static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_total, const CgArgs &a, _Float16 *Zp,
                           hipStream_t stream) {
@@ -784,11 +1055,29 @@ int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, in
                               const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                               int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const int rc = cg_check("ts_conv_class_gemm_f16", K, groups, c_red, c_out, m_pad, feat, w, zp, src, tile_info, n_tiles);
-  if (rc != TS_OK) return rc;
+  const int chk = cg_check("ts_conv_class_gemm_f16", K, groups, c_red, c_out, m_pad, feat, w, zp, src, tile_info, n_tiles);
+  if (chk != TS_OK) return chk;
   CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}};
   if (side) a.side = *side;
   const _Float16 *x = (const _Float16 *)feat, *wh = (const _Float16 *)w;
+  // TASEG_CLASS_H_SLICES=1 in the environment keeps the 32-column slice form (A/B runs)
+  static const bool slices = getenv("TASEG_CLASS_H_SLICES") != nullptr;
+  const int rc = slices ? 0 : cgh_row_chunk(c_red);
+#define CGH2_RC(BN, WR, RC)                                                                      \
+  (wt ? launch_class_h2<BN, WR, true, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)         \
+      : launch_class_h2<BN, WR, false, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))
+#define CGH2_GO(BN, WR)                                                                          \
+  (rc == 128 ? CGH2_RC(BN, WR, 128) : rc == 96 ? CGH2_RC(BN, WR, 96) : rc == 64 ? CGH2_RC(BN, WR, 64) : CGH2_RC(BN, WR, 32))
+  if (rc) {
+    switch (cg_tile_columns(c_out)) {
+      case 128: return CGH2_GO(128, 2);
+      case 96: return CGH2_GO(96, 2);
+      case 64: return CGH2_GO(64, 2);
+      default: return CGH2_GO(32, 4);
+    }
+  }
+#undef CGH2_GO
+#undef CGH2_RC
 #define CGH_GO(BN, WR)                                                                         \
   (wt ? launch_class_h<BN, WR, true>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)           \
       : launch_class_h<BN, WR, false>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))

@@ -16,12 +16,24 @@ ap.add_argument("--cout", type=int, default=96)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--half", action="store_true", help="IEEE-half rows (the autocast path)")
 ap.add_argument("--ms", action="store_true", help="lexicographic stride-1 order (the multi-scan models' voxel order) instead of hash order")
+ap.add_argument("--morton", type=int, default=0, help="stride-1 rows in Morton order of (x, y, z) >> MORTON-1 blocks (lexicographic inside a block)")
 args = ap.parse_args()
 coords, feats, labels, _ = bench.make_scans(0, 2, 120000, "minkunet")
 if args.ms:
     import numpy as np
     c = coords.cpu().numpy()
     coords = torch.from_numpy(c[np.lexsort((c[:, 2], c[:, 1], c[:, 0], c[:, 3]))]).cuda()
+if args.morton:
+    import numpy as np
+    c = coords.cpu().numpy().astype(np.int64)
+    sh = args.morton - 1
+    q = (c[:, :3] - c[:, :3].min(0)) >> sh
+    code = np.zeros(len(c), dtype=np.int64)
+    for b in range(16):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + (2 - a))
+    order = np.lexsort((c[:, 2], c[:, 1], c[:, 0], code, c[:, 3]))
+    coords = torch.from_numpy(c[order].astype(np.int32)).cuda()
 x = SparseTensor(None, coords, 1)
 spF.build_pyramid(x, 4)
 s = args.stride
