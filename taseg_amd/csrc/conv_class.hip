@@ -584,9 +584,8 @@ extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float 
 }
 
 // ------------------------------------------------------------------------------------------- half storage
-// The same walk for IEEE-half rows (torch.autocast; conv_pairs_h.hip): one v_mfma_f32_16x16x32_f16 per product, fp32 sums, the
-// gathered operand and the weight slice double-buffered in LDS (one barrier per slice), Z' rows rounded to half ONCE per
-// (row, group) - the two-pass form rounds every pair's Z row.
+// The same walk for IEEE-half rows (torch.autocast; conv_pairs_h.hip): one v_mfma_f32_16x16x32_f16 per product, fp32 sums,
+// Z' rows rounded to half ONCE per (row, group) - the two-pass form rounds every pair's Z row.
 typedef _Float16 ch8 __attribute__((ext_vector_type(8)));
 typedef __fp16 chv4t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ ch8 cgh_frag_tr(const _Float16 *img, int pitch, int r0, int c0, int tq, int tp) {
@@ -599,184 +598,11 @@ __device__ __forceinline__ ch8 cgh_frag_tr(const _Float16 *img, int pitch, int r
   return v;
 }
 
-template <int BN, int WR, bool WT>
-__global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(const _Float16 *__restrict__ X, int R,
-                                                             const _Float16 *__restrict__ W, int O_total,
-                                                             const int *__restrict__ src, int64_t m_pad,
-                                                             const int2 *__restrict__ tile_info,
-                                                             const int *__restrict__ n_tiles, int K, int gk, int mirror,
-                                                             const int *__restrict__ rows, _Float16 *__restrict__ Zp,
-                                                             TsWgradReduce side, int tile_blocks) {
-  constexpr int BM = CG_BM;
-  constexpr int WC = 4 / WR;
-  constexpr int MI = (BM / 16) / WR;
-  constexpr int NI = (BN / 16) / WC;
-  constexpr int A_HALVES = BM * CG_AP;
-  constexpr int BP = BN + 8;
-  constexpr int B_HALVES = WT ? BN * CG_AP : CG_BK * BP;
-  constexpr int A_IT = BM * (CG_BK / 8) / 256;
-  constexpr int B_IT = (BN * (CG_BK / 8) + 255) / 256;
-  constexpr int ZP = BN + 8;
-  extern __shared__ __attribute__((aligned(16))) _Float16 smem_cgh[];
-  _Float16 *Abuf = smem_cgh;
-  _Float16 *Bbuf = Abuf + 2 * A_HALVES;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, g = lane >> 4;
-  const int tq = r16 >> 2, tp = lane & 3;
-  const int wr = wave / WC, wc = wave % WC;
-  const int o0 = blockIdx.y * BN;
-  const int tile = (int)blockIdx.x;
-  if (tile >= tile_blocks) {                    // side job: ordered sum of the weight-gradient partials
-    if (blockIdx.y == 0) {
-      const int64_t step = (int64_t)(gridDim.x - tile_blocks) * 256;
-      for (int64_t i = (int64_t)(tile - tile_blocks) * 256 + tid; i < (int64_t)side.K * side.cacb4; i += step)
-        ts_wgrad_reduce_one(side, i);
-    }
-    return;
-  }
-  if (tile >= *n_tiles) return;
-  const int2 info = tile_info[tile];
-  const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
-  int mask = __builtin_amdgcn_readfirstlane(info.y);
-  const int64_t row0 = (int64_t)(__builtin_amdgcn_readfirstlane(info.x) >> 2) * BM;
-  if (mask == 0) {                              // direct plans: rows without any neighbour
-    const ch8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int e = tid; e < BM * (BN / 8); e += 256) {
-      const int r = e / (BN / 8), c8 = e - r * (BN / 8);
-      const int dst = rows ? rows[row0 + r] : (int)(row0 + r);
-      if (dst >= 0) *(ch8 *)(Zp + (int64_t)dst * O_total + o0 + 8 * c8) = zero;
-    }
-    return;
-  }
-
-  const int arow0 = tid >> 2, acol = (tid & 3) << 3;
-  int boff[B_IT], bdst[B_IT];
-#pragma unroll
-  for (int it = 0; it < B_IT; ++it) {
-    const int e = min(tid + it * 256, BN * 4 - 1);
-    if (WT) {
-      const int col = e >> 2, c8 = (e & 3) << 3;
-      boff[it] = col * R + c8;
-      bdst[it] = col * CG_AP + c8;
-    } else {
-      constexpr int q8 = BN >> 3;
-      const int kk = e / q8, c8 = (e - kk * q8) << 3;
-      boff[it] = kk * O_total + c8;
-      bdst[it] = kk * BP + c8;
-    }
-  }
-  f32x4 acc[MI][NI], tot[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = tot[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const _Float16 *aptr[A_IT];
-  bool alive[A_IT];
-  const _Float16 *wk = W;
-  int nsrc[A_IT];
-  auto fetch = [&](int kl) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) nsrc[it] = src[(int64_t)kl * m_pad + row0 + arow0 + 64 * it];
-  };
-  auto bind = [&](int kl) {
-    const int k = gk * grp + kl;
-    const int kw = (WT && mirror) ? (K - 1 - k) : k;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      alive[it] = nsrc[it] >= 0;
-      aptr[it] = X + (int64_t)max(nsrc[it], 0) * R + acol;
-    }
-    wk = WT ? W + ((int64_t)kw * O_total + o0) * R : W + (int64_t)kw * R * O_total + o0;
-  };
-  ch8 ra[A_IT], rb[B_IT];
-  auto load_regs = [&](int c0) {
-    const ch8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      ra[it] = zero;
-      if (alive[it]) ra[it] = *(const ch8 *)(aptr[it] + c0);
-    }
-    const _Float16 *wb = WT ? wk + c0 : wk + (int64_t)c0 * O_total;
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) rb[it] = *(const ch8 *)(wb + boff[it]);
-  };
-  auto store_lds = [&](_Float16 *At, _Float16 *Bt) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) *(ch8 *)&At[(arow0 + 64 * it) * CG_AP + acol] = ra[it];
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      if (B_IT * 256 == BN * 4 || tid + it * 256 < BN * 4) *(ch8 *)&Bt[bdst[it]] = rb[it];
-  };
-  auto mma = [&](const _Float16 *At, const _Float16 *Bt) {
-    ch8 a[MI], b[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a[mi] = *(const ch8 *)&At[((wr * MI + mi) * 16 + r16) * CG_AP + 8 * g];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-      b[ni] = WT ? *(const ch8 *)&Bt[((wc * NI + ni) * 16 + r16) * CG_AP + 8 * g]
-                 : cgh_frag_tr(Bt, BP, 8 * g, (wc * NI + ni) * 16, tq, tp);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-  };
-
-  fetch(__builtin_ctz(mask));
-  bind(__builtin_ctz(mask));
-  mask &= mask - 1;
-  load_regs(0);
-  int t = 0;
-  while (true) {
-    if (mask) fetch(__builtin_ctz(mask));
-    for (int c0 = 0; c0 < R; c0 += CG_BK, ++t) {
-      _Float16 *At = Abuf + (t & 1) * A_HALVES, *Bt = Bbuf + (t & 1) * B_HALVES;
-      store_lds(At, Bt);
-      __syncthreads();
-      if (c0 + CG_BK < R) {
-        load_regs(c0 + CG_BK);
-      } else if (mask) {
-        bind(__builtin_ctz(mask));
-        load_regs(0);
-      }
-      mma(At, Bt);
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        tot[mi][ni] += acc[mi][ni];
-        acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    if (!mask) break;
-    mask &= mask - 1;
-  }
-  // Z' tile: sums -> half -> LDS image [row][col] -> 16-byte chunks of whole rows
-  __syncthreads();
-  _Float16 *Zt = smem_cgh;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        Zt[((wr * MI + mi) * 16 + 4 * g + q) * ZP + (wc * NI + ni) * 16 + r16] = (_Float16)tot[mi][ni][q];
-  __syncthreads();
-  constexpr int CH = BN / 8;
-  for (int e = tid; e < BM * CH; e += 256) {
-    const int row = e / CH, ch = e - row * CH;
-    const int64_t dst = rows ? (int64_t)rows[row0 + row] : row0 + row;      // direct plan: the destination row of the slot
-    if (dst >= 0) *(ch8 *)(Zp + dst * O_total + o0 + ch * 8) = *(const ch8 *)&Zt[row * ZP + ch * 8];
-  }
-}
-
-// Whole-row, persistent form of the half kernel.  A step = (tile, offset of the tile's mask, RC-column chunk of the rows).
-// The slice form above keeps ONE 32-column slice (8 KB of gathered rows per workgroup) in flight and a workgroup lives for the
-// 3.7 offsets of its tile: every workgroup pays the chain tile entry -> row indices -> rows -> LDS before its first MFMA, and
-// every slice a fabric round trip (3.2 TB/s on the stride-1 96 -> 96 layer).  Here
+// Whole rows, persistent workgroups.  A step = (tile, offset of the tile's mask, RC-column chunk of the rows).  (The first form
+// of this kernel walked 32-column slices like the fp32 kernel above, one tile per workgroup: ONE slice - 8 KB of gathered rows per
+// workgroup - in flight, a workgroup living for the 3.7 offsets of its tile, every workgroup paying the chain tile entry -> row
+// indices -> rows -> LDS before its first MFMA and every slice a fabric round trip: 3.2 TB/s on the stride-1 96 -> 96 layer,
+// profiles/r04_class_h_whole_rows_probe.txt.  Without a split there is too little arithmetic per byte to hide that.)  Here
 //   * the WHOLE [128 x RC] block of gathered rows and the [RC x BN] weight block of step s + 1 are in flight (registers) while
 //     step s multiplies from LDS (16-byte pieces of a row on consecutive lanes: full lines per request), the row indices of the
 //     offset after that are fetched a step earlier still, the entry of the next tile a tile ahead;
@@ -796,7 +622,7 @@ struct CgStep {
 };
 
 template <int BN, int WR, bool WT, int RC>
-__global__ __launch_bounds__(256, 2) void class_gemm_h2_kernel(
+__global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
     const _Float16 *__restrict__ X, int R, const _Float16 *__restrict__ W, int O_total, const int *__restrict__ src, int64_t m_pad,
     const int2 *__restrict__ tile_info, const int *__restrict__ n_tiles_p, int K, int gk, int mirror, const int *__restrict__ rows,
     _Float16 *__restrict__ Zp, TsWgradReduce side, int G) {
@@ -1013,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h2_kernel(
 }
 
 template <int BN, int WR, bool WT, int RC>
-static int launch_class_h2(const _Float16 *X, int R, const _Float16 *W, int O_total, const CgArgs &a, _Float16 *Zp,
+static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_total, const CgArgs &a, _Float16 *Zp,
                            hipStream_t stream) {
   const size_t stage = (size_t)(CG_BM * (RC + 8) + (WT ? BN * (RC + 8) : RC * (BN + 8))) * 2;
   const size_t ztile = (size_t)CG_BM * (BN + 8) * 2;
@@ -1023,33 +849,19 @@ static int launch_class_h2(const _Float16 *X, int R, const _Float16 *W, int O_to
   // one resident workgroup per slot the kernel can hold on the chip (registers and LDS of THIS instantiation), each walking the list
   static const int per_cu = [&] {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, class_gemm_h2_kernel<BN, WR, WT, RC>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, class_gemm_h_kernel<BN, WR, WT, RC>, 256, lds) != hipSuccess || nb < 1) nb = 1;
     return nb;
   }();
   const int ny = O_total / BN;
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cus * per_cu / ny));
   dim3 grid((unsigned)G + (a.side.K > 0 ? 64u : 0u), (unsigned)ny);
-  class_gemm_h2_kernel<BN, WR, WT, RC><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K,
+  class_gemm_h_kernel<BN, WR, WT, RC><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K,
                                                                     a.gk, a.mirror, a.rows, Zp, a.side, G);
   TS_CHECK_LAUNCH("ts_conv_class_gemm_f16 (whole rows)");
   return TS_OK;
 }
 // row chunk of the deep-prefetch form: the largest of 128 / 96 / 64 / 32 that divides the reduction width
 static int cgh_row_chunk(int c_red) { return c_red % 128 == 0 ? 128 : c_red % 96 == 0 ? 96 : c_red % 64 == 0 ? 64 : c_red % 32 == 0 ? 32 : 0; }
-
-template <int BN, int WR, bool WT>
-static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_total, const CgArgs &a, _Float16 *Zp,
-                          hipStream_t stream) {
-  const size_t stage = (size_t)2 * (CG_BM * CG_AP + (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
-  const size_t ztile = (size_t)CG_BM * (BN + 8) * 2;
-  const unsigned tiles = (unsigned)(a.m_pad / CG_BM);
-  dim3 grid(tiles + (a.side.K > 0 ? 64u : 0u), (unsigned)(O_total / BN));
-  class_gemm_h_kernel<BN, WR, WT><<<grid, 256, std::max(stage, ztile), stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info,
-                                                                                 a.n_tiles, a.K, a.gk, a.mirror, a.rows, Zp,
-                                                                                 a.side, (int)tiles);
-  TS_CHECK_LAUNCH("ts_conv_class_gemm_f16");
-  return TS_OK;
-}
 
 int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
                               const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
@@ -1060,34 +872,20 @@ int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, in
   CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}};
   if (side) a.side = *side;
   const _Float16 *x = (const _Float16 *)feat, *wh = (const _Float16 *)w;
-  // TASEG_CLASS_H_SLICES=1 in the environment keeps the 32-column slice form (A/B runs)
-  static const bool slices = getenv("TASEG_CLASS_H_SLICES") != nullptr;
-  const int rc = slices ? 0 : cgh_row_chunk(c_red);
+  const int rc = cgh_row_chunk(c_red);
 #define CGH2_RC(BN, WR, RC)                                                                      \
-  (wt ? launch_class_h2<BN, WR, true, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)         \
-      : launch_class_h2<BN, WR, false, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))
+  (wt ? launch_class_h<BN, WR, true, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)         \
+      : launch_class_h<BN, WR, false, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))
 #define CGH2_GO(BN, WR)                                                                          \
   (rc == 128 ? CGH2_RC(BN, WR, 128) : rc == 96 ? CGH2_RC(BN, WR, 96) : rc == 64 ? CGH2_RC(BN, WR, 64) : CGH2_RC(BN, WR, 32))
-  if (rc) {
-    switch (cg_tile_columns(c_out)) {
-      case 128: return CGH2_GO(128, 2);
-      case 96: return CGH2_GO(96, 2);
-      case 64: return CGH2_GO(64, 2);
-      default: return CGH2_GO(32, 4);
-    }
+  switch (cg_tile_columns(c_out)) {
+    case 128: return CGH2_GO(128, 2);
+    case 96: return CGH2_GO(96, 2);
+    case 64: return CGH2_GO(64, 2);
+    default: return CGH2_GO(32, 4);
   }
 #undef CGH2_GO
 #undef CGH2_RC
-#define CGH_GO(BN, WR)                                                                         \
-  (wt ? launch_class_h<BN, WR, true>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)           \
-      : launch_class_h<BN, WR, false>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))
-  switch (cg_tile_columns(c_out)) {
-    case 128: return CGH_GO(128, 2);
-    case 96: return CGH_GO(96, 2);
-    case 64: return CGH_GO(64, 2);
-    default: return CGH_GO(32, 4);
-  }
-#undef CGH_GO
 }
 
 // half rows: feat / zp IEEE half, w = the half weight [K, C_in, C_out] as stored (wt = 0: forward, read in place through the

@@ -339,7 +339,7 @@ _CLASS_MIN_ROWS = 16384          # <= 64 channels (module attributes: tests forc
 _CLASS_MIN_ROWS_96 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_96", "48000"))
 _CLASS_MIN_ROWS_128 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_128", "60000"))
 _CLASS_MAX_WORK = 1.6        # a class plan is used while its row-products stay under 1.6x the rulebook's pairs
-_CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "48000"))
+_CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "16384"))
 # one-pass 2x2x2 strided / transposed convolutions on direct class plans (TASEG_DIRECT_CONV=0: pair GEMM + pass 2)
 _DIRECT_CONV = os.environ.get("TASEG_DIRECT_CONV", "1") != "0"
 _DIRECT_MIN_ROWS = int(os.environ.get("TASEG_DIRECT_MIN_ROWS", "0"))

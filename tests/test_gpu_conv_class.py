@@ -95,12 +95,15 @@ def test_class_gemm_is_the_convolution(ci, co):
     assert torch.equal(y, y_b)
 
 
-@pytest.mark.parametrize("ci,co", [(32, 32), (64, 96), (96, 96), (128, 96), (96, 128)])
-def test_class_gemm_half_storage(ci, co):
+@pytest.mark.parametrize("ci,co,n,extent", [(32, 32, 20000, 30), (64, 96, 20000, 30), (96, 96, 20000, 30), (128, 96, 20000, 30),
+                                            (96, 128, 20000, 30), (192, 96, 20000, 30), (256, 128, 9000, 24), (384, 256, 3000, 16),
+                                            (160, 64, 6000, 20), (64, 64, 100, 6), (96, 96, 120000, 70), (32, 64, 120000, 70)])
+def test_class_gemm_half_storage(ci, co, n, extent):
     """IEEE-half rows: the class path rounds a Z' row once per (row, z-plane), the two-pass form once per pair - both within
-    half precision of the fp32 evaluation"""
+    half precision of the fp32 evaluation.  Row chunks of 128 / 96 / 64 / 32 columns (one to five per row), one and two column
+    tiles, tile lists shorter and longer than the persistent grid (120 000 voxels: ~2 800 tiles on <= 1 024 workgroups)"""
     from taseg_amd import backend as B
-    c = _cloud(11, 20000, 30)
+    c = _cloud(11, n, extent)
     offs = O.get_kernel_offsets(3, 1, 1)
     km = B.build_kmap(_T(c), _T(c), _T(offs))
     plan = B.conv_class_plan(km["nbr"])

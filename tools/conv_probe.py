@@ -19,6 +19,7 @@ ap.add_argument("--cout", type=int, default=128)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--what", default="fwd,dgrad,wgrad,gsum")
 ap.add_argument("--impl", type=int, default=0)
+ap.add_argument("--planes", action="store_true", help="hand the pre-split weight planes to the pair GEMM (what the training step does)")
 args = ap.parse_args()
 
 coords, feats, labels, _ = bench.make_scans(0, 2, 120000, "minkunet")
@@ -53,6 +54,16 @@ def timed(fn, label, fl=None, byts=None):
 
 
 what = args.what.split(",")
+if args.planes:
+    from taseg_amd import _lib as L
+    planes = torch.empty(3 * w.numel(), dtype=torch.int16, device="cuda")
+    L.check(L.load().ts_conv_split_planes(w.data_ptr(), 27, args.cin, args.cout, planes.data_ptr(), L.stream()), "split")
+    _pg = B.conv_pair_gemm
+
+    def _hinted(*a, **k):
+        L.load().ts_conv_planes_hint(w.data_ptr(), planes.data_ptr(), 27, args.cin, args.cout)
+        return _pg(*a, **k)
+    B.conv_pair_gemm = _hinted
 if "fwd" in what:
     timed(lambda: B.conv_pair_gemm(xf, w, km.nbmaps_buf, km.nboffs, P, 0), "fwd", flops)
 if "dgrad" in what:
