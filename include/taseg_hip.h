@@ -619,14 +619,22 @@ int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_
  *     gradient; every fine row has exactly one pair); mirror = 0.  Rows without any neighbour are written as zeros.
  *   ts_conv_class_rows2(n, groups)  m_pad = groups * roundup(n, 128): slots of src / rows of Z' (ts_conv_class_rows: groups = 3)
  *   ts_conv_class_plan      nbr [K][n] -> src [K / groups][m_pad] (input row of (group offset, slot) or -1), tile_info
- *                           [m_pad / 128][2], n_tiles [2] (device: listed tiles, and their (tile, offset) steps - 128 * steps
+ *                           [m_pad / 128][2], n_tiles [3] (device: listed tiles; their (tile, offset) steps - 128 * steps
  *                           row-products against the rulebook's P pairs says what the plan costs: mask-sorted LiDAR rows give
- *                           ~1.1 P, rows with unrelated masks up to 3.7 P), and exactly one of pos [groups][n] (row of Z' per
- *                           (group, destination) or -1) and rows [m_pad] (destination row per slot or -1; groups == 1)
+ *                           ~1.1 P, rows with unrelated masks up to 3.7 P; and, three-group plans, how many listed tiles come
+ *                           before the centre group's - the list holds the outer groups' tiles first), and exactly one of
+ *                           pos [groups][n] (row of Z' per (group, destination) or -1) and rows [m_pad] (destination row per slot
+ *                           or -1; groups == 1)
  *   ts_conv_nbr_transposed  nbr_t [K][n_in] of a kernel map from its pos_in table and rulebook
  *   ts_conv_class_gemm      wt = 0: feat = input rows, kernel [K, c_red, c_out]; wt = 1: the transposed product (feat = output
  *                           gradients [*, c_red], kernel [K, c_out, c_red] as stored; mirror selects the slice K-1-k);
- *                           rows == NULL: zp [m_pad, c_out]; rows != NULL: zp [n, c_out] = the result */
+ *                           rows == NULL: zp [m_pad, c_out]; rows != NULL: zp [n, c_out] = the result
+ *   ts_conv_class_conv      the WHOLE convolution on a three-group plan, out [n, c_out] (+ addend [n, c_out], optional): every row
+ *                           is its own centre neighbour, so the centre group's tiles hold every output row exactly once - they
+ *                           run as a second launch of the product, add the other two groups' Z' rows of their rows (pass 2's
+ *                           additions in pass 2's order: the same bits as ts_conv_class_gemm + ts_conv_gather_sum) and store the
+ *                           result rows; no pass-2 launch, the centre group's third of Z' is never written.  zp [m_pad, c_out]
+ *                           is scratch for the outer groups' rows. */
 int64_t ts_conv_class_rows(int64_t n);
 int64_t ts_conv_class_rows2(int64_t n, int32_t groups);
 size_t ts_conv_class_plan_workspace_bytes(int64_t n);
@@ -642,10 +650,20 @@ int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
 int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                        const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                        int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream);
-/* half storage (torch.autocast): feat / zp IEEE half, w = the half weight [K, C_in, C_out] as stored */
+/* does finishing inside the product beat pass 2 on a map of n rows (measured thresholds; what the block calls use) */
+int32_t ts_conv_class_finish_pays(int64_t n, int32_t half);
+int ts_conv_class_conv(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                       const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                       int32_t mirror, const int32_t *pos, int64_t n, const float *addend, float *zp, float *out,
+                       ts_stream_t stream);
+/* half storage (torch.autocast): feat / zp / out / addend IEEE half, w = the half weight [K, C_in, C_out] as stored */
 int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
                            const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                            int32_t mirror, const int32_t *rows, void *zp, ts_stream_t stream);
+int ts_conv_class_conv_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
+                           const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                           int32_t mirror, const int32_t *pos, int64_t n, const void *addend, void *zp, void *out,
+                           ts_stream_t stream);
 
 /* Diagnostic: while `stamps` (device memory, 16 x uint64 per workgroup, `capacity` workgroups) is set, the 96- / 128-
  * column fp32 pair GEMMs run an instrumented instantiation whose workgroups leave shader-clock stamps of their phases

@@ -132,6 +132,9 @@ SIGNATURES = {
     "ts_conv_class_supported": (_i32, [_i32, _i32]),
     "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_class_gemm_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "ts_conv_class_finish_pays": (_i32, [_i64, _i32]),
+    "ts_conv_class_conv": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "ts_conv_class_conv_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_conv_planes_hint": (None, [_vp, _vp, _i32, _i32, _i32]),
     "ts_debug_phase_stamps": (None, [_vp, _i64]),
     "ts_fuse_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),

@@ -18,7 +18,7 @@ __all__ = [
     "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs", "devox_csr",
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
-    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16",
+    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
     "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
@@ -611,6 +611,9 @@ def profile_end():
             out.append(("class_gemm", _Ms(ms), None, dict(name=f"class_gemm_kernel<{pick(c_out)}>", pairs=pairs, c_red=c_red,
                                                           c_out=c_out, k=k, esize=esize, n_rows=rows, z_rows=max(int(wt), 0),
                                                           out_rows=max(-int(wt), 0))))
+        elif int(kind) == 4:      # ... finished inside the product: `wt` = Z' rows moved (written + read back), result rows = rows
+            out.append(("class_gemm", _Ms(ms), None, dict(name=f"class_gemm_kernel<{pick(c_out)}>", pairs=pairs, c_red=c_red,
+                                                          c_out=c_out, k=k, esize=esize, n_rows=rows, z_rows=int(wt), out_rows=rows)))
         elif int(kind) == 1:
             name = gather_sum_kernel_name(c_out, k, half)
             out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,
@@ -978,8 +981,8 @@ def conv_class_plan(nbr, groups=3, direct=False):
     through offset k, or -1): the K offsets in `groups` groups of <= 9, destination rows sorted by their neighbour mask per group.
     groups = 3: submanifold 3x3x3 maps (build_kmap with in == out), pass 2 adds the three group rows through plan["pos"];
     direct (groups = 1): 2x2x2 strided maps, the sums are stored straight into the rows plan["rows"] names - no Z, no pass 2.
-    Returns dict(src [K / groups, m_pad], tile_info [m_pad / 128, 2], n_tiles [2] (device: listed tiles, (tile, offset) steps),
-    pos | rows, m_pad, n, K, groups, mirror).  No host sync."""
+    Returns dict(src [K / groups, m_pad], tile_info [m_pad / 128, 2], n_tiles [3] (device: listed tiles, (tile, offset) steps,
+    tiles listed before the centre group's), pos | rows, m_pad, n, K, groups, mirror).  No host sync."""
     L.require_device(nbr)
     nbr = _i32(nbr, "nbr")
     k, n = nbr.shape
@@ -990,7 +993,7 @@ def conv_class_plan(nbr, groups=3, direct=False):
     dev = nbr.device
     src = torch.empty((k // groups, m_pad), dtype=torch.int32, device=dev)
     tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
-    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)          # (listed tiles, (tile, offset) steps)
+    n_tiles = torch.empty(3, dtype=torch.int32, device=dev)          # (listed tiles, (tile, offset) steps, outer groups' tiles)
     pos = None if direct else torch.empty((groups, n), dtype=torch.int32, device=dev)
     rows = torch.empty(m_pad, dtype=torch.int32, device=dev) if direct else None
     ws = L.workspace(lib.ts_conv_class_plan_workspace_bytes(n), dev)
@@ -1014,7 +1017,7 @@ def conv_class_plan_pairs(nbmaps, nboffs, k, n_pairs):
     dev = nbmaps.device
     src = torch.empty((k, m_pad), dtype=torch.int32, device=dev)
     tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
-    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)
+    n_tiles = torch.empty(3, dtype=torch.int32, device=dev)
     rows = torch.empty(m_pad, dtype=torch.int32, device=dev)
     ws = L.workspace(4 * (m_pad // 128) + 256, dev)
     L.check(lib.ts_conv_class_plan_pairs(L.ptr(nbmaps), L.ptr(nboffs), k, n, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles),
@@ -1066,6 +1069,70 @@ def conv_class_gemm(feat, kernel, plan, weight_transposed=False):
                                             1 if weight_transposed else 0, plan["mirror"], L.ptr(plan["rows"]), L.ptr(zp),
                                             L.stream()), "ts_conv_class_gemm")
     return zp
+
+
+def _z_moves(plan):
+    """Z' rows the finish-in-the-product form moves: the two outer groups' rows are written and read back once"""
+    z = int(plan.get("z_rows") or plan["m_pad"])
+    return 2 * max(0, z - (plan["n"] + 127) // 128 * 128)
+
+
+def class_finish_pays(n, half=False):
+    """does the finish inside the product (conv_class_conv) beat class GEMM + pass 2 on a map of n rows"""
+    return bool(L.load().ts_conv_class_finish_pays(int(n), 1 if half else 0))
+
+
+def conv_class_conv(feat, kernel, plan, weight_transposed=False, addend=None):
+    """The whole convolution on a three-group class plan: out [n, C] (+ addend) in two launches of the product - the centre
+    group's tiles add the outer groups' rows themselves; the same bits as conv_gather_sum(conv_class_gemm(...), plan["pos"], n)."""
+    L.require_device(feat, kernel)
+    feat, kernel = _f32(feat, "feat"), _f32(kernel, "kernel")
+    k, c_in, c_out = kernel.shape
+    c_red, cols = (c_out, c_in) if weight_transposed else (c_in, c_out)
+    if feat.shape[1] != c_red:
+        raise ValueError(f"conv_class_conv: feat has {feat.shape[1]} channels, the product reduces over {c_red}")
+    if plan["rows"] is not None or plan["groups"] != 3:
+        raise ValueError("conv_class_conv: a three-group pass-2 plan is needed")
+    if addend is not None:
+        addend = _f32(addend, "addend")
+        if addend.shape != (plan["n"], cols):
+            raise ValueError(f"conv_class_conv: addend shape {tuple(addend.shape)} != {(plan['n'], cols)}")
+    zp = torch.empty((plan["m_pad"], cols), dtype=torch.float32, device=feat.device)
+    out = torch.empty((plan["n"], cols), dtype=torch.float32, device=feat.device)
+    with _Timed("class_gemm", name=f"class_gemm_kernel<{_tile_cols(cols)}>", pairs=int(plan.get("pairs", 0)), c_red=c_red,
+                c_out=cols, k=k, esize=4, n_rows=feat.shape[0], z_rows=_z_moves(plan), out_rows=plan["n"]):
+        L.check(L.load().ts_conv_class_conv(L.ptr(feat), c_red, L.ptr(kernel), k, 3, cols, L.ptr(plan["src"]), plan["m_pad"],
+                                            L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
+                                            plan["mirror"], L.ptr(plan["pos"]), plan["n"], L.ptr(addend), L.ptr(zp), L.ptr(out),
+                                            L.stream()), "ts_conv_class_conv")
+    return out
+
+
+def conv_class_conv_f16(feat, w16, plan, weight_transposed=False, addend=None):
+    """conv_class_conv for IEEE-half rows (fp32 sums, the result rounded once)."""
+    L.require_device(feat, w16)
+    if feat.dtype != torch.float16 or w16.dtype != torch.float16 or (addend is not None and addend.dtype != torch.float16):
+        raise TypeError("conv_class_conv_f16: half tensors expected")
+    feat, w16 = feat.contiguous(), w16.contiguous()
+    k, c_in, c_out = w16.shape
+    c_red, cols = (c_out, c_in) if weight_transposed else (c_in, c_out)
+    if feat.shape[1] != c_red:
+        raise ValueError(f"conv_class_conv_f16: feat has {feat.shape[1]} channels, the product reduces over {c_red}")
+    if plan["rows"] is not None or plan["groups"] != 3:
+        raise ValueError("conv_class_conv_f16: a three-group pass-2 plan is needed")
+    if addend is not None:
+        addend = addend.contiguous()
+        if addend.shape != (plan["n"], cols):
+            raise ValueError(f"conv_class_conv_f16: addend shape {tuple(addend.shape)} != {(plan['n'], cols)}")
+    zp = torch.empty((plan["m_pad"], cols), dtype=torch.float16, device=feat.device)
+    out = torch.empty((plan["n"], cols), dtype=torch.float16, device=feat.device)
+    with _Timed("class_gemm", name=f"class_gemm_kernel<{_tile_cols(cols)}>", pairs=int(plan.get("pairs", 0)), c_red=c_red,
+                c_out=cols, k=k, esize=2, n_rows=feat.shape[0], z_rows=_z_moves(plan), out_rows=plan["n"]):
+        L.check(L.load().ts_conv_class_conv_f16(L.ptr(feat), c_red, L.ptr(w16), k, 3, cols, L.ptr(plan["src"]), plan["m_pad"],
+                                                L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]), 1 if weight_transposed else 0,
+                                                plan["mirror"], L.ptr(plan["pos"]), plan["n"], L.ptr(addend), L.ptr(zp),
+                                                L.ptr(out), L.stream()), "ts_conv_class_conv_f16")
+    return out
 
 
 def conv_class_gemm_f16(feat, w16, plan, weight_transposed=False):

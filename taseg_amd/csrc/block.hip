@@ -165,6 +165,14 @@ static bool plan_fits(const TsClassPlan *p, int32_t K, int64_t n_dest, int32_t c
   return p->pos && p->m_pad <= n_pairs;
 }
 static double plan_z_rows(const TsClassPlan *p) { return (double)(p->z_rows > 0 ? p->z_rows : p->m_pad); }
+// a three-group pass-2 plan finishes inside the product (conv_class.hip, TsClassFinish)
+static bool plan_finishes(const TsClassPlan *p, int32_t half) {
+  return p && !p->rows && p->pos && p->groups == 3 && p->K == 27 && ts_conv_class_finish_pays(p->n, half);
+}
+// ... and moves these Z' rows: the two outer groups' rows are written and read back once (the centre group holds every row)
+static double plan_z_moves(const TsClassPlan *p, int64_t n) {
+  return 2.0 * std::max(0.0, plan_z_rows(p) - (double)((n + 127) / 128 * 128));
+}
 
 // The convolution of a block: conv_out [n_out, c_out] = sum over the rulebook, on the class plan of opts (where it fits) or as pair
 // GEMM + pass 2 through z.  Shared by the training forward and the evaluation forward.
@@ -181,18 +189,23 @@ static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const
     if (cp) {
       // class-sorted implicit GEMM: the sums of a group of offsets stay in the accumulators; a direct plan (2x2x2 maps) stores
       // the result rows themselves, a pass-2 plan leaves <= 3 rows of Z' per output
+      // a three-group pass-2 plan finishes the sum in the product (two launches, no pass 2); other pass-2 plans leave Z' to pass 2
+      const bool fused = plan_finishes(cp, half);
       void *dst = cp->rows ? conv_out : z;
+      const TsClassFinish fin = {cp->pos, n_out, conv_out, nullptr};
       {
-        // (last field: rows of Z' a pass-2 plan writes, or minus the result rows a direct plan writes)
-        ProfScope ps(3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, cp->rows ? -(double)n_out : plan_z_rows(cp));
+        // (last field, kind 3: rows of Z' a pass-2 plan writes, or minus the result rows a direct plan writes; kind 4: the Z' rows
+        // the finish-in-the-product form moves - written by the two outer groups, read back by the centre group)
+        ProfScope ps(fused ? 4 : 3, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d,
+                     cp->rows ? -(double)n_out : fused ? plan_z_moves(cp, n_out) : plan_z_rows(cp));
         if (half)
           TS_TRY(ts_conv_class_gemm_f16_ex(feat, c_in, w16, K, cp->groups, c_out, cp->src, cp->m_pad, cp->tile_info, cp->n_tiles,
-                                           0, 0, cp->rows, dst, nullptr, stream));
+                                           0, 0, cp->rows, dst, nullptr, fused ? &fin : nullptr, stream));
         else
           TS_TRY(ts_conv_class_gemm_ex((const float *)feat, c_in, kernel, K, cp->groups, c_out, cp->src, cp->m_pad, cp->tile_info,
-                                       cp->n_tiles, 0, 0, cp->rows, (float *)dst, nullptr, stream));
+                                       cp->n_tiles, 0, 0, cp->rows, (float *)dst, nullptr, fused ? &fin : nullptr, stream));
       }
-      if (!cp->rows) {
+      if (!cp->rows && !fused) {
         ProfScope ps(1, stream, plan_z_rows(cp), 0, c_out, cp->groups, (double)n_out, es_d, 0);
         if (half)
           TS_TRY(ts_conv_gather_sum_f16(z, c_out, cp->pos, cp->groups, n_out, cp->m_pad, conv_out, stream));
@@ -386,18 +399,22 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   if (cp) {
     // input gradient on the class plan: gy rows through W_k^T (mirror: W_{K-1-k}^T), the sums of a group of offsets in the
     // accumulators; a direct plan writes grad_feat itself and carries the weight-gradient sum
+    const bool fused = plan_finishes(cp, half);
     void *dst = cp->rows ? grad_feat : z;
+    const TsClassFinish fin = {cp->pos, n_dgrad_rows, grad_feat, addend};
     {
-      ProfScope ps(3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, cp->rows ? -(double)n_dgrad_rows : plan_z_rows(cp));
-      const TsWgradReduce *side = (cp->rows && ride) ? &job : nullptr;
+      ProfScope ps(fused ? 4 : 3, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d,
+                   cp->rows ? -(double)n_dgrad_rows : fused ? plan_z_moves(cp, n_dgrad_rows) : plan_z_rows(cp));
+      const TsWgradReduce *side = ((cp->rows || fused) && ride) ? &job : nullptr;
       if (half)
         TS_TRY(ts_conv_class_gemm_f16_ex(grad_conv, c_out, weights, K, cp->groups, c_in, cp->src, cp->m_pad, cp->tile_info,
-                                         cp->n_tiles, 1, cp->mirror, cp->rows, dst, side, stream));
+                                         cp->n_tiles, 1, cp->mirror, cp->rows, dst, side, fused ? &fin : nullptr, stream));
       else
         TS_TRY(ts_conv_class_gemm_ex((const float *)grad_conv, c_out, (const float *)weights, K, cp->groups, c_in, cp->src,
-                                     cp->m_pad, cp->tile_info, cp->n_tiles, 1, cp->mirror, cp->rows, (float *)dst, side, stream));
+                                     cp->m_pad, cp->tile_info, cp->n_tiles, 1, cp->mirror, cp->rows, (float *)dst, side,
+                                     fused ? &fin : nullptr, stream));
     }
-    if (!cp->rows) {
+    if (!cp->rows && !fused) {
       ProfScope ps(1, stream, plan_z_rows(cp), 0, c_in, cp->groups, (double)n_dgrad_rows, es_d, side_bytes);
       if (half)
         TS_TRY(ts_conv_gather_sum_f16_ex(z, c_in, cp->pos, cp->groups, n_dgrad_rows, cp->m_pad, grad_feat, ride ? &job : nullptr,

@@ -222,13 +222,25 @@ struct TsPlanesHint {
 };
 extern thread_local TsPlanesHint g_ts_planes_hint;   // one-shot: set by ts_conv_planes_hint, cleared by the call that reads it
 
-// class-sorted implicit GEMM (csrc/conv_class.hip), library-internal forms: + the ordered weight-gradient sum riding on the launch
+// class-sorted implicit GEMM (csrc/conv_class.hip), library-internal forms: + the ordered weight-gradient sum riding on the launch,
+// + the finish of a three-group plan inside the product (fin != NULL, rows == NULL, groups == 3): two launches - the groups
+// without the centre offset write their Z' rows, then the centre group's tiles (every row is in one: a row is its own centre
+// neighbour) add the other groups' rows of their output rows in pass 2's order, the addend, and store the RESULT rows - no pass 2,
+// a third of Z' never written; the same bits as class GEMM + ts_conv_gather_sum_ex.
+struct TsClassFinish {
+  const int32_t *pos;        // [3][n] position table of the plan
+  int64_t n;                 // output rows
+  void *out;                 // [n, c_out] result
+  const void *addend;        // optional [n, c_out]
+};
 int ts_conv_class_gemm_ex(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                           const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                          int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, ts_stream_t stream);
+                          int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, const TsClassFinish *fin,
+                          ts_stream_t stream);
 int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
                               const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                              int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, ts_stream_t stream);
+                              int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, const TsClassFinish *fin,
+                              ts_stream_t stream);
 
 // Library-internal forms used by the fused block calls (csrc/block.hip): the gather-sum pass can form the ordered sum
 // of the weight-gradient partials on the side (saves the reduce launch), and the atomic form of the weight gradient

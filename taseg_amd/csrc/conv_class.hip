@@ -104,33 +104,40 @@ __global__ __launch_bounds__(CG_BM) void class_fill_kernel(const int *__restrict
 // live tiles, longest (most offsets) first: tile_info[t] = (group + 4 * tile, union mask); one workgroup (<= 70k tiles at the
 // 3e6-voxel cap).  The order inside a length class follows the arrival of the LDS atomics - every tile owns its Z' rows, so
 // the order of the list changes the schedule, never a result.  direct: tiles of rows WITHOUT any neighbour are listed too (last,
-// with mask 0): their destination rows must be written (zeros).
+// with mask 0): their destination rows must be written (zeros).  gfin >= 0 (three-group plans: the group of the centre offset):
+// the list is cut in two parts - the tiles of the other groups, then the tiles of group gfin, each longest first - and
+// n_tiles[2] = length of the first part (the finish-in-the-product form launches the parts one after the other).
 __global__ __launch_bounds__(1024) void class_tiles_kernel(const int *__restrict__ tile_mask, int n_all, int64_t npad, int direct,
-                                                           int2 *__restrict__ tile_info, int *__restrict__ n_tiles) {
-  __shared__ int cnt[CG_GK + 1], base[CG_GK + 1];
-  if (threadIdx.x <= CG_GK) cnt[threadIdx.x] = 0;
+                                                           int gfin, int2 *__restrict__ tile_info, int *__restrict__ n_tiles) {
+  constexpr int NB = CG_GK + 1;
+  __shared__ int cnt[2 * NB], base[2 * NB];
+  if (threadIdx.x < 2 * NB) cnt[threadIdx.x] = 0;
   __syncthreads();
+  const int tiles_per_group = (int)(npad / CG_BM);
   for (int t = threadIdx.x; t < n_all; t += 1024) {
     const int m = tile_mask[t];
-    if ((m & 511) || (direct && (m >> 30))) atomicAdd(&cnt[__builtin_popcount(m & 511)], 1);
+    if ((m & 511) || (direct && (m >> 30)))
+      atomicAdd(&cnt[(t / tiles_per_group == gfin ? NB : 0) + __builtin_popcount(m & 511)], 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0, steps = 0;
-    for (int c = CG_GK; c >= 0; --c) {
-      base[c] = run;
-      run += cnt[c];
-      steps += c * cnt[c];
+    for (int part = 0; part < 2; ++part) {
+      for (int c = CG_GK; c >= 0; --c) {
+        base[part * NB + c] = run;
+        run += cnt[part * NB + c];
+        steps += c * cnt[part * NB + c];
+      }
+      if (part == 0) n_tiles[2] = run;
     }
     n_tiles[0] = run;
     n_tiles[1] = steps;        // (tile, offset) steps of the plan: 128 * steps row-products against the rulebook's pairs
   }
   __syncthreads();
-  const int tiles_per_group = (int)(npad / CG_BM);
   for (int t = threadIdx.x; t < n_all; t += 1024) {
     const int m = tile_mask[t];
     if ((m & 511) || (direct && (m >> 30))) {
-      const int at = atomicAdd(&base[__builtin_popcount(m & 511)], 1);
+      const int at = atomicAdd(&base[(t / tiles_per_group == gfin ? NB : 0) + __builtin_popcount(m & 511)], 1);
       tile_info[at] = make_int2(t / tiles_per_group + 4 * t, m & 511);
     }
   }
@@ -148,7 +155,7 @@ extern "C" size_t ts_conv_class_plan_workspace_bytes(int64_t n) {
 
 // nbr [K][n] = input row feeding destination row j through offset k, or -1 (ts_build_kmap's `nbr` table; for the transposed
 // direction of a strided map the table of the inverse map) -> src [K / groups][m_pad], tile_info [m_pad / 128] (x, y) pairs,
-// n_tiles [2] = (listed tiles, their (tile, offset) steps), and either pos [groups][n] (pass 2 adds the groups' rows) or - direct
+// n_tiles [3] = (listed tiles, their (tile, offset) steps, tiles listed before the centre group's), and either pos [groups][n] (pass 2 adds the groups' rows) or - direct
 // plans, groups == 1 - rows [m_pad] (destination row of every list slot, -1 = padding);  m_pad = ts_conv_class_rows2(n, groups)
 extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t groups, int32_t *src, int32_t *tile_info,
                                   int32_t *n_tiles, int32_t *pos, int32_t *rows, void *ws, size_t ws_bytes, ts_stream_t stream_) {
@@ -180,7 +187,8 @@ extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int3
   TS_CHECK_HIP(rocprim::radix_sort_pairs(p, sort_bytes, k0, k1, v0, v1, (size_t)m, 0, 11, stream), "ts_conv_class_plan/sort");
   class_fill_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>(nbr, n, npad, groups, gk, k1, v1, src, pos, rows, tmask);
   TS_CHECK_LAUNCH("ts_conv_class_plan/fill");
-  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), npad, rows ? 1 : 0, (int2 *)tile_info, n_tiles);
+  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), npad, rows ? 1 : 0, groups == CG_GROUPS ? (K / 2) / gk : -1,
+                                         (int2 *)tile_info, n_tiles);
   TS_CHECK_LAUNCH("ts_conv_class_plan/tiles");
   return TS_OK;
 }
@@ -229,7 +237,7 @@ extern "C" int ts_conv_class_plan_pairs(const int32_t *nbmaps, const int32_t *nb
   int *tmask = (int *)ws;
   class_fill_pairs_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>((const int2 *)nbmaps, nboffs, K, n_pairs, m, src, rows, tmask);
   TS_CHECK_LAUNCH("ts_conv_class_plan_pairs/fill");
-  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), m, 1, (int2 *)tile_info, n_tiles);
+  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), m, 1, -1, (int2 *)tile_info, n_tiles);
   TS_CHECK_LAUNCH("ts_conv_class_plan_pairs/tiles");
   return TS_OK;
 }
@@ -290,6 +298,18 @@ __device__ __forceinline__ bf8 cg_frag_tr(const unsigned short *img, int pitch, 
     ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[0], (B)[0], ACC, 0, 0, 0);        \
   } while (0)
 
+// finish of a three-group plan inside the product (common.h, TsClassFinish): phase 0 = every listed tile, Z' rows (pass 2 follows);
+// phase 1 = the first part of the list (groups without the centre offset), Z' rows; phase 2 = the second part (the centre
+// group: every output row is in exactly one of its tiles), the RESULT rows: out[r] = ((z_0[r] +) own sums (+ z_2[r])) (+ addend[r]),
+// r = the slot's own row (its centre neighbour, offset klc of the group) - pass 2's additions in pass 2's order
+struct CgFinish {
+  const int *pos;
+  const void *addend;
+  void *out;
+  int64_t n;
+  int phase, klc;
+};
+
 // X [n, R] fp32 rows; W [K, R, O_total] (WT = false: forward) or [K, O_total, R] (WT = true: the input gradient multiplies with
 // the transposed slice of the MIRRORED offset); Zp [m_pad, O_total].  grid (upper bound of the tile count, O_total / BN).
 // gk offsets per group (k = gk * group + kl); mirror: the transposed product takes the slice of offset K-1-k (submanifold maps: the
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
                                                            const int2 *__restrict__ tile_info,
                                                            const int *__restrict__ n_tiles, int K, int gk, int mirror,
                                                            const int *__restrict__ rows, float *__restrict__ Zp,
-                                                           TsWgradReduce side, int tile_blocks) {
+                                                           TsWgradReduce side, int tile_blocks, CgFinish fin) {
   constexpr int BM = CG_BM;
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
   const int tq = r16 >> 2, tp = lane & 3;
   const int wr = wave / WC, wc = wave % WC;
   const int o0 = blockIdx.y * BN;
-  const int tile = (int)blockIdx.x;             // launch order = list order (longest first): every XCD gets tiles of every length
+  int tile = (int)blockIdx.x;                   // launch order = list order (longest first): every XCD gets tiles of every length
   if (tile >= tile_blocks) {                    // side job: ordered sum of the weight-gradient partials
     if (blockIdx.y == 0) {
       const int64_t step = (int64_t)(gridDim.x - tile_blocks) * 256;
@@ -333,7 +353,11 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
     }
     return;
   }
-  if (tile >= *n_tiles) return;
+  {
+    const int t_all = n_tiles[0], t_cut = fin.phase ? n_tiles[2] : 0;
+    if (fin.phase == 2) tile += t_cut;
+    if (tile >= (fin.phase == 1 ? t_cut : t_all)) return;
+  }
   const int2 info = tile_info[tile];
   const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
   int mask = __builtin_amdgcn_readfirstlane(info.y);
@@ -500,6 +524,37 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
       }
     return;
   }
+  if (fin.phase == 2) {                         // the centre group: result rows, through an LDS image of the tile's sums so that
+    // the other groups' rows, the addend and the result move as 16-byte pieces of whole rows
+    constexpr int ZF = BN + 4;
+    float *Zt = (float *)smem_cg;
+    __syncthreads();                            // every wave has read the last slice
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          Zt[((wr * MI + mi) * 16 + 4 * g + q) * ZF + (wc * NI + ni) * 16 + r16] = tot[mi][ni][q];
+    __syncthreads();
+    const int *crow = src + (int64_t)fin.klc * m_pad + row0;
+    float *out = (float *)fin.out;
+    const float *add = (const float *)fin.addend;
+    constexpr int C4 = BN / 4;
+    for (int e = tid; e < BM * C4; e += 256) {
+      const int row = e / C4, c4 = e - row * C4;
+      const int r = crow[row];
+      if (r < 0) continue;
+      const int p0 = fin.pos[r], p2 = fin.pos[2 * fin.n + r];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p0 >= 0) v += *(const f32x4 *)(Zp + (int64_t)p0 * O_total + o0 + 4 * c4);
+      v += *(const f32x4 *)&Zt[row * ZF + 4 * c4];
+      if (p2 >= 0) v += *(const f32x4 *)(Zp + (int64_t)p2 * O_total + o0 + 4 * c4);
+      if (add) v += *(const f32x4 *)(add + (int64_t)r * O_total + o0 + 4 * c4);
+      *(f32x4 *)(out + (int64_t)r * O_total + o0 + 4 * c4) = v;
+    }
+    return;
+  }
   float *zt = Zp + row0 * O_total + o0;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -517,20 +572,27 @@ struct CgArgs {          // what a class-GEMM launch takes beyond operands and r
   const int *n_tiles;
   int K, gk, mirror;
   const int *rows;
-  TsWgradReduce side;    // side.K == 0: none
+  TsWgradReduce side;
+  CgFinish fin;          // phase 0: plain launch
+  int groups;
 };
+// tiles a launch can meet: all of the list, or - finish inside the product - the non-centre groups (phase 1) / the centre group (2)
+static int64_t cg_tile_bound(const CgArgs &a) {
+  const int64_t all = a.m_pad / CG_BM;
+  return a.fin.phase == 0 ? all : a.fin.phase == 2 ? all / a.groups : all - all / a.groups;
+}
 
 template <int BN, int WR, bool WT>
 static int launch_class(const float *X, int R, const float *W, int O_total, const CgArgs &a, float *Zp, hipStream_t stream) {
-  const size_t lds = (size_t)3 * (CG_BM * CG_AP + (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
-  const unsigned tiles = (unsigned)(a.m_pad / CG_BM);
+  const size_t stage = (size_t)3 * (CG_BM * CG_AP + (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
+  const size_t lds = a.fin.phase == 2 ? std::max(stage, (size_t)CG_BM * (BN + 4) * 4) : stage;      // phase 2: the image of the sums
+  const unsigned tiles = (unsigned)cg_tile_bound(a);
   dim3 grid(tiles + (a.side.K > 0 ? 64u : 0u), (unsigned)(O_total / BN));
   class_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K, a.gk,
-                                                            a.mirror, a.rows, Zp, a.side, (int)tiles);
+                                                            a.mirror, a.rows, Zp, a.side, (int)tiles, a.fin);
   TS_CHECK_LAUNCH("ts_conv_class_gemm");
   return TS_OK;
 }
-
 static int cg_tile_columns(int c_out) { return c_out % 128 == 0 ? 128 : c_out % 96 == 0 ? 96 : c_out % 64 == 0 ? 64 : c_out % 32 == 0 ? 32 : 0; }
 
 extern "C" int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out) {
@@ -551,24 +613,62 @@ static int cg_check(const char *what, int K, int groups, int c_red, int c_out, i
   return TS_OK;
 }
 
-// library-internal form (csrc/block.hip): + the weight-gradient sum riding on the launch
+// Where the finish inside the product pays.  It trades pass 2 (one launch, 4 row moves per output row) for a second launch of the
+// product (2 row moves, but two launch tails instead of one).  Alone on the device (profiles/r04_class_finish_probe.txt) that is a
+// gain from ~60k rows in half storage (stride-1 96 -> 96: 105 -> 89 us) and only on the largest maps in fp32 (178k rows: 233 -> 224
+// us; 84k rows: level; 30k rows: a third slower); inside the training step, with the staging stream's kernels beside it, the
+// nuScenes autocast step got 0.2 ms SLOWER with it (16.94 -> 17.17 ms, profiles/r04_ab_class_finish.txt).  So the block calls keep
+// pass 2 (thresholds 0 = never); TASEG_CLASS_FINISH_ROWS / TASEG_CLASS_FINISH_ROWS_HALF (rows from which the finish is taken) switch
+// it on for A/B runs, and ts_conv_class_conv is there for callers that want the convolution in one call.
+extern "C" int32_t ts_conv_class_finish_pays(int64_t n, int32_t half) {
+  static const int64_t rows32 = getenv("TASEG_CLASS_FINISH_ROWS") ? atoll(getenv("TASEG_CLASS_FINISH_ROWS")) : 0;
+  static const int64_t rows16 = getenv("TASEG_CLASS_FINISH_ROWS_HALF") ? atoll(getenv("TASEG_CLASS_FINISH_ROWS_HALF")) : 0;
+  const int64_t lim = half ? rows16 : rows32;
+  return lim > 0 && n >= lim;
+}
+
+// shared by the fp32 and the half entry: the finish descriptor of a call (checked), and the two launches it turns into
+static int cg_finish(const char *what, const TsClassFinish *fin, int K, int groups, const int32_t *rows, CgFinish &out) {
+  out = CgFinish{nullptr, nullptr, nullptr, 0, 0, 0};
+  if (!fin) return TS_OK;
+  TS_REQUIRE(groups == CG_GROUPS && !rows && (K / 2) / (K / groups) == 1, TS_ERR_INVALID_ARGUMENT,
+             "%s: the finish inside the product needs a three-group pass-2 plan", what);
+  TS_REQUIRE(fin->pos && fin->out && fin->n > 0 && (((uintptr_t)fin->out) & 15) == 0 && (((uintptr_t)fin->addend) & 15) == 0,
+             TS_ERR_INVALID_ARGUMENT, "%s: finish: null / misaligned pointer", what);
+  out = CgFinish{fin->pos, fin->addend, fin->out, fin->n, 1, (K / 2) % (K / groups)};
+  return TS_OK;
+}
+
+// library-internal form (csrc/block.hip): + the weight-gradient sum riding on the launch, + the finish inside the product
 int ts_conv_class_gemm_ex(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                           const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                          int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, ts_stream_t stream_) {
+                          int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, const TsClassFinish *fin,
+                          ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int rc = cg_check("ts_conv_class_gemm", K, groups, c_red, c_out, m_pad, feat, kernel, zp, src, tile_info, n_tiles);
   if (rc != TS_OK) return rc;
-  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}};
-  if (side) a.side = *side;
+  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}, {}, groups};
+  {
+    const int frc = cg_finish("ts_conv_class_gemm", fin, K, groups, rows, a.fin);
+    if (frc != TS_OK) return frc;
+  }
 #define CG_GO(BN, WR)                                                                  \
   (wt ? launch_class<BN, WR, true>(feat, c_red, kernel, c_out, a, zp, stream)          \
       : launch_class<BN, WR, false>(feat, c_red, kernel, c_out, a, zp, stream))
-  switch (cg_tile_columns(c_out)) {
-    case 128: return CG_GO(128, 2);
-    case 96: return CG_GO(96, 2);
-    case 64: return CG_GO(64, 2);
-    default: return CG_GO(32, 4);
+  // phase 1 (or the one plain launch), then - finish inside the product - phase 2, which also carries the side job
+  for (int phase = a.fin.phase; phase <= (fin ? 2 : 0); ++phase) {
+    a.fin.phase = phase;
+    a.side = (side && phase != 1) ? *side : TsWgradReduce{};
+    int r;
+    switch (cg_tile_columns(c_out)) {
+      case 128: r = CG_GO(128, 2); break;
+      case 96: r = CG_GO(96, 2); break;
+      case 64: r = CG_GO(64, 2); break;
+      default: r = CG_GO(32, 4); break;
+    }
+    if (r != TS_OK) return r;
   }
+  return TS_OK;
 #undef CG_GO
 }
 
@@ -580,7 +680,19 @@ extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float 
                                   const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                                   int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream) {
   return ts_conv_class_gemm_ex(feat, c_red, kernel, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, rows, zp, nullptr,
-                               stream);
+                               nullptr, stream);
+}
+
+// The whole convolution on a three-group plan: out [n, c_out] = sum over the offsets (+ addend), as ts_conv_class_gemm followed by
+// ts_conv_gather_sum(zp, pos, 3) - the same bits - in two launches of the product kernel and without the centre group's Z' rows
+// (zp [m_pad, c_out] is scratch for the other two groups' rows).
+extern "C" int ts_conv_class_conv(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                                  const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                                  int32_t mirror, const int32_t *pos, int64_t n, const float *addend, float *zp, float *out,
+                                  ts_stream_t stream) {
+  const TsClassFinish fin = {pos, n, out, addend};
+  return ts_conv_class_gemm_ex(feat, c_red, kernel, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, nullptr, zp, nullptr,
+                               &fin, stream);
 }
 
 // ------------------------------------------------------------------------------------------- half storage
@@ -625,7 +737,7 @@ template <int BN, int WR, bool WT, int RC>
 __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
     const _Float16 *__restrict__ X, int R, const _Float16 *__restrict__ W, int O_total, const int *__restrict__ src, int64_t m_pad,
     const int2 *__restrict__ tile_info, const int *__restrict__ n_tiles_p, int K, int gk, int mirror, const int *__restrict__ rows,
-    _Float16 *__restrict__ Zp, TsWgradReduce side, int G) {
+    _Float16 *__restrict__ Zp, TsWgradReduce side, int G, CgFinish fin) {
   constexpr int BM = CG_BM;
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
@@ -663,7 +775,11 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
   cur.G = G;
   cur.slot = (int)blockIdx.x;
   cur.round = 0;
-  cur.n_tiles = __builtin_amdgcn_readfirstlane(*n_tiles_p);
+  // the part of the list this launch walks: all of it, or (finish inside the product) the groups without the centre offset /
+  // the centre group
+  const int t_cut = fin.phase ? __builtin_amdgcn_readfirstlane(n_tiles_p[2]) : 0;
+  const int t_base = fin.phase == 2 ? t_cut : 0;
+  cur.n_tiles = (fin.phase == 1 ? t_cut : __builtin_amdgcn_readfirstlane(n_tiles_p[0])) - t_base;
   cur.tile = cur.slot;
   cur.rest = 0;
   cur.row0 = cur.grp = 0;
@@ -671,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
   auto tile_of = [&](int round) { return round * G + ((round & 1) ? G - 1 - cur.slot : cur.slot); };
   auto load_entry = [&](int t) -> int2 {
     int2 e = make_int2(0, 0);
-    if (t < cur.n_tiles) e = tile_info[t];
+    if (t < cur.n_tiles) e = tile_info[t_base + t];
     return make_int2(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y));
   };
   auto zero_tile = [&](int row0) {               // direct plans: a tile of rows without any neighbour - their result is zero
@@ -795,6 +911,45 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
           acc[mi][ni][q] = 0.f;
         }
     __syncthreads();
+    if (fin.phase == 2) {                 // the centre group: result rows (pass 2's additions in pass 2's order, fp32, one rounding)
+      const int *crow = src + (int64_t)fin.klc * m_pad + row0;
+      _Float16 *out = (_Float16 *)fin.out;
+      const _Float16 *add = (const _Float16 *)fin.addend;
+      for (int e = tid; e < BM * CH; e += 256) {
+        const int row = e / CH, ch = e - row * CH;
+        const int r = crow[row];
+        if (r < 0) continue;
+        const int p0 = fin.pos[r], p2 = fin.pos[2 * fin.n + r];
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        if (p0 >= 0) {
+          const ch8 z = *(const ch8 *)(Zp + (int64_t)p0 * O_total + o0 + ch * 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += (float)z[i];
+        }
+        {
+          const ch8 z = *(const ch8 *)&Zt[row * ZP + ch * 8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += (float)z[i];
+        }
+        if (p2 >= 0) {
+          const ch8 z = *(const ch8 *)(Zp + (int64_t)p2 * O_total + o0 + ch * 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += (float)z[i];
+        }
+        if (add) {
+          const ch8 z = *(const ch8 *)(add + (int64_t)r * O_total + o0 + ch * 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += (float)z[i];
+        }
+        ch8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (_Float16)v[i];
+        *(ch8 *)(out + (int64_t)r * O_total + o0 + ch * 8) = o;
+      }
+      return;
+    }
     for (int e = tid; e < BM * CH; e += 256) {
       const int row = e / CH, ch = e - row * CH;
       const int64_t dst = rows ? (int64_t)rows[row0 + row] : (int64_t)row0 + row;
@@ -844,7 +999,7 @@ static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_tot
   const size_t stage = (size_t)(CG_BM * (RC + 8) + (WT ? BN * (RC + 8) : RC * (BN + 8))) * 2;
   const size_t ztile = (size_t)CG_BM * (BN + 8) * 2;
   const size_t lds = std::max(stage, ztile);
-  const int64_t tiles = a.m_pad / CG_BM;
+  const int64_t tiles = cg_tile_bound(a);
   static const int cus = ts_cu_count();
   // one resident workgroup per slot the kernel can hold on the chip (registers and LDS of THIS instantiation), each walking the list
   static const int per_cu = [&] {
@@ -856,7 +1011,7 @@ static int launch_class_h(const _Float16 *X, int R, const _Float16 *W, int O_tot
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cus * per_cu / ny));
   dim3 grid((unsigned)G + (a.side.K > 0 ? 64u : 0u), (unsigned)ny);
   class_gemm_h_kernel<BN, WR, WT, RC><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K,
-                                                                    a.gk, a.mirror, a.rows, Zp, a.side, G);
+                                                                    a.gk, a.mirror, a.rows, Zp, a.side, G, a.fin);
   TS_CHECK_LAUNCH("ts_conv_class_gemm_f16 (whole rows)");
   return TS_OK;
 }
@@ -865,25 +1020,36 @@ static int cgh_row_chunk(int c_red) { return c_red % 128 == 0 ? 128 : c_red % 96
 
 int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
                               const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                              int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, ts_stream_t stream_) {
+                              int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, const TsClassFinish *fin,
+                              ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int chk = cg_check("ts_conv_class_gemm_f16", K, groups, c_red, c_out, m_pad, feat, w, zp, src, tile_info, n_tiles);
   if (chk != TS_OK) return chk;
-  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}};
-  if (side) a.side = *side;
+  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}, {}, groups};
+  {
+    const int frc = cg_finish("ts_conv_class_gemm_f16", fin, K, groups, rows, a.fin);
+    if (frc != TS_OK) return frc;
+  }
   const _Float16 *x = (const _Float16 *)feat, *wh = (const _Float16 *)w;
   const int rc = cgh_row_chunk(c_red);
 #define CGH2_RC(BN, WR, RC)                                                                      \
-  (wt ? launch_class_h<BN, WR, true, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)         \
+  (wt ? launch_class_h<BN, WR, true, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream)          \
       : launch_class_h<BN, WR, false, RC>(x, c_red, wh, c_out, a, (_Float16 *)zp, stream))
 #define CGH2_GO(BN, WR)                                                                          \
   (rc == 128 ? CGH2_RC(BN, WR, 128) : rc == 96 ? CGH2_RC(BN, WR, 96) : rc == 64 ? CGH2_RC(BN, WR, 64) : CGH2_RC(BN, WR, 32))
-  switch (cg_tile_columns(c_out)) {
-    case 128: return CGH2_GO(128, 2);
-    case 96: return CGH2_GO(96, 2);
-    case 64: return CGH2_GO(64, 2);
-    default: return CGH2_GO(32, 4);
+  for (int phase = a.fin.phase; phase <= (fin ? 2 : 0); ++phase) {
+    a.fin.phase = phase;
+    a.side = (side && phase != 1) ? *side : TsWgradReduce{};
+    int r;
+    switch (cg_tile_columns(c_out)) {
+      case 128: r = CGH2_GO(128, 2); break;
+      case 96: r = CGH2_GO(96, 2); break;
+      case 64: r = CGH2_GO(64, 2); break;
+      default: r = CGH2_GO(32, 4); break;
+    }
+    if (r != TS_OK) return r;
   }
+  return TS_OK;
 #undef CGH2_GO
 #undef CGH2_RC
 }
@@ -894,5 +1060,15 @@ extern "C" int ts_conv_class_gemm_f16(const void *feat, int32_t c_red, const voi
                                       const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles,
                                       int32_t wt, int32_t mirror, const int32_t *rows, void *zp, ts_stream_t stream) {
   return ts_conv_class_gemm_f16_ex(feat, c_red, w, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, rows, zp, nullptr,
-                                   stream);
+                                   nullptr, stream);
+}
+
+// ts_conv_class_conv for IEEE-half rows (fp32 sums, one rounding of the result)
+extern "C" int ts_conv_class_conv_f16(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
+                                      const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles,
+                                      int32_t wt, int32_t mirror, const int32_t *pos, int64_t n, const void *addend, void *zp,
+                                      void *out, ts_stream_t stream) {
+  const TsClassFinish fin = {pos, n, out, addend};
+  return ts_conv_class_gemm_f16_ex(feat, c_red, w, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, nullptr, zp, nullptr,
+                                   &fin, stream);
 }

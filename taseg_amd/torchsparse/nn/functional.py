@@ -242,7 +242,7 @@ class KernelMap:
             # one host read (the map's builder has just read the pair total the same way): is the plan worth walking?  Rows with
             # LiDAR-like neighbour masks sort into near-uniform tiles (128 * steps ~ 1.1 P); rows with unrelated masks would make
             # every tile walk all nine offsets of its group with most rows absent (up to 3.7 P row-products): two passes then
-            tiles, steps = cls["n_tiles"].tolist()
+            tiles, steps = cls["n_tiles"].tolist()[:2]
             cls["z_rows"], cls["steps"] = 128 * tiles, steps
             cls["map_id"], cls["pairs"] = self.nboffs, self.total          # the identity of the map the plan belongs to
             if 128 * steps <= _CLASS_MAX_WORK * self.total:
@@ -347,6 +347,17 @@ _DIRECT_DOWN_MIN_ROWS = 8000        # smallest destination-row count any "down" 
 _DIRECT_FORCE = os.environ.get("TASEG_DIRECT_CONV") == "force"        # every fitting 2x2x2 product on its direct plan (tests, probes)
 
 
+def class_conv(x, w, plan, f16, wt=False):
+    """the convolution (wt: its transposed product) on a class plan: a direct plan's product IS the result; a three-group plan
+    finishes inside the product where that pays (B.class_finish_pays), else through pass 2 - the same bits either way"""
+    if plan["rows"] is not None:
+        return (B.conv_class_gemm_f16 if f16 else B.conv_class_gemm)(x, w, plan, weight_transposed=wt)
+    if plan["groups"] == 3 and B.class_finish_pays(plan["n"], f16):
+        return (B.conv_class_conv_f16 if f16 else B.conv_class_conv)(x, w, plan, weight_transposed=wt)
+    z = (B.conv_class_gemm_f16 if f16 else B.conv_class_gemm)(x, w, plan, weight_transposed=wt)
+    return (B.conv_gather_sum_f16 if f16 else B.conv_gather_sum)(z, plan["pos"], plan["n"])
+
+
 def class_gemm_pays(n_rows: int, c_in: int, c_out: int, half: bool = False) -> bool:
     if half:
         return n_rows >= _CLASS_MIN_ROWS_HALF
@@ -435,17 +446,12 @@ class _SparseConv(Function):
         # transposed maps in ONE pass (direct plans)
         cls, cls_d = kmap.plans_for(transposed, weight.shape[1], weight.shape[2], half)
 
-        def finish(z, plan, n_rows, f16):
-            if plan["rows"] is not None:
-                return z                          # direct plan: the product IS the result
-            return (B.conv_gather_sum_f16 if f16 else B.conv_gather_sum)(z, plan["pos"], n_rows)
-
         with _no_autocast():
             if half:
                 fh = feats.contiguous().half()
                 w16, _ = B.cast_weights_f16(weight.detach().float(), want=(True, False))
                 if cls is not None:
-                    out = finish(B.conv_class_gemm_f16(fh, w16, cls), cls, rows, True)
+                    out = class_conv(fh, w16, cls, True)
                 else:
                     z = B.conv_pair_gemm_f16(fh, w16, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol, natural=True)
                     out = B.conv_gather_sum_f16(z, table, rows)
@@ -456,7 +462,7 @@ class _SparseConv(Function):
                 if w32.data_ptr() != weight.data_ptr():
                     planes = None             # a converted copy: the planes belong to the parameter's own storage
                 if cls is not None:
-                    out = finish(B.conv_class_gemm(f32, w32, cls), cls, rows, False)
+                    out = class_conv(f32, w32, cls, False)
                 else:
                     _planes.hint(w32, planes)
                     z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
@@ -482,8 +488,7 @@ class _SparseConv(Function):
             if ctx.half:
                 gh = grad_out.contiguous().half()
                 if ctx.needs_input_grad[0] and ctx.cls is not None:
-                    z = B.conv_class_gemm_f16(gh, weight, ctx.cls, weight_transposed=True)
-                    grad_feats = (z if ctx.cls["rows"] is not None else B.conv_gather_sum_f16(z, ctx.cls["pos"], rows)).to(ctx.in_dtype)
+                    grad_feats = class_conv(gh, weight, ctx.cls, True, True).to(ctx.in_dtype)
                 elif ctx.needs_input_grad[0]:
                     # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T: rows of W_k (= w16) are the output columns
                     z = B.conv_pair_gemm_f16(gh, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
@@ -494,8 +499,7 @@ class _SparseConv(Function):
             else:
                 g32 = grad_out.contiguous().float()
                 if ctx.needs_input_grad[0] and ctx.cls is not None:
-                    z = B.conv_class_gemm(g32, weight, ctx.cls, weight_transposed=True)
-                    grad_feats = (z if ctx.cls["rows"] is not None else B.conv_gather_sum(z, ctx.cls["pos"], rows)).to(ctx.in_dtype)
+                    grad_feats = class_conv(g32, weight, ctx.cls, False, True).to(ctx.in_dtype)
                 elif ctx.needs_input_grad[0]:
                     _planes.hint(weight, ctx.planes)
                     z = B.conv_pair_gemm(g32, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol,

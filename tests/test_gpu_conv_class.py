@@ -24,7 +24,8 @@ def _T(a):
 @pytest.mark.parametrize("n,extent", [(1, 4), (100, 3), (127, 40), (129, 6), (5000, 14), (40000, 40)])
 def test_class_plan_lists_every_pair_once(n, extent):
     """every (output row, offset) pair of the rulebook appears exactly once in src, at the row pos names; dead rows and the
-    padding carry -1; the tile list holds every tile with a live row, longest first, with the union of its rows' masks"""
+    padding carry -1; the tile list holds every tile with a live row (the outer groups' tiles, then the centre group's, each part
+    longest first) with the union of its rows' masks"""
     from taseg_amd import backend as B
     c = _cloud(n, n, extent)
     offs = O.get_kernel_offsets(3, 1, 1)
@@ -56,7 +57,10 @@ def test_class_plan_lists_every_pair_once(n, extent):
     masks = ((src >= 0).reshape(9, -1, 128).any(2) * (1 << np.arange(9))[:, None]).sum(0)
     assert np.array_equal(info[:, 1], masks[tiles]) and np.array_equal(info[:, 0] & 3, tiles // (m_pad // 3 // 128))
     pop = np.array([bin(int(v)).count("1") for v in info[:, 1]])
-    assert np.all(pop[:-1] >= pop[1:])                                           # longest first
+    cut = int(plan["n_tiles"][2])                                                # the outer groups' tiles, then the centre group's
+    assert np.all((info[:cut, 0] & 3) != 1) and np.all((info[cut:, 0] & 3) == 1)
+    for part in (pop[:cut], pop[cut:]):
+        assert np.all(part[:-1] >= part[1:])                                     # each part longest first
     assert int(plan["n_tiles"][1]) == int(pop.sum())                             # the plan's (tile, offset) steps
 
 
@@ -129,6 +133,54 @@ def test_class_gemm_half_storage(ci, co, n, extent):
         assert err(got, ref) <= 1.5 * err(two, ref) + 2e-4       # same error budget: 3 roundings of group sums vs 6.5 of pair products
 
 
+@pytest.mark.parametrize("ci,co,n,extent", [(32, 32, 3000, 16), (96, 96, 20000, 30), (128, 96, 20000, 30), (64, 128, 9000, 24),
+                                            (256, 128, 3000, 16), (96, 96, 120000, 70)])
+@pytest.mark.parametrize("half", [False, True])
+def test_class_conv_finishes_in_the_product_with_the_bits_of_pass_2(ci, co, n, extent, half):
+    """ts_conv_class_conv: the centre group's tiles add the outer groups' Z' rows, the addend, and store the result rows - the same
+    additions in the same order as ts_conv_class_gemm + ts_conv_gather_sum (+ addend): bit-identical, forward and transposed product,
+    fp32 and half storage; the tile list comes in two parts (outer groups, centre group), each longest first"""
+    from taseg_amd import backend as B
+    c = _cloud(5, n, extent)
+    offs = O.get_kernel_offsets(3, 1, 1)
+    km = B.build_kmap(_T(c), _T(c), _T(offs))
+    plan = B.conv_class_plan(km["nbr"])
+    nv = len(c)
+    tiles, steps, cut = plan["n_tiles"].tolist()
+    info = plan["tile_info"][:tiles].cpu().numpy()
+    grp = info[:, 0] & 3
+    assert 0 < cut < tiles and (grp[:cut] != 1).all() and (grp[cut:] == 1).all()
+    assert tiles - cut == (nv + 127) // 128                                    # every row is in one centre-group tile
+    for part in (info[:cut], info[cut:]):
+        lens = np.array([bin(int(m)).count("1") for m in part[:, 1]])
+        assert (np.diff(lens) <= 0).all()
+    rs = np.random.RandomState(3)
+    x = _T(rs.randn(nv, ci).astype(np.float32))
+    gy = _T(rs.randn(nv, co).astype(np.float32))
+    w = _T((rs.randn(27, ci, co) / np.sqrt(ci)).astype(np.float32))
+    add_x = _T(rs.randn(nv, ci).astype(np.float32))
+    if half:
+        x, gy, w, add_x = x.half(), gy.half(), w.half(), add_x.half()
+        gemm, conv, gsum = B.conv_class_gemm_f16, B.conv_class_conv_f16, B.conv_gather_sum_f16
+    else:
+        gemm, conv, gsum = B.conv_class_gemm, B.conv_class_conv, B.conv_gather_sum
+    y_ref = gsum(gemm(x, w, plan), plan["pos"], nv)
+    g_ref = gsum(gemm(gy, w, plan, weight_transposed=True), plan["pos"], nv)
+    assert torch.equal(conv(x, w, plan), y_ref)
+    assert torch.equal(conv(gy, w, plan, weight_transposed=True), g_ref)
+    # the addend lands in the same store: one more add after the sum over the offsets, as in ts_conv_gather_sum_ex
+    got = conv(gy, w, plan, weight_transposed=True, addend=add_x)
+    zt = gemm(gy, w, plan, weight_transposed=True).float()
+    acc = torch.zeros(nv, ci, device=DEV)
+    for grp_i in range(3):                                      # fp32 sums in group order, the addend last, ONE rounding
+        p = plan["pos"][grp_i].long()
+        acc[p >= 0] += zt[p[p >= 0]]
+    assert torch.equal(acc.to(g_ref.dtype), g_ref)
+    assert torch.equal(got, (acc + add_x.float()).to(g_ref.dtype))
+    with pytest.raises(ValueError):
+        conv(x, w, B.conv_class_plan(km["nbr"][:8].contiguous(), direct=True))
+
+
 def test_class_plan_is_kept_only_while_its_work_stays_near_the_pairs(monkeypatch):
     """KernelMap.build_class_plan reads the plan's (tile, offset) steps and keeps the plan only while 128 * steps stays under
     _CLASS_MAX_WORK x the rulebook's pairs.  Sorting by mask makes that easy to meet - a LiDAR-like surface gives 1.03, even 35 %
@@ -151,7 +203,7 @@ def test_class_plan_is_kept_only_while_its_work_stays_near_the_pairs(monkeypatch
         assert len(c) >= 16384
         km = F.build_kernel_map(_T(c), _T(c), 3, 1)
         plan = km.build_class_plan()
-        tiles, steps = B.conv_class_plan(km.nbr)["n_tiles"].tolist()
+        tiles, steps = B.conv_class_plan(km.nbr)["n_tiles"].tolist()[:2]
         got[name] = (plan is not None, 128 * steps / km.total)
         if plan is not None:
             assert plan["z_rows"] == 128 * tiles and km.class_rows() == 128 * tiles

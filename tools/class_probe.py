@@ -112,8 +112,13 @@ for wt, name, feat, c_out in ((0, "fwd", xf, args.cout), (1, "dgrad", gy, args.c
     e64 = [float((y[sel].double() - ref).abs().max()) / float(ref.abs().max()) for y in (y2, y1)]
     t_a, t_b = timed(two1), timed(lambda: gsum(z, table, n))
     t_c, t_d = timed(go), timed(lambda: gsum(zp, pos, n))
+    conv = B.conv_class_conv_f16 if args.half else B.conv_class_conv
+    yf = conv(feat, w, plan, weight_transposed=bool(wt))
+    t_f = timed(lambda: conv(feat, w, plan, weight_transposed=bool(wt)))
+    same = bool(torch.equal(yf, y1))
     if t_plan is None:
         t_plan = timed(lambda: B.conv_class_plan(nbr))
         print(f"plan build {t_plan:.1f} us (once per batch and stride, staging stream)")
     print(f"{name:6s} two passes {t_a:7.1f} + {t_b:6.1f} = {t_a + t_b:7.1f} us   class-sorted {t_c:7.1f} + {t_d:6.1f} = {t_c + t_d:7.1f} us   "
-          f"ratio {(t_a + t_b) / (t_c + t_d):.2f}x   max |diff| / max |y| {err:.1e}   vs float64: two passes {e64[0]:.1e}, class-sorted {e64[1]:.1e}")
+          f"ratio {(t_a + t_b) / (t_c + t_d):.2f}x   finished in the product {t_f:7.1f} us ({(t_a + t_b) / t_f:.2f}x, same bits: {same})   "
+          f"max |diff| / max |y| {err:.1e}   vs float64: two passes {e64[0]:.1e}, class-sorted {e64[1]:.1e}")
