@@ -619,12 +619,10 @@ int ts_cast_weights_f16_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_
  *     gradient; every fine row has exactly one pair); mirror = 0.  Rows without any neighbour are written as zeros.
  *   ts_conv_class_rows2(n, groups)  m_pad = groups * roundup(n, 128): slots of src / rows of Z' (ts_conv_class_rows: groups = 3)
  *   ts_conv_class_plan      nbr [K][n] -> src [K / groups][m_pad] (input row of (group offset, slot) or -1), tile_info
- *                           [m_pad / 128][2], n_tiles [3] (device: listed tiles; their (tile, offset) steps - 128 * steps
+ *                           [m_pad / 128][2], n_tiles [2] (device: listed tiles, and their (tile, offset) steps - 128 * steps
  *                           row-products against the rulebook's P pairs says what the plan costs: mask-sorted LiDAR rows give
- *                           ~1.1 P, rows with unrelated masks up to 3.7 P; and, three-group plans, how many listed tiles come
- *                           before the centre group's - the list holds the outer groups' tiles first), and exactly one of
- *                           pos [groups][n] (row of Z' per (group, destination) or -1) and rows [m_pad] (destination row per slot
- *                           or -1; groups == 1)
+ *                           ~1.1 P, rows with unrelated masks up to 3.7 P), and exactly one of pos [groups][n] (row of Z' per
+ *                           (group, destination) or -1) and rows [m_pad] (destination row per slot or -1; groups == 1)
  *   ts_conv_nbr_transposed  nbr_t [K][n_in] of a kernel map from its pos_in table and rulebook
  *   ts_conv_class_gemm      wt = 0: feat = input rows, kernel [K, c_red, c_out]; wt = 1: the transposed product (feat = output
  *                           gradients [*, c_red], kernel [K, c_out, c_red] as stored; mirror selects the slice K-1-k);

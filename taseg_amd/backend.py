@@ -981,8 +981,8 @@ def conv_class_plan(nbr, groups=3, direct=False):
     through offset k, or -1): the K offsets in `groups` groups of <= 9, destination rows sorted by their neighbour mask per group.
     groups = 3: submanifold 3x3x3 maps (build_kmap with in == out), pass 2 adds the three group rows through plan["pos"];
     direct (groups = 1): 2x2x2 strided maps, the sums are stored straight into the rows plan["rows"] names - no Z, no pass 2.
-    Returns dict(src [K / groups, m_pad], tile_info [m_pad / 128, 2], n_tiles [3] (device: listed tiles, (tile, offset) steps,
-    tiles listed before the centre group's), pos | rows, m_pad, n, K, groups, mirror).  No host sync."""
+    Returns dict(src [K / groups, m_pad], tile_info [m_pad / 128, 2], n_tiles [2] (device: listed tiles, (tile, offset) steps),
+    pos | rows, m_pad, n, K, groups, mirror).  No host sync."""
     L.require_device(nbr)
     nbr = _i32(nbr, "nbr")
     k, n = nbr.shape
@@ -993,7 +993,7 @@ def conv_class_plan(nbr, groups=3, direct=False):
     dev = nbr.device
     src = torch.empty((k // groups, m_pad), dtype=torch.int32, device=dev)
     tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
-    n_tiles = torch.empty(3, dtype=torch.int32, device=dev)          # (listed tiles, (tile, offset) steps, outer groups' tiles)
+    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)          # (listed tiles, (tile, offset) steps)
     pos = None if direct else torch.empty((groups, n), dtype=torch.int32, device=dev)
     rows = torch.empty(m_pad, dtype=torch.int32, device=dev) if direct else None
     ws = L.workspace(lib.ts_conv_class_plan_workspace_bytes(n), dev)
@@ -1017,7 +1017,7 @@ def conv_class_plan_pairs(nbmaps, nboffs, k, n_pairs):
     dev = nbmaps.device
     src = torch.empty((k, m_pad), dtype=torch.int32, device=dev)
     tile_info = torch.empty((max(m_pad // 128, 1), 2), dtype=torch.int32, device=dev)
-    n_tiles = torch.empty(3, dtype=torch.int32, device=dev)
+    n_tiles = torch.empty(2, dtype=torch.int32, device=dev)
     rows = torch.empty(m_pad, dtype=torch.int32, device=dev)
     ws = L.workspace(4 * (m_pad // 128) + 256, dev)
     L.check(lib.ts_conv_class_plan_pairs(L.ptr(nbmaps), L.ptr(nboffs), k, n, L.ptr(src), L.ptr(tile_info), L.ptr(n_tiles),

@@ -104,40 +104,34 @@ __global__ __launch_bounds__(CG_BM) void class_fill_kernel(const int *__restrict
 // live tiles, longest (most offsets) first: tile_info[t] = (group + 4 * tile, union mask); one workgroup (<= 70k tiles at the
 // 3e6-voxel cap).  The order inside a length class follows the arrival of the LDS atomics - every tile owns its Z' rows, so
 // the order of the list changes the schedule, never a result.  direct: tiles of rows WITHOUT any neighbour are listed too (last,
-// with mask 0): their destination rows must be written (zeros).  gfin >= 0 (three-group plans: the group of the centre offset):
-// the list is cut in two parts - the tiles of the other groups, then the tiles of group gfin, each longest first - and
-// n_tiles[2] = length of the first part (the finish-in-the-product form launches the parts one after the other).
+// with mask 0): their destination rows must be written (zeros).  (A list in two parts - the outer groups' tiles, then the centre
+// group's, for the finish inside the product - cost the ordinary launch 0.1 ms per step: the phases filter the one list instead.)
 __global__ __launch_bounds__(1024) void class_tiles_kernel(const int *__restrict__ tile_mask, int n_all, int64_t npad, int direct,
-                                                           int gfin, int2 *__restrict__ tile_info, int *__restrict__ n_tiles) {
-  constexpr int NB = CG_GK + 1;
-  __shared__ int cnt[2 * NB], base[2 * NB];
-  if (threadIdx.x < 2 * NB) cnt[threadIdx.x] = 0;
+                                                           int2 *__restrict__ tile_info, int *__restrict__ n_tiles) {
+  __shared__ int cnt[CG_GK + 1], base[CG_GK + 1];
+  if (threadIdx.x <= CG_GK) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int tiles_per_group = (int)(npad / CG_BM);
   for (int t = threadIdx.x; t < n_all; t += 1024) {
     const int m = tile_mask[t];
-    if ((m & 511) || (direct && (m >> 30)))
-      atomicAdd(&cnt[(t / tiles_per_group == gfin ? NB : 0) + __builtin_popcount(m & 511)], 1);
+    if ((m & 511) || (direct && (m >> 30))) atomicAdd(&cnt[__builtin_popcount(m & 511)], 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0, steps = 0;
-    for (int part = 0; part < 2; ++part) {
-      for (int c = CG_GK; c >= 0; --c) {
-        base[part * NB + c] = run;
-        run += cnt[part * NB + c];
-        steps += c * cnt[part * NB + c];
-      }
-      if (part == 0) n_tiles[2] = run;
+    for (int c = CG_GK; c >= 0; --c) {
+      base[c] = run;
+      run += cnt[c];
+      steps += c * cnt[c];
     }
     n_tiles[0] = run;
     n_tiles[1] = steps;        // (tile, offset) steps of the plan: 128 * steps row-products against the rulebook's pairs
   }
   __syncthreads();
+  const int tiles_per_group = (int)(npad / CG_BM);
   for (int t = threadIdx.x; t < n_all; t += 1024) {
     const int m = tile_mask[t];
     if ((m & 511) || (direct && (m >> 30))) {
-      const int at = atomicAdd(&base[(t / tiles_per_group == gfin ? NB : 0) + __builtin_popcount(m & 511)], 1);
+      const int at = atomicAdd(&base[__builtin_popcount(m & 511)], 1);
       tile_info[at] = make_int2(t / tiles_per_group + 4 * t, m & 511);
     }
   }
@@ -155,7 +149,7 @@ extern "C" size_t ts_conv_class_plan_workspace_bytes(int64_t n) {
 
 // nbr [K][n] = input row feeding destination row j through offset k, or -1 (ts_build_kmap's `nbr` table; for the transposed
 // direction of a strided map the table of the inverse map) -> src [K / groups][m_pad], tile_info [m_pad / 128] (x, y) pairs,
-// n_tiles [3] = (listed tiles, their (tile, offset) steps, tiles listed before the centre group's), and either pos [groups][n] (pass 2 adds the groups' rows) or - direct
+// n_tiles [2] = (listed tiles, their (tile, offset) steps), and either pos [groups][n] (pass 2 adds the groups' rows) or - direct
 // plans, groups == 1 - rows [m_pad] (destination row of every list slot, -1 = padding);  m_pad = ts_conv_class_rows2(n, groups)
 extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int32_t groups, int32_t *src, int32_t *tile_info,
                                   int32_t *n_tiles, int32_t *pos, int32_t *rows, void *ws, size_t ws_bytes, ts_stream_t stream_) {
@@ -187,8 +181,7 @@ extern "C" int ts_conv_class_plan(const int32_t *nbr, int64_t n, int32_t K, int3
   TS_CHECK_HIP(rocprim::radix_sort_pairs(p, sort_bytes, k0, k1, v0, v1, (size_t)m, 0, 11, stream), "ts_conv_class_plan/sort");
   class_fill_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>(nbr, n, npad, groups, gk, k1, v1, src, pos, rows, tmask);
   TS_CHECK_LAUNCH("ts_conv_class_plan/fill");
-  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), npad, rows ? 1 : 0, groups == CG_GROUPS ? (K / 2) / gk : -1,
-                                         (int2 *)tile_info, n_tiles);
+  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), npad, rows ? 1 : 0, (int2 *)tile_info, n_tiles);
   TS_CHECK_LAUNCH("ts_conv_class_plan/tiles");
   return TS_OK;
 }
@@ -237,7 +230,7 @@ extern "C" int ts_conv_class_plan_pairs(const int32_t *nbmaps, const int32_t *nb
   int *tmask = (int *)ws;
   class_fill_pairs_kernel<<<(unsigned)(m / CG_BM), CG_BM, 0, stream>>>((const int2 *)nbmaps, nboffs, K, n_pairs, m, src, rows, tmask);
   TS_CHECK_LAUNCH("ts_conv_class_plan_pairs/fill");
-  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), m, 1, -1, (int2 *)tile_info, n_tiles);
+  class_tiles_kernel<<<1, 1024, 0, stream>>>(tmask, (int)(m / CG_BM), m, 1, (int2 *)tile_info, n_tiles);
   TS_CHECK_LAUNCH("ts_conv_class_plan_pairs/tiles");
   return TS_OK;
 }
@@ -299,15 +292,16 @@ __device__ __forceinline__ bf8 cg_frag_tr(const unsigned short *img, int pitch, 
   } while (0)
 
 // finish of a three-group plan inside the product (common.h, TsClassFinish): phase 0 = every listed tile, Z' rows (pass 2 follows);
-// phase 1 = the first part of the list (groups without the centre offset), Z' rows; phase 2 = the second part (the centre
-// group: every output row is in exactly one of its tiles), the RESULT rows: out[r] = ((z_0[r] +) own sums (+ z_2[r])) (+ addend[r]),
-// r = the slot's own row (its centre neighbour, offset klc of the group) - pass 2's additions in pass 2's order
+// phase 1 = the tiles of the groups without the centre offset, Z' rows; phase 2 = the tiles of the centre group gfin (every
+// output row is in exactly one of them), the RESULT rows: out[r] = ((z_0[r] +) own sums (+ z_2[r])) (+ addend[r]), r = the slot's
+// own row (its centre neighbour, offset klc of the group) - pass 2's additions in pass 2's order.  Both phases walk the one tile
+// list and skip the other phase's tiles.
 struct CgFinish {
   const int *pos;
   const void *addend;
   void *out;
   int64_t n;
-  int phase, klc;
+  int phase, klc, gfin;
 };
 
 // X [n, R] fp32 rows; W [K, R, O_total] (WT = false: forward) or [K, O_total, R] (WT = true: the input gradient multiplies with
@@ -353,13 +347,10 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
     }
     return;
   }
-  {
-    const int t_all = n_tiles[0], t_cut = fin.phase ? n_tiles[2] : 0;
-    if (fin.phase == 2) tile += t_cut;
-    if (tile >= (fin.phase == 1 ? t_cut : t_all)) return;
-  }
+  if (tile >= *n_tiles) return;
   const int2 info = tile_info[tile];
   const int grp = __builtin_amdgcn_readfirstlane(info.x) & 3;
+  if (fin.phase && (grp == fin.gfin) != (fin.phase == 2)) return;      // the other phase's tile
   int mask = __builtin_amdgcn_readfirstlane(info.y);
   const int64_t row0 = (int64_t)(__builtin_amdgcn_readfirstlane(info.x) >> 2) * BM;
   if (mask == 0) {                              // direct plans: a tile of rows without any neighbour - their result is zero
@@ -576,11 +567,7 @@ struct CgArgs {          // what a class-GEMM launch takes beyond operands and r
   CgFinish fin;          // phase 0: plain launch
   int groups;
 };
-// tiles a launch can meet: all of the list, or - finish inside the product - the non-centre groups (phase 1) / the centre group (2)
-static int64_t cg_tile_bound(const CgArgs &a) {
-  const int64_t all = a.m_pad / CG_BM;
-  return a.fin.phase == 0 ? all : a.fin.phase == 2 ? all / a.groups : all - all / a.groups;
-}
+static int64_t cg_tile_bound(const CgArgs &a) { return a.m_pad / CG_BM; }      // tiles a launch can meet (every phase walks the list)
 
 template <int BN, int WR, bool WT>
 static int launch_class(const float *X, int R, const float *W, int O_total, const CgArgs &a, float *Zp, hipStream_t stream) {
@@ -629,13 +616,13 @@ extern "C" int32_t ts_conv_class_finish_pays(int64_t n, int32_t half) {
 
 // shared by the fp32 and the half entry: the finish descriptor of a call (checked), and the two launches it turns into
 static int cg_finish(const char *what, const TsClassFinish *fin, int K, int groups, const int32_t *rows, CgFinish &out) {
-  out = CgFinish{nullptr, nullptr, nullptr, 0, 0, 0};
+  out = CgFinish{nullptr, nullptr, nullptr, 0, 0, 0, 0};
   if (!fin) return TS_OK;
   TS_REQUIRE(groups == CG_GROUPS && !rows && (K / 2) / (K / groups) == 1, TS_ERR_INVALID_ARGUMENT,
              "%s: the finish inside the product needs a three-group pass-2 plan", what);
   TS_REQUIRE(fin->pos && fin->out && fin->n > 0 && (((uintptr_t)fin->out) & 15) == 0 && (((uintptr_t)fin->addend) & 15) == 0,
              TS_ERR_INVALID_ARGUMENT, "%s: finish: null / misaligned pointer", what);
-  out = CgFinish{fin->pos, fin->addend, fin->out, fin->n, 1, (K / 2) % (K / groups)};
+  out = CgFinish{fin->pos, fin->addend, fin->out, fin->n, 1, (K / 2) % (K / groups), (K / 2) / (K / groups)};
   return TS_OK;
 }
 
@@ -775,11 +762,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
   cur.G = G;
   cur.slot = (int)blockIdx.x;
   cur.round = 0;
-  // the part of the list this launch walks: all of it, or (finish inside the product) the groups without the centre offset /
-  // the centre group
-  const int t_cut = fin.phase ? __builtin_amdgcn_readfirstlane(n_tiles_p[2]) : 0;
-  const int t_base = fin.phase == 2 ? t_cut : 0;
-  cur.n_tiles = (fin.phase == 1 ? t_cut : __builtin_amdgcn_readfirstlane(n_tiles_p[0])) - t_base;
+  cur.n_tiles = __builtin_amdgcn_readfirstlane(*n_tiles_p);
   cur.tile = cur.slot;
   cur.rest = 0;
   cur.row0 = cur.grp = 0;
@@ -787,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
   auto tile_of = [&](int round) { return round * G + ((round & 1) ? G - 1 - cur.slot : cur.slot); };
   auto load_entry = [&](int t) -> int2 {
     int2 e = make_int2(0, 0);
-    if (t < cur.n_tiles) e = tile_info[t_base + t];
+    if (t < cur.n_tiles) e = tile_info[t];
     return make_int2(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y));
   };
   auto zero_tile = [&](int row0) {               // direct plans: a tile of rows without any neighbour - their result is zero
@@ -815,7 +798,8 @@ __global__ __launch_bounds__(256, 2) void class_gemm_h_kernel(
       cur.grp = e.x & 3;
       cur.row0 = (e.x >> 2) * BM;
       cur.rest = e.y;
-      if (cur.rest == 0) zero_tile(cur.row0);
+      if (fin.phase && (cur.grp == fin.gfin) != (fin.phase == 2)) cur.rest = 0;      // the other phase's tile
+      else if (cur.rest == 0) zero_tile(cur.row0);
     }
     st.kl = __builtin_ctz(cur.rest);
     cur.rest &= cur.rest - 1;

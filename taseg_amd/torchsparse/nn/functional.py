@@ -242,7 +242,7 @@ class KernelMap:
             # one host read (the map's builder has just read the pair total the same way): is the plan worth walking?  Rows with
             # LiDAR-like neighbour masks sort into near-uniform tiles (128 * steps ~ 1.1 P); rows with unrelated masks would make
             # every tile walk all nine offsets of its group with most rows absent (up to 3.7 P row-products): two passes then
-            tiles, steps = cls["n_tiles"].tolist()[:2]
+            tiles, steps = cls["n_tiles"].tolist()
             cls["z_rows"], cls["steps"] = 128 * tiles, steps
             cls["map_id"], cls["pairs"] = self.nboffs, self.total          # the identity of the map the plan belongs to
             if 128 * steps <= _CLASS_MAX_WORK * self.total:

@@ -24,8 +24,7 @@ def _T(a):
 @pytest.mark.parametrize("n,extent", [(1, 4), (100, 3), (127, 40), (129, 6), (5000, 14), (40000, 40)])
 def test_class_plan_lists_every_pair_once(n, extent):
     """every (output row, offset) pair of the rulebook appears exactly once in src, at the row pos names; dead rows and the
-    padding carry -1; the tile list holds every tile with a live row (the outer groups' tiles, then the centre group's, each part
-    longest first) with the union of its rows' masks"""
+    padding carry -1; the tile list holds every tile with a live row, longest first, with the union of its rows' masks"""
     from taseg_amd import backend as B
     c = _cloud(n, n, extent)
     offs = O.get_kernel_offsets(3, 1, 1)
@@ -57,10 +56,7 @@ def test_class_plan_lists_every_pair_once(n, extent):
     masks = ((src >= 0).reshape(9, -1, 128).any(2) * (1 << np.arange(9))[:, None]).sum(0)
     assert np.array_equal(info[:, 1], masks[tiles]) and np.array_equal(info[:, 0] & 3, tiles // (m_pad // 3 // 128))
     pop = np.array([bin(int(v)).count("1") for v in info[:, 1]])
-    cut = int(plan["n_tiles"][2])                                                # the outer groups' tiles, then the centre group's
-    assert np.all((info[:cut, 0] & 3) != 1) and np.all((info[cut:, 0] & 3) == 1)
-    for part in (pop[:cut], pop[cut:]):
-        assert np.all(part[:-1] >= part[1:])                                     # each part longest first
+    assert np.all(pop[:-1] >= pop[1:])                                           # longest first
     assert int(plan["n_tiles"][1]) == int(pop.sum())                             # the plan's (tile, offset) steps
 
 
@@ -139,21 +135,16 @@ def test_class_gemm_half_storage(ci, co, n, extent):
 def test_class_conv_finishes_in_the_product_with_the_bits_of_pass_2(ci, co, n, extent, half):
     """ts_conv_class_conv: the centre group's tiles add the outer groups' Z' rows, the addend, and store the result rows - the same
     additions in the same order as ts_conv_class_gemm + ts_conv_gather_sum (+ addend): bit-identical, forward and transposed product,
-    fp32 and half storage; the tile list comes in two parts (outer groups, centre group), each longest first"""
+    fp32 and half storage"""
     from taseg_amd import backend as B
     c = _cloud(5, n, extent)
     offs = O.get_kernel_offsets(3, 1, 1)
     km = B.build_kmap(_T(c), _T(c), _T(offs))
     plan = B.conv_class_plan(km["nbr"])
     nv = len(c)
-    tiles, steps, cut = plan["n_tiles"].tolist()
+    tiles, steps = plan["n_tiles"].tolist()
     info = plan["tile_info"][:tiles].cpu().numpy()
-    grp = info[:, 0] & 3
-    assert 0 < cut < tiles and (grp[:cut] != 1).all() and (grp[cut:] == 1).all()
-    assert tiles - cut == (nv + 127) // 128                                    # every row is in one centre-group tile
-    for part in (info[:cut], info[cut:]):
-        lens = np.array([bin(int(m)).count("1") for m in part[:, 1]])
-        assert (np.diff(lens) <= 0).all()
+    assert int(((info[:, 0] & 3) == 1).sum()) == (nv + 127) // 128            # every row is in one centre-group tile
     rs = np.random.RandomState(3)
     x = _T(rs.randn(nv, ci).astype(np.float32))
     gy = _T(rs.randn(nv, co).astype(np.float32))
@@ -203,7 +194,7 @@ def test_class_plan_is_kept_only_while_its_work_stays_near_the_pairs(monkeypatch
         assert len(c) >= 16384
         km = F.build_kernel_map(_T(c), _T(c), 3, 1)
         plan = km.build_class_plan()
-        tiles, steps = B.conv_class_plan(km.nbr)["n_tiles"].tolist()[:2]
+        tiles, steps = B.conv_class_plan(km.nbr)["n_tiles"].tolist()
         got[name] = (plan is not None, 128 * steps / km.total)
         if plan is not None:
             assert plan["z_rows"] == 128 * tiles and km.class_rows() == 128 * tiles
