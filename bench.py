@@ -127,6 +127,8 @@ def parse():
                     help="azimuth sector of one scan the 1-thread CPU baseline leg runs on (360 = the whole scan, ~15 s per pass)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="timed passes of the 1-thread CPU leg (value = their median)")
     ap.add_argument("--cpu-warmup", type=int, default=1, help="un-timed passes of the 1-thread CPU leg")
+    ap.add_argument("--no-wgrad-tune", action="store_true",
+                    help="skip the timing of the weight gradients on a second stream (TASEG_WGRAD_STREAM=0 / 1 pins the setting)")
     ap.add_argument("--cpu-sector-deg-all", type=float, default=45.0,
                     help="sector of the all-cores leg (the reference's CPU convolution gets SLOWER with threads: its "
                          "OpenMP pragma is on the inner channel loop; 0 = skip the leg)")
@@ -782,6 +784,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # weight gradients on a second stream (csrc/block.hip, taseg_amd/_fast.py): both settings are timed on this model, batch and
+    # machine BEFORE the warm-up (16 steps) and the faster one is kept - like a convolution-algorithm search, outside the contract's
+    # W + K steps.  One process only: the gradient buckets of N > 1 read p.grad while the backward pass is still running.
+    wgrad_side = None
+    if dist is None and flat and not args.no_wgrad_tune:
+        from taseg_amd import _fast
+        wgrad_side = _fast.tune_wgrad_stream(step, fence)
+        if rank == 0:
+            note(f"weight gradients on a second stream: {wgrad_side[0]} (step {wgrad_side[1]} ms without, {wgrad_side[2]} ms with)")
     if rank == 0:
         note(f"{name} {args.workload}: {args.warmup} warm-up + {args.steps} timed steps on {world} rank(s)")
     for i in range(args.warmup):
@@ -849,7 +860,9 @@ def main():
                                    f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
                                    f"bs={args.batch}/GPU, voxel {voxel:g} m, {'AMP fp16' if args.amp else 'fp32'}, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       # chosen by a timing of both settings before the warm-up (None: not applicable / not tuned)
+                       "wgrad_on_second_stream": None if wgrad_side is None else bool(wgrad_side[0])},
             "loss": float(loss.detach()),
             # inside ms_per_step; gradient clipping + SGD (world > 1: + the tail of the bucketed all-reduce it waits for)
             "grad_allreduce": bus,

@@ -498,9 +498,22 @@ typedef struct TsConvBlockOpts {
   const void *planes;
   int32_t w16_current;
   const void *addend;
+  /* backward only: the weight gradient on a second stream.  wgrad_stream != NULL: the gradient w.r.t. the convolution output is
+   * written into wgrad_ws (>= ts_conv_block_wgrad_ws_bytes) instead of the call's own workspace, and the weight gradient - partial
+   * tiles + ordered sum, deterministic as before - is enqueued on wgrad_stream behind an event of the caller's stream; the input
+   * gradient follows on the caller's stream without waiting for it.  wgrad_slot (0 .. 7) names the ring slot wgrad_ws belongs to:
+   * a later call with the same slot first waits (on the caller's stream) for the slot's previous weight gradient.  grad_kernel is
+   * complete on wgrad_stream: the caller joins the streams (ts_stream_join) before it reads the weight gradients. */
+  ts_stream_t wgrad_stream;
+  void *wgrad_ws;
+  size_t wgrad_ws_bytes;
+  int32_t wgrad_slot;
 } TsConvBlockOpts;
 size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
                                      int32_t half);
+size_t ts_conv_block_wgrad_ws_bytes(int64_t n_pairs, int64_t n_out, int32_t c_in, int32_t c_out, int32_t K, int32_t half);
+/* `waiter` waits for everything enqueued on `other` so far (one event; no host synchronisation) */
+int ts_stream_join(ts_stream_t waiter, ts_stream_t other);
 int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
                           const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
                           const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight,

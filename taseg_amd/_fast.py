@@ -33,4 +33,54 @@ def module():
         warnings.warn(f"taseg_amd: native fast path not usable ({e}); using the Python autograd nodes")
         return None
     _mod = mod
+    if os.environ.get("TASEG_WGRAD_STREAM", "0") == "1":
+        wgrad_stream(True)
     return _mod
+
+
+_side = None
+
+
+def wgrad_stream(on):
+    """Weight gradients of the block backward on a second stream (csrc/block.hip, TsConvBlockOpts.wgrad_stream): the node hands
+    every block's weight gradient to one side stream and joins it when the backward pass ends.  TASEG_WGRAD_STREAM=1 switches it
+    on at import; gradient buckets (taseg_amd.parallel.GradBucketReducer) switch it off - their hooks read p.grad mid-pass."""
+    global _side
+    mod = module()
+    if mod is None:
+        return False
+    import torch
+    if on and torch.cuda.is_available():
+        if _side is None:
+            _side = torch.cuda.Stream()
+        mod.set_wgrad_stream(int(_side.cuda_stream), int(_side.stream_id), int(_side.device_index), int(_side.device_type))
+        return True
+    mod.set_wgrad_stream(0, 0, 0, 0)
+    return False
+
+
+def tune_wgrad_stream(step, fence, rounds=2, steps=4):
+    """Time `step()` (one full training step: forward, backward, optimizer) with the weight gradients on the caller's stream and on
+    the second stream - `rounds` alternating rounds of `steps` steps after one unmeasured step each, `fence()` = device (and rank)
+    synchronisation - and keep the faster setting.  The second stream is worth 2-3 % of a device-bound step and costs a host-bound
+    one 10-20 % (four event calls and one more launch per block: profiles/r04_ab_wgrad_stream.txt), which only a measurement on the
+    actual model, batch and machine tells apart.  TASEG_WGRAD_STREAM=0 / 1 pins the setting.  Returns (chosen, ms_off, ms_on)."""
+    import time
+    pinned = os.environ.get("TASEG_WGRAD_STREAM", "auto")
+    if module() is None or pinned in ("0", "1"):
+        return (wgrad_stream(pinned == "1") if module() is not None else False), None, None
+    best = {False: float("inf"), True: float("inf")}
+    for _ in range(rounds):
+        for on in (False, True):
+            if wgrad_stream(on) != on:
+                return False, None, None
+            step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            best[on] = min(best[on], (time.perf_counter() - t0) / steps * 1e3)
+    choice = best[True] < 0.99 * best[False]
+    wgrad_stream(choice)
+    return choice, best[False], best[True]

@@ -28,6 +28,39 @@ extern "C" size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_
   return total;
 }
 
+// the part of the backward call's scratch that the weight gradient on a second stream reads and writes (TsConvBlockOpts):
+// the gradient w.r.t. the convolution output, then the partial tiles
+extern "C" size_t ts_conv_block_wgrad_ws_bytes(int64_t n_pairs, int64_t n_out, int32_t c_in, int32_t c_out, int32_t K, int32_t half) {
+  const size_t es = half ? 2 : 4;
+  return blk_align((size_t)n_out * (size_t)std::max(c_in, c_out) * es) + blk_align(ts_wgrad_partial_bytes(n_pairs, c_in, c_out, K));
+}
+
+extern "C" int ts_stream_join(ts_stream_t waiter, ts_stream_t other) {
+  if (waiter == other) return TS_OK;
+  hipEvent_t ev;
+  TS_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "ts_stream_join: event");
+  TS_CHECK_HIP(hipEventRecord(ev, (hipStream_t)other), "ts_stream_join: record");
+  TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)waiter, ev, 0), "ts_stream_join: wait");
+  TS_CHECK_HIP(hipEventDestroy(ev), "ts_stream_join: destroy");      // released once the wait has completed
+  return TS_OK;
+}
+
+// events of the weight-gradient ring (TsConvBlockOpts.wgrad_slot): ready[s] = the slot's output gradient exists (caller's stream),
+// done[s] = the slot's weight gradient has finished (second stream)
+static hipEvent_t g_wg_ready[8], g_wg_done[8];
+static bool g_wg_used[8] = {false, false, false, false, false, false, false, false};
+static int wg_events() {
+  static bool made = false;
+  if (!made) {
+    for (int i = 0; i < 8; ++i) {
+      TS_CHECK_HIP(hipEventCreateWithFlags(&g_wg_ready[i], hipEventDisableTiming), "weight-gradient ring: event");
+      TS_CHECK_HIP(hipEventCreateWithFlags(&g_wg_done[i], hipEventDisableTiming), "weight-gradient ring: event");
+    }
+    made = true;
+  }
+  return TS_OK;
+}
+
 #define TS_TRY(expr)              \
   do {                            \
     const int rc_ = (expr);       \
@@ -352,6 +385,22 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   if (half) p += blk_align((size_t)K * c_in * c_out * 2);
   void *bn_ws = p;
   const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+  // the weight gradient on a second stream (TsConvBlockOpts): its operands live in the caller's ring slot, not in ws
+  const bool det_ok = grad_kernel && ((int64_t)c_in * c_out) % 4 == 0 && (((uintptr_t)grad_kernel) & 15) == 0 && g_ts_conv_impl != 1;
+  const bool side_on = o.wgrad_stream && o.wgrad_stream != stream && o.wgrad_ws && !comm && det_ok;
+  float *side_part = nullptr;
+  if (side_on) {
+    TS_REQUIRE(o.wgrad_slot >= 0 && o.wgrad_slot < 8 && (((uintptr_t)o.wgrad_ws) & 255) == 0 &&
+                   o.wgrad_ws_bytes >= ts_conv_block_wgrad_ws_bytes(n_pairs, n_out, c_in, c_out, K, half),
+               TS_ERR_INVALID_ARGUMENT, "ts_conv_block_backward: weight-gradient ring slot / scratch");
+    TS_TRY(wg_events());
+    grad_conv = o.wgrad_ws;
+    side_part = (float *)((char *)o.wgrad_ws + blk_align((size_t)n_out * cmax * es));
+    // the slot's previous weight gradient (another layer's) must have read its operands before they are overwritten
+    // (usually long finished: a query is cheaper than a wait in the stream)
+    if (g_wg_used[o.wgrad_slot] && hipEventQuery(g_wg_done[o.wgrad_slot]) != hipSuccess)
+      TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_wg_done[o.wgrad_slot], 0), "ring wait");
+  }
   if (comm) {
     TS_TRY(ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums,
                                grad_conv, grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));
@@ -369,10 +418,15 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   // finishes the input gradient (pass 2, or the direct class GEMM) - no reduce launch, no fill of grad_kernel, no float
   // atomics.  A block without an input gradient (the first layer) sums with a launch of its own.
   const double es_d = half ? 2 : 4;
-  float *part = (float *)(((char *)bn_ws) + blk_align(bn_ws_bytes));
-  const bool det = grad_kernel && ((int64_t)c_in * c_out) % 4 == 0 && (((uintptr_t)grad_kernel) & 15) == 0 &&
-                   g_ts_conv_impl != 1;
+  float *part = side_on ? side_part : (float *)(((char *)bn_ws) + blk_align(bn_ws_bytes));
+  const bool det = det_ok;
   TsWgradReduce job = {};
+  const ts_stream_t main_stream = stream;
+  if (side_on) {                         // from here to the end of the weight gradient: the second stream
+    TS_CHECK_HIP(hipEventRecord(g_wg_ready[o.wgrad_slot], (hipStream_t)main_stream), "ring record");
+    TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)o.wgrad_stream, g_wg_ready[o.wgrad_slot], 0), "ring wait");
+    stream = o.wgrad_stream;
+  }
   if (grad_kernel) {
     ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, (double)n_out);
     if (det) g_ts_wgrad_part = part;
@@ -387,7 +441,14 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     if (rc != TS_OK) return rc;
     if (det) job = TsWgradReduce{part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
   }
-  const bool ride = det && grad_feat && n_dgrad_rows > 0;
+  if (side_on) {                         // the ordered sum follows on the second stream; the slot is free when it has run
+    // (blocks without an input gradient sum with the stand-alone kernel's order on either path)
+    TS_TRY((grad_feat && n_dgrad_rows > 0) ? ts_wgrad_reduce_seq(job, stream) : ts_wgrad_reduce(job, stream));
+    TS_CHECK_HIP(hipEventRecord(g_wg_done[o.wgrad_slot], (hipStream_t)stream), "ring record");
+    g_wg_used[o.wgrad_slot] = true;
+    stream = main_stream;
+  }
+  const bool ride = det && grad_feat && n_dgrad_rows > 0 && !side_on;
   const TsClassPlan *cp = (grad_feat && plan_fits(o.dgrad_plan, K, n_dgrad_rows, c_out, c_in, n_pairs, nboffs) &&
                            !(o.dgrad_plan->rows && addend))
                               ? o.dgrad_plan
@@ -445,6 +506,6 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                      ride ? &job : nullptr, (const float *)addend, stream));
     }
   }
-  if (det && !ride) TS_TRY(ts_wgrad_reduce(job, stream));
+  if (det && !ride && !side_on) TS_TRY(ts_wgrad_reduce(job, stream));
   return TS_OK;
 }

@@ -187,6 +187,7 @@ struct TsWgradReduce {       // everything the ordered sum needs (by value into 
 extern thread_local float *g_ts_wgrad_part;    // != nullptr: the next weight-gradient launch stores partial tiles here
 extern thread_local TsWgradPlan g_ts_wgrad_plan;   // ... and leaves the plan it used here
 int ts_wgrad_reduce(const TsWgradReduce &job, ts_stream_t stream);
+int ts_wgrad_reduce_seq(const TsWgradReduce &job, ts_stream_t stream);   // ... in the riding form's order (chunk after chunk)
 size_t ts_wgrad_partial_bytes(int64_t n_pairs, int32_t c_a, int32_t c_b, int32_t K);
 
 __device__ __forceinline__ void ts_wgrad_reduce_one(const TsWgradReduce &job, int64_t i) {

@@ -1383,6 +1383,20 @@ int ts_wgrad_reduce(const TsWgradReduce &job, ts_stream_t stream_) {
   return TS_OK;
 }
 
+// The ordered sum in the order of the form that rides on another launch (ts_wgrad_reduce_one: chunk after chunk), as a launch of its
+// own: what the weight gradient on a second stream uses, so that it leaves the bits of the riding form.
+__global__ __launch_bounds__(256) void wgrad_reduce_seq_kernel(TsWgradReduce job) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (int64_t)job.K * job.cacb4) ts_wgrad_reduce_one(job, i);
+}
+int ts_wgrad_reduce_seq(const TsWgradReduce &job, ts_stream_t stream_) {
+  const int64_t n = (int64_t)job.K * job.cacb4;
+  if (n == 0) return TS_OK;
+  wgrad_reduce_seq_kernel<<<(unsigned)ts_cdiv(n, 256), 256, 0, (hipStream_t)stream_>>>(job);
+  TS_CHECK_LAUNCH("wgrad_reduce (chunk order)");
+  return TS_OK;
+}
+
 // bytes of the partial buffer of a deterministic weight gradient: an upper bound over the tilings the launchers pick
 // (the chunk length grows with the tile count, so one tile gives the most chunks; every kernel family steps by 32 pairs
 // and caps chunks at 1024)

@@ -6,9 +6,12 @@
 // bookkeeping and argument marshalling around ~25 us of launches.  PyTorch supplies memory, streams and the autograd
 // graph only.
 #include <dlfcn.h>
+#include <c10/core/Stream.h>
+#include <torch/csrc/autograd/engine.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -22,6 +25,8 @@ struct Api {
   decltype(&ts_conv_block_forward) forward = nullptr;
   decltype(&ts_conv_block_backward) backward = nullptr;
   decltype(&ts_conv_block_eval) eval = nullptr;
+  decltype(&ts_conv_block_wgrad_ws_bytes) wgrad_ws_bytes = nullptr;
+  decltype(&ts_stream_join) stream_join = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
@@ -51,6 +56,33 @@ at::Tensor workspace(size_t nbytes, const at::Tensor &like, int64_t stream) {
     it = ws_pool.find(key);
   }
   return it->second;
+}
+
+// Weight gradients on a second stream (TsConvBlockOpts.wgrad_stream, csrc/block.hip): per device one stream from torch's pool and
+// a ring of scratch buffers, one per slot, that hold the output gradient and the partial tiles of the layer the slot was last given
+// to; the backend orders the ring with events.  The gradients are complete on the second stream: a callback queued on the autograd
+// engine joins it into the node's stream when the backward pass ends (every consumer of p.grad comes after that).  Off unless
+// set_wgrad_stream(true) (taseg_amd.fast: TASEG_WGRAD_STREAM; never with gradient buckets, whose hooks read p.grad mid-pass).
+constexpr int WG_SLOTS = 8;
+struct WgSide {
+  bool on = false;
+  int64_t raw = 0;                       // hipStream_t of the second stream (torch.cuda.Stream.cuda_stream)
+  int64_t stream_id = 0, device_index = 0, device_type = 0;   // ... and what c10::Stream::unpack3 rebuilds it from (record_stream)
+  at::Tensor ring[WG_SLOTS];
+  int next = 0;
+};
+std::mutex wg_mutex;
+WgSide wg_side;
+std::atomic<bool> wg_join_queued{false};
+
+// raw == 0 switches the second stream off
+void set_wgrad_stream(int64_t raw, int64_t stream_id, int64_t device_index, int64_t device_type) {
+  std::lock_guard<std::mutex> lock(wg_mutex);
+  wg_side.on = raw != 0;
+  wg_side.raw = raw;
+  wg_side.stream_id = stream_id;
+  wg_side.device_index = device_index;
+  wg_side.device_type = device_type;
 }
 
 // SyncBatchNorm over torch.distributed: process groups registered from Python (register_group), addressed by index.  The
@@ -152,7 +184,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     // everything the call may use beyond the rulebook, explicitly (TsConvBlockOpts): the class plans of this block's kernel map
     // (csrc/conv_class.hip), the pre-split planes / the kept half copy of the weight
     const PlanRef pf(plan_f, plan_f_meta, nboffs);
-    TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr};
+    TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0};
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
@@ -235,7 +267,32 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const std::vector<at::Tensor> plan_d = ctx->saved_data["plan_d"].toTensorVector();
     const std::vector<int64_t> plan_d_meta = ctx->saved_data["plan_d_meta"].toIntVector();
     const PlanRef pd(grad_feat.defined() ? plan_d : std::vector<at::Tensor>(), plan_d_meta, nboffs);
-    TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr};
+    TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
+    if (wg_side.on && grad_w.defined() && !comm && !split && x.get_device() == wg_side.device_index && stream != wg_side.raw) {
+      std::lock_guard<std::mutex> lock(wg_mutex);
+      WgSide &sd = wg_side;
+      const size_t need = api.wgrad_ws_bytes(total, rows, (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
+      const int slot = sd.next;
+      sd.next = (sd.next + 1) % WG_SLOTS;
+      if (!sd.ring[slot].defined() || (size_t)sd.ring[slot].numel() < need)
+        sd.ring[slot] = at::empty({(int64_t)(need * 1.25) + 256}, x.options().dtype(at::kByte));
+      bopts.wgrad_stream = (ts_stream_t)sd.raw;
+      bopts.wgrad_ws = sd.ring[slot].data_ptr();
+      bopts.wgrad_ws_bytes = (size_t)sd.ring[slot].numel();
+      bopts.wgrad_slot = slot;
+      // the second stream reads x and writes grad_w: the allocator must not hand their memory out again before it has
+      const c10::Stream side = c10::Stream::unpack3(sd.stream_id, (c10::DeviceIndex)sd.device_index, (c10::DeviceType)sd.device_type);
+      x.record_stream(side);
+      grad_w.record_stream(side);
+      if (!wg_join_queued.exchange(true)) {
+        const ts_stream_t side_raw = bopts.wgrad_stream;
+        const int64_t main_raw = stream;
+        torch::autograd::Engine::get_default_engine().queue_callback([side_raw, main_raw]() {
+          wg_join_queued = false;
+          check(api.stream_join((ts_stream_t)main_raw, side_raw), "ts_stream_join");
+        });
+      }
+    }
     auto call = [&](void *c) {
       check(api.backward(g.data_ptr(), (const uint8_t *)ptr(mask), conv_out.data_ptr(), st, st + c_out,
                          (const float *)bn_weight.data_ptr(), pack.defined() ? pack.data_ptr<double>() + 2 * c_out : nullptr,
@@ -281,6 +338,8 @@ void load_backend(const std::string &libpath) {
 #define TS_BIND(field, sym)                                      \
   api.field = (decltype(api.field))dlsym(h, sym);                \
   TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
+  TS_BIND(wgrad_ws_bytes, "ts_conv_block_wgrad_ws_bytes");
+  TS_BIND(stream_join, "ts_stream_join");
   TS_BIND(downsample_ws, "ts_downsample_workspace_bytes");
   TS_BIND(downsample, "ts_downsample");
   TS_BIND(build_kmap_ws, "ts_build_kmap_workspace_bytes");
@@ -342,7 +401,7 @@ at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, co
   const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
   at::Tensor ws = workspace(nb, x, stream);
   const PlanRef pf(plan_f, plan_f_meta, nboffs);
-  TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr};
+  TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0};
   check(api.eval(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
                  (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0, (const int32_t *)table.data_ptr(), rows,
                  (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(), (const float *)bn_bias.data_ptr(),
@@ -514,6 +573,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");
   m.def("conv_block", &conv_block, "act(BN(conv(x)) [+ residual]) as one native autograd node");
   m.def("conv_block_eval", &conv_block_eval, "act(BN_eval(conv(x)) [+ residual]) on the running statistics, no graph");
+  m.def("set_wgrad_stream", &set_wgrad_stream, "weight gradients of conv_block's backward on a second stream (joined at the end of the pass)");
   m.def("register_group", &register_group, "process group -> id for conv_block's c10d SyncBatchNorm path");
   m.def("clear_groups", &clear_groups, "drop the registered process groups (before destroy_process_group)");
 }

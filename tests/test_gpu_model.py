@@ -695,3 +695,45 @@ def test_block_call_options_are_explicit_and_checked(monkeypatch):
     assert not torch.equal(own[0], base[0])                              # (c): the class path ran ...
     for a, b in zip(own, base):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))       # ... and computes the same block
+
+
+def test_weight_gradients_on_a_second_stream_give_the_same_bits():
+    """TsConvBlockOpts.wgrad_stream (csrc/block.hip, taseg_amd/_fast.py): the weight gradient of every block on a side stream behind
+    an event, its operands in a ring of scratch slots, one join when the backward pass ends - three optimizer steps with it leave
+    the same parameters, bit for bit, as three steps without (fp32 and autocast; the deterministic partial-tile sum either way)"""
+    from taseg_amd import _fast
+    from taseg_amd.optim import FlatSGD
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    if _fast.module() is None:
+        pytest.skip("native block node not built")
+    import bench
+    DEV = "cuda"
+    coords, feats, labels, _ = bench.make_scans(3, 2, 20000, "minkunet")
+    offset = torch.tensor([len(coords)], device=DEV, dtype=torch.int32)
+
+    def run(side, amp):
+        torch.manual_seed(0)
+        cfg = make_model_cfg("MinkUNet", in_dim=4, cr=0.5)
+        model = build_network(cfg, 20).to(DEV).train()
+        opt = FlatSGD(model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=10.0, amp=amp)
+        assert _fast.wgrad_stream(side) == side
+        try:
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                    ret, _, _ = model({"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset})
+                (ret["loss"].float().mean() * opt.loss_scale()).backward()
+                opt.step()
+                losses.append(float(ret["loss"]))
+            torch.cuda.synchronize()
+        finally:
+            _fast.wgrad_stream(False)
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    for amp in (False, True):
+        l0, p0 = run(False, amp)
+        l1, p1 = run(True, amp)
+        assert l0 == l1
+        assert all(torch.equal(a, b) for a, b in zip(p0, p1))
