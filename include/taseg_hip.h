@@ -508,12 +508,21 @@ typedef struct TsConvBlockOpts {
   void *wgrad_ws;
   size_t wgrad_ws_bytes;
   int32_t wgrad_slot;
+  /* wgrad_deferred != 0: the call only marks the point on its stream where the output gradient exists and leaves the weight
+   * gradient to a ts_conv_block_wgrad_side call with the same arguments - from any host thread, so that its launches need not
+   * come from the thread that issues the step */
+  int32_t wgrad_deferred;
 } TsConvBlockOpts;
 size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
                                      int32_t half);
 size_t ts_conv_block_wgrad_ws_bytes(int64_t n_pairs, int64_t n_out, int32_t c_in, int32_t c_out, int32_t K, int32_t half);
 /* `waiter` waits for everything enqueued on `other` so far (one event; no host synchronisation) */
 int ts_stream_join(ts_stream_t waiter, ts_stream_t other);
+int ts_conv_block_wgrad_side(const void *feat, int64_t n_feat_rows, int32_t c_in, int32_t K, const int32_t *nbmaps,
+                             const int32_t *nboffs, int64_t n_pairs, int32_t wgrad_col_a, int64_t n_out, int32_t c_out, int32_t half,
+                             float *grad_kernel, int32_t chunk_order, void *wgrad_ws, size_t wgrad_ws_bytes, int32_t slot,
+                             ts_stream_t side_stream);
+int ts_set_device(int32_t device);      /* hipSetDevice for a host thread the caller created */
 int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
                           const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
                           const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight,

@@ -62,9 +62,9 @@ def wgrad_stream(on):
 def tune_wgrad_stream(step, fence, rounds=2, steps=4):
     """Time `step()` (one full training step: forward, backward, optimizer) with the weight gradients on the caller's stream and on
     the second stream - `rounds` alternating rounds of `steps` steps after one unmeasured step each, `fence()` = device (and rank)
-    synchronisation - and keep the faster setting.  The second stream is worth 2-3 % of a device-bound step and costs a host-bound
-    one 10-20 % (four event calls and one more launch per block: profiles/r04_ab_wgrad_stream.txt), which only a measurement on the
-    actual model, batch and machine tells apart.  TASEG_WGRAD_STREAM=0 / 1 pins the setting.  Returns (chosen, ms_off, ms_on)."""
+    synchronisation - and keep the faster setting.  The second stream is worth 2-4 % of a device-bound step; a host-bound one gains
+    nothing from it and, before the launches moved to a thread of their own, lost 10-20 % to the event calls
+    (profiles/r04_ab_wgrad_stream.txt) - only a measurement on the actual model, batch and machine tells the cases apart.  TASEG_WGRAD_STREAM=0 / 1 pins the setting.  Returns (chosen, ms_off, ms_on)."""
     import time
     pinned = os.environ.get("TASEG_WGRAD_STREAM", "auto")
     if module() is None or pinned in ("0", "1"):

@@ -103,6 +103,8 @@ SIGNATURES = {
     "ts_conv_block_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "ts_conv_block_wgrad_ws_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "ts_stream_join": (_i32, [_vp, _vp]),
+    "ts_conv_block_wgrad_side": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
+    "ts_set_device": (_i32, [_i32]),
     "ts_conv_block_forward": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),
@@ -166,7 +168,7 @@ class TsConvBlockOpts(_c.Structure):
     """include/taseg_hip.h: what a ts_conv_block_* call may use beyond the rulebook"""
     _fields_ = [("fwd_plan", _c.POINTER(TsClassPlan)), ("dgrad_plan", _c.POINTER(TsClassPlan)), ("planes", _vp),
                 ("w16_current", _i32), ("addend", _vp), ("wgrad_stream", _vp), ("wgrad_ws", _vp), ("wgrad_ws_bytes", _sz),
-                ("wgrad_slot", _i32)]
+                ("wgrad_slot", _i32), ("wgrad_deferred", _i32)]
 
 
 _lib = None

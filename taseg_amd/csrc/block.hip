@@ -9,6 +9,10 @@
 // caller's workspace.  What they remove is host work: the step of a 2-scan batch is ~1200 launches, and with one
 // Python -> C crossing and one autograd node per block instead of four / two the host side of the step drops below
 // the device side on slow hosts too.
+#include <sched.h>
+
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -48,7 +52,8 @@ extern "C" int ts_stream_join(ts_stream_t waiter, ts_stream_t other) {
 // events of the weight-gradient ring (TsConvBlockOpts.wgrad_slot): ready[s] = the slot's output gradient exists (caller's stream),
 // done[s] = the slot's weight gradient has finished (second stream)
 static hipEvent_t g_wg_ready[8], g_wg_done[8];
-static bool g_wg_used[8] = {false, false, false, false, false, false, false, false};
+static std::atomic<bool> g_wg_used[8];          // done[s] has been recorded at least once
+static std::atomic<int> g_wg_owed[8];           // deferred form: the slot's weight gradient has been promised but not enqueued yet
 static int wg_events() {
   static bool made = false;
   if (!made) {
@@ -83,8 +88,10 @@ struct ProfRec {
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
 bool g_prof_on = false;
+std::mutex g_prof_mutex;          // the weight gradients may be launched by a second host thread (ts_conv_block_wgrad_side)
 
 hipEvent_t prof_event() {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (!g_prof_pool.empty()) {
     hipEvent_t e = g_prof_pool.back();
     g_prof_pool.pop_back();
@@ -111,7 +118,10 @@ struct ProfScope {
     live = hipEventRecord(rec.e0, stream) == hipSuccess;
   }
   ~ProfScope() {
-    if (live && hipEventRecord(rec.e1, stream) == hipSuccess) g_prof.push_back(rec);
+    if (live && hipEventRecord(rec.e1, stream) == hipSuccess) {
+      std::lock_guard<std::mutex> lock(g_prof_mutex);
+      g_prof.push_back(rec);
+    }
   }
 };
 }  // namespace
@@ -121,6 +131,7 @@ extern "C" void ts_prof_enable(int32_t on) { g_prof_on = on != 0; }
 // create `n_events` events ahead of time (hipEventCreate costs ~15 us; the pool otherwise grows inside the first
 // recorded steps)
 extern "C" int ts_prof_reserve(int64_t n_events) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   while ((int64_t)g_prof_pool.size() < n_events) {
     hipEvent_t e = nullptr;
     TS_CHECK_HIP(hipEventCreate(&e), "hipEventCreate");
@@ -131,6 +142,7 @@ extern "C" int ts_prof_reserve(int64_t n_events) {
 
 // records [capacity][9] doubles out; returns the number of records written (and forgets them), or -1 on a HIP error
 extern "C" int64_t ts_prof_collect(double *records, int64_t capacity) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   int64_t n = 0;
   for (const ProfRec &r : g_prof) {
     float ms = 0.f;
@@ -397,8 +409,15 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     grad_conv = o.wgrad_ws;
     side_part = (float *)((char *)o.wgrad_ws + blk_align((size_t)n_out * cmax * es));
     // the slot's previous weight gradient (another layer's) must have read its operands before they are overwritten
+    // deferred form: until the slot's last weight gradient has been ENQUEUED (by the caller's other thread) its done event says
+    // nothing - wait for that on the host (bounded; normally it happened several blocks ago)
+    for (int spin = 0; g_wg_owed[o.wgrad_slot].load(std::memory_order_acquire) != 0; ++spin) {
+      TS_REQUIRE(spin < 20000000, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_backward: the deferred weight gradient of ring slot %d was never launched",
+                 o.wgrad_slot);
+      if (spin > 64) sched_yield();
+    }
     // (usually long finished: a query is cheaper than a wait in the stream)
-    if (g_wg_used[o.wgrad_slot] && hipEventQuery(g_wg_done[o.wgrad_slot]) != hipSuccess)
+    if (g_wg_used[o.wgrad_slot].load() && hipEventQuery(g_wg_done[o.wgrad_slot]) != hipSuccess)
       TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_wg_done[o.wgrad_slot], 0), "ring wait");
   }
   if (comm) {
@@ -422,12 +441,17 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   const bool det = det_ok;
   TsWgradReduce job = {};
   const ts_stream_t main_stream = stream;
+  const bool deferred = side_on && o.wgrad_deferred;
   if (side_on) {                         // from here to the end of the weight gradient: the second stream
     TS_CHECK_HIP(hipEventRecord(g_wg_ready[o.wgrad_slot], (hipStream_t)main_stream), "ring record");
-    TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)o.wgrad_stream, g_wg_ready[o.wgrad_slot], 0), "ring wait");
-    stream = o.wgrad_stream;
+    if (deferred) {
+      g_wg_owed[o.wgrad_slot].store(1, std::memory_order_release);      // the caller launches it: ts_conv_block_wgrad_side
+    } else {
+      TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)o.wgrad_stream, g_wg_ready[o.wgrad_slot], 0), "ring wait");
+      stream = o.wgrad_stream;
+    }
   }
-  if (grad_kernel) {
+  if (grad_kernel && !deferred) {
     ProfScope ps(2, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, es_d, (double)n_out);
     if (det) g_ts_wgrad_part = part;
     int rc;
@@ -441,11 +465,11 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     if (rc != TS_OK) return rc;
     if (det) job = TsWgradReduce{part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
   }
-  if (side_on) {                         // the ordered sum follows on the second stream; the slot is free when it has run
+  if (side_on && !deferred) {            // the ordered sum follows on the second stream; the slot is free when it has run
     // (blocks without an input gradient sum with the stand-alone kernel's order on either path)
     TS_TRY((grad_feat && n_dgrad_rows > 0) ? ts_wgrad_reduce_seq(job, stream) : ts_wgrad_reduce(job, stream));
     TS_CHECK_HIP(hipEventRecord(g_wg_done[o.wgrad_slot], (hipStream_t)stream), "ring record");
-    g_wg_used[o.wgrad_slot] = true;
+    g_wg_used[o.wgrad_slot].store(true);
     stream = main_stream;
   }
   const bool ride = det && grad_feat && n_dgrad_rows > 0 && !side_on;
@@ -507,5 +531,47 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
     }
   }
   if (det && !ride && !side_on) TS_TRY(ts_wgrad_reduce(job, stream));
+  return TS_OK;
+}
+
+// The weight gradient a ts_conv_block_backward call with opts->wgrad_deferred left out: waits (on side_stream) for the ring slot's
+// output gradient, launches the partial tiles and their ordered sum there, marks the slot.  May be called from another host thread
+// than the backward call (that is the point: the launches leave the thread that issues the step); the arguments are the backward
+// call's own.  chunk_order: the backward call had an input gradient (the ordered sum then keeps the order of the riding form).
+extern "C" int ts_conv_block_wgrad_side(const void *feat, int64_t n_feat_rows, int32_t c_in, int32_t K, const int32_t *nbmaps,
+                                        const int32_t *nboffs, int64_t n_pairs, int32_t wgrad_col_a, int64_t n_out, int32_t c_out,
+                                        int32_t half, float *grad_kernel, int32_t chunk_order, void *wgrad_ws, size_t wgrad_ws_bytes,
+                                        int32_t slot, ts_stream_t side_stream) {
+  TS_REQUIRE(slot >= 0 && slot < 8 && wgrad_ws && grad_kernel && feat && side_stream &&
+                 wgrad_ws_bytes >= ts_conv_block_wgrad_ws_bytes(n_pairs, n_out, c_in, c_out, K, half),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_block_wgrad_side: bad arguments");
+  const size_t es = half ? 2 : 4;
+  const size_t cmax = (size_t)std::max(c_in, c_out);
+  const void *grad_conv = wgrad_ws;
+  float *part = (float *)((char *)wgrad_ws + blk_align((size_t)n_out * cmax * es));
+  int rc = TS_OK;
+  {
+    TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, g_wg_ready[slot], 0), "ring wait");
+    ProfScope ps(2, side_stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, half ? 2.0 : 4.0, (double)n_out);
+    g_ts_wgrad_part = part;
+    if (half)
+      rc = ts_conv_wgrad_f16_ex(feat, c_in, grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs, grad_kernel, 1, side_stream);
+    else
+      rc = ts_conv_wgrad_ex((const float *)feat, c_in, (const float *)grad_conv, c_out, nbmaps, nboffs, K, wgrad_col_a, n_pairs,
+                            grad_kernel, 1, side_stream);
+    g_ts_wgrad_part = nullptr;
+  }
+  if (rc == TS_OK) {
+    const TsWgradReduce job = {part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
+    rc = chunk_order ? ts_wgrad_reduce_seq(job, side_stream) : ts_wgrad_reduce(job, side_stream);
+  }
+  if (hipEventRecord(g_wg_done[slot], (hipStream_t)side_stream) != hipSuccess && rc == TS_OK) rc = TS_ERR_LAUNCH_FAILED;
+  g_wg_used[slot].store(true);
+  g_wg_owed[slot].store(0, std::memory_order_release);
+  return rc;
+}
+
+extern "C" int ts_set_device(int32_t device) {
+  TS_CHECK_HIP(hipSetDevice(device), "ts_set_device");
   return TS_OK;
 }

@@ -12,7 +12,11 @@
 #include <torch/extension.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 #include "taseg_hip.h"
@@ -27,6 +31,8 @@ struct Api {
   decltype(&ts_conv_block_eval) eval = nullptr;
   decltype(&ts_conv_block_wgrad_ws_bytes) wgrad_ws_bytes = nullptr;
   decltype(&ts_stream_join) stream_join = nullptr;
+  decltype(&ts_conv_block_wgrad_side) wgrad_side = nullptr;
+  decltype(&ts_set_device) set_device = nullptr;
   decltype(&ts_last_error) last_error = nullptr;
   decltype(&ts_downsample_workspace_bytes) downsample_ws = nullptr;
   decltype(&ts_downsample) downsample = nullptr;
@@ -75,14 +81,86 @@ std::mutex wg_mutex;
 WgSide wg_side;
 std::atomic<bool> wg_join_queued{false};
 
+// The launches of the second stream come from a thread of their own: the node's thread only marks the point where a block's
+// output gradient exists (one event record inside ts_conv_block_backward) and queues the rest - wait for that event, partial
+// tiles, ordered sum, the slot's done event: ts_conv_block_wgrad_side - here.  A job keeps the tensors it reads and writes alive
+// until it has been enqueued (record_stream covers them from then on).
+struct WgWorker {
+  std::mutex m;
+  std::condition_variable cv, idle;
+  std::deque<std::function<void()>> q;
+  int busy = 0;
+  bool stop = false, started = false;
+  std::string error;
+  std::thread th;
+  void start(int device) {
+    if (started) return;
+    started = true;
+    th = std::thread([this, device] {
+      if (api.set_device) api.set_device(device);
+      for (;;) {
+        std::function<void()> job;
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [this] { return stop || !q.empty(); });
+          if (q.empty()) return;
+          job = std::move(q.front());
+          q.pop_front();
+          busy = 1;
+        }
+        try {
+          job();
+        } catch (const std::exception &e) {
+          std::lock_guard<std::mutex> lk(m);
+          if (error.empty()) error = e.what();
+        }
+        job = nullptr;                   // (drops the tensors it held)
+        {
+          std::lock_guard<std::mutex> lk(m);
+          busy = 0;
+          if (q.empty()) idle.notify_all();
+        }
+      }
+    });
+  }
+  void push(std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      q.push_back(std::move(job));
+    }
+    cv.notify_one();
+  }
+  void drain() {                         // every queued launch has been enqueued on the second stream
+    std::unique_lock<std::mutex> lk(m);
+    idle.wait(lk, [this] { return q.empty() && busy == 0; });
+    if (!error.empty()) {
+      const std::string e = error;
+      error.clear();
+      TORCH_CHECK(false, "conv_block: weight gradient on the second stream: ", e);
+    }
+  }
+  ~WgWorker() {
+    if (!started) return;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+WgWorker wg_worker;
+
 // raw == 0 switches the second stream off
 void set_wgrad_stream(int64_t raw, int64_t stream_id, int64_t device_index, int64_t device_type) {
+  if (wg_worker.started) wg_worker.drain();
   std::lock_guard<std::mutex> lock(wg_mutex);
   wg_side.on = raw != 0;
   wg_side.raw = raw;
   wg_side.stream_id = stream_id;
   wg_side.device_index = device_index;
   wg_side.device_type = device_type;
+  if (wg_side.on) wg_worker.start((int)device_index);
 }
 
 // SyncBatchNorm over torch.distributed: process groups registered from Python (register_group), addressed by index.  The
@@ -184,7 +262,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     // everything the call may use beyond the rulebook, explicitly (TsConvBlockOpts): the class plans of this block's kernel map
     // (csrc/conv_class.hip), the pre-split planes / the kept half copy of the weight
     const PlanRef pf(plan_f, plan_f_meta, nboffs);
-    TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0};
+    TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0};
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
@@ -267,28 +345,49 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const std::vector<at::Tensor> plan_d = ctx->saved_data["plan_d"].toTensorVector();
     const std::vector<int64_t> plan_d_meta = ctx->saved_data["plan_d_meta"].toIntVector();
     const PlanRef pd(grad_feat.defined() ? plan_d : std::vector<at::Tensor>(), plan_d_meta, nboffs);
-    TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
+    TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0};
+    std::function<void()> side_job;
     if (wg_side.on && grad_w.defined() && !comm && !split && x.get_device() == wg_side.device_index && stream != wg_side.raw) {
       std::lock_guard<std::mutex> lock(wg_mutex);
       WgSide &sd = wg_side;
       const size_t need = api.wgrad_ws_bytes(total, rows, (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
       const int slot = sd.next;
       sd.next = (sd.next + 1) % WG_SLOTS;
-      if (!sd.ring[slot].defined() || (size_t)sd.ring[slot].numel() < need)
+      if (!sd.ring[slot].defined() || (size_t)sd.ring[slot].numel() < need) {
+        wg_worker.drain();               // (a queued job may still point into the old buffer)
         sd.ring[slot] = at::empty({(int64_t)(need * 1.25) + 256}, x.options().dtype(at::kByte));
+        sd.ring[slot].record_stream(c10::Stream::unpack3(sd.stream_id, (c10::DeviceIndex)sd.device_index, (c10::DeviceType)sd.device_type));
+      }
       bopts.wgrad_stream = (ts_stream_t)sd.raw;
       bopts.wgrad_ws = sd.ring[slot].data_ptr();
       bopts.wgrad_ws_bytes = (size_t)sd.ring[slot].numel();
       bopts.wgrad_slot = slot;
+      bopts.wgrad_deferred = 1;
       // the second stream reads x and writes grad_w: the allocator must not hand their memory out again before it has
       const c10::Stream side = c10::Stream::unpack3(sd.stream_id, (c10::DeviceIndex)sd.device_index, (c10::DeviceType)sd.device_type);
       x.record_stream(side);
       grad_w.record_stream(side);
+      {
+        // (grad_w by address only: one more owner and autograd's AccumulateGrad would copy the gradient - before it exists -
+        // instead of adopting the tensor as p.grad; the memory lives on as p.grad or as the bucket slot it aliases)
+        const at::Tensor xk = x, nbk = nbmaps, nok = nboffs, ringk = sd.ring[slot];
+        float *const gw_ptr = (float *)grad_w.data_ptr();
+        const ts_stream_t side_raw = bopts.wgrad_stream;
+        const int64_t n_feat = x.size(0);
+        const int32_t col_a = transposed ? 1 : 0, chunk_order = grad_feat.defined() && drows > 0 ? 1 : 0;
+        side_job = [=]() {
+          check(api.wgrad_side(xk.data_ptr(), n_feat, (int32_t)c_in, (int32_t)k, (const int32_t *)nbk.data_ptr(),
+                               (const int32_t *)nok.data_ptr(), total, col_a, rows, (int32_t)c_out, half ? 1 : 0,
+                               gw_ptr, chunk_order, ringk.data_ptr(), (size_t)ringk.numel(), slot, side_raw),
+                "ts_conv_block_wgrad_side");
+        };
+      }
       if (!wg_join_queued.exchange(true)) {
         const ts_stream_t side_raw = bopts.wgrad_stream;
         const int64_t main_raw = stream;
         torch::autograd::Engine::get_default_engine().queue_callback([side_raw, main_raw]() {
           wg_join_queued = false;
+          wg_worker.drain();
           check(api.stream_join((ts_stream_t)main_raw, side_raw), "ts_stream_join");
         });
       }
@@ -314,6 +413,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
       bopts.addend = addend.data_ptr();
     }
     call(split ? COMM_POST : (void *)comm);
+    if (side_job) wg_worker.push(std::move(side_job));      // (the call has recorded the slot's ready event)
     if (grad_feat.defined() && grad_feat.scalar_type() != in_dtype) grad_feat = grad_feat.to(in_dtype);
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
@@ -340,6 +440,8 @@ void load_backend(const std::string &libpath) {
   TORCH_CHECK(api.field, "libtaseg_hip.so lacks ", sym)
   TS_BIND(wgrad_ws_bytes, "ts_conv_block_wgrad_ws_bytes");
   TS_BIND(stream_join, "ts_stream_join");
+  TS_BIND(wgrad_side, "ts_conv_block_wgrad_side");
+  TS_BIND(set_device, "ts_set_device");
   TS_BIND(downsample_ws, "ts_downsample_workspace_bytes");
   TS_BIND(downsample, "ts_downsample");
   TS_BIND(build_kmap_ws, "ts_build_kmap_workspace_bytes");
@@ -401,7 +503,7 @@ at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, co
   const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
   at::Tensor ws = workspace(nb, x, stream);
   const PlanRef pf(plan_f, plan_f_meta, nboffs);
-  TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0};
+  TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0};
   check(api.eval(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
                  (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0, (const int32_t *)table.data_ptr(), rows,
                  (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(), (const float *)bn_bias.data_ptr(),

@@ -776,7 +776,7 @@ def _block_opts(plan_f, plan_d, planes, w16_current, addend):
     LB = B.L
     pf = None if plan_f is None else _ctypes.pointer(B.class_plan_struct(plan_f))
     pd = None if plan_d is None else _ctypes.pointer(B.class_plan_struct(plan_d))
-    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend), None, None, 0, 0)
+    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend), None, None, 0, 0, 0)
 
 
 class _ConvBlock(Function):
