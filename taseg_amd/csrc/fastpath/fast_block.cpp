@@ -229,7 +229,12 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const c10::optional<at::Tensor> &pf2, const c10::optional<at::Tensor> &pf3,
                             const std::vector<int64_t> &plan_f_meta, const c10::optional<at::Tensor> &pd0,
                             const c10::optional<at::Tensor> &pd1, const c10::optional<at::Tensor> &pd2,
-                            const c10::optional<at::Tensor> &pd3, const std::vector<int64_t> &plan_d_meta) {
+                            const c10::optional<at::Tensor> &pd3, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok) {
+    // a backward pass that died mid-way leaves its join behind: nothing of the second stream outlives the next forward call
+    if (wg_join_queued.exchange(false)) {
+      wg_worker.drain();
+      check(api.stream_join((ts_stream_t)stream, (ts_stream_t)wg_side.raw), "ts_stream_join");
+    }
     // (the plans cross the autograd boundary as four optional tensors + their meta each: a fixed number of node inputs)
     std::vector<at::Tensor> plan_f, plan_d;
     if (pf0.has_value() && pf0->defined()) plan_f = {*pf0, *pf1, *pf2, *pf3};
@@ -284,6 +289,9 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
     ctx->saved_data["plan_d"] = c10::List<at::Tensor>(plan_d);        // the input gradient's plan (tensors + meta)
     ctx->saved_data["plan_d_meta"] = c10::List<int64_t>(plan_d_meta);
+    // the weight gradient may leave for the second stream only if autograd will ADOPT it as p.grad (p.grad undefined now): an
+    // accumulation into an existing p.grad reads it on this stream, at once
+    ctx->saved_data["wgrad_side_ok"] = wgrad_side_ok;
     // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
     ctx->saved_data["grad_dest"] = (grad_dest.has_value() && grad_dest->defined()) ? *grad_dest : at::Tensor();
     ctx->saved_data["total"] = total;
@@ -347,7 +355,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const PlanRef pd(grad_feat.defined() ? plan_d : std::vector<at::Tensor>(), plan_d_meta, nboffs);
     TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0};
     std::function<void()> side_job;
-    if (wg_side.on && grad_w.defined() && !comm && !split && x.get_device() == wg_side.device_index && stream != wg_side.raw) {
+    if (wg_side.on && ctx->saved_data["wgrad_side_ok"].toBool() && grad_w.defined() && !comm && !split &&
+        x.get_device() == wg_side.device_index && stream != wg_side.raw) {
       std::lock_guard<std::mutex> lock(wg_mutex);
       WgSide &sd = wg_side;
       const size_t need = api.wgrad_ws_bytes(total, rows, (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
@@ -419,7 +428,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none};
+            none, none, none, none, none, none, none};
   }
 };
 
@@ -463,7 +472,7 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       const c10::optional<at::Tensor> &planes, bool passthrough,
                       const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
                       const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta,
-                      const std::vector<at::Tensor> &plan_d, const std::vector<int64_t> &plan_d_meta) {
+                      const std::vector<at::Tensor> &plan_d, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   TORCH_CHECK((plan_f.empty() || plan_f.size() == 4) && (plan_d.empty() || plan_d.size() == 4),
               "conv_block: a plan is (src, tile_info, n_tiles, pos | rows)");
@@ -471,7 +480,7 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
                           passthrough, grad_dest, group_id, at_(plan_f, 0), at_(plan_f, 1), at_(plan_f, 2), at_(plan_f, 3),
-                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta);
+                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta, wgrad_side_ok);
 }
 
 // Evaluation form of the block (eval-mode BatchNorm on its running statistics, no graph): ts_conv_block_eval without the

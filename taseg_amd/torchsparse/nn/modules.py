@@ -247,7 +247,8 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                                       kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
                                       state[1], state[2], float(mod.momentum), float(mod.eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
-                                      bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d))
+                                      bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d),
+                                      conv.kernel.grad is None)
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
                 out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,

@@ -737,3 +737,21 @@ def test_weight_gradients_on_a_second_stream_give_the_same_bits():
         l1, p1 = run(True, amp)
         assert l0 == l1
         assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+
+    # gradient accumulation: the second pass adds into an existing p.grad on the caller's stream - its blocks keep their weight
+    # gradient there (the node is told whether p.grad is undefined when the block runs forward); plain torch optimizer semantics
+    def accumulate(side):
+        torch.manual_seed(0)
+        model = build_network(make_model_cfg("MinkUNet", in_dim=4, cr=0.5), 20).to(DEV).train()
+        _fast.wgrad_stream(side)
+        try:
+            for _ in range(2):
+                ret, _, _ = model({"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset})
+                ret["loss"].float().mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            _fast.wgrad_stream(False)
+        return [p.grad.detach().clone() for p in model.parameters() if p.grad is not None]
+
+    g0, g1 = accumulate(False), accumulate(True)
+    assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
