@@ -70,7 +70,9 @@ def tune_wgrad_stream(step, fence, rounds=2, steps=4):
     if module() is None or pinned in ("0", "1"):
         return (wgrad_stream(pinned == "1") if module() is not None else False), None, None
     best = {False: float("inf"), True: float("inf")}
+    wins = 0
     for _ in range(rounds):
+        t = {}
         for on in (False, True):
             if wgrad_stream(on) != on:
                 return False, None, None
@@ -80,7 +82,11 @@ def tune_wgrad_stream(step, fence, rounds=2, steps=4):
             for _ in range(steps):
                 step()
             fence()
-            best[on] = min(best[on], (time.perf_counter() - t0) / steps * 1e3)
-    choice = best[True] < 0.99 * best[False]
+            t[on] = (time.perf_counter() - t0) / steps * 1e3
+            best[on] = min(best[on], t[on])
+        wins += t[True] < 0.99 * t[False]
+    # the second stream must win EVERY round by > 1 % and the best-of-rounds by > 2 %: a host-bound line, whose step time wanders by
+    # several per cent between runs, keeps one stream
+    choice = wins == rounds and best[True] < 0.98 * best[False]
     wgrad_stream(choice)
     return choice, best[False], best[True]
