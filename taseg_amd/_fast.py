@@ -66,6 +66,9 @@ def tune_wgrad_stream(step, fence, rounds=2, steps=4):
     nothing from it and, before the launches moved to a thread of their own, lost 10-20 % to the event calls
     (profiles/r04_ab_wgrad_stream.txt) - only a measurement on the actual model, batch and machine tells the cases apart.  TASEG_WGRAD_STREAM=0 / 1 pins the setting.  Returns (chosen, ms_off, ms_on)."""
     import time
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return wgrad_stream(False), None, None          # gradient buckets read p.grad while the pass is still running
     pinned = os.environ.get("TASEG_WGRAD_STREAM", "auto")
     if module() is None or pinned in ("0", "1"):
         return (wgrad_stream(pinned == "1") if module() is not None else False), None, None

@@ -400,6 +400,10 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   // the weight gradient on a second stream (TsConvBlockOpts): its operands live in the caller's ring slot, not in ws
   const bool det_ok = grad_kernel && ((int64_t)c_in * c_out) % 4 == 0 && (((uintptr_t)grad_kernel) & 15) == 0 && g_ts_conv_impl != 1;
   const bool side_on = o.wgrad_stream && o.wgrad_stream != stream && o.wgrad_ws && !comm && det_ok;
+  // a caller that has queued the weight gradient for another thread must not find it done here as well
+  TS_REQUIRE(!(o.wgrad_stream && o.wgrad_deferred) || side_on, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv_block_backward: this call cannot defer its weight gradient (SyncBatchNorm communicator, odd C_in * C_out, "
+             "misaligned grad_kernel, the scalar cross-check implementation, or the caller's own stream as second stream)");
   float *side_part = nullptr;
   if (side_on) {
     TS_REQUIRE(o.wgrad_slot >= 0 && o.wgrad_slot < 8 && (((uintptr_t)o.wgrad_ws) & 255) == 0 &&

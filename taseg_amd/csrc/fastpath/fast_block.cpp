@@ -356,7 +356,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0};
     std::function<void()> side_job;
     if (wg_side.on && ctx->saved_data["wgrad_side_ok"].toBool() && grad_w.defined() && !comm && !split &&
-        x.get_device() == wg_side.device_index && stream != wg_side.raw) {
+        x.get_device() == wg_side.device_index && stream != wg_side.raw && (c_in * c_out) % 4 == 0 &&
+        (((uintptr_t)grad_w.data_ptr()) & 15) == 0) {
       std::lock_guard<std::mutex> lock(wg_mutex);
       WgSide &sd = wg_side;
       const size_t need = api.wgrad_ws_bytes(total, rows, (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
