@@ -512,6 +512,10 @@ typedef struct TsConvBlockOpts {
    * gradient to a ts_conv_block_wgrad_side call with the same arguments - from any host thread, so that its launches need not
    * come from the thread that issues the step */
   int32_t wgrad_deferred;
+  /* fp32 blocks: per-offset exponents of THIS call's weight (ts_conv_weight_exponents_batch, [K] int32, in step with the weight):
+   * the class-sorted products then run as three IEEE-half MFMAs per fp32 product with local power-of-two scales (csrc/conv_class.hip)
+   * instead of six bf16 ones - other rounding (closer to float64), half the matrix-pipe work; NULL: the six-product split */
+  const int32_t *w_exp;
 } TsConvBlockOpts;
 size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
                                      int32_t half);
@@ -618,6 +622,8 @@ typedef struct TsPlaneJob {
   int32_t K, c_in, c_out;
 } TsPlaneJob;
 int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *planes, ts_stream_t stream);
+/* per-offset exponents for the three-product class kernels: job.planes = int32 [K], wexp[k] with max |W_k| 2^wexp[k] in [2^14, 2^15) */
+int ts_conv_weight_exponents_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out);
 /* The half-storage counterpart: job.planes = w16 [K, c_in, c_out] IEEE half (what ts_cast_weights_f16 writes), 16 weights
@@ -670,6 +676,12 @@ int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
 int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                        const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                        int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream);
+/* ts_conv_class_gemm on three IEEE-half MFMAs per fp32 product (local power-of-two scales: one exponent per (row, 32-column slice)
+ * of the gathered operand, found in the kernel, one per offset of the weight: wexp [K] from ts_conv_weight_exponents_batch) instead of
+ * six bf16 ones; same plan, same result layout, 1e-7-close to the six-product kernels and closer to float64 */
+int ts_conv_class_gemm_x(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
+                         const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
+                         int32_t mirror, const int32_t *rows, const int32_t *wexp, float *zp, ts_stream_t stream);
 /* does finishing inside the product beat pass 2 on a map of n rows (measured thresholds; what the block calls use) */
 int32_t ts_conv_class_finish_pays(int64_t n, int32_t half);
 int ts_conv_class_conv(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,

@@ -17,7 +17,7 @@ SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip
 # measured-and-shelved kernels live in tools/experiments/ and are NOT part of libtaseg_hip.so:
 # `python -m taseg_amd.csrc.build --experiments` builds them into tools/experiments/build/libtaseg_exp.so for the probes there
 EXP_DIR = os.path.join(ROOT, "tools", "experiments")
-EXPERIMENTS = ["conv_os.hip", "conv_pairs_x.hip"]
+EXPERIMENTS = ["conv_os.hip", "conv_pairs_x.hip", "conv_class_x.hip"]
 LIB = os.path.join(PKG, "libtaseg_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -213,7 +213,8 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 plan_f, _ = kmap.plans_for(conv.transposed, conv.kernel.shape[1], conv.kernel.shape[2], half)
                 out = fast.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod),
                                            kmap.nbmaps_buf, kmap.nboffs, kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out,
-                                           conv.transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f))
+                                           conv.transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f),
+                                           None if (half or plan_f is None) else _planes.exps_for(conv.kernel))
             else:
                 out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), kmap,
                                         conv.transposed, relu, half, planes)
@@ -248,7 +249,9 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                                       state[1], state[2], float(mod.momentum), float(mod.eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
                                       bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d),
-                                      conv.kernel.grad is None)
+                                      conv.kernel.grad is None,
+                                      # per-offset weight exponents: the fp32 class products on three half MFMAs (planes.exps_for)
+                                      None if (half or (plan_f is None and plan_d is None)) else _planes.exps_for(conv.kernel))
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
                 out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
