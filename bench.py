@@ -588,21 +588,29 @@ def eval_run(args):
     from taseg_amd.data.stage import DevicePrefetcher
     pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare, threaded=True)
 
-    def one_pass():
+    def issue():
         if pf is None:
             bd = make_batch()
         else:
             bd = pf.next()
             pf.prefetch_early()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
-            return model(bd)
+            return model(bd, defer=True)          # forward + tail enqueued, the arrays collected one pass later
 
-    for _ in range(args.warmup):
-        out = one_pass()
+    def passes(n):
+        # one batch in flight, as pcseg/eval.py runs the loop: pass i + 1 is issued before the host waits for the arrays of pass i
+        pending, out = None, None
+        for _ in range(n):
+            cur = issue()
+            if pending is not None:
+                out = pending.result()
+            pending = cur
+        return pending.result() if pending is not None else out
+
+    out = passes(args.warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
+    out = passes(args.steps)                     # K passes issued AND collected inside the timed region
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert len(out["point_predict"]) == batch and out["point_predict"][0].shape[0] == int(counts[0])

@@ -127,9 +127,26 @@ def evaluate(model, batches: Iterable[Dict], num_class: int, tta_votes: int = 0,
     was_training = model.training
     model.eval()
     try:
-        for batch in _staged(model, batches, prefetch):
-            with torch.no_grad():
-                ret = model(batch)
+        # one batch in flight: the forward pass of batch i + 1 is issued before the host waits for the arrays of batch i (models
+        # whose forward takes `defer`; see minkunet.PendingPredictions)
+        import inspect
+        can_defer = "defer" in inspect.signature(model.forward).parameters
+
+        def results():
+            pending = None
+            for batch in _staged(model, batches, prefetch):
+                with torch.no_grad():
+                    cur = model(batch, defer=True) if can_defer else model(batch)
+                if pending is not None:
+                    yield pending.result()
+                if can_defer:
+                    pending = cur
+                else:
+                    yield cur
+            if pending is not None:
+                yield pending.result()
+
+        for ret in results():
             if tta_votes:
                 payload = vote_payload(accumulate_votes(ret, tta_votes), dataset)
                 preds.append(payload)

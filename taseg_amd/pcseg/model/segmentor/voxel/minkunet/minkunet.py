@@ -360,59 +360,136 @@ class MinkUNetBackbone(BaseSegmentor):
         return {"loss": loss}, {"loss": lazy}, {"loss": lazy}
 
 
+class _PinnedRing:
+    """host buffers for the evaluation tail's device -> host copies: page-locked (the copies are asynchronous), grown on demand,
+    four generations deep - a deferred result stays valid until three further deferred tails have been issued"""
+    DEPTH = 4
+
+    def __init__(self):
+        self.bufs, self.at = {}, 0
+
+    def next_generation(self):
+        self.at = (self.at + 1) % self.DEPTH
+
+    def take(self, key, like, numel):
+        k = (key, self.at)
+        b = self.bufs.get(k)
+        if b is None or b.dtype != like.dtype or b.numel() < numel:
+            b = self.bufs[k] = torch.empty(max(int(numel * 1.25), 1024), dtype=like.dtype, pin_memory=True)
+        return b[:numel]
+
+
+_pinned = _PinnedRing()
+
+
+class PendingPredictions:
+    """The evaluation tail in flight (`model(batch, defer=True)`): every device -> host copy has been enqueued into page-locked
+    buffers behind the forward pass, one event marks their end.  `result()` waits for the event, checks what the reference's
+    indexing would have raised on, and slices the dictionary of numpy arrays `model(batch)` returns.  The arrays are views of a
+    ring of host buffers: valid until three further deferred tails have been issued (copy them to keep them longer)."""
+
+    def __init__(self, event, meta_h, result_h, mapped_h, labels_h, shapes, names, n_scenes, has_ms):
+        self.event, self.meta_h, self.result_h, self.mapped_h, self.labels_h = event, meta_h, result_h, mapped_h, labels_h
+        self.shapes, self.names, self.n_scenes, self.has_ms = shapes, names, n_scenes, has_ms
+        self._out = None
+
+    def result(self):
+        if self._out is not None:
+            return self._out
+        self.event.synchronize()
+        n = self.n_scenes
+        meta = self.meta_h.numpy()
+        bad, cnt_p_h, cnt_k_h = int(meta[0]), meta[1:1 + n].tolist(), meta[1 + n:1 + 2 * n].tolist()
+        cnt_l_h = meta[1 + 2 * n:1 + 3 * n].tolist()
+        n_cur_h = meta[1 + 3 * n:1 + 4 * n].tolist()
+        if bad:
+            raise IndexError("inverse_map names a voxel outside its scene")
+        if self.has_ms:
+            n_ms_h = meta[1 + 4 * n:1 + 5 * n].tolist()
+            if n_ms_h != cnt_p_h:
+                raise IndexError(f"num_points_ms {n_ms_h} does not match the inverse map's points per scene {cnt_p_h}")
+        result_h = self.result_h.numpy().reshape(self.shapes[0])
+        mapped_h = None if self.mapped_h is None else self.mapped_h.numpy().reshape(self.shapes[1])
+        labels_h = self.labels_h.numpy().reshape(self.shapes[2])
+        point_predict, point_labels, point_predict_logits = [], [], []
+        at_k = at_l = 0
+        for b in range(n):
+            n_cur = int(n_cur_h[b])
+            seg = slice(at_k, at_k + min(int(cnt_k_h[b]), n_cur))
+            point_predict.append(result_h[seg])                 # (views of the batch's arrays: no second host copy)
+            if mapped_h is not None:
+                point_predict_logits.append(mapped_h[seg])
+            point_labels.append(labels_h[at_l: at_l + min(int(cnt_l_h[b]), n_cur)])
+            at_k += int(cnt_k_h[b])
+            at_l += int(cnt_l_h[b])
+        self._out = {"point_predict": point_predict, "point_labels": point_labels, "name": self.names,
+                     "point_predict_logits": point_predict_logits}
+        return self._out
+
+
 def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_probs, point_mask=None, num_points_ms=None,
-                           names=None):
+                           names=None, defer=False):
     """The evaluation tail of the segmentors (minkunet.py:435-455, minkunet_ms.py:433-458) for the WHOLE batch at once: per scene
     `out[scene][inverse_map of the scene]` (Ms: `[point_mask of the scene]`), trimmed to the scan's own point count; arg-max and
     logits (or the soft-max under return_logit / return_tta) and the mapped labels as numpy arrays, scene by scene - what the
     reference's per-scene loop of boolean masks returns, with three stable sorts, one gather and a handful of device -> host
-    copies instead of ~12 launches and 6 host reads per scene."""
+    copies instead of ~12 launches and 6 host reads per scene.  defer: return a PendingPredictions instead of waiting for the
+    copies - the caller issues the next batch's forward pass first and collects `result()` afterwards (pcseg/eval.py, bench.py
+    --eval): the host never waits for the device between two batches."""
     dev = out.device
     b_vox, b_pts, b_lab = vox_batch.long(), invs.C[:, -1].long(), all_labels.C[:, -1].long()
-    cnt_v, cnt_p, cnt_l = torch.bincount(b_vox), torch.bincount(b_pts), torch.bincount(b_lab)
-    order_v = torch.sort(b_vox, stable=True)[1]            # out[scene] = out[order_v[start : start + count]] (original order kept)
-    bp_sorted, order_p = torch.sort(b_pts, stable=True)
-    order_l = torch.sort(b_lab, stable=True)[1]
+    n_scenes = len(names) if names is not None else int(torch.as_tensor(num_points).numel())
+    cnt_v = torch.bincount(b_vox, minlength=n_scenes)
+    cnt_p, cnt_l = torch.bincount(b_pts, minlength=n_scenes), torch.bincount(b_lab, minlength=n_scenes)
+    if not (cnt_v.shape[0] == cnt_p.shape[0] == cnt_l.shape[0] == n_scenes):
+        raise IndexError(f"batch indices beyond the {n_scenes} scenes of the batch")       # (shapes are host-side: no device read)
+    # stable sorts by scene: 8-bit keys where the batch allows it (one radix pass instead of the eight of a 64-bit key)
+    narrow = (lambda t: t.to(torch.uint8)) if n_scenes <= 255 else (lambda t: t)
+    order_v = torch.sort(narrow(b_vox), stable=True)[1]    # out[scene] = out[order_v[start : start + count]] (original order kept)
+    bp_sorted, order_p = torch.sort(narrow(b_pts), stable=True)
+    bp_sorted = bp_sorted.long()
+    order_l = torch.sort(narrow(b_lab), stable=True)[1]
     start_v = torch.cumsum(cnt_v, 0) - cnt_v
-    start_v = torch.nn.functional.pad(start_v, (0, max(0, int(cnt_p.shape[0]) - int(start_v.shape[0]))))
     local = invs.F[order_p].long()
-    cnt_v_pad = torch.nn.functional.pad(cnt_v, (0, max(0, int(cnt_p.shape[0]) - int(cnt_v.shape[0]))))
-    bad = ((local < 0) | (local >= cnt_v_pad[bp_sorted])).any()       # read below with the counts (the reference's indexing raises)
+    bad = ((local < 0) | (local >= cnt_v[bp_sorted])).any()           # read with the counts (the reference's indexing raises)
     rows = order_v[(start_v[bp_sorted] + local).clamp_(0, max(int(order_v.shape[0]) - 1, 0))]
     mapped = out[rows]                                      # [points, classes], scene-major, the scene's own point order
     kept_scene = bp_sorted
     if point_mask is not None:
         keep = point_mask.to(dev).bool()
         mapped, kept_scene = mapped[keep], bp_sorted[keep]
-    cnt_k = torch.bincount(kept_scene, minlength=int(cnt_p.shape[0]))
+    cnt_k = torch.bincount(kept_scene, minlength=n_scenes)
     result = mapped.softmax(1) if want_probs else mapped.argmax(1)
     labels_sorted = all_labels.F[order_l]
-    # device -> host: everything the per-scene slicing needs
-    n_scenes = int(cnt_p.shape[0])
-    cnt_p_h, cnt_k_h, cnt_l_h = cnt_p.tolist(), cnt_k.tolist(), cnt_l.tolist() + [0] * n_scenes
-    if bool(bad):
-        raise IndexError("inverse_map names a voxel outside its scene")
-    n_cur_h = [int(v) for v in torch.as_tensor(num_points).reshape(-1).tolist()]
+    # one small tensor with everything the per-scene slicing needs, then the arrays themselves: asynchronous copies into page-locked
+    # buffers, one event behind them
+    parts = [bad.reshape(1).long(), cnt_p.long(), cnt_k.long(), cnt_l.long(),
+             torch.as_tensor(num_points).reshape(-1)[:n_scenes].to(dev, non_blocking=True).long()]
     if num_points_ms is not None:
-        n_ms_h = [int(v) for v in torch.as_tensor(num_points_ms).reshape(-1).tolist()]
-        if n_ms_h[:n_scenes] != cnt_p_h:
-            raise IndexError(f"num_points_ms {n_ms_h[:n_scenes]} does not match the inverse map's points per scene {cnt_p_h}")
-    result_h = result.cpu().numpy()
-    mapped_h = None if want_probs else mapped.cpu().numpy()
-    labels_h = labels_sorted.cpu().numpy()
-    point_predict, point_labels, point_predict_logits = [], [], []
-    at_k = at_l = 0
-    for b in range(n_scenes):
-        n_cur = n_cur_h[b]
-        seg = slice(at_k, at_k + min(cnt_k_h[b], n_cur))
-        point_predict.append(result_h[seg])                 # (views of the batch's arrays: no second host copy)
-        if mapped_h is not None:
-            point_predict_logits.append(mapped_h[seg])
-        point_labels.append(labels_h[at_l: at_l + min(cnt_l_h[b], n_cur)])
-        at_k += cnt_k_h[b]
-        at_l += cnt_l_h[b]
-    return {"point_predict": point_predict, "point_labels": point_labels, "name": names,
-            "point_predict_logits": point_predict_logits}
+        parts.append(torch.as_tensor(num_points_ms).reshape(-1)[:n_scenes].to(dev, non_blocking=True).long())
+    meta = torch.cat(parts)
+    if defer:
+        _pinned.next_generation()
+
+    def to_host(key, t):
+        t = t.contiguous()
+        if not defer:
+            return t.reshape(-1).cpu()           # fresh arrays, as `model(batch)` has always returned them
+        h = _pinned.take(key, t, t.numel())
+        h.copy_(t.reshape(-1), non_blocking=True)
+        return h
+
+    meta_h = to_host("meta", meta)
+    result_h = to_host("result", result)
+    mapped_h = None if want_probs else to_host("mapped", mapped)
+    labels_h = to_host("labels", labels_sorted)
+    event = torch.cuda.Event()
+    event.record()
+    pending = PendingPredictions(event, meta_h, result_h, mapped_h, labels_h, (tuple(result.shape), tuple(mapped.shape), tuple(labels_sorted.shape)),
+                                 names, n_scenes, num_points_ms is not None)
+    # (the device tensors stay alive until the copies have run: the event's owner keeps them)
+    pending._keep = (meta, result, mapped, labels_sorted)
+    return pending if defer else pending.result()
 
 
 class MinkUNet(MinkUNetBackbone):
@@ -427,7 +504,7 @@ class MinkUNet(MinkUNetBackbone):
         batch_dict["_plan"] = plan
         return plan
 
-    def forward(self, batch_dict, return_logit=False, return_tta=False):
+    def forward(self, batch_dict, return_logit=False, return_tta=False, defer=False):
         x = batch_dict["lidar"]
         x.F = x.F[:, :self.in_feature_dim]
         plan = batch_dict.get("_plan") or self.prepare(batch_dict)
@@ -439,7 +516,7 @@ class MinkUNet(MinkUNetBackbone):
             return self._train_outputs(out, target, batch_dict["lidar"].C[:, :3].float(), batch_dict["offset"])
 
         return unvoxelise_predictions(out, x.C[:, -1], batch_dict["inverse_map"], batch_dict["targets_mapped"],
-                                      batch_dict["num_points"], return_logit or return_tta, names=batch_dict["name"])
+                                      batch_dict["num_points"], return_logit or return_tta, names=batch_dict["name"], defer=defer)
 
     def forward_ensemble(self, batch_dict):
         return self.forward(batch_dict, return_tta=True)

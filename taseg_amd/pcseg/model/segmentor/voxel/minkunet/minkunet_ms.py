@@ -18,7 +18,7 @@ class MinkUNetMs(MinkUNetBackbone):
         batch_dict["_plan"] = plan
         return plan
 
-    def forward(self, batch_dict, return_logit=False, return_tta=False):
+    def forward(self, batch_dict, return_logit=False, return_tta=False, defer=False):
         x_ms = batch_dict["lidar_ms"]
         x_ms.F = x_ms.F[:, :self.in_feature_dim]
         plan = batch_dict.get("_plan") or self.prepare(batch_dict)
@@ -33,7 +33,7 @@ class MinkUNetMs(MinkUNetBackbone):
         # points (`point_mask`), trim to the scan's own point count (minkunet_ms.py:433-458)
         return unvoxelise_predictions(out_ms, x_ms.C[:, -1], batch_dict["inverse_map_ms"], batch_dict["targets_mapped"],
                                       batch_dict["num_points"], return_logit or return_tta, point_mask=batch_dict["point_mask"],
-                                      num_points_ms=batch_dict["num_points_ms"], names=batch_dict["name"])
+                                      num_points_ms=batch_dict["num_points_ms"], names=batch_dict["name"], defer=defer)
 
     def forward_ensemble(self, batch_dict):
         return self.forward(batch_dict, return_tta=True)

@@ -172,6 +172,36 @@ def test_evaluate_loop_with_and_without_the_staged_index_plan(g_eval_ms):
     assert (tta["predictions"][0] == g["minkunet_ms_tta_label"]).mean() >= 0.999
 
 
+def test_deferred_evaluation_tail_gives_the_arrays_of_the_synchronous_call(g_eval_ms):
+    """`model(batch, defer=True)` (minkunet.PendingPredictions): forward pass and evaluation tail enqueued, device -> host copies into
+    page-locked buffers behind one event; `result()` of passes issued back to back - two in flight, as pcseg.eval.evaluate and
+    `bench.py --eval` run them - holds exactly the arrays of the synchronous call, and the errors the synchronous call raises come
+    out of `result()`"""
+    from taseg_amd.pcseg.model import build_network
+    g = g_eval_ms
+    cfg = make_model_cfg("MinkUNetMs", in_dim=5, cr=0.5, num_layer=[1] * 8)
+    model = fill_parameters(build_network(cfg, 20), seed=3).cuda().eval()
+    with torch.no_grad():
+        want = model(_eval_batch(g, "batch_"))
+        want_tta = model(_eval_batch(g, "tta_"), return_tta=True)
+        p1 = model(_eval_batch(g, "batch_"), defer=True)
+        p2 = model(_eval_batch(g, "tta_"), return_tta=True, defer=True)
+        p3 = model(_eval_batch(g, "batch_"), defer=True)
+    for pend, ref in ((p1, want), (p2, want_tta), (p3, want)):
+        got = pend.result()
+        assert got["name"] == ref["name"] and len(got["point_predict"]) == len(ref["point_predict"])
+        for key in ("point_predict", "point_labels", "point_predict_logits"):
+            assert len(got[key]) == len(ref[key])
+            for a, b in zip(got[key], ref[key]):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+    bad = _eval_batch(g, "batch_")
+    bad["num_points_ms"] = bad["num_points_ms"] + 1
+    with torch.no_grad():
+        pend = model(bad, defer=True)
+    with pytest.raises(IndexError):
+        pend.result()
+
+
 def test_reference_format_checkpoint_loads(tmp_path):
     """R/train.py:319-342 checkpoint layout, DDP-prefixed keys: load_params_from_file (base_segmentors.py:16-37), then
     the loaded model reproduces the reference model's eval logits"""
