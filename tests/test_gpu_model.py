@@ -755,3 +755,53 @@ def test_weight_gradients_on_a_second_stream_give_the_same_bits():
 
     g0, g1 = accumulate(False), accumulate(True)
     assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+def test_block_backward_launches_its_weight_gradient_on_a_second_stream_itself(monkeypatch):
+    """TsConvBlockOpts.wgrad_stream without wgrad_deferred: ts_conv_block_backward itself enqueues the weight gradient on the second
+    stream (event, ring slot, chunk-order sum) - the form a C caller without a launch thread uses.  Driven through the Python
+    autograd node with the options struct extended on the way in; the weight gradients of a training step are the bits of the
+    one-stream step."""
+    from taseg_amd import _fast, backend as B
+    from taseg_amd.pcseg.model import build_network
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.nn import functional as F
+    import bench
+    monkeypatch.setattr(_fast, "_mod", None)            # the Python node (the C++ node defers to its launch thread)
+    monkeypatch.setattr(_fast, "_tried", True)
+    coords, feats, labels, _ = bench.make_scans(5, 2, 12000, "minkunet")
+    offset = torch.tensor([len(coords)], device="cuda", dtype=torch.int32)
+    lib = B.L.load()
+    side = torch.cuda.Stream()
+    ring = [torch.empty(96 << 20, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    state = {"on": False, "slot": 0, "used": 0}
+    plain = F._block_opts
+
+    def opts_with_side(plan_f, plan_d, planes, w16_current, addend, w_exp=None):
+        o = plain(plan_f, plan_d, planes, w16_current, addend, w_exp)
+        if state["on"] and plan_f is None:              # a backward call (the forward passes its forward plan or builds none: see below)
+            slot = state["slot"] = (state["slot"] + 1) % 8
+            o.wgrad_stream, o.wgrad_ws, o.wgrad_ws_bytes, o.wgrad_slot = side.cuda_stream, ring[slot].data_ptr(), ring[slot].numel(), slot
+            state["used"] += 1
+        return o
+
+    monkeypatch.setattr(F, "_block_opts", opts_with_side)
+
+    def grads(on):
+        torch.manual_seed(0)
+        model = build_network(make_model_cfg("MinkUNet", in_dim=4, cr=0.5), 20).cuda().train()
+        ret, _, _ = model({"lidar": SparseTensor(feats, coords), "targets": SparseTensor(labels, coords), "offset": offset})
+        state["on"] = on
+        try:
+            # (retain_graph: the saved activations the second stream reads stay allocated until it has been joined - what the C++
+            # node arranges with record_stream)
+            ret["loss"].float().mean().backward(retain_graph=True)
+        finally:
+            state["on"] = False
+        B.L.check(lib.ts_stream_join(B.L.stream(), side.cuda_stream), "ts_stream_join")
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    g0, g1 = grads(False), grads(True)
+    assert state["used"] >= 40                               # the blocks' backward calls took the second stream
+    assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
