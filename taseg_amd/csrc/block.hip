@@ -423,8 +423,10 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
       }
     }
     // (usually long finished: a query is cheaper than a wait in the stream)
-    if (g_wg_used[o.wgrad_slot].load() && hipEventQuery(g_wg_done[o.wgrad_slot]) != hipSuccess)
+    if (g_wg_used[o.wgrad_slot].load() && hipEventQuery(g_wg_done[o.wgrad_slot]) != hipSuccess) {
+      (void)hipGetLastError();             // "not ready" is an answer, not an error for the launch checks that follow
       TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_wg_done[o.wgrad_slot], 0), "ring wait");
+    }
   }
   if (comm) {
     TS_TRY(ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums,
