@@ -221,10 +221,26 @@ static double plan_z_moves(const TsClassPlan *p, int64_t n) {
 
 // The convolution of a block: conv_out [n_out, c_out] = sum over the rulebook, on the class plan of opts (where it fits) or as pair
 // GEMM + pass 2 through z.  Shared by the training forward and the evaluation forward.
+// tail (evaluation block only): where the convolution ends in the list form of pass 2, that launch applies the block's elementwise
+// tail in its store and writes tail_out instead of conv_out; *tail_done says whether it did.
 static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K, const int32_t *nbmaps,
                       const int32_t *nboffs, int64_t n_pairs, int32_t gather_col, const int32_t *pos, int64_t n_out, int32_t c_out,
                       int32_t half, void *conv_out, void *w16, const TsConvBlockOpts &o, const PlanesScope &planes, void *z,
-                      ts_stream_t stream) {
+                      ts_stream_t stream, const TsGatherEpilogue *tail = nullptr, void *tail_out = nullptr, bool *tail_done = nullptr) {
+  // pass 2 of this convolution, with the tail where it applies
+  auto pass2 = [&](const void *zz, const int32_t *table, int32_t kk, int64_t zrows) -> int {
+    if (tail && tail_out) {
+      const int rc = half ? ts_conv_gather_sum_f16_epi(zz, c_out, table, kk, n_out, zrows, tail_out, *tail, stream)
+                          : ts_conv_gather_sum_epi((const float *)zz, c_out, table, kk, n_out, zrows, (float *)tail_out, *tail, stream);
+      if (rc == TS_OK) {
+        if (tail_done) *tail_done = true;
+        return TS_OK;
+      }
+      if (rc != TS_ERR_UNSUPPORTED) return rc;
+    }
+    return half ? ts_conv_gather_sum_f16(zz, c_out, table, kk, n_out, zrows, conv_out, stream)
+                : ts_conv_gather_sum((const float *)zz, c_out, table, kk, n_out, zrows, (float *)conv_out, stream);
+  };
   const TsClassPlan *cp = plan_fits(o.fwd_plan, K, n_out, c_in, c_out, n_pairs, nboffs) ? o.fwd_plan : nullptr;
   {
     // half storage: one half copy in the kernel's own layout serves both passes (the forward reads it through the transposing
@@ -252,10 +268,7 @@ static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const
       }
       if (!cp->rows && !fused) {
         ProfScope ps(1, stream, plan_z_rows(cp), 0, c_out, cp->groups, (double)n_out, es_d, 0);
-        if (half)
-          TS_TRY(ts_conv_gather_sum_f16(z, c_out, cp->pos, cp->groups, n_out, cp->m_pad, conv_out, stream));
-        else
-          TS_TRY(ts_conv_gather_sum((const float *)z, c_out, cp->pos, cp->groups, n_out, cp->m_pad, (float *)conv_out, stream));
+        TS_TRY(pass2(z, cp->pos, cp->groups, cp->m_pad));
       }
     } else if (half) {
       {
@@ -264,7 +277,7 @@ static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const
       }
       {
         ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 2, 0);
-        TS_TRY(ts_conv_gather_sum_f16(z, c_out, pos, K, n_out, n_pairs, conv_out, stream));
+        TS_TRY(pass2(z, pos, K, n_pairs));
       }
     } else {
       {
@@ -275,7 +288,7 @@ static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const
       }
       {
         ProfScope ps(1, stream, (double)n_pairs, 0, c_out, K, (double)n_out, 4, 0);
-        TS_TRY(ts_conv_gather_sum((const float *)z, c_out, pos, K, n_out, n_pairs, (float *)conv_out, stream));
+        TS_TRY(pass2(z, pos, K, n_pairs));
       }
     }
   }
@@ -356,8 +369,14 @@ extern "C" int ts_conv_block_eval(const void *feat, int64_t n_feat_rows, int32_t
   void *z = p;
   p += blk_align((size_t)n_pairs * cmax * es);
   void *conv_out = p;
+  // the elementwise tail rides on pass 2 where the convolution ends in its list form (csrc/conv_pairs*.hip: one launch and one
+  // round trip of the convolution output less; TASEG_EVAL_TAIL_IN_PASS2=0 keeps the separate pass)
+  static const bool tail_in_pass2 = !(getenv("TASEG_EVAL_TAIL_IN_PASS2") && atoi(getenv("TASEG_EVAL_TAIL_IN_PASS2")) == 0);
+  const TsGatherEpilogue tail = {mean, invstd, bn_weight, bn_bias, residual, relu ? 1 : 0};
+  bool tail_done = false;
   TS_TRY(block_conv(feat, n_feat_rows, c_in, kernel, K, nbmaps, nboffs, n_pairs, gather_col, pos, n_out, c_out, half, conv_out, w16, o,
-                    planes, z, stream));
+                    planes, z, stream, tail_in_pass2 ? &tail : nullptr, out, &tail_done));
+  if (tail_done) return TS_OK;
   if (half)
     return ts_bn_act_forward_f16(conv_out, residual, mean, invstd, bn_weight, bn_bias, n_out, c_out, relu, out, nullptr, stream);
   return ts_bn_act_forward((const float *)conv_out, (const float *)residual, mean, invstd, bn_weight, bn_bias, n_out, c_out, relu,

@@ -252,6 +252,18 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
                           float *out, const TsWgradReduce *side, const float *addend, ts_stream_t stream);
 int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs,
                               void *out, const TsWgradReduce *side, const void *addend, ts_stream_t stream);
+// Pass 2 with the evaluation block's elementwise tail in its store: out = act((sum - mean) invstd w + b [+ residual]) - the
+// arithmetic of bn_act_fwd_kernel on the fp32 sum (half storage: the sum is not rounded to half in between).  Returns
+// TS_ERR_UNSUPPORTED (and launches nothing) where the list form of pass 2 does not apply: the caller then runs the two launches.
+struct TsGatherEpilogue {
+  const float *mean, *invstd, *w, *b;      // [c]
+  const void *residual;                    // optional [n_rows, c]
+  int relu;
+};
+int ts_conv_gather_sum_epi(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs, float *out,
+                           const TsGatherEpilogue &epi, ts_stream_t stream);
+int ts_conv_gather_sum_f16_epi(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs, void *out,
+                               const TsGatherEpilogue &epi, ts_stream_t stream);
 int ts_conv_wgrad_ex(const float *a_feat, int32_t c_a, const float *b_feat, int32_t c_b, const int32_t *nbmaps,
                      const int32_t *nboffs, int32_t K, int32_t col_a, int64_t n_pairs, float *grad_kernel,
                      int32_t already_zero, ts_stream_t stream);

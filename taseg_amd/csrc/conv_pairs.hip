@@ -831,7 +831,7 @@ template <int R>
 __global__ __launch_bounds__(256) void gather_list_kernel(const float *__restrict__ Z, int C,
                                                           const int *__restrict__ pos, int K, int64_t n,
                                                           int64_t n_pairs, float *__restrict__ out, TsWgradReduce side,
-                                                          const float *__restrict__ addend, int rpw) {
+                                                          const float *__restrict__ addend, int rpw, TsGatherEpilogue epi) {
   __shared__ int lst[64][33];
   __shared__ int cnt[64];
   const int tid = threadIdx.x;
@@ -882,15 +882,31 @@ __global__ __launch_bounds__(256) void gather_list_kernel(const float *__restric
     acc.z += a.z;
     acc.w += a.w;
   }
+  if (epi.mean) {                        // evaluation block: bn_act_fwd_kernel's arithmetic on the sum
+    const float4 m = *(const float4 *)(epi.mean + c), s = *(const float4 *)(epi.invstd + c);
+    const float4 ww = *(const float4 *)(epi.w + c), bb = *(const float4 *)(epi.b + c);
+    acc.x = (acc.x - m.x) * s.x * ww.x + bb.x;
+    acc.y = (acc.y - m.y) * s.y * ww.y + bb.y;
+    acc.z = (acc.z - m.z) * s.z * ww.z + bb.z;
+    acc.w = (acc.w - m.w) * s.w * ww.w + bb.w;
+    if (epi.residual) {
+      const float4 r = *(const float4 *)((const float *)epi.residual + j * C + c);
+      acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+    if (epi.relu) {
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+  }
   *(float4 *)(out + j * C + c) = acc;
 }
 
 static int launch_gather_list(const float *z, int c, const int *pos, int K, int64_t n_rows, int64_t n_pairs, float *out,
-                              const TsWgradReduce &side, const float *addend, hipStream_t stream) {
+                              const TsWgradReduce &side, const float *addend, hipStream_t stream,
+                              const TsGatherEpilogue &epi = TsGatherEpilogue{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   const int cv = c >> 2, rpw = 256 / cv;
   const unsigned grid = (unsigned)ts_cdiv(n_rows, rpw);
   // R = 4 / 8 / 12 / 16 measured within 3 % of each other on every layer (profiles/r02_v9_gather_forms_probe.txt)
-  gather_list_kernel<8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend, rpw);
+  gather_list_kernel<8><<<grid, 256, 0, stream>>>(z, c, pos, K, n_rows, n_pairs, out, side, addend, rpw, epi);
   TS_CHECK_LAUNCH("conv_gather_sum (list)");
   return TS_OK;
 }
@@ -931,6 +947,17 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
   }
   TS_CHECK_LAUNCH("conv_gather_sum");
   return TS_OK;
+}
+
+int ts_conv_gather_sum_epi(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs, float *out,
+                           const TsGatherEpilogue &epi, ts_stream_t stream_) {
+  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  const bool vec = (c % 4 == 0) && ((((uintptr_t)z) | ((uintptr_t)out) | ((uintptr_t)epi.residual) | ((uintptr_t)epi.mean) |
+                                     ((uintptr_t)epi.invstd) | ((uintptr_t)epi.w) | ((uintptr_t)epi.b)) & 15) == 0;
+  if (!(vec && K > 0 && K <= 32 && c >= 16 && c <= 1024 && !k_registers && g_ts_conv_impl != 1 && n_rows > 0 && z && pos && out &&
+        epi.mean && epi.invstd && epi.w && epi.b))
+    return TS_ERR_UNSUPPORTED;
+  return launch_gather_list(z, c, pos, K, n_rows, n_pairs, out, TsWgradReduce{}, nullptr, (hipStream_t)stream_, epi);
 }
 
 // ------------------------------------------------------------------------------------- weight gradient

@@ -362,7 +362,7 @@ template <int R>
 __global__ __launch_bounds__(256) void gather_list_h_kernel(const _Float16 *__restrict__ Z, int C,
                                                             const int *__restrict__ pos, int K, int64_t n,
                                                             _Float16 *__restrict__ out, TsWgradReduce side,
-                                                            const _Float16 *__restrict__ addend, int rpw) {
+                                                            const _Float16 *__restrict__ addend, int rpw, TsGatherEpilogue epi) {
   __shared__ int lst[64][33];
   __shared__ int cnt[64];
   const int tid = threadIdx.x;
@@ -406,6 +406,17 @@ __global__ __launch_bounds__(256) void gather_list_h_kernel(const _Float16 *__re
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] += (float)a[q];
   }
+  if (epi.mean) {                        // evaluation block: bn_act_fwd_h_kernel's arithmetic on the fp32 sum
+    h8 r;
+    if (epi.residual) r = *(const h8 *)((const _Float16 *)epi.residual + j * C + c8);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = (acc[q] - epi.mean[c8 + q]) * epi.invstd[c8 + q] * epi.w[c8 + q] + epi.b[c8 + q];
+      if (epi.residual) v += (float)r[q];
+      if (epi.relu) v = fmaxf(v, 0.f);
+      acc[q] = v;
+    }
+  }
   h8 o;
 #pragma unroll
   for (int q = 0; q < 8; ++q) o[q] = (_Float16)acc[q];
@@ -437,7 +448,8 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
   if (K <= 32 && c >= 64 && c <= 2048 && !k_registers && g_ts_conv_impl != 1) {   // 32 channels: 64 rows per workgroup, the list build costs more than it saves
     const int rpw = 256 / (c >> 3);
     gather_list_h_kernel<8><<<(unsigned)ts_cdiv(n_rows, rpw), 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side,
-                                                                                (const _Float16 *)addend, rpw);
+                                                                                (const _Float16 *)addend, rpw,
+                                                                                TsGatherEpilogue{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     TS_CHECK_LAUNCH("ts_conv_gather_sum_f16 (list)");
     return TS_OK;
   }
@@ -449,6 +461,20 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
   else
     gather_sum_h_kernel<0><<<grid, 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side, (const _Float16 *)addend);
   TS_CHECK_LAUNCH("ts_conv_gather_sum_f16");
+  return TS_OK;
+}
+
+int ts_conv_gather_sum_f16_epi(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs, void *out,
+                               const TsGatherEpilogue &epi, ts_stream_t stream_) {
+  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  if (!(K > 0 && K <= 32 && c >= 64 && c <= 2048 && (c & 7) == 0 && !k_registers && g_ts_conv_impl != 1 && n_rows > 0 && z && pos &&
+        out && epi.mean && epi.invstd && epi.w && epi.b &&
+        ((((uintptr_t)z) | ((uintptr_t)out) | ((uintptr_t)epi.residual)) & 15) == 0))
+    return TS_ERR_UNSUPPORTED;
+  const int rpw = 256 / (c >> 3);
+  gather_list_h_kernel<8><<<(unsigned)ts_cdiv(n_rows, rpw), 256, 0, (hipStream_t)stream_>>>(
+      (const _Float16 *)z, c, pos, K, n_rows, (_Float16 *)out, TsWgradReduce{}, nullptr, rpw, epi);
+  TS_CHECK_LAUNCH("ts_conv_gather_sum_f16 (list + evaluation tail)");
   return TS_OK;
 }
 
