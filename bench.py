@@ -609,10 +609,18 @@ def eval_run(args):
 
     out = passes(args.warmup)
     torch.cuda.synchronize()
+    host_prof = None
+    if os.environ.get("TASEG_BENCH_CPROFILE"):   # diagnostic: interpreter profile of the timed passes
+        import cProfile
+        host_prof = cProfile.Profile()
+        host_prof.enable()
     t0 = time.perf_counter()
     out = passes(args.steps)                     # K passes issued AND collected inside the timed region
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if host_prof is not None:
+        host_prof.disable()
+        host_prof.dump_stats(os.environ["TASEG_BENCH_CPROFILE"])
     assert len(out["point_predict"]) == batch and out["point_predict"][0].shape[0] == int(counts[0])
     ms = 1e3 * dt / args.steps
     print(json.dumps({
@@ -750,23 +758,40 @@ def main():
 
     opt_events = []
 
+    # TASEG_BENCH_HOST_PHASES=1 (diagnostic): host time the training thread spends ISSUING each phase of a step (no device
+    # synchronisation: what a host-bound line is made of), printed to stderr after the run
+    host_phases = {} if os.environ.get("TASEG_BENCH_HOST_PHASES") == "1" else None
+
+    def _hp(name, t):
+        if host_phases is not None:
+            now = time.perf_counter()
+            host_phases[name] = host_phases.get(name, 0.0) + now - t
+            return now
+        return t
+
     def step(time_optimizer=False):
         # one step = stage one batch (rulebooks / index plan; for minkunet_ms also the temporal aggregation and
         # voxelisation) + forward + loss + backward + clip + SGD.  With the prefetcher the batch staged inside
         # step i is the one step i+1 trains on (every timed step still stages exactly one batch).
+        th = time.perf_counter() if host_phases is not None else 0.0
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             if pf is None:
                 ret, _, _ = net(make_batch())
             else:
-                ret, _, _ = net(pf.next())
+                bd_ = pf.next()
+                th = _hp("next_batch", th)
+                ret, _, _ = net(bd_)
+        th = _hp("forward", th)
         if pf is not None and early_stage:
             pf.prefetch_early()          # the next batch is staged beside this step's backward pass (worker thread)
         loss = ret["loss"].float().mean()
+        th = _hp("loss", th)
         if flat:
             (loss * opt.loss_scale()).backward()
         else:
             scaler.scale(loss).backward()
+        th = _hp("backward", th)
         if time_optimizer:               # BASELINE's metric wants the optimizer's share stated: events on sampled steps
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
@@ -782,8 +807,12 @@ def main():
         if time_optimizer:
             ev[1].record()
             opt_events.append(ev)
+        th = _hp("optimizer", th)
         if pf is not None:
             pf.prefetch()
+        th = _hp("stage_next", th)
+        if host_phases is not None:
+            host_phases["steps"] = host_phases.get("steps", 0) + 1
         return ret["loss"]
 
     def fence():
@@ -813,6 +842,13 @@ def main():
         ctypes.CDLL(None).fflush(None)      # every rank: push RCCL's C-stdio version banner out before the result line
     if not args.no_kernel_events:
         B.profile_begin(expected_launches=800 * len(range(0, args.steps, EVENT_EVERY)))   # ~330 (bs 2) .. per step
+    if host_phases is not None:
+        host_phases.clear()
+    host_prof = None
+    if os.environ.get("TASEG_BENCH_CPROFILE") and rank == 0:      # diagnostic: interpreter profile of the timed steps
+        import cProfile
+        host_prof = cProfile.Profile()
+        host_prof.enable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not args.no_kernel_events:
@@ -830,6 +866,13 @@ def main():
     dog.beat("fence after the timed steps")
     fence()
     dt = time.perf_counter() - t0
+    if host_prof is not None:
+        host_prof.disable()
+        host_prof.dump_stats(os.environ["TASEG_BENCH_CPROFILE"])
+    if host_phases is not None and rank == 0:
+        n_hp = max(host_phases.pop("steps", 1), 1)
+        note("host issue time per step (ms, timed steps): " +
+             ", ".join(f"{k} {1e3 * v / n_hp:.2f}" for k, v in host_phases.items()))
     dog.beat("collect")
     records = B.profile_end()
     # what an event pair measures with nothing between its two records, after the timed region: the per-launch figures

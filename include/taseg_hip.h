@@ -516,6 +516,11 @@ typedef struct TsConvBlockOpts {
    * the class-sorted products then run as three IEEE-half MFMAs per fp32 product with local power-of-two scales (csrc/conv_class.hip)
    * instead of six bf16 ones - other rounding (closer to float64), half the matrix-pipe work; NULL: the six-product split */
   const int32_t *w_exp;
+  /* natural != 0: a 1x1x1 convolution on the identity rulebook (K = 1, pair p = (p, p), n_pairs = n_out: conv.py:135-140's
+   * `feats.matmul(weight)` as a block) - the pair GEMM's rows ARE the result rows: the product is written straight into the
+   * convolution output / the input gradient, no Z, no pass 2, no position table read (pos may be any valid pointer); the shortcut
+   * branch of a residual block (minkunet.py:105-111) as one call per direction.  Not combined with class plans or an addend. */
+  int32_t natural;
 } TsConvBlockOpts;
 size_t ts_conv_block_workspace_bytes(int64_t n_pairs, int64_t n_rows_max, int32_t c_in, int32_t c_out, int32_t K,
                                      int32_t half);

@@ -59,7 +59,7 @@ def wgrad_stream(on):
     return False
 
 
-def tune_wgrad_stream(step, fence, rounds=2, steps=4):
+def tune_wgrad_stream(step, fence, rounds=3, steps=4):
     """Time `step()` (one full training step: forward, backward, optimizer) with the weight gradients on the caller's stream and on
     the second stream - `rounds` alternating rounds of `steps` steps after one unmeasured step each, `fence()` = device (and rank)
     synchronisation - and keep the faster setting.  The second stream is worth 2-4 % of a device-bound step; a host-bound one gains
@@ -88,8 +88,9 @@ def tune_wgrad_stream(step, fence, rounds=2, steps=4):
             t[on] = (time.perf_counter() - t0) / steps * 1e3
             best[on] = min(best[on], t[on])
         wins += t[True] < 0.99 * t[False]
-    # the second stream must win EVERY round by > 1 % and the best-of-rounds by > 2 %: a host-bound line, whose step time wanders by
-    # several per cent between runs, keeps one stream
-    choice = wins == rounds and best[True] < 0.98 * best[False]
+    # the second stream must win all rounds but one by > 1 % and the best-of-rounds by > 2 %: a host-bound line, whose step time
+    # wanders by several per cent between runs, keeps one stream (with "every round" one slow round of four steps cost a
+    # device-bound line the 4 % the second stream is worth: 15.85 / 15.15 ms best-of-rounds and still "off")
+    choice = wins >= max(rounds - 1, 1) and best[True] < 0.98 * best[False]
     wgrad_stream(choice)
     return choice, best[False], best[True]

@@ -170,7 +170,7 @@ class TsConvBlockOpts(_c.Structure):
     """include/taseg_hip.h: what a ts_conv_block_* call may use beyond the rulebook"""
     _fields_ = [("fwd_plan", _c.POINTER(TsClassPlan)), ("dgrad_plan", _c.POINTER(TsClassPlan)), ("planes", _vp),
                 ("w16_current", _i32), ("addend", _vp), ("wgrad_stream", _vp), ("wgrad_ws", _vp), ("wgrad_ws_bytes", _sz),
-                ("wgrad_slot", _i32), ("wgrad_deferred", _i32), ("w_exp", _vp)]
+                ("wgrad_slot", _i32), ("wgrad_deferred", _i32), ("w_exp", _vp), ("natural", _i32)]
 
 
 _lib = None

@@ -241,6 +241,17 @@ static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const
     return half ? ts_conv_gather_sum_f16(zz, c_out, table, kk, n_out, zrows, conv_out, stream)
                 : ts_conv_gather_sum((const float *)zz, c_out, table, kk, n_out, zrows, (float *)conv_out, stream);
   };
+  if (o.natural) {
+    // 1x1x1 convolution on the identity rulebook: the pair GEMM's rows are the result rows
+    TS_REQUIRE(K == 1 && n_pairs == n_out && n_feat_rows == n_out, TS_ERR_INVALID_ARGUMENT,
+               "ts_conv_block: a natural call needs K = 1 and one pair per row (%d offsets, %lld pairs, %lld / %lld rows)", K,
+               (long long)n_pairs, (long long)n_feat_rows, (long long)n_out);
+    if (half && !o.w16_current) TS_TRY(ts_cast_weights_f16(kernel, K, c_in, c_out, w16, nullptr, stream));
+    ProfScope ps(0, stream, (double)n_pairs, c_in, c_out, K, (double)n_feat_rows, half ? 2 : 4, 0);
+    if (half) return ts_conv_pair_gemm_f16_nat(feat, n_feat_rows, c_in, w16, K, nbmaps, nboffs, n_pairs, gather_col, conv_out, c_out, stream);
+    return ts_conv_pair_gemm((const float *)feat, n_feat_rows, c_in, kernel, K, 0, nbmaps, nboffs, n_pairs, gather_col,
+                             (float *)conv_out, c_out, stream);
+  }
   const TsClassPlan *cp = plan_fits(o.fwd_plan, K, n_out, c_in, c_out, n_pairs, nboffs) ? o.fwd_plan : nullptr;
   {
     // half storage: one half copy in the kernel's own layout serves both passes (the forward reads it through the transposing
@@ -309,7 +320,7 @@ extern "C" int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int3
                                      int32_t relu, int32_t half, void *comm, double *pack, void *conv_out, float *mean,
                                      float *invstd, void *out, uint8_t *mask, void *w16, const TsConvBlockOpts *opts, void *ws,
                                      size_t ws_bytes, ts_stream_t stream) {
-  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts none = {};
   const TsConvBlockOpts &o = opts ? *opts : none;
   PlanesScope planes(kernel, half ? nullptr : o.planes, K, c_in, c_out);
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT,
@@ -355,7 +366,7 @@ extern "C" int ts_conv_block_eval(const void *feat, int64_t n_feat_rows, int32_t
                                   const float *bn_bias, const float *mean, const float *invstd, int32_t relu, int32_t half,
                                   void *out, void *w16, const TsConvBlockOpts *opts, void *ws, size_t ws_bytes,
                                   ts_stream_t stream) {
-  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts none = {};
   const TsConvBlockOpts &o = opts ? *opts : none;
   PlanesScope planes(kernel, half ? nullptr : o.planes, K, c_in, c_out);
   TS_REQUIRE(n_pairs > 0 && n_out > 0 && c_in > 0 && c_out > 0 && K > 0, TS_ERR_INVALID_ARGUMENT, "ts_conv_block_eval: bad sizes");
@@ -396,7 +407,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
                                       int32_t wgrad_col_a, void *grad_feat, void *grad_residual, float *grad_kernel,
                                       float *grad_bn_weight, float *grad_bn_bias, const TsConvBlockOpts *opts, void *ws,
                                       size_t ws_bytes, ts_stream_t stream) {
-  const TsConvBlockOpts none = {nullptr, nullptr, nullptr, 0, nullptr};
+  const TsConvBlockOpts none = {};
   const TsConvBlockOpts &o = opts ? *opts : none;
   PlanesScope planes((const float *)weights, half ? nullptr : o.planes, K, c_in, c_out);
   const void *addend = o.addend;                // added into grad_feat's store
@@ -404,6 +415,8 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
              "ts_conv_block_backward: bad sizes");
   TS_REQUIRE(!addend || (grad_feat && (((uintptr_t)addend) & 15) == 0), TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_backward: an addend needs grad_feat and 16-byte alignment");
+  TS_REQUIRE(!o.natural || (K == 1 && n_pairs == n_out && n_dgrad_rows == n_out && n_feat_rows == n_out && !addend),
+             TS_ERR_INVALID_ARGUMENT, "ts_conv_block_backward: a natural call needs K = 1, one pair per row and no addend");
   TS_REQUIRE(ws && ws_bytes >= ts_conv_block_workspace_bytes(n_pairs, n_out, c_in, c_out, K, half), TS_ERR_INVALID_ARGUMENT,
              "ts_conv_block_backward: workspace too small");
   const size_t es = half ? 2 : 4;
@@ -494,13 +507,13 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   }
   if (side_on && !deferred) {            // the ordered sum follows on the second stream; the slot is free when it has run
     // (blocks without an input gradient sum with the stand-alone kernel's order on either path)
-    TS_TRY((grad_feat && n_dgrad_rows > 0) ? ts_wgrad_reduce_seq(job, stream) : ts_wgrad_reduce(job, stream));
+    TS_TRY((grad_feat && n_dgrad_rows > 0 && !o.natural) ? ts_wgrad_reduce_seq(job, stream) : ts_wgrad_reduce(job, stream));
     TS_CHECK_HIP(hipEventRecord(g_wg_done[o.wgrad_slot], (hipStream_t)stream), "ring record");
     g_wg_used[o.wgrad_slot].store(true);
     stream = main_stream;
   }
-  const bool ride = det && grad_feat && n_dgrad_rows > 0 && !side_on;
-  const TsClassPlan *cp = (grad_feat && plan_fits(o.dgrad_plan, K, n_dgrad_rows, c_out, c_in, n_pairs, nboffs) &&
+  const bool ride = det && grad_feat && n_dgrad_rows > 0 && !side_on && !o.natural;     // (a natural call has no pass 2 to ride on)
+  const TsClassPlan *cp = (grad_feat && !o.natural && plan_fits(o.dgrad_plan, K, n_dgrad_rows, c_out, c_in, n_pairs, nboffs) &&
                            !(o.dgrad_plan->rows && addend))
                               ? o.dgrad_plan
                               : nullptr;
@@ -535,6 +548,15 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
         TS_TRY(ts_conv_gather_sum_ex((const float *)z, c_in, cp->pos, cp->groups, n_dgrad_rows, cp->m_pad, (float *)grad_feat,
                                      ride ? &job : nullptr, (const float *)addend, stream));
     }
+  } else if (grad_feat && o.natural) {
+    // identity rulebook: the rows of the product through W^T are the input gradient's rows
+    ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, 1);
+    if (half)
+      TS_TRY(ts_conv_pair_gemm_f16(grad_conv, n_out, c_out, weights, K, nbmaps, nboffs, n_pairs, dgrad_gather_col, grad_feat, c_in,
+                                   stream));
+    else
+      TS_TRY(ts_conv_pair_gemm((const float *)grad_conv, n_out, c_out, (const float *)weights, K, 1, nbmaps, nboffs, n_pairs,
+                               dgrad_gather_col, (float *)grad_feat, c_in, stream));
   } else if (grad_feat) {
     {
       ProfScope ps(0, stream, (double)n_pairs, c_out, c_in, K, (double)n_out, es_d, 1);

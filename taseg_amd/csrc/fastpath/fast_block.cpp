@@ -230,7 +230,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const std::vector<int64_t> &plan_f_meta, const c10::optional<at::Tensor> &pd0,
                             const c10::optional<at::Tensor> &pd1, const c10::optional<at::Tensor> &pd2,
                             const c10::optional<at::Tensor> &pd3, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok,
-                            const c10::optional<at::Tensor> &wexp) {
+                            const c10::optional<at::Tensor> &wexp, bool natural) {
     // a backward pass that died mid-way leaves its join behind: nothing of the second stream outlives the next forward call
     if (wg_join_queued.exchange(false)) {
       wg_worker.drain();
@@ -240,7 +240,10 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     std::vector<at::Tensor> plan_f, plan_d;
     if (pf0.has_value() && pf0->defined()) plan_f = {*pf0, *pf1, *pf2, *pf3};
     if (pd0.has_value() && pd0->defined()) plan_d = {*pd0, *pd1, *pd2, *pd3};
-    const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
+    // a 1x1x1 convolution's weight is [C_in, C_out] (conv.py:135-140); it comes with the identity rulebook and natural = true
+    const bool flat = weight.dim() == 2;
+    TORCH_CHECK(flat == natural, "conv_block: a [C_in, C_out] weight goes with the identity rulebook (natural) and vice versa");
+    const int64_t k = flat ? 1 : weight.size(0), c_in = weight.size(flat ? 0 : 1), c_out = weight.size(flat ? 1 : 2);
     const bool split = comm == 0 && group_id >= 0;
     const auto dt = half ? at::kHalf : at::kFloat;
     const int64_t rows = transposed ? n_in : n_out;
@@ -272,7 +275,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor wx;
     if (!half && own_weight && wexp.has_value() && wexp->defined() && wexp->scalar_type() == at::kInt && wexp->numel() == k) wx = *wexp;
     TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0,
-                             wx.defined() ? (const int32_t *)wx.data_ptr() : nullptr};
+                             wx.defined() ? (const int32_t *)wx.data_ptr() : nullptr, natural ? 1 : 0};
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
@@ -300,6 +303,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     ctx->saved_data["wexp"] = wx;            // (not a graph tensor: refreshed in place when the optimizer has stepped)
     // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
     ctx->saved_data["grad_dest"] = (grad_dest.has_value() && grad_dest->defined()) ? *grad_dest : at::Tensor();
+    ctx->saved_data["natural"] = natural;
     ctx->saved_data["total"] = total;
     ctx->saved_data["n_in"] = n_in;
     ctx->saved_data["n_out"] = n_out;
@@ -329,7 +333,9 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                has_res = ctx->saved_data["has_res"].toBool();
     const auto in_dtype = (at::ScalarType)ctx->saved_data["in_dtype"].toInt();
     const auto res_dtype = (at::ScalarType)ctx->saved_data["res_dtype"].toInt();
-    const int64_t k = w.size(0), c_in = w.size(1), c_out = w.size(2), rows = conv_out.size(0);
+    const bool natural = ctx->saved_data["natural"].toBool();
+    const bool flat = w.dim() == 2;                      // (the fp32 weight of a 1x1x1 convolution; its half copy is [1, C_in, C_out])
+    const int64_t k = flat ? 1 : w.size(0), c_in = w.size(flat ? 0 : 1), c_out = w.size(flat ? 1 : 2), rows = conv_out.size(0);
     const int64_t stream = ctx->saved_data["stream"].toInt();   // the engine runs a node on its forward stream
     TORCH_CHECK(grads[0].defined(), "conv_block: the block's output received no gradient");
     at::Tensor g = grads[0].contiguous().to(conv_out.scalar_type());
@@ -340,11 +346,12 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     if (ctx->needs_input_grad(0)) grad_feat = at::empty({drows, c_in}, opts);
     if (ctx->needs_input_grad(1)) {
       const at::Tensor dest = ctx->saved_data["grad_dest"].toTensor();
-      if (dest.defined() && dest.scalar_type() == at::kFloat && dest.is_contiguous() && dest.dim() == 3 && dest.size(0) == k &&
-          dest.size(1) == c_in && dest.size(2) == c_out && dest.device() == conv_out.device())
+      const std::vector<int64_t> wshape = natural ? std::vector<int64_t>{c_in, c_out} : std::vector<int64_t>{k, c_in, c_out};
+      if (dest.defined() && dest.scalar_type() == at::kFloat && dest.is_contiguous() && dest.sizes().vec() == wshape &&
+          dest.device() == conv_out.device())
         grad_w = dest.alias();             // a fresh alias of the bucket slot: autograd adopts it as p.grad, no copy
       else
-        grad_w = at::empty({k, c_in, c_out}, opts.dtype(at::kFloat));
+        grad_w = at::empty(wshape, opts.dtype(at::kFloat));
     }
     if (has_res && ctx->needs_input_grad(2)) grad_res = at::empty_like(conv_out);
     at::Tensor gwb = at::empty({2, c_out}, opts.dtype(at::kFloat));
@@ -361,7 +368,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const PlanRef pd(grad_feat.defined() ? plan_d : std::vector<at::Tensor>(), plan_d_meta, nboffs);
     const at::Tensor wx = ctx->saved_data["wexp"].toTensor();
     TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0,
-                             (wx.defined() && !half) ? (const int32_t *)wx.data_ptr() : nullptr};
+                             (wx.defined() && !half) ? (const int32_t *)wx.data_ptr() : nullptr, natural ? 1 : 0};
     std::function<void()> side_job;
     if (wg_side.on && ctx->saved_data["wgrad_side_ok"].toBool() && grad_w.defined() && !comm && !split &&
         x.get_device() == wg_side.device_index && stream != wg_side.raw && (c_in * c_out) % 4 == 0 &&
@@ -392,7 +399,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
         float *const gw_ptr = (float *)grad_w.data_ptr();
         const ts_stream_t side_raw = bopts.wgrad_stream;
         const int64_t n_feat = x.size(0);
-        const int32_t col_a = transposed ? 1 : 0, chunk_order = grad_feat.defined() && drows > 0 ? 1 : 0;
+        const int32_t col_a = transposed ? 1 : 0, chunk_order = (grad_feat.defined() && drows > 0 && !natural) ? 1 : 0;
         side_job = [=]() {
           check(api.wgrad_side(xk.data_ptr(), n_feat, (int32_t)c_in, (int32_t)k, (const int32_t *)nbk.data_ptr(),
                                (const int32_t *)nok.data_ptr(), total, col_a, rows, (int32_t)c_out, half ? 1 : 0,
@@ -426,6 +433,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     }
     at::Tensor addend;                   // gradient of the passed-through input, in grad_feat's storage type
     if (grads.size() > 1 && grads[1].defined() && grad_feat.defined()) {
+      TORCH_CHECK(!natural, "conv_block: a 1x1x1 block does not pass its input through");
       addend = grads[1].contiguous().to(conv_out.scalar_type());
       TORCH_CHECK(addend.sizes() == grad_feat.sizes(), "conv_block: pass-through gradient has the wrong shape");
       bopts.addend = addend.data_ptr();
@@ -437,7 +445,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     at::Tensor none;
     return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -482,15 +490,18 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
                       const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta,
                       const std::vector<at::Tensor> &plan_d, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok,
-                      const c10::optional<at::Tensor> &wexp) {
+                      const c10::optional<at::Tensor> &wexp, bool natural) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  TORCH_CHECK(!natural || (!passthrough && !transposed && plan_f.empty() && plan_d.empty() && n_in == n_out && total == n_out),
+              "conv_block: a natural (1x1x1, identity rulebook) block takes no plans, no pass-through and one pair per row");
   TORCH_CHECK((plan_f.empty() || plan_f.size() == 4) && (plan_d.empty() || plan_d.size() == 4),
               "conv_block: a plan is (src, tile_info, n_tiles, pos | rows)");
   auto at_ = [](const std::vector<at::Tensor> &v, size_t i) { return v.size() == 4 ? c10::optional<at::Tensor>(v[i]) : c10::nullopt; };
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
                           passthrough, grad_dest, group_id, at_(plan_f, 0), at_(plan_f, 1), at_(plan_f, 2), at_(plan_f, 3),
-                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta, wgrad_side_ok, wexp);
+                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta, wgrad_side_ok, wexp,
+                          natural);
 }
 
 // Evaluation form of the block (eval-mode BatchNorm on its running statistics, no graph): ts_conv_block_eval without the
@@ -502,10 +513,14 @@ at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, co
                            const at::Tensor &pos_out, const at::Tensor &pos_in, int64_t n_in, int64_t n_out, bool transposed,
                            bool relu, bool half, int64_t stream, const c10::optional<at::Tensor> &planes,
                            const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta,
-                           const c10::optional<at::Tensor> &wexp) {
+                           const c10::optional<at::Tensor> &wexp, bool natural) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   at::NoGradGuard nograd;
-  const int64_t k = weight.size(0), c_in = weight.size(1), c_out = weight.size(2);
+  const bool flat = weight.dim() == 2;
+  TORCH_CHECK(flat == natural, "conv_block_eval: a [C_in, C_out] weight goes with the identity rulebook (natural) and vice versa");
+  TORCH_CHECK(!natural || (!transposed && plan_f.empty() && n_in == n_out && total == n_out),
+              "conv_block_eval: a natural (1x1x1, identity rulebook) block takes no plan and one pair per row");
+  const int64_t k = flat ? 1 : weight.size(0), c_in = weight.size(flat ? 0 : 1), c_out = weight.size(flat ? 1 : 2);
   const auto dt = half ? at::kHalf : at::kFloat;
   const int64_t rows = transposed ? n_in : n_out;
   const at::Tensor &table = transposed ? pos_in : pos_out;
@@ -526,7 +541,7 @@ at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, co
   const bool wx_ok = !half && w32.data_ptr() == weight.data_ptr() && wexp.has_value() && wexp->defined() &&
                      wexp->scalar_type() == at::kInt && wexp->numel() == k;
   TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0,
-                           wx_ok ? (const int32_t *)wexp->data_ptr() : nullptr};
+                           wx_ok ? (const int32_t *)wexp->data_ptr() : nullptr, natural ? 1 : 0};
   check(api.eval(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
                  (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0, (const int32_t *)table.data_ptr(), rows,
                  (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(), (const float *)bn_bias.data_ptr(),

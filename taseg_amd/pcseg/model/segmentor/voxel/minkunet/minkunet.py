@@ -101,7 +101,9 @@ class ResidualBlock(nn.Module):
         # relu(net(x) + downsample(x)) with the BN / add / ReLU tails fused (same module parameters / buffers)
         # (the first block hands x through: the shortcut's gradient then lands in the store of conv1's input gradient)
         h, x = spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True, passthrough=True)
-        shortcut = x if isinstance(self.downsample, nn.Identity) else self.downsample(x)
+        # (the 1x1x1 shortcut + its BatchNorm: one block call on the identity rulebook, spnn.conv_bn_act)
+        shortcut = x if isinstance(self.downsample, nn.Identity) else \
+            spnn.conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
         return spnn.conv_bn_act(self.net[3], self.net[4], h, relu=True, residual=shortcut)
 
 
@@ -402,7 +404,9 @@ class PendingPredictions:
         bad, cnt_p_h, cnt_k_h = int(meta[0]), meta[1:1 + n].tolist(), meta[1 + n:1 + 2 * n].tolist()
         cnt_l_h = meta[1 + 2 * n:1 + 3 * n].tolist()
         n_cur_h = meta[1 + 3 * n:1 + 4 * n].tolist()
-        if bad:
+        if bad & 2:
+            raise IndexError(f"batch indices beyond the {n} scenes of the batch")
+        if bad & 1:
             raise IndexError("inverse_map names a voxel outside its scene")
         if self.has_ms:
             n_ms_h = meta[1 + 4 * n:1 + 5 * n].tolist()
@@ -439,31 +443,42 @@ def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_pr
     dev = out.device
     b_vox, b_pts, b_lab = vox_batch.long(), invs.C[:, -1].long(), all_labels.C[:, -1].long()
     n_scenes = len(names) if names is not None else int(torch.as_tensor(num_points).numel())
-    cnt_v = torch.bincount(b_vox, minlength=n_scenes)
-    cnt_p, cnt_l = torch.bincount(b_pts, minlength=n_scenes), torch.bincount(b_lab, minlength=n_scenes)
-    if not (cnt_v.shape[0] == cnt_p.shape[0] == cnt_l.shape[0] == n_scenes):
-        raise IndexError(f"batch indices beyond the {n_scenes} scenes of the batch")       # (shapes are host-side: no device read)
-    # stable sorts by scene: 8-bit keys where the batch allows it (one radix pass instead of the eight of a 64-bit key)
-    narrow = (lambda t: t.to(torch.uint8)) if n_scenes <= 255 else (lambda t: t)
-    order_v = torch.sort(narrow(b_vox), stable=True)[1]    # out[scene] = out[order_v[start : start + count]] (original order kept)
+    # stable sorts by scene: 8-bit keys where the batch allows it (one radix pass instead of the eight of a 64-bit key; an index
+    # outside 0 .. 254 wraps to a value that is still >= n_scenes or lands in the wrong scene's count - both are reported below)
+    narrow = (lambda t: t.clamp(-1, 255).to(torch.uint8)) if n_scenes < 255 else (lambda t: t)
+    bv_sorted, order_v = torch.sort(narrow(b_vox), stable=True)   # out[scene] = out[order_v[start : start + count]] (original order kept)
     bp_sorted, order_p = torch.sort(narrow(b_pts), stable=True)
+    bl_sorted, order_l = torch.sort(narrow(b_lab), stable=True)
+    # rows per scene from the SORTED keys (torch.bincount reads the largest index on the host: with four of them the "deferred" tail
+    # waited for the forward pass four times per batch - the host issue time of bench.py --eval was 2.3 ms of bincount)
+    edges = torch.arange(n_scenes + 1, device=dev)
+
+    def counts(sorted_keys):
+        at = torch.searchsorted(sorted_keys.long(), edges)
+        # (second value: rows whose scene index is outside 0 .. n_scenes - 1 - the reference's boolean masks would drop them
+        # silently and fail on the shapes later; reported when the arrays are collected)
+        return at[1:] - at[:-1], (at[0] != 0) | (at[-1] != sorted_keys.shape[0])
+    cnt_v, out_v = counts(bv_sorted)
+    cnt_p, out_p = counts(bp_sorted)
+    cnt_l, out_l = counts(bl_sorted)
     bp_sorted = bp_sorted.long()
-    order_l = torch.sort(narrow(b_lab), stable=True)[1]
     start_v = torch.cumsum(cnt_v, 0) - cnt_v
     local = invs.F[order_p].long()
-    bad = ((local < 0) | (local >= cnt_v[bp_sorted])).any()           # read with the counts (the reference's indexing raises)
-    rows = order_v[(start_v[bp_sorted] + local).clamp_(0, max(int(order_v.shape[0]) - 1, 0))]
+    scene_p = bp_sorted.clamp(0, n_scenes - 1)
+    bad = ((local < 0) | (local >= cnt_v[scene_p])).any()           # read with the counts (the reference's indexing raises)
+    rows = order_v[(start_v[scene_p] + local).clamp_(0, max(int(order_v.shape[0]) - 1, 0))]
     mapped = out[rows]                                      # [points, classes], scene-major, the scene's own point order
-    kept_scene = bp_sorted
+    cnt_k = cnt_p
     if point_mask is not None:
         keep = point_mask.to(dev).bool()
-        mapped, kept_scene = mapped[keep], bp_sorted[keep]
-    cnt_k = torch.bincount(kept_scene, minlength=n_scenes)
+        mapped, kept_scene = mapped[keep], bp_sorted[keep]          # (boolean indexing: one host read, Ms models only)
+        cnt_k, _ = counts(kept_scene)
     result = mapped.softmax(1) if want_probs else mapped.argmax(1)
     labels_sorted = all_labels.F[order_l]
     # one small tensor with everything the per-scene slicing needs, then the arrays themselves: asynchronous copies into page-locked
     # buffers, one event behind them
-    parts = [bad.reshape(1).long(), cnt_p.long(), cnt_k.long(), cnt_l.long(),
+    code = bad.long() + 2 * (out_v | out_p | out_l).long()      # bit 0: inverse map outside its scene; bit 1: scene index outside the batch
+    parts = [code.reshape(1), cnt_p.long(), cnt_k.long(), cnt_l.long(),
              torch.as_tensor(num_points).reshape(-1)[:n_scenes].to(dev, non_blocking=True).long()]
     if num_points_ms is not None:
         parts.append(torch.as_tensor(num_points_ms).reshape(-1)[:n_scenes].to(dev, non_blocking=True).long())

@@ -84,7 +84,8 @@ def _refresh(stream, device, entries=None, fn="ts_conv_split_planes_batch"):
         if w.device != device:
             continue
         if not e.fresh(w, stream):
-            jobs.append((w.data_ptr(), e.planes.data_ptr(), w.shape[0], w.shape[1], w.shape[2]))
+            k, c_in, c_out = w.shape if w.dim() == 3 else (1, w.shape[0], w.shape[1])      # (1x1x1 weights are [C_in, C_out])
+            jobs.append((w.data_ptr(), e.planes.data_ptr(), k, c_in, c_out))
             done.append((e, w))
     if not jobs:
         return
@@ -115,9 +116,10 @@ def planes_for(weight):
 
 
 def eligible_half(weight) -> bool:
-    """fp32 [K, C_in, C_out] parameter on a ROCm device that the half-storage block call can take a kept copy of."""
-    return (_ENABLED and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 3 and weight.is_contiguous()
-            and (weight.shape[1] * weight.shape[2]) % 8 == 0 and weight.data_ptr() % 16 == 0)
+    """fp32 [K, C_in, C_out] (1x1x1: [C_in, C_out]) parameter on a ROCm device that the half-storage block call can take a kept
+    copy of."""
+    return (_ENABLED and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() in (2, 3) and weight.is_contiguous()
+            and (weight.shape[-2] * weight.shape[-1]) % 8 == 0 and weight.data_ptr() % 16 == 0)
 
 
 def half_for(weight):

@@ -703,6 +703,52 @@ def _identity_rows(n, dev):
     return hit
 
 
+class IdentityMap:
+    """The identity rulebook of a 1x1x1 convolution over n rows (pair p = (p, p), one offset) with the attributes of a KernelMap
+    that the block calls read: the shortcut branch of a residual block (minkunet.py:105-111) then runs as ONE block call per
+    direction (csrc/block.hip, TsConvBlockOpts.natural) instead of a GEMM node + a BatchNorm node.  Cached per (n, device) like
+    `_identity_rows`."""
+    __slots__ = ("nbmaps_buf", "nboffs", "total", "pos_out", "pos_in", "sizes")
+
+    def __init__(self, n, dev):
+        pairs, offs = _identity_rows(n, dev)
+        self.nbmaps_buf, self.nboffs, self.total = pairs, offs, n
+        self.pos_out = self.pos_in = pairs         # never read by a natural call (any valid int32 pointer)
+        self.sizes = (n, n)
+
+    def plans_for(self, transposed, c_in, c_out, half):
+        return None, None
+
+
+_ident_maps = {}
+
+
+def identity_map(n, dev) -> IdentityMap:
+    key = (int(n), dev.type, dev.index)
+    hit = _ident_maps.get(key)
+    if hit is None:
+        if len(_ident_maps) >= 32:
+            _ident_maps.pop(next(iter(_ident_maps)))
+        hit = _ident_maps[key] = IdentityMap(n, dev)
+    return hit
+
+
+def pointwise_block_ok(feats: torch.Tensor, weight: torch.Tensor, residual) -> bool:
+    """Can the block call serve this 1x1x1 convolution + BatchNorm (identity rulebook, full-tile channel counts)?"""
+    if not (feats.is_cuda and weight.dim() == 2 and feats.dim() == 2 and weight.is_cuda and weight.dtype == torch.float32):
+        return False
+    half = _amp_half(feats)
+    c_in, c_out = weight.shape
+    if not _dense_ok(c_in, c_out) or (half and not _half_ok(c_in, c_out)):
+        return False
+    if not half and feats.dtype != torch.float32:
+        return False
+    n = feats.shape[0]
+    if c_out > 1024 or n <= 0 or feats.shape[1] != c_in:
+        return False
+    return residual is None or tuple(residual.shape) == (n, c_out)
+
+
 def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias: Optional[torch.Tensor] = None,
            stride: Union[int, List[int], Tuple[int, ...]] = 1, dilation: Union[int, Tuple[int, ...]] = 1,
            transposed: bool = False, planes: Optional[torch.Tensor] = None) -> SparseTensor:
@@ -771,12 +817,18 @@ _COMM_PRE, _COMM_POST = _ctypes.c_void_p(1), _ctypes.c_void_p(2)      # split-ca
 from ...rccl import c10d_sum as _c10d_sum  # noqa: E402
 
 
-def _block_opts(plan_f, plan_d, planes, w16_current, addend, w_exp=None):
+def _block_opts(plan_f, plan_d, planes, w16_current, addend, w_exp=None, natural=False):
     """TsConvBlockOpts of one block call (the struct only holds pointers: the caller keeps the tensors alive over the call)"""
     LB = B.L
     pf = None if plan_f is None else _ctypes.pointer(B.class_plan_struct(plan_f))
     pd = None if plan_d is None else _ctypes.pointer(B.class_plan_struct(plan_d))
-    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend), None, None, 0, 0, 0, LB.ptr(w_exp))
+    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend), None, None, 0, 0, 0, LB.ptr(w_exp),
+                              1 if natural else 0)
+
+
+def _kcc(weight):
+    """(K, C_in, C_out) of a convolution weight; a 1x1x1 weight is [C_in, C_out] (conv.py:135-140)"""
+    return (1, weight.shape[0], weight.shape[1]) if weight.dim() == 2 else tuple(weight.shape)
 
 
 class _ConvBlock(Function):
@@ -791,7 +843,8 @@ class _ConvBlock(Function):
         lib = B.L.load()
         L = B.L
         n_in, n_out = kmap.sizes
-        k, c_in, c_out = weight.shape
+        k, c_in, c_out = _kcc(weight)
+        natural = weight.dim() == 2              # 1x1x1 on the identity rulebook (IdentityMap): TsConvBlockOpts.natural
         gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
         dt = torch.float16 if half else torch.float32
         x = feats.contiguous().to(dt)
@@ -821,7 +874,7 @@ class _ConvBlock(Function):
         if not half and (plan_f is not None or plan_d is not None) and w32.data_ptr() == weight.data_ptr():
             wexp = _planes.exps_for(weight)
         ctx.wexp = wexp
-        opts = _block_opts(plan_f, plan_d, None if half else planes, half and planes is not None, None, wexp)
+        opts = _block_opts(plan_f, plan_d, None if half else planes, half and planes is not None, None, wexp, natural)
 
         def call(c):
             L.check(lib.ts_conv_block_forward(
@@ -841,6 +894,7 @@ class _ConvBlock(Function):
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
         ctx.group = group if split else None
         ctx.planes = None if half else planes
+        ctx.natural, ctx.wshape = natural, tuple(weight.shape)
         ctx.plan_d = plan_d
         ctx.grad_dest = grad_dest        # where the weight gradient is wanted (a gradient bucket's view), or None
         ctx.total_dev = None if pack is None else pack[2 * c_out:]
@@ -856,7 +910,7 @@ class _ConvBlock(Function):
         lib = B.L.load()
         L = B.L
         n_in, n_out = kmap.sizes
-        k, c_in, c_out = w.shape
+        k, c_in, c_out = _kcc(w)
         rows = conv_out.shape[0]
         dt = conv_out.dtype
         dev = x.device
@@ -868,11 +922,11 @@ class _ConvBlock(Function):
         grad_w = None
         if need[1]:
             dest = ctx.grad_dest
-            if (dest is not None and dest.dtype == torch.float32 and dest.is_contiguous() and tuple(dest.shape) == (k, c_in, c_out)
+            if (dest is not None and dest.dtype == torch.float32 and dest.is_contiguous() and tuple(dest.shape) == ctx.wshape
                     and dest.device == dev):
                 grad_w = dest.view_as(dest)      # a fresh alias of the bucket slot: autograd adopts it as p.grad, no copy
             else:
-                grad_w = torch.empty((k, c_in, c_out), dtype=torch.float32, device=dev)
+                grad_w = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
         grad_res = torch.empty_like(conv_out) if (ctx.res_dtype is not None and need[2]) else None
         gwb = torch.empty((2, c_out), dtype=torch.float32, device=dev)
         split = ctx.group is not None
@@ -882,7 +936,7 @@ class _ConvBlock(Function):
 
         addend = grad_pass.contiguous().to(dt) if (grad_pass is not None and grad_feat is not None) else None
         opts = _block_opts(None, ctx.plan_d if grad_feat is not None else None, None if half else ctx.planes, False, addend,
-                           None if half else ctx.wexp)
+                           None if half else ctx.wexp, ctx.natural)
 
         def call(c):
             L.check(lib.ts_conv_block_backward(
@@ -911,7 +965,7 @@ def conv_block_eval(feats, weight, residual, bn_weight, bn_bias, mean, invstd, k
     lib = B.L.load()
     L = B.L
     n_in, n_out = kmap.sizes
-    k, c_in, c_out = weight.shape
+    k, c_in, c_out = _kcc(weight)
     gcol, table, rows = (1, kmap.pos_in, n_in) if transposed else (0, kmap.pos_out, n_out)
     dt = torch.float16 if half else torch.float32
     x = feats.contiguous().to(dt)
@@ -926,7 +980,7 @@ def conv_block_eval(feats, weight, residual, bn_weight, bn_bias, mean, invstd, k
     ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
     plan_f, _ = kmap.plans_for(transposed, c_in, c_out, half)
     wexp = _planes.exps_for(weight) if (not half and plan_f is not None and w32.data_ptr() == weight.data_ptr()) else None
-    opts = _block_opts(plan_f, None, None if half else planes, half and planes is not None, None, wexp)
+    opts = _block_opts(plan_f, None, None if half else planes, half and planes is not None, None, wexp, weight.dim() == 2)
     L.check(lib.ts_conv_block_eval(
         L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), rows,
         c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(mean), L.ptr(invstd), 1 if relu else 0, 1 if half else 0,

@@ -17,6 +17,8 @@ __all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act"
 
 
 _FUSED_BLOCK = os.environ.get("TASEG_FUSED_BLOCK", "1") != "0"
+# the 1x1x1 shortcut + its BatchNorm as one block call on the identity rulebook (_pointwise_bn_act); 0: GEMM node + BatchNorm node
+_POINTWISE_BLOCK = os.environ.get("TASEG_POINTWISE_BLOCK", "1") != "0"
 
 
 class Conv3d(nn.Module):
@@ -181,6 +183,56 @@ def _eval_invstd(mod):
     return hit[2]
 
 
+def _pointwise_bn_act(conv, mod, input: SparseTensor, relu, residual):
+    """relu(BN(conv(input)) [+ residual]) for a 1x1x1 convolution (conv.py:135-140: a dense GEMM over the rows) as one native block
+    call per direction on the identity rulebook - the shortcut of a residual block (minkunet.py:105-111); None when the block
+    call does not apply (the caller then chains the modules)."""
+    ones = (1, 1, 1)
+    fast = _fast.module()
+    if conv.bias is not None or make_ntuple(conv.stride, ndim=3) != ones \
+            or make_ntuple(conv.dilation, ndim=3) != ones or conv.transposed or not mod.affine \
+            or conv._forward_hooks or conv._forward_pre_hooks:
+        return None
+    feats = input.feats
+    res = None if residual is None else residual.feats
+    if not F.pointwise_block_ok(feats, conv.kernel, res) or mod.weight.dtype != torch.float32:
+        return None
+    half = F._amp_half(feats)
+    n = feats.shape[0]
+    imap = F.identity_map(n, feats.device)
+    w16 = _planes.half_for(conv.kernel) if half else None
+    if not mod.training and not torch.is_grad_enabled() and mod.track_running_stats and mod.running_var is not None \
+            and mod.running_mean.dtype == torch.float32 and not (mod._forward_hooks or mod._forward_pre_hooks):
+        if fast is not None:
+            out = fast.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod),
+                                       imap.nbmaps_buf, imap.nboffs, n, imap.pos_out, imap.pos_in, n, n, False, relu, half,
+                                       _B.L.stream(), w16, [], [], None, True)
+        else:
+            out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), imap,
+                                    False, relu, half, w16)
+        return input._like(out)
+    if not (mod.training and torch.is_grad_enabled() and mod.momentum is not None):
+        return None
+    from ...rccl import direct_comm
+    group = _sync_group(mod)
+    _require_rows(feats, group)
+    comm = None if group is None else direct_comm(group)
+    track = mod.track_running_stats
+    if fast is None:
+        state = (mod.running_mean if track else None, mod.running_var if track else None,
+                 mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
+        out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, imap, False, state, relu, comm, half, w16, False,
+                                 _claim_grad_dest(conv.kernel), group if (group is not None and comm is None) else None)
+        return input._like(out)
+    out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, imap.nbmaps_buf, imap.nboffs, n, imap.pos_out,
+                          imap.pos_in, n, n, False, mod.running_mean if track else None, mod.running_var if track else None,
+                          mod.num_batches_tracked if track else None, float(mod.momentum), float(mod.eps), relu,
+                          (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), w16, False,
+                          _claim_grad_dest(conv.kernel), _group_id(fast, group if (group is not None and comm is None) else None),
+                          [], [], [], [], conv.kernel.grad is None, None, True)
+    return input._like(out[0])
+
+
 def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, residual: SparseTensor = None,
                 passthrough: bool = False):
     """relu(BN(conv(input)) [+ residual]) for a Conv3d and its BatchNorm / SyncBatchNorm module: one autograd node and
@@ -196,6 +248,11 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     ones = (1, 1, 1)
     ks, stride = conv.kernel_size, conv.stride
     dil = make_ntuple(conv.dilation, ndim=3)
+    if ks == ones:
+        out = _pointwise_bn_act(conv, mod, input, relu, residual) if (_FUSED_BLOCK and _POINTWISE_BLOCK and not passthrough) else None
+        if out is None:
+            out = bn_act(mod, conv(input), relu=relu, residual=residual)
+        return (out, input) if passthrough else out
     if _FUSED_BLOCK and conv.bias is None and ks != ones and not mod.training and not torch.is_grad_enabled() and mod.affine \
             and mod.track_running_stats and mod.running_var is not None \
             and not (conv._forward_hooks or conv._forward_pre_hooks or mod._forward_hooks or mod._forward_pre_hooks):
@@ -214,7 +271,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 out = fast.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod),
                                            kmap.nbmaps_buf, kmap.nboffs, kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out,
                                            conv.transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f),
-                                           None if (half or plan_f is None) else _planes.exps_for(conv.kernel))
+                                           None if (half or plan_f is None) else _planes.exps_for(conv.kernel), False)
             else:
                 out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), kmap,
                                         conv.transposed, relu, half, planes)
@@ -251,7 +308,8 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                                       bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d),
                                       conv.kernel.grad is None,
                                       # per-offset weight exponents: the fp32 class products on three half MFMAs (planes.exps_for)
-                                      None if (half or (plan_f is None and plan_d is None)) else _planes.exps_for(conv.kernel))
+                                      None if (half or (plan_f is None and plan_d is None)) else _planes.exps_for(conv.kernel),
+                                      False)
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
                 out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,

@@ -596,6 +596,93 @@ def test_residual_block_passes_its_input_through(monkeypatch, node, inc, outc):
     assert all(torch.equal(a, b) for a, b in zip(pa, pb))
 
 
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("node", ["native", "python"])
+def test_pointwise_shortcut_block_equals_the_module_chain(monkeypatch, node, amp):
+    """The 1x1x1 shortcut of a residual block (minkunet.py:105-111; conv.py:135-140: `feats.matmul(weight)`) + its BatchNorm as ONE
+    block call per direction on the identity rulebook (TsConvBlockOpts.natural: the pair GEMM's rows are the result rows) against
+    the chained modules (Conv3d -> BatchNorm, torch.matmul reference): training output, all gradients, running statistics, and the
+    evaluation form; the C++ node and the Python node issue the same call."""
+    from taseg_amd import _fast
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import ResidualBlock
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.nn import modules as M
+    import taseg_amd.backend as B
+    if node == "native" and _fast.module() is None:
+        pytest.skip("taseg_amd/_fast_block.so has not been built")
+
+    def pin_node():
+        if node == "python":
+            monkeypatch.setattr(_fast, "_mod", None)
+            monkeypatch.setattr(_fast, "_tried", True)
+    inc, outc = 96, 64
+    rs = np.random.RandomState(11)
+    c = np.unique(rs.randint(0, 28, size=(9000, 3)), axis=0).astype(np.int32)
+    coords = torch.from_numpy(np.concatenate([c, np.zeros((len(c), 1), np.int32)], 1)).cuda()
+    feats = torch.from_numpy(rs.randn(len(c), inc).astype(np.float32)).cuda()
+    gout = torch.from_numpy(rs.randn(len(c), outc).astype(np.float32)).cuda()
+
+    def run(fused, train=True):
+        pin_node()
+        monkeypatch.setattr(M, "_FUSED_BLOCK", fused)
+        torch.manual_seed(0)
+        block = ResidualBlock(inc, outc).cuda()
+        with torch.no_grad():
+            block.downsample[1].weight.uniform_(0.5, 1.5)
+            block.downsample[1].bias.uniform_(-0.5, 0.5)
+        block.train(train)
+        x = feats.clone().requires_grad_(train)
+        B.profile_begin(expected_launches=200)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp), torch.set_grad_enabled(train):
+            sc = M.conv_bn_act(block.downsample[0], block.downsample[1], SparseTensor(x, coords, 1), relu=False)
+        if train:
+            sc.F.float().backward(gout)
+        recs = B.profile_end()
+        bn = block.downsample[1]
+        monkeypatch.undo()
+        out = [sc.F.detach().float().clone(), bn.running_mean.clone(), bn.running_var.clone()]
+        if train:
+            out += [x.grad.clone(), block.downsample[0].kernel.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()]
+        return out, recs
+
+    for train in (True, False):
+        a, ra = run(True, train)
+        b, _ = run(False, train)
+        # dense reference of the forward: BatchNorm (batch / running statistics) of feats @ W
+        torch.manual_seed(0)
+        ref_block = ResidualBlock(inc, outc).cuda()
+        w = ref_block.downsample[0].kernel.detach().double()
+        z = feats.double() @ w
+        tol = 2e-2 if amp else 2e-5
+        for u, v in zip(a, b):
+            assert u.shape == v.shape
+            scale = max(1.0, float(v.abs().max()))
+            assert float((u - v).abs().max()) <= tol * scale, (train, float((u - v).abs().max()), scale)
+        if train:
+            mean, var = z.mean(0), z.var(0, unbiased=False)
+            assert float((a[1].double() - 0.1 * mean).abs().max()) <= (5e-3 if amp else 1e-5)
+            # one pair GEMM per direction, no pass 2, one weight gradient in the fused form
+            kinds = sorted(r[0] for r in ra)
+            assert kinds == ["conv_wgrad", "pair_gemm", "pair_gemm"], kinds
+    # both nodes: same call, same bits
+    if node == "native":
+        a, _ = run(True, True)
+        monkeypatch.setattr(_fast, "_mod", None)
+        monkeypatch.setattr(_fast, "_tried", True)
+        monkeypatch.setattr(M, "_FUSED_BLOCK", True)
+        torch.manual_seed(0)
+        block = ResidualBlock(inc, outc).cuda().train()
+        with torch.no_grad():
+            block.downsample[1].weight.uniform_(0.5, 1.5)
+            block.downsample[1].bias.uniform_(-0.5, 0.5)
+        x = feats.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            sc = M.conv_bn_act(block.downsample[0], block.downsample[1], SparseTensor(x, coords, 1), relu=False)
+        sc.F.float().backward(gout)
+        assert torch.equal(sc.F.detach().float(), a[0]) and torch.equal(x.grad, a[3])
+        assert torch.equal(block.downsample[0].kernel.grad, a[4])
+
+
 def test_weight_gradient_bucket_slot_is_handed_out_once_per_step():
     """The conv block's backward writes its weight gradient straight into the parameter's gradient-bucket slot (a full
     overwrite that autograd adopts as p.grad).  That is only sound while nothing has been accumulated for the step: a
@@ -777,8 +864,8 @@ def test_block_backward_launches_its_weight_gradient_on_a_second_stream_itself(m
     state = {"on": False, "slot": 0, "used": 0}
     plain = F._block_opts
 
-    def opts_with_side(plan_f, plan_d, planes, w16_current, addend, w_exp=None):
-        o = plain(plan_f, plan_d, planes, w16_current, addend, w_exp)
+    def opts_with_side(plan_f, plan_d, planes, w16_current, addend, w_exp=None, natural=False):
+        o = plain(plan_f, plan_d, planes, w16_current, addend, w_exp, natural)
         if state["on"] and plan_f is None:              # a backward call (the forward passes its forward plan or builds none: see below)
             slot = state["slot"] = (state["slot"] + 1) % 8
             o.wgrad_stream, o.wgrad_ws, o.wgrad_ws_bytes, o.wgrad_slot = side.cuda_stream, ring[slot].data_ptr(), ring[slot].numel(), slot
