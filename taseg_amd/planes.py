@@ -100,6 +100,9 @@ def _refresh(stream, device, entries=None, fn="ts_conv_split_planes_batch"):
 def planes_for(weight):
     """The planes tensor of `weight` (int16 storage of 3 * numel bf16), in step with the weight on the current stream,
     or None when the mechanism does not apply."""
+    e = _entries.get(id(weight))
+    if e is not None and e.ref() is weight and e.fresh(weight, L.stream()) and e.planes.device == weight.device:
+        return e.planes              # (the common case first: same storage, version, epoch and stream as when the planes were made)
     if not eligible(weight):
         return None
     if weight.device.index != torch.cuda.current_device():
@@ -127,6 +130,10 @@ def half_for(weight):
     weight, conv.py:19, done once per optimizer step for ALL weights of the model - 16 per launch - instead of once per
     convolution call), in step with the weight on the current stream; None when the mechanism does not apply.  Hand it to
     the block call as its w16 buffer and name it in `hint(weight, w16)`: the call then launches no cast."""
+    e = _half_entries.get(id(weight))
+    if e is not None and e.ref() is weight and e.fresh(weight, L.stream()) and e.planes.device == weight.device \
+            and e.planes.shape == weight.shape:
+        return e.planes              # (the common case first)
     if not eligible_half(weight) or weight.device.index != torch.cuda.current_device():
         return None
     stream = L.stream()

@@ -86,9 +86,11 @@ def _bn_forward(mod, feats, torch_forward, group=None):
 def _sync_group(mod):
     """process group whose ranks share batch statistics, or None for local statistics.  A one-rank group behaves
     like None; TASEG_SYNCBN_SINGLE_RANK=1 keeps the collective path on anyway (lets one GPU exercise it)."""
+    if not isinstance(mod, nn.SyncBatchNorm):           # (first: 63 calls per pass, and a plain BatchNorm needs none of the rest)
+        return None
     import os
     import torch.distributed as dist
-    if isinstance(mod, nn.SyncBatchNorm) and mod.training and dist.is_available() and dist.is_initialized() \
+    if mod.training and dist.is_available() and dist.is_initialized() \
             and (dist.get_world_size() > 1 or os.environ.get("TASEG_SYNCBN_SINGLE_RANK") == "1"):
         return mod.process_group if mod.process_group is not None else dist.group.WORLD
     return None
@@ -243,8 +245,6 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     consumer of the input (the shortcut of a residual block) sends its gradient back INTO the node, where it is added
     in the store of the convolution's input gradient instead of by a separate add launch.  Use input' in place of
     `input` downstream; on the unfused paths input' is `input` itself."""
-    from ...rccl import direct_comm
-    from .batchnorm import fast_path_ok  # noqa: F401  (same shape rules as the BatchNorm fast path)
     ones = (1, 1, 1)
     ks, stride = conv.kernel_size, conv.stride
     dil = make_ntuple(conv.dilation, ndim=3)
@@ -280,39 +280,46 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and torch.is_grad_enabled() and mod.momentum is not None \
             and mod.affine and not (conv._forward_hooks or conv._forward_pre_hooks):      # hooks on the conv module must still fire
         group = _sync_group(mod)
-        _require_rows(input.feats, group)
-        comm = None if group is None else direct_comm(group)
+        comm = None
+        if group is not None:
+            from ...rccl import direct_comm
+            _require_rows(input.feats, group)
+            comm = direct_comm(group)
         # SyncBatchNorm without the library-owned communicator: the Python node splits the block call around c10d's all-reduce
-        kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)
+        # (module attributes are read once: every `conv.kernel` / `mod.weight` is a trip through nn.Module.__getattr__, ~1000 of
+        # them per pass made 0.2 ms of a host-bound step)
+        kernel, transposed = conv.kernel, conv.transposed
+        kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, transposed)
         n_in, n_out = kmap.sizes
-        rows = n_in if conv.transposed else n_out
+        rows = n_in if transposed else n_out
         res = None if residual is None else residual.feats
         feats = input.feats
-        if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
+        if feats.shape[0] == (n_out if transposed else n_in) and F.conv_block_ok(feats, kernel, kmap, res, rows):
             track = mod.track_running_stats
+            momentum, eps = mod.momentum, mod.eps
             state = (mod.running_mean if track else None, mod.running_var if track else None,
-                     mod.num_batches_tracked if track else None, mod.momentum, mod.eps)
+                     mod.num_batches_tracked if track else None, momentum, eps)
             fast = _fast.module()
             half = F._amp_half(feats)
             # fp32: pre-split bf16 planes of the weight; half storage: its kept half copy (taseg_amd/planes.py)
-            planes = _planes.half_for(conv.kernel) if half else _planes.planes_for(conv.kernel)
-            dest = _claim_grad_dest(conv.kernel)                            # bucket slot of the weight gradient (parallel.py)
+            planes = _planes.half_for(kernel) if half else _planes.planes_for(kernel)
+            dest = _claim_grad_dest(kernel)                            # bucket slot of the weight gradient (parallel.py)
             c10d_group = group if (group is not None and comm is None) else None
             # class plans of this kernel map for the forward product / the input gradient (functional.KernelMap.plans_for)
-            plan_f, plan_d = kmap.plans_for(conv.transposed, conv.kernel.shape[1], conv.kernel.shape[2], half)
+            plan_f, plan_d = kmap.plans_for(transposed, kernel.shape[1], kernel.shape[2], half)
             if fast is not None:                          # C++ autograd node, same backend calls (csrc/fastpath)
-                out = fast.conv_block(feats, conv.kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
-                                      kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, conv.transposed, state[0],
-                                      state[1], state[2], float(mod.momentum), float(mod.eps), relu,
+                out = fast.conv_block(feats, kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
+                                      kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, transposed, state[0],
+                                      state[1], state[2], float(momentum), float(eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
                                       bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d),
-                                      conv.kernel.grad is None,
+                                      kernel.grad is None,
                                       # per-offset weight exponents: the fp32 class products on three half MFMAs (planes.exps_for)
-                                      None if (half or (plan_f is None and plan_d is None)) else _planes.exps_for(conv.kernel),
+                                      None if (half or (plan_f is None and plan_d is None)) else _planes.exps_for(kernel),
                                       False)
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
-                out = F._ConvBlock.apply(feats, conv.kernel, res, mod.weight, mod.bias, kmap, conv.transposed, state,
+                out = F._ConvBlock.apply(feats, kernel, res, mod.weight, mod.bias, kmap, transposed, state,
                                          relu, comm, half, planes, bool(passthrough), dest, c10d_group)
                 out, passed = out if passthrough else (out, None)
             result = F._conv_output(input, out, out_coords, out_stride)
