@@ -12,6 +12,7 @@
 #include <torch/extension.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -185,6 +186,13 @@ void group_sum(int64_t id, at::Tensor buf) {
 
 void *const COMM_PRE = (void *)1, *const COMM_POST = (void *)2;
 
+// host-time accounting of the node (diagnostic, tools/block_host_probe.py): time inside the backend calls (= issuing the launches)
+// against the whole of forward() / backward()
+struct HostClock {
+  std::atomic<int64_t> ns_fwd{0}, ns_fwd_api{0}, ns_bwd{0}, ns_bwd_api{0}, n_fwd{0}, n_bwd{0};
+} host_clock;
+inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 inline void *ptr(const at::Tensor &t) { return t.defined() ? t.data_ptr() : nullptr; }
 inline void *optr(const c10::optional<at::Tensor> &t) { return (t.has_value() && t->defined()) ? t->data_ptr() : nullptr; }
 
@@ -231,6 +239,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const c10::optional<at::Tensor> &pd1, const c10::optional<at::Tensor> &pd2,
                             const c10::optional<at::Tensor> &pd3, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok,
                             const c10::optional<at::Tensor> &wexp, bool natural) {
+    const int64_t t_in = now_ns();
     // a backward pass that died mid-way leaves its join behind: nothing of the second stream outlives the next forward call
     if (wg_join_queued.exchange(false)) {
       wg_worker.drain();
@@ -286,6 +295,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                         &bopts, ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
             "ts_conv_block_forward");
     };
+    const int64_t t_api = now_ns();
     if (split) {
       call(COMM_PRE);                    // convolution + this rank's sums (the planes hint is consumed here)
       group_sum(group_id, pack);
@@ -293,6 +303,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     } else {
       call((void *)comm);
     }
+    host_clock.ns_fwd_api += now_ns() - t_api;
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
     ctx->saved_data["plan_d"] = c10::List<at::Tensor>(plan_d);        // the input gradient's plan (tensors + meta)
@@ -315,6 +326,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     ctx->saved_data["has_res"] = res.defined();
     ctx->saved_data["in_dtype"] = (int64_t)feats.scalar_type();
     ctx->saved_data["res_dtype"] = (int64_t)(res.defined() ? residual->scalar_type() : at::kFloat);
+    host_clock.ns_fwd += now_ns() - t_in;
+    host_clock.n_fwd += 1;
     // passthrough: the input leaves the node a second time (autograd aliases it); whatever consumes THAT tensor - the
     // shortcut of a residual block - sends its gradient back into this node, where it joins the input gradient's store
     if (passthrough) return {out, feats};
@@ -323,6 +336,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
 
   static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx,
                                                  torch::autograd::variable_list grads) {
+    const int64_t t_in = now_ns();
     const auto saved = ctx->get_saved_variables();
     const at::Tensor &x = saved[0], &w = saved[1], &conv_out = saved[2], &stats = saved[3], &mask = saved[4],
                      &bn_weight = saved[5], &nbmaps = saved[6], &nboffs = saved[7], &pos_out = saved[8], &pos_in = saved[9],
@@ -438,12 +452,17 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
       TORCH_CHECK(addend.sizes() == grad_feat.sizes(), "conv_block: pass-through gradient has the wrong shape");
       bopts.addend = addend.data_ptr();
     }
+    const int64_t t_api = now_ns();
     call(split ? COMM_POST : (void *)comm);
+    host_clock.ns_bwd_api += now_ns() - t_api;
     if (side_job) wg_worker.push(std::move(side_job));      // (the call has recorded the slot's ready event)
     if (grad_feat.defined() && grad_feat.scalar_type() != in_dtype) grad_feat = grad_feat.to(in_dtype);
     if (grad_res.defined() && grad_res.scalar_type() != res_dtype) grad_res = grad_res.to(res_dtype);
     at::Tensor none;
-    return {grad_feat, grad_w, grad_res, gwb[0], gwb[1], none, none, none, none, none, none, none, none,
+    at::Tensor gbw = gwb[0], gbb = gwb[1];
+    host_clock.ns_bwd += now_ns() - t_in;
+    host_clock.n_bwd += 1;
+    return {grad_feat, grad_w, grad_res, gbw, gbb, none, none, none, none, none, none, none, none,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none,
             none, none, none, none, none, none, none, none, none};
   }
@@ -708,7 +727,15 @@ index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num
   return {cmaps, sub_t, down_t, totals, tri_idx, tri_w, orders};
 }
 
+// (calls, ns in total, ns inside the backend call) of the node's forward and backward since the last call; resets the counters
+std::vector<int64_t> host_times() {
+  std::vector<int64_t> v = {host_clock.n_fwd.exchange(0), host_clock.ns_fwd.exchange(0), host_clock.ns_fwd_api.exchange(0),
+                            host_clock.n_bwd.exchange(0), host_clock.ns_bwd.exchange(0), host_clock.ns_bwd_api.exchange(0)};
+  return v;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("host_times", &host_times, "diagnostic: (calls, ns, ns in the backend call) of the block node's forward and backward; resets");
   m.def("index_plan", &index_plan, "coordinate pyramid + kernel maps + trilinear maps of a MinkUNet pass (releases the GIL)");
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");
   m.def("conv_block", &conv_block, "act(BN(conv(x)) [+ residual]) as one native autograd node");

@@ -57,11 +57,19 @@ def main():
             y = spnn.conv_bn_act(conv, bn, x)
         y.F.backward(y.F)
 
+    from taseg_amd import _fast
+    fast = _fast.module()
     conv.eval(), bn.eval()
     e = timed(ev, args.calls)
     conv.train(), bn.train()
     t = timed(tr, args.calls)
+    if fast is not None:
+        fast.host_times()
     b = timed(trb, args.calls // 3)
+    if fast is not None:
+        nf, tf, taf, nb, tb, tab = fast.host_times()
+        print(f"  inside the C++ node: forward {tf / nf / 1e3:.1f} us ({taf / nf / 1e3:.1f} in the backend call), "
+              f"backward {tb / nb / 1e3:.1f} us ({tab / nb / 1e3:.1f} in the backend call)")
     print(f"{'amp ' if args.amp else 'fp32'} voxels {len(c)}: eval {e:.1f} us / call, train forward {t:.1f}, train forward + backward {b:.1f}")
 
 
