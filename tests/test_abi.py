@@ -64,3 +64,29 @@ def test_cpu_tensors_fail_loudly():
         B.hash_cuda(torch.zeros((3, 4), dtype=torch.int32))
     with pytest.raises(RuntimeError):
         B.conv_nbr(torch.zeros(3, 4), torch.zeros(27, 4, 8), torch.zeros((27, 3), dtype=torch.int32), 3)
+
+
+def test_ctypes_structs_have_the_headers_layout(tmp_path):
+    """TsConvBlockOpts / TsClassPlan / TsPlaneJob cross the boundary by pointer: the ctypes mirrors in taseg_amd/_lib.py
+    (and taseg_amd/planes.py) must have the size and the field offsets a C compiler gives the header's structs."""
+    import shutil
+    import subprocess
+    from taseg_amd import _lib, planes
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    structs = {"TsConvBlockOpts": _lib.TsConvBlockOpts, "TsClassPlan": _lib.TsClassPlan, "TsPlaneJob": planes.TsPlaneJob}
+    lines = []
+    for name, st in structs.items():
+        offs = ", ".join(f"offsetof({name}, {f[0]})" for f in st._fields_)
+        fmt = " ".join(["%zu"] * (1 + len(st._fields_)))
+        lines.append(f'  printf("{name} {fmt}\\n", sizeof({name}), {offs});')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "taseg_hip.h"\nint main(void) {\n' + "\n".join(lines) +
+                   "\n  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    seen = {ln.split()[0]: [int(v) for v in ln.split()[1:]] for ln in out}
+    for name, st in structs.items():
+        mine = [ctypes.sizeof(st)] + [getattr(st, f[0]).offset for f in st._fields_]
+        assert seen[name] == mine, (name, seen[name], mine)
