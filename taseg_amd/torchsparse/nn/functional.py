@@ -779,14 +779,18 @@ def conv_geometry(input: SparseTensor, kernel_size, stride, dilation, transposed
     (kernel map, output coordinates, output stride), creating and caching `cmaps` / `kmaps` entries like the reference."""
     ones = (1, 1, 1)
     if not transposed:
-        out_stride = tuple(input.stride[k] * stride[k] for k in range(3))
-        if out_stride in input.cmaps:
-            out_coords = input.cmaps[out_stride]
+        s_in = input.stride
+        out_stride = (s_in[0] * stride[0], s_in[1] * stride[1], s_in[2] * stride[2])
+        out_coords = input.cmaps.get(out_stride)
+        key = (s_in, kernel_size, stride, dilation)
+        if out_coords is not None:
+            km = input.kmaps.get(key)
+            if km is not None:                    # (every call but the first of a pass)
+                return km, out_coords, out_stride
         elif stride == ones:
             out_coords = input.coords
         else:
             out_coords = spdownsample(input.coords, stride, kernel_size, input.stride)
-        key = (input.stride, kernel_size, stride, dilation)
         if key not in input.kmaps:
             km = build_kernel_map(input.coords, out_coords, kernel_size, input.stride, dilation)
             # (a class plan's input gradient relies on the map being its own transpose: only for a map over ONE coordinate set -
@@ -797,7 +801,8 @@ def conv_geometry(input: SparseTensor, kernel_size, stride, dilation, transposed
                 km.build_direct_plans()   # 2x2x2 strided map: one-pass plans of its two directions
             input.kmaps[key] = km
         return input.kmaps[key], out_coords, out_stride
-    out_stride = tuple(input.stride[k] // stride[k] for k in range(3))
+    s_in = input.stride
+    out_stride = (s_in[0] // stride[0], s_in[1] // stride[1], s_in[2] // stride[2])
     return input.kmaps[(out_stride, kernel_size, stride, dilation)], input.cmaps[out_stride], out_stride
 
 

@@ -19,6 +19,7 @@ __all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act"
 _FUSED_BLOCK = os.environ.get("TASEG_FUSED_BLOCK", "1") != "0"
 # the 1x1x1 shortcut + its BatchNorm as one block call on the identity rulebook (_pointwise_bn_act); 0: GEMM node + BatchNorm node
 _POINTWISE_BLOCK = os.environ.get("TASEG_POINTWISE_BLOCK", "1") != "0"
+_DIL1 = (1, 1, 1)
 
 
 class Conv3d(nn.Module):
@@ -176,8 +177,8 @@ def _plan_args(plan):
 
 def _eval_invstd(mod):
     """1 / sqrt(running_var + eps) of a BatchNorm module, kept until the buffer changes (63 modules x 10 TTA votes per scan)"""
-    rv = mod.running_var
-    hit = getattr(mod, "_taseg_eval_invstd", None)
+    rv = mod._buffers["running_var"]
+    hit = mod.__dict__.get("_taseg_eval_invstd")
     if hit is None or hit[0] != rv._version or hit[1] is not rv or hit[2].device != rv.device:
         with torch.no_grad():
             hit = (rv._version, rv, torch.rsqrt(rv.float() + mod.eps))
@@ -247,37 +248,44 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
     `input` downstream; on the unfused paths input' is `input` itself."""
     ones = (1, 1, 1)
     ks, stride = conv.kernel_size, conv.stride
-    dil = make_ntuple(conv.dilation, ndim=3)
+    dil = conv.dilation
+    if type(dil) is not tuple or len(dil) != 3:
+        dil = _DIL1 if dil == 1 else make_ntuple(dil, ndim=3)
     if ks == ones:
         out = _pointwise_bn_act(conv, mod, input, relu, residual) if (_FUSED_BLOCK and _POINTWISE_BLOCK and not passthrough) else None
         if out is None:
             out = bn_act(mod, conv(input), relu=relu, residual=residual)
         return (out, input) if passthrough else out
-    if _FUSED_BLOCK and conv.bias is None and ks != ones and not mod.training and not torch.is_grad_enabled() and mod.affine \
-            and mod.track_running_stats and mod.running_var is not None \
+    # (parameters and buffers are read from the modules' own dictionaries: `conv.kernel` / `mod.weight` go through
+    # nn.Module.__getattr__ after a failed instance lookup, ~0.5 us each and ~15 of them per block call)
+    cpar, mpar, mbuf = conv._parameters, mod._parameters, mod._buffers
+    if _FUSED_BLOCK and cpar["bias"] is None and not mod.training and not torch.is_grad_enabled() and mod.affine \
+            and mod.track_running_stats and mbuf.get("running_var") is not None \
             and not (conv._forward_hooks or conv._forward_pre_hooks or mod._forward_hooks or mod._forward_pre_hooks):
         # evaluation (eval-mode BatchNorm, no graph): one backend call per block on the running statistics
-        kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, conv.transposed)
+        kernel, transposed = cpar["kernel"], conv.transposed
+        kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, transposed)
         n_in, n_out = kmap.sizes
-        rows = n_in if conv.transposed else n_out
+        rows = n_in if transposed else n_out
         res = None if residual is None else residual.feats
         feats = input.feats
-        if feats.shape[0] == (n_out if conv.transposed else n_in) and F.conv_block_ok(feats, conv.kernel, kmap, res, rows):
+        if feats.shape[0] == (n_out if transposed else n_in) and F.conv_block_ok(feats, kernel, kmap, res, rows):
             half = F._amp_half(feats)
-            planes = _planes.half_for(conv.kernel) if half else _planes.planes_for(conv.kernel)
+            planes = _planes.half_for(kernel) if half else _planes.planes_for(kernel)
             fast = _fast.module()
-            if fast is not None and mod.running_mean.dtype == torch.float32 and mod.weight.dtype == torch.float32:
-                plan_f, _ = kmap.plans_for(conv.transposed, conv.kernel.shape[1], conv.kernel.shape[2], half)
-                out = fast.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod),
+            bn_w, bn_b, rmean = mpar["weight"], mpar["bias"], mbuf["running_mean"]
+            if fast is not None and rmean.dtype == torch.float32 and bn_w.dtype == torch.float32:
+                plan_f, _ = kmap.plans_for(transposed, kernel.shape[1], kernel.shape[2], half)
+                out = fast.conv_block_eval(feats, kernel, res, bn_w, bn_b, rmean, _eval_invstd(mod),
                                            kmap.nbmaps_buf, kmap.nboffs, kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out,
-                                           conv.transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f),
-                                           None if (half or plan_f is None) else _planes.exps_for(conv.kernel), False)
+                                           transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f),
+                                           None if (half or plan_f is None) else _planes.exps_for(kernel), False)
             else:
-                out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), kmap,
-                                        conv.transposed, relu, half, planes)
+                out = F.conv_block_eval(feats, kernel, res, bn_w, bn_b, rmean, _eval_invstd(mod), kmap,
+                                        transposed, relu, half, planes)
             result = F._conv_output(input, out, out_coords, out_stride)
             return (result, input) if passthrough else result
-    if _FUSED_BLOCK and conv.bias is None and ks != ones and mod.training and torch.is_grad_enabled() and mod.momentum is not None \
+    if _FUSED_BLOCK and cpar["bias"] is None and mod.training and torch.is_grad_enabled() and mod.momentum is not None \
             and mod.affine and not (conv._forward_hooks or conv._forward_pre_hooks):      # hooks on the conv module must still fire
         group = _sync_group(mod)
         comm = None
@@ -288,7 +296,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
         # SyncBatchNorm without the library-owned communicator: the Python node splits the block call around c10d's all-reduce
         # (module attributes are read once: every `conv.kernel` / `mod.weight` is a trip through nn.Module.__getattr__, ~1000 of
         # them per pass made 0.2 ms of a host-bound step)
-        kernel, transposed = conv.kernel, conv.transposed
+        kernel, transposed = cpar["kernel"], conv.transposed
         kmap, out_coords, out_stride = F.conv_geometry(input, ks, stride, dil, transposed)
         n_in, n_out = kmap.sizes
         rows = n_in if transposed else n_out
@@ -297,8 +305,9 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
         if feats.shape[0] == (n_out if transposed else n_in) and F.conv_block_ok(feats, kernel, kmap, res, rows):
             track = mod.track_running_stats
             momentum, eps = mod.momentum, mod.eps
-            state = (mod.running_mean if track else None, mod.running_var if track else None,
-                     mod.num_batches_tracked if track else None, momentum, eps)
+            state = (mbuf["running_mean"] if track else None, mbuf["running_var"] if track else None,
+                     mbuf["num_batches_tracked"] if track else None, momentum, eps)
+            bn_w, bn_b = mpar["weight"], mpar["bias"]
             fast = _fast.module()
             half = F._amp_half(feats)
             # fp32: pre-split bf16 planes of the weight; half storage: its kept half copy (taseg_amd/planes.py)
@@ -308,7 +317,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
             # class plans of this kernel map for the forward product / the input gradient (functional.KernelMap.plans_for)
             plan_f, plan_d = kmap.plans_for(transposed, kernel.shape[1], kernel.shape[2], half)
             if fast is not None:                          # C++ autograd node, same backend calls (csrc/fastpath)
-                out = fast.conv_block(feats, kernel, res, mod.weight, mod.bias, kmap.nbmaps_buf, kmap.nboffs,
+                out = fast.conv_block(feats, kernel, res, bn_w, bn_b, kmap.nbmaps_buf, kmap.nboffs,
                                       kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out, transposed, state[0],
                                       state[1], state[2], float(momentum), float(eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
@@ -319,7 +328,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                                       False)
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
-                out = F._ConvBlock.apply(feats, kernel, res, mod.weight, mod.bias, kmap, transposed, state,
+                out = F._ConvBlock.apply(feats, kernel, res, bn_w, bn_b, kmap, transposed, state,
                                          relu, comm, half, planes, bool(passthrough), dest, c10d_group)
                 out, passed = out if passthrough else (out, None)
             result = F._conv_output(input, out, out_coords, out_stride)
