@@ -57,7 +57,10 @@ class BasicConvolutionBlock(nn.Module):
         )
 
     def forward(self, x):
-        return spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True)      # conv -> BN -> ReLU, one node
+        # (children straight from the module dictionaries: `self.net[0]` is nn.Module.__getattr__ + nn.Sequential.__getitem__,
+        # ~2 us each and five of them per residual block)
+        net = self._modules["net"]._modules
+        return spnn.conv_bn_act(net["0"], net["1"], x, relu=True)      # conv -> BN -> ReLU, one node
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -72,7 +75,8 @@ class BasicDeconvolutionBlock(nn.Module):
         )
 
     def forward(self, x):
-        return spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True)
+        net = self._modules["net"]._modules
+        return spnn.conv_bn_act(net["0"], net["1"], x, relu=True)
 
 
 def _shortcut(inc, outc, stride, if_dist):
@@ -100,11 +104,16 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         # relu(net(x) + downsample(x)) with the BN / add / ReLU tails fused (same module parameters / buffers)
         # (the first block hands x through: the shortcut's gradient then lands in the store of conv1's input gradient)
-        h, x = spnn.conv_bn_act(self.net[0], self.net[1], x, relu=True, passthrough=True)
+        mods = self._modules
+        net, down = mods["net"]._modules, mods["downsample"]
+        h, x = spnn.conv_bn_act(net["0"], net["1"], x, relu=True, passthrough=True)
         # (the 1x1x1 shortcut + its BatchNorm: one block call on the identity rulebook, spnn.conv_bn_act)
-        shortcut = x if isinstance(self.downsample, nn.Identity) else \
-            spnn.conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
-        return spnn.conv_bn_act(self.net[3], self.net[4], h, relu=True, residual=shortcut)
+        if isinstance(down, nn.Identity):
+            shortcut = x
+        else:
+            dm = down._modules
+            shortcut = spnn.conv_bn_act(dm["0"], dm["1"], x, relu=False)
+        return spnn.conv_bn_act(net["3"], net["4"], h, relu=True, residual=shortcut)
 
 
 class Bottleneck(nn.Module):
