@@ -284,3 +284,97 @@ def test_traffic_parser_recovers_names_rocprofv3_leaves_mangled():
              "bytes_per_step": 1e9, "ideal_fused_bytes_per_step": 1e8}]
     fam = bench.summarise_families(prof, True, table)[0]
     assert abs(fam["traffic_bytes_per_launch"] - 65e6) < 1.0          # launch-weighted over the two instantiations
+
+
+class _NoEvent:
+    """stands in for torch.cuda.Event where the tail runs on CPU tensors"""
+
+    def record(self, *a):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def _tail_case(rs, n_vox, n_pts, classes=5):
+    from taseg_amd.torchsparse import SparseTensor
+    vox_batch = torch.from_numpy(np.concatenate([np.full(n, b) for b, n in enumerate(n_vox)])).int()
+    vox_batch = vox_batch[torch.from_numpy(rs.permutation(len(vox_batch)))]          # scenes interleaved
+    out = torch.from_numpy(rs.randn(len(vox_batch), classes).astype(np.float32))
+    inv = np.concatenate([rs.randint(0, n_vox[b], n_pts[b]) for b in range(len(n_vox))])
+    bat = np.concatenate([np.full(n_pts[b], b) for b in range(len(n_vox))])
+    perm = rs.permutation(len(inv))
+    inv, bat = inv[perm], bat[perm]
+    coords = torch.zeros(len(inv), 4, dtype=torch.int32)
+    coords[:, 3] = torch.from_numpy(bat).int()
+    labels = torch.from_numpy(rs.randint(0, classes, len(inv))).long()
+    return out, vox_batch, SparseTensor(torch.from_numpy(inv).long(), coords), SparseTensor(labels, coords)
+
+
+def test_evaluation_tail_for_the_whole_batch_equals_the_per_scene_loop(monkeypatch):
+    """unvoxelise_predictions (the eval branch's tail, minkunet.py:435-455, for all scenes at once and without host reads before the
+    arrays are collected) against the reference's per-scene boolean-mask loop; scene indices outside the batch and inverse maps
+    outside their scene are reported when the arrays are collected."""
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import unvoxelise_predictions
+    from taseg_amd.torchsparse import SparseTensor
+    monkeypatch.setattr(torch.cuda, "Event", _NoEvent)
+    rs = np.random.RandomState(3)
+    n_vox, n_pts = [50, 70, 40], [80, 90, 60]
+    out, vox_batch, invs, labs = _tail_case(rs, n_vox, n_pts)
+    names = ["a", "b", "c"]
+    for want_probs in (False, True):
+        r = unvoxelise_predictions(out, vox_batch, invs, labs, torch.tensor(n_pts), want_probs, names=names)
+        for b in range(3):
+            ob = out[vox_batch == b]
+            sel = invs.C[:, 3] == b
+            ref = ob[invs.F[sel]]
+            want = ref.softmax(1) if want_probs else ref.argmax(1)
+            assert np.allclose(r["point_predict"][b], want.numpy(), atol=1e-6)
+            if not want_probs:
+                assert np.array_equal(r["point_predict_logits"][b], ref.numpy())
+            assert np.array_equal(r["point_labels"][b], labs.F[sel].numpy())
+    # a scan shorter than its inverse map is trimmed like the reference trims it ([:num_points])
+    r = unvoxelise_predictions(out, vox_batch, invs, labs, torch.tensor([80, 50, 60]), False, names=names)
+    assert [len(a) for a in r["point_predict"]] == [80, 50, 60]
+    for bad_index in (7, -1):
+        c2 = invs.C.clone()
+        c2[0, 3] = bad_index
+        with pytest.raises(IndexError, match="beyond the 3 scenes"):
+            unvoxelise_predictions(out, vox_batch, SparseTensor(invs.F, c2), labs, torch.tensor(n_pts), False, names=names)
+    f2 = invs.F.clone()
+    f2[3] = 1000
+    with pytest.raises(IndexError, match="outside its scene"):
+        unvoxelise_predictions(out, vox_batch, SparseTensor(f2, invs.C), labs, torch.tensor(n_pts), False, names=names)
+
+
+def test_wgrad_stream_tuner_keeps_the_second_stream_only_on_a_clear_win(monkeypatch):
+    """_fast.tune_wgrad_stream: all rounds but one must win by > 1 % and the best of rounds by > 2 %; an environment pin and a
+    world size above one skip the timing."""
+    import time
+    from taseg_amd import _fast
+    state = {"on": False}
+    monkeypatch.setattr(_fast, "module", lambda: object())
+    monkeypatch.setattr(_fast, "wgrad_stream", lambda on: state.__setitem__("on", bool(on)) or bool(on))
+    monkeypatch.delenv("TASEG_WGRAD_STREAM", raising=False)
+
+    clock = {"t": 0.0}
+    monkeypatch.setattr(time, "perf_counter", lambda: clock["t"])      # a clock that only the steps advance: no timing noise
+
+    def run(ms_off, ms_on):
+        calls = {"n": 0}
+
+        def step():
+            seq = ms_on if state["on"] else ms_off
+            clock["t"] += seq[min(calls["n"] // 10, len(seq) - 1)] / 1e3       # 10 steps per round (2 settings x (1 + 4))
+            calls["n"] += 1
+        return _fast.tune_wgrad_stream(step, lambda: None, rounds=3, steps=4)[0]
+
+    assert run([4.0], [3.6]) is True                      # 10 % faster in every round
+    assert run([4.0], [3.98]) is False                    # inside the noise
+    assert run([4.0], [4.4]) is False                     # slower
+    assert run([4.0, 4.0, 4.0], [3.6, 4.1, 3.6]) is True  # one lost round of three is allowed
+    assert run([4.0, 4.0, 4.0], [3.6, 4.1, 4.1]) is False
+    monkeypatch.setenv("TASEG_WGRAD_STREAM", "1")
+    assert _fast.tune_wgrad_stream(lambda: None, lambda: None) == (True, None, None)
+    monkeypatch.setenv("TASEG_WGRAD_STREAM", "0")
+    assert _fast.tune_wgrad_stream(lambda: None, lambda: None) == (False, None, None)
