@@ -183,6 +183,60 @@ def test_eval_block_call_equals_the_module_chain(g_minkunet, monkeypatch, amp):
         assert torch.equal(grabbed["py"], outs[2])
 
 
+def test_eval_tail_in_pass_2_has_the_bits_of_the_separate_pass(tmp_path):
+    """ts_conv_block_eval applies the BatchNorm / residual / ReLU tail in the store of pass 2 (TsGatherEpilogue, csrc/conv_pairs*.hip)
+    where the convolution ends in its list form.  Same arithmetic as the separate elementwise pass: fp32 logits of a whole evaluation
+    pass are bit-equal with TASEG_EVAL_TAIL_IN_PASS2=0 (the switch is read once per process: two child processes); half storage rounds
+    once instead of twice and stays within half precision of it."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["REPO"])
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, synth_scan
+from taseg_amd.pcseg.model import build_network
+from taseg_amd.torchsparse import SparseTensor
+from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+model = fill_parameters(build_network(make_model_cfg("MinkUNet", in_dim=4, cr=1.0), 20), seed=5).cuda().train()
+torch.manual_seed(0)
+for m in model.modules():
+    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+        m.eval()
+        with torch.no_grad():
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+pts, lab = synth_scan(2, n_points=40000, n_beams=48, n_az=1200)
+pc = np.round(pts[:, :3] / 0.05).astype(np.int32); pc -= pc.min(0)
+_, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+coords = torch.from_numpy(np.concatenate([pc[idx], np.zeros((len(idx), 1), np.int32)], 1)).cuda()
+bd = lambda: {"lidar": SparseTensor(torch.from_numpy(pts[idx]).cuda(), coords),
+              "targets": SparseTensor(torch.from_numpy(lab[idx].astype(np.int64)).cuda(), coords), "offset": torch.tensor([0])}
+out = {}
+for amp in (False, True):
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("y", o.detach().float().cpu().numpy()))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        model(bd())
+    h.remove()
+    out["amp" if amp else "fp32"] = grabbed["y"]
+np.savez(os.environ["OUT"], **out)
+print("TAIL_OK")
+'''
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"tail{mode}.npz")
+        env = dict(os.environ, REPO=repo, OUT=path, TASEG_EVAL_TAIL_IN_PASS2=mode)
+        run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert "TAIL_OK" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
+        res[mode] = np.load(path)
+    assert np.array_equal(res["1"]["fp32"], res["0"]["fp32"]), float(np.abs(res["1"]["fp32"] - res["0"]["fp32"]).max())
+    scale = max(1.0, float(np.abs(res["0"]["amp"]).max()))
+    assert float(np.abs(res["1"]["amp"] - res["0"]["amp"]).max()) <= 2e-2 * scale
+    assert float(np.abs(res["1"]["amp"] - res["1"]["fp32"]).max()) <= 5e-2 * scale       # (and autocast stays autocast-close to fp32)
+
+
 def test_dropout_does_not_touch_devoxelised_features():
     """DROPOUT_P > 0 (the default when the key is absent is 0.3): z1 / z2 are devoxelised from the features BEFORE
     dropout (minkunet.py:400-412).  The concat path collects its sources before the dropout call, so with the same
