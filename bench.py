@@ -586,7 +586,9 @@ def eval_run(args):
     # the index plan of batch i + 1 (coordinates only) is staged on a second stream / worker thread while batch i runs - the role
     # of the reference's DataLoader workers; --no-prefetch builds it inline
     from taseg_amd.data.stage import DevicePrefetcher
-    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare, threaded=True)
+    # (two batches staged ahead, each on its own stream and thread: one index plan takes longer beside a forward pass than the pass)
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare, threaded=True,
+                                                        depth=int(os.environ.get("TASEG_EVAL_STAGE_DEPTH", "2")))
 
     def issue():
         if pf is None:

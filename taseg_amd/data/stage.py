@@ -348,11 +348,18 @@ class DevicePrefetcher:
     read it.
     """
 
-    def __init__(self, make_batch, prepare=None, device=None, threaded=False):
+    def __init__(self, make_batch, prepare=None, device=None, threaded=False, depth=1):
         self.make_batch, self.prepare = make_batch, prepare
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
-        self._staged = None          # (batch, ready_event) or a Future of it
+        # depth > 1 (threaded only): that many batches staged ahead, each on a stream and a worker thread of its own - for a loop
+        # whose pass is shorter than one stage (evaluation under autocast: the index plan is a chain of ~300 small launches and
+        # five host reads, 2.7 ms on its own and ~4.7 ms beside a forward pass)
+        self.depth = max(int(depth), 1) if threaded else 1
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.stream = self.streams[0]
+        self._turn = 0
+        self._last_made = None       # depth > 1: batches are MADE one after the other (order, and make_batch need not be thread-safe)
+        self._staged = []            # FIFO of (batch, ready_event) or Futures of it
         self._inflight = []          # [(batch, done_event)] handed out, possibly still read by the launch stream
         self._current = None
         # threaded=True runs the stage on a worker thread (its host reads release the GIL while they wait).  With the
@@ -362,7 +369,7 @@ class DevicePrefetcher:
         self._pool = None
         if threaded:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="taseg-stage")
+            self._pool = ThreadPoolExecutor(max_workers=self.depth, thread_name_prefix="taseg-stage")
 
     def _retire(self):
         if self._current is not None:
@@ -386,50 +393,69 @@ class DevicePrefetcher:
         step is host-bound and the stage runs on a worker thread (`threaded=True`; measured: the AMP step at bs 2 waited
         2.6 ms per step for a stage that was started at the end of the previous step).  The current batch is NOT retired
         here; next() / prefetch() do that."""
-        if self._staged is not None:
+        if len(self._staged) >= self.depth:
             return
-        if not self._inflight and self._current is None:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        self._staged = self._pool.submit(self._stage) if self._pool is not None else self._stage()
+        self._top_up(not self._inflight and self._current is None)
 
     def prefetch(self):
-        if self._staged is not None:
+        if len(self._staged) >= self.depth:
             return
         self._retire()
-        if not self._inflight:
-            # first use (or idle device): inputs created on the launch stream must be complete
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        if self._pool is not None:
-            self._staged = self._pool.submit(self._stage)
-        else:
-            self._staged = self._stage()
+        self._top_up(not self._inflight)
 
-    def _stage(self):
+    def _top_up(self, idle):
+        while len(self._staged) < self.depth:
+            stream = self.streams[self._turn % self.depth]
+            self._turn += 1
+            if idle:
+                # first use (or idle device): inputs created on the launch stream must be complete
+                stream.wait_stream(torch.cuda.current_stream(self.device))
+            if self._pool is None:
+                self._staged.append(self._stage(stream))
+                continue
+            made = None
+            if self.depth > 1:
+                import threading
+                made = threading.Event()
+            self._staged.append(self._pool.submit(self._stage, stream, self._last_made, made))
+            self._last_made = made
+
+    def _stage(self, stream=None, after=None, made=None):
+        stream = self.stream if stream is None else stream
         torch.cuda.set_device(self.device)
-        with torch.cuda.stream(self.stream), torch.no_grad():
-            batch = self.make_batch()
+        with torch.cuda.stream(stream), torch.no_grad():
+            try:
+                if after is not None:
+                    after.wait()             # the batch before this one has been taken from the source
+                batch = self.make_batch()
+            finally:
+                if made is not None:
+                    made.set()
             if self.prepare is not None:
                 self.prepare(batch)
             ready = torch.cuda.Event()
-            ready.record(self.stream)
+            ready.record(stream)
         return batch, ready
 
     def next(self):
         self._retire()               # the previous batch: every launch that reads it has been issued by now
         self.prefetch()
-        staged = self._staged
+        staged = self._staged.pop(0)
         batch, ready = staged.result() if hasattr(staged, "result") else staged
-        self._staged = None
         torch.cuda.current_stream(self.device).wait_event(ready)
         self._current = batch
         return batch
 
     def close(self):
-        if hasattr(self._staged, "result"):
-            self._staged.result()
+        for staged in self._staged:
+            if hasattr(staged, "result"):
+                try:
+                    staged.result()
+                except Exception:  # noqa: BLE001 - a stage that failed has nothing left to wait for; next() reports failures
+                    pass
         self._retire()
         torch.cuda.synchronize(self.device)
-        self._inflight, self._staged = [], None
+        self._inflight, self._staged = [], []
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None

@@ -106,13 +106,21 @@ def _staged(model, batches: Iterable[Dict], prefetch: bool):
     from ..data.stage import DevicePrefetcher
     it = iter(batches)
     done = object()
-    pf = DevicePrefetcher(lambda: next(it, done), lambda b: b if b is done else prepare(b), threaded=True)
-    while True:
-        batch = pf.next()
-        if batch is done:
-            return
-        pf.prefetch_early()
-        yield batch
+    import os
+    # two batches staged ahead (each on a stream and thread of its own; the batches are taken from `batches` one after the other, in
+    # order): beside a forward pass one index plan takes longer than the pass (bench.py --eval: 5.9-6.3 -> 5.4 ms fp32, 4.2-5.1 -> 3.5-3.8
+    # ms under autocast).  TASEG_EVAL_STAGE_DEPTH=1: one.
+    pf = DevicePrefetcher(lambda: next(it, done), lambda b: b if b is done else prepare(b), threaded=True,
+                          depth=int(os.environ.get("TASEG_EVAL_STAGE_DEPTH", "2")))
+    try:
+        while True:
+            batch = pf.next()
+            if batch is done:
+                return
+            pf.prefetch_early()
+            yield batch
+    finally:
+        pf.close()
 
 
 def evaluate(model, batches: Iterable[Dict], num_class: int, tta_votes: int = 0, dataset: str = "semantickitti",

@@ -422,6 +422,40 @@ def test_prefetched_batches_train_like_inline_ones():
     assert la == lc and all(torch.equal(a, b) for a, b in zip(wa, wc)), "batches staged on a worker thread trained differently"
 
 
+def test_two_batches_staged_ahead_come_back_in_order():
+    """DevicePrefetcher(depth=2): two stage jobs in flight, each on a stream and thread of its own; the batches are taken from the
+    source one after the other (a generator is not thread-safe) and handed out in source order, every one exactly once."""
+    import time
+    from taseg_amd.data.stage import DevicePrefetcher
+    done = object()
+
+    def source():
+        for i in range(7):
+            yield {"id": i, "x": torch.full((1000,), float(i), device="cuda")}
+    it = source()
+    seen_streams = set()
+
+    def prepare(b):
+        if b is done:
+            return
+        time.sleep(0.002 * (1 + b["id"] % 3))                     # uneven stage times: later jobs may finish first
+        b["y"] = b["x"] * 2                                       # work on the stage's stream
+        b["stream"] = torch.cuda.current_stream().cuda_stream
+        seen_streams.add(b["stream"])
+    pf = DevicePrefetcher(lambda: next(it, done), prepare, threaded=True, depth=2)
+    ids = []
+    while True:
+        b = pf.next()
+        if b is done:
+            break
+        pf.prefetch_early()
+        assert float(b["y"].sum()) == 2000.0 * b["id"]            # (the launch stream waited for the stage's event)
+        ids.append(b["id"])
+    pf.close()
+    assert ids == list(range(7))
+    assert len(seen_streams) == 2 and torch.cuda.current_stream().cuda_stream not in seen_streams
+
+
 def test_miou_parity_200_scans(g_miou):
     """mIoU parity gate of SURVEY 8(d): 200 seeded synthetic scans, identical weights - the HIP model's per-voxel arg-max
     against the REAL reference's (golden: reference MinkUNet run scan by scan on the CPU; here 8 scans per batch through
