@@ -751,7 +751,8 @@ def main():
     from taseg_amd.data.stage import DevicePrefetcher
     prepare = (lambda bd: bd.get("_plan") or model.prepare(bd)) if os.environ.get("TASEG_REUSE_PLAN") == "1" else model.prepare
     threaded = os.environ.get("TASEG_STAGE_THREAD", "1" if args.amp else "0") == "1"
-    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, prepare, threaded=threaded)
+    pf = None if args.no_prefetch else DevicePrefetcher(make_batch, prepare, threaded=threaded,
+                                                        depth=int(os.environ.get("TASEG_STAGE_DEPTH", "1")))
     # host-bound steps (the threaded stage is their mark) start staging batch i + 1 right after the forward pass of step i
     early_stage = os.environ.get("TASEG_STAGE_EARLY", "1" if threaded else "0") == "1"
 
