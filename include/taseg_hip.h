@@ -532,6 +532,15 @@ int ts_conv_block_wgrad_side(const void *feat, int64_t n_feat_rows, int32_t c_in
                              float *grad_kernel, int32_t chunk_order, void *wgrad_ws, size_t wgrad_ws_bytes, int32_t slot,
                              ts_stream_t side_stream);
 int ts_set_device(int32_t device);      /* hipSetDevice for a host thread the caller created */
+/* Column concatenation / slicing of row-major feature matrices - torchsparse.cat (TS/torchsparse/operators.py:10-17: torch.cat of
+ * the feature matrices along dim 1, the skip connections of the decoder, R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:403-416)
+ * and its gradient, for callers that chain block calls without tensors (the stage programs of csrc/fastpath/stage_program.h).
+ * Widths and pitches in BYTES (any element size); 16-byte vector copies when every pointer, pitch and width allows, else 4 / 2 / 1.
+ *   ts_cat_cols   dst[r] = a[r] | b[r]   (dst pitch = a_bytes + b_bytes), one launch
+ *   ts_copy_cols  dst[r, 0:width] = src[r, offset : offset + width]   (src rows src_pitch apart, dst rows dst_pitch apart) */
+int ts_cat_cols(const void *a, int64_t a_bytes, const void *b, int64_t b_bytes, int64_t rows, void *dst, ts_stream_t stream);
+int ts_copy_cols(const void *src, int64_t src_pitch, int64_t offset, int64_t width, int64_t rows, void *dst, int64_t dst_pitch,
+                 ts_stream_t stream);
 int ts_conv_block_forward(const void *feat, int64_t n_feat_rows, int32_t c_in, const float *kernel, int32_t K,
                           const int32_t *nbmaps, const int32_t *nboffs, int64_t n_pairs, int32_t gather_col,
                           const int32_t *pos, int64_t n_out, int32_t c_out, const void *residual, const float *bn_weight,

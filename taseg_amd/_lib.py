@@ -105,6 +105,8 @@ SIGNATURES = {
     "ts_stream_join": (_i32, [_vp, _vp]),
     "ts_conv_block_wgrad_side": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
     "ts_set_device": (_i32, [_i32]),
+    "ts_cat_cols": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "ts_copy_cols": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "ts_conv_block_forward": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),

@@ -624,3 +624,67 @@ extern "C" int ts_set_device(int32_t device) {
   TS_CHECK_HIP(hipSetDevice(device), "ts_set_device");
   return TS_OK;
 }
+
+// ---- column concatenation / slicing (torchsparse.cat, operators.py:10-17, and its gradient) for the stage programs -------------
+// One thread per VEC-byte piece of a destination row; rows of the decoder's concatenations are 128-1536 bytes wide.
+template <typename V>
+__global__ void cat_cols_kernel(const V *__restrict__ a, int wa, const V *__restrict__ b, int wb, int64_t rows, V *__restrict__ dst) {
+  const int w = wa + wb;
+  const int64_t n = rows * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / w;
+    const int c = (int)(i - r * w);
+    dst[i] = c < wa ? a[r * wa + c] : b[r * wb + (c - wa)];
+  }
+}
+template <typename V>
+__global__ void copy_cols_kernel(const V *__restrict__ src, int64_t src_pitch, int w, int64_t rows, V *__restrict__ dst, int64_t dst_pitch) {
+  const int64_t n = rows * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / w;
+    const int c = (int)(i - r * w);
+    dst[r * dst_pitch + c] = src[r * src_pitch + c];
+  }
+}
+static inline int cols_vec(uintptr_t bits) { return (bits & 15) == 0 ? 16 : (bits & 3) == 0 ? 4 : (bits & 1) == 0 ? 2 : 1; }
+static inline unsigned cols_grid(int64_t n) { return (unsigned)std::min<int64_t>(std::max<int64_t>(ts_cdiv(n, 256), 1), 256 * 16); }
+
+extern "C" int ts_cat_cols(const void *a, int64_t a_bytes, const void *b, int64_t b_bytes, int64_t rows, void *dst, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(a && b && dst && a_bytes > 0 && b_bytes > 0 && rows >= 0 && a_bytes + b_bytes < (1 << 30), TS_ERR_INVALID_ARGUMENT,
+             "ts_cat_cols: bad arguments");
+  if (rows == 0) return TS_OK;
+  const int v = cols_vec((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst | (uintptr_t)a_bytes | (uintptr_t)b_bytes);
+  const int64_t n = rows * ((a_bytes + b_bytes) / v);
+  if (v == 16)
+    cat_cols_kernel<uint4><<<cols_grid(n), 256, 0, stream>>>((const uint4 *)a, (int)(a_bytes / 16), (const uint4 *)b, (int)(b_bytes / 16), rows, (uint4 *)dst);
+  else if (v == 4)
+    cat_cols_kernel<uint32_t><<<cols_grid(n), 256, 0, stream>>>((const uint32_t *)a, (int)(a_bytes / 4), (const uint32_t *)b, (int)(b_bytes / 4), rows, (uint32_t *)dst);
+  else if (v == 2)
+    cat_cols_kernel<uint16_t><<<cols_grid(n), 256, 0, stream>>>((const uint16_t *)a, (int)(a_bytes / 2), (const uint16_t *)b, (int)(b_bytes / 2), rows, (uint16_t *)dst);
+  else
+    cat_cols_kernel<uint8_t><<<cols_grid(n), 256, 0, stream>>>((const uint8_t *)a, (int)a_bytes, (const uint8_t *)b, (int)b_bytes, rows, (uint8_t *)dst);
+  TS_CHECK_LAUNCH("ts_cat_cols");
+  return TS_OK;
+}
+
+extern "C" int ts_copy_cols(const void *src, int64_t src_pitch, int64_t offset, int64_t width, int64_t rows, void *dst, int64_t dst_pitch,
+                            ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(src && dst && width > 0 && offset >= 0 && offset + width <= src_pitch && width <= dst_pitch && rows >= 0 && width < (1 << 30),
+             TS_ERR_INVALID_ARGUMENT, "ts_copy_cols: bad arguments");
+  if (rows == 0) return TS_OK;
+  const char *s = (const char *)src + offset;
+  const int v = cols_vec((uintptr_t)s | (uintptr_t)dst | (uintptr_t)src_pitch | (uintptr_t)dst_pitch | (uintptr_t)width);
+  const int64_t n = rows * (width / v);
+  if (v == 16)
+    copy_cols_kernel<uint4><<<cols_grid(n), 256, 0, stream>>>((const uint4 *)s, src_pitch / 16, (int)(width / 16), rows, (uint4 *)dst, dst_pitch / 16);
+  else if (v == 4)
+    copy_cols_kernel<uint32_t><<<cols_grid(n), 256, 0, stream>>>((const uint32_t *)s, src_pitch / 4, (int)(width / 4), rows, (uint32_t *)dst, dst_pitch / 4);
+  else if (v == 2)
+    copy_cols_kernel<uint16_t><<<cols_grid(n), 256, 0, stream>>>((const uint16_t *)s, src_pitch / 2, (int)(width / 2), rows, (uint16_t *)dst, dst_pitch / 2);
+  else
+    copy_cols_kernel<uint8_t><<<cols_grid(n), 256, 0, stream>>>((const uint8_t *)s, src_pitch, (int)width, rows, (uint8_t *)dst, dst_pitch);
+  TS_CHECK_LAUNCH("ts_copy_cols");
+  return TS_OK;
+}

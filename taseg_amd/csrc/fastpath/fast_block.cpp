@@ -43,6 +43,8 @@ struct Api {
   decltype(&ts_trilinear_map) trilinear_map = nullptr;
   decltype(&ts_devox_order_workspace_bytes) devox_order_ws = nullptr;
   decltype(&ts_devox_order) devox_order = nullptr;
+  decltype(&ts_cat_cols) cat_cols = nullptr;
+  decltype(&ts_copy_cols) copy_cols = nullptr;
 } api;
 
 void check(int rc, const char *what) {
@@ -304,6 +306,9 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
       call((void *)comm);
     }
     host_clock.ns_fwd_api += now_ns() - t_api;
+    // (the running statistics were written through raw pointers: whoever caches something derived from them keys on the version)
+    if (running_mean.has_value() && running_mean->defined()) running_mean->unsafeGetTensorImpl()->bump_version();
+    if (running_var.has_value() && running_var->defined()) running_var->unsafeGetTensorImpl()->bump_version();
     ctx->save_for_backward({x, half ? w16 : w32, conv_out, stats, mask, bn_weight, nbmaps, nboffs, pos_out, pos_in, pack});
     ctx->saved_data["planes"] = pl;      // not a graph tensor: refreshed in place when the optimizer has stepped
     ctx->saved_data["plan_d"] = c10::List<at::Tensor>(plan_d);        // the input gradient's plan (tensors + meta)
@@ -468,6 +473,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
   }
 };
 
+#include "stage_program.h"
+
 }  // namespace
 
 void load_backend(const std::string &libpath) {
@@ -495,6 +502,8 @@ void load_backend(const std::string &libpath) {
   TS_BIND(trilinear_map, "ts_trilinear_map");
   TS_BIND(devox_order_ws, "ts_devox_order_workspace_bytes");
   TS_BIND(devox_order, "ts_devox_order");
+  TS_BIND(cat_cols, "ts_cat_cols");
+  TS_BIND(copy_cols, "ts_copy_cols");
 #undef TS_BIND
   api.handle = h;
 }
@@ -735,6 +744,20 @@ std::vector<int64_t> host_times() {
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  py::class_<stage::Program, std::shared_ptr<stage::Program>>(m, "StageProgram",
+                                                               "op list + parameter tensors of one MinkUNet stage (csrc/fastpath/stage_program.h)")
+      .def(py::init<int, int, const std::vector<std::tuple<int, int, int, int, int, bool, bool>> &,
+                    const std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, c10::optional<at::Tensor>, c10::optional<at::Tensor>,
+                                                 c10::optional<at::Tensor>, double, double>> &>())
+      .def("set_planes", &stage::Program::set_planes)
+      .def("set_grad_dests", &stage::Program::set_grad_dests)
+      .def_readonly("n_inputs", &stage::Program::n_inputs);
+  py::class_<stage::Geometry, std::shared_ptr<stage::Geometry>>(m, "StageGeometry", "kernel maps + class plans per op of a stage for one batch")
+      .def(py::init<const std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t, int64_t>> &,
+                    const std::vector<int> &, const std::vector<std::vector<at::Tensor>> &, const std::vector<std::vector<int64_t>> &,
+                    const std::vector<std::vector<at::Tensor>> &, const std::vector<std::vector<int64_t>> &, bool>());
+  m.def("stage_run", &stage::run, "a whole stage (block calls + concatenation) as ONE autograd node, training mode");
+  m.def("stage_run_eval", &stage::run_eval, "a whole stage on the running statistics, no graph");
   m.def("host_times", &host_times, "diagnostic: (calls, ns, ns in the backend call) of the block node's forward and backward; resets");
   m.def("index_plan", &index_plan, "coordinate pyramid + kernel maps + trilinear maps of a MinkUNet pass (releases the GIL)");
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");

@@ -53,6 +53,8 @@ class FlatSGD:
         return self.state[0]
 
     def zero_grad(self, set_to_none: bool = True):
+        from .parallel import bump_grad_epoch
+        bump_grad_epoch()
         for b in self.reducer.buckets:
             for p in b["params"]:
                 p.grad = None

@@ -16,6 +16,21 @@ __all__ = ["env_rank", "init_distributed", "shard_seeds", "wrap_ddp", "reduce_ma
            "GradBucketReducer"]
 
 
+_grad_epoch = 0
+
+
+def grad_epoch() -> int:
+    """Counter of "gradient slots may be handed out again" events (GradBucketReducer.finish(), FlatSGD.zero_grad()): a producer that
+    writes a gradient straight into a bucket slot (the stage programs, csrc/fastpath/stage_program.h) claims a parameter's slot at
+    most once per epoch - the second use of a weight in one graph gets a fresh tensor and autograd adds the two."""
+    return _grad_epoch
+
+
+def bump_grad_epoch():
+    global _grad_epoch
+    _grad_epoch += 1
+
+
 def env_rank():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
             int(os.environ.get("WORLD_SIZE", 1)))
@@ -184,6 +199,7 @@ class GradBucketReducer:
             if not b["launched"]:
                 self._launch(b)
         self._next = 0
+        bump_grad_epoch()
         for w in self._works:
             w.wait()
         self._works = []

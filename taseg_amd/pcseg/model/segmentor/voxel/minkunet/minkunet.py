@@ -18,6 +18,7 @@ from ...base_segmentors import BaseSegmentor
 from taseg_amd import backend as B
 from taseg_amd import _fast
 from .utils import voxel_to_point, voxelize_index
+from . import stage_program as _SP
 
 __all__ = ["MinkUNet", "unvoxelise_predictions"]
 
@@ -331,6 +332,9 @@ class MinkUNetBackbone(BaseSegmentor):
             z.additional_features["counts"][1] = plan["vox_counts"]
         x0 = spnn.conv_bn_act(self.stem[0], self.stem[1], x0, relu=True)          # stem = 2 x (conv, BN, ReLU)
         x0 = spnn.conv_bn_act(self.stem[3], self.stem[4], x0, relu=True)
+        progs = self._stage_programs(x0.F, plan)
+        if progs is not None:
+            return self._unet_stages(progs, x0.F, plan, concat)
         z0 = voxel_to_point(x0, z, nearest=False, features=False)      # z0.F is never read (cache carrier only)
 
         x1 = self.stage1(x0)
@@ -364,6 +368,62 @@ class MinkUNetBackbone(BaseSegmentor):
                                         [(plan["tri_idx"][k], plan["tri_w"][k], orders.get(k)) for _, k in sources])
         z3 = voxel_to_point(y4, z2)
         return z1.F, z2.F, z3.F
+
+    def _stage_programs(self, feats, plan):
+        """the compiled stage programs of this model (stage_program.StagePrograms) if they can serve this pass on this index plan,
+        else None: the module-by-module path then runs (TASEG_STAGE_PROGRAM=0, no native binding, Bottleneck blocks, hooks on
+        the conv modules, widths off the full-tile paths, an index plan without the U-Net's kernel maps ...)"""
+        if not _SP.enabled():
+            return None
+        progs = self.__dict__.get("_stage_progs")
+        if progs is None:
+            try:
+                progs = _SP.StagePrograms(self)
+            except _SP._Unsupported:
+                progs = False
+            self.__dict__["_stage_progs"] = progs
+        if progs is False or not progs.usable(feats, self.training, torch.is_grad_enabled()):
+            return None
+        if not all(k in plan["tri_idx"] for k in ((16, 16, 16), (4, 4, 4), (1, 1, 1))):
+            return None
+        half = spF._amp_half(feats)
+        self.__dict__["_stage_half"] = half          # (prepare() resolves the NEXT batch's geometry for this storage mode)
+        try:
+            progs.prepare(plan, half)                # cached in the plan: a no-op when the data stage has done it
+        except _SP._Unsupported:
+            return None
+        return progs
+
+    def _stage_prepare(self, plan):
+        """resolve the stage programs' geometry (kernel maps + class plans per op) with the index plan - on the thread that stages
+        the batch, not on the one that issues the step; a no-op until the first pass has compiled the programs"""
+        progs = self.__dict__.get("_stage_progs")
+        if progs:
+            try:
+                progs.prepare(plan, bool(self.__dict__.get("_stage_half", False)))
+            except _SP._Unsupported:
+                pass
+        return plan
+
+    def _unet_stages(self, progs, f0, plan, concat):
+        """stage1 .. up4 of `_unet_point_features` on the stage programs: one call (and one autograd node) per stage"""
+        tr = self.training
+        f1 = progs.run("stage1", (f0,), plan, tr)
+        f2 = progs.run("stage2", (f1,), plan, tr)
+        f3 = progs.run("stage3", (f2,), plan, tr)
+        f4 = progs.run("stage4", (f3,), plan, tr)
+        drop = torch.nn.functional.dropout
+        # (out of place: the point head devoxelises the features BEFORE dropout, minkunet.py:400-412)
+        y1 = progs.run("up1", (drop(f4, self.dropout.p, tr, False), f3), plan, tr)
+        y2 = progs.run("up2", (y1, f2), plan, tr)
+        y3 = progs.run("up3", (drop(y2, self.dropout.p, tr, False), f1), plan, tr)
+        y4 = progs.run("up4", (y3, f0), plan, tr)
+        keys = ((16, 16, 16), (4, 4, 4), (1, 1, 1))
+        tri_idx, tri_w, orders = plan["tri_idx"], plan["tri_w"], plan["tri_order"]
+        maps = [(tri_idx[k], tri_w[k], orders.get(k)) for k in keys]
+        if concat:
+            return spF.spdevoxelize_cat([f4, y2, y4], maps)
+        return tuple(spF.spdevoxelize(f, i, w, o) for f, (i, w, o) in zip((f4, y2, y4), maps))
 
     def _train_outputs(self, logits, target, coords_xyz, offset):
         loss = self.criterion_losses(logits, target, xyz=coords_xyz, offset=offset)
@@ -524,7 +584,7 @@ class MinkUNet(MinkUNetBackbone):
         with torch.no_grad():
             z = PointTensor(None, batch_dict["lidar"].C.float())
             coords, vox_idx, vox_counts = voxelize_index(z, self.pres, self.vres)      # minkunet.py:388-390
-        plan = self._index_plan(coords, z.C, vox_idx=vox_idx, vox_counts=vox_counts)
+        plan = self._stage_prepare(self._index_plan(coords, z.C, vox_idx=vox_idx, vox_counts=vox_counts))
         batch_dict["_plan"] = plan
         return plan
 

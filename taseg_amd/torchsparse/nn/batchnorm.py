@@ -19,6 +19,14 @@ def fast_path_ok(x: torch.Tensor) -> bool:
     return (x.dtype == torch.float32 and x.shape[1] % 4 == 0) or (x.dtype == torch.float16 and x.shape[1] % 8 == 0)
 
 
+def _bump(*buffers):
+    """the kernels wrote these buffers through raw pointers: move their version counters, as an in-place torch op would have -
+    whoever caches something derived from them (the evaluation blocks' 1 / sqrt(running_var + eps)) keys on the version"""
+    for b in buffers:
+        if b is not None:
+            torch.autograd.graph.increment_version(b)
+
+
 class _BatchNormActTrain(Function):
     """act(BN(x) [+ residual]) in training mode, forward and backward each as (one reduction + one elementwise
     pass) over [N, C]; the ReLU mask is one bit per element written by the forward."""
@@ -76,6 +84,7 @@ class _BatchNormActTrain(Function):
                     "ts_bn_act_forward" + sfx)
         ctx.save_for_backward(x, weight, mean, invstd, mask)
         ctx.group, ctx.total_dev, ctx.has_res, ctx.half, ctx.comm = group, total_dev, residual is not None, half, comm
+        _bump(running_mean, running_var)
         return out
 
     @staticmethod

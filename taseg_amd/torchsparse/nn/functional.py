@@ -896,6 +896,9 @@ class _ConvBlock(Function):
         else:
             call(comm)
         ctx.save_for_backward(x, w16 if half else w32, conv_out, stats, mask, bn_weight)
+        for buf in (running_mean, running_var):      # written through raw pointers: move the version counters (batchnorm._bump)
+            if buf is not None:
+                torch.autograd.graph.increment_version(buf)
         ctx.kmap, ctx.transposed, ctx.half, ctx.comm = kmap, transposed, half, comm
         ctx.group = group if split else None
         ctx.planes = None if half else planes

@@ -1,0 +1,185 @@
+"""The stage programs (csrc/fastpath/stage_program.h, minkunet/stage_program.py: one C++ issue loop and one autograd node per
+encoder / decoder stage) against the per-block nodes they replace: the same backend calls in the same order, so every result is
+compared BIT FOR BIT - loss, logits, all 191 gradients, running statistics, parameters after optimizer steps, evaluation logits;
+fp32 and autocast; plain autograd delivery and gradient-bucket slots; weight gradients on the caller's stream and on the second
+one.  Reference structure: R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:83-129 (blocks), :393-422 (the U-Net pass)."""
+import numpy as np
+import pytest
+import torch
+
+from taseg_amd.data.synthetic import fill_parameters, make_model_cfg, synth_scan
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan_batch(seed=5, n_points=30000, batch=1):
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.utils.quantize import sparse_quantize
+    cs, fs, ls = [], [], []
+    for b in range(batch):
+        pts, lab = synth_scan(seed + 7 * b, n_points=n_points, n_beams=32, n_az=1400)
+        pc = np.round(pts[:, :3] / 0.05).astype(np.int32)
+        pc -= pc.min(0)
+        _, idx, _ = sparse_quantize(pc, return_index=True, return_inverse=True)
+        cs.append(np.concatenate([pc[idx], np.full((len(idx), 1), b, np.int32)], 1))
+        fs.append(pts[idx])
+        ls.append(lab[idx].astype(np.int64))
+    coords = torch.from_numpy(np.concatenate(cs)).cuda()
+    feats = torch.from_numpy(np.concatenate(fs)).cuda()
+    labels = torch.from_numpy(np.concatenate(ls)).cuda()
+
+    def make():
+        return {"lidar": SparseTensor(feats.clone(), coords), "targets": SparseTensor(labels, coords), "offset": torch.tensor([0])}
+    return make, int(coords.shape[0])
+
+
+def _model(num_layer=None, seed=3, name="MinkUNet"):
+    from taseg_amd.pcseg.model import build_network
+    cfg = make_model_cfg(name, in_dim=4, cr=1.0, **({"num_layer": num_layer} if num_layer else {}))
+    return fill_parameters(build_network(cfg, 20), seed=seed).cuda()
+
+
+def _set(on):
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet import stage_program as SP
+    SP._ON = on
+    return SP
+
+
+def _train_pass(model, make, amp, use_programs):
+    SP = _set(use_programs)
+    grabbed = {}
+    h = model.classifier.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach().clone()))
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(11)                                  # the two dropout masks
+    with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        ret, _, _ = model(make())
+    ret["loss"].float().backward()
+    torch.cuda.synchronize()
+    h.remove()
+    _set(True)
+    progs = model.__dict__.get("_stage_progs")
+    return dict(loss=ret["loss"].detach().clone(), logits=grabbed["logits"],
+                grads={k: p.grad.detach().clone() for k, p in model.named_parameters()},
+                buffers={k: b.detach().clone() for k, b in model.named_buffers()}, compiled=bool(progs)), SP
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_stage_programs_train_step_equals_the_block_nodes(amp):
+    make, n = _scan_batch()
+    a, b = _model(), _model()
+    a.train()
+    b.train()
+    ref, _ = _train_pass(a, make, amp, use_programs=False)
+    got, _ = _train_pass(b, make, amp, use_programs=True)
+    assert got["compiled"] and not ref["compiled"]          # the second model really went through the programs
+    assert torch.equal(ref["loss"], got["loss"])
+    assert torch.equal(ref["logits"], got["logits"])
+    assert set(ref["grads"]) == set(got["grads"]) and len(got["grads"]) == 191          # 63 x (kernel, BatchNorm weight, bias) + the class head
+    bad = [k for k in ref["grads"] if not torch.equal(ref["grads"][k], got["grads"][k])]
+    assert not bad, bad[:5]
+    bad = [k for k in ref["buffers"] if not torch.equal(ref["buffers"][k], got["buffers"][k])]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_stage_programs_evaluation_equals_the_block_calls(amp):
+    make, n = _scan_batch(seed=8)
+    model = _model(seed=5).eval()
+    out = {}
+    for on in (False, True):
+        _set(on)
+        bd = make()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            plan = model.prepare(bd)
+            x = bd["lidar"]
+            from taseg_amd.torchsparse.nn import functional as spF
+            feats = spF.spvoxelize(x.F, plan["vox_idx"], plan["vox_counts"])
+            out[on] = model._unet(feats, x.F, plan).float().clone()
+    _set(True)
+    assert torch.equal(out[False], out[True])
+    assert bool(model.__dict__.get("_stage_progs"))
+
+
+@pytest.mark.parametrize("amp,side", [(False, False), (True, False), (False, True)])
+def test_stage_programs_with_flat_sgd_keep_the_parameters_bit_equal(amp, side):
+    """three optimizer steps on FlatSGD (gradient-bucket slots: the programs write all three gradients of a layer straight into
+    them), per-block nodes against stage programs, optionally with the weight gradients on the second stream"""
+    from taseg_amd import _fast
+    from taseg_amd.optim import FlatSGD
+    make, n = _scan_batch(batch=2, n_points=20000)
+    res = {}
+    for on in (False, True):
+        SP = _set(on)
+        model = _model(num_layer=[1, 2, 1, 2, 1, 1, 1, 1]).train()
+        opt = FlatSGD(model, lr=0.05, momentum=0.9, weight_decay=1e-4, max_norm=10.0, amp=amp)
+        _fast.wgrad_stream(side)
+        losses = []
+        for it in range(3):
+            opt.zero_grad()
+            torch.manual_seed(100 + it)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                ret, _, _ = model(make())
+            (ret["loss"].float().mean() * opt.loss_scale()).backward()
+            opt.step()
+            losses.append(float(ret["loss"]))
+        torch.cuda.synchronize()
+        _fast.wgrad_stream(False)
+        res[on] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, bool(model.__dict__.get("_stage_progs")))
+    _set(True)
+    assert res[True][2] and not res[False][2]
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    bad = [k for k in res[False][1] if not torch.equal(res[False][1][k], res[True][1][k])]
+    assert not bad, bad[:5]
+
+
+def test_running_statistics_written_by_a_training_pass_reach_the_evaluation_pass():
+    """the block calls update running_mean / running_var through raw pointers: an evaluation pass after MORE training must not reuse
+    the 1 / sqrt(running_var + eps) it cached before (both paths)"""
+    make, n = _scan_batch(seed=9)
+    for on in (False, True):
+        _set(on)
+        model = _model(num_layer=[1] * 8, seed=2)
+
+        def evaluate():
+            model.eval()
+            bd = make()
+            with torch.no_grad():
+                plan = model.prepare(bd)
+                from taseg_amd.torchsparse.nn import functional as spF
+                x = bd["lidar"]
+                return model._unet(spF.spvoxelize(x.F, plan["vox_idx"], plan["vox_counts"]), x.F, plan).clone()
+
+        def train_once():
+            model.train()
+            model.zero_grad(set_to_none=True)
+            ret, _, _ = model(make())
+            ret["loss"].backward()
+
+        train_once()
+        first = evaluate()
+        train_once()
+        second = evaluate()
+        # a model that only ever evaluates with the SAME buffers gives the reference answer for `second`
+        fresh = _model(num_layer=[1] * 8, seed=2)
+        fresh.load_state_dict(model.state_dict())
+        model_backup, model = model, fresh
+        want = evaluate()
+        model = model_backup
+        assert not torch.equal(first, second)
+        assert torch.equal(second, want), float((second - want).abs().max())
+    _set(True)
+
+
+def test_stage_program_falls_back_where_it_does_not_apply():
+    """hooks on a conv module, a frozen BatchNorm layer: the module-by-module path serves the pass (same results as ever)"""
+    make, n = _scan_batch(seed=4)
+    model = _model(num_layer=[1] * 8).train()
+    seen = []
+    h = model.stage2[1].net[0].register_forward_hook(lambda m, i, o: seen.append(tuple(o.F.shape)))
+    ret, _, _ = model(make())
+    ret["loss"].backward()
+    h.remove()
+    assert seen, "the hook on stage2's first convolution must fire"
+    model.stage3[1].net[1].eval()                     # one BatchNorm on its running statistics inside a training model
+    ret, _, _ = model(make())
+    assert torch.isfinite(ret["loss"])
