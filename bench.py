@@ -847,6 +847,9 @@ def main():
         B.profile_begin(expected_launches=800 * len(range(0, args.steps, EVENT_EVERY)))   # ~330 (bs 2) .. per step
     if host_phases is not None:
         host_phases.clear()
+        from taseg_amd import _fast as _f
+        if _f.module() is not None:
+            _f.module().host_times()
     host_prof = None
     if os.environ.get("TASEG_BENCH_CPROFILE") and rank == 0:      # diagnostic: interpreter profile of the timed steps
         import cProfile
@@ -876,6 +879,11 @@ def main():
         n_hp = max(host_phases.pop("steps", 1), 1)
         note("host issue time per step (ms, timed steps): " +
              ", ".join(f"{k} {1e3 * v / n_hp:.2f}" for k, v in host_phases.items()))
+        from taseg_amd import _fast as _f
+        if _f.module() is not None:      # the native block / stage nodes' own clocks (reset after the warm-up)
+            nf, tf, af, nb, tb, ab = _f.module().host_times()
+            note(f"native nodes per step: forward {nf / n_hp:.0f} blocks {1e-6 * tf / n_hp:.2f} ms ({1e-6 * af / n_hp:.2f} in the backend "
+                 f"calls), backward {nb / n_hp:.0f} blocks {1e-6 * tb / n_hp:.2f} ms ({1e-6 * ab / n_hp:.2f} in the backend calls)")
     dog.beat("collect")
     records = B.profile_end()
     # what an event pair measures with nothing between its two records, after the timed region: the per-launch figures

@@ -16,7 +16,7 @@ SRC = os.path.join(HERE, "fast_block.cpp")
 
 
 def build(force=False, verbose=False):
-    deps = [SRC, os.path.join(ROOT, "include", "taseg_hip.h"), os.path.abspath(__file__)]
+    deps = [SRC, os.path.join(HERE, "stage_program.h"), os.path.join(ROOT, "include", "taseg_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     from torch.utils import cpp_extension

@@ -271,6 +271,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
   static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, at::TensorList inputs_, at::TensorList params,
                                                 std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
                                                 int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
+    const int64_t t_in = now_ns();
     if (wg_join_queued.exchange(false)) {
       wg_worker.drain();
       check(api.stream_join((ts_stream_t)stream, (ts_stream_t)wg_side.raw), "ts_stream_join");
@@ -366,6 +367,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
                           r.stats + l.c_out, r.out, r.mask, r.w16, &bopts, ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
               "ts_conv_block_forward");
       };
+      const int64_t t_api = now_ns();
       if (split) {
         call(COMM_PRE);
         group_sum(st->group_id, view_of(st->arena, r.pack, 1, 2 * l.c_out + 1, at::kDouble).view({-1}));
@@ -373,16 +375,21 @@ class StageRun : public torch::autograd::Function<StageRun> {
       } else {
         call((void *)comm);
       }
+      host_clock.ns_fwd_api += now_ns() - t_api;
       // (the running statistics were written through raw pointers: whoever caches something derived from them must see a new version)
       if (l.rvar.defined()) l.rvar.unsafeGetTensorImpl()->bump_version();
       if (l.rmean.defined()) l.rmean.unsafeGetTensorImpl()->bump_version();
       reg[o.dst] = r.out;
     }
     ctx->saved_data["state"] = c10::IValue::make_capsule(st);
-    return {view_of(st->arena, reg[p.out_reg], rows[p.out_reg], ch[p.out_reg], dt)};
+    at::Tensor result = view_of(st->arena, reg[p.out_reg], rows[p.out_reg], ch[p.out_reg], dt);
+    host_clock.ns_fwd += now_ns() - t_in;
+    host_clock.n_fwd += (int64_t)p.layers.size();
+    return {result};
   }
 
   static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads) {
+    const int64_t t_in = now_ns();
     auto st = c10::static_intrusive_pointer_cast<State>(ctx->saved_data["state"].toCapsule());
     Program &p = *st->prog;
     const Geometry &g = *st->geom;
@@ -445,7 +452,6 @@ class StageRun : public torch::autograd::Function<StageRun> {
     G[p.out_reg] = g_out.data_ptr();
     std::vector<at::Tensor> gparams(3 * p.layers.size());
     const bool side_possible = wg_side.on && !comm && !split && like.get_device() == wg_side.device_index && stream != wg_side.raw;
-    bool side_used = false;
     for (int i = (int)n_ops - 1; i >= 0; --i) {
       const Op &o = p.ops[i];
       if (o.kind == CAT) {
@@ -516,11 +522,12 @@ class StageRun : public torch::autograd::Function<StageRun> {
         bopts.wgrad_ws_bytes = (size_t)sd.ring[slot].numel();
         bopts.wgrad_slot = slot;
         bopts.wgrad_deferred = 1;
-        if (!side_used) {                 // the second stream reads the blocks' inputs: the forward arena and the stage's inputs
-          st->arena.record_stream(side);
-          for (const at::Tensor &x : st->inputs) x.record_stream(side);
-          side_used = true;
-        }
+        // What the second stream reads (block inputs: the forward arena, the stage's inputs) stays alive through `keep` below until
+        // the job has been enqueued and through the graph until the pass has ended - and the pass ends with the join of the second
+        // stream into this one (the engine callback below): whatever reuses that memory afterwards is ordered behind the reads.  No
+        // record_stream on the arena: a block with a pending cross-stream event is withheld from the allocator's pool while the
+        // device is behind the host, and a device-bound fp32 step then spent 3 ms per pass in the allocator.  A fresh weight
+        // gradient becomes p.grad and may be dropped by the caller at any time: that one is marked.
         if (!r.use_dest) grad_w.record_stream(side);
         {
           // (grad_w by address only: one more owner and AccumulateGrad would copy the gradient instead of adopting the tensor)
@@ -564,7 +571,9 @@ class StageRun : public torch::autograd::Function<StageRun> {
         call(COMM_PRE);                   // this rank's sums of the BatchNorm backward
         group_sum(st->group_id, view_of(garena, sums, 1, 2 * l.c_out, at::kDouble).view({-1}));
       }
+      const int64_t t_api = now_ns();
       call(split ? COMM_POST : (void *)comm);
+      host_clock.ns_bwd_api += now_ns() - t_api;
       if (side_job) wg_worker.push(std::move(side_job));      // (the call has recorded the slot's ready event)
       if (feat_add) view_of(garena, grad_feat, drows, l.c_in, dt).add_(view_of(garena, G[o.src], drows, l.c_in, dt));
       if (grad_feat) G[o.src] = grad_feat;
@@ -587,6 +596,8 @@ class StageRun : public torch::autograd::Function<StageRun> {
     }
     for (auto &t : gparams) out.push_back(std::move(t));
     for (int i = 0; i < 7; ++i) out.push_back(at::Tensor());      // prog, geom, half, stream, comm, group_id, grad_epoch
+    host_clock.ns_bwd += now_ns() - t_in;
+    host_clock.n_bwd += (int64_t)p.layers.size();
     return out;
   }
 };
