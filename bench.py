@@ -359,6 +359,8 @@ def summarise_profile(records, steps):
             byts = p * m["c_out"] * es + m["n_rows"] * m["c_out"] * es + m["k"] * m["n_rows"] * 4 + m.get("side_bytes", 0.0)
         elif kind == "conv_wgrad":   # both gathered operands + rulebook + the gradient written once (no scatter term)
             byts = p * (m["c_red"] * es + m["c_out"] * es + 8) + m["k"] * m["c_red"] * m["c_out"] * 4
+        elif kind == "wgrad_reduce": # partial tiles read once + the gradient written (csrc/block.hip, second-stream form)
+            byts = m["bytes"]
         else:                        # single-launch forms (conv_nbr, conv_os): gather read + output rows + table + weights
             byts = p * (m["c_red"] * es + 8) + m.get("n_out", m.get("n_rows", 0)) * m["c_out"] * es + m["k"] * m["c_red"] * m["c_out"] * es
         # ideal-fused lower bound of the same launch: every feature row read / written once, the
@@ -370,6 +372,8 @@ def summarise_profile(records, steps):
             ideal = rows * m["c_out"] * es
         elif kind == "conv_wgrad":
             ideal = rows * m["c_red"] * es + m.get("n_rows_b", 0) * m["c_out"] * es + 8 * p + m["k"] * m["c_red"] * m["c_out"] * 4
+        elif kind == "wgrad_reduce":
+            ideal = 0.0                  # (a fused weight gradient writes its result once: counted with conv_wgrad)
         else:
             ideal = byts
         g = groups.setdefault(m["name"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "ideal": 0.0})

@@ -100,8 +100,11 @@ class _Sparse:
 class OracleMinkUNet:
     """params: dict name -> torch CPU tensor (the reference state_dict layout)."""
 
-    def __init__(self, params, cfg, num_class=20, backend="numpy", training=True):
+    def __init__(self, params, cfg, num_class=20, backend="numpy", training=True, act=None):
         self.p = params
+        # the activation of every block: ReLU (minkunet.py:42-51) - a smooth stand-in lets a gradient comparison judge arithmetic
+        # alone (no ReLU flips between two roundings of the same pre-activation: tests/test_gpu_bench_backward.py)
+        self.act = torch.relu if act is None else act
         self.cfg = cfg
         self.backend = backend
         self.training = training
@@ -145,18 +148,18 @@ class OracleMinkUNet:
 
     def conv_bn_relu(self, x, name, ks, stride=1, transposed=False):
         x = self.bn(self.conv(x, name + ".net.0", ks, stride, transposed), name + ".net.1")
-        return x.like(torch.relu(x.F))
+        return x.like(self.act(x.F))
 
     def resblock(self, x, name):
         """R/.../minkunet.py:83-129."""
         y = self.bn(self.conv(x, name + ".net.0", 3), name + ".net.1")
-        y = y.like(torch.relu(y.F))
+        y = y.like(self.act(y.F))
         y = self.bn(self.conv(y, name + ".net.3", 3), name + ".net.4")
         if (name + ".downsample.0.kernel") in self.p:
             sc = self.bn(self.conv(x, name + ".downsample.0", 1), name + ".downsample.1")
         else:
             sc = x
-        return y.like(torch.relu(y.F + sc.F))
+        return y.like(self.act(y.F + sc.F))
 
     def stage(self, x, name, depth):
         x = self.conv_bn_relu(x, name + ".0", 2, 2)
@@ -183,9 +186,9 @@ class OracleMinkUNet:
         nl = self.num_layer
         cache = {}
         x0 = self.bn(self.conv(x0, "stem.0", 3), "stem.1")
-        x0 = x0.like(torch.relu(x0.F))
+        x0 = x0.like(self.act(x0.F))
         x0 = self.bn(self.conv(x0, "stem.3", 3), "stem.4")
-        x0 = x0.like(torch.relu(x0.F))
+        x0 = x0.like(self.act(x0.F))
         self.voxel_to_point(x0, zC, cache)  # z0: only the cached maps matter
         x1 = self.stage(x0, "stage1", nl[0])
         x2 = self.stage(x1, "stage2", nl[1])

@@ -614,6 +614,9 @@ def profile_end():
         elif int(kind) == 4:      # ... finished inside the product: `wt` = Z' rows moved (written + read back), result rows = rows
             out.append(("class_gemm", _Ms(ms), None, dict(name=f"class_gemm_kernel<{pick(c_out)}>", pairs=pairs, c_red=c_red,
                                                           c_out=c_out, k=k, esize=esize, n_rows=rows, z_rows=int(wt), out_rows=rows)))
+        elif int(kind) == 5:      # the ordered sum of the weight gradient's partial tiles as a launch of its own (second stream)
+            out.append(("wgrad_reduce", _Ms(ms), None, dict(name="wgrad_reduce_seq_kernel" if rows else "wgrad_reduce_kernel", pairs=0,
+                                                            c_red=c_red, c_out=c_out, k=k, esize=4, n_rows=0, bytes=float(wt))))
         elif int(kind) == 1:
             name = gather_sum_kernel_name(c_out, k, half)
             out.append(("gather_sum", _Ms(ms), None, dict(name=name, pairs=pairs, c_red=0, c_out=c_out, k=k, n_rows=rows,

@@ -612,6 +612,9 @@ extern "C" int ts_conv_block_wgrad_side(const void *feat, int64_t n_feat_rows, i
   }
   if (rc == TS_OK) {
     const TsWgradReduce job = {part, nboffs, grad_kernel, K, g_ts_wgrad_plan.chunk, (int64_t)c_in * c_out / 4};
+    // (kind 5: the ordered sum of the partial tiles as a launch of its own; last field = its bytes, `rows` = 1 for the chunk order
+    // of the riding form, wgrad_reduce_seq_kernel)
+    ProfScope ps(5, side_stream, 0, c_in, c_out, K, chunk_order ? 1.0 : 0.0, 4, 4.0 * c_in * c_out * ((double)g_ts_wgrad_plan.slots + K));
     rc = chunk_order ? ts_wgrad_reduce_seq(job, side_stream) : ts_wgrad_reduce(job, side_stream);
   }
   if (hipEventRecord(g_wg_done[slot], (hipStream_t)side_stream) != hipSuccess && rc == TS_OK) rc = TS_ERR_LAUNCH_FAILED;

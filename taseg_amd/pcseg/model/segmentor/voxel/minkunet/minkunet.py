@@ -375,19 +375,17 @@ class MinkUNetBackbone(BaseSegmentor):
         the conv modules, widths off the full-tile paths, an index plan without the U-Net's kernel maps ...)"""
         if not _SP.enabled():
             return None
-        progs = self.__dict__.get("_stage_progs")
+        progs = _SP.programs_of(self)
         if progs is None:
-            try:
-                progs = _SP.StagePrograms(self)
-            except _SP._Unsupported:
-                progs = False
-            self.__dict__["_stage_progs"] = progs
-        if progs is False or not progs.usable(feats, self.training, torch.is_grad_enabled()):
+            return None
+        if not progs.usable(feats, self.training, torch.is_grad_enabled()):
+            if progs.stale:                          # parameter / buffer objects were replaced: compile again at the next pass
+                _SP.forget(self)
             return None
         if not all(k in plan["tri_idx"] for k in ((16, 16, 16), (4, 4, 4), (1, 1, 1))):
             return None
         half = spF._amp_half(feats)
-        self.__dict__["_stage_half"] = half          # (prepare() resolves the NEXT batch's geometry for this storage mode)
+        progs.half = half                            # (prepare() resolves the NEXT batch's geometry for this storage mode)
         try:
             progs.prepare(plan, half)                # cached in the plan: a no-op when the data stage has done it
         except _SP._Unsupported:
@@ -397,10 +395,10 @@ class MinkUNetBackbone(BaseSegmentor):
     def _stage_prepare(self, plan):
         """resolve the stage programs' geometry (kernel maps + class plans per op) with the index plan - on the thread that stages
         the batch, not on the one that issues the step; a no-op until the first pass has compiled the programs"""
-        progs = self.__dict__.get("_stage_progs")
-        if progs:
+        progs = _SP.programs_of(self, compile=False)
+        if progs is not None:
             try:
-                progs.prepare(plan, bool(self.__dict__.get("_stage_half", False)))
+                progs.prepare(plan, progs.half)
             except _SP._Unsupported:
                 pass
         return plan

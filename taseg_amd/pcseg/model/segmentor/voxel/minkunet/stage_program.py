@@ -11,6 +11,7 @@ path stays behind `TASEG_STAGE_PROGRAM=0` and serves every model the programs do
 modules, channel counts off the full-tile paths, frozen BatchNorm layers ...).
 """
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -23,7 +24,7 @@ from taseg_amd.torchsparse.nn import functional as spF
 from taseg_amd.torchsparse.nn import modules as spM
 from taseg_amd.torchsparse.utils import make_ntuple
 
-__all__ = ["StagePrograms", "enabled"]
+__all__ = ["StagePrograms", "enabled", "programs_of", "forget", "compiled"]
 
 _ON = os.environ.get("TASEG_STAGE_PROGRAM", "1") != "0"
 _ONES = (1, 1, 1)
@@ -38,9 +39,34 @@ class _Unsupported(Exception):
     pass
 
 
+# model -> StagePrograms | False (this model's structure is not served).  Kept here, not on the module: a module's __dict__ is
+# what copy.deepcopy / pickle walk, and a compiled program is neither
+_PROGRAMS = weakref.WeakKeyDictionary()
+
+
+def programs_of(model, compile=True):
+    """the compiled programs of `model`, compiling them at the first call; None when its structure is not served"""
+    hit = _PROGRAMS.get(model)
+    if hit is None and compile:
+        try:
+            hit = StagePrograms(model)
+        except _Unsupported:
+            hit = False
+        _PROGRAMS[model] = hit
+    return hit or None
+
+
+def forget(model):
+    _PROGRAMS.pop(model, None)
+
+
+def compiled(model) -> bool:
+    return bool(_PROGRAMS.get(model))
+
+
 class _Stage:
     """one compiled stage: the C++ program, its (conv, bn) modules and the kernel-map key of every op"""
-    __slots__ = ("program", "layers", "ops", "keys", "in_strides", "planes_state", "dest_state", "bns", "convs")
+    __slots__ = ("program", "layers", "ops", "keys", "in_strides", "planes_state", "dest_state", "bns", "convs", "modules", "held")
 
 
 def _tup(v):
@@ -51,6 +77,8 @@ class StagePrograms:
     def __init__(self, model):
         fast = _fast.module()
         self.fast = fast
+        self.stale = False
+        self.half = False                 # storage mode of the last pass (what prepare() resolves the next batch for)
         self.stages = {}
         from .minkunet import BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock
         self._kinds = (BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock)
@@ -59,6 +87,9 @@ class StagePrograms:
         for name, stride in (("up1", 16), ("up2", 8), ("up3", 4), ("up4", 2)):
             up = getattr(model, name)
             self.stages[name] = self._compile([up[0]] + list(up[1].children()), (stride, stride // 2), cat_after_first=True)
+        for name, st in self.stages.items():
+            # every module the program stands in for: a forward / backward hook on any of them must still fire (module path then)
+            st.modules = list(getattr(model, name).modules())
 
     # ------------------------------------------------------------------ model side
     def _compile(self, blocks, in_strides, cat_after_first):
@@ -128,6 +159,8 @@ class StagePrograms:
             track = bn.track_running_stats and bn.running_mean is not None
             layers.append((conv.kernel, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
                            bn.num_batches_tracked if track else None, float(bn.momentum), float(bn.eps)))
+        st.held = [(c._parameters["kernel"], b._parameters["weight"], b._parameters["bias"], b._buffers.get("running_mean"),
+                    b._buffers.get("running_var")) for c, b in st.layers]
         st.program = self.fast.StageProgram(len(in_strides), cur, st.ops, layers)
         st.planes_state = {False: None, True: None}
         st.dest_state = None
@@ -196,9 +229,19 @@ class StagePrograms:
         if not half and feats.dtype != torch.float32:
             return False
         for st in self.stages.values():
-            for conv, bn in st.layers:
-                if bn.training != training or conv._forward_hooks or conv._forward_pre_hooks or bn._forward_hooks \
-                        or bn._forward_pre_hooks:
+            for m in st.modules:
+                if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                    return False
+            for (conv, bn), held in zip(st.layers, st.held):
+                if bn.training != training:
+                    return False
+                # the program holds these tensor objects: a module whose parameter / buffer objects were replaced since
+                # (`.to()` swaps buffers, an assignment swaps a parameter) needs a new program
+                pb = bn._buffers
+                if conv._parameters["kernel"] is not held[0] or bn._parameters["weight"] is not held[1] \
+                        or bn._parameters["bias"] is not held[2] or pb.get("running_mean") is not held[3] \
+                        or pb.get("running_var") is not held[4]:
+                    self.stale = True
                     return False
                 k = conv.kernel
                 c_in, c_out = k.shape[-2], k.shape[-1]
