@@ -98,10 +98,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms", "nuscenes_ms"],
+    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms", "nuscenes_ms", "tiaf"],
                     help="minkunet = BASELINE configs[1] (headline); minkunet_ms = configs[2] (4-scan TFA); "
                          "nuscenes_ms = configs[4] shape: 32-beam 34.7k-point sweeps, 15 history sweeps, voxel 0.1 m, "
-                         "17 classes, bs 4 (fp32 here)")
+                         "17 classes, bs 4 (fp32 here); tiaf = MinkUNetMsMm (temporal image aggregation and fusion, "
+                         "minkunet_mk34_cr10_fsa_tiaf.yaml): 16 fused history scans, 5 camera frames of 384 x 1280 per sample, bs 2")
     ap.add_argument("--batch", type=int, default=None, help="scans per GPU per step (default 2; 4 for nuscenes_ms)")
     ap.add_argument("--points", type=int, default=None, help="points per scan (default 120000; 34700 for nuscenes_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,6 +188,76 @@ def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label
             npts += len(p)
         scans.append({"points": pts, "labels": labs, "poses": poses, "name": f"{rank}/{b}"})
     return scans, npts
+
+
+TIAF_HEIGHT, TIAF_WIDTH, TIAF_MULTISCAN, TIAF_MULTISCAN_IMAGE, TIAF_STEP_IMAGE = 384, 1280, 16, 48, 12   # tiaf yaml :17-22
+
+
+def make_tiaf_frames(rank, batch, points, n_beams=64, n_az=2083):
+    """Resident inputs of the TIAF workload (R/tools/cfgs/voxel/semantic_kitti/minkunet_mk34_cr10_fsa_tiaf.yaml: MULTISCAN 16,
+    MULTISCAN_IMAGE 48, STEP_IMAGE 12, HEIGHT 384, WIDTH 1280, bs 2): per sample the current scan, the 16 history scans the LiDAR
+    aggregation walks and the scans of the camera frames at -24 / -36 / -48, each with labels, pseudo labels and pose; a
+    KITTI-sized uint8 camera image (376 x 1241) + label map for the current frame and every 12th history frame; P2 @ Tr of a
+    camera looking along +x.  Everything the reference's dataset does with them (projection, FOV test, crop / pad, temporal
+    aggregation, three-cloud voxelisation, collate: semantickitti_ms_mm.py:304-461, semantickitti_voxel_ms_mm.py:79-266) runs on
+    the device INSIDE the timed step (taseg_amd.data.tiaf)."""
+    from taseg_amd.data.synthetic import synth_pose, synth_scan
+    dev = torch.device("cuda")
+    with_img = [d for d in range(0, -TIAF_MULTISCAN_IMAGE - 1, -TIAF_STEP_IMAGE)]
+    deltas = sorted(set(range(0, -TIAF_MULTISCAN - 1, -1)) | set(with_img))
+    proj = torch.tensor([[609.5, -721.5, 0.0, -44.86], [172.85, 0.0, -721.5, -216.4], [1.0, 0.0, 0.0, -0.27]], dtype=torch.float64, device=dev)
+    samples, npts = [], 0
+    for b in range(batch):
+        seed = 1000 * rank + 100 * b
+        rs = np.random.RandomState(seed)
+        frames = {}
+        for d in deltas:
+            pose = synth_pose(-d)
+            p, l = synth_scan(seed - d, n_points=points, pose=pose, scene_seed=seed, n_beams=n_beams, n_az=n_az)
+            lab = torch.from_numpy(l.astype(np.int64)).to(dev)
+            f = {"points": torch.from_numpy(p).to(dev), "labels": lab, "pseudo": lab, "pose": torch.from_numpy(pose).to(dev)}
+            if d in with_img:
+                f["image"] = torch.from_numpy(rs.randint(0, 256, (376, 1241, 3), dtype=np.uint8)).to(dev)
+                f["semantic"] = torch.from_numpy(rs.randint(0, 20, (376, 1241, 1)).astype(np.float32)).to(dev)
+            frames[d] = f
+            npts += len(p)
+        samples.append(frames)
+    return samples, proj, npts
+
+
+def tiaf_gather_roofline(model, bd):
+    """The image -> point gather and its adjoint (csrc/image.hip) alone on the device, at the shapes of this batch: HIP events
+    around 20 launches each on the current stream; algorithmic bytes n * C * 4 gathered + n * C * 4 written (forward), n * C * 4
+    read + 2 * 4 * C per touched pixel read-modify-written (adjoint, into the map's other gradient)."""
+    from taseg_amd import backend as B
+    fov = bd["lidar_fov_ms"]
+    pix = fov.F[:, -2:].float().contiguous()
+    pbatch = fov.C[:, -1].int().contiguous()
+    frame_end = bd["offset_img"].int().contiguous()
+    T = int(bd["image_ms"].shape[0])
+    out = []
+    for name, c, shift in (("u4 (full scale, 96 channels)", 96, 0), ("u2 (1/4 scale, 128 channels)", 128, 2), ("logits (full scale, 20 channels)", 20, 0)):
+        plan = B.image_plan(pix, pbatch, frame_end, T, TIAF_HEIGHT, TIAF_WIDTH, shift)
+        hs, ws = plan["shape"]
+        feat = torch.randn(T, c, hs, ws, device="cuda")
+        gout = torch.randn(plan["n"], c, device="cuda")
+        touched = int((plan["run"][:plan["n"]] > 0).sum())
+        rec = {"map": name, "points": plan["n"], "touched_pixels": touched}
+        for kind, fn, byts in (("forward", lambda: B.image_gather_forward(feat, plan), plan["n"] * c * 8.0),
+                               ("adjoint", lambda: B.image_gather_backward(gout, plan, c, into=feat), plan["n"] * c * 4.0 + touched * c * 8.0)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / 20
+            rec[kind] = {"avg_us": us, "algorithmic_bytes": byts, "achieved_GBs": byts / us / 1e3, "hbm_frac": byts / us / 1e3 / HBM_PEAK_GBS}
+        out.append(rec)
+        del feat, gout
+    return out
 
 
 def make_nusc_samples(rank, batch, points, multiscan=15, step=1.0):
@@ -513,9 +584,12 @@ def secondary_runs(steps=30, warmup=8):
     own JSON line cut down to value / ms_per_step / dtype / config."""
     import subprocess
     out = []
-    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"], ["--eval"], ["--eval", "--amp"]):
+    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"], ["--eval"], ["--eval", "--amp"],
+                  ["--workload", "tiaf"]):
         note("secondary run: " + " ".join(extra))
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+        # (a TIAF step is ~20x a LiDAR-only step - dense 2-D convolutions over ten 384 x 1280 frames: fewer of them)
+        k, w = (8, 3) if "tiaf" in extra else (steps, warmup)
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(k), "--warmup", str(w), "--no-cpu-baseline",
                "--no-secondary"] + extra           # per-launch events on the first timed step: every entry has its roofline
         entry = {"args": " ".join(extra)}
         try:
@@ -534,6 +608,8 @@ def secondary_runs(steps=30, warmup=8):
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
                                                              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
                                                              "whole_step_lower_bound_ms")} if roof else None
+                if rec.get("image_gather") is not None:
+                    entry["image_gather"] = rec["image_gather"]
                 entry["conv_bytes_per_step"] = rec.get("conv_bytes_per_step")
                 entry["ideal_fused_bytes_per_step"] = rec.get("ideal_fused_bytes_per_step")
         except Exception as exc:      # a failed side run must not lose the headline line
@@ -682,17 +758,24 @@ def main():
     from taseg_amd.torchsparse import SparseTensor
 
     B.set_conv_impl(args.conv_impl)
+    if args.workload == "tiaf":
+        args.no_kernel_events = True      # (its roofline entry is the image gather's, measured after the timed steps)
     nusc = args.workload == "nuscenes_ms"
-    ms = args.workload in ("minkunet_ms", "nuscenes_ms")
+    tiaf = args.workload == "tiaf"
+    ms = args.workload in ("minkunet_ms", "nuscenes_ms", "tiaf")
     if args.batch is None:
         args.batch = 4 if nusc else 2
     if args.points is None:
         args.points = 34700 if nusc else 120000
     voxel = 0.1 if nusc else VOXEL
     num_class = 17 if nusc else 20
-    name = "MinkUNetMs" if ms else "MinkUNet"
+    name = "MinkUNetMsMm" if tiaf else "MinkUNetMs" if ms else "MinkUNet"
     # nuScenes FSA feeds 4 features (the time flag column is cut by IN_FEATURE_DIM: 4, nuscenes fsa yaml:16,27)
-    cfg = make_model_cfg(name, in_dim=(4 if nusc else 5) if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn)
+    extra_cfg = {}
+    if tiaf:
+        from taseg_amd.data.synthetic import TIAF_CFG
+        extra_cfg = dict(TIAF_CFG)
+    cfg = make_model_cfg(name, in_dim=(4 if nusc else 5) if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn, **extra_cfg)
     torch.manual_seed(0)
     model = build_network(cfg, num_class).cuda().train()
     net = model
@@ -728,6 +811,18 @@ def main():
             def make_batch():
                 bd = build_nuscenes_batch(nsamples, voxel, FLEXIBLE_STEPS_NUSC)
                 nvox[0] = int(bd["lidar_ms"].C.shape[0])
+                return bd
+        elif tiaf:
+            from taseg_amd.data.tiaf import build_tiaf_batch, build_tiaf_sample
+            tiaf_frames, tiaf_proj, npts = make_tiaf_frames(rank, args.batch, args.points)
+            n_fov = [0]
+
+            def make_batch():
+                samples = [build_tiaf_sample(fr, FLEXIBLE_STEPS_KITTI, TIAF_MULTISCAN, TIAF_STEP_IMAGE, tiaf_proj,
+                                             (TIAF_HEIGHT, TIAF_WIDTH), voxel, name=f"{rank}/{b}") for b, fr in enumerate(tiaf_frames)]
+                bd = build_tiaf_batch(samples)
+                nvox[0] = int(bd["lidar_ms"].C.shape[0])
+                n_fov[0] = int(bd["lidar_fov_ms"].C.shape[0])
                 return bd
         else:
             scans, npts = make_multiscans(rank, args.batch, args.points)
@@ -935,7 +1030,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 storage / f32 accumulate (torch.autocast)" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": f"{name} mk34 cr1.0 ("
-                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
+                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else 'TIAF: 16 fused history scans + 5 camera frames of 384 x 1280 per sample, UNet2D + UNet3D + fusion head, five losses' if tiaf else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
                                    f"bs={args.batch}/GPU, voxel {voxel:g} m, {'AMP fp16' if args.amp else 'fp32'}, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}",
@@ -952,7 +1047,10 @@ def main():
             "conv_bytes_per_step": sum(r["bytes_per_step"] for r in prof) if prof else None,
             "ideal_fused_bytes_per_step": sum(r["ideal_fused_bytes_per_step"] for r in prof) if prof else None,
         }
-        if world == 1 and not args.no_cpu_baseline and not nusc:      # cpu_baseline is defined on the KITTI-shaped scan
+        if tiaf:
+            line["config"]["fov_points_per_step_per_gpu"] = n_fov[0]
+            line["image_gather"] = tiaf_gather_roofline(model, pf._current if pf is not None and pf._current is not None else make_batch())
+        if world == 1 and not args.no_cpu_baseline and not nusc and not tiaf:      # cpu_baseline is defined on the KITTI-shaped scan
             line["cpu_baseline"] = cpu_baseline(args, name, cfg.IN_FEATURE_DIM)
             if line["cpu_baseline"]["value"]:
                 line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

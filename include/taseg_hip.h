@@ -360,14 +360,24 @@ int ts_devoxelize_backward_cells_f16_ld(const void *grad_out, int64_t go_ld, con
  * feat [T, C, H >> shift, W >> shift] f32 (the stacked camera frames of all samples), pix [n, 2] f32 = (row, col) in
  * the sample's tall (T_b * H, W) image (truncated like the reference's `.long()`), pbatch [n] sample index,
  * frame_end [n_batch] cumulative frame counts (`offset_img`), shift = 0 (full scale) or 2 (the 1/4-scale map,
- * `row // 4, col // 4`).  *err is set to 1 if a pixel falls outside its sample's frames (the reference raises).
- * The backward zeroes grad_feat and accumulates with float atomics. */
-int ts_image_gather_forward(const float *feat, const float *pix, const int32_t *pbatch, const int32_t *frame_end,
-                            int64_t n_pts, int32_t n_batch, int32_t T, int32_t C, int32_t H, int32_t W,
-                            int32_t shift, float *out, int32_t *err, ts_stream_t stream);
-int ts_image_gather_backward(const float *grad_out, const float *pix, const int32_t *pbatch, const int32_t *frame_end,
-                             int64_t n_pts, int32_t n_batch, int32_t T, int32_t C, int32_t H, int32_t W,
-                             int32_t shift, float *grad_feat, ts_stream_t stream);
+ * `row // 4, col // 4`).
+ *   ts_image_plan            once per batch and scale: the points in RASTER order of their pixels - perm [n] (point index of the
+ *                            i-th point of that order; stable: equal pixels keep index order), paddr [n] (pixel address
+ *                            (frame * hs + r) * ws + c of that point, -1 if it falls outside its sample's frames: *err is then set
+ *                            to 1 - the reference raises), run [n] (points on that pixel if i is the first of them, else 0)
+ *   ts_image_gather_forward  out [n, C] rows in the original point order from one map of that scale (hw = hs * ws); lanes run
+ *                            along the points of the raster order, one plane at a time, rows leave through an LDS transpose
+ *   ts_image_gather_backward the adjoint as a segmented sum over the same order - no atomics, run-to-run identical: grad_feat
+ *                            (n_feat = T * C * hw elements) += per-pixel sums, touching only pixels that have points;
+ *                            accumulate == 0 zero-fills grad_feat first, != 0 adds into the gradient the map already has */
+size_t ts_image_plan_workspace_bytes(int64_t n_pts);
+int ts_image_plan(const float *pix, const int32_t *pbatch, const int32_t *frame_end, int64_t n_pts, int32_t n_batch, int32_t T, int32_t H,
+                  int32_t W, int32_t shift, int32_t *perm, int32_t *paddr, int32_t *run, int32_t *err, void *ws, size_t ws_bytes,
+                  ts_stream_t stream);
+int ts_image_gather_forward(const float *feat, int32_t C, int64_t hw, const int32_t *perm, const int32_t *paddr, int64_t n_pts, float *out,
+                            ts_stream_t stream);
+int ts_image_gather_backward(const float *grad_out, int32_t C, int64_t hw, const int32_t *perm, const int32_t *paddr, const int32_t *run,
+                             int64_t n_pts, float *grad_feat, int64_t n_feat, int32_t accumulate, ts_stream_t stream);
 
 /* ---- fp16 storage / fp32 accumulation (the reference trains under AMP: conv.py:19 `custom_fwd(cast_inputs=half)`).
  * `void *` operands are IEEE half arrays.  Channel counts must be multiples of 32, K <= 63.

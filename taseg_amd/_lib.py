@@ -73,8 +73,10 @@ SIGNATURES = {
     "ts_devox_order_workspace_bytes": (_sz, [_i64]),
     "ts_devox_order": (_i32, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "ts_devoxelize_backward_runs": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
-    "ts_image_gather_forward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "ts_image_gather_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_image_plan_workspace_bytes": (_sz, [_i64]),
+    "ts_image_plan": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_image_gather_forward": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "ts_image_gather_backward": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_pair_gemm_f16_nat": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),

@@ -733,37 +733,60 @@ def conv_wgrad(a_feat, b_feat, nbmaps, nboffs, kernel_volume, col_a, max_pairs):
     return out
 
 
-def image_gather_forward(feat, pix, pbatch, frame_end, height, width, shift=0):
-    """out[n, c] = feat[first_frame(b_n) + row_n // H, c, (row_n % H) >> shift, col_n >> shift]  (unet2d.py:180-214).
-
-    feat [T, C, H >> shift, W >> shift]; pix [n, 2] float (row in the sample's stacked frames, col); pbatch [n]
-    int32; frame_end [B] int32 cumulative frame counts.  Returns (out [n, C], err int32[1]) - err != 0 if a pixel
-    lies outside its sample's frames (checked lazily by the caller: reading it is a host sync)."""
-    L.require_device(feat, pix, pbatch, frame_end)
-    feat, pix = _f32(feat, "feat"), _f32(pix, "pix")
+def image_plan(pix, pbatch, frame_end, frames, height, width, shift=0):
+    """The FOV points of a batch in raster order of the pixels they project to, for one scale of the camera stack (unet2d.py:180-214;
+    csrc/image.hip): dict(perm, paddr, run, err, n, hw, frames, shape) - `err` (int32[1], device) is non-zero if a point falls outside
+    its sample's frames (the reference's indexing raises; reading it is a host sync, so the caller checks it lazily).
+    pix [n, 2] float (row in the sample's stacked frames, col); pbatch [n] int32; frame_end [B] int32 cumulative frame counts."""
+    L.require_device(pix, pbatch, frame_end)
+    pix = _f32(pix, "pix")
     pbatch, frame_end = _i32(pbatch, "pbatch"), _i32(frame_end, "frame_end")
-    t, c, hs, ws = feat.shape
-    if (hs, ws) != (height >> shift, width >> shift):
-        raise ValueError(f"feature map {hs}x{ws} does not match {height}x{width} >> {shift}")
-    n = pix.shape[0]
+    n = int(pix.shape[0])
+    dev = pix.device
+    perm, paddr, run = (torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(3))
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = L.load()
+    ws = L.workspace(lib.ts_image_plan_workspace_bytes(n), dev)
+    L.check(lib.ts_image_plan(L.ptr(pix), L.ptr(pbatch), L.ptr(frame_end), n, frame_end.shape[0], int(frames), int(height), int(width),
+                              int(shift), L.ptr(perm), L.ptr(paddr), L.ptr(run), L.ptr(err), L.ptr(ws), ws.numel(), L.stream()),
+            "ts_image_plan")
+    hs, ws_ = int(height) >> shift, int(width) >> shift
+    return dict(perm=perm, paddr=paddr, run=run, err=err, n=n, hw=hs * ws_, frames=int(frames), shape=(hs, ws_), shift=int(shift))
+
+
+def image_gather_forward(feat, plan):
+    """out[n, c] = feat[first_frame(b_n) + row_n // H, c, (row_n % H) >> shift, col_n >> shift]  (unet2d.py:180-214) for the points
+    of `plan`; feat [T, C, H >> shift, W >> shift] float32 NCHW.  Returns out [n, C] float32 in the original point order."""
+    L.require_device(feat)
+    feat = _f32(feat, "feat")
+    t, c, hs, ws_ = feat.shape
+    if (hs, ws_) != plan["shape"] or t != plan["frames"]:
+        raise ValueError(f"feature stack {t}x{hs}x{ws_} does not match the plan's {plan['frames']}x{plan['shape'][0]}x{plan['shape'][1]}")
+    n = plan["n"]
     out = torch.empty((n, c), dtype=torch.float32, device=feat.device)
-    err = torch.zeros(1, dtype=torch.int32, device=feat.device)
-    L.check(L.load().ts_image_gather_forward(L.ptr(feat), L.ptr(pix), L.ptr(pbatch), L.ptr(frame_end), n,
-                                             frame_end.shape[0], t, c, int(height), int(width), int(shift),
-                                             L.ptr(out), L.ptr(err), L.stream()), "ts_image_gather_forward")
-    return out, err
+    L.check(L.load().ts_image_gather_forward(L.ptr(feat), c, plan["hw"], L.ptr(plan["perm"]), L.ptr(plan["paddr"]), n, L.ptr(out),
+                                             L.stream()), "ts_image_gather_forward")
+    return out
 
 
-def image_gather_backward(grad_out, pix, pbatch, frame_end, frames, height, width, shift=0):
-    """Adjoint of image_gather_forward: grad_feat [T, C, H >> shift, W >> shift] (float atomics)."""
-    L.require_device(grad_out, pix, pbatch, frame_end)
-    grad_out, pix = _f32(grad_out, "grad_out"), _f32(pix, "pix")
-    pbatch, frame_end = _i32(pbatch, "pbatch"), _i32(frame_end, "frame_end")
+def image_gather_backward(grad_out, plan, channels, into=None):
+    """Adjoint of image_gather_forward as a segmented sum in raster order (no atomics, run-to-run identical).  `into` = the
+    gradient the map already has from its other consumer, float32 contiguous [T, C, hs, ws]: the per-pixel sums are added to it IN
+    PLACE (only pixels with points are touched) and it is returned; None: a zero-filled tensor is made first."""
+    L.require_device(grad_out)
+    grad_out = _f32(grad_out, "grad_out")
     n, c = grad_out.shape
-    out = torch.empty((int(frames), c, height >> shift, width >> shift), dtype=torch.float32, device=grad_out.device)
-    L.check(L.load().ts_image_gather_backward(L.ptr(grad_out), L.ptr(pix), L.ptr(pbatch), L.ptr(frame_end), n,
-                                              frame_end.shape[0], int(frames), c, int(height), int(width), int(shift),
-                                              L.ptr(out), L.stream()), "ts_image_gather_backward")
+    assert n == plan["n"] and c == channels
+    hs, ws_ = plan["shape"]
+    shape = (plan["frames"], c, hs, ws_)
+    if into is None:
+        out, acc = torch.empty(shape, dtype=torch.float32, device=grad_out.device), 0
+    else:
+        assert tuple(into.shape) == shape and into.dtype == torch.float32 and into.is_contiguous()
+        out, acc = into, 1
+    L.check(L.load().ts_image_gather_backward(L.ptr(grad_out), c, plan["hw"], L.ptr(plan["perm"]), L.ptr(plan["paddr"]),
+                                              L.ptr(plan["run"]), n, L.ptr(out), out.numel(), acc, L.stream()),
+            "ts_image_gather_backward")
     return out
 
 

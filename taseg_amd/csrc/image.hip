@@ -1,12 +1,27 @@
-// TIAF image -> point gather (and its adjoint).
+// TIAF image -> point gather and its adjoint.
 //
-// Reference: R/pcseg/model/segmentor/voxel/minkunet/unet2d.py:180-214 makes NHWC copies
-// (`permute(0, 2, 3, 1)`) of five full feature stacks, reshapes every sample's T frames into one tall
-// (T*H, W, C) image and fancy-indexes it with the (row, col) pairs stored in the last two feature columns of the
-// FOV cloud; the 1/4-scale map is indexed with (row // 4, col // 4).  Here the gather reads the NCHW stack in
-// place: out[n, c] = feat[first_frame(batch n) + row_n / H, c, (row_n % H) >> shift, col_n >> shift], one thread
-// per (point, channel), channel fastest (coalesced output rows; the scattered reads of one point stay inside
-// C cache lines).  The adjoint accumulates with float atomics (several points can share a pixel).
+// Reference: R/pcseg/model/segmentor/voxel/minkunet/unet2d.py:180-214 makes NHWC copies (`permute(0, 2, 3, 1)`) of five full
+// feature stacks, reshapes every sample's T frames into one tall (T*H, W, C) image and fancy-indexes it with the (row, col) pairs
+// stored in the last two feature columns of the FOV cloud; the 1/4-scale map is indexed with (row // 4, col // 4); the adjoint is
+// index_put(accumulate) into a zero-filled copy of the stack.
+//
+// Here the stacks stay NCHW and nothing is copied.  Once per batch and scale the points are put in RASTER order
+// (`ts_image_plan`: pixel address = (frame * hs + r) * ws + c as sort key, stable radix sort, run lengths of equal addresses).
+// Then, per feature map:
+//   * gather  (`image_gather_rows_kernel`): a workgroup takes 64 consecutive points of that order.  Lanes run along the POINTS for
+//     one channel at a time, so a wave reads neighbouring pixels of ONE plane (LiDAR returns of a scan line are 2-3 pixels apart:
+//     a handful of cache lines per wave instead of 64 planes x 4 useful bytes with lanes along the channels); the 64 x 32 tile is
+//     transposed through LDS and leaves as contiguous 128-byte pieces of the [n, C] rows (original point order).
+//   * adjoint (`image_scatter_rows_kernel`): the same tiles the other way round - gradient rows in, transposed through LDS, and
+//     the points of one pixel (adjacent in raster order) summed in index order by the lane of the run's first point, which then
+//     adds the sum to the pixel with a plain read-modify-write: every pixel has exactly one such lane in the whole grid.  No
+//     atomics, run-to-run identical, and only the pixels that have points are touched: the caller hands in the gradient the map
+//     already has from its dense consumer (unet2d.py: classifier / next decoder stage) and gets the sum back in place - no
+//     zero-filled T x C x H x W tensor, no second dense add.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.h"
 
 __device__ __forceinline__ bool image_pixel(const float *__restrict__ pix, const int *__restrict__ pbatch,
@@ -22,85 +37,214 @@ __device__ __forceinline__ bool image_pixel(const float *__restrict__ pix, const
   return frame < T && frame < frame_end[b] && c < (W >> shift);
 }
 
-__global__ __launch_bounds__(256) void image_gather_fwd_kernel(const float *__restrict__ feat,
-                                                               const float *__restrict__ pix,
-                                                               const int *__restrict__ pbatch,
-                                                               const int *__restrict__ frame_end, int64_t n_pts,
-                                                               int n_batch, int T, int C, int H, int W, int shift,
-                                                               float *__restrict__ out, int *__restrict__ err) {
+// key = pixel address in the [T, hs, ws] stack, `limit` (= T * hs * ws) for a point outside its sample's frames (sorts last)
+__global__ __launch_bounds__(256) void image_key_kernel(const float *__restrict__ pix, const int *__restrict__ pbatch,
+                                                        const int *__restrict__ frame_end, int64_t n_pts, int n_batch, int T, int H,
+                                                        int W, int shift, unsigned limit, unsigned *__restrict__ keys,
+                                                        int *__restrict__ idx, int *__restrict__ err) {
   const int hs = H >> shift, ws = W >> shift;
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = n_pts * C, step = (int64_t)gridDim.x * blockDim.x;
-  for (; e < total; e += step) {
-    const int64_t n = e / C;
-    const int ch = (int)(e - n * C);
-    int f, r, c;
-    float v = 0.f;
-    if (image_pixel(pix, pbatch, frame_end, n, n_batch, T, H, W, shift, f, r, c))
-      v = feat[(((int64_t)f * C + ch) * hs + r) * ws + c];
-    else if (ch == 0)
-      *err = 1;   // the reference would raise an IndexError
-    out[e] = v;
-  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pts) return;
+  int f, r, c;
+  unsigned key = limit;
+  if (image_pixel(pix, pbatch, frame_end, i, n_batch, T, H, W, shift, f, r, c))
+    key = (unsigned)((f * hs + r) * ws + c);
+  else
+    *err = 1;          // the reference would raise an IndexError
+  keys[i] = key;
+  idx[i] = (int)i;
 }
 
-__global__ __launch_bounds__(256) void image_gather_bwd_kernel(const float *__restrict__ gout,
-                                                               const float *__restrict__ pix,
-                                                               const int *__restrict__ pbatch,
-                                                               const int *__restrict__ frame_end, int64_t n_pts,
-                                                               int n_batch, int T, int C, int H, int W, int shift,
-                                                               float *__restrict__ gfeat) {
-  const int hs = H >> shift, ws = W >> shift;
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = n_pts * C, step = (int64_t)gridDim.x * blockDim.x;
-  for (; e < total; e += step) {
-    const int64_t n = e / C;
-    const int ch = (int)(e - n * C);
-    int f, r, c;
-    if (image_pixel(pix, pbatch, frame_end, n, n_batch, T, H, W, shift, f, r, c))
-      atomicAdd(&gfeat[(((int64_t)f * C + ch) * hs + r) * ws + c], gout[e]);
+// paddr[i] = pixel address of the i-th point in raster order (-1: none); run[i] = number of consecutive points on that pixel if i is
+// the first of them, else 0
+__global__ __launch_bounds__(256) void image_runs_kernel(const unsigned *__restrict__ keys, int64_t n_pts, unsigned limit,
+                                                         int *__restrict__ paddr, int *__restrict__ run) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pts) return;
+  const unsigned k = keys[i];
+  paddr[i] = k < limit ? (int)k : -1;
+  int len = 0;
+  if (k < limit && (i == 0 || keys[i - 1] != k)) {
+    len = 1;
+    while (i + len < n_pts && keys[i + len] == k) ++len;
   }
+  run[i] = len;
 }
 
-static int image_check(const char *what, const void *a, const void *pix, const void *pbatch, const void *frame_end,
-                       int64_t n_pts, int n_batch, int T, int C, int H, int W, int shift) {
-  TS_REQUIRE(n_pts >= 0 && n_batch > 0 && T > 0 && C > 0 && H > 0 && W > 0 && shift >= 0 && shift < 8,
-             TS_ERR_INVALID_ARGUMENT, "%s: bad sizes", what);
-  TS_REQUIRE((H % (1 << shift)) == 0 && (W % (1 << shift)) == 0, TS_ERR_INVALID_ARGUMENT,
-             "%s: H and W must be multiples of the scale", what);
-  TS_REQUIRE(a && frame_end && (n_pts == 0 || (pix && pbatch)), TS_ERR_INVALID_ARGUMENT, "%s: null pointer", what);
+static size_t image_sort_bytes(int64_t n) {
+  size_t need = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, need, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr, (int *)nullptr, (size_t)std::max<int64_t>(n, 1), 0,
+                                  32, (hipStream_t)0);
+  return need;
+}
+
+extern "C" size_t ts_image_plan_workspace_bytes(int64_t n_pts) {
+  const size_t n = (size_t)std::max<int64_t>(n_pts, 1);
+  return ts_align_up(n * 4, 256) * 3 + ts_align_up(image_sort_bytes(n_pts), 256);
+}
+
+extern "C" int ts_image_plan(const float *pix, const int32_t *pbatch, const int32_t *frame_end, int64_t n_pts, int32_t n_batch, int32_t T,
+                             int32_t H, int32_t W, int32_t shift, int32_t *perm, int32_t *paddr, int32_t *run, int32_t *err, void *ws,
+                             size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n_pts >= 0 && n_batch > 0 && T > 0 && H > 0 && W > 0 && shift >= 0 && shift < 8 && n_pts < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
+             "ts_image_plan: bad sizes");
+  TS_REQUIRE((H % (1 << shift)) == 0 && (W % (1 << shift)) == 0, TS_ERR_INVALID_ARGUMENT, "ts_image_plan: H and W must be multiples of the scale");
+  const int64_t limit64 = (int64_t)T * (H >> shift) * (W >> shift);
+  TS_REQUIRE(limit64 < (1LL << 31), TS_ERR_INVALID_ARGUMENT, "ts_image_plan: more than 2^31 pixels in the stack");
+  if (n_pts == 0) return TS_OK;
+  TS_REQUIRE(pix && pbatch && frame_end && perm && paddr && run && err && ws && ws_bytes >= ts_image_plan_workspace_bytes(n_pts),
+             TS_ERR_INVALID_ARGUMENT, "ts_image_plan: null pointer / workspace too small");
+  char *p = (char *)ws;
+  unsigned *keys = (unsigned *)p;
+  p += ts_align_up((size_t)n_pts * 4, 256);
+  unsigned *keys_sorted = (unsigned *)p;
+  p += ts_align_up((size_t)n_pts * 4, 256);
+  int *idx = (int *)p;
+  p += ts_align_up((size_t)n_pts * 4, 256);
+  size_t tmp_bytes = ws_bytes - (size_t)(p - (char *)ws);
+  const unsigned limit = (unsigned)limit64;
+  const unsigned grid = (unsigned)ts_cdiv(n_pts, 256);
+  image_key_kernel<<<grid, 256, 0, stream>>>(pix, pbatch, frame_end, n_pts, n_batch, T, H, W, shift, limit, keys, idx, err);
+  TS_CHECK_LAUNCH("ts_image_plan/keys");
+  int bits = 1;
+  while ((1ULL << bits) <= (unsigned long long)limit) ++bits;      // keys are <= limit
+  TS_CHECK_HIP(rocprim::radix_sort_pairs(p, tmp_bytes, keys, keys_sorted, idx, perm, (size_t)n_pts, 0, bits, stream), "ts_image_plan: sort");
+  image_runs_kernel<<<grid, 256, 0, stream>>>(keys_sorted, n_pts, limit, paddr, run);
+  TS_CHECK_LAUNCH("ts_image_plan/runs");
   return TS_OK;
 }
 
-extern "C" int ts_image_gather_forward(const float *feat, const float *pix, const int32_t *pbatch,
-                                       const int32_t *frame_end, int64_t n_pts, int32_t n_batch, int32_t T, int32_t C,
-                                       int32_t H, int32_t W, int32_t shift, float *out, int32_t *err,
-                                       ts_stream_t stream_) {
+#define IG_PTS 64      // points per workgroup tile
+#define IG_CH 32       // channels per LDS pass
+
+__global__ __launch_bounds__(256) void image_gather_rows_kernel(const float *__restrict__ feat, int C, int64_t hw,
+                                                                const int *__restrict__ perm, const int *__restrict__ paddr,
+                                                                int64_t n_pts, float *__restrict__ out) {
+  __shared__ float tile[IG_PTS][IG_CH + 1];
+  __shared__ int s_perm[IG_PTS];
+  __shared__ int64_t s_off[IG_PTS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * IG_PTS;
+  if (t < IG_PTS) {
+    const int64_t i = base + t;
+    int pm = -1;
+    int64_t off = -1;
+    if (i < n_pts) {
+      pm = perm[i];
+      const int a = paddr[i];
+      if (a >= 0) {
+        const int64_t f = a / hw;
+        off = f * C * hw + (a - f * hw);       // element (f, channel 0, r, c) of the NCHW stack
+      }
+    }
+    s_perm[t] = pm;
+    s_off[t] = off;
+  }
+  __syncthreads();
+  const int64_t my_off = s_off[lane];
+  for (int c0 = 0; c0 < C; c0 += IG_CH) {
+    // lanes along the points, one channel per wave and round: neighbouring pixels of one plane
+    for (int cc = wave; cc < IG_CH; cc += 4) {
+      const int c = c0 + cc;
+      tile[lane][cc] = (c < C && my_off >= 0) ? feat[my_off + (int64_t)c * hw] : 0.f;
+    }
+    __syncthreads();
+    // rows out: 32 consecutive lanes write 128 contiguous bytes of one point's row
+    for (int e = t; e < IG_PTS * IG_CH; e += 256) {
+      const int r = e / IG_CH, cc = e - r * IG_CH;
+      const int pm = s_perm[r];
+      if (pm >= 0 && c0 + cc < C) out[(int64_t)pm * C + c0 + cc] = tile[r][cc];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void image_scatter_rows_kernel(const float *__restrict__ gout, int C, int64_t hw,
+                                                                 const int *__restrict__ perm, const int *__restrict__ paddr,
+                                                                 const int *__restrict__ run, int64_t n_pts, float *__restrict__ gfeat) {
+  __shared__ float tile[IG_PTS][IG_CH + 1];
+  __shared__ int s_perm[IG_PTS], s_run[IG_PTS];
+  __shared__ int64_t s_off[IG_PTS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * IG_PTS;
+  if (t < IG_PTS) {
+    const int64_t i = base + t;
+    int pm = -1, rn = 0;
+    int64_t off = -1;
+    if (i < n_pts) {
+      pm = perm[i];
+      rn = run[i];
+      const int a = paddr[i];
+      if (a >= 0) {
+        const int64_t f = a / hw;
+        off = f * C * hw + (a - f * hw);
+      }
+    }
+    s_perm[t] = pm;
+    s_run[t] = rn;
+    s_off[t] = off;
+  }
+  __syncthreads();
+  const int64_t my_off = s_off[lane];
+  const int my_run = s_run[lane];
+  for (int c0 = 0; c0 < C; c0 += IG_CH) {
+    for (int e = t; e < IG_PTS * IG_CH; e += 256) {
+      const int r = e / IG_CH, cc = e - r * IG_CH;
+      const int pm = s_perm[r];
+      tile[r][cc] = (pm >= 0 && c0 + cc < C) ? gout[(int64_t)pm * C + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+    if (my_run > 0 && my_off >= 0) {
+      for (int cc = wave; cc < IG_CH; cc += 4) {
+        const int c = c0 + cc;
+        if (c >= C) break;
+        float sum = 0.f;
+        for (int q = 0; q < my_run; ++q) {
+          const int r = lane + q;
+          // (a run that leaves the tile: its tail comes straight from memory - a pixel rarely holds more than a few points)
+          sum += r < IG_PTS ? tile[r][cc] : gout[(int64_t)perm[base + r] * C + c];
+        }
+        float *dst = gfeat + my_off + (int64_t)c * hw;
+        *dst += sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int image_rows_check(const char *what, const void *a, const void *b, const void *perm, const void *paddr, int64_t n_pts, int32_t C,
+                            int64_t hw) {
+  TS_REQUIRE(n_pts >= 0 && C > 0 && hw > 0 && n_pts < (1LL << 31), TS_ERR_INVALID_ARGUMENT, "%s: bad sizes", what);
+  TS_REQUIRE(n_pts == 0 || (a && b && perm && paddr), TS_ERR_INVALID_ARGUMENT, "%s: null pointer", what);
+  return TS_OK;
+}
+
+// out[n, C] (every row written; a point outside its sample's frames - plan's err - reads as zeros); feat [T, C, hs, ws], hw = hs * ws
+extern "C" int ts_image_gather_forward(const float *feat, int32_t C, int64_t hw, const int32_t *perm, const int32_t *paddr, int64_t n_pts,
+                                       float *out, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  int rc = image_check("ts_image_gather_forward", feat, pix, pbatch, frame_end, n_pts, n_batch, T, C, H, W, shift);
+  const int rc = image_rows_check("ts_image_gather_forward", feat, out, perm, paddr, n_pts, C, hw);
   if (rc != TS_OK) return rc;
   if (n_pts == 0) return TS_OK;
-  TS_REQUIRE(out && err, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_forward: null pointer");
-  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(n_pts * C, 256), 1 << 16);
-  image_gather_fwd_kernel<<<grid, 256, 0, stream>>>(feat, pix, pbatch, frame_end, n_pts, n_batch, T, C, H, W, shift,
-                                                    out, err);
+  image_gather_rows_kernel<<<(unsigned)ts_cdiv(n_pts, IG_PTS), 256, 0, stream>>>(feat, C, hw, perm, paddr, n_pts, out);
   TS_CHECK_LAUNCH("ts_image_gather_forward");
   return TS_OK;
 }
 
-extern "C" int ts_image_gather_backward(const float *grad_out, const float *pix, const int32_t *pbatch,
-                                        const int32_t *frame_end, int64_t n_pts, int32_t n_batch, int32_t T,
-                                        int32_t C, int32_t H, int32_t W, int32_t shift, float *grad_feat,
+// grad_feat [T, C, hs, ws] += adjoint(grad_out [n, C]) on the pixels that have points.  accumulate == 0: grad_feat (n_feat elements)
+// is zero-filled first (the stand-alone adjoint); != 0: the caller's tensor already holds the map's other gradient.
+extern "C" int ts_image_gather_backward(const float *grad_out, int32_t C, int64_t hw, const int32_t *perm, const int32_t *paddr,
+                                        const int32_t *run, int64_t n_pts, float *grad_feat, int64_t n_feat, int32_t accumulate,
                                         ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  int rc = image_check("ts_image_gather_backward", grad_feat, pix, pbatch, frame_end, n_pts, n_batch, T, C, H, W, shift);
+  TS_REQUIRE(grad_feat && n_feat >= 0, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_backward: null pointer");
+  const int rc = image_rows_check("ts_image_gather_backward", grad_out, grad_feat, perm, paddr, n_pts, C, hw);
   if (rc != TS_OK) return rc;
-  TS_CHECK_HIP(hipMemsetAsync(grad_feat, 0, (size_t)T * C * (H >> shift) * (W >> shift) * 4, stream), "image gather memset");
+  if (!accumulate) TS_CHECK_HIP(hipMemsetAsync(grad_feat, 0, (size_t)n_feat * 4, stream), "image gather memset");
   if (n_pts == 0) return TS_OK;
-  TS_REQUIRE(grad_out, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_backward: null pointer");
-  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(n_pts * C, 256), 1 << 16);
-  image_gather_bwd_kernel<<<grid, 256, 0, stream>>>(grad_out, pix, pbatch, frame_end, n_pts, n_batch, T, C, H, W,
-                                                    shift, grad_feat);
+  TS_REQUIRE(run, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_backward: null pointer");
+  image_scatter_rows_kernel<<<(unsigned)ts_cdiv(n_pts, IG_PTS), 256, 0, stream>>>(grad_out, C, hw, perm, paddr, run, n_pts, grad_feat);
   TS_CHECK_LAUNCH("ts_image_gather_backward");
   return TS_OK;
 }

@@ -6,8 +6,10 @@ its checkpoints load (`stem.0.conv1.weight`, `stage2.bn1.running_mean`, `up3.con
 
 What is rebuilt is the image -> point hand-over (unet2d.py:180-214): the reference materialises NHWC copies of five
 feature stacks (6.8 GB for the 96-channel full-resolution map of 36 frames) and fancy-indexes them per sample;
-`image_gather` reads the NCHW stacks in place with one HIP kernel per map (`ts_image_gather_forward`) and
-accumulates its adjoint with atomics (`ts_image_gather_backward`).
+`image_gather` reads the NCHW stacks in place: the FOV points are put in raster order of their pixels once per batch and scale
+(`ts_image_plan`), every map is gathered with lanes along the points of that order (`ts_image_gather_forward`), and the adjoint is
+a segmented sum over the same order added into the map's other gradient in place (`ts_image_gather_backward`: no atomics, no
+zero-filled stack).
 """
 import torch
 from torch import nn
@@ -15,27 +17,61 @@ from torch.autograd import Function
 
 from taseg_amd import backend as B
 
-__all__ = ["UNet2D", "image_gather"]
+__all__ = ["UNet2D", "image_gather", "image_gather_through", "image_plan"]
 
 
 class _ImageGather(Function):
-    @staticmethod
-    def forward(ctx, feat, pix, pbatch, frame_end, height, width, shift):
-        out, err = B.image_gather_forward(feat, pix, pbatch, frame_end, height, width, shift)
-        ctx.saved = (pix, pbatch, frame_end, feat.shape[0], height, width, shift)
-        ctx.mark_non_differentiable(err)
-        return out, err
+    """rows of one map at the plan's pixels; the adjoint is a zero-filled stack + the per-pixel sums"""
 
     @staticmethod
-    def backward(ctx, grad_out, _grad_err):
-        pix, pbatch, frame_end, frames, height, width, shift = ctx.saved
-        grad = B.image_gather_backward(grad_out.contiguous(), pix, pbatch, frame_end, frames, height, width, shift)
-        return grad, None, None, None, None, None, None
+    def forward(ctx, feat, plan):
+        ctx.plan, ctx.channels = plan, feat.shape[1]
+        return B.image_gather_forward(feat, plan)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return B.image_gather_backward(grad_out.contiguous().float(), ctx.plan, ctx.channels), None
 
 
-def image_gather(feat, pix, pbatch, frame_end, height, width, shift=0):
+class _ImageGatherThrough(Function):
+    """(feat', rows) = (feat, rows of feat at the plan's pixels): the map leaves the node a second time, and whatever consumes
+    THAT tensor (the next decoder stage, the classifier, the dense loss) sends its gradient back INTO the node, where the adjoint
+    of the gather is added to it in place on the pixels that have points - no zero-filled T x C x H x W stack (1.9 GB for the
+    96-channel full-resolution map of a bs-2 TIAF batch), no second dense add by the autograd engine.  Use feat' downstream."""
+
+    @staticmethod
+    def forward(ctx, feat, plan):
+        ctx.plan, ctx.shape = plan, tuple(feat.shape)
+        return feat.view_as(feat), B.image_gather_forward(feat, plan)
+
+    @staticmethod
+    def backward(ctx, grad_feat, grad_rows):
+        if grad_rows is None:
+            return grad_feat, None
+        g = grad_rows.contiguous().float()
+        if grad_feat is None:
+            return B.image_gather_backward(g, ctx.plan, ctx.shape[1]), None
+        # the incoming gradient is the engine's own buffer for this output (a fresh result of the consumer's backward, or the sum
+        # the engine formed): adding into it is what the engine would do with a second dense tensor
+        into = grad_feat if (grad_feat.dtype == torch.float32 and grad_feat.is_contiguous()) else grad_feat.float().contiguous()
+        return B.image_gather_backward(g, ctx.plan, ctx.shape[1], into=into), None
+
+
+def image_plan(pix, pbatch, frame_end, frames, height, width, shift=0):
+    """raster-order plan of the FOV points for one scale of the camera stack (backend.image_plan)"""
+    return B.image_plan(pix, pbatch, frame_end, int(frames), int(height), int(width), int(shift))
+
+
+def image_gather(feat, pix, pbatch, frame_end, height, width, shift=0, plan=None):
     """Rows of `feat` [T, C, H >> shift, W >> shift] at the pixels the FOV points project to -> ([n, C], err)."""
-    return _ImageGather.apply(feat.contiguous().float(), pix, pbatch, frame_end, int(height), int(width), int(shift))
+    if plan is None:
+        plan = image_plan(pix, pbatch, frame_end, feat.shape[0], height, width, shift)
+    return _ImageGather.apply(feat.contiguous().float(), plan), plan["err"]
+
+
+def image_gather_through(feat, plan):
+    """(feat', rows): see _ImageGatherThrough"""
+    return _ImageGatherThrough.apply(feat.contiguous().float(), plan)
 
 
 def _leaky():
@@ -146,24 +182,27 @@ class UNet2D(nn.Module):
         x3, s3 = self.stage3(x2)
         x4, s4 = self.stage4(x3)
         x5 = self.mid_stage(x4)
-        u1 = self.up1(x5, s4)
-        u2 = self.up2(u1, s3)           # 1/4 scale, 128 channels
-        u3 = self.up3(u2, s2)
-        u4 = self.up4(u3, s1)           # full scale, 96 channels
-        logits = self.classifier(u4)
-        data_dict["image_logits"] = logits
-
         fov = data_dict["lidar_fov_ms"]
         pix = fov.F[:, -2:].float().contiguous()                      # (row in the sample's stacked frames, col)
         pbatch = fov.C[:, -1].int().contiguous()
         frame_end = torch.as_tensor(data_dict["offset_img"], device=x.device).int().contiguous()
-        args = (pix, pbatch, frame_end, height, width)
-        logits_fov, err = image_gather(logits, *args)
+        with torch.no_grad():       # the points in raster order, once per scale (csrc/image.hip)
+            plan0 = image_plan(pix, pbatch, frame_end, x.shape[0], height, width, 0)
+            plan4 = image_plan(pix, pbatch, frame_end, x.shape[0], height, width, 2)
+        u1 = self.up1(x5, s4)
+        u2 = self.up2(u1, s3)           # 1/4 scale, 128 channels
+        # (the gathered maps go on THROUGH their gather nodes: the adjoint is added into the gradient they get from here on)
+        u2, feat4 = image_gather_through(u2, plan4)
+        u3 = self.up3(u2, s2)
+        u4 = self.up4(u3, s1)           # full scale, 96 channels
+        u4, feat0 = image_gather_through(u4, plan0)
+        logits = self.classifier(u4)
+        logits, logits_fov = image_gather_through(logits, plan0)
+        data_dict["image_logits"] = logits
+        err = plan0["err"]
         with torch.no_grad():
-            targets_fov, _ = image_gather(data_dict["semantic_map_ms"].float(), *args)
-            rgb_fov, _ = image_gather(x, *args)
-        feat0, _ = image_gather(u4, *args)
-        feat4, _ = image_gather(u2, *args, shift=2)
+            targets_fov, _ = image_gather(data_dict["semantic_map_ms"].float(), None, None, None, height, width, plan=plan0)
+            rgb_fov, _ = image_gather(x, None, None, None, height, width, plan=plan0)
         data_dict["image_logits_fov"] = logits_fov
         data_dict["image_targets_fov"] = targets_fov[:, 0].to(data_dict["semantic_map_ms"].dtype)
         data_dict["image_rgb_fov"] = rgb_fov

@@ -48,8 +48,44 @@ def test_image_gather_matches_indexing(shift, c):
     # a pixel beyond the sample's frames is reported, not read
     bad = pix.clone()
     bad[0, 0] = frames[0] * H + 1
-    _, err = B.image_gather_forward(feat.detach(), bad, pbatch, frame_end, H, W, shift)
-    assert int(err) == 1
+    plan = B.image_plan(bad, pbatch, frame_end, sum(frames), H, W, shift)
+    assert int(plan["err"]) == 1
+    assert torch.equal(B.image_gather_forward(feat.detach(), plan)[1:], want.detach()[1:])       # the other rows are what they were
+
+
+@pytest.mark.parametrize("shift,c", [(0, 96), (2, 128), (0, 20)])
+def test_image_gather_at_tiaf_size_through_path(shift, c):
+    """>= 20k FOV points on a camera-sized stack (minkunet_mk34_cr10_fsa_tiaf.yaml: 384 x 1280): the raster-order gather against
+    plain indexing and the oracle, and the adjoint ADDED into the map's other gradient in place (unet2d.image_gather_through)
+    against autograd's own sum of the two gradients - run-to-run identical (no atomics)."""
+    from oracle import ts_oracle as O
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import image_gather_through, image_plan
+    g = torch.Generator().manual_seed(11)
+    frames, H, W = [2, 1], 384, 1280
+    T = sum(frames)
+    frame_end = torch.tensor(np.cumsum(frames), dtype=torch.int32, device="cuda")
+    feat = torch.randn(T, c, H >> shift, W >> shift, generator=g).cuda().requires_grad_()
+    n = 60000
+    pbatch = torch.sort(torch.randint(0, 2, (n,), generator=g)).values.int().cuda()
+    # scan-line-like pixels: a few rows, neighbouring columns, several points per pixel
+    rows = torch.stack([torch.randint(0, frames[b] * H, (1,), generator=g) for b in pbatch.tolist()]).view(-1)
+    rows = (rows // 6) * 6
+    pix = torch.stack([rows, torch.randint(0, W // 3, (n,), generator=g) * 3], 1).float().cuda()
+    plan = image_plan(pix, pbatch, frame_end, T, H, W, shift)
+    assert int(plan["err"]) == 0
+    through, out = image_gather_through(feat, plan)
+    want = _reference_gather(feat, pix, pbatch, frame_end, shift)
+    assert torch.equal(out, want)
+    assert np.array_equal(out.detach().cpu().numpy(), O.image_gather(feat.detach().cpu().numpy(), pix.cpu().numpy(),
+                                                                     pbatch.cpu().numpy(), frame_end.cpu().numpy(), shift))
+    w = torch.randn(n, c, generator=g).cuda()
+    dense = torch.randn(feat.shape, generator=g).cuda()
+    loss = (out * w).sum() + (through * dense).sum()             # the map's second consumer
+    (g_ours,) = torch.autograd.grad(loss, feat, retain_graph=True)
+    (g_again,) = torch.autograd.grad(loss, feat)
+    (g_ref,) = torch.autograd.grad((want * w).sum() + (feat * dense).sum(), feat)
+    assert torch.equal(g_ours, g_again)                          # deterministic
+    assert float((g_ours - g_ref).abs().max()) <= 1e-5 * max(1.0, float(g_ref.abs().max()))
 
 
 def _tiaf_batch(g):
