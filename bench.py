@@ -925,9 +925,10 @@ def main():
 
     # weight gradients on a second stream (csrc/block.hip, taseg_amd/_fast.py): both settings are timed on this model, batch and
     # machine BEFORE the warm-up (16 steps) and the faster one is kept - like a convolution-algorithm search, outside the contract's
-    # W + K steps.  One process only: the gradient buckets of N > 1 read p.grad while the backward pass is still running.
+    # W + K steps.  With several ranks every rank times its own (the second stream is rank-local; the gradient buckets join it
+    # before their all-reduce, parallel.GradBucketReducer._launch).
     wgrad_side = None
-    if dist is None and flat and not args.no_wgrad_tune:
+    if flat and not args.no_wgrad_tune:
         from taseg_amd import _fast
         wgrad_side = _fast.tune_wgrad_stream(step, fence)
         if rank == 0:

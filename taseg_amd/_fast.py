@@ -44,7 +44,7 @@ _side = None
 def wgrad_stream(on):
     """Weight gradients of the block backward on a second stream (csrc/block.hip, TsConvBlockOpts.wgrad_stream): the node hands
     every block's weight gradient to one side stream and joins it when the backward pass ends.  TASEG_WGRAD_STREAM=1 switches it
-    on at import; gradient buckets (taseg_amd.parallel.GradBucketReducer) switch it off - their hooks read p.grad mid-pass."""
+    on at import; gradient buckets (taseg_amd.parallel.GradBucketReducer) join it before a bucket's all-reduce."""
     global _side
     mod = module()
     if mod is None:
@@ -59,6 +59,13 @@ def wgrad_stream(on):
     return False
 
 
+def join_wgrad_stream():
+    """The current stream waits for every weight gradient handed to the second stream so far (a no-op while it is off): what a
+    consumer of p.grad in the MIDDLE of a backward pass needs - parallel.GradBucketReducer calls it before a bucket's all-reduce."""
+    if _mod is not None and _side is not None:
+        _mod.join_wgrad_stream(L.stream())
+
+
 def tune_wgrad_stream(step, fence, rounds=3, steps=4):
     """Time `step()` (one full training step: forward, backward, optimizer) with the weight gradients on the caller's stream and on
     the second stream - `rounds` alternating rounds of `steps` steps after one unmeasured step each, `fence()` = device (and rank)
@@ -66,9 +73,9 @@ def tune_wgrad_stream(step, fence, rounds=3, steps=4):
     nothing from it and, before the launches moved to a thread of their own, lost 10-20 % to the event calls
     (profiles/r04_ab_wgrad_stream.txt) - only a measurement on the actual model, batch and machine tells the cases apart.  TASEG_WGRAD_STREAM=0 / 1 pins the setting.  Returns (chosen, ms_off, ms_on)."""
     import time
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return wgrad_stream(False), None, None          # gradient buckets read p.grad while the pass is still running
+    # (several ranks: every rank runs the same number of steps here - they contain collectives - and may end up with its own
+    # setting: the second stream is rank-local, the sequence of collectives does not depend on it; the gradient buckets join the
+    # second stream before their all-reduce, parallel.GradBucketReducer._launch)
     pinned = os.environ.get("TASEG_WGRAD_STREAM", "auto")
     if module() is None or pinned in ("0", "1"):
         return (wgrad_stream(pinned == "1") if module() is not None else False), None, None

@@ -429,6 +429,13 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   if (half) p += blk_align((size_t)K * c_in * c_out * 2);
   void *bn_ws = p;
   const size_t bn_ws_bytes = ts_bn_train_workspace_bytes(std::max(c_in, c_out));
+  if (comm == TS_COMM_CALLER_PRE) {
+    // first half of a split call: this rank's sums of the BatchNorm backward, which the caller all-reduces; nothing else is
+    // touched (the second half writes the gradient w.r.t. the convolution output - into the ring slot where the weight gradient
+    // goes to the second stream)
+    return ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums, grad_conv,
+                               grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream);
+  }
   // the weight gradient on a second stream (TsConvBlockOpts): its operands live in the caller's ring slot, not in ws
   const bool det_ok = grad_kernel && ((int64_t)c_in * c_out) % 4 == 0 && (((uintptr_t)grad_kernel) & 15) == 0 && g_ts_conv_impl != 1;
   const bool side_on = o.wgrad_stream && o.wgrad_stream != stream && o.wgrad_ws && !comm && det_ok;
@@ -463,8 +470,6 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
   if (comm) {
     TS_TRY(ts_bn_sync_backward(comm, grad_out, mask, conv_out, mean, invstd, bn_weight, total_dev, n_out, c_out, half, sums,
                                grad_conv, grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));
-    // first half of a split call: the local sums are out, the caller all-reduces them
-    if (comm == TS_COMM_CALLER_PRE) return TS_OK;
   } else if (half) {
     TS_TRY(ts_bn_act_train_backward_f16(grad_out, mask, conv_out, mean, invstd, bn_weight, n_out, c_out, grad_conv,
                                         grad_residual, grad_bn_weight, grad_bn_bias, bn_ws, bn_ws_bytes, stream));

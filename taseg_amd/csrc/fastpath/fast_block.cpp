@@ -166,6 +166,16 @@ void set_wgrad_stream(int64_t raw, int64_t stream_id, int64_t device_index, int6
   if (wg_side.on) wg_worker.start((int)device_index);
 }
 
+// The caller is about to read weight gradients mid-pass (a gradient bucket whose all-reduce is launched while the backward pass is
+// still running, taseg_amd/parallel.py): everything queued for the second stream so far is enqueued, and `main_raw` waits for it.
+void join_wgrad_stream(int64_t main_raw) {
+  if (!wg_side.on || !wg_worker.started) return;
+  // (called from a Python hook: the worker thread may need the interpreter lock to let go of a tensor a finished job held)
+  py::gil_scoped_release nogil;
+  wg_worker.drain();
+  check(api.stream_join((ts_stream_t)main_raw, (ts_stream_t)wg_side.raw), "ts_stream_join");
+}
+
 // SyncBatchNorm over torch.distributed: process groups registered from Python (register_group), addressed by index.  The
 // node then splits its backend call around ProcessGroup::allreduce on the group's own communicator (csrc/block.hip: comm
 // sentinels 1 / 2) - the C++ counterpart of functional._ConvBlock's split path, without the interpreter in between.
@@ -763,6 +773,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");
   m.def("conv_block", &conv_block, "act(BN(conv(x)) [+ residual]) as one native autograd node");
   m.def("conv_block_eval", &conv_block_eval, "act(BN_eval(conv(x)) [+ residual]) on the running statistics, no graph");
+  m.def("join_wgrad_stream", &join_wgrad_stream, "the given stream waits for every weight gradient handed to the second stream so far");
   m.def("set_wgrad_stream", &set_wgrad_stream, "weight gradients of conv_block's backward on a second stream (joined at the end of the pass)");
   m.def("register_group", &register_group, "process group -> id for conv_block's c10d SyncBatchNorm path");
   m.def("clear_groups", &clear_groups, "drop the registered process groups (before destroy_process_group)");

@@ -451,6 +451,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
     std::vector<at::Tensor> gin(n_in);                // ... or, for an input, the strided view described above
     G[p.out_reg] = g_out.data_ptr();
     std::vector<at::Tensor> gparams(3 * p.layers.size());
+    // (not beside SyncBatchNorm: the block call keeps the weight gradient of a statistics-exchanging block on its own stream)
     const bool side_possible = wg_side.on && !comm && !split && like.get_device() == wg_side.device_index && stream != wg_side.raw;
     for (int i = (int)n_ops - 1; i >= 0; --i) {
       const Op &o = p.ops[i];

@@ -104,11 +104,6 @@ class GradBucketReducer:
         # also usable without a process group (one process): the buckets then only flatten the gradients
         live = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if live else 1
-        if self.world > 1:
-            # the bucket hooks read p.grad while the backward pass is still running: weight gradients on a second stream
-            # (joined at the END of the pass, taseg_amd/_fast.py) are not for them
-            from . import _fast
-            _fast.wgrad_stream(False)
         if live and process_group is None and self.world > 1 and os.environ.get("TASEG_DIST_BUCKETS_ON_DEFAULT_GROUP") != "1":
             process_group = dist.new_group(backend=dist.get_backend())
         self.group = process_group
@@ -173,6 +168,10 @@ class GradBucketReducer:
         return hook
 
     def _launch(self, bucket):
+        # weight gradients on a second stream (taseg_amd/_fast.py) are complete THERE: this stream - on which the bucket is scaled and
+        # whose work the all-reduce waits for - first waits for everything handed to the second stream so far (one event)
+        from . import _fast
+        _fast.join_wgrad_stream()
         src, dst = [], []
         bucket["unused"] = [i for i, p in enumerate(bucket["params"]) if p.grad is None]
         for p, v in zip(bucket["params"], bucket["views"]):

@@ -59,6 +59,9 @@ def one_step(model, batches, process_group=None, amp=False):
     from taseg_amd.optim import FlatSGD
     from taseg_amd.torchsparse import SparseTensor
     opt = FlatSGD(model, lr=0.0, momentum=0.0, weight_decay=0.0, process_group=process_group)
+    if os.environ.get("TASEG_WORKER_SIDE") == "1":      # weight gradients on the second stream, joined before every bucket's all-reduce
+        from taseg_amd import _fast
+        assert _fast.wgrad_stream(True)
     coords = torch.from_numpy(np.concatenate([b[0] for b in batches])).cuda()
     feats = torch.from_numpy(np.concatenate([b[1] for b in batches])).cuda()
     labels = torch.from_numpy(np.concatenate([b[2] for b in batches])).cuda()
@@ -128,7 +131,8 @@ def main():
     amp = os.environ.get("TASEG_WORKER_AMP") == "1"
     # TASEG_DIST_SINGLE_COMM (default): buckets and SyncBatchNorm share the default group, as in bench.py
     group = dist.new_group(backend=backend)      # the buckets' own communicator, as bench.py passes it
-    out.update(pack("", *one_step(build(True), [scan], group, amp=amp)))
+    # TASEG_WORKER_LOCAL_BN=1: plain BatchNorm (per-rank statistics, bench.py --local-bn) instead of the configs' SyncBatchNorm
+    out.update(pack("", *one_step(build(os.environ.get("TASEG_WORKER_LOCAL_BN") != "1"), [scan], group, amp=amp)))
     direct = rccl.direct_comm(dist.group.WORLD)
     out["direct_rccl"] = np.int64(1 if direct is not None else 0)
     if backend == "nccl" and world > 1:

@@ -103,6 +103,21 @@ def test_ranks_share_one_device(tmp_path, world, amp, single):
           f"concatenated batch: worst relative gradient error {worst:.2e}")
 
 
+def test_second_stream_under_the_bucket_reducer_gives_the_same_bits(tmp_path):
+    """weight gradients on the second stream with N > 1 (per-rank BatchNorm statistics: a block that exchanges statistics keeps its
+    weight gradient on its own stream): every bucket's all-reduce first joins the second stream (parallel.GradBucketReducer._launch) -
+    logits, averaged gradients and running statistics bit-equal to the one-stream run"""
+    env = {"TASEG_RCCL_DIRECT": "0", "TASEG_WORKER_AMP": "0", "TASEG_WORKER_LOCAL_BN": "1"}
+    (tmp_path / "one").mkdir()
+    (tmp_path / "two").mkdir()
+    one, _ = _run_ranks(2, "gloo", tmp_path / "one", env)
+    two, _ = _run_ranks(2, "gloo", tmp_path / "two", dict(env, TASEG_WORKER_SIDE="1"))
+    for a, b in zip(one, two):
+        assert set(a) == set(b)
+        bad = [k for k in a if not np.array_equal(a[k], b[k])]
+        assert not bad, bad[:5]
+
+
 def test_flat_sgd_unused_parameter_rule_is_global(tmp_path):
     """A parameter with a gradient on rank 0 only: FlatSGD applies the averaged gradient on BOTH ranks (replicas stay
     bit-identical, DDP's find_unused_parameters rule); a parameter unused on every rank is left untouched (torch.optim.SGD)."""
