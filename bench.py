@@ -533,6 +533,17 @@ def summarise_families(prof, amp, traffic_table):
     return out
 
 
+def launches_of(args):
+    """kernel launches per step of this configuration on all streams, from the committed rocprofv3 kernel trace of the tree
+    (profiles/launches.json: written by tools/collect_profiles.sh; None when the configuration has no entry)"""
+    path = os.path.join(ROOT, "profiles", "launches.json")
+    if not os.path.exists(path):
+        return None
+    key = ("eval " if getattr(args, "eval", False) else "") + args.workload + (" amp" if args.amp else "") + \
+        (" force-dist" if args.force_dist else "") + (f" bs{args.batch}" if args.batch not in (None, 2, 4) else "")
+    return json.load(open(path)).get(key)
+
+
 def build_roofline(prof, amp, bracket_us):
     """The `roofline` object of the JSON line: the kernel FAMILY with the largest share of the step's convolution time
     (all its instantiations together), bound = the larger of its matrix-pipe and HBM times at peak, both fractions stated;
@@ -602,7 +613,8 @@ def secondary_runs(steps=30, warmup=8):
             if r.returncode != 0 or rec is None:
                 entry["error"] = (r.stderr or r.stdout)[-400:]
             else:
-                entry.update({k: rec.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss")})
+                entry.update({k: rec.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss",
+                                                      "host_issue_ms_per_step", "launches_per_step")})
                 roof = rec.get("roofline") or {}
                 entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us", "avg_us_net", "hbm_frac_net", "mfma_frac_net",
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
@@ -670,14 +682,20 @@ def eval_run(args):
     pf = None if args.no_prefetch else DevicePrefetcher(make_batch, model.prepare, threaded=True,
                                                         depth=int(os.environ.get("TASEG_EVAL_STAGE_DEPTH", "2")))
 
+    issue_s = [0.0, 0]
+
     def issue():
+        t_i = time.perf_counter()
         if pf is None:
             bd = make_batch()
         else:
             bd = pf.next()
             pf.prefetch_early()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
-            return model(bd, defer=True)          # forward + tail enqueued, the arrays collected one pass later
+            out_ = model(bd, defer=True)          # forward + tail enqueued, the arrays collected one pass later
+        issue_s[0] += time.perf_counter() - t_i
+        issue_s[1] += 1
+        return out_
 
     def passes(n):
         # one batch in flight, as pcseg/eval.py runs the loop: pass i + 1 is issued before the host waits for the arrays of pass i
@@ -696,10 +714,21 @@ def eval_run(args):
         import cProfile
         host_prof = cProfile.Profile()
         host_prof.enable()
+    from taseg_amd import backend as B
+    issue_s[0], issue_s[1] = 0.0, 0
     t0 = time.perf_counter()
     out = passes(args.steps)                     # K passes issued AND collected inside the timed region
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-launch events around the convolution kernels of a few more passes AFTER the timed region (the roofline of the line)
+    roofline = None
+    if not args.no_kernel_events:
+        B.profile_begin(expected_launches=800)
+        passes(3)
+        torch.cuda.synchronize()
+        records = B.profile_end()
+        bracket_us = B.profile_empty_bracket_us() if records else 0.0
+        roofline = build_roofline(summarise_profile(records, 3), args.amp, bracket_us)
     if host_prof is not None:
         host_prof.disable()
         host_prof.dump_stats(os.environ["TASEG_BENCH_CPROFILE"])
@@ -709,6 +738,7 @@ def eval_run(args):
         "metric": "scans/sec (eval forward + un-voxelisation + arg-max per point)", "value": batch * args.steps / dt, "unit": "scans/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16-storage/f32-accumulate" if args.amp else "f32", "data": "synthetic", "loss": None,
+        "roofline": roofline, "host_issue_ms_per_step": round(1e3 * issue_s[0] / max(issue_s[1], 1), 3), "launches_per_step": launches_of(args),
         "config": {"workload": f"MinkUNet mk34 cr1.0 evaluation pass (eval-mode BatchNorm, no graph), bs={batch}, voxel 0.05 m, "
                                f"{'autocast fp16' if args.amp else 'fp32'}, index plan + forward + un-voxelisation + arg-max",
                    "points_per_step_per_gpu": int(npts), "voxels_per_step_per_gpu": int(coords.shape[0])}}), flush=True)
@@ -862,20 +892,21 @@ def main():
 
     # TASEG_BENCH_HOST_PHASES=1 (diagnostic): host time the training thread spends ISSUING each phase of a step (no device
     # synchronisation: what a host-bound line is made of), printed to stderr after the run
-    host_phases = {} if os.environ.get("TASEG_BENCH_HOST_PHASES") == "1" else None
+    # host time the training thread spends ISSUING each phase of a step (no device synchronisation: what a host-bound line is made
+    # of; seven clock reads per step).  Always collected: `host_issue_ms_per_step` of the JSON line; TASEG_BENCH_HOST_PHASES=1
+    # prints the phases to stderr after the run
+    host_phases = {}
 
     def _hp(name, t):
-        if host_phases is not None:
-            now = time.perf_counter()
-            host_phases[name] = host_phases.get(name, 0.0) + now - t
-            return now
-        return t
+        now = time.perf_counter()
+        host_phases[name] = host_phases.get(name, 0.0) + now - t
+        return now
 
     def step(time_optimizer=False):
         # one step = stage one batch (rulebooks / index plan; for minkunet_ms also the temporal aggregation and
         # voxelisation) + forward + loss + backward + clip + SGD.  With the prefetcher the batch staged inside
         # step i is the one step i+1 trains on (every timed step still stages exactly one batch).
-        th = time.perf_counter() if host_phases is not None else 0.0
+        th = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             if pf is None:
@@ -913,8 +944,7 @@ def main():
         if pf is not None:
             pf.prefetch()
         th = _hp("stage_next", th)
-        if host_phases is not None:
-            host_phases["steps"] = host_phases.get("steps", 0) + 1
+        host_phases["steps"] = host_phases.get("steps", 0) + 1
         return ret["loss"]
 
     def fence():
@@ -945,11 +975,10 @@ def main():
         ctypes.CDLL(None).fflush(None)      # every rank: push RCCL's C-stdio version banner out before the result line
     if not args.no_kernel_events:
         B.profile_begin(expected_launches=800 * len(range(0, args.steps, EVENT_EVERY)))   # ~330 (bs 2) .. per step
-    if host_phases is not None:
-        host_phases.clear()
-        from taseg_amd import _fast as _f
-        if _f.module() is not None:
-            _f.module().host_times()
+    host_phases.clear()
+    from taseg_amd import _fast as _f
+    if _f.module() is not None:
+        _f.module().host_times()
     host_prof = None
     if os.environ.get("TASEG_BENCH_CPROFILE") and rank == 0:      # diagnostic: interpreter profile of the timed steps
         import cProfile
@@ -975,11 +1004,10 @@ def main():
     if host_prof is not None:
         host_prof.disable()
         host_prof.dump_stats(os.environ["TASEG_BENCH_CPROFILE"])
-    if host_phases is not None and rank == 0:
-        n_hp = max(host_phases.pop("steps", 1), 1)
-        note("host issue time per step (ms, timed steps): " +
-             ", ".join(f"{k} {1e3 * v / n_hp:.2f}" for k, v in host_phases.items()))
-        from taseg_amd import _fast as _f
+    n_hp = max(host_phases.pop("steps", 1), 1)
+    host_issue = {k: 1e3 * v / n_hp for k, v in host_phases.items()}
+    if os.environ.get("TASEG_BENCH_HOST_PHASES") == "1" and rank == 0:
+        note("host issue time per step (ms, timed steps): " + ", ".join(f"{k} {v:.2f}" for k, v in host_issue.items()))
         if _f.module() is not None:      # the native block / stage nodes' own clocks (reset after the warm-up)
             nf, tf, af, nb, tb, ab = _f.module().host_times()
             note(f"native nodes per step: forward {nf / n_hp:.0f} blocks {1e-6 * tf / n_hp:.2f} ms ({1e-6 * af / n_hp:.2f} in the backend "
@@ -1039,6 +1067,11 @@ def main():
                        "wgrad_on_second_stream": None if wgrad_side is None else bool(wgrad_side[0])},
             "loss": float(loss.detach()),
             # inside ms_per_step; gradient clipping + SGD (world > 1: + the tail of the bucketed all-reduce it waits for)
+            # host time per step the training thread spends issuing the step (forward + loss + backward + optimizer: everything but
+            # waiting for the staged batch and staging the next one in line) - against ms_per_step: how far the line is from host-bound
+            "host_issue_ms_per_step": round(sum(v for k, v in host_issue.items() if k in ("forward", "loss", "backward", "optimizer")), 3),
+            "host_issue_phases_ms": {k: round(v, 3) for k, v in host_issue.items()},
+            "launches_per_step": launches_of(args),
             "grad_allreduce": bus,
             "optimizer_ms_per_step": (sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events)) if opt_events else None,
             "roofline": roofline,

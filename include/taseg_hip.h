@@ -522,10 +522,6 @@ typedef struct TsConvBlockOpts {
    * gradient to a ts_conv_block_wgrad_side call with the same arguments - from any host thread, so that its launches need not
    * come from the thread that issues the step */
   int32_t wgrad_deferred;
-  /* fp32 blocks: per-offset exponents of THIS call's weight (ts_conv_weight_exponents_batch, [K] int32, in step with the weight):
-   * the class-sorted products then run as three IEEE-half MFMAs per fp32 product with local power-of-two scales (csrc/conv_class.hip)
-   * instead of six bf16 ones - other rounding (closer to float64), half the matrix-pipe work; NULL: the six-product split */
-  const int32_t *w_exp;
   /* natural != 0: a 1x1x1 convolution on the identity rulebook (K = 1, pair p = (p, p), n_pairs = n_out: conv.py:135-140's
    * `feats.matmul(weight)` as a block) - the pair GEMM's rows ARE the result rows: the product is written straight into the
    * convolution output / the input gradient, no Z, no pass 2, no position table read (pos may be any valid pointer); the shortcut
@@ -542,6 +538,20 @@ int ts_conv_block_wgrad_side(const void *feat, int64_t n_feat_rows, int32_t c_in
                              float *grad_kernel, int32_t chunk_order, void *wgrad_ws, size_t wgrad_ws_bytes, int32_t slot,
                              ts_stream_t side_stream);
 int ts_set_device(int32_t device);      /* hipSetDevice for a host thread the caller created */
+/* The evaluation tail of the segmentors for a whole batch (R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:435-455, minkunet_ms.py:
+ * 433-458: per scene `out[scene mask][inverse_map of the scene]`, arg-max) without the per-scene loop of boolean masks:
+ *   ts_scene_counts  counts [3][n_scenes] int64 = rows per scene of the voxel / point / label batch-index arrays (int32, `stride`
+ *                    elements apart: the last column of an [N, 4] coordinate matrix is stride 4); *flags: bit 0 an index outside
+ *                    0 .. n_scenes - 1, bit 1 an array that is not grouped by scene in ascending order (the caller then sorts).
+ *                    counts and flags are zero-filled by the call.  n_scenes <= 64.
+ *   ts_unvoxelise    for arrays grouped by scene: mapped [n_pts, C] (same type as logits; may be NULL) = logits[start of the point's
+ *                    scene + inv[p], :], pred [n_pts] int64 (may be NULL) = index of the row's first maximum; *flags |= 4 where inv[p]
+ *                    lies outside its scene (the reference's indexing raises).  counts = ts_scene_counts' first n_scenes entries. */
+int ts_scene_counts(const int32_t *b_vox, int64_t stride_vox, int64_t n_vox, const int32_t *b_pts, int64_t stride_pts, int64_t n_pts,
+                    const int32_t *b_lab, int64_t stride_lab, int64_t n_lab, int32_t n_scenes, int64_t *counts, int32_t *flags,
+                    ts_stream_t stream);
+int ts_unvoxelise(const void *logits, int32_t half, int32_t C, const int64_t *counts, int32_t n_scenes, const int32_t *b_pts,
+                  int64_t stride_pts, const int64_t *inv, int64_t n_pts, void *mapped, int64_t *pred, int32_t *flags, ts_stream_t stream);
 /* Column concatenation / slicing of row-major feature matrices - torchsparse.cat (TS/torchsparse/operators.py:10-17: torch.cat of
  * the feature matrices along dim 1, the skip connections of the decoder, R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:403-416)
  * and its gradient, for callers that chain block calls without tensors (the stage programs of csrc/fastpath/stage_program.h).
@@ -646,8 +656,6 @@ typedef struct TsPlaneJob {
   int32_t K, c_in, c_out;
 } TsPlaneJob;
 int ts_conv_split_planes(const float *w, int32_t K, int32_t c_in, int32_t c_out, void *planes, ts_stream_t stream);
-/* per-offset exponents for the three-product class kernels: job.planes = int32 [K], wexp[k] with max |W_k| 2^wexp[k] in [2^14, 2^15) */
-int ts_conv_weight_exponents_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 int ts_conv_split_planes_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream);
 void ts_conv_planes_hint(const float *w, const void *planes, int32_t K, int32_t c_in, int32_t c_out);
 /* The half-storage counterpart: job.planes = w16 [K, c_in, c_out] IEEE half (what ts_cast_weights_f16 writes), 16 weights
@@ -700,12 +708,6 @@ int32_t ts_conv_class_supported(int32_t c_red, int32_t c_out);
 int ts_conv_class_gemm(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                        const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                        int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream);
-/* ts_conv_class_gemm on three IEEE-half MFMAs per fp32 product (local power-of-two scales: one exponent per (row, 32-column slice)
- * of the gathered operand, found in the kernel, one per offset of the weight: wexp [K] from ts_conv_weight_exponents_batch) instead of
- * six bf16 ones; same plan, same result layout, 1e-7-close to the six-product kernels and closer to float64 */
-int ts_conv_class_gemm_x(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
-                         const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                         int32_t mirror, const int32_t *rows, const int32_t *wexp, float *zp, ts_stream_t stream);
 /* does finishing inside the product beat pass 2 on a map of n rows (measured thresholds; what the block calls use) */
 int32_t ts_conv_class_finish_pays(int64_t n, int32_t half);
 int ts_conv_class_conv(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,

@@ -107,6 +107,8 @@ SIGNATURES = {
     "ts_stream_join": (_i32, [_vp, _vp]),
     "ts_conv_block_wgrad_side": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i32, _vp, _sz, _i32, _vp]),
     "ts_set_device": (_i32, [_i32]),
+    "ts_scene_counts": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "ts_unvoxelise": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_cat_cols": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "ts_copy_cols": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "ts_conv_block_forward": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
@@ -141,8 +143,6 @@ SIGNATURES = {
     "ts_conv_class_gemm": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_class_gemm_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_class_finish_pays": (_i32, [_i64, _i32]),
-    "ts_conv_class_gemm_x": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "ts_conv_weight_exponents_batch": (_i32, [_vp, _i32, _vp]),
     "ts_conv_class_conv": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_conv_class_conv_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ts_conv_planes_hint": (None, [_vp, _vp, _i32, _i32, _i32]),
@@ -174,7 +174,7 @@ class TsConvBlockOpts(_c.Structure):
     """include/taseg_hip.h: what a ts_conv_block_* call may use beyond the rulebook"""
     _fields_ = [("fwd_plan", _c.POINTER(TsClassPlan)), ("dgrad_plan", _c.POINTER(TsClassPlan)), ("planes", _vp),
                 ("w16_current", _i32), ("addend", _vp), ("wgrad_stream", _vp), ("wgrad_ws", _vp), ("wgrad_ws_bytes", _sz),
-                ("wgrad_slot", _i32), ("wgrad_deferred", _i32), ("w_exp", _vp), ("natural", _i32)]
+                ("wgrad_slot", _i32), ("wgrad_deferred", _i32), ("natural", _i32)]
 
 
 _lib = None

@@ -18,7 +18,7 @@ __all__ = [
     "devoxelize_forward_cuda", "devoxelize_backward_cuda", "devox_order", "devoxelize_backward_runs", "devox_csr",
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
-    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays", "weight_exponents",
+    "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
     "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
 ]
 
@@ -1075,19 +1075,7 @@ def class_plan_struct(plan):
     return st
 
 
-def weight_exponents(kernel):
-    """per-offset exponents [K] int32 of an fp32 weight [K, C_in, C_out] for the three-product class kernels (one launch)"""
-    L.require_device(kernel)
-    kernel = _f32(kernel, "kernel")
-    k, c_in, c_out = kernel.shape
-    out = torch.empty(k, dtype=torch.int32, device=kernel.device)
-    from .planes import TsPlaneJob
-    job = (TsPlaneJob * 1)(TsPlaneJob(kernel.data_ptr(), out.data_ptr(), k, c_in, c_out))
-    L.check(L.load().ts_conv_weight_exponents_batch(job, 1, L.stream()), "ts_conv_weight_exponents_batch")
-    return out
-
-
-def conv_class_gemm(feat, kernel, plan, weight_transposed=False, wexp=None):
+def conv_class_gemm(feat, kernel, plan, weight_transposed=False):
     """The product on a class plan.  Pass-2 plans: z' [m_pad, C] with one row per (destination row, group of offsets); the
     convolution is conv_gather_sum(z', plan["pos"], n).  Direct plans: the result [n, C] itself.  weight_transposed: the
     transposed product (feat = output gradients, kernel as stored)."""
@@ -1102,16 +1090,10 @@ def conv_class_gemm(feat, kernel, plan, weight_transposed=False, wexp=None):
     with _Timed("class_gemm", name=f"class_gemm_kernel<{_tile_cols(cols)}>", pairs=int(plan.get("pairs", 0)), c_red=c_red,
                 c_out=cols, k=k, esize=4, n_rows=feat.shape[0], z_rows=0 if direct else int(plan.get("z_rows") or plan["m_pad"]),
                 out_rows=plan["n"] if direct else 0):
-        if wexp is not None:           # three IEEE-half products per fp32 product (wexp = weight_exponents(kernel))
-            L.check(L.load().ts_conv_class_gemm_x(L.ptr(feat), c_red, L.ptr(kernel), k, plan["groups"], cols, L.ptr(plan["src"]),
-                                                  plan["m_pad"], L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]),
-                                                  1 if weight_transposed else 0, plan["mirror"], L.ptr(plan["rows"]),
-                                                  L.ptr(_i32(wexp, "wexp")), L.ptr(zp), L.stream()), "ts_conv_class_gemm_x")
-        else:
-            L.check(L.load().ts_conv_class_gemm(L.ptr(feat), c_red, L.ptr(kernel), k, plan["groups"], cols, L.ptr(plan["src"]),
-                                                plan["m_pad"], L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]),
-                                                1 if weight_transposed else 0, plan["mirror"], L.ptr(plan["rows"]), L.ptr(zp),
-                                                L.stream()), "ts_conv_class_gemm")
+        L.check(L.load().ts_conv_class_gemm(L.ptr(feat), c_red, L.ptr(kernel), k, plan["groups"], cols, L.ptr(plan["src"]),
+                                            plan["m_pad"], L.ptr(plan["tile_info"]), L.ptr(plan["n_tiles"]),
+                                            1 if weight_transposed else 0, plan["mirror"], L.ptr(plan["rows"]), L.ptr(zp),
+                                            L.stream()), "ts_conv_class_gemm")
     return zp
 
 

@@ -275,7 +275,7 @@ static int block_conv(const void *feat, int64_t n_feat_rows, int32_t c_in, const
                                            0, 0, cp->rows, dst, nullptr, fused ? &fin : nullptr, stream));
         else
           TS_TRY(ts_conv_class_gemm_ex((const float *)feat, c_in, kernel, K, cp->groups, c_out, cp->src, cp->m_pad, cp->tile_info,
-                                       cp->n_tiles, 0, 0, cp->rows, (float *)dst, nullptr, fused ? &fin : nullptr, o.w_exp, stream));
+                                       cp->n_tiles, 0, 0, cp->rows, (float *)dst, nullptr, fused ? &fin : nullptr, stream));
       }
       if (!cp->rows && !fused) {
         ProfScope ps(1, stream, plan_z_rows(cp), 0, c_out, cp->groups, (double)n_out, es_d, 0);
@@ -542,7 +542,7 @@ extern "C" int ts_conv_block_backward(const void *grad_out, const uint8_t *mask,
       else
         TS_TRY(ts_conv_class_gemm_ex((const float *)grad_conv, c_out, (const float *)weights, K, cp->groups, c_in, cp->src,
                                      cp->m_pad, cp->tile_info, cp->n_tiles, 1, cp->mirror, cp->rows, (float *)dst, side,
-                                     fused ? &fin : nullptr, o.w_exp, stream));
+                                     fused ? &fin : nullptr, stream));
     }
     if (!cp->rows && !fused) {
       ProfScope ps(1, stream, plan_z_rows(cp), 0, c_in, cp->groups, (double)n_dgrad_rows, es_d, side_bytes);

@@ -237,7 +237,7 @@ struct TsClassFinish {
 int ts_conv_class_gemm_ex(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                           const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                           int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, const TsClassFinish *fin,
-                          const int32_t *wexp, ts_stream_t stream);      // wexp: per-offset weight exponents -> three half products
+                          ts_stream_t stream);
 int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, int32_t K, int32_t groups, int32_t c_out,
                               const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                               int32_t mirror, const int32_t *rows, void *zp, const TsWgradReduce *side, const TsClassFinish *fin,

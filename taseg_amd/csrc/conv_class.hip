@@ -291,47 +291,6 @@ __device__ __forceinline__ bf8 cg_frag_tr(const unsigned short *img, int pitch, 
     ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A)[0], (B)[0], ACC, 0, 0, 0);        \
   } while (0)
 
-// Three IEEE-half products per fp32 product (XF kernels, round 4): an operand slice times a power of two that brings its largest
-// magnitude into [2^14, 2^15) is x 2^e = h + 2^-11 l' with h = rn_f16(x 2^e), l' = rn_f16((x 2^e - h) 2^11) - 22 significant bits
-// of the slice's largest value - and a product is l'_a (2^-11 h_b) + h_a (2^-11 l'_b) + h_a h_b (half products are exact in fp32,
-// the dropped l' l' term is 2^-22 of it): half the matrix-pipe work of the six-product bf16 split, at LOWER error against float64
-// (tools/experiments/class_x_probe.py: 3.3-4.1e-7 of a row's largest value against 4.4-7.1e-7).  The scale is what stopped this
-// in round 3 (one exponent per TENSOR, from every producer).  Here it is local: the gathered operand gets one exponent per (row,
-// 32-column slice), computed where the slice is split (a max3 chain + two cross-lane steps over the four lanes that hold it), the
-// weight one per OFFSET (`wexp` [K], written beside the weight once per optimizer step: ts_conv_weight_exponents_batch) - both
-// factor out of a slice's MFMAs, whose accumulator is flushed into the running total with the factor 2^-(e_row + wexp[k]).
-typedef _Float16 xh2 __attribute__((ext_vector_type(2)));
-typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned cg_pk_f16(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, xh2));
-}
-__device__ __forceinline__ float cg_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
-// 8 floats times the power of two s -> planes h, l'
-__device__ __forceinline__ void cg_split8x(const f32x4 &v0, const f32x4 &v1, float s, u32x4 &h, u32x4 &l) {
-  const float a[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x0 = a[2 * i] * s, x1 = a[2 * i + 1] * s;
-    const unsigned hh = cg_pk_f16(x0, x1);
-    const xh2 hv = __builtin_bit_cast(xh2, hh);
-    h[i] = hh;
-    l[i] = cg_pk_f16((x0 - (float)hv[0]) * 2048.f, (x1 - (float)hv[1]) * 2048.f);
-  }
-}
-__device__ __forceinline__ u32x4 cg_down(const u32x4 &v) {                       // 2^-11 v (four v_pk_mul_f16)
-  const _Float16 c = (_Float16)0.00048828125f;
-  return __builtin_bit_cast(u32x4, __builtin_bit_cast(xh8, v) * (xh8){c, c, c, c, c, c, c, c});
-}
-// exponent e with max|x| 2^e in [2^14, 2^15) for the 8 values here and the 24 in the three neighbouring lanes (0 for an all-zero slice)
-__device__ __forceinline__ int cg_slice_exp(const f32x4 &v0, const f32x4 &v1) {
-  float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
-                  fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
-  m = fmaxf(m, __shfl_xor(m, 1, 64));
-  m = fmaxf(m, __shfl_xor(m, 2, 64));
-  const int ex = (int)((__float_as_uint(m) >> 23) & 255u) - 126;               // m < 2^ex
-  return m > 0.f ? min(max(15 - ex, -100), 100) : 0;
-}
-
 // finish of a three-group plan inside the product (common.h, TsClassFinish): phase 0 = every listed tile, Z' rows (pass 2 follows);
 // phase 1 = the tiles of the groups without the centre offset, Z' rows; phase 2 = the tiles of the centre group gfin (every
 // output row is in exactly one of them), the RESULT rows: out[r] = ((z_0[r] +) own sums (+ z_2[r])) (+ addend[r]), r = the slot's
@@ -352,14 +311,13 @@ struct CgFinish {
 // rows != NULL (direct plans): list slot i is stored into row rows[i] of Zp (= the result itself), -1 = padding.
 // Workgroups with blockIdx.x >= tile_blocks (launched when side.K > 0) form the ordered sum of the weight-gradient partials of the
 // launch before this one (common.h) - the job that rides on pass 2 where there is one.
-template <int BN, int WR, bool WT, bool XF>
+template <int BN, int WR, bool WT>
 __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restrict__ X, int R, const float *__restrict__ W,
                                                            int O_total, const int *__restrict__ src, int64_t m_pad,
                                                            const int2 *__restrict__ tile_info,
                                                            const int *__restrict__ n_tiles, int K, int gk, int mirror,
                                                            const int *__restrict__ rows, float *__restrict__ Zp,
-                                                           TsWgradReduce side, int tile_blocks, CgFinish fin,
-                                                           const int *__restrict__ wexp) {
+                                                           TsWgradReduce side, int tile_blocks, CgFinish fin) {
   constexpr int BM = CG_BM;
   constexpr int WC = 4 / WR;
   constexpr int MI = (BM / 16) / WR;
@@ -370,11 +328,10 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
   constexpr int A_IT = BM * (CG_BK / 8) / 256;
   constexpr int B_CHUNKS = BN * (CG_BK / 8);
   constexpr int B_IT = (B_CHUNKS + 255) / 256;
-  constexpr int A_PLANES = XF ? 2 : 3;                         // XF: h, l' of the gathered slice
+  constexpr int A_PLANES = 3;                                  // h, m, l of the gathered slice
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_cg[];
   unsigned short *Ap = smem_cg;                                // planes [128][CG_AP]
-  unsigned short *Bp = Ap + A_PLANES * A_PLANE;                // 3 planes (XF: h, 2^-11 l', 2^-11 h of the weight slice)
-  int *sc = (int *)(Bp + 3 * B_PLANE);                         // XF: exponent of every row's slice
+  unsigned short *Bp = Ap + A_PLANES * A_PLANE;                // 3 planes of the weight slice
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -435,7 +392,6 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
   const float *aptr[A_IT];
   bool alive[A_IT];
   const float *wk = W;
-  int we_next = 0, we_regs = 0, we_lds = 0;     // XF: weight exponent of the offset just bound / of the slice in rb / of the slice in LDS
   int nsrc[A_IT];                       // input rows of the NEXT offset of the mask, fetched an offset ahead
   auto fetch = [&](int kl) {
 #pragma unroll
@@ -450,7 +406,6 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
       aptr[it] = X + (int64_t)max(nsrc[it], 0) * R + acol;
     }
     wk = WT ? W + ((int64_t)kw * O_total + o0) * R : W + (int64_t)kw * R * O_total + o0;
-    if (XF) we_next = wexp[kw];
   };
   f32x4 ra[A_IT][2], rb[B_IT][2];
   bool rlive[A_IT];
@@ -477,40 +432,21 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
       const int rr = arow0 + 64 * it;
       const f32x4 v0 = rlive[it] ? ra[it][0] : zero, v1 = rlive[it] ? ra[it][1] : zero;
       unsigned short *dst = Ap + rr * CG_AP + acol;
-      if (XF) {
-        const int e = cg_slice_exp(v0, v1);
-        u32x4 h, l;
-        cg_split8x(v0, v1, cg_pow2(e), h, l);
-        *(u32x4 *)dst = h;
-        *(u32x4 *)(dst + A_PLANE) = l;
-        if ((tid & 3) == 0) sc[rr] = e;
-      } else {
-        u32x4 h, m, l;
-        cg_split8(v0, v1, h, m, l);
-        *(u32x4 *)dst = h;
-        *(u32x4 *)(dst + A_PLANE) = m;
-        *(u32x4 *)(dst + 2 * A_PLANE) = l;
-      }
+      u32x4 h, m, l;
+      cg_split8(v0, v1, h, m, l);
+      *(u32x4 *)dst = h;
+      *(u32x4 *)(dst + A_PLANE) = m;
+      *(u32x4 *)(dst + 2 * A_PLANE) = l;
     }
-    we_lds = we_regs;
-    const float sw = cg_pow2(we_regs);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       if (B_IT * 256 == B_CHUNKS || tid + it * 256 < B_CHUNKS) {
         unsigned short *dst = Bp + bdst[it];
-        if (XF) {
-          u32x4 h, l;
-          cg_split8x(rb[it][0], rb[it][1], sw, h, l);
-          *(u32x4 *)dst = h;
-          *(u32x4 *)(dst + B_PLANE) = cg_down(l);
-          *(u32x4 *)(dst + 2 * B_PLANE) = cg_down(h);
-        } else {
-          u32x4 h, m, l;
-          cg_split8(rb[it][0], rb[it][1], h, m, l);
-          *(u32x4 *)dst = h;
-          *(u32x4 *)(dst + B_PLANE) = m;
-          *(u32x4 *)(dst + 2 * B_PLANE) = l;
-        }
+        u32x4 h, m, l;
+        cg_split8(rb[it][0], rb[it][1], h, m, l);
+        *(u32x4 *)dst = h;
+        *(u32x4 *)(dst + B_PLANE) = m;
+        *(u32x4 *)(dst + 2 * B_PLANE) = l;
       }
     }
   };
@@ -521,15 +457,6 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
 #pragma unroll
       for (int p = 0; p < A_PLANES; ++p)
         a[mi][p] = *(const bf8 *)&Ap[p * A_PLANE + ((wr * MI + mi) * 16 + r16) * CG_AP + 8 * g];
-    f32x4 rs[MI];                          // XF: 2^-(e_row + wexp[k]) of this slice, rows 4g .. 4g+3 of every 16-row block
-    if (XF) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int *sp = sc + (wr * MI + mi) * 16 + 4 * g;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs[mi][q] = cg_pow2(-(sp[q] + we_lds));
-      }
-    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       bf8 b[3];
@@ -541,18 +468,7 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
           b[p] = cg_frag_tr(Bp + p * B_PLANE, BP, 8 * g, (wc * NI + ni) * 16, tq, tp);
       }
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (XF) {                          // three half products into a fresh accumulator, flushed with the slice's factor
-          f32x4 t = {0.f, 0.f, 0.f, 0.f};
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xh8, a[mi][1]), __builtin_bit_cast(xh8, b[2]), t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xh8, a[mi][0]), __builtin_bit_cast(xh8, b[1]), t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xh8, a[mi][0]), __builtin_bit_cast(xh8, b[0]), t, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) tot[mi][ni][q] = fmaf(t[q], rs[mi][q], tot[mi][ni][q]);
-        } else {
-          CG_MMA(acc[mi][ni], a[mi], b);
-        }
-      }
+      for (int mi = 0; mi < MI; ++mi) CG_MMA(acc[mi][ni], a[mi], b);
     }
   };
 
@@ -561,7 +477,6 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
   bind(__builtin_ctz(mask));
   mask &= mask - 1;
   load_regs(0);
-  we_regs = we_next;
   bool first = true;
   while (true) {
     if (mask) fetch(__builtin_ctz(mask));  // rows of the next offset: needed only when this offset's last slice is staged
@@ -575,19 +490,16 @@ __global__ __launch_bounds__(256, 2) void class_gemm_kernel(const float *__restr
       } else if (mask) {
         bind(__builtin_ctz(mask));         // first slice of the next offset, in flight behind this slice's MFMAs
         load_regs(0);
-        we_regs = we_next;
       }
       mma();
     }
-    if (!XF) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          tot[mi][ni] += acc[mi][ni];
-          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
+      for (int ni = 0; ni < NI; ++ni) {
+        tot[mi][ni] += acc[mi][ni];
+        acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     if (!mask) break;
     mask &= mask - 1;
   }
@@ -656,25 +568,19 @@ struct CgArgs {          // what a class-GEMM launch takes beyond operands and r
   TsWgradReduce side;
   CgFinish fin;          // phase 0: plain launch
   int groups;
-  const int *wexp;       // fp32: per-offset weight exponents -> the three-product kernels (NULL: six bf16 products)
 };
 static int64_t cg_tile_bound(const CgArgs &a) { return a.m_pad / CG_BM; }      // tiles a launch can meet (every phase walks the list)
 
-template <int BN, int WR, bool WT, bool XF>
-static int launch_class_x(const float *X, int R, const float *W, int O_total, const CgArgs &a, float *Zp, hipStream_t stream) {
-  const size_t stage = (size_t)((XF ? 2 : 3) * CG_BM * CG_AP + 3 * (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2 + (XF ? CG_BM * 4 : 0);
+template <int BN, int WR, bool WT>
+static int launch_class(const float *X, int R, const float *W, int O_total, const CgArgs &a, float *Zp, hipStream_t stream) {
+  const size_t stage = (size_t)(3 * CG_BM * CG_AP + 3 * (WT ? BN * CG_AP : CG_BK * (BN + 8))) * 2;
   const size_t lds = a.fin.phase == 2 ? std::max(stage, (size_t)CG_BM * (BN + 4) * 4) : stage;      // phase 2: the image of the sums
   const unsigned tiles = (unsigned)cg_tile_bound(a);
   dim3 grid(tiles + (a.side.K > 0 ? 64u : 0u), (unsigned)(O_total / BN));
-  class_gemm_kernel<BN, WR, WT, XF><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K, a.gk,
-                                                                a.mirror, a.rows, Zp, a.side, (int)tiles, a.fin, a.wexp);
+  class_gemm_kernel<BN, WR, WT><<<grid, 256, lds, stream>>>(X, R, W, O_total, a.src, a.m_pad, a.tile_info, a.n_tiles, a.K, a.gk,
+                                                            a.mirror, a.rows, Zp, a.side, (int)tiles, a.fin);
   TS_CHECK_LAUNCH("ts_conv_class_gemm");
   return TS_OK;
-}
-template <int BN, int WR, bool WT>
-static int launch_class(const float *X, int R, const float *W, int O_total, const CgArgs &a, float *Zp, hipStream_t stream) {
-  return a.wexp ? launch_class_x<BN, WR, WT, true>(X, R, W, O_total, a, Zp, stream)
-                : launch_class_x<BN, WR, WT, false>(X, R, W, O_total, a, Zp, stream);
 }
 static int cg_tile_columns(int c_out) { return c_out % 128 == 0 ? 128 : c_out % 96 == 0 ? 96 : c_out % 64 == 0 ? 64 : c_out % 32 == 0 ? 32 : 0; }
 
@@ -726,11 +632,11 @@ static int cg_finish(const char *what, const TsClassFinish *fin, int K, int grou
 int ts_conv_class_gemm_ex(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
                           const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                           int32_t mirror, const int32_t *rows, float *zp, const TsWgradReduce *side, const TsClassFinish *fin,
-                          const int32_t *wexp, ts_stream_t stream_) {
+                          ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int rc = cg_check("ts_conv_class_gemm", K, groups, c_red, c_out, m_pad, feat, kernel, zp, src, tile_info, n_tiles);
   if (rc != TS_OK) return rc;
-  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}, {}, groups, wexp};
+  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}, {}, groups};
   {
     const int frc = cg_finish("ts_conv_class_gemm", fin, K, groups, rows, a.fin);
     if (frc != TS_OK) return frc;
@@ -763,65 +669,9 @@ extern "C" int ts_conv_class_gemm(const float *feat, int32_t c_red, const float 
                                   const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
                                   int32_t mirror, const int32_t *rows, float *zp, ts_stream_t stream) {
   return ts_conv_class_gemm_ex(feat, c_red, kernel, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, rows, zp, nullptr,
-                               nullptr, nullptr, stream);
+                               nullptr, stream);
 }
 
-// ts_conv_class_gemm with the three-product arithmetic: wexp [K] = ts_conv_weight_exponents_batch of `kernel`
-extern "C" int ts_conv_class_gemm_x(const float *feat, int32_t c_red, const float *kernel, int32_t K, int32_t groups, int32_t c_out,
-                                    const int32_t *src, int64_t m_pad, const int32_t *tile_info, const int32_t *n_tiles, int32_t wt,
-                                    int32_t mirror, const int32_t *rows, const int32_t *wexp, float *zp, ts_stream_t stream) {
-  TS_REQUIRE(wexp, TS_ERR_INVALID_ARGUMENT, "ts_conv_class_gemm_x: the weight exponents are missing");
-  return ts_conv_class_gemm_ex(feat, c_red, kernel, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, rows, zp, nullptr,
-                               nullptr, wexp, stream);
-}
-
-// Per-offset exponents of convolution weights for the three-product kernels: wexp[k] with max |W_k| 2^wexp[k] in [2^14, 2^15)
-// (0 for an all-zero slice); one workgroup per (weight, offset), 16 weights per launch - what the caller refreshes whenever the
-// weight has changed (taseg_amd/planes.py keeps it beside the parameter like the planes).
-struct CgExpJob {
-  const float *w;
-  int *wexp;
-  int K, n;              // offsets, elements per offset (C_in * C_out)
-};
-struct CgExpJobs {
-  CgExpJob job[16];
-};
-__global__ __launch_bounds__(256) void weight_exponents_kernel(CgExpJobs jobs) {
-  __shared__ float red[4];
-  const CgExpJob jb = jobs.job[blockIdx.y];
-  const int k = (int)blockIdx.x;
-  if (k >= jb.K) return;
-  const float *w = jb.w + (int64_t)k * jb.n;
-  float m = 0.f;
-  for (int i = threadIdx.x; i < jb.n; i += 256) m = fmaxf(m, fabsf(w[i]));
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const int ex = (int)((__float_as_uint(m) >> 23) & 255u) - 126;
-    jb.wexp[k] = m > 0.f ? min(max(15 - ex, -100), 100) : 0;
-  }
-}
-extern "C" int ts_conv_weight_exponents_batch(const TsPlaneJob *jobs, int32_t n_jobs, ts_stream_t stream) {
-  TS_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), TS_ERR_INVALID_ARGUMENT, "ts_conv_weight_exponents_batch: bad arguments");
-  for (int32_t j0 = 0; j0 < n_jobs; j0 += 16) {
-    CgExpJobs chunk;
-    const int cnt = std::min(16, n_jobs - j0);
-    int kmax = 0;
-    for (int j = 0; j < cnt; ++j) {
-      const TsPlaneJob &jb = jobs[j0 + j];
-      TS_REQUIRE(jb.w && jb.planes && jb.K > 0 && jb.c_in > 0 && jb.c_out > 0, TS_ERR_INVALID_ARGUMENT,
-                 "ts_conv_weight_exponents_batch: job %d: null pointer or bad shape", j0 + j);
-      chunk.job[j] = CgExpJob{jb.w, (int *)jb.planes, jb.K, jb.c_in * jb.c_out};
-      kmax = std::max(kmax, jb.K);
-    }
-    weight_exponents_kernel<<<dim3((unsigned)kmax, (unsigned)cnt), 256, 0, (hipStream_t)stream>>>(chunk);
-    TS_CHECK_LAUNCH("ts_conv_weight_exponents_batch");
-  }
-  return TS_OK;
-}
 
 // The whole convolution on a three-group plan: out [n, c_out] = sum over the offsets (+ addend), as ts_conv_class_gemm followed by
 // ts_conv_gather_sum(zp, pos, 3) - the same bits - in two launches of the product kernel and without the centre group's Z' rows
@@ -832,7 +682,7 @@ extern "C" int ts_conv_class_conv(const float *feat, int32_t c_red, const float 
                                   ts_stream_t stream) {
   const TsClassFinish fin = {pos, n, out, addend};
   return ts_conv_class_gemm_ex(feat, c_red, kernel, K, groups, c_out, src, m_pad, tile_info, n_tiles, wt, mirror, nullptr, zp, nullptr,
-                               &fin, nullptr, stream);
+                               &fin, stream);
 }
 
 // ------------------------------------------------------------------------------------------- half storage
@@ -1162,7 +1012,7 @@ int ts_conv_class_gemm_f16_ex(const void *feat, int32_t c_red, const void *w, in
   hipStream_t stream = (hipStream_t)stream_;
   const int chk = cg_check("ts_conv_class_gemm_f16", K, groups, c_red, c_out, m_pad, feat, w, zp, src, tile_info, n_tiles);
   if (chk != TS_OK) return chk;
-  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}, {}, groups, nullptr};
+  CgArgs a = {src, m_pad, (const int2 *)tile_info, n_tiles, K, K / groups, mirror ? 1 : 0, rows, {}, {}, groups};
   {
     const int frc = cg_finish("ts_conv_class_gemm_f16", fin, K, groups, rows, a.fin);
     if (frc != TS_OK) return frc;

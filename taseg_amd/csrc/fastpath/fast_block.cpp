@@ -250,7 +250,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
                             const std::vector<int64_t> &plan_f_meta, const c10::optional<at::Tensor> &pd0,
                             const c10::optional<at::Tensor> &pd1, const c10::optional<at::Tensor> &pd2,
                             const c10::optional<at::Tensor> &pd3, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok,
-                            const c10::optional<at::Tensor> &wexp, bool natural) {
+                            bool natural) {
     const int64_t t_in = now_ns();
     // a backward pass that died mid-way leaves its join behind: nothing of the second stream outlives the next forward call
     if (wg_join_queued.exchange(false)) {
@@ -292,11 +292,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     // everything the call may use beyond the rulebook, explicitly (TsConvBlockOpts): the class plans of this block's kernel map
     // (csrc/conv_class.hip), the pre-split planes / the kept half copy of the weight
     const PlanRef pf(plan_f, plan_f_meta, nboffs);
-    // per-offset exponents of the weight (taseg_amd/planes.py: exps_for): the fp32 class products on three half MFMAs
-    at::Tensor wx;
-    if (!half && own_weight && wexp.has_value() && wexp->defined() && wexp->scalar_type() == at::kInt && wexp->numel() == k) wx = *wexp;
     TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0,
-                             wx.defined() ? (const int32_t *)wx.data_ptr() : nullptr, natural ? 1 : 0};
+                             natural ? 1 : 0};
     auto call = [&](void *c) {
       check(api.forward(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k,
                         (const int32_t *)nbmaps.data_ptr(), (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0,
@@ -326,7 +323,6 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     // the weight gradient may leave for the second stream only if autograd will ADOPT it as p.grad (p.grad undefined now): an
     // accumulation into an existing p.grad reads it on this stream, at once
     ctx->saved_data["wgrad_side_ok"] = wgrad_side_ok;
-    ctx->saved_data["wexp"] = wx;            // (not a graph tensor: refreshed in place when the optimizer has stepped)
     // where the weight gradient is wanted (a gradient bucket's view, taseg_amd/parallel.py), if anywhere
     ctx->saved_data["grad_dest"] = (grad_dest.has_value() && grad_dest->defined()) ? *grad_dest : at::Tensor();
     ctx->saved_data["natural"] = natural;
@@ -395,9 +391,8 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     const std::vector<at::Tensor> plan_d = ctx->saved_data["plan_d"].toTensorVector();
     const std::vector<int64_t> plan_d_meta = ctx->saved_data["plan_d_meta"].toIntVector();
     const PlanRef pd(grad_feat.defined() ? plan_d : std::vector<at::Tensor>(), plan_d_meta, nboffs);
-    const at::Tensor wx = ctx->saved_data["wexp"].toTensor();
     TsConvBlockOpts bopts = {nullptr, pd.get(), (pl.defined() && !half) ? pl.data_ptr() : nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0,
-                             (wx.defined() && !half) ? (const int32_t *)wx.data_ptr() : nullptr, natural ? 1 : 0};
+                             natural ? 1 : 0};
     std::function<void()> side_job;
     if (wg_side.on && ctx->saved_data["wgrad_side_ok"].toBool() && grad_w.defined() && !comm && !split &&
         x.get_device() == wg_side.device_index && stream != wg_side.raw && (c_in * c_out) % 4 == 0 &&
@@ -479,7 +474,7 @@ class ConvBlock : public torch::autograd::Function<ConvBlock> {
     host_clock.n_bwd += 1;
     return {grad_feat, grad_w, grad_res, gbw, gbb, none, none, none, none, none, none, none, none,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none};
   }
 };
 
@@ -527,8 +522,7 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
                       const c10::optional<at::Tensor> &planes, bool passthrough,
                       const c10::optional<at::Tensor> &grad_dest, int64_t group_id,
                       const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta,
-                      const std::vector<at::Tensor> &plan_d, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok,
-                      const c10::optional<at::Tensor> &wexp, bool natural) {
+                      const std::vector<at::Tensor> &plan_d, const std::vector<int64_t> &plan_d_meta, bool wgrad_side_ok, bool natural) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   TORCH_CHECK(!natural || (!passthrough && !transposed && plan_f.empty() && plan_d.empty() && n_in == n_out && total == n_out),
               "conv_block: a natural (1x1x1, identity rulebook) block takes no plans, no pass-through and one pair per row");
@@ -538,8 +532,7 @@ std::vector<at::Tensor> conv_block(const at::Tensor &feats, const at::Tensor &we
   return ConvBlock::apply(feats, weight, residual, bn_weight, bn_bias, nbmaps, nboffs, total, pos_out, pos_in, n_in, n_out,
                           transposed, running_mean, running_var, nbt, momentum, eps, relu, comm, half, stream, planes,
                           passthrough, grad_dest, group_id, at_(plan_f, 0), at_(plan_f, 1), at_(plan_f, 2), at_(plan_f, 3),
-                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta, wgrad_side_ok, wexp,
-                          natural);
+                          plan_f_meta, at_(plan_d, 0), at_(plan_d, 1), at_(plan_d, 2), at_(plan_d, 3), plan_d_meta, wgrad_side_ok, natural);
 }
 
 // Evaluation form of the block (eval-mode BatchNorm on its running statistics, no graph): ts_conv_block_eval without the
@@ -550,8 +543,7 @@ at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, co
                            const at::Tensor &invstd, const at::Tensor &nbmaps, const at::Tensor &nboffs, int64_t total,
                            const at::Tensor &pos_out, const at::Tensor &pos_in, int64_t n_in, int64_t n_out, bool transposed,
                            bool relu, bool half, int64_t stream, const c10::optional<at::Tensor> &planes,
-                           const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta,
-                           const c10::optional<at::Tensor> &wexp, bool natural) {
+                           const std::vector<at::Tensor> &plan_f, const std::vector<int64_t> &plan_f_meta, bool natural) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
   at::NoGradGuard nograd;
   const bool flat = weight.dim() == 2;
@@ -576,10 +568,8 @@ at::Tensor conv_block_eval(const at::Tensor &feats, const at::Tensor &weight, co
   const size_t nb = api.workspace_bytes(total, std::max(n_in, n_out), (int32_t)c_in, (int32_t)c_out, (int32_t)k, half ? 1 : 0);
   at::Tensor ws = workspace(nb, x, stream);
   const PlanRef pf(plan_f, plan_f_meta, nboffs);
-  const bool wx_ok = !half && w32.data_ptr() == weight.data_ptr() && wexp.has_value() && wexp->defined() &&
-                     wexp->scalar_type() == at::kInt && wexp->numel() == k;
   TsConvBlockOpts bopts = {pf.get(), nullptr, pl.defined() ? pl.data_ptr() : nullptr, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0,
-                           wx_ok ? (const int32_t *)wexp->data_ptr() : nullptr, natural ? 1 : 0};
+                           natural ? 1 : 0};
   check(api.eval(x.data_ptr(), x.size(0), (int32_t)c_in, w32.data_ptr<float>(), (int32_t)k, (const int32_t *)nbmaps.data_ptr(),
                  (const int32_t *)nboffs.data_ptr(), total, transposed ? 1 : 0, (const int32_t *)table.data_ptr(), rows,
                  (int32_t)c_out, ptr(res), (const float *)bn_weight.data_ptr(), (const float *)bn_bias.data_ptr(),

@@ -357,7 +357,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
       if (r.use_dest) l.claimed = grad_epoch;
       const at::Tensor &table = o.transposed ? m.pos_in : m.pos_out;
       const void *pl = (!half && l.planes32.defined()) ? l.planes32.data_ptr() : nullptr;
-      TsConvBlockOpts bopts = {g.plan_f[i].get(), nullptr, pl, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, l.natural ? 1 : 0};
+      TsConvBlockOpts bopts = {g.plan_f[i].get(), nullptr, pl, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0, l.natural ? 1 : 0};
       auto call = [&](void *c) {
         check(api.forward(r.x, r.x_rows, (int32_t)l.c_in, l.kernel.data_ptr<float>(), (int32_t)l.k, (const int32_t *)m.nbmaps.data_ptr(),
                           (const int32_t *)m.nboffs.data_ptr(), m.total, o.transposed ? 1 : 0, (const int32_t *)table.data_ptr(), n_rows,
@@ -503,8 +503,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
         grad_w = at::empty(wshape, like.options().dtype(at::kFloat));
       }
       const void *pl = (!half && l.planes32.defined()) ? l.planes32.data_ptr() : nullptr;
-      TsConvBlockOpts bopts = {nullptr, grad_feat ? g.plan_d[i].get() : nullptr, pl, 0, addend, nullptr, nullptr, 0, 0, 0, nullptr,
-                               l.natural ? 1 : 0};
+      TsConvBlockOpts bopts = {nullptr, grad_feat ? g.plan_d[i].get() : nullptr, pl, 0, addend, nullptr, nullptr, 0, 0, 0, l.natural ? 1 : 0};
       std::function<void()> side_job;
       if (side_possible && r.side_ok && (l.c_in * l.c_out) % 4 == 0 && (((uintptr_t)grad_w.data_ptr()) & 15) == 0) {
         std::lock_guard<std::mutex> lock(wg_mutex);
@@ -669,7 +668,7 @@ inline at::Tensor run_eval(const std::vector<at::Tensor> &inputs_, std::shared_p
     if (half) w16 = kept16 ? l.half16.data_ptr() : take((size_t)l.k * l.c_in * l.c_out * 2);
     const at::Tensor &table = o.transposed ? m.pos_in : m.pos_out;
     const void *pl = (!half && l.planes32.defined()) ? l.planes32.data_ptr() : nullptr;
-    TsConvBlockOpts bopts = {g.plan_f[i].get(), nullptr, pl, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, l.natural ? 1 : 0};
+    TsConvBlockOpts bopts = {g.plan_f[i].get(), nullptr, pl, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0, l.natural ? 1 : 0};
     check(api.eval(reg[o.src], rows[o.src], (int32_t)l.c_in, l.kernel.data_ptr<float>(), (int32_t)l.k, (const int32_t *)m.nbmaps.data_ptr(),
                    (const int32_t *)m.nboffs.data_ptr(), m.total, o.transposed ? 1 : 0, (const int32_t *)table.data_ptr(), rows[o.dst],
                    (int32_t)l.c_out, o.aux >= 0 ? reg[o.aux] : nullptr, (const float *)l.bn_w.data_ptr(), (const float *)l.bn_b.data_ptr(),

@@ -457,9 +457,10 @@ class PendingPredictions:
     indexing would have raised on, and slices the dictionary of numpy arrays `model(batch)` returns.  The arrays are views of a
     ring of host buffers: valid until three further deferred tails have been issued (copy them to keep them longer)."""
 
-    def __init__(self, event, meta_h, result_h, mapped_h, labels_h, shapes, names, n_scenes, has_ms):
+    def __init__(self, event, meta_h, result_h, mapped_h, labels_h, shapes, names, n_scenes, has_ms, fused=False, fallback=None):
         self.event, self.meta_h, self.result_h, self.mapped_h, self.labels_h = event, meta_h, result_h, mapped_h, labels_h
         self.shapes, self.names, self.n_scenes, self.has_ms = shapes, names, n_scenes, has_ms
+        self.fused, self.fallback = fused, fallback
         self._out = None
 
     def result(self):
@@ -468,7 +469,18 @@ class PendingPredictions:
         self.event.synchronize()
         n = self.n_scenes
         meta = self.meta_h.numpy()
-        bad, cnt_p_h, cnt_k_h = int(meta[0]), meta[1:1 + n].tolist(), meta[1 + n:1 + 2 * n].tolist()
+        if self.fused:
+            # the fused tail (csrc/evaltail.hip): [flags, voxels per scene, points per scene, labels per scene, ...]; flags bit 0:
+            # a scene index outside the batch, bit 1: an index array not grouped by scene (the sorted form then serves the batch),
+            # bit 2: inverse map outside its scene
+            flags = int(meta[0])
+            if flags & 2:
+                self._out = self.fallback()
+                return self._out
+            bad = (1 if flags & 4 else 0) | (2 if flags & 1 else 0)
+            cnt_p_h = cnt_k_h = meta[1 + n:1 + 2 * n].tolist()
+        else:
+            bad, cnt_p_h, cnt_k_h = int(meta[0]), meta[1:1 + n].tolist(), meta[1 + n:1 + 2 * n].tolist()
         cnt_l_h = meta[1 + 2 * n:1 + 3 * n].tolist()
         n_cur_h = meta[1 + 3 * n:1 + 4 * n].tolist()
         if bad & 2:
@@ -498,8 +510,44 @@ class PendingPredictions:
         return self._out
 
 
+_FUSED_TAIL = _os.environ.get("TASEG_FUSED_EVAL_TAIL", "1") != "0"
+
+
+def _fused_tail(out, vox_batch, invs, all_labels, num_points, want_probs, num_points_ms, names, defer, n_scenes):
+    """unvoxelise_predictions for index arrays grouped by scene (what sparse_collate builds) in two launches of csrc/evaltail.hip -
+    rows per scene, then gather + arg-max - instead of three stable sorts and ~45 tensor ops; None where it does not apply.  A batch
+    that is not grouped is detected on the device and served by the sorted form when the arrays are collected."""
+    bv, bp, bl = vox_batch, invs.C[:, -1], all_labels.C[:, -1]
+    if not (out.is_cuda and out.dim() == 2 and out.dtype in (torch.float32, torch.float16) and n_scenes <= 64
+            and all(t.dtype == torch.int32 and t.is_cuda and t.dim() == 1 for t in (bv, bp, bl))):
+        return None
+    L = B.L
+    lib = L.load()
+    dev = out.device
+    inv = invs.F if invs.F.dtype == torch.int64 else invs.F.long()
+    inv = inv.contiguous()
+    n = n_scenes
+    has_ms = num_points_ms is not None
+    meta = torch.zeros(1 + (5 if has_ms else 4) * n, dtype=torch.int64, device=dev)      # [flags | counts 3 x n | num_points (| _ms)]
+    st = L.stream()
+    stride = lambda t: int(t.stride(0)) if t.shape[0] > 1 else 1  # noqa: E731
+    L.check(lib.ts_scene_counts(L.ptr(bv), stride(bv), bv.shape[0], L.ptr(bp), stride(bp), bp.shape[0], L.ptr(bl), stride(bl),
+                                bl.shape[0], n, meta.data_ptr() + 8, meta.data_ptr(), st), "ts_scene_counts")
+    logits = out.contiguous()
+    pts, c = inv.shape[0], logits.shape[1]
+    mapped = torch.empty((pts, c), dtype=logits.dtype, device=dev)
+    pred = None if want_probs else torch.empty(pts, dtype=torch.int64, device=dev)
+    L.check(lib.ts_unvoxelise(L.ptr(logits), 1 if logits.dtype == torch.float16 else 0, c, meta.data_ptr() + 8, n, L.ptr(bp), stride(bp),
+                              L.ptr(inv), pts, L.ptr(mapped), L.ptr(pred), meta.data_ptr(), st), "ts_unvoxelise")
+    meta[1 + 3 * n:1 + 4 * n].copy_(torch.as_tensor(num_points).reshape(-1)[:n], non_blocking=True)
+    if has_ms:
+        meta[1 + 4 * n:1 + 5 * n].copy_(torch.as_tensor(num_points_ms).reshape(-1)[:n], non_blocking=True)
+    result = mapped.softmax(1) if want_probs else pred
+    return meta, result, mapped, all_labels.F
+
+
 def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_probs, point_mask=None, num_points_ms=None,
-                           names=None, defer=False):
+                           names=None, defer=False, _fused=True):
     """The evaluation tail of the segmentors (minkunet.py:435-455, minkunet_ms.py:433-458) for the WHOLE batch at once: per scene
     `out[scene][inverse_map of the scene]` (Ms: `[point_mask of the scene]`), trimmed to the scan's own point count; arg-max and
     logits (or the soft-max under return_logit / return_tta) and the mapped labels as numpy arrays, scene by scene - what the
@@ -508,8 +556,15 @@ def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_pr
     copies - the caller issues the next batch's forward pass first and collects `result()` afterwards (pcseg/eval.py, bench.py
     --eval): the host never waits for the device between two batches."""
     dev = out.device
-    b_vox, b_pts, b_lab = vox_batch.long(), invs.C[:, -1].long(), all_labels.C[:, -1].long()
     n_scenes = len(names) if names is not None else int(torch.as_tensor(num_points).numel())
+    fused = _fused_tail(out, vox_batch, invs, all_labels, num_points, want_probs, num_points_ms, names, defer, n_scenes) \
+        if (_fused and _FUSED_TAIL and point_mask is None) else None
+    if fused is not None:
+        meta, result, mapped, labels_sorted = fused
+        return _tail_to_host(meta, result, mapped, labels_sorted, want_probs, defer, names, n_scenes, num_points_ms is not None, True,
+                             lambda: unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_probs, point_mask,
+                                                            num_points_ms, names, False, _fused=False))
+    b_vox, b_pts, b_lab = vox_batch.long(), invs.C[:, -1].long(), all_labels.C[:, -1].long()
     # stable sorts by scene: 8-bit keys where the batch allows it (one radix pass instead of the eight of a 64-bit key; an index
     # outside 0 .. 254 wraps to a value that is still >= n_scenes or lands in the wrong scene's count - both are reported below)
     narrow = (lambda t: t.clamp(-1, 255).to(torch.uint8)) if n_scenes < 255 else (lambda t: t)
@@ -550,6 +605,12 @@ def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_pr
     if num_points_ms is not None:
         parts.append(torch.as_tensor(num_points_ms).reshape(-1)[:n_scenes].to(dev, non_blocking=True).long())
     meta = torch.cat(parts)
+    return _tail_to_host(meta, result, mapped, labels_sorted, want_probs, defer, names, n_scenes, num_points_ms is not None, False, None)
+
+
+def _tail_to_host(meta, result, mapped, labels_sorted, want_probs, defer, names, n_scenes, has_ms, fused, fallback):
+    """one small tensor with everything the per-scene slicing needs, then the arrays themselves: asynchronous copies into page-locked
+    buffers, one event behind them"""
     if defer:
         _pinned.next_generation()
 
@@ -568,7 +629,7 @@ def unvoxelise_predictions(out, vox_batch, invs, all_labels, num_points, want_pr
     event = torch.cuda.Event()
     event.record()
     pending = PendingPredictions(event, meta_h, result_h, mapped_h, labels_h, (tuple(result.shape), tuple(mapped.shape), tuple(labels_sorted.shape)),
-                                 names, n_scenes, num_points_ms is not None)
+                                 names, n_scenes, has_ms, fused, fallback)
     # (the device tensors stay alive until the copies have run: the event's owner keeps them)
     pending._keep = (meta, result, mapped, labels_sorted)
     return pending if defer else pending.result()

@@ -32,7 +32,7 @@ _BLOCK, _CAT = 0, 1
 
 
 def enabled() -> bool:
-    return _ON and _fast.module() is not None and hasattr(_fast.module(), "stage_run") and not _planes._CLASS_X
+    return _ON and _fast.module() is not None and hasattr(_fast.module(), "stage_run")
 
 
 class _Unsupported(Exception):
@@ -66,7 +66,7 @@ def compiled(model) -> bool:
 
 class _Stage:
     """one compiled stage: the C++ program, its (conv, bn) modules and the kernel-map key of every op"""
-    __slots__ = ("program", "layers", "ops", "keys", "in_strides", "planes_state", "dest_state", "bns", "convs", "modules", "held")
+    __slots__ = ("program", "layers", "ops", "keys", "in_strides", "planes_state", "dest_state", "bns", "convs", "modules", "entries")
 
 
 def _tup(v):
@@ -90,6 +90,7 @@ class StagePrograms:
         for name, st in self.stages.items():
             # every module the program stands in for: a forward / backward hook on any of them must still fire (module path then)
             st.modules = list(getattr(model, name).modules())
+        self._finish_compile()
 
     # ------------------------------------------------------------------ model side
     def _compile(self, blocks, in_strides, cat_after_first):
@@ -159,8 +160,7 @@ class StagePrograms:
             track = bn.track_running_stats and bn.running_mean is not None
             layers.append((conv.kernel, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
                            bn.num_batches_tracked if track else None, float(bn.momentum), float(bn.eps)))
-        st.held = [(c._parameters["kernel"], b._parameters["weight"], b._parameters["bias"], b._buffers.get("running_mean"),
-                    b._buffers.get("running_var")) for c, b in st.layers]
+        st.entries = {False: None, True: None}      # per storage mode: [(planes entry | None, weight)] as last handed to the program
         st.program = self.fast.StageProgram(len(in_strides), cur, st.ops, layers)
         st.planes_state = {False: None, True: None}
         st.dest_state = None
@@ -220,50 +220,72 @@ class StagePrograms:
 
     # ------------------------------------------------------------------ per call
     def usable(self, feats, training, grad):
-        """can the programs serve this pass?  (training with a graph, or evaluation without one; full-tile channel counts)"""
-        if not feats.is_cuda:
-            return False
-        if training != grad:
+        """can the programs serve this pass?  (training with a graph, or evaluation without one; full-tile channel counts).  Runs
+        once per pass over ~300 modules: only dictionary truth tests and identity comparisons on objects collected at compile time"""
+        if not feats.is_cuda or training != grad:
             return False           # (training-mode BatchNorm without a graph, eval-mode BatchNorm with one: the module path)
         half = spF._amp_half(feats)
         if not half and feats.dtype != torch.float32:
             return False
+        if not (self.ok_half if half else self.ok_f32) or (not training and not self.ok_eval):
+            return False
+        for d in self.hook_dicts:              # a forward / backward hook on any module the programs stand in for must still fire
+            if d:
+                return False
+        for bn in self.all_bns:
+            if bn.training != training:
+                return False
+        # the programs hold these tensor objects: a module whose parameter / buffer objects were replaced since (`.to()` swaps
+        # buffers, an assignment swaps a parameter) needs a new program
+        for d, key, held in self.held_slots:
+            if d.get(key) is not held:
+                self.stale = True
+                return False
+        return True
+
+    def _finish_compile(self):
+        """what usable() reads: shape rules decided once, the hook dictionaries and (dictionary, key, tensor) slots of every module"""
+        layers = [(c, b) for st in self.stages.values() for c, b in st.layers]
+        shapes = [(c.kernel.shape[-2], c.kernel.shape[-1], c.kernel.dim()) for c, _ in layers]
+        base = all(co <= 1024 and (dim == 3 or spF._dense_ok(ci, co)) for ci, co, dim in shapes)
+        self.ok_f32 = base and all(co % 4 == 0 for _, co, _ in shapes)
+        self.ok_half = base and all(ci % 32 == 0 and co % 32 == 0 for ci, co, _ in shapes)
+        self.ok_eval = all(b.track_running_stats and b._buffers.get("running_var") is not None
+                           and b._buffers["running_mean"].dtype == torch.float32 for _, b in layers)
+        self.all_bns = [b for _, b in layers]
+        self.hook_dicts = []
         for st in self.stages.values():
             for m in st.modules:
-                if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
-                    return False
-            for (conv, bn), held in zip(st.layers, st.held):
-                if bn.training != training:
-                    return False
-                # the program holds these tensor objects: a module whose parameter / buffer objects were replaced since
-                # (`.to()` swaps buffers, an assignment swaps a parameter) needs a new program
-                pb = bn._buffers
-                if conv._parameters["kernel"] is not held[0] or bn._parameters["weight"] is not held[1] \
-                        or bn._parameters["bias"] is not held[2] or pb.get("running_mean") is not held[3] \
-                        or pb.get("running_var") is not held[4]:
-                    self.stale = True
-                    return False
-                k = conv.kernel
-                c_in, c_out = k.shape[-2], k.shape[-1]
-                if half and not (c_in % 32 == 0 and c_out % 32 == 0):
-                    return False
-                if c_out % (8 if half else 4) != 0 or c_out > 1024 or (k.dim() == 2 and not spF._dense_ok(c_in, c_out)):
-                    return False
-                if not training and not (bn.track_running_stats and bn.running_var is not None and bn.running_mean.dtype == torch.float32):
-                    return False
-        return True
+                self.hook_dicts += [m._forward_hooks, m._forward_pre_hooks, m._backward_hooks, m._backward_pre_hooks]
+        self.held_slots = []
+        for c, b in layers:
+            self.held_slots += [(c._parameters, "kernel", c._parameters["kernel"]), (b._parameters, "weight", b._parameters["weight"]),
+                                (b._parameters, "bias", b._parameters["bias"]), (b._buffers, "running_mean", b._buffers.get("running_mean")),
+                                (b._buffers, "running_var", b._buffers.get("running_var"))]
 
     def _refresh(self, st, half):
         """planes / kept half copies of the stage's weights in step with the weights (taseg_amd/planes.py refreshes every stale
         weight of the model in one batch of launches at the first stale one it is asked for), gradient-bucket slots of the
         parameters as the reducer names them"""
-        get = _planes.half_for if half else _planes.planes_for
-        cur = [get(c.kernel) for c in st.convs]
-        ident = tuple(id(t) for t in cur)
-        if st.planes_state[half] != ident:
-            none = [None] * len(cur)
-            st.program.set_planes(none if half else cur, cur if half else none)
-            st.planes_state[True], st.planes_state[False] = (ident, None) if half else (None, ident)
+        stream = B.L.stream()
+        epoch = _planes._epoch
+        ents = st.entries[half]
+        fresh = ents is not None
+        if fresh:
+            # (taseg_amd/planes._Entry.fresh inlined: 61 of these per pass)
+            for e, w in ents:
+                if e is not None and (e.ptr != w.data_ptr() or e.version != w._version or e.epoch != epoch or e.stream != stream):
+                    fresh = False
+                    break
+        if not fresh:
+            get, table = (_planes.half_for, _planes._half_entries) if half else (_planes.planes_for, _planes._entries)
+            cur = [get(c.kernel) for c in st.convs]
+            st.entries[half] = [(table.get(id(c.kernel)) if t is not None else None, c.kernel) for c, t in zip(st.convs, cur)]
+            ident = tuple(id(t) for t in cur)
+            if st.planes_state[half] != ident:
+                none = [None] * len(cur)
+                st.program.set_planes(none if half else cur, cur if half else none)
+                st.planes_state[True], st.planes_state[False] = (ident, None) if half else (None, ident)
         first = getattr(st.convs[0].kernel, "_taseg_grad_dest", None)
         if st.dest_state is not first:
             dests = []
@@ -272,13 +294,13 @@ class StagePrograms:
                           getattr(bn.bias, "_taseg_grad_dest", None)]
             st.program.set_grad_dests(dests)
             st.dest_state = first
+        return stream
 
     def run(self, name, inputs, plan, training):
         st = self.stages[name]
         half = spF._amp_half(inputs[0])
         geom = self.geometry(name, plan, half)
-        self._refresh(st, half)
-        stream = B.L.stream()
+        stream = self._refresh(st, half)
         if not training:
             return self.fast.stage_run_eval(list(inputs), st.program, geom, half, stream)
         comm, group_id = 0, -1

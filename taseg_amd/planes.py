@@ -18,17 +18,11 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["planes_for", "half_for", "exps_for", "invalidate", "eligible", "eligible_half", "hint", "stats"]
+__all__ = ["planes_for", "half_for", "invalidate", "eligible", "eligible_half", "hint", "stats"]
 
 _ENABLED = os.environ.get("TASEG_PRESPLIT", "1") != "0"
 _entries = {}          # id(weight) -> _Entry (bf16 planes of the fp32 kernels)
 _half_entries = {}     # id(weight) -> _Entry (IEEE-half copy for the half-storage kernels)
-_exp_entries = {}      # id(weight) -> _Entry (per-offset exponents for the three-product class kernels)
-# three IEEE-half MFMAs per fp32 product in the class-sorted kernels (csrc/conv_class.hip, XF), TASEG_CLASS_X=1.  Off by default: it
-# is closer to float64 than the six-product bf16 split at operator level and worth 1-1.5 % of the fp32 step
-# (profiles/r04_ab_class_x.txt), but another rounding moves which ReLUs flip against the reference, and with them the model-level
-# gradient comparison by more than the gain is worth
-_CLASS_X = os.environ.get("TASEG_CLASS_X", "0") == "1"
 _epoch = 0
 stats = {"refreshes": 0, "launch_batches": 0}
 
@@ -41,10 +35,9 @@ class TsPlaneJob(ctypes.Structure):
 class _Entry:
     __slots__ = ("ref", "planes", "ptr", "version", "epoch", "stream")
 
-    def __init__(self, weight, half=False, exps=False):
+    def __init__(self, weight, half=False):
         self.ref = weakref.ref(weight)
-        self.planes = (torch.empty(weight.shape[0], dtype=torch.int32, device=weight.device) if exps else
-                       torch.empty(weight.shape, dtype=torch.float16, device=weight.device) if half else
+        self.planes = (torch.empty(weight.shape, dtype=torch.float16, device=weight.device) if half else
                        torch.empty(3 * weight.numel(), dtype=torch.int16, device=weight.device))
         self.ptr = self.version = self.epoch = self.stream = None
 
@@ -142,24 +135,6 @@ def half_for(weight):
         e = _half_entries[id(weight)] = _Entry(weight, half=True)
     if not e.fresh(weight, stream):
         _refresh(stream, weight.device, _half_entries, "ts_cast_weights_f16_batch")
-    return e.planes
-
-
-def exps_for(weight):
-    """Per-offset exponents [K] int32 of an fp32 convolution weight (max |W_k| 2^e in [2^14, 2^15)) for the three-product class
-    kernels, in step with the weight on the current stream (all stale weights of the model in one batch of launches); None when
-    the mechanism is off or does not apply."""
-    if not (_CLASS_X and _ENABLED and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 3
-            and weight.is_contiguous() and weight.shape[0] <= 27 and weight.shape[1] % 32 == 0 and weight.shape[2] % 32 == 0):
-        return None
-    if weight.device.index != torch.cuda.current_device():
-        return None
-    stream = L.stream()
-    e = _exp_entries.get(id(weight))
-    if e is None or e.ref() is not weight or e.planes.device != weight.device or e.planes.numel() != weight.shape[0]:
-        e = _exp_entries[id(weight)] = _Entry(weight, exps=True)
-    if not e.fresh(weight, stream):
-        _refresh(stream, weight.device, _exp_entries, "ts_conv_weight_exponents_batch")
     return e.planes
 
 

@@ -822,13 +822,12 @@ _COMM_PRE, _COMM_POST = _ctypes.c_void_p(1), _ctypes.c_void_p(2)      # split-ca
 from ...rccl import c10d_sum as _c10d_sum  # noqa: E402
 
 
-def _block_opts(plan_f, plan_d, planes, w16_current, addend, w_exp=None, natural=False):
+def _block_opts(plan_f, plan_d, planes, w16_current, addend, natural=False):
     """TsConvBlockOpts of one block call (the struct only holds pointers: the caller keeps the tensors alive over the call)"""
     LB = B.L
     pf = None if plan_f is None else _ctypes.pointer(B.class_plan_struct(plan_f))
     pd = None if plan_d is None else _ctypes.pointer(B.class_plan_struct(plan_d))
-    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend), None, None, 0, 0, 0, LB.ptr(w_exp),
-                              1 if natural else 0)
+    return LB.TsConvBlockOpts(pf, pd, LB.ptr(planes), 1 if w16_current else 0, LB.ptr(addend), None, None, 0, 0, 0, 1 if natural else 0)
 
 
 def _kcc(weight):
@@ -874,12 +873,7 @@ class _ConvBlock(Function):
         # THIS kernel map (large submanifold maps: class-sorted implicit GEMM; 2x2x2 maps: direct one-pass plans), the pre-split
         # planes / the kept half copy of the weight
         plan_f, plan_d = kmap.plans_for(transposed, c_in, c_out, half)
-        # per-offset exponents of the parameter: the fp32 class products on three half MFMAs (planes.exps_for)
-        wexp = None
-        if not half and (plan_f is not None or plan_d is not None) and w32.data_ptr() == weight.data_ptr():
-            wexp = _planes.exps_for(weight)
-        ctx.wexp = wexp
-        opts = _block_opts(plan_f, plan_d, None if half else planes, half and planes is not None, None, wexp, natural)
+        opts = _block_opts(plan_f, plan_d, None if half else planes, half and planes is not None, None, natural)
 
         def call(c):
             L.check(lib.ts_conv_block_forward(
@@ -943,8 +937,7 @@ class _ConvBlock(Function):
         ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
 
         addend = grad_pass.contiguous().to(dt) if (grad_pass is not None and grad_feat is not None) else None
-        opts = _block_opts(None, ctx.plan_d if grad_feat is not None else None, None if half else ctx.planes, False, addend,
-                           None if half else ctx.wexp, ctx.natural)
+        opts = _block_opts(None, ctx.plan_d if grad_feat is not None else None, None if half else ctx.planes, False, addend, ctx.natural)
 
         def call(c):
             L.check(lib.ts_conv_block_backward(
@@ -987,8 +980,7 @@ def conv_block_eval(feats, weight, residual, bn_weight, bn_bias, mean, invstd, k
     total = kmap.total
     ws = L.workspace(lib.ts_conv_block_workspace_bytes(total, max(n_in, n_out), c_in, c_out, k, 1 if half else 0), dev)
     plan_f, _ = kmap.plans_for(transposed, c_in, c_out, half)
-    wexp = _planes.exps_for(weight) if (not half and plan_f is not None and w32.data_ptr() == weight.data_ptr()) else None
-    opts = _block_opts(plan_f, None, None if half else planes, half and planes is not None, None, wexp, weight.dim() == 2)
+    opts = _block_opts(plan_f, None, None if half else planes, half and planes is not None, None, weight.dim() == 2)
     L.check(lib.ts_conv_block_eval(
         L.ptr(x), x.shape[0], c_in, L.ptr(w32), k, L.ptr(kmap.nbmaps_buf), L.ptr(kmap.nboffs), total, gcol, L.ptr(table), rows,
         c_out, L.ptr(res), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(mean), L.ptr(invstd), 1 if relu else 0, 1 if half else 0,

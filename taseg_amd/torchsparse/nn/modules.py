@@ -209,7 +209,7 @@ def _pointwise_bn_act(conv, mod, input: SparseTensor, relu, residual):
         if fast is not None:
             out = fast.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod),
                                        imap.nbmaps_buf, imap.nboffs, n, imap.pos_out, imap.pos_in, n, n, False, relu, half,
-                                       _B.L.stream(), w16, [], [], None, True)
+                                       _B.L.stream(), w16, [], [], True)
         else:
             out = F.conv_block_eval(feats, conv.kernel, res, mod.weight, mod.bias, mod.running_mean, _eval_invstd(mod), imap,
                                     False, relu, half, w16)
@@ -232,7 +232,7 @@ def _pointwise_bn_act(conv, mod, input: SparseTensor, relu, residual):
                           mod.num_batches_tracked if track else None, float(mod.momentum), float(mod.eps), relu,
                           (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), w16, False,
                           _claim_grad_dest(conv.kernel), _group_id(fast, group if (group is not None and comm is None) else None),
-                          [], [], [], [], conv.kernel.grad is None, None, True)
+                          [], [], [], [], conv.kernel.grad is None, True)
     return input._like(out[0])
 
 
@@ -278,8 +278,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                 plan_f, _ = kmap.plans_for(transposed, kernel.shape[1], kernel.shape[2], half)
                 out = fast.conv_block_eval(feats, kernel, res, bn_w, bn_b, rmean, _eval_invstd(mod),
                                            kmap.nbmaps_buf, kmap.nboffs, kmap.total, kmap.pos_out, kmap.pos_in, n_in, n_out,
-                                           transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f),
-                                           None if (half or plan_f is None) else _planes.exps_for(kernel), False)
+                                           transposed, relu, half, _B.L.stream(), planes, *_plan_args(plan_f), False)
             else:
                 out = F.conv_block_eval(feats, kernel, res, bn_w, bn_b, rmean, _eval_invstd(mod), kmap,
                                         transposed, relu, half, planes)
@@ -322,10 +321,7 @@ def conv_bn_act(conv: "Conv3d", mod, input: SparseTensor, relu: bool = True, res
                                       state[1], state[2], float(momentum), float(eps), relu,
                                       (comm.value or 0) if comm is not None else 0, half, _B.L.stream(), planes,
                                       bool(passthrough), dest, _group_id(fast, c10d_group), *_plan_args(plan_f), *_plan_args(plan_d),
-                                      kernel.grad is None,
-                                      # per-offset weight exponents: the fp32 class products on three half MFMAs (planes.exps_for)
-                                      None if (half or (plan_f is None and plan_d is None)) else _planes.exps_for(kernel),
-                                      False)
+                                      kernel.grad is None, False)
                 out, passed = (out[0], out[1]) if passthrough else (out[0], None)
             else:
                 out = F._ConvBlock.apply(feats, kernel, res, bn_w, bn_b, kmap, transposed, state,

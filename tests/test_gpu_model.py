@@ -952,8 +952,8 @@ def test_block_backward_launches_its_weight_gradient_on_a_second_stream_itself(m
     state = {"on": False, "slot": 0, "used": 0}
     plain = F._block_opts
 
-    def opts_with_side(plan_f, plan_d, planes, w16_current, addend, w_exp=None, natural=False):
-        o = plain(plan_f, plan_d, planes, w16_current, addend, w_exp, natural)
+    def opts_with_side(plan_f, plan_d, planes, w16_current, addend, natural=False):
+        o = plain(plan_f, plan_d, planes, w16_current, addend, natural)
         if state["on"] and plan_f is None:              # a backward call (the forward passes its forward plan or builds none: see below)
             slot = state["slot"] = (state["slot"] + 1) % 8
             o.wgrad_stream, o.wgrad_ws, o.wgrad_ws_bytes, o.wgrad_slot = side.cuda_stream, ring[slot].data_ptr(), ring[slot].numel(), slot

@@ -686,12 +686,11 @@ def test_new_entry_points_accept_empty_inputs(B):
     g = B.devoxelize_backward_runs(torch.empty((0, 32), device=dev), idx, w, 10, None)
     assert g.shape == (10, 32) and float(g.abs().sum()) == 0.0
     feat = torch.randn(2, 8, 4, 6, device=dev)
-    out, err = B.image_gather_forward(feat, torch.empty((0, 2), device=dev), torch.empty(0, dtype=torch.int32, device=dev),
-                                      torch.tensor([2], dtype=torch.int32, device=dev), 4, 6)
-    assert out.shape == (0, 8) and int(err) == 0
-    gf = B.image_gather_backward(torch.empty((0, 8), device=dev), torch.empty((0, 2), device=dev),
-                                 torch.empty(0, dtype=torch.int32, device=dev),
-                                 torch.tensor([2], dtype=torch.int32, device=dev), 2, 4, 6)
+    plan = B.image_plan(torch.empty((0, 2), device=dev), torch.empty(0, dtype=torch.int32, device=dev),
+                        torch.tensor([2], dtype=torch.int32, device=dev), 2, 4, 6)
+    out = B.image_gather_forward(feat, plan)
+    assert out.shape == (0, 8) and int(plan["err"]) == 0
+    gf = B.image_gather_backward(torch.empty((0, 8), device=dev), plan, 8)
     assert gf.shape == (2, 8, 4, 6) and float(gf.abs().sum()) == 0.0
     # no pairs at all: an isolated voxel convolved with a kernel whose centre is the only hit still works; a rulebook
     # with zero pairs yields zeros

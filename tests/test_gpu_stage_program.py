@@ -183,3 +183,57 @@ def test_stage_program_falls_back_where_it_does_not_apply():
     model.stage3[1].net[1].eval()                     # one BatchNorm on its running statistics inside a training model
     ret, _, _ = model(make())
     assert torch.isfinite(ret["loss"])
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+@pytest.mark.parametrize("half,probs", [(False, False), (True, False), (False, True)])
+def test_fused_evaluation_tail_equals_the_sorted_form(grouped, half, probs):
+    """csrc/evaltail.hip (rows per scene + gather + arg-max, two launches) against the tensor form with its three stable sorts
+    (minkunet.py:435-455): the same dictionary of arrays; a batch whose index arrays are NOT grouped by scene is detected on the
+    device and served by the sorted form; an inverse map outside its scene raises like the reference's indexing"""
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.minkunet import unvoxelise_predictions
+    from taseg_amd.torchsparse import SparseTensor
+    g = torch.Generator().manual_seed(3)
+    n_scenes, classes = 3, 20
+    vox_counts, pt_counts = [5000, 7000, 3000], [9000, 12000, 4000]
+    b_vox = torch.cat([torch.full((c,), b, dtype=torch.int32) for b, c in enumerate(vox_counts)])
+    b_pts = torch.cat([torch.full((c,), b, dtype=torch.int32) for b, c in enumerate(pt_counts)])
+    inv = torch.cat([torch.randint(0, vox_counts[b], (c,), generator=g) for b, c in enumerate(pt_counts)])
+    labels = torch.randint(0, classes, (sum(pt_counts),), generator=g)
+    if not grouped:
+        perm_v, perm_p = torch.randperm(len(b_vox), generator=g), torch.randperm(len(b_pts), generator=g)
+        # a permuted voxel order changes which row a scene-local index names: remap the inverse map accordingly
+        rank = torch.empty_like(perm_v)
+        for b in range(n_scenes):
+            sel = (b_vox[perm_v] == b).nonzero().view(-1)           # positions (new order) of scene b's voxels, ascending
+            old_local = perm_v[sel] - sum(vox_counts[:b])
+            rank_b = torch.empty(vox_counts[b], dtype=torch.long)
+            rank_b[old_local] = torch.arange(len(sel))
+            rank[sum(vox_counts[:b]):sum(vox_counts[:b + 1])] = rank_b
+        inv = torch.cat([rank[sum(vox_counts[:b]):sum(vox_counts[:b + 1])][inv[sum(pt_counts[:b]):sum(pt_counts[:b + 1])]]
+                         for b in range(n_scenes)])
+        b_vox, b_pts, inv, labels = b_vox[perm_v], b_pts[perm_p], inv[perm_p], labels[perm_p]
+    out = torch.randn(len(b_vox), classes, generator=g)
+    if not grouped:
+        out = out          # rows follow the (permuted) voxel order by construction of `rank`
+    out = (out.half() if half else out).cuda()
+    cv = torch.zeros((len(b_vox), 4), dtype=torch.int32)
+    cv[:, 3] = b_vox
+    cp = torch.zeros((len(b_pts), 4), dtype=torch.int32)
+    cp[:, 3] = b_pts
+    invs = SparseTensor(inv.cuda(), cp.cuda())
+    labs = SparseTensor(labels.cuda(), cp.cuda())
+    num_points = torch.tensor([c - 7 for c in pt_counts])          # the scans' own point counts trim the arrays
+    names = [f"s{b}" for b in range(n_scenes)]
+    a = unvoxelise_predictions(out, cv.cuda()[:, -1], invs, labs, num_points, probs, names=names, _fused=True)
+    b = unvoxelise_predictions(out, cv.cuda()[:, -1], invs, labs, num_points, probs, names=names, _fused=False)
+    assert a["name"] == b["name"]
+    for key in ("point_predict", "point_labels", "point_predict_logits"):
+        assert len(a[key]) == len(b[key])
+        for x, y in zip(a[key], b[key]):
+            assert x.shape == y.shape and np.array_equal(x, y), key
+    if grouped:
+        bad = inv.clone()
+        bad[5] = vox_counts[0] + 3
+        with pytest.raises(IndexError):
+            unvoxelise_predictions(out, cv.cuda()[:, -1], SparseTensor(bad.cuda(), cp.cuda()), labs, num_points, probs, names=names)

@@ -23,6 +23,7 @@ lo, hi = marks[-steps - 1], marks[-1]
 rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
 window = (hi - lo) / 1e6
 print(f"{steps} steps, window {window:.2f} ms = {window / steps:.3f} ms per step (under the profiler), {len(rows) / steps:.0f} launches per step")
+print(f"LAUNCHES_PER_STEP {len(rows) / steps:.1f}")
 qs = defaultdict(list)
 for s, e, q, n in rows:
     qs[q].append((s, e))
