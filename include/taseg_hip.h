@@ -160,6 +160,10 @@ int ts_unique_i64(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *invers
  *   nbsizes  [K] int32        : hits per offset (== conv.py:168);
  *   nboffs   [K+1] int32      : exclusive prefix of nbsizes (nboffs[K] = P). */
 size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int32_t n_offsets);
+/*   ts_build_kmap_sym: the same tables, bit for bit, for a SUBMANIFOLD map (one coordinate set, K odd, offsets[K - 1 - k] =
+ *   -offsets[k]: get_kernel_offsets of an odd kernel, nn/utils/kernel.py:11-32) on HALF the probes - offset k of voxel j finding r is
+ *   offset K - 1 - k of r finding j.  Needs unique coordinates; a duplicate is detected on the device: nboffs[K] then reads -1 and
+ *   the caller builds the map with ts_build_kmap.  Workspace: ts_build_kmap_workspace_bytes(n, n, K). */
 /*   pos_out  [K, n_out] int32 : row of nbmaps holding the pair (k, j), or -1  (may be NULL);
  *   pos_in   [K, n_in]  int32 : row of nbmaps holding the pair of input i at offset k, or -1 (may be NULL). */
 int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords,
@@ -167,6 +171,8 @@ int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coo
                   int32_t *nbr_t, int32_t *nbmaps, int32_t *nbsizes, int32_t *nboffs,
                   int32_t *pos_out, int32_t *pos_in, void *ws, size_t ws_bytes,
                   ts_stream_t stream);
+int ts_build_kmap_sym(const int32_t *coords, int64_t n, const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t, int32_t *nbmaps,
+                      int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws, size_t ws_bytes, ts_stream_t stream);
 
 /* Neighbour table from an explicit rulebook (the reference-form entry points
  * above go through this): nbr[k, col_out] = col_in for every pair of offset k.

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ts_unique_i64": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_build_kmap_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "ts_build_kmap": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_build_kmap_sym": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_nbr_from_nbmaps": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "ts_trilinear_workspace_bytes": (_sz, [_i64]),
     "ts_trilinear_map": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -142,7 +142,7 @@ __device__ __forceinline__ void ts_table_find_n(const TsTable &t, const unsigned
 // One launch that fills up to TS_FILL_MAX buffers with a 32-bit pattern each (pointers 4-byte aligned, sizes multiples of
 // 4 bytes; empty segments are skipped) - the index-plan builders clear their tables and counters with it instead of one
 // hipMemsetAsync per buffer.
-#define TS_FILL_MAX 6
+#define TS_FILL_MAX 8
 struct TsFillSeg {
   void *p;
   size_t bytes;

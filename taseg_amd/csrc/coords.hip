@@ -273,12 +273,70 @@ __global__ __launch_bounds__(KM_BLOCK) void kmap_probe_kernel(TsTable t, const i
   for (int k = threadIdx.x; k < K; k += KM_BLOCK) blk_counts[(int64_t)k * nblk + blockIdx.x] = lds_cnt[k];
 }
 
+// Submanifold maps (in == out, unique coordinates, offsets[K - 1 - k] == -offsets[k]: nn/utils/kernel.py:11-32 enumerates an odd
+// volume that way): offset k of voxel j finding r IS offset K - 1 - k of voxel r finding j.  Every thread probes the first half of
+// the offsets and the centre (14 look-ups instead of 27) and stores the mirrored entry nbr[K - 1 - k][r] = j beside its own - one
+// writer per entry, since r's neighbour at that offset is unique; the mirrored half was filled with -1 before.  The centre probe
+// must return j itself: anything else is a duplicated coordinate, for which the symmetry does not hold - *dup is set and the caller
+// builds the map with the full probe.
+__global__ __launch_bounds__(KM_BLOCK) void kmap_probe_sym_kernel(TsTable t, const int4 *__restrict__ coords, int64_t n,
+                                                                 const int *__restrict__ offsets, int K, int *__restrict__ nbr,
+                                                                 unsigned *__restrict__ blk_counts, int nblk, int *__restrict__ dup) {
+  constexpr int KM_MLP = 9;
+  extern __shared__ unsigned lds_cnt[];
+  const int half = K / 2;
+  for (int k = threadIdx.x; k <= half; k += KM_BLOCK) lds_cnt[k] = 0;
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+  const bool valid = j < n;
+  const int4 c = valid ? coords[j] : make_int4(0, 0, 0, 0);
+  for (int k0 = 0; k0 <= half; k0 += KM_MLP) {
+    unsigned long long want[KM_MLP];
+    int r[KM_MLP];
+#pragma unroll
+    for (int i = 0; i < KM_MLP; ++i) {
+      const int k = min(k0 + i, half);
+      want[i] = ts_fnv60(c.x + offsets[3 * k], c.y + offsets[3 * k + 1], c.z + offsets[3 * k + 2], c.w);
+    }
+    ts_table_find_n<KM_MLP>(t, want, valid, r);
+#pragma unroll
+    for (int i = 0; i < KM_MLP; ++i) {
+      const int k = k0 + i;
+      if (k <= half) {                                            // (uniform)
+        if (valid) {
+          nbr[(int64_t)k * n + j] = r[i];
+          if (k < half && r[i] >= 0) nbr[(int64_t)(K - 1 - k) * n + r[i]] = (int)j;
+          if (k == half && r[i] != (int)j) *dup = 1;
+        }
+        unsigned long long m = __ballot(valid && r[i] >= 0);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&lds_cnt[k], (unsigned)__popcll(m));
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= half; k += KM_BLOCK) blk_counts[(int64_t)k * nblk + blockIdx.x] = lds_cnt[k];
+}
+
+// hits per (offset, block of 256 rows) of the mirrored half, counted from the table (grid (nblk, K / 2))
+__global__ __launch_bounds__(KM_BLOCK) void kmap_count_kernel(const int *__restrict__ nbr, int64_t n, int K,
+                                                             unsigned *__restrict__ blk_counts, int nblk) {
+  __shared__ unsigned wave_cnt[KM_BLOCK / 64];
+  const int k = K / 2 + 1 + (int)blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+  const bool hit = j < n && nbr[(int64_t)k * n + j] >= 0;
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_counts[(int64_t)k * nblk + blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
 __global__ void kmap_sizes_kernel(const unsigned *__restrict__ blk_offs, int K, int nblk, int *__restrict__ nbsizes,
-                                  int *__restrict__ nboffs) {
+                                  int *__restrict__ nboffs, const int *__restrict__ dup) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k <= K) {
     unsigned o = blk_offs[(int64_t)k * nblk];
-    if (nboffs) nboffs[k] = (int)o;
+    // (symmetric builder: a duplicated coordinate voids the map - the pair total reads -1 and the caller probes in full)
+    if (nboffs) nboffs[k] = (k == K && dup && *dup) ? -1 : (int)o;
     if (k < K && nbsizes) nbsizes[k] = (int)(blk_offs[(int64_t)(k + 1) * nblk] - o);
   }
 }
@@ -315,13 +373,13 @@ __global__ __launch_bounds__(KM_BLOCK) void kmap_compact_kernel(const int *__res
 extern "C" size_t ts_build_kmap_workspace_bytes(int64_t n_in, int64_t n_out, int32_t K) {
   int64_t nblk = ts_cdiv(n_out < 1 ? 1 : n_out, KM_BLOCK);
   size_t cnt = ts_align_up(((size_t)K * nblk + 1) * 4, 256);
-  return ts_table_bytes(n_in < 0 ? 0 : n_in) + 2 * cnt + ts_align_up(cnt + (1u << 20), 256);
+  return ts_table_bytes(n_in < 0 ? 0 : n_in) + 2 * cnt + ts_align_up(cnt + (1u << 20), 256) + 256;      // (+ the symmetric builder's flag)
 }
 
-extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords, int64_t n_out,
-                             const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t, int32_t *nbmaps,
-                             int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws,
-                             size_t ws_bytes, ts_stream_t stream_) {
+static int build_kmap_impl(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords, int64_t n_out,
+                           const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t, int32_t *nbmaps,
+                           int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws,
+                           size_t ws_bytes, ts_stream_t stream_, bool sym) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(n_in >= 0 && n_out >= 0 && K > 0 && K <= 4096, TS_ERR_INVALID_ARGUMENT, "ts_build_kmap: bad sizes");
   TS_REQUIRE(n_in < (1LL << 30) && n_out < (1LL << 30) && (int64_t)K * n_out < (1LL << 31), TS_ERR_UNSUPPORTED,
@@ -344,23 +402,37 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
   size_t cnt_bytes = ts_align_up(n_cnt * 4, 256);
   size_t used = ts_table_bytes(n_in);
   TS_REQUIRE(used <= ws_bytes, TS_ERR_WORKSPACE_TOO_SMALL, "ts_build_kmap: workspace too small");
-  // table keys / values, the two inverse tables and the closing element of the per-block counts: ONE fill launch
-  const TsFillSeg extra[3] = {inverse[0], inverse[1], {(unsigned *)((char *)ws + used) + (n_cnt - 1), 4, 0u}};
-  int rc = ts_table_init(&t, n_in, ws, ws_bytes, stream, &used, extra, 3);
+  // table keys / values, the two inverse tables and the closing element of the per-block counts: ONE fill launch (symmetric
+  // builder: + the mirrored half of nbr, which only hits write, + the duplicate flag, kept in the last word of the scan scratch)
+  const int half = K / 2;
+  // (the flag sits in the last 256 bytes of what ts_build_kmap_workspace_bytes asks for, behind the scan's scratch)
+  const size_t flag_at = ts_build_kmap_workspace_bytes(n_in, n_out, K) - 256;
+  int *dup = sym ? (int *)((char *)ws + flag_at) : nullptr;
+  const TsFillSeg extra[5] = {inverse[0], inverse[1], {(unsigned *)((char *)ws + used) + (n_cnt - 1), 4, 0u},
+                              {nbr + (size_t)(half + 1) * n_out, (size_t)half * n_out * 4, 0xFFFFFFFFu}, {dup, 4, 0u}};
+  int rc = ts_table_init(&t, n_in, ws, ws_bytes, stream, &used, extra, sym ? 5 : 3);
   if (rc != TS_OK) return rc;
   unsigned *blk_counts = (unsigned *)((char *)ws + used);
   unsigned *blk_offs = (unsigned *)((char *)ws + used + cnt_bytes);
   void *tmp = (char *)ws + used + 2 * cnt_bytes;
-  size_t tmp_bytes = ws_bytes - used - 2 * cnt_bytes;
+  size_t tmp_bytes = (sym ? flag_at : ws_bytes) - used - 2 * cnt_bytes;
 
   if (n_in > 0) {
     int grid = (int)std::min<int64_t>(ts_cdiv(n_in, 256), 4096);
     table_insert_coords_kernel<<<grid, 256, 0, stream>>>(t, (const int4 *)in_coords, n_in);
     TS_CHECK_LAUNCH("ts_build_kmap/insert");
   }
-  kmap_probe_kernel<<<nblk, KM_BLOCK, (size_t)K * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
-                                                               blk_counts, nblk);
-  TS_CHECK_LAUNCH("ts_build_kmap/probe");
+  if (sym) {
+    kmap_probe_sym_kernel<<<nblk, KM_BLOCK, (size_t)(half + 1) * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
+                                                                              blk_counts, nblk, dup);
+    TS_CHECK_LAUNCH("ts_build_kmap_sym/probe");
+    kmap_count_kernel<<<dim3(nblk, half), KM_BLOCK, 0, stream>>>(nbr, n_out, K, blk_counts, nblk);
+    TS_CHECK_LAUNCH("ts_build_kmap_sym/count");
+  } else {
+    kmap_probe_kernel<<<nblk, KM_BLOCK, (size_t)K * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
+                                                                 blk_counts, nblk);
+    TS_CHECK_LAUNCH("ts_build_kmap/probe");
+  }
   if (!nbmaps && !nbr_t && !nbsizes && !nboffs && !pos_out && !pos_in) return TS_OK;
   size_t need = 0;
   TS_CHECK_HIP(rocprim::exclusive_scan(nullptr, need, blk_counts, blk_offs, 0u, n_cnt, rocprim::plus<unsigned>(), stream),
@@ -368,7 +440,7 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
   TS_REQUIRE(need <= tmp_bytes, TS_ERR_WORKSPACE_TOO_SMALL, "ts_build_kmap: scan scratch %zu > %zu", need, tmp_bytes);
   TS_CHECK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, blk_counts, blk_offs, 0u, n_cnt, rocprim::plus<unsigned>(), stream),
                "scan");
-  kmap_sizes_kernel<<<(int)ts_cdiv(K + 1, 256), 256, 0, stream>>>(blk_offs, K, nblk, nbsizes, nboffs);
+  kmap_sizes_kernel<<<(int)ts_cdiv(K + 1, 256), 256, 0, stream>>>(blk_offs, K, nblk, nbsizes, nboffs, dup);
   TS_CHECK_LAUNCH("ts_build_kmap/sizes");
   if (nbmaps || nbr_t || pos_out || pos_in) {
     dim3 grid(nblk, K);
@@ -377,6 +449,25 @@ extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32
     TS_CHECK_LAUNCH("ts_build_kmap/compact");
   }
   return TS_OK;
+}
+
+extern "C" int ts_build_kmap(const int32_t *in_coords, int64_t n_in, const int32_t *out_coords, int64_t n_out,
+                             const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t, int32_t *nbmaps,
+                             int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws,
+                             size_t ws_bytes, ts_stream_t stream) {
+  return build_kmap_impl(in_coords, n_in, out_coords, n_out, offsets, K, nbr, nbr_t, nbmaps, nbsizes, nboffs, pos_out, pos_in, ws,
+                         ws_bytes, stream, false);
+}
+
+// ts_build_kmap for a SUBMANIFOLD map (one coordinate set, odd K, offsets[K - 1 - k] == -offsets[k]: conv.py:156-176 with
+// kernel_size odd and stride 1) on half the probes; same tables, bit for bit.  Precondition the call checks on the device:
+// UNIQUE coordinates - otherwise nboffs[K] reads -1 (nothing else is meaningful) and the caller falls back to ts_build_kmap.
+extern "C" int ts_build_kmap_sym(const int32_t *coords, int64_t n, const int32_t *offsets, int32_t K, int32_t *nbr, int32_t *nbr_t,
+                                 int32_t *nbmaps, int32_t *nbsizes, int32_t *nboffs, int32_t *pos_out, int32_t *pos_in, void *ws,
+                                 size_t ws_bytes, ts_stream_t stream) {
+  TS_REQUIRE(K > 1 && (K & 1) && nboffs && nbr && n > 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_build_kmap_sym: an odd number of offsets > 1, rows and the nbr / nboffs outputs are required");
+  return build_kmap_impl(coords, n, coords, n, offsets, K, nbr, nbr_t, nbmaps, nbsizes, nboffs, pos_out, pos_in, ws, ws_bytes, stream, true);
 }
 
 // ------------------------------------------------------------------ nbr from an explicit rulebook

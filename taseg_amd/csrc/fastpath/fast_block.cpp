@@ -39,6 +39,7 @@ struct Api {
   decltype(&ts_downsample) downsample = nullptr;
   decltype(&ts_build_kmap_workspace_bytes) build_kmap_ws = nullptr;
   decltype(&ts_build_kmap) build_kmap = nullptr;
+  decltype(&ts_build_kmap_sym) build_kmap_sym = nullptr;
   decltype(&ts_trilinear_workspace_bytes) trilinear_ws = nullptr;
   decltype(&ts_trilinear_map) trilinear_map = nullptr;
   decltype(&ts_devox_order_workspace_bytes) devox_order_ws = nullptr;
@@ -503,6 +504,7 @@ void load_backend(const std::string &libpath) {
   TS_BIND(downsample, "ts_downsample");
   TS_BIND(build_kmap_ws, "ts_build_kmap_workspace_bytes");
   TS_BIND(build_kmap, "ts_build_kmap");
+  TS_BIND(build_kmap_sym, "ts_build_kmap_sym");
   TS_BIND(trilinear_ws, "ts_trilinear_workspace_bytes");
   TS_BIND(trilinear_map, "ts_trilinear_map");
   TS_BIND(devox_order_ws, "ts_devox_order_workspace_bytes");
@@ -632,7 +634,9 @@ struct Kmap {
   int64_t n_in = 0, n_out = 0;
 };
 
-Kmap make_kmap(const at::Tensor &in_c, const at::Tensor &out_c, const at::Tensor &offsets, int64_t stream) {
+// sym: a submanifold map (in_c IS out_c, odd symmetric offsets) on half the probes (ts_build_kmap_sym); its pair total reads -1 if
+// the coordinates hold a duplicate - index_plan then calls again with sym = false
+Kmap make_kmap(const at::Tensor &in_c, const at::Tensor &out_c, const at::Tensor &offsets, int64_t stream, bool sym = false) {
   Kmap km;
   km.n_in = in_c.size(0);
   km.n_out = out_c.size(0);
@@ -645,12 +649,19 @@ Kmap make_kmap(const at::Tensor &in_c, const at::Tensor &out_c, const at::Tensor
   km.pos_out = at::empty({k, km.n_out}, o);
   km.pos_in = at::empty({k, km.n_in}, o);
   at::Tensor ws = workspace(api.build_kmap_ws(km.n_in, km.n_out, (int32_t)k), in_c, stream);
-  check(api.build_kmap((const int32_t *)in_c.data_ptr(), km.n_in, (const int32_t *)out_c.data_ptr(), km.n_out,
-                       (const int32_t *)offsets.data_ptr(), (int32_t)k, (int32_t *)km.nbr.data_ptr(), nullptr,
-                       (int32_t *)km.nbmaps.data_ptr(), (int32_t *)km.nbsizes.data_ptr(), (int32_t *)km.nboffs.data_ptr(),
-                       (int32_t *)km.pos_out.data_ptr(), (int32_t *)km.pos_in.data_ptr(), ws.data_ptr(), (size_t)ws.numel(),
-                       (ts_stream_t)stream),
-        "ts_build_kmap");
+  if (sym && km.n_out > 0)
+    check(api.build_kmap_sym((const int32_t *)in_c.data_ptr(), km.n_in, (const int32_t *)offsets.data_ptr(), (int32_t)k,
+                             (int32_t *)km.nbr.data_ptr(), nullptr, (int32_t *)km.nbmaps.data_ptr(), (int32_t *)km.nbsizes.data_ptr(),
+                             (int32_t *)km.nboffs.data_ptr(), (int32_t *)km.pos_out.data_ptr(), (int32_t *)km.pos_in.data_ptr(),
+                             ws.data_ptr(), (size_t)ws.numel(), (ts_stream_t)stream),
+          "ts_build_kmap_sym");
+  else
+    check(api.build_kmap((const int32_t *)in_c.data_ptr(), km.n_in, (const int32_t *)out_c.data_ptr(), km.n_out,
+                         (const int32_t *)offsets.data_ptr(), (int32_t)k, (int32_t *)km.nbr.data_ptr(), nullptr,
+                         (int32_t *)km.nbmaps.data_ptr(), (int32_t *)km.nbsizes.data_ptr(), (int32_t *)km.nboffs.data_ptr(),
+                         (int32_t *)km.pos_out.data_ptr(), (int32_t *)km.pos_in.data_ptr(), ws.data_ptr(), (size_t)ws.numel(),
+                         (ts_stream_t)stream),
+          "ts_build_kmap");
   return km;
 }
 
@@ -674,13 +685,14 @@ index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num
   py::gil_scoped_release nogil;
   at::NoGradGuard nograd;
   at::Tensor coords = coords_in.contiguous(), points = points_in.contiguous();
+  static const bool sym_probe = !(getenv("TASEG_KMAP_SYM") && atoi(getenv("TASEG_KMAP_SYM")) == 0);
   std::vector<at::Tensor> cmaps;
   std::vector<Kmap> sub, down;
   cmaps.push_back(coords);
   int stride = 1;
   for (int64_t level = 0; level <= num_levels; ++level) {
     const at::Tensor &cur = cmaps.back();
-    sub.push_back(make_kmap(cur, cur, kernel_offsets(3, stride, cur), stream));
+    sub.push_back(make_kmap(cur, cur, kernel_offsets(3, stride, cur), stream, sym_probe));
     if (level == num_levels) break;
     // spdownsample(kernel 2, stride 2): unique strided coordinates, (b, x, y, z)-sorted; one host read (the count)
     const int64_t n = cur.size(0);
@@ -706,6 +718,13 @@ index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num
   }
   at::Tensor tot = at::cat(lasts).cpu();
   std::vector<int64_t> totals(tot.data_ptr<int>(), tot.data_ptr<int>() + tot.numel());
+  // a submanifold map whose coordinates hold a duplicate (the symmetric builder says so with a total of -1): the full probe
+  for (int64_t level = 0; level <= num_levels; ++level) {
+    if (totals[2 * level] >= 0) continue;
+    int st = 1 << level;
+    sub[level] = make_kmap(cmaps[level], cmaps[level], kernel_offsets(3, st, cmaps[level]), stream, false);
+    totals[2 * level] = sub[level].nboffs.narrow(0, sub[level].nboffs.size(0) - 1, 1).cpu().item<int>();
+  }
   // trilinear maps at strides 1, 16, 4 (+ the devoxelize-backward walk order of the coarse ones)
   std::vector<at::Tensor> tri_idx, tri_w, orders;
   const int64_t np = points.size(0);

@@ -247,13 +247,14 @@ class MinkUNetBackbone(BaseSegmentor):
                 nn.init.constant_(m.bias, 0)
 
     @staticmethod
-    def _index_plan(coords: torch.Tensor, point_coords: torch.Tensor, **extra):
+    def _index_plan(coords: torch.Tensor, point_coords: torch.Tensor, backward: bool = True, **extra):
         """Everything of a pass that depends on coordinates only - no features, no parameters: the
         coordinate set and kernel map of every stride (same `cmaps` / `kmaps` entries conv3d would create
         lazily, conv.py:144-177) and the trilinear point<->voxel maps `voxel_to_point` caches per stride
         (utils.py:72-82; the U-Net devoxelises at strides 1, 16 and 4).  Built before the first convolution
         so the host reads (voxel counts, pair totals) do not stall the launch stream mid-network; a data stage
-        may build it for the NEXT batch on another stream (`taseg_amd.data.stage.DevicePrefetcher`)."""
+        may build it for the NEXT batch on another stream (`taseg_amd.data.stage.DevicePrefetcher`).  backward=False (an
+        evaluation pass): without the walk orders of the devoxelize BACKWARD (three plans, one host read, ~25 launches)."""
         fast = _fast.module()
         if fast is not None and coords.is_cuda and coords.dtype == torch.int32 and point_coords.dtype == torch.float32:
             # native, interpreter-lock-free form of the block below (csrc/fastpath: same backend calls, same results)
@@ -268,17 +269,18 @@ class MinkUNetBackbone(BaseSegmentor):
                 s = 1 << lvl
                 km = spF.KernelMap(dict(zip(names, sub_t[lvl])), (cm[lvl].shape[0], cm[lvl].shape[0]))
                 km._total = int(totals[2 * lvl])
-                km.build_class_plan()                 # large maps: plan of the class-sorted implicit GEMM (csrc/conv_class.hip)
+                km.build_class_plan(defer=True)       # large maps: plan of the class-sorted implicit GEMM (csrc/conv_class.hip)
                 kmaps[((s, s, s), (3, 3, 3), (1, 1, 1), (1, 1, 1))] = km
                 if lvl < 4:
                     km = spF.KernelMap(dict(zip(names, down_t[lvl])), (cm[lvl].shape[0], cm[lvl + 1].shape[0]))
                     km._total = int(totals[2 * lvl + 1])
                     km.build_direct_plans()               # 2x2x2 strided map: one-pass plans of its two directions
                     kmaps[((s, s, s), (2, 2, 2), (2, 2, 2), (1, 1, 1))] = km
+            spF.accept_class_plans(list(kmaps.values()))       # ONE host read for the class plans of all levels
             keys = ((1, 1, 1), (16, 16, 16), (4, 4, 4))
             tri_idx, tri_w = dict(zip(keys, t_idx)), dict(zip(keys, t_w))
-            tri_order = {keys[1]: orders[0]} if _DEVOX_ATOMIC else {}
-            for key in (keys if not _DEVOX_ATOMIC else (keys[0], keys[2])):
+            tri_order = {keys[1]: orders[0]} if (_DEVOX_ATOMIC and backward) else {}
+            for key in ((keys if not _DEVOX_ATOMIC else (keys[0], keys[2])) if backward else ()):
                 plan = _coarse_devox_plan if key == keys[1] else B.devox_csr
                 tri_order[key] = plan(tri_idx[key], tri_w[key], cmaps[key].shape[0])
             return dict(coords=coords, point_coords=pc, cmaps=cmaps, kmaps=kmaps, tri_idx=tri_idx, tri_w=tri_w,
@@ -296,6 +298,8 @@ class MinkUNetBackbone(BaseSegmentor):
             for s in (1, 16, 4):
                 key = (s, s, s)
                 tri_idx[key], tri_w[key] = B.trilinear_map(pc, probe.cmaps[key], s)
+                if not backward:
+                    continue
                 # how the devoxelize backward walks this map: a gather along the inverse map, no atomics, fixed summation
                 # order (the whole training step is run-to-run deterministic).  TASEG_DEVOX_ATOMIC=1: stride 16 (~4 live
                 # corners, ~60 points per voxel) adds runs of points of one interpolation cell with float atomics instead,
@@ -643,7 +647,7 @@ class MinkUNet(MinkUNetBackbone):
         with torch.no_grad():
             z = PointTensor(None, batch_dict["lidar"].C.float())
             coords, vox_idx, vox_counts = voxelize_index(z, self.pres, self.vres)      # minkunet.py:388-390
-        plan = self._stage_prepare(self._index_plan(coords, z.C, vox_idx=vox_idx, vox_counts=vox_counts))
+        plan = self._stage_prepare(self._index_plan(coords, z.C, backward=self.training, vox_idx=vox_idx, vox_counts=vox_counts))
         batch_dict["_plan"] = plan
         return plan
 

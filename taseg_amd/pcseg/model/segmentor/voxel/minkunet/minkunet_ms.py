@@ -14,7 +14,7 @@ __all__ = ["MinkUNetMs"]
 class MinkUNetMs(MinkUNetBackbone):
     def prepare(self, batch_dict):
         x_ms = batch_dict["lidar_ms"]
-        plan = self._stage_prepare(self._index_plan(x_ms.C, x_ms.C.float()))
+        plan = self._stage_prepare(self._index_plan(x_ms.C, x_ms.C.float(), backward=self.training))
         batch_dict["_plan"] = plan
         return plan
 

@@ -135,7 +135,9 @@ class _DevoxelizeCat(Function):
         half = _amp_half(feats[0])
         n = maps[0][0].shape[0]
         cs = [f.shape[1] for f in feats]
-        stored_half = half and all(f.dtype == torch.float16 for f in feats) and all(isinstance(o, tuple) for _, _, o in maps)
+        # (a backward pass through the half kernels walks the inverse maps / cell plans; a forward-only pass needs none)
+        stored_half = half and all(f.dtype == torch.float16 for f in feats) \
+            and (all(isinstance(o, tuple) for _, _, o in maps) or not any(ctx.needs_input_grad[1:]))
         out = torch.empty((n, sum(cs)), dtype=torch.float16 if stored_half else torch.float32, device=feats[0].device)
         col = 0
         for f, (idx, w, _order), c in zip(feats, maps, cs):
@@ -229,26 +231,32 @@ class KernelMap:
         self._nbmaps = None
         self._total = None
         self.cls = None                       # plan of the class-sorted implicit GEMM (csrc/conv_class.hip), large 3x3x3 maps
+        self._cls_pending = None              # ... launched, not yet judged (accept_class_plans)
         self.direct = None                    # {"down", "up"}: direct plans of a 2x2x2 strided map (no Z, no pass 2)
         self._plans = {}                      # plans_for() answers (dropped when a plan is built)
 
-    def build_class_plan(self):
+    def build_class_plan(self, defer=False):
         """Plan of the class-sorted implicit GEMM for a SUBMANIFOLD 3x3x3 map (in == out; the caller knows): rows sorted by
         the neighbour mask of each z-plane of offsets.  Built with the map, on the stream that builds it; maps too small to
-        gain (class_gemm_pays) go without."""
-        if (_CLASS_GEMM and self.cls is None and self.nbr.shape[0] == 27 and self.sizes[0] == self.sizes[1]
-                and self.sizes[0] >= _CLASS_MIN_ROWS):
-            cls = B.conv_class_plan(self.nbr)
-            # one host read (the map's builder has just read the pair total the same way): is the plan worth walking?  Rows with
-            # LiDAR-like neighbour masks sort into near-uniform tiles (128 * steps ~ 1.1 P); rows with unrelated masks would make
-            # every tile walk all nine offsets of its group with most rows absent (up to 3.7 P row-products): two passes then
-            tiles, steps = cls["n_tiles"].tolist()
-            cls["z_rows"], cls["steps"] = 128 * tiles, steps
-            cls["map_id"], cls["pairs"] = self.nboffs, self.total          # the identity of the map the plan belongs to
-            if 128 * steps <= _CLASS_MAX_WORK * self.total:
-                self.cls = cls
-                self._plans.clear()
+        gain (class_gemm_pays) go without.  defer=True only launches the builder: `accept_class_plans` then judges the plans of
+        several maps with ONE host read (an index plan has three such maps)."""
+        if (_CLASS_GEMM and self.cls is None and self._cls_pending is None and self.nbr.shape[0] == 27
+                and self.sizes[0] == self.sizes[1] and self.sizes[0] >= _CLASS_MIN_ROWS):
+            self._cls_pending = B.conv_class_plan(self.nbr)
+        if not defer:
+            accept_class_plans([self])
         return self.cls
+
+    def _accept(self, tiles, steps):
+        # is the plan worth walking?  Rows with LiDAR-like neighbour masks sort into near-uniform tiles (128 * steps ~ 1.1 P);
+        # rows with unrelated masks would make every tile walk all nine offsets of its group with most rows absent (up to 3.7 P
+        # row-products): two passes then
+        cls, self._cls_pending = self._cls_pending, None
+        cls["z_rows"], cls["steps"] = 128 * tiles, steps
+        cls["map_id"], cls["pairs"] = self.nboffs, self.total          # the identity of the map the plan belongs to
+        if 128 * steps <= _CLASS_MAX_WORK * self.total:
+            self.cls = cls
+            self._plans.clear()
 
     def build_direct_plans(self):
         """The two DIRECT plans of a 2x2x2 strided map (csrc/conv_class.hip): every destination row holds all its offsets in one
@@ -329,6 +337,18 @@ class KernelMap:
 
     def __len__(self):
         return 3
+
+
+def accept_class_plans(kmaps):
+    """judge the class plans launched by `build_class_plan(defer=True)` on these maps: one host read for all of them (the map's
+    builder has read the pair totals the same way)"""
+    pending = [km for km in kmaps if km._cls_pending is not None]
+    if not pending:
+        return
+    counts = torch.stack([km._cls_pending["n_tiles"] for km in pending]).tolist() if len(pending) > 1 \
+        else [pending[0]._cls_pending["n_tiles"].tolist()]
+    for km, (tiles, steps) in zip(pending, counts):
+        km._accept(tiles, steps)
 
 
 # Class-sorted implicit GEMM (csrc/conv_class.hip) - where it beats pair GEMM + gather-sum (profiles/r03_class_gemm_layers.txt):

@@ -1132,3 +1132,39 @@ def test_gather_sum_list_form_gives_the_bits_of_the_register_form(B, k, n, c):
     close(got, ref, 1e-5)
     if want_h is not None:
         assert torch.equal(B.conv_gather_sum_f16(z.half(), pos_t, n), want_h)
+
+
+@pytest.mark.parametrize("dup", [False, True])
+def test_symmetric_submanifold_kernel_maps_equal_the_full_probe(dup):
+    """ts_build_kmap_sym (half the probes + mirrored stores, what the index plan builds its five submanifold maps with) against
+    ts_build_kmap on the same coordinates: every table bit for bit (nn/functional/conv.py:156-176 order kept); coordinates with a
+    duplicate are detected on the device and the index plan falls back to the full probe"""
+    from taseg_amd import _fast
+    from taseg_amd import backend as B
+    from taseg_amd.data.synthetic import synth_scan
+    from taseg_amd.torchsparse.nn import functional as spF
+    from taseg_amd.torchsparse.nn.utils import get_kernel_offsets
+    fast = _fast.module()
+    if fast is None:
+        pytest.skip("native fast path not built")
+    pts, _ = synth_scan(3, n_points=40000, n_beams=32, n_az=1400)
+    pc = np.unique(np.round(pts[:, :3] / 0.05).astype(np.int32), axis=0)
+    pc -= pc.min(0)
+    coords = np.concatenate([pc, np.zeros((len(pc), 1), np.int32)], 1)
+    if dup:
+        coords = np.concatenate([coords, coords[100:103]], 0)          # three voxels twice
+    c = torch.from_numpy(coords).cuda()
+    cm, sub_t, down_t, totals, _, _, _ = fast.index_plan(c, c.float(), 4, B.L.stream())
+    names = ("nbr", "nbmaps", "nbsizes", "nboffs", "pos_out", "pos_in")
+    for lvl in range(5):
+        s = 1 << lvl
+        offs = get_kernel_offsets(3, stride=s, dilation=1, device=c.device)
+        full = B.build_kmap(cm[lvl], cm[lvl], offs)
+        total = int(full["nboffs"][-1])
+        assert int(totals[2 * lvl]) == total
+        got = dict(zip(names, sub_t[lvl]))
+        for k in names:
+            a, b = got[k], full[k]
+            if k == "nbmaps":
+                a, b = a[:total], b[:total]
+            assert torch.equal(a, b), (lvl, k)
