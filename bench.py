@@ -533,6 +533,24 @@ def summarise_families(prof, amp, traffic_table):
     return out
 
 
+def small_layer_share(records, steps, rows_below=64000):
+    """the convolution launches of the deep levels (strides 8 / 16 at bs 2: fewer than `rows_below` rows of the gathered matrix) as an
+    entry of their own: launches and milliseconds per step - < 10 % of the flops in ~40 % of the convolution launches"""
+    ms = n = all_ms = all_n = 0.0
+    for kind, e0, e1, m in records:
+        t = e0.elapsed_time(e1)
+        all_ms += t
+        all_n += 1
+        rows = m.get("n_rows") or m.get("n_out") or 0
+        if 0 < rows < rows_below:
+            ms += t
+            n += 1
+    if not all_n:
+        return None
+    return {"rows_below": rows_below, "launches_per_step": n / steps, "ms_per_step": ms / steps, "avg_us": 1e3 * ms / max(n, 1),
+            "share_of_conv_launches": n / all_n, "share_of_conv_ms": ms / all_ms}
+
+
 def launches_of(args):
     """kernel launches per step of this configuration on all streams, from the committed rocprofv3 kernel trace of the tree
     (profiles/launches.json: written by tools/collect_profiles.sh; None when the configuration has no entry)"""
@@ -595,12 +613,12 @@ def secondary_runs(steps=30, warmup=8):
     own JSON line cut down to value / ms_per_step / dtype / config."""
     import subprocess
     out = []
-    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"], ["--eval"], ["--eval", "--amp"],
-                  ["--workload", "tiaf"]):
+    # (`--workload tiaf` is NOT among them: on a fresh box its first steps are MIOpen's search over the 2-D convolutions of UNet2D -
+    # 3.5 minutes of a default invocation - and a line is only as good as the solvers that search ends with; run it by hand,
+    # profiles/r05_bench_workloadtiaf.json holds the round's line)
+    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"], ["--eval"], ["--eval", "--amp"]):
         note("secondary run: " + " ".join(extra))
-        # (a TIAF step is ~20x a LiDAR-only step - dense 2-D convolutions over ten 384 x 1280 frames: fewer of them)
-        k, w = (8, 3) if "tiaf" in extra else (steps, warmup)
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(k), "--warmup", str(w), "--no-cpu-baseline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
                "--no-secondary"] + extra           # per-launch events on the first timed step: every entry has its roofline
         entry = {"args": " ".join(extra)}
         try:
@@ -619,7 +637,7 @@ def secondary_runs(steps=30, warmup=8):
                 entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us", "avg_us_net", "hbm_frac_net", "mfma_frac_net",
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
                                                              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
-                                                             "whole_step_lower_bound_ms")} if roof else None
+                                                             "whole_step_lower_bound_ms", "small_layers")} if roof else None
                 if rec.get("image_gather") is not None:
                     entry["image_gather"] = rec["image_gather"]
                 entry["conv_bytes_per_step"] = rec.get("conv_bytes_per_step")
@@ -1048,6 +1066,8 @@ def main():
     if rank == 0:
         prof = summarise_profile(records, profiled_steps)
         roofline = build_roofline(prof, args.amp, bracket_us)
+        if roofline is not None:
+            roofline["small_layers"] = small_layer_share(records, profiled_steps)
         if roofline is not None and wgrad_side is not None:
             roofline["weight_gradients_on_second_stream"] = bool(wgrad_side[0])
             roofline["profiled_steps"] = ("weight gradients on the caller's stream (kernels timed one at a time); the other timed steps "

@@ -31,8 +31,8 @@ trace ms "minkunet_ms" sgd_decide_kernel 20 --workload minkunet_ms --steps 20 --
 export TASEG_WGRAD_STREAM=1
 trace default_side "minkunet second-stream" sgd_decide_kernel 20 --steps 20 --warmup 5
 unset TASEG_WGRAD_STREAM
-trace eval "eval minkunet" "ArgMax|argmax" 40 --eval --steps 40 --warmup 8
-trace evalamp "eval minkunet amp" "ArgMax|argmax" 40 --eval --amp --steps 40 --warmup 8
+trace eval "eval minkunet" "unvoxelise_kernel" 40 --eval --steps 40 --warmup 8
+trace evalamp "eval minkunet amp" "unvoxelise_kernel" 40 --eval --amp --steps 40 --warmup 8
 echo "  \"_source\": \"rocprofv3 --kernel-trace of the tree, kernels of all streams inside the timed steps (tools/stream_busy.py)\"" >> $OUT/launches.json
 echo "}" >> $OUT/launches.json
 export TASEG_WGRAD_STREAM=0
@@ -47,6 +47,9 @@ python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collectio
 cp profiles/traffic.json $OUT/traffic.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_amp $OUT/pmc_write_amp
 say "side lines"
-for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist" "--workload tiaf --steps 8 --warmup 3"; do
+for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist"; do
   tag=$(echo $w | tr -d ' -'); say "bench $w"; python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary > $OUT/bench_$tag.json 2> /dev/null; done
+say "host phases"
+for w in "" "--amp"; do TASEG_BENCH_HOST_PHASES=1 python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes|second stream" | sed "s/^/[bench.py $w] /" >> $OUT/host_phases.txt; done
+for t in 0 1; do TASEG_STAGE_THREAD=$t TASEG_BENCH_HOST_PHASES=1 python bench.py --amp --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes" | sed "s/^/[bench.py --amp, TASEG_STAGE_THREAD=$t] /" >> $OUT/host_phases.txt; done
 tail -c 400 $OUT/bench_default.json
