@@ -770,6 +770,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                                                  c10::optional<at::Tensor>, double, double>> &>())
       .def("set_planes", &stage::Program::set_planes)
       .def("set_grad_dests", &stage::Program::set_grad_dests)
+      .def("set_deliver", &stage::Program::set_deliver)
       .def_readonly("n_inputs", &stage::Program::n_inputs);
   py::class_<stage::Geometry, std::shared_ptr<stage::Geometry>>(m, "StageGeometry", "kernel maps + class plans per op of a stage for one batch")
       .def(py::init<const std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t, int64_t>> &,

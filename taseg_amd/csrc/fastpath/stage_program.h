@@ -43,6 +43,11 @@ struct Program {
   std::vector<Op> ops;
   int n_inputs = 1, n_regs = 0, out_reg = 0;
   std::vector<int> uses;                  // consumers of every register inside the stage
+  // Direct delivery (parallel.GradBucketReducer.deliver): with the reducer's slots on every parameter of the stage the node does not
+  // hand the gradients to autograd at all - it writes them into the slots and calls this ONCE at the end of its backward pass; the
+  // reducer re-points p.grad and counts the bucket down.  183 AccumulateGrad nodes and 183 Python hooks per step (each a trip to
+  // the interpreter lock from the engine's thread, beside a staging thread that also wants it) become 8 calls.
+  std::function<void()> deliver;
 
   // ops: (kind, layer, src, dst, aux, transposed, relu); layers: (kernel, bn_w, bn_b, running_mean, running_var, nbt, momentum, eps)
   Program(int n_inputs_, int out_reg_, const std::vector<std::tuple<int, int, int, int, int, bool, bool>> &ops_,
@@ -110,6 +115,31 @@ struct Program {
       layers[i].planes32 = p32[i].has_value() ? *p32[i] : at::Tensor();
       layers[i].half16 = h16[i].has_value() ? *h16[i] : at::Tensor();
     }
+  }
+  void set_deliver(py::object fn) {
+    if (fn.is_none()) {
+      deliver = nullptr;
+      return;
+    }
+    // (the callable is kept in a shared holder whose deleter takes the interpreter lock)
+    std::shared_ptr<py::object> hold(new py::object(std::move(fn)), [](py::object *o) {
+      py::gil_scoped_acquire gil;
+      delete o;
+    });
+    deliver = [hold]() {
+      py::gil_scoped_acquire gil;
+      (*hold)();
+    };
+  }
+  // may this pass deliver its gradients directly?  (every slot present, nothing accumulated, slots not yet handed out this epoch)
+  bool direct_ok(int64_t grad_epoch) const {
+    if (!deliver) return false;
+    for (const Layer &l : layers)
+      if (!(l.dest_w.defined() && l.dest_g.defined() && l.dest_b.defined()) || l.claimed == grad_epoch || l.kernel.grad().defined() ||
+          l.bn_w.grad().defined() || l.bn_b.grad().defined() || !l.kernel.requires_grad() || !l.bn_w.requires_grad() ||
+          !l.bn_b.requires_grad())
+        return false;
+    return true;
   }
   // gradient-bucket slots of (kernel, bn weight, bn bias) per layer, or none
   void set_grad_dests(const std::vector<c10::optional<at::Tensor>> &d) {
@@ -208,7 +238,7 @@ struct State : torch::CustomClassHolder {
   std::vector<OpRec> recs;
   std::vector<int64_t> reg_rows, reg_ch;
   std::vector<at::ScalarType> in_dtypes;
-  bool half = false;
+  bool half = false, direct = false;
   int64_t stream = 0, comm = 0, group_id = -1;
 };
 
@@ -270,7 +300,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
   // to the bucket slots behind autograd's back is NOT done here: parameters always travel through autograd
   static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, at::TensorList inputs_, at::TensorList params,
                                                 std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
-                                                int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
+                                                int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch, bool direct) {
     const int64_t t_in = now_ns();
     if (wg_join_queued.exchange(false)) {
       wg_worker.drain();
@@ -278,12 +308,13 @@ class StageRun : public torch::autograd::Function<StageRun> {
     }
     Program &p = *prog;
     const Geometry &g = *geom;
-    TORCH_CHECK(params.size() == 3 * p.layers.size(), "stage run: three parameters per layer");
+    TORCH_CHECK(params.size() == (direct ? 0 : 3 * p.layers.size()), "stage run: three parameters per layer (none with direct delivery)");
     TORCH_CHECK(g.half == half, "stage run: the geometry was resolved for the other storage mode");
     auto st = c10::make_intrusive<State>();
     st->prog = prog;
     st->geom = geom;
     st->half = half;
+    st->direct = direct;
     st->stream = stream;
     st->comm = comm;
     st->group_id = (comm == 0 && group_id >= 0) ? group_id : -1;
@@ -354,6 +385,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
       const bool fresh = !l.kernel.grad().defined() && !l.bn_w.grad().defined() && !l.bn_b.grad().defined();
       r.side_ok = !l.kernel.grad().defined();
       r.use_dest = fresh && l.dest_w.defined() && l.dest_g.defined() && l.dest_b.defined() && l.claimed != grad_epoch;
+      TORCH_CHECK(!direct || r.use_dest, "stage run: direct delivery without the reducer's slots");
       if (r.use_dest) l.claimed = grad_epoch;
       const at::Tensor &table = o.transposed ? m.pos_in : m.pos_out;
       const void *pl = (!half && l.planes32.defined()) ? l.planes32.data_ptr() : nullptr;
@@ -594,8 +626,13 @@ class StageRun : public torch::autograd::Function<StageRun> {
       if (gi.defined() && gi.scalar_type() != st->in_dtypes[i]) gi = gi.to(st->in_dtypes[i]);
       out.push_back(std::move(gi));
     }
-    for (auto &t : gparams) out.push_back(std::move(t));
-    for (int i = 0; i < 7; ++i) out.push_back(at::Tensor());      // prog, geom, half, stream, comm, group_id, grad_epoch
+    if (!st->direct)
+      for (auto &t : gparams) out.push_back(std::move(t));
+    for (int i = 0; i < 8; ++i) out.push_back(at::Tensor());      // prog, geom, half, stream, comm, group_id, grad_epoch, direct
+    if (st->direct) {
+      gparams.clear();                    // (the aliases of the slots: the reducer's own views become p.grad)
+      p.deliver();
+    }
     host_clock.ns_bwd += now_ns() - t_in;
     host_clock.n_bwd += (int64_t)p.layers.size();
     return out;
@@ -605,8 +642,12 @@ class StageRun : public torch::autograd::Function<StageRun> {
 inline at::Tensor run(const std::vector<at::Tensor> &inputs, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
                       int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
-  const std::vector<at::Tensor> params = prog->parameters();
-  return StageRun::apply(at::TensorList(inputs), at::TensorList(params), prog, geom, half, stream, comm, group_id, grad_epoch)[0];
+  // (the node must still be recorded: with its parameters off the graph that takes an input that requires a gradient)
+  bool wanted = false;
+  for (const at::Tensor &x : inputs) wanted = wanted || x.requires_grad();
+  const bool direct = at::GradMode::is_enabled() && wanted && prog->direct_ok(grad_epoch);
+  const std::vector<at::Tensor> params = direct ? std::vector<at::Tensor>() : prog->parameters();
+  return StageRun::apply(at::TensorList(inputs), at::TensorList(params), prog, geom, half, stream, comm, group_id, grad_epoch, direct)[0];
 }
 
 // The evaluation form (modules in eval mode, no graph: minkunet.py:435-455, R/train.py:452-540): the same op list on

@@ -108,6 +108,7 @@ class GradBucketReducer:
             process_group = dist.new_group(backend=dist.get_backend())
         self.group = process_group
         self._next = 0              # index of the next bucket to launch (launch order = index order on every rank)
+        self._slot_of = {}          # id(parameter) -> (bucket index, position in the bucket)
         params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []
         cur, cur_bytes = [], 0
@@ -144,11 +145,16 @@ class GradBucketReducer:
         flat_all = torch.zeros(off + n_flags, dtype=first.dtype, device=first.device)
         flat, flags = flat_all[:off], flat_all[off:off + len(params)]
         views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, params)]
-        for p, v in zip(params, views):
+        import weakref
+        bucket_index = len(self.buckets)
+        for i, (p, v) in enumerate(zip(params, views)):
             # producers that can write a gradient wherever they are told (the conv block nodes: their weight gradient is
             # a full overwrite) put it straight into the bucket; _launch then finds p.grad already in place and copies
             # nothing for it (the convolution weights are 99 % of the gradient bytes)
             p._taseg_grad_dest = v
+            # ... and producers that deliver a whole stage's gradients themselves (deliver below) find their way back here
+            p._taseg_reducer = weakref.ref(self)
+            self._slot_of[id(p)] = (bucket_index, i)
         self.buckets.append({"params": list(params), "flat": flat, "flat_all": flat_all, "flags": flags, "views": views,
                              "offsets": offsets, "pending": len(params), "launched": False, "unused": []})
 
@@ -166,6 +172,22 @@ class GradBucketReducer:
                 self._launch(self.buckets[self._next])
                 self._next += 1
         return hook
+
+    def deliver(self, params):
+        """Gradients of `params` have been written straight into their bucket slots by a producer that bypasses autograd's
+        AccumulateGrad for them (the stage programs, csrc/fastpath/stage_program.h: one call per stage and backward pass instead of
+        one hook per parameter): p.grad becomes the slot's view and the buckets count down exactly as the hooks would have."""
+        for p in params:
+            b, i = self._slot_of[id(p)]
+            bucket = self.buckets[b]
+            if bucket["launched"] or bucket["pending"] <= 0:
+                raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket whose all-reduce was already "
+                                   "launched - exactly one backward pass per finish() / optimizer step is supported")
+            p.grad = bucket["views"][i]
+            bucket["pending"] -= 1
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, bucket):
         # weight gradients on a second stream (taseg_amd/_fast.py) are complete THERE: this stream - on which the bucket is scaled and

@@ -27,6 +27,7 @@ from taseg_amd.torchsparse.utils import make_ntuple
 __all__ = ["StagePrograms", "enabled", "programs_of", "forget", "compiled"]
 
 _ON = os.environ.get("TASEG_STAGE_PROGRAM", "1") != "0"
+_DIRECT_GRADS = os.environ.get("TASEG_DIRECT_GRADS", "1") != "0"
 _ONES = (1, 1, 1)
 _BLOCK, _CAT = 0, 1
 
@@ -294,6 +295,16 @@ class StagePrograms:
                           getattr(bn.bias, "_taseg_grad_dest", None)]
             st.program.set_grad_dests(dests)
             st.dest_state = first
+            # with a reducer behind the slots the stage delivers its gradients itself, once per backward pass (TASEG_DIRECT_GRADS=0:
+            # through autograd's AccumulateGrad and the reducer's per-parameter hooks)
+            ref = getattr(st.convs[0].kernel, "_taseg_reducer", None)
+            reducer = ref() if ref is not None else None
+            if reducer is not None and _DIRECT_GRADS and all(d is not None for d in dests):
+                params = [p for conv, bn in st.layers for p in (conv.kernel, bn.weight, bn.bias)]
+                rref = ref
+                st.program.set_deliver(lambda: rref().deliver(params))
+            else:
+                st.program.set_deliver(None)
         return stream
 
     def run(self, name, inputs, plan, training):

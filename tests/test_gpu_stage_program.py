@@ -237,3 +237,35 @@ def test_fused_evaluation_tail_equals_the_sorted_form(grouped, half, probs):
         bad[5] = vox_counts[0] + 3
         with pytest.raises(IndexError):
             unvoxelise_predictions(out, cv.cuda()[:, -1], SparseTensor(bad.cuda(), cp.cuda()), labs, num_points, probs, names=names)
+
+
+def test_direct_gradient_delivery_counts_the_buckets_down_like_the_hooks():
+    """with a reducer behind the parameters the stage programs deliver a stage's gradients themselves - one
+    GradBucketReducer.deliver call per stage instead of one AccumulateGrad node + hook per parameter: p.grad IS the bucket view,
+    every bucket is launched exactly once, and a second backward pass before finish() raises as it does through the hooks"""
+    from taseg_amd.optim import FlatSGD
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet import stage_program as SP
+    _set(True)
+    make, n = _scan_batch(seed=6)
+    model = _model(num_layer=[1] * 8).train()
+    opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=0.0, max_norm=10.0, bucket_mb=8.0)
+    calls = []
+    real = opt.reducer.deliver
+    opt.reducer.deliver = lambda params: (calls.append(len(params)), real(params))[1]
+    opt.zero_grad()
+    ret, _, _ = model(make())
+    ret["loss"].backward()
+    n_pairs = sum(len(st.layers) for st in SP.programs_of(model).stages.values())            # conv + BatchNorm pairs inside the 8 stages
+    assert SP.compiled(model) and len(calls) == 8 and sum(calls) == 3 * n_pairs, calls
+    for b in opt.reducer.buckets:
+        for p, v in zip(b["params"], b["views"]):
+            assert p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+    opt.step()
+    torch.cuda.synchronize()
+    # a second backward pass inside one optimizer step is refused (the bucket's all-reduce may already be in flight)
+    opt.zero_grad()
+    ret, _, _ = model(make())
+    ret["loss"].backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="one backward pass per finish"):
+        ret["loss"].backward()
+    opt.reducer.finish()
