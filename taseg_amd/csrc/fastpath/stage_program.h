@@ -642,6 +642,8 @@ class StageRun : public torch::autograd::Function<StageRun> {
 inline at::Tensor run(const std::vector<at::Tensor> &inputs, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
                       int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  // the issue loop touches no Python object: another thread (the data stage of the next batch) may have the interpreter meanwhile
+  py::gil_scoped_release nogil;
   // (the node must still be recorded: with its parameters off the graph that takes an input that requires a gradient)
   bool wanted = false;
   for (const at::Tensor &x : inputs) wanted = wanted || x.requires_grad();
@@ -655,6 +657,7 @@ inline at::Tensor run(const std::vector<at::Tensor> &inputs, std::shared_ptr<Pro
 inline at::Tensor run_eval(const std::vector<at::Tensor> &inputs_, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
                            int64_t stream) {
   TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  py::gil_scoped_release nogil;
   at::NoGradGuard nograd;
   Program &p = *prog;
   const Geometry &g = *geom;
