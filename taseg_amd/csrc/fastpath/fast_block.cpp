@@ -778,6 +778,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     const std::vector<std::vector<at::Tensor>> &, const std::vector<std::vector<int64_t>> &, bool>());
   m.def("stage_run", &stage::run, "a whole stage (block calls + concatenation) as ONE autograd node, training mode");
   m.def("stage_run_eval", &stage::run_eval, "a whole stage on the running statistics, no graph");
+  m.def("unet_run", &stage::unet_run, "stage1 .. up4 of the U-Net pass in one call (eight stage programs, the dropouts between them)");
   m.def("host_times", &host_times, "diagnostic: (calls, ns, ns in the backend call) of the block node's forward and backward; resets");
   m.def("index_plan", &index_plan, "coordinate pyramid + kernel maps + trilinear maps of a MinkUNet pass (releases the GIL)");
   m.def("load_backend", &load_backend, "bind libtaseg_hip.so");

@@ -639,11 +639,9 @@ class StageRun : public torch::autograd::Function<StageRun> {
   }
 };
 
-inline at::Tensor run(const std::vector<at::Tensor> &inputs, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
-                      int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
-  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
-  // the issue loop touches no Python object: another thread (the data stage of the next batch) may have the interpreter meanwhile
-  py::gil_scoped_release nogil;
+// (callers hold no interpreter lock: the issue loop touches no Python object)
+inline at::Tensor run_inner(const std::vector<at::Tensor> &inputs, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
+                            int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
   // (the node must still be recorded: with its parameters off the graph that takes an input that requires a gradient)
   bool wanted = false;
   for (const at::Tensor &x : inputs) wanted = wanted || x.requires_grad();
@@ -652,12 +650,18 @@ inline at::Tensor run(const std::vector<at::Tensor> &inputs, std::shared_ptr<Pro
   return StageRun::apply(at::TensorList(inputs), at::TensorList(params), prog, geom, half, stream, comm, group_id, grad_epoch, direct)[0];
 }
 
+inline at::Tensor run(const std::vector<at::Tensor> &inputs, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
+                      int64_t stream, int64_t comm, int64_t group_id, int64_t grad_epoch) {
+  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  // another thread (the data stage of the next batch) may have the interpreter while the stage is issued
+  py::gil_scoped_release nogil;
+  return run_inner(inputs, std::move(prog), std::move(geom), half, stream, comm, group_id, grad_epoch);
+}
+
 // The evaluation form (modules in eval mode, no graph: minkunet.py:435-455, R/train.py:452-540): the same op list on
 // ts_conv_block_eval with the running statistics.
-inline at::Tensor run_eval(const std::vector<at::Tensor> &inputs_, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
-                           int64_t stream) {
-  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
-  py::gil_scoped_release nogil;
+inline at::Tensor run_eval_inner(const std::vector<at::Tensor> &inputs_, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom,
+                                 bool half, int64_t stream) {
   at::NoGradGuard nograd;
   Program &p = *prog;
   const Geometry &g = *geom;
@@ -722,6 +726,32 @@ inline at::Tensor run_eval(const std::vector<at::Tensor> &inputs_, std::shared_p
     reg[o.dst] = dst;
   }
   return view_of(arena, reg[p.out_reg], rows[p.out_reg], ch[p.out_reg], dt);
+}
+
+inline at::Tensor run_eval(const std::vector<at::Tensor> &inputs, std::shared_ptr<Program> prog, std::shared_ptr<Geometry> geom, bool half,
+                           int64_t stream) {
+  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  py::gil_scoped_release nogil;
+  return run_eval_inner(inputs, std::move(prog), std::move(geom), half, stream);
+}
+
+// stage1 .. stage4, up1 .. up4 of the U-Net pass (minkunet.py:393-422) in ONE call: the eight stage programs in order, the two
+// dropouts between them (at::dropout = torch.nn.functional.dropout: same generator use), the skip connections handed on as matrices;
+// returns the three feature matrices the point head devoxelises (stride-16 encoder output, stride-4 and stride-1 decoder outputs,
+// each BEFORE its dropout: minkunet.py:400-412).  The whole backbone is issued without the interpreter lock.
+inline std::vector<at::Tensor> unet_run(const at::Tensor &f0, const std::vector<std::shared_ptr<Program>> &progs,
+                                        const std::vector<std::shared_ptr<Geometry>> &geoms, bool training, bool half, int64_t stream,
+                                        int64_t comm, int64_t group_id, int64_t grad_epoch, double dropout_p) {
+  TORCH_CHECK(api.handle, "taseg_amd fast path: load_backend() has not been called");
+  TORCH_CHECK(progs.size() == 8 && geoms.size() == 8, "unet_run: eight stage programs (stage1-4, up1-4) and their geometries");
+  py::gil_scoped_release nogil;
+  auto go = [&](int i, std::vector<at::Tensor> in) {
+    return training ? run_inner(in, progs[i], geoms[i], half, stream, comm, group_id, grad_epoch) : run_eval_inner(in, progs[i], geoms[i], half, stream);
+  };
+  auto drop = [&](const at::Tensor &x) { return at::dropout(x, dropout_p, training); };
+  at::Tensor f1 = go(0, {f0}), f2 = go(1, {f1}), f3 = go(2, {f2}), f4 = go(3, {f3});
+  at::Tensor y1 = go(4, {drop(f4), f3}), y2 = go(5, {y1, f2}), y3 = go(6, {drop(y2), f1}), y4 = go(7, {y3, f0});
+  return {f4, y2, y4};
 }
 
 }  // namespace stage

@@ -409,17 +409,9 @@ class MinkUNetBackbone(BaseSegmentor):
 
     def _unet_stages(self, progs, f0, plan, concat):
         """stage1 .. up4 of `_unet_point_features` on the stage programs: one call (and one autograd node) per stage"""
-        tr = self.training
-        f1 = progs.run("stage1", (f0,), plan, tr)
-        f2 = progs.run("stage2", (f1,), plan, tr)
-        f3 = progs.run("stage3", (f2,), plan, tr)
-        f4 = progs.run("stage4", (f3,), plan, tr)
-        drop = torch.nn.functional.dropout
-        # (out of place: the point head devoxelises the features BEFORE dropout, minkunet.py:400-412)
-        y1 = progs.run("up1", (drop(f4, self.dropout.p, tr, False), f3), plan, tr)
-        y2 = progs.run("up2", (y1, f2), plan, tr)
-        y3 = progs.run("up3", (drop(y2, self.dropout.p, tr, False), f1), plan, tr)
-        y4 = progs.run("up4", (y3, f0), plan, tr)
+        # (the eight stages and the two out-of-place dropouts between them - the point head devoxelises the features BEFORE
+        # dropout, minkunet.py:400-412 - in one native call, issued without the interpreter lock)
+        f4, y2, y4 = progs.run_unet(f0, plan, self.training, self.dropout.p)
         keys = ((16, 16, 16), (4, 4, 4), (1, 1, 1))
         tri_idx, tri_w, orders = plan["tri_idx"], plan["tri_w"], plan["tri_order"]
         maps = [(tri_idx[k], tri_w[k], orders.get(k)) for k in keys]

@@ -307,6 +307,31 @@ class StagePrograms:
                 st.program.set_deliver(None)
         return stream
 
+    ORDER = ("stage1", "stage2", "stage3", "stage4", "up1", "up2", "up3", "up4")
+
+    def run_unet(self, f0, plan, training, dropout_p):
+        """stage1 .. up4 in ONE native call (csrc/fastpath/stage_program.h::unet_run): returns the features of the stride-16
+        encoder output and the stride-4 / stride-1 decoder outputs, each before its dropout"""
+        half = spF._amp_half(f0)
+        progs, geoms, stream = [], [], None
+        for name in self.ORDER:
+            st = self.stages[name]
+            geoms.append(self.geometry(name, plan, half))
+            stream = self._refresh(st, half)
+            progs.append(st.program)
+        comm, group_id = 0, -1
+        if training:
+            group = spM._sync_group(self.stages["stage1"].bns[0])
+            if group is not None:
+                from taseg_amd.rccl import direct_comm
+                spM._require_rows(f0, group)
+                c = direct_comm(group)
+                if c is not None:
+                    comm = c.value or 0
+                else:
+                    group_id = spM._group_id(self.fast, group)
+        return self.fast.unet_run(f0, progs, geoms, bool(training), half, stream, comm, group_id, _parallel.grad_epoch(), float(dropout_p))
+
     def run(self, name, inputs, plan, training):
         st = self.stages[name]
         half = spF._amp_half(inputs[0])
