@@ -98,11 +98,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms", "nuscenes_ms", "tiaf"],
+    ap.add_argument("--workload", default="minkunet", choices=["minkunet", "minkunet_ms", "nuscenes_ms", "tiaf", "kd"],
                     help="minkunet = BASELINE configs[1] (headline); minkunet_ms = configs[2] (4-scan TFA); "
                          "nuscenes_ms = configs[4] shape: 32-beam 34.7k-point sweeps, 15 history sweeps, voxel 0.1 m, "
                          "17 classes, bs 4 (fp32 here); tiaf = MinkUNetMsMm (temporal image aggregation and fusion, "
-                         "minkunet_mk34_cr10_fsa_tiaf.yaml): 16 fused history scans, 5 camera frames of 384 x 1280 per sample, bs 2")
+                         "minkunet_mk34_cr10_fsa_tiaf.yaml): 16 fused history scans, 5 camera frames of 384 x 1280 per sample, bs 2; "
+                         "kd = MinkUNetMsKd (mask distillation, minkunet_mk34_cr10_fsa_kd.yaml): 16 history scans fused twice per sample "
+                         "(pseudo-label masks for the student, ground-truth masks for the frozen teacher), bs 6")
     ap.add_argument("--batch", type=int, default=None, help="scans per GPU per step (default 2; 4 for nuscenes_ms)")
     ap.add_argument("--points", type=int, default=None, help="points per scan (default 120000; 34700 for nuscenes_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +168,7 @@ def make_scans(rank, batch, points, workload):
             torch.from_numpy(np.concatenate(labels)).to(dev), npts)
 
 
-def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label_map=None):
+def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label_map=None, pseudo_flip=0.0):
     """Raw resident scans for the "4-scan TFA" workload: per sample the
     current scan plus `history` earlier scans of the same scene seen from the ego poses
     synth_pose(t) (1.1 m and 0.4 deg per frame).  The temporal aggregation + voxelisation itself runs on the
@@ -187,6 +189,16 @@ def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label
             poses.append(torch.from_numpy(pose).to(dev))
             npts += len(p)
         scans.append({"points": pts, "labels": labs, "poses": poses, "name": f"{rank}/{b}"})
+        if pseudo_flip > 0:
+            # pseudo labels of the history scans (the reference reads a trained model's predictions, semantickitti_ms_kd.py:318-323):
+            # the annotation with a share of the points moved to another class
+            g = torch.Generator(device="cpu").manual_seed(seed + 7)
+            ps = []
+            for l in labs[:-1]:
+                flip = (torch.rand(l.shape[0], generator=g) < pseudo_flip).to(dev)
+                other = torch.randint(1, 20, (l.shape[0],), generator=g).to(dev)
+                ps.append(torch.where(flip, other, l))
+            scans[-1]["pseudo"] = ps
     return scans, npts
 
 
@@ -810,22 +822,29 @@ def main():
         args.no_kernel_events = True      # (its roofline entry is the image gather's, measured after the timed steps)
     nusc = args.workload == "nuscenes_ms"
     tiaf = args.workload == "tiaf"
-    ms = args.workload in ("minkunet_ms", "nuscenes_ms", "tiaf")
+    kd = args.workload == "kd"
+    ms = args.workload in ("minkunet_ms", "nuscenes_ms", "tiaf", "kd")
+    if kd:
+        args.no_kernel_events = True      # (two networks in one step: the per-kernel table of the single-network lines does not apply)
     if args.batch is None:
-        args.batch = 4 if nusc else 2
+        args.batch = 4 if nusc else 6 if kd else 2       # (kd yaml :44 BATCH_SIZE_PER_GPU 6)
     if args.points is None:
         args.points = 34700 if nusc else 120000
     voxel = 0.1 if nusc else VOXEL
     num_class = 17 if nusc else 20
-    name = "MinkUNetMsMm" if tiaf else "MinkUNetMs" if ms else "MinkUNet"
+    name = "MinkUNetMsMm" if tiaf else "MinkUNetMsKd" if kd else "MinkUNetMs" if ms else "MinkUNet"
     # nuScenes FSA feeds 4 features (the time flag column is cut by IN_FEATURE_DIM: 4, nuscenes fsa yaml:16,27)
     extra_cfg = {}
     if tiaf:
         from taseg_amd.data.synthetic import TIAF_CFG
         extra_cfg = dict(TIAF_CFG)
+    if kd:
+        extra_cfg = dict(SAMPLING_TYPE="random", MAX_VOXEL=3000, FEAT_KD="mse", FEAT_KD_WEIGHT=10.0)      # kd yaml :35-38
     cfg = make_model_cfg(name, in_dim=(4 if nusc else 5) if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn, **extra_cfg)
     torch.manual_seed(0)
     model = build_network(cfg, num_class).cuda().train()
+    if kd:
+        model.fix_part_param()           # the teacher's parameters are frozen (R/train.py calls it for this model; minkunet_ms_kd.py:719-722)
     net = model
     reducer = None
     lr, mom, wd = 0.02 * args.batch * world, 0.9, 1e-4
@@ -871,6 +890,19 @@ def main():
                 bd = build_tiaf_batch(samples)
                 nvox[0] = int(bd["lidar_ms"].C.shape[0])
                 n_fov[0] = int(bd["lidar_fov_ms"].C.shape[0])
+                return bd
+        elif kd:
+            # MULTISCAN 16, ONLY_HISTORY (kd yaml :17-21): the student's cloud keeps the history points whose PSEUDO label's class is
+            # due at that frame offset, the teacher's those whose ANNOTATION is (semantickitti_ms_kd.py:140-147, 290-358)
+            scans, npts = make_multiscans(rank, args.batch, args.points, history=16, pseudo_flip=0.1)
+            scans_gt = [{k: v for k, v in s.items() if k != "pseudo"} for s in scans]
+            nvox_gt = [0]
+
+            def make_batch():
+                bd = build_multiscan_batch(scans, voxel, FLEXIBLE_STEPS_KITTI)
+                bd["lidar_ms_gt"] = build_multiscan_batch(scans_gt, voxel, FLEXIBLE_STEPS_KITTI)["lidar_ms"]
+                nvox[0] = int(bd["lidar_ms"].C.shape[0])
+                nvox_gt[0] = int(bd["lidar_ms_gt"].C.shape[0])
                 return bd
         else:
             scans, npts = make_multiscans(rank, args.batch, args.points)
@@ -1079,7 +1111,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 storage / f32 accumulate (torch.autocast)" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": f"{name} mk34 cr1.0 ("
-                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else 'TIAF: 16 fused history scans + 5 camera frames of 384 x 1280 per sample, UNet2D + UNet3D + fusion head, five losses' if tiaf else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
+                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else 'TIAF: 16 fused history scans + 5 camera frames of 384 x 1280 per sample, UNet2D + UNet3D + fusion head, five losses' if tiaf else 'mask distillation: 16 history scans fused twice per sample, frozen teacher forward + student step, segmentation + feature MSE losses' if kd else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
                                    f"bs={args.batch}/GPU, voxel {voxel:g} m, {'AMP fp16' if args.amp else 'fp32'}, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}",
@@ -1104,7 +1136,9 @@ def main():
         if tiaf:
             line["config"]["fov_points_per_step_per_gpu"] = n_fov[0]
             line["image_gather"] = tiaf_gather_roofline(model, pf._current if pf is not None and pf._current is not None else make_batch())
-        if world == 1 and not args.no_cpu_baseline and not nusc and not tiaf:      # cpu_baseline is defined on the KITTI-shaped scan
+        if kd:
+            line["config"]["teacher_voxels_per_step_per_gpu"] = nvox_gt[0]
+        if world == 1 and not args.no_cpu_baseline and not nusc and not tiaf and not kd:      # cpu_baseline is defined on the KITTI-shaped scan
             line["cpu_baseline"] = cpu_baseline(args, name, cfg.IN_FEATURE_DIM)
             if line["cpu_baseline"]["value"]:
                 line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -19,6 +19,9 @@ from .minkunet import LazyScalar, MinkUNetBackbone, unvoxelise_predictions
 
 __all__ = ["MinkUNetMsKd"]
 
+# TASEG_KD_LOSS_ON_DEVICE=0: the reference's literal per-sample loop (three host reads per sample) instead of _kd_loss_on_device
+_KD_ON_DEVICE = os.environ.get("TASEG_KD_LOSS_ON_DEVICE", "1") != "0"
+
 _PARTS = ("stem", "stage1", "stage2", "stage3", "stage4", "up1", "up2", "up3", "up4", "classifier", "dropout")
 
 
@@ -45,8 +48,36 @@ class MinkUNetMsKd(MinkUNetBackbone):
         plan["teacher"] = self._index_plan(x_gt.C, x_gt.C.float())
         with torch.no_grad():          # student voxel -> teacher voxel (or -1), by coordinate hash (:613-615)
             plan["s2t"] = spF.sphashquery(spF.sphash(x_ms.C.int()), spF.sphash(x_gt.C.int()))
+            # (:618 - read here, where the batch is staged, so that the step itself reads nothing back)
+            plan["batch_size"] = int(x_ms.C[:, -1].max()) + 1
         batch_dict["_plan"] = plan
         return plan
+
+    def _kd_loss_on_device(self, feat_s, feat_t, s2t, batch_col, batch_size):
+        """The feature-distillation term (minkunet_ms_kd.py:617-633: per sample, the voxels present in both clouds, a uniformly
+        random subset of at most MAX_VOXEL of them, MSE against the teacher's features, weighted mean over the samples) without the
+        reference's per-sample host reads (`max()`, `sum() >`, `nonzero()`): one random key per voxel, one sort by (sample, key) -
+        a voxel is picked iff it is among its sample's first MAX_VOXEL candidates in that order - and the <= B * MAX_VOXEL picked rows
+        gathered through a fixed-size index list.  Same distribution of picks, same value when nothing is sub-sampled (up to
+        summation order); a sample without common voxels makes the term NaN like `mse_loss` of an empty selection does."""
+        n, dev = s2t.shape[0], s2t.device
+        b = batch_col.long()
+        cand = s2t >= 0
+        key = torch.where(cand, torch.rand(n, device=dev, dtype=torch.float64), torch.full((), 2.0, device=dev, dtype=torch.float64))
+        order = torch.argsort(b.double() * 4.0 + key)                       # sample-major, candidates first, random among them
+        rows = torch.bincount(b, minlength=batch_size)[:batch_size]
+        start = torch.cumsum(rows, 0) - rows
+        rank = torch.empty(n, dtype=torch.int64, device=dev)
+        rank[order] = torch.arange(n, device=dev) - start[b[order]]
+        pick = cand & (rank < self.max_voxel)
+        n_b = torch.zeros(batch_size, dtype=torch.float32, device=dev).index_add_(0, b, pick.float())
+        cap = min(n, batch_size * int(self.max_voxel))
+        sel = torch.argsort((~pick).to(torch.uint8), stable=True)[:cap]   # the picked rows first (ascending row), fixed length
+        valid = pick[sel].float()
+        d = feat_s[sel] - feat_t[s2t[sel].clamp(min=0)].detach()
+        per_row = (d * d).sum(1) * valid / (n_b[b[sel]].clamp(min=1.0) * feat_s.shape[1])
+        empty = torch.where(n_b == 0, torch.full((), float("nan"), device=dev), torch.zeros((), device=dev)).sum()
+        return (per_row.sum() + empty) * (self.feat_kd_weight / batch_size)
 
     def forward(self, batch_dict, return_logit=False, return_tta=False):
         plan = batch_dict.get("_plan") or self.prepare(batch_dict)
@@ -66,14 +97,17 @@ class MinkUNetMsKd(MinkUNetBackbone):
             if self.sampling_type != "random":
                 raise NotImplementedError("SAMPLING_TYPE must be 'random' (the only branch the reference implements, :621)")
             s2t = plan["s2t"]
-            batch_size = int(x_ms.C[:, -1].max()) + 1
-            loss_kd = out_ms.new_zeros(())
-            for b in range(batch_size):
-                pick = ((s2t >= 0) & (x_ms.C[:, -1] == b)).nonzero().reshape(-1)
-                if pick.numel() > self.max_voxel:
-                    pick = pick[torch.randperm(pick.numel(), device=pick.device)[:self.max_voxel]]
-                mse = torch.nn.functional.mse_loss(feat_s[pick], feat_t[s2t[pick]].detach())
-                loss_kd = loss_kd + mse * self.feat_kd_weight / batch_size
+            batch_size = plan["batch_size"]
+            if _KD_ON_DEVICE:
+                loss_kd = self._kd_loss_on_device(feat_s, feat_t, s2t, x_ms.C[:, -1], batch_size)
+            else:
+                loss_kd = out_ms.new_zeros(())
+                for b in range(batch_size):
+                    pick = ((s2t >= 0) & (x_ms.C[:, -1] == b)).nonzero().reshape(-1)
+                    if pick.numel() > self.max_voxel:
+                        pick = pick[torch.randperm(pick.numel(), device=pick.device)[:self.max_voxel]]
+                    mse = torch.nn.functional.mse_loss(feat_s[pick], feat_t[s2t[pick]].detach())
+                    loss_kd = loss_kd + mse * self.feat_kd_weight / batch_size
             loss = loss_seg + loss_kd
             disp = {"loss": LazyScalar(loss), "loss_seg": LazyScalar(loss_seg), "loss_feat_kd": LazyScalar(loss_kd)}
             return {"loss": loss}, disp, dict(disp)

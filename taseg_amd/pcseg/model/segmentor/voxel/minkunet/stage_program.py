@@ -223,8 +223,10 @@ class StagePrograms:
     def usable(self, feats, training, grad):
         """can the programs serve this pass?  (training with a graph, or evaluation without one; full-tile channel counts).  Runs
         once per pass over ~300 modules: only dictionary truth tests and identity comparisons on objects collected at compile time"""
-        if not feats.is_cuda or training != grad:
-            return False           # (training-mode BatchNorm without a graph, eval-mode BatchNorm with one: the module path)
+        if not feats.is_cuda or (grad and not training):
+            return False           # (eval-mode BatchNorm with a graph: the module path)
+        # (training-mode BatchNorm without a graph - the frozen teacher of MinkUNetMsKd, minkunet_ms_kd.py:533 - runs the training
+        # program: its autograd node records nothing under no_grad and the forward arena goes with the call)
         half = spF._amp_half(feats)
         if not half and feats.dtype != torch.float32:
             return False

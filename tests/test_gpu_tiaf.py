@@ -265,3 +265,45 @@ def test_kd_checkpoint_loader_fills_the_teacher(tmp_path):
         assert torch.equal(sd[k].cpu(), v) and torch.equal(sd[f"{head}_gt.{rest}"].cpu(), v), k
     kd.fix_part_param()
     assert all(p.requires_grad != ("_gt" in n) for n, p in kd.named_parameters())
+
+
+def test_kd_feature_loss_on_device_equals_the_per_sample_loop():
+    """MinkUNetMsKd._kd_loss_on_device (no host reads) against the reference's literal loop (minkunet_ms_kd.py:617-633): equal where
+    nothing is sub-sampled; with MAX_VOXEL below the candidate counts, on features that differ from the teacher's by a constant the
+    MSE of ANY subset is that constant squared - and the gradient reaches exactly min(candidates, MAX_VOXEL) rows per sample"""
+    _, model = _build_kd()
+    torch.manual_seed(5)
+    n, nt, c, bs = 5000, 4000, 48, 3
+    batch = torch.sort(torch.randint(0, bs, (n,), device="cuda"))[0].int()
+    s2t = torch.randint(-1, nt, (n,), device="cuda")
+    s2t[torch.rand(n, device="cuda") < 0.3] = -1
+    feat_t = torch.randn(nt, c, device="cuda")
+    feat_s = torch.randn(n, c, device="cuda", requires_grad=True)
+
+    def loop(max_voxel):
+        total = feat_s.new_zeros(())
+        for b in range(bs):
+            pick = ((s2t >= 0) & (batch == b)).nonzero().reshape(-1)[:max_voxel]
+            total = total + torch.nn.functional.mse_loss(feat_s[pick], feat_t[s2t[pick]]) * model.feat_kd_weight / bs
+        return total
+
+    model.max_voxel = 100000
+    a, b = model._kd_loss_on_device(feat_s, feat_t, s2t, batch, bs), loop(100000)
+    assert abs(float(a) - float(b)) <= 1e-5 * abs(float(b))
+    ga, = torch.autograd.grad(a, feat_s)
+    gb, = torch.autograd.grad(b, feat_s)
+    assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-9)
+
+    model.max_voxel = 200
+    shifted = (feat_t[s2t.clamp(min=0)] + 0.5).detach().requires_grad_(True)
+    loss = model._kd_loss_on_device(shifted, feat_t, s2t, batch, bs)
+    assert abs(float(loss) - 0.25 * model.feat_kd_weight) <= 1e-5
+    g, = torch.autograd.grad(loss, shifted)
+    touched = (g.abs().sum(1) > 0)
+    for b in range(bs):
+        cand = int(((s2t >= 0) & (batch == b)).sum())
+        assert int((touched & (batch == b)).sum()) == min(cand, 200)
+    assert not bool((touched & (s2t < 0)).any())
+    # a sample without common voxels: NaN like mse_loss of an empty selection
+    s2t_empty = torch.where(batch == 1, torch.full_like(s2t, -1), s2t)
+    assert torch.isnan(model._kd_loss_on_device(feat_s, feat_t, s2t_empty, batch, bs))

@@ -47,7 +47,7 @@ python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collectio
 cp profiles/traffic.json $OUT/traffic.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_amp $OUT/pmc_write_amp
 say "side lines"
-for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist"; do
+for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist" "--workload kd"; do
   tag=$(echo $w | tr -d ' -'); say "bench $w"; python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary > $OUT/bench_$tag.json 2> /dev/null; done
 say "host phases"
 for w in "" "--amp"; do TASEG_BENCH_HOST_PHASES=1 python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes|second stream" | sed "s/^/[bench.py $w] /" >> $OUT/host_phases.txt; done

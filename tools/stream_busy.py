@@ -1,6 +1,8 @@
 """Per-queue busy time of a rocprofv3 --kernel-trace run: how much device time does each HIP stream (HSA queue) carry per step?
 
-    python tools/stream_busy.py <trace dir> <steps> [marker regex]
+    python tools/stream_busy.py <trace dir> <steps> [marker regex] [names]
+
+(a fourth argument lists, per queue, the kernels behind its launches: launches and busy ms per step by kernel name)
 
 Reads *_kernel_trace.csv.  The timed steps are the last <steps> occurrences of the marker kernel (default: sgd_decide_kernel, launched
 once per training step; an evaluation loop has e.g. `argmax|ArgMax`); the window runs from the end of the marker before them to the end
@@ -24,9 +26,12 @@ rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
 window = (hi - lo) / 1e6
 print(f"{steps} steps, window {window:.2f} ms = {window / steps:.3f} ms per step (under the profiler), {len(rows) / steps:.0f} launches per step")
 print(f"LAUNCHES_PER_STEP {len(rows) / steps:.1f}")
-qs = defaultdict(list)
+qs, names = defaultdict(list), defaultdict(lambda: defaultdict(lambda: [0, 0]))
 for s, e, q, n in rows:
     qs[q].append((s, e))
+    short = re.sub(r"^void |rocprim::ROCPRIM_\d+_NS::detail::|\(.*$", "", n)[:70]
+    names[q][short][0] += 1
+    names[q][short][1] += e - s
 
 
 def union(iv):
@@ -48,3 +53,8 @@ for q, iv in sorted(qs.items(), key=lambda kv: -len(kv[1])):
 allq = [x for iv in qs.values() for x in iv]
 print(f"all queues: busy {sum(e - s for s, e in allq) / 1e6 / steps:.3f} ms / step, union {union(allq) / 1e6 / steps:.3f} ms / step "
       f"({100 * union(allq) / 1e6 / window:.1f} % of the window)")
+if len(sys.argv) > 4:
+    for q, iv in sorted(qs.items(), key=lambda kv: -len(kv[1])):
+        print(f"queue {q}:")
+        for n, (cnt, ns) in sorted(names[q].items(), key=lambda kv: -kv[1][0]):
+            print(f"  {cnt / steps:7.1f} launches / step  {ns / 1e6 / steps:7.3f} ms / step  {n}")
