@@ -269,3 +269,30 @@ def test_direct_gradient_delivery_counts_the_buckets_down_like_the_hooks():
     with pytest.raises(RuntimeError, match="one backward pass per finish"):
         ret["loss"].backward()
     opt.reducer.finish()
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_training_mode_pass_without_a_graph_runs_on_the_programs(amp):
+    """train-mode BatchNorm under no_grad - the frozen teacher of MinkUNetMsKd (R/.../minkunet_ms_kd.py:533) - on the stage programs:
+    per-point features and running statistics bit-equal to the module-by-module pass, nothing kept for a backward pass"""
+    from taseg_amd.torchsparse.nn import functional as spF
+    make, n = _scan_batch(seed=9)
+    out, stats = {}, {}
+    for on in (False, True):
+        _set(on)
+        model = _model(seed=6).train()
+        bd = make()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            plan = model.prepare(bd)
+            x = bd["lidar"]
+            feats = spF.spvoxelize(x.F, plan["vox_idx"], plan["vox_counts"])
+            out[on] = model._unet(feats, x.F, plan).float().clone()
+        assert not out[on].requires_grad
+        stats[on] = {k: b.detach().clone() for k, b in model.named_buffers()}
+        compiled = bool(_set(True).compiled(model))
+        assert compiled == on
+    assert torch.equal(out[False], out[True])
+    bad = [k for k in stats[False] if not torch.equal(stats[False][k], stats[True][k])]
+    assert not bad, bad[:5]
+    moved = [k for k in stats[True] if k.endswith("num_batches_tracked") and int(stats[True][k]) != 1]
+    assert not moved, moved[:5]                       # every BatchNorm of the pass updated its running statistics once
