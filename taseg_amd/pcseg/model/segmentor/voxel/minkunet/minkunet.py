@@ -22,6 +22,7 @@ from . import stage_program as _SP
 
 __all__ = ["MinkUNet", "unvoxelise_predictions"]
 
+import contextlib
 import os as _os
 _DEVOX_ATOMIC = _os.environ.get("TASEG_DEVOX_ATOMIC", "0") == "1"
 _DEVOX_CELLS = _os.environ.get("TASEG_DEVOX_CELLS", "1") != "0"     # stride-16 devoxelize backward: cell-reduced two-stage sum
@@ -445,6 +446,16 @@ class _PinnedRing:
 
 
 _pinned = _PinnedRing()
+# TASEG_EVAL_COPY_STREAM=0: the deferred tail's device -> host copies on the launch stream
+_COPY_STREAM = _os.environ.get("TASEG_EVAL_COPY_STREAM", "1") != "0"
+_copy_streams = {}
+
+
+def _copy_stream(device):
+    s = _copy_streams.get(device)
+    if s is None:
+        s = _copy_streams[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class PendingPredictions:
@@ -609,21 +620,30 @@ def _tail_to_host(meta, result, mapped, labels_sorted, want_probs, defer, names,
     buffers, one event behind them"""
     if defer:
         _pinned.next_generation()
+    meta, result, labels_sorted = meta.contiguous(), result.contiguous(), labels_sorted.contiguous()
+    mapped = mapped if want_probs else mapped.contiguous()
 
     def to_host(key, t):
-        t = t.contiguous()
         if not defer:
             return t.reshape(-1).cpu()           # fresh arrays, as `model(batch)` has always returned them
         h = _pinned.take(key, t, t.numel())
         h.copy_(t.reshape(-1), non_blocking=True)
         return h
 
-    meta_h = to_host("meta", meta)
-    result_h = to_host("result", result)
-    mapped_h = None if want_probs else to_host("mapped", mapped)
-    labels_h = to_host("labels", labels_sorted)
-    event = torch.cuda.Event()
-    event.record()
+    # deferred: the copies (the logits of every point among them: 19 MB per bench batch) run on a stream of their own behind an
+    # event of the launch stream - there they are blit kernels that would hold the next pass's forward up (0.3 ms per pass)
+    side = _copy_stream(meta.device) if (defer and _COPY_STREAM) else None
+    if side is not None:
+        ready = torch.cuda.Event()
+        ready.record()
+        side.wait_event(ready)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        meta_h = to_host("meta", meta)
+        result_h = to_host("result", result)
+        mapped_h = None if want_probs else to_host("mapped", mapped)
+        labels_h = to_host("labels", labels_sorted)
+        event = torch.cuda.Event()
+        event.record()
     pending = PendingPredictions(event, meta_h, result_h, mapped_h, labels_h, (tuple(result.shape), tuple(mapped.shape), tuple(labels_sorted.shape)),
                                  names, n_scenes, has_ms, fused, fallback)
     # (the device tensors stay alive until the copies have run: the event's owner keeps them)
