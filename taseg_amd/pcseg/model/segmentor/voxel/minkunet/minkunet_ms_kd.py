@@ -63,8 +63,13 @@ class MinkUNetMsKd(MinkUNetBackbone):
         n, dev = s2t.shape[0], s2t.device
         b = batch_col.long()
         cand = s2t >= 0
-        key = torch.where(cand, torch.rand(n, device=dev, dtype=torch.float64), torch.full((), 2.0, device=dev, dtype=torch.float64))
-        order = torch.argsort(b.double() * 4.0 + key)                       # sample-major, candidates first, random among them
+        if batch_size <= 64:                # 31-bit keys: [sample | not a candidate | 24 random bits] - four radix passes
+            key = torch.where(cand, torch.randint(0, 1 << 24, (n,), device=dev, dtype=torch.int32),
+                              torch.full((), 1 << 24, device=dev, dtype=torch.int32))
+            order = torch.argsort(batch_col.int() * (1 << 25) + key)
+        else:
+            key = torch.where(cand, torch.rand(n, device=dev, dtype=torch.float64), torch.full((), 2.0, device=dev, dtype=torch.float64))
+            order = torch.argsort(b.double() * 4.0 + key)                       # sample-major, candidates first, random among them
         rows = torch.bincount(b, minlength=batch_size)[:batch_size]
         start = torch.cumsum(rows, 0) - rows
         rank = torch.empty(n, dtype=torch.int64, device=dev)
@@ -84,11 +89,12 @@ class MinkUNetMsKd(MinkUNetBackbone):
         x_gt = batch_dict["lidar_ms_gt"]
         x_gt.F = x_gt.F[:, :self.in_feature_dim]
         with torch.no_grad():
-            feat_t = torch.cat(self._teacher._unet_point_features(x_gt.F, x_gt.F, plan["teacher"]), dim=1)
+            # (concat=True: the three feature blocks interpolated straight into the columns of one matrix, as MinkUNet's own pass)
+            feat_t = self._teacher._unet_point_features(x_gt.F, x_gt.F, plan["teacher"], concat=True)
             batch_dict["teacher_logits"] = self.classifier_gt(feat_t)     # the reference computes them too (:573), unused
         x_ms = batch_dict["lidar_ms"]
         x_ms.F = x_ms.F[:, :self.in_feature_dim]
-        feat_s = torch.cat(self._unet_point_features(x_ms.F, x_ms.F, plan), dim=1)
+        feat_s = self._unet_point_features(x_ms.F, x_ms.F, plan, concat=True)
         out_ms = self.classifier(feat_s)
 
         if self.training:
