@@ -304,3 +304,53 @@ def test_training_mode_pass_without_a_graph_runs_on_the_programs(amp):
         assert not bad, bad[:5]
     moved = [k for k in stats[True] if k.endswith("num_batches_tracked") and int(stats[True][k]) != 1]
     assert not moved, moved[:5]                       # every BatchNorm of the pass updated its running statistics once
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_one_call_backbone_equals_the_stage_by_stage_calls(training):
+    """`StagePrograms.run_unet` (stage1 .. up4 in one native call, csrc/fastpath/stage_program.h::unet_run) against eight
+    `StagePrograms.run` calls with the dropouts between them in Python: the three feature matrices the point head reads and - in
+    training mode - every parameter gradient, bit for bit"""
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse.nn import functional as spF
+    from taseg_amd.torchsparse import nn as spnn
+    make, n = _scan_batch(seed=12)
+    SP = _set(True)
+    model = _model(seed=8)
+    model.train(training)
+    got = {}
+    for form in ("one call", "stage by stage"):
+        bd = make()
+        model.zero_grad(set_to_none=True)
+        with torch.set_grad_enabled(training):
+            plan = model.prepare(bd)
+            x = bd["lidar"]
+            feats = spF.spvoxelize(x.F, plan["vox_idx"], plan["vox_counts"])
+            x0 = SparseTensor(feats, plan["coords"], 1)
+            x0.cmaps, x0.kmaps = plan["cmaps"], plan["kmaps"]
+            x0 = spnn.conv_bn_act(model.stem[0], model.stem[1], x0, relu=True)
+            x0 = spnn.conv_bn_act(model.stem[3], model.stem[4], x0, relu=True)
+            progs = model._stage_programs(x0.F, plan)
+            assert progs is not None
+            f0 = x0.F
+            if form == "one call":
+                f4, y2, y4 = progs.run_unet(f0, plan, training, model.dropout.p)
+            else:
+                f1 = progs.run("stage1", (f0,), plan, training)
+                f2 = progs.run("stage2", (f1,), plan, training)
+                f3 = progs.run("stage3", (f2,), plan, training)
+                f4 = progs.run("stage4", (f3,), plan, training)
+                y1 = progs.run("up1", (torch.nn.functional.dropout(f4, model.dropout.p, training, False), f3), plan, training)
+                y2 = progs.run("up2", (y1, f2), plan, training)
+                y3 = progs.run("up3", (torch.nn.functional.dropout(y2, model.dropout.p, training, False), f1), plan, training)
+                y4 = progs.run("up4", (y3, f0), plan, training)
+            if training:
+                (f4.float().sum() + y2.float().sum() * 0.5 + y4.float().sum() * 0.25).backward()
+        torch.cuda.synchronize()
+        got[form] = dict(outs=[t.detach().clone() for t in (f4, y2, y4)],
+                         grads={k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    a, b = got["one call"], got["stage by stage"]
+    assert all(torch.equal(x, y) for x, y in zip(a["outs"], b["outs"]))
+    assert set(a["grads"]) == set(b["grads"]) and (len(a["grads"]) >= 180 if training else not a["grads"])
+    bad = [k for k in a["grads"] if not torch.equal(a["grads"][k], b["grads"][k])]
+    assert not bad, bad[:5]
