@@ -279,10 +279,12 @@ __global__ __launch_bounds__(KM_BLOCK) void kmap_probe_kernel(TsTable t, const i
 // writer per entry, since r's neighbour at that offset is unique; the mirrored half was filled with -1 before.  The centre probe
 // must return j itself: anything else is a duplicated coordinate, for which the symmetry does not hold - *dup is set and the caller
 // builds the map with the full probe.
+// KM_MLP look-ups in flight per round: 14 = the 13 + 1 probes of a 3x3x3 map in ONE round (two dependent round trips in all; rounds
+// of 9 made it 9 + 9 with four of the second round's probes clamped duplicates of the centre - 18 look-ups for 14).
+template <int KM_MLP>
 __global__ __launch_bounds__(KM_BLOCK) void kmap_probe_sym_kernel(TsTable t, const int4 *__restrict__ coords, int64_t n,
                                                                  const int *__restrict__ offsets, int K, int *__restrict__ nbr,
                                                                  unsigned *__restrict__ blk_counts, int nblk, int *__restrict__ dup) {
-  constexpr int KM_MLP = 9;
   extern __shared__ unsigned lds_cnt[];
   const int half = K / 2;
   for (int k = threadIdx.x; k <= half; k += KM_BLOCK) lds_cnt[k] = 0;
@@ -423,8 +425,12 @@ static int build_kmap_impl(const int32_t *in_coords, int64_t n_in, const int32_t
     TS_CHECK_LAUNCH("ts_build_kmap/insert");
   }
   if (sym) {
-    kmap_probe_sym_kernel<<<nblk, KM_BLOCK, (size_t)(half + 1) * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
-                                                                              blk_counts, nblk, dup);
+    if (half + 1 <= 14 && half + 1 > 9)
+      kmap_probe_sym_kernel<14><<<nblk, KM_BLOCK, (size_t)(half + 1) * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
+                                                                                    blk_counts, nblk, dup);
+    else
+      kmap_probe_sym_kernel<9><<<nblk, KM_BLOCK, (size_t)(half + 1) * 4, stream>>>(t, (const int4 *)out_coords, n_out, offsets, K, nbr,
+                                                                                   blk_counts, nblk, dup);
     TS_CHECK_LAUNCH("ts_build_kmap_sym/probe");
     kmap_count_kernel<<<dim3(nblk, half), KM_BLOCK, 0, stream>>>(nbr, n_out, K, blk_counts, nblk);
     TS_CHECK_LAUNCH("ts_build_kmap_sym/count");

@@ -723,7 +723,8 @@ index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num
     if (totals[2 * level] >= 0) continue;
     int st = 1 << level;
     sub[level] = make_kmap(cmaps[level], cmaps[level], kernel_offsets(3, st, cmaps[level]), stream, false);
-    totals[2 * level] = sub[level].nboffs.narrow(0, sub[level].nboffs.size(0) - 1, 1).cpu().item<int>();
+    // (reported as -(pairs + 1): the caller marks the map - no class plans, scatter form of the input gradient)
+    totals[2 * level] = -(int64_t)sub[level].nboffs.narrow(0, sub[level].nboffs.size(0) - 1, 1).cpu().item<int>() - 1;
   }
   // trilinear maps at strides 1, 16, 4 (+ the devoxelize-backward walk order of the coarse ones)
   std::vector<at::Tensor> tri_idx, tri_w, orders;

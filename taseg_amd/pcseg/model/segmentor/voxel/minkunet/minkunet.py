@@ -269,7 +269,9 @@ class MinkUNetBackbone(BaseSegmentor):
             for lvl in range(5):
                 s = 1 << lvl
                 km = spF.KernelMap(dict(zip(names, sub_t[lvl])), (cm[lvl].shape[0], cm[lvl].shape[0]))
-                km._total = int(totals[2 * lvl])
+                t = int(totals[2 * lvl])
+                # (a negative entry: the level's coordinates hold a duplicate - the map was built by the full probe, -(pairs + 1))
+                km._total, km._dup = (-t - 1, True) if t < 0 else (t, False)
                 km.build_class_plan(defer=True)       # large maps: plan of the class-sorted implicit GEMM (csrc/conv_class.hip)
                 kmaps[((s, s, s), (3, 3, 3), (1, 1, 1), (1, 1, 1))] = km
                 if lvl < 4:

@@ -186,6 +186,8 @@ class StagePrograms:
 
     def _build_geometry(self, st, plan, half):
         kmaps, cmaps = plan["kmaps"], plan["cmaps"]
+        if any(km.dup for km in kmaps.values()):
+            raise _Unsupported("a coordinate set with a duplicate: the block calls' list-form input gradient does not apply")
         rows = {i: cmaps[(s,) * 3].shape[0] for i, s in enumerate(st.in_strides)}
         dev = plan["coords"].device
         maps, op_map, pf, pfm, pd, pdm = [], [], [], [], [], []

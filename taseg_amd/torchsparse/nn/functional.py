@@ -230,6 +230,11 @@ class KernelMap:
         self.sizes = sizes
         self._nbmaps = None
         self._total = None
+        # duplicated coordinates in a map over ONE coordinate set (`dup`): an input row then has TWO pairs at one offset, which the
+        # position table pos_in [K, n_in] of the list-form input gradient cannot hold (and the map is not its own transpose, which
+        # the class plans' input gradient relies on) - such a map takes the scatter form of the input gradient and no plans
+        self._dup_dev = tables.get("dup")     # device flag (None: a map between two coordinate sets), read with the pair total
+        self._dup = None if self._dup_dev is not None else False
         self.cls = None                       # plan of the class-sorted implicit GEMM (csrc/conv_class.hip), large 3x3x3 maps
         self._cls_pending = None              # ... launched, not yet judged (accept_class_plans)
         self.direct = None                    # {"down", "up"}: direct plans of a 2x2x2 strided map (no Z, no pass 2)
@@ -241,7 +246,7 @@ class KernelMap:
         gain (class_gemm_pays) go without.  defer=True only launches the builder: `accept_class_plans` then judges the plans of
         several maps with ONE host read (an index plan has three such maps)."""
         if (_CLASS_GEMM and self.cls is None and self._cls_pending is None and self.nbr.shape[0] == 27
-                and self.sizes[0] == self.sizes[1] and self.sizes[0] >= _CLASS_MIN_ROWS):
+                and self.sizes[0] == self.sizes[1] and self.sizes[0] >= _CLASS_MIN_ROWS and not self.dup):
             self._cls_pending = B.conv_class_plan(self.nbr)
         if not defer:
             accept_class_plans([self])
@@ -295,7 +300,7 @@ class KernelMap:
         return hit
 
     def _choose_plans(self, transposed, c_in, c_out, half):
-        if not _dense_ok(c_in, c_out):
+        if not _dense_ok(c_in, c_out) or self.dup:
             return None, None
         if self.cls is not None and not transposed and class_gemm_pays(self.cls["n"], c_in, c_out, half):
             return self.cls, self.cls
@@ -315,8 +320,22 @@ class KernelMap:
         """number of pairs P: the one host read of a kernel map (sizes the pair-GEMM grid and its Z buffer);
         `build_pyramid` fills it for all maps of a forward pass with a single device->host copy"""
         if self._total is None:
-            self._total = int(self.nboffs[-1].item())
+            if self._dup is None:
+                t, d = torch.stack([self.nboffs[-1], self._dup_dev.to(self.nboffs.dtype)]).tolist()      # (still one read)
+                self._total, self._dup = int(t), bool(d)
+            else:
+                self._total = int(self.nboffs[-1].item())
         return self._total
+
+    @property
+    def dup(self) -> bool:
+        """does the map's one coordinate set hold a coordinate twice?  (False for maps between two coordinate sets)"""
+        if self._dup is None:
+            if self._total is None:
+                self.total
+            else:
+                self._dup = bool(self._dup_dev.item())
+        return self._dup
 
     @property
     def nbmaps(self) -> torch.Tensor:
@@ -407,6 +426,11 @@ def direct_conv_pays(up: bool, n_dest: int, c_red: int, c_cols: int, half: bool)
 def build_kernel_map(in_coords, out_coords, kernel_size, tensor_stride, dilation=1) -> KernelMap:
     offsets = get_kernel_offsets(kernel_size, stride=tensor_stride, dilation=dilation, device=in_coords.device)
     tables = B.build_kmap(in_coords, out_coords, offsets)
+    k, n = offsets.shape[0], out_coords.shape[0]
+    if (k & 1) and n > 0 and in_coords.shape == out_coords.shape and in_coords.data_ptr() == out_coords.data_ptr():
+        # one coordinate set, odd kernel: the centre offset of row j must find j itself - anything else is a coordinate held twice
+        # (the table keeps one row per coordinate, minkunet/utils.py / hash semantics of sphashquery)
+        tables["dup"] = (tables["nbr"][k // 2] != torch.arange(n, device=out_coords.device, dtype=tables["nbr"].dtype)).any()
     return KernelMap(tables, (in_coords.shape[0], out_coords.shape[0]))
 
 
@@ -474,7 +498,7 @@ class _SparseConv(Function):
                     out = class_conv(fh, w16, cls, True)
                 else:
                     z = B.conv_pair_gemm_f16(fh, w16, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol, natural=True)
-                    out = B.conv_gather_sum_f16(z, table, rows)
+                    out = _scatter_pairs(z, kmap, False, rows) if (transposed and kmap.dup) else B.conv_gather_sum_f16(z, table, rows)
                 ctx.save_for_backward(fh, w16)
             else:
                 # pass 1: z[p] = feats[source row of pair p] @ W[k(p)];  pass 2: out[row] = sum_k z[pos[k, row]]
@@ -486,7 +510,8 @@ class _SparseConv(Function):
                 else:
                     _planes.hint(w32, planes)
                     z = B.conv_pair_gemm(f32, w32, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
-                    out = B.conv_gather_sum(z, table, rows)
+                    # (a transposed product over a map with duplicated coordinates: two pairs may end in one row - scatter form)
+                    out = _scatter_pairs(z, kmap, False, rows) if (transposed and kmap.dup) else B.conv_gather_sum(z, table, rows)
                 ctx.save_for_backward(f32, w32)
                 if want_half:
                     out = out.half()          # stem (C_in = 4 / 5): fp32 kernels, half result like the reference
@@ -512,7 +537,8 @@ class _SparseConv(Function):
                 elif ctx.needs_input_grad[0]:
                     # d feats[i] = sum_k grad_out[partner(i, k)] @ W_k^T: rows of W_k (= w16) are the output columns
                     z = B.conv_pair_gemm_f16(gh, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol)
-                    grad_feats = B.conv_gather_sum_f16(z, table, rows).to(ctx.in_dtype)
+                    grad_feats = (_scatter_pairs(z, kmap, transposed, rows) if kmap.dup else
+                                  B.conv_gather_sum_f16(z, table, rows)).to(ctx.in_dtype)
                 if ctx.needs_input_grad[1]:
                     grad_weight = B.conv_wgrad_f16(feats, gh, kmap.nbmaps_buf, kmap.nboffs, k,
                                                    col_a=1 if transposed else 0, max_pairs=kmap.total)
@@ -524,11 +550,21 @@ class _SparseConv(Function):
                     _planes.hint(weight, ctx.planes)
                     z = B.conv_pair_gemm(g32, weight, kmap.nbmaps_buf, kmap.nboffs, kmap.total, gather_col=gcol,
                                          weight_transposed=True)
-                    grad_feats = B.conv_gather_sum(z, table, rows).to(ctx.in_dtype)
+                    grad_feats = (_scatter_pairs(z, kmap, transposed, rows) if kmap.dup else
+                                  B.conv_gather_sum(z, table, rows)).to(ctx.in_dtype)
                 if ctx.needs_input_grad[1]:
                     grad_weight = B.conv_wgrad(feats, g32, kmap.nbmaps_buf, kmap.nboffs, k,
                                                col_a=1 if transposed else 0, max_pairs=kmap.total)
         return grad_feats, grad_weight, None, None, None
+
+
+def _scatter_pairs(z, kmap, transposed, rows):
+    """input gradient of a map with duplicated coordinates: the rows of the per-pair product added into their input rows like the
+    reference's scatter (convolution_cuda.cu:153-161) - the list form reads ONE pair per (offset, input row)"""
+    total = kmap.total
+    idx = kmap.nbmaps_buf[:total, 1 if transposed else 0].long()
+    out = torch.zeros((rows, z.shape[1]), dtype=torch.float32, device=z.device)
+    return out.index_add_(0, idx, z[:total].float()).to(z.dtype)
 
 
 def build_pyramid(x: SparseTensor, num_levels: int = 4, kernel_size: int = 3, down_kernel: int = 2) -> None:
@@ -561,9 +597,13 @@ def build_pyramid(x: SparseTensor, num_levels: int = 4, kernel_size: int = 3, do
         coords, stride = x.cmaps[nxt], nxt
     pending = [m for m in maps if m._total is None]
     if pending:
-        totals = torch.stack([m.nboffs[-1] for m in pending]).tolist()      # one sync for all maps
-        for m, t in zip(pending, totals):
+        zero = pending[0].nboffs.new_zeros(())
+        flags = [zero if m._dup_dev is None else m._dup_dev.to(zero.dtype) for m in pending]
+        totals = torch.stack([m.nboffs[-1] for m in pending] + flags).tolist()      # one sync for all maps
+        for m, t, d in zip(pending, totals, totals[len(pending):]):
             m._total = int(t)
+            if m._dup is None:
+                m._dup = bool(d)
     del cur
 
 
@@ -729,6 +769,7 @@ class IdentityMap:
     direction (csrc/block.hip, TsConvBlockOpts.natural) instead of a GEMM node + a BatchNorm node.  Cached per (n, device) like
     `_identity_rows`."""
     __slots__ = ("nbmaps_buf", "nboffs", "total", "pos_out", "pos_in", "sizes")
+    dup = False                        # (one pair per row)
 
     def __init__(self, n, dev):
         pairs, offs = _identity_rows(n, dev)
@@ -1018,7 +1059,7 @@ def conv_block_ok(feats: torch.Tensor, weight: torch.Tensor, kmap: "KernelMap", 
         return False
     if not half and feats.dtype != torch.float32:
         return False
-    if c_out % (8 if half else 4) != 0 or c_out > 1024 or rows <= 0 or kmap.total <= 0 or weight.shape[0] > 63:
+    if c_out % (8 if half else 4) != 0 or c_out > 1024 or rows <= 0 or kmap.total <= 0 or weight.shape[0] > 63 or kmap.dup:
         return False
     if feats.shape[1] != c_in:
         return False

@@ -1161,10 +1161,58 @@ def test_symmetric_submanifold_kernel_maps_equal_the_full_probe(dup):
         offs = get_kernel_offsets(3, stride=s, dilation=1, device=c.device)
         full = B.build_kmap(cm[lvl], cm[lvl], offs)
         total = int(full["nboffs"][-1])
-        assert int(totals[2 * lvl]) == total
+        # (a level whose coordinates hold a duplicate is reported as -(pairs + 1): the caller marks its map, functional.KernelMap.dup;
+        # every coarser level is unique again - spdownsample deduplicates)
+        assert int(totals[2 * lvl]) == (-(total + 1) if (dup and lvl == 0) else total)
         got = dict(zip(names, sub_t[lvl]))
         for k in names:
+            if dup and lvl == 0 and k == "pos_in":
+                continue      # two pairs per (offset, input row) there: the table holds whichever was written last
             a, b = got[k], full[k]
             if k == "nbmaps":
                 a, b = a[:total], b[:total]
             assert torch.equal(a, b), (lvl, k)
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_convolution_over_duplicated_coordinates_sums_every_pair(half):
+    """a coordinate held twice (the reference's API does not forbid it): the rulebook then has two pairs per (offset, input row),
+    which the list-form input gradient cannot hold - the map is marked (`KernelMap.dup`) and takes the scatter form, like the
+    reference's `convolution_backward` (convolution_cuda.cu:153-161, 236-263).  Output, input gradient and weight gradient against
+    the plain sum over the rulebook in float64"""
+    from taseg_amd.torchsparse import SparseTensor
+    from taseg_amd.torchsparse import nn as spnn
+    g = torch.Generator().manual_seed(3)
+    base = torch.unique(torch.randint(0, 12, (600, 3), generator=g), dim=0)
+    coords = torch.cat([base, base[5:9]], 0)                       # four voxels twice
+    coords = torch.cat([coords, torch.zeros(len(coords), 1, dtype=coords.dtype)], 1).int().cuda()
+    c_in, c_out = 32, 64
+    feats = torch.randn(len(coords), c_in, generator=g).cuda().requires_grad_(True)
+    conv = spnn.Conv3d(c_in, c_out, 3).cuda()
+    x = SparseTensor(feats.half() if half else feats, coords)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+        y = conv(x)
+    km = x.kmaps[((1, 1, 1), (3, 3, 3), (1, 1, 1), (1, 1, 1))]
+    assert km.dup
+    go = torch.randn(y.F.shape, generator=g).cuda()
+    (y.F.float() * go).sum().backward()
+    # the rulebook sum in float64
+    nbmaps, nbsizes = km.nbmaps.cpu(), km.nbsizes.cpu()
+    f64 = feats.detach().double().cpu().requires_grad_(True)
+    w64 = conv.kernel.detach().double().cpu().requires_grad_(True)
+    out = torch.zeros(len(coords), c_out, dtype=torch.float64)
+    at = 0
+    for k, n in enumerate(nbsizes.tolist()):
+        pr = nbmaps[at:at + n]
+        out = out.index_add(0, pr[:, 1], f64[pr[:, 0]] @ w64[k])
+        at += n
+    (out * go.double().cpu()).sum().backward()
+    tol = 2e-2 if half else 1e-5
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())  # noqa: E731
+    assert rel(y.F.detach(), out.detach()) <= tol
+    assert rel(feats.grad, f64.grad) <= tol
+    assert rel(conv.kernel.grad, w64.grad) <= tol
+    # the same coordinates without the repeats: an ordinary map
+    x1 = SparseTensor(feats.detach()[:len(base)], coords[:len(base)].contiguous())
+    conv(x1)
+    assert not x1.kmaps[((1, 1, 1), (3, 3, 3), (1, 1, 1), (1, 1, 1))].dup
