@@ -66,20 +66,63 @@ def single_communicator() -> bool:
     """TASEG_DIST_SINGLE_COMM (default 1): SyncBatchNorm's statistics all-reduces go through torch.distributed's default
     process group (c10d, on the compute stream) like nn.SyncBatchNorm under DDP in the reference (R/train.py:247-251); the
     gradient buckets always use a communicator of their own (parallel.GradBucketReducer), launched in bucket-index order.
-    TASEG_DIST_SINGLE_COMM=0 moves the statistics onto a library-owned RCCL communicator inline on the compute stream
-    (~1 ms per step faster on one rank) - not the default until it has run with more than one rank on real devices
+    By default the library issues them on that group's own communicator itself (`_borrow`: the same RCCL calls on the same
+    communicator and stream, without c10d's per-call dispatch).  TASEG_DIST_SINGLE_COMM=0 moves the statistics onto a communicator
+    CREATED by this module - not the default until it has run with more than one rank on real devices
     (tests/test_gpu_dist.py::test_two_ranks_rccl needs two GPUs and has been skipped on every box so far)."""
     return os.environ.get("TASEG_DIST_SINGLE_COMM", "1") != "0"
 
 
+def _borrow(group):
+    """The process group's OWN RCCL communicator (ProcessGroupNCCL._comm_ptr) as the handle of the direct path: the statistics
+    all-reduces are then the same `ncclAllReduce` calls on the same communicator and the same (current) stream that
+    `c10d_sum` makes through the dispatcher - issued from the library instead (126 calls per training step, ~10-16 us of host time
+    each through c10d).  Nothing is created or bootstrapped here; the handle is never destroyed by this module.  None where the
+    group's backend has no such communicator (gloo) or the self-test fails on any rank."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = L.load()
+    ok, comm = True, None
+    try:
+        backend = group._get_backend(dev) if hasattr(group, "_get_backend") else None
+        if backend is None or not hasattr(backend, "_comm_ptr"):
+            return None                                   # (a property of the group's type: the same answer on every rank)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        L.check(lib.ts_rccl_load(path.encode() if os.path.exists(path) else None), "ts_rccl_load")
+        # the communicator of a device exists after the group's first collective on it
+        t = torch.tensor([dist.get_rank(group) + 1.0, 1.0], dtype=torch.float64, device=dev)
+        want = t.clone()
+        c10d_sum(want, group)
+        comm = ctypes.c_void_p(int(backend._comm_ptr()))
+        ok = bool(comm.value) and lib.ts_rccl_allreduce_f64(comm, L.ptr(t), 2, L.stream()) == 0 and torch.equal(t, want)
+    except Exception as e:  # noqa: BLE001 - any failure means "go through torch.distributed"
+        warnings.warn(f"taseg_amd: the process group's communicator cannot be used directly ({e}); SyncBatchNorm goes through "
+                      f"torch.distributed")
+        ok = False
+    if not _agree(ok, group, dev):
+        return None
+    _borrowed.add(id(group))
+    return comm
+
+
+_borrowed = set()
+
+
 def direct_comm(group):
-    """Communicator handle (ctypes.c_void_p) for `group`, created on first use; None = use dist.all_reduce.
-    Off under TASEG_DIST_SINGLE_COMM (the default) unless TASEG_RCCL_DIRECT=1 asks for it explicitly."""
+    """Communicator handle (ctypes.c_void_p) for `group`, resolved on first use (collectively: every rank reaches the first
+    SyncBatchNorm forward); None = go through torch.distributed (`c10d_sum`).
+      default (TASEG_DIST_SINGLE_COMM=1, TASEG_RCCL_DIRECT unset): the group's OWN communicator, called from the library (`_borrow`) -
+        the calls c10d would make, without its dispatch; where that is not available (gloo), torch.distributed;
+      TASEG_RCCL_DIRECT=0: always through torch.distributed;
+      TASEG_RCCL_DIRECT=1 or TASEG_DIST_SINGLE_COMM=0: a communicator created by this module (`_create`)."""
     key = id(group)
     if key not in _comms:
         want = os.environ.get("TASEG_RCCL_DIRECT")
-        on = (want == "1") if want is not None else not single_communicator()
-        _comms[key] = _create(group) if on else None
+        if want == "0":
+            _comms[key] = None
+        elif want == "1" or not single_communicator():
+            _comms[key] = _create(group)
+        else:
+            _comms[key] = _borrow(group)
     return _comms[key]
 
 
@@ -111,6 +154,7 @@ def shutdown():
     _modules._group_ids.clear()
     lib = L.load()
     for key, comm in list(_comms.items()):
-        if comm is not None and comm.value:
+        if comm is not None and comm.value and key not in _borrowed:      # (a borrowed communicator belongs to its process group)
             lib.ts_rccl_comm_destroy(comm)
         del _comms[key]
+    _borrowed.clear()

@@ -300,10 +300,12 @@ def test_flat_sgd_leaves_parameters_without_gradient_alone():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), n
 
 
-def test_syncbn_collective_path_on_one_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["created", "borrowed"])
+def test_syncbn_collective_path_on_one_rank(tmp_path, mode):
     """The SyncBatchNorm / DDP code path that `bench.py --gpus N` executes, on a one-rank RCCL group: fused BN+act
     with the all-reduce between reduction and apply must equal the single-process path, and a DDP-wrapped training
-    step must run (the multi-GPU scaling bench cannot be launched from the build box)."""
+    step must run (the multi-GPU scaling bench cannot be launched from the build box).  mode: the direct path on a communicator
+    the library creates (TASEG_RCCL_DIRECT=1) / on the process group's own communicator (the default, rccl._borrow)."""
     import os
     import subprocess
     import sys
@@ -323,7 +325,12 @@ w = (torch.rand(c, generator=g) + 0.5).cuda().requires_grad_()
 b = torch.randn(c, generator=g).cuda().requires_grad_()
 from taseg_amd import rccl
 comm = rccl.direct_comm(dist.group.WORLD)
-assert comm is not None and comm.value, "library-owned RCCL communicator was not created"
+assert comm is not None and comm.value, "no communicator for the direct path"
+if os.environ["MODE"] == "borrowed":
+    assert id(dist.group.WORLD) in rccl._borrowed
+    assert comm.value == dist.group.WORLD._get_backend(torch.device("cuda"))._comm_ptr()
+else:
+    assert not rccl._borrowed
 for dtype, tol in ((torch.float32, 2e-4), (torch.float16, 2e-2)):      # fp32 and half-storage activations
     outs = []
     # single process | SyncBN with the library's own communicator (csrc/rccl.hip) | SyncBN through the process group
@@ -361,11 +368,17 @@ ret, _, _ = net(bd)
 ret["loss"].mean().backward()
 assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 rccl.shutdown()
+t = torch.ones(4, device="cuda")
+dist.all_reduce(t)                      # (a borrowed communicator is still the process group's: not destroyed by shutdown())
+assert float(t.sum()) == 4.0
 dist.destroy_process_group()
 print("SYNC_OK")
 '''
-    # TASEG_RCCL_DIRECT=1: the library-owned communicator is opt-in while TASEG_DIST_SINGLE_COMM is the default (taseg_amd/rccl.py)
-    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), TASEG_RCCL_DIRECT="1")
+    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MODE=mode)
+    env.pop("TASEG_RCCL_DIRECT", None)
+    env.pop("TASEG_DIST_SINGLE_COMM", None)
+    if mode == "created":
+        env["TASEG_RCCL_DIRECT"] = "1"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "SYNC_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
