@@ -81,24 +81,47 @@ def _borrow(group):
     group's backend has no such communicator (gloo) or the self-test fails on any rank."""
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = L.load()
-    ok, comm = True, None
+    backend = None
     try:
         backend = group._get_backend(dev) if hasattr(group, "_get_backend") else None
-        if backend is None or not hasattr(backend, "_comm_ptr"):
-            return None                                   # (a property of the group's type: the same answer on every rank)
+    except Exception:  # noqa: BLE001 - a group without a device backend
+        backend = None
+    if backend is None or not hasattr(backend, "_comm_ptr"):
+        return None                                       # (a property of the group's type: the same answer on every rank)
+
+    def step(fn):
+        """one rank-local step; afterwards the ranks agree whether ALL of them succeeded (every rank issues the same collectives
+        in the same order whatever happens locally)"""
+        ok = True
+        try:
+            ok = bool(fn())
+        except Exception as e:  # noqa: BLE001 - any failure means "go through torch.distributed"
+            warnings.warn(f"taseg_amd: the process group's communicator cannot be used directly ({e}); SyncBatchNorm goes through "
+                          f"torch.distributed")
+            ok = False
+        return _agree(ok, group, dev)
+
+    def load():
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         L.check(lib.ts_rccl_load(path.encode() if os.path.exists(path) else None), "ts_rccl_load")
-        # the communicator of a device exists after the group's first collective on it
-        t = torch.tensor([dist.get_rank(group) + 1.0, 1.0], dtype=torch.float64, device=dev)
-        want = t.clone()
-        c10d_sum(want, group)
-        comm = ctypes.c_void_p(int(backend._comm_ptr()))
-        ok = bool(comm.value) and lib.ts_rccl_allreduce_f64(comm, L.ptr(t), 2, L.stream()) == 0 and torch.equal(t, want)
-    except Exception as e:  # noqa: BLE001 - any failure means "go through torch.distributed"
-        warnings.warn(f"taseg_amd: the process group's communicator cannot be used directly ({e}); SyncBatchNorm goes through "
-                      f"torch.distributed")
-        ok = False
-    if not _agree(ok, group, dev):
+        return True
+
+    if not step(load):
+        return None
+    # the communicator of a device exists after the group's first collective on it
+    t = torch.tensor([dist.get_rank(group) + 1.0, 1.0], dtype=torch.float64, device=dev)
+    want = t.clone()
+    c10d_sum(want, group)
+    comm = ctypes.c_void_p()
+
+    def handle():
+        comm.value = int(backend._comm_ptr())
+        return bool(comm.value)
+
+    if not step(handle):
+        return None
+    # one all-reduce through the library on the borrowed handle against the group's own result
+    if not step(lambda: lib.ts_rccl_allreduce_f64(comm, L.ptr(t), 2, L.stream()) == 0 and torch.equal(t, want)):
         return None
     _borrowed.add(id(group))
     return comm

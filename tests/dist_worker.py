@@ -135,6 +135,7 @@ def main():
     out.update(pack("", *one_step(build(os.environ.get("TASEG_WORKER_LOCAL_BN") != "1"), [scan], group, amp=amp)))
     direct = rccl.direct_comm(dist.group.WORLD)
     out["direct_rccl"] = np.int64(1 if direct is not None else 0)
+    out["borrowed"] = np.int64(1 if id(dist.group.WORLD) in rccl._borrowed else 0)
     if backend == "nccl" and world > 1:
         # (a) the same step with the SyncBatchNorm collectives through torch.distributed
         rccl._comms[id(dist.group.WORLD)] = None

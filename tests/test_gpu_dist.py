@@ -133,17 +133,22 @@ def test_flat_sgd_unused_parameter_rule_is_global(tmp_path):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two ROCm devices (RCCL refuses two ranks on one)")
 def test_two_ranks_rccl(tmp_path):
-    """the RCCL wire (needs two devices): first the DEFAULT arrangement - one communicator, SyncBatchNorm and gradient buckets
-    through torch.distributed's default group (TASEG_DIST_SINGLE_COMM=1) - then the library-owned communicator for
-    SyncBatchNorm beside a dedicated bucket group (TASEG_DIST_SINGLE_COMM=0), each against ONE process on the concatenated batch"""
+    """the RCCL wire (needs two devices): first the DEFAULT arrangement - SyncBatchNorm's all-reduces on torch.distributed's
+    default group's own communicator, issued by the library (rccl._borrow; the "c10d/" half of every worker repeats the step
+    through torch.distributed's dispatcher), gradient buckets on a group of their own - then a communicator the library CREATES for
+    SyncBatchNorm (TASEG_DIST_SINGLE_COMM=0), each against ONE process on the concatenated batch"""
     (tmp_path / "single").mkdir()
     (tmp_path / "direct").mkdir()
     ranks, _ = _run_ranks(2, "nccl", tmp_path / "single")
-    assert int(ranks[0]["direct_rccl"]) == 0                   # the default keeps the library-owned communicator out
+    assert int(ranks[0]["direct_rccl"]) == 1 and int(ranks[0]["borrowed"]) == 1      # the process group's own communicator
     _check_against_single(ranks)
     _check_against_single(ranks, "c10d/")
+    for got in ranks:                  # the same RCCL calls on the same communicator, issued from two places
+        for k in got:
+            if k.startswith("c10d/"):
+                assert np.allclose(got[k], got[k[5:]], rtol=1e-6, atol=1e-7), k
     ranks, outs = _run_ranks(2, "nccl", tmp_path / "direct", {"TASEG_DIST_SINGLE_COMM": "0"})
-    assert int(ranks[0]["direct_rccl"]) == 1, "the library-owned RCCL communicator was not created"
+    assert int(ranks[0]["direct_rccl"]) == 1 and int(ranks[0]["borrowed"]) == 0, "the library-owned RCCL communicator was not created"
     _check_against_single(ranks)
     _check_against_single(ranks, "c10d/")
     for got in ranks:                  # both SyncBatchNorm transports run the same kernels around the same sums
