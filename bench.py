@@ -141,6 +141,8 @@ def parse():
     ap.add_argument("--eval", action="store_true",
                     help="evaluation pass instead of a training step: eval-mode forward on the index plan + un-voxelisation + "
                          "arg-max per point, as the segmentors' eval branch returns it (minkunet.py:435-455, R/train.py:452-540)")
+    ap.add_argument("--image-layout", default=None, choices=["nhwc", "nchw"],
+                    help="tiaf: memory format of UNet2D and form of the image gather (default: taseg_amd.options.image_layout = nhwc)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short runs of the other workloads (minkunet_ms, --amp, nuscenes_ms --amp) that the "
                          "default N=1 run appends as `secondary`")
@@ -237,11 +239,14 @@ def make_tiaf_frames(rank, batch, points, n_beams=64, n_az=2083):
     return samples, proj, npts
 
 
-def tiaf_gather_roofline(model, bd):
-    """The image -> point gather and its adjoint (csrc/image.hip) alone on the device, at the shapes of this batch: HIP events
-    around 20 launches each on the current stream; algorithmic bytes n * C * 4 gathered + n * C * 4 written (forward), n * C * 4
-    read + 2 * 4 * C per touched pixel read-modify-written (adjoint, into the map's other gradient)."""
+def tiaf_gather_roofline(model, bd, layout="nhwc", dtype=torch.float32):
+    """The image -> point gather and its adjoint (csrc/image.hip) alone on the device, at the shapes of this batch, in the memory
+    format and element type the step uses (channels-last rows / NCHW planes; fp32 / the fp16 maps of an autocast step): HIP events
+    around 20 launches each on the current stream; algorithmic bytes n * C * s gathered + n * C * s written (forward), n * C * s
+    read + 2 * s * C per touched pixel read-modify-written (adjoint, into the map's other gradient), s = element size."""
     from taseg_amd import backend as B
+    rows = layout == "nhwc"
+    es = 2 if (rows and dtype == torch.float16) else 4
     fov = bd["lidar_fov_ms"]
     pix = fov.F[:, -2:].float().contiguous()
     pbatch = fov.C[:, -1].int().contiguous()
@@ -253,10 +258,16 @@ def tiaf_gather_roofline(model, bd):
         hs, ws = plan["shape"]
         feat = torch.randn(T, c, hs, ws, device="cuda")
         gout = torch.randn(plan["n"], c, device="cuda")
+        if rows:
+            feat = feat.to(dtype).contiguous(memory_format=torch.channels_last)
+            gout = gout.to(dtype)
+            fwd, adj = (lambda: B.image_gather_rows_forward(feat, plan)), (lambda: B.image_gather_rows_backward(gout, plan, c, into=feat))
+        else:
+            fwd, adj = (lambda: B.image_gather_forward(feat, plan)), (lambda: B.image_gather_backward(gout, plan, c, into=feat))
         touched = int((plan["run"][:plan["n"]] > 0).sum())
-        rec = {"map": name, "points": plan["n"], "touched_pixels": touched}
-        for kind, fn, byts in (("forward", lambda: B.image_gather_forward(feat, plan), plan["n"] * c * 8.0),
-                               ("adjoint", lambda: B.image_gather_backward(gout, plan, c, into=feat), plan["n"] * c * 4.0 + touched * c * 8.0)):
+        rec = {"map": name, "points": plan["n"], "touched_pixels": touched, "layout": layout, "element_bytes": es}
+        for kind, fn, byts in (("forward", fwd, plan["n"] * c * 2.0 * es),
+                               ("adjoint", adj, plan["n"] * c * 1.0 * es + touched * c * 2.0 * es)):
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -269,6 +280,75 @@ def tiaf_gather_roofline(model, bd):
             rec[kind] = {"avg_us": us, "algorithmic_bytes": byts, "achieved_GBs": byts / us / 1e3, "hbm_frac": byts / us / 1e3 / HBM_PEAK_GBS}
         out.append(rec)
         del feat, gout
+    return out
+
+
+def tiaf_phase_table(model, net, opt, make_batch, amp, steps=3):
+    """Where a TIAF step's DEVICE time goes, by branch: `steps` further steps after the timed region, staged in line (no
+    prefetcher), with HIP events at the branch boundaries - forward hooks around UNet2D (with its gathers) and UNet3D, a tensor hook
+    on the gathered image features (their gradient is complete when the sparse branches' backward is: what follows is the gather
+    adjoints + UNet2D's backward; the dense image loss's own backward runs first and is counted with the sparse part).
+    Milliseconds per step, averages."""
+    marks_all = []
+    cur = {}
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        cur[name] = e
+
+    def tensor_mark(name):
+        def hook(grad):
+            if name not in cur:
+                mark(name)
+            return grad
+        return hook
+
+    def after_unet2d(mod, inp, out):
+        mark("unet2d_out")
+        feats = out["image_features_fov"]
+        if feats.requires_grad:
+            feats.register_hook(tensor_mark("bwd_features"))
+
+    hooks = [model.image_backbone.register_forward_pre_hook(lambda m, i: mark("unet2d_in")),
+             model.image_backbone.register_forward_hook(after_unet2d),
+             model.lidar_backbone.register_forward_pre_hook(lambda m, i: mark("unet3d_in")),
+             model.lidar_backbone.register_forward_hook(lambda m, i, o: mark("unet3d_out"))]
+    try:
+        for _ in range(steps):
+            cur = {}
+            opt.zero_grad(set_to_none=True)
+            mark("start")
+            bd = make_batch()
+            model.prepare(bd)
+            mark("staged")
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                ret, _, _ = net(bd)
+            loss = ret["loss"].float().mean()
+            mark("forward_done")
+            (loss * opt.loss_scale()).backward()
+            mark("backward_done")
+            opt.step()
+            mark("optimizer_done")
+            marks_all.append(cur)
+        torch.cuda.synchronize()
+    finally:
+        for h in hooks:
+            h.remove()
+    spans = (("data stage (16-scan fuse x 3 clouds, projection, voxelisation, index plan)", "start", "staged"),
+             ("forward: up to UNet2D (input stack)", "staged", "unet2d_in"),
+             ("forward: UNet2D + image gathers", "unet2d_in", "unet2d_out"),
+             ("forward: FOV feature concat", "unet2d_out", "unet3d_in"),
+             ("forward: UNet3D (FOV cloud)", "unet3d_in", "unet3d_out"),
+             ("forward: MinkUNet on the fused cloud + fusion head + five losses", "unet3d_out", "forward_done"),
+             ("backward: losses, fusion head, MinkUNet, UNet3D, dense image loss", "forward_done", "bwd_features"),
+             ("backward: gather adjoints + UNet2D", "bwd_features", "backward_done"),
+             ("optimizer (clip + SGD)", "backward_done", "optimizer_done"))
+    out = {}
+    for name, a, b in spans:
+        vals = [m[a].elapsed_time(m[b]) for m in marks_all if a in m and b in m]
+        out[name] = round(sum(vals) / len(vals), 3) if vals else None
+    out["step (staged in line)"] = round(sum(m["start"].elapsed_time(m["optimizer_done"]) for m in marks_all) / len(marks_all), 3)
     return out
 
 
@@ -806,7 +886,8 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            os.environ["TASEG_SYNCBN_SINGLE_RANK"] = "1"
+            from taseg_amd.options import options as _opts
+            _opts.syncbn_single_rank = True      # the collective path on a one-rank group
         dog.beat("init_process_group")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     dog.beat("build model and inputs")
@@ -837,7 +918,10 @@ def main():
     extra_cfg = {}
     if tiaf:
         from taseg_amd.data.synthetic import TIAF_CFG
+        from taseg_amd.options import options as _opts
         extra_cfg = dict(TIAF_CFG)
+        if args.image_layout:
+            _opts.image_layout = args.image_layout
     if kd:
         extra_cfg = dict(SAMPLING_TYPE="random", MAX_VOXEL=3000, FEAT_KD="mse", FEAT_KD_WEIGHT=10.0)      # kd yaml :35-38
     cfg = make_model_cfg(name, in_dim=(4 if nusc else 5) if ms else 4, cr=1.0, if_dist=use_dist and not args.local_bn, **extra_cfg)
@@ -1134,8 +1218,23 @@ def main():
             "ideal_fused_bytes_per_step": sum(r["ideal_fused_bytes_per_step"] for r in prof) if prof else None,
         }
         if tiaf:
+            from taseg_amd.options import options as _opts
             line["config"]["fov_points_per_step_per_gpu"] = n_fov[0]
-            line["image_gather"] = tiaf_gather_roofline(model, pf._current if pf is not None and pf._current is not None else make_batch())
+            line["config"]["image_layout"] = _opts.image_layout
+            gat = tiaf_gather_roofline(model, pf._current if pf is not None and pf._current is not None else make_batch(),
+                                       _opts.image_layout, torch.float16 if args.amp else torch.float32)
+            line["image_gather"] = gat
+            # the line's roofline object: the hand-written kernel of this workload that moves the most bytes - the gather of the
+            # 96-channel full-resolution map - forward and adjoint (HBM-bound: algorithmic bytes / event-bracketed launch time)
+            u4 = gat[0]
+            line["roofline"] = {"bound": "hbm", "kernel": "image_rows_gather_kernel / image_rows_scatter_kernel (u4)" if _opts.image_layout == "nhwc"
+                                else "image_gather_rows_kernel / image_scatter_rows_kernel (u4)",
+                                "achieved": u4["forward"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u4["forward"]["hbm_frac"],
+                                "traffic": None, "avg_us": u4["forward"]["avg_us"], "algorithmic_bytes_per_launch": u4["forward"]["algorithmic_bytes"],
+                                "adjoint": u4["adjoint"], "all_maps": [{"map": g_["map"], "forward_hbm_frac": round(g_["forward"]["hbm_frac"], 3),
+                                                                         "adjoint_hbm_frac": round(g_["adjoint"]["hbm_frac"], 3)} for g_ in gat]}
+            if flat:
+                line["phases_ms"] = tiaf_phase_table(model, net, opt, make_batch, args.amp)
         if kd:
             line["config"]["teacher_voxels_per_step_per_gpu"] = nvox_gt[0]
         if world == 1 and not args.no_cpu_baseline and not nusc and not tiaf and not kd:      # cpu_baseline is defined on the KITTI-shaped scan

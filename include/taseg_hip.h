@@ -45,6 +45,28 @@ const char *ts_version(void);
 /* Thread-local message describing the last non-TS_OK return. */
 const char *ts_last_error(void);
 
+/* Tuning values of the library (process-wide; the host side's options object - taseg_amd/options.py - pushes its fields when it
+ * loads the library; the library itself reads no environment variable).  0 is every key's default.
+ *   TS_OPT_GATHER_POSITIONS        != 0: pass 2 with K position registers per lane instead of LDS lists
+ *   TS_OPT_WGRAD_WGS               workgroup target of the weight gradient's chunking (64 .. 8192; 0 = 512)
+ *   TS_OPT_EVAL_TAIL_SEPARATE      != 0: the evaluation block's BatchNorm tail as a launch of its own
+ *   TS_OPT_CLASS_FINISH_ROWS[_HALF] rows from which a class plan's finish runs inside the product (0 = never)
+ *   TS_OPT_DEBUG_BN_ABLATE         timing diagnostics of csrc/bn.hip (bit field)
+ *   TS_OPT_KMAP_FULL_PROBE         != 0: submanifold kernel maps on all 27 probes
+ * ts_set_option returns TS_ERR_INVALID_ARGUMENT for an unknown key. */
+enum {
+  TS_OPT_GATHER_POSITIONS = 0,
+  TS_OPT_WGRAD_WGS = 1,
+  TS_OPT_EVAL_TAIL_SEPARATE = 2,
+  TS_OPT_CLASS_FINISH_ROWS = 3,
+  TS_OPT_CLASS_FINISH_ROWS_HALF = 4,
+  TS_OPT_DEBUG_BN_ABLATE = 5,
+  TS_OPT_KMAP_FULL_PROBE = 6,
+  TS_OPT_COUNT = 7
+};
+int ts_set_option(int32_t key, int64_t value);
+int64_t ts_get_option(int32_t key);
+
 /* ------------------------------------------------------------------------ */
 /* 1. The ten entry points of torchsparse.backend                           */
 /*    (backend/pybind_cuda.cpp:18-39)                                       */
@@ -384,6 +406,20 @@ int ts_image_gather_forward(const float *feat, int32_t C, int64_t hw, const int3
                             ts_stream_t stream);
 int ts_image_gather_backward(const float *grad_out, int32_t C, int64_t hw, const int32_t *perm, const int32_t *paddr, const int32_t *run,
                              int64_t n_pts, float *grad_feat, int64_t n_feat, int32_t accumulate, ts_stream_t stream);
+
+/* The same gather on a CHANNELS-LAST stack - feat [T, hs, ws, C] in memory, the layout the reference indexes (unet2d.py:183-187:
+ * `permute(0, 2, 3, 1)` then row indexing) and the one the fp16 2-D convolutions produce: a pixel is one contiguous row of
+ * C * elem_bytes bytes at row index paddr (ts_image_plan's pixel address), moved in 16-byte pieces by the threads of one row.
+ *   ts_image_gather_rows_forward   out [n, C] in the original point order; a pure move: elements of elem_bytes = 1 / 2 / 4 / 8 bytes
+ *   ts_image_gather_rows_backward  grad_feat [T, hs, ws, C] (n_feat elements) += per-pixel sums of grad_out [n, C]; half != 0: IEEE
+ *                                  half rows and map (fp32 accumulation over the points of a pixel, one rounding into the map);
+ *                                  every pixel row has one owner thread group: no atomics, run-to-run identical;
+ *                                  accumulate as in ts_image_gather_backward */
+int ts_image_gather_rows_forward(const void *feat, int32_t C, int32_t elem_bytes, const int32_t *perm, const int32_t *paddr, int64_t n_pts,
+                                 void *out, ts_stream_t stream);
+int ts_image_gather_rows_backward(const void *grad_out, int32_t C, int32_t half, const int32_t *perm, const int32_t *paddr,
+                                  const int32_t *run, int64_t n_pts, void *grad_feat, int64_t n_feat, int32_t accumulate,
+                                  ts_stream_t stream);
 
 /* ---- fp16 storage / fp32 accumulation (the reference trains under AMP: conv.py:19 `custom_fwd(cast_inputs=half)`).
  * `void *` operands are IEEE half arrays.  Channel counts must be multiples of 32, K <= 63.

@@ -6,6 +6,7 @@ import importlib.util
 import os
 
 from . import _lib as L
+from .options import options
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "_fast_block.so")
@@ -19,7 +20,7 @@ def module():
     if _tried:
         return _mod
     _tried = True
-    if os.environ.get("TASEG_FAST_BLOCK", "1") == "0" or not os.path.exists(_PATH):
+    if not options.fast_block or not os.path.exists(_PATH):
         return None
     import torch  # noqa: F401  (libtorch must be loaded before the extension)
     L.load()          # the kernels themselves are not optional: a missing libtaseg_hip.so raises here
@@ -33,7 +34,7 @@ def module():
         warnings.warn(f"taseg_amd: native fast path not usable ({e}); using the Python autograd nodes")
         return None
     _mod = mod
-    if os.environ.get("TASEG_WGRAD_STREAM", "0") == "1":
+    if options.wgrad_stream == "1":
         wgrad_stream(True)
     return _mod
 
@@ -76,7 +77,7 @@ def tune_wgrad_stream(step, fence, rounds=3, steps=4):
     # (several ranks: every rank runs the same number of steps here - they contain collectives - and may end up with its own
     # setting: the second stream is rank-local, the sequence of collectives does not depend on it; the gradient buckets join the
     # second stream before their all-reduce, parallel.GradBucketReducer._launch)
-    pinned = os.environ.get("TASEG_WGRAD_STREAM", "auto")
+    pinned = options.wgrad_stream
     if module() is None or pinned in ("0", "1"):
         return (wgrad_stream(pinned == "1") if module() is not None else False), None, None
     best = {False: float("inf"), True: float("inf")}

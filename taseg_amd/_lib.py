@@ -11,7 +11,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TASEG_HIP_LIB") or os.path.join(_HERE, "libtaseg_hip.so")   # override: A/B builds of the kernels
+from .options import options as _options
+
+LIB_PATH = _options.hip_lib or os.path.join(_HERE, "libtaseg_hip.so")   # override: A/B builds of the kernels
 
 TS_OK = 0
 _c = ctypes
@@ -21,6 +23,8 @@ _vp, _i64, _i32, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_size_t
 SIGNATURES = {
     "ts_version": (_c.c_char_p, []),
     "ts_last_error": (_c.c_char_p, []),
+    "ts_set_option": (_i32, [_i32, _i64]),
+    "ts_get_option": (_i64, [_i32]),
     "ts_hash": (_i32, [_vp, _i64, _vp, _vp]),
     "ts_kernel_hash": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
     "ts_hash_query_workspace_bytes": (_sz, [_i64]),
@@ -78,6 +82,8 @@ SIGNATURES = {
     "ts_image_plan": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_image_gather_forward": (_i32, [_vp, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),
     "ts_image_gather_backward": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "ts_image_gather_rows_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "ts_image_gather_rows_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_pair_gemm_f16_nat": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
@@ -202,8 +208,23 @@ def load():
                 fn = getattr(lib, name)  # AttributeError if the .so lags behind the header
                 fn.restype = res
                 fn.argtypes = args
+            push_options(lib)
             _lib = lib
     return _lib
+
+
+# include/taseg_hip.h TS_OPT_*: key -> value taken from the options object
+_OPTION_KEYS = {0: lambda o: int(o.gather_positions), 1: lambda o: o.wgrad_wgs, 2: lambda o: int(not o.eval_tail_in_pass2),
+                3: lambda o: o.class_finish_rows, 4: lambda o: o.class_finish_rows_half,
+                5: lambda o: int(o.debug_bn_ablate or 0), 6: lambda o: int(not o.kmap_sym)}
+
+
+def push_options(lib=None):
+    """hand the library its tuning values (called when it is loaded; call again after changing one of those fields)"""
+    lib = lib or load()
+    for key, get in _OPTION_KEYS.items():
+        if lib.ts_set_option(key, int(get(_options))) != TS_OK:
+            raise BackendError(f"ts_set_option({key}): " + lib.ts_last_error().decode("utf-8", "replace"))
 
 
 def check(rc, what=""):

@@ -11,6 +11,7 @@ import torch
 
 from . import _lib as L
 from ._lib import BackendError, check
+from .options import options
 
 __all__ = [
     "hash_cuda", "kernel_hash_cuda", "hash_query_cuda", "count_cuda",
@@ -19,7 +20,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward",
 ]
 
 
@@ -387,7 +388,7 @@ def build_kmap(in_coords, out_coords, offsets, want_pairs=True, want_inverse=Fal
 def gather_sum_kernel_name(c, k, half=False):
     """The kernel ts_conv_gather_sum[_f16] launches for rows of c channels and K = k offsets (csrc/conv_pairs{,_h}.hip)."""
     import os
-    lists = not os.environ.get("TASEG_GATHER_POSITIONS")
+    lists = not options.gather_positions
     kt = k if k in (8, 27) else 0
     if half:
         return "gather_list_h_kernel<8>" if lists and k <= 32 and 64 <= c <= 2048 else f"gather_sum_h_kernel<{kt}>"
@@ -787,6 +788,52 @@ def image_gather_backward(grad_out, plan, channels, into=None):
     L.check(L.load().ts_image_gather_backward(L.ptr(grad_out), c, plan["hw"], L.ptr(plan["perm"]), L.ptr(plan["paddr"]),
                                               L.ptr(plan["run"]), n, L.ptr(out), out.numel(), acc, L.stream()),
             "ts_image_gather_backward")
+    return out
+
+
+def _channels_last_rows(t, what):
+    """a [T, C, hs, ws] tensor whose MEMORY is [T, hs, ws, C] (torch.channels_last), or raise"""
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError(f"{what}: expected a 4-d tensor in torch.channels_last memory format (shape {tuple(t.shape)}, strides {t.stride()})")
+    return t
+
+
+def image_gather_rows_forward(feat, plan):
+    """image_gather_forward on a CHANNELS-LAST stack (any dtype): out [n, C] of feat's dtype, original point order; feat
+    [T, C, hs, ws] with [T, hs, ws, C] memory - a pixel is one contiguous row (csrc/image.hip, ts_image_gather_rows_forward)."""
+    L.require_device(feat)
+    feat = _channels_last_rows(feat, "image_gather_rows_forward")
+    t, c, hs, ws_ = feat.shape
+    if (hs, ws_) != plan["shape"] or t != plan["frames"]:
+        raise ValueError(f"feature stack {t}x{hs}x{ws_} does not match the plan's {plan['frames']}x{plan['shape'][0]}x{plan['shape'][1]}")
+    n = plan["n"]
+    out = torch.empty((n, c), dtype=feat.dtype, device=feat.device)
+    L.check(L.load().ts_image_gather_rows_forward(L.ptr(feat), c, feat.element_size(), L.ptr(plan["perm"]), L.ptr(plan["paddr"]), n,
+                                                  L.ptr(out), L.stream()), "ts_image_gather_rows_forward")
+    return out
+
+
+def image_gather_rows_backward(grad_out, plan, channels, dtype=None, into=None):
+    """Adjoint of image_gather_rows_forward (segmented sum in raster order, no atomics, run-to-run identical) for float32 / float16
+    maps.  `into` = the channels-last gradient the map already has from its other consumer: the per-pixel sums are added to it IN
+    PLACE (only pixel rows with points are touched) and it is returned; None: a zero-filled channels-last tensor is made first."""
+    L.require_device(grad_out)
+    dtype = dtype or (into.dtype if into is not None else grad_out.dtype)
+    if dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"image_gather_rows_backward: float32 / float16 maps only, got {dtype}")
+    grad_out = grad_out.to(dtype).contiguous()
+    n, c = grad_out.shape
+    assert n == plan["n"] and c == channels
+    hs, ws_ = plan["shape"]
+    shape = (plan["frames"], c, hs, ws_)
+    if into is None:
+        out, acc = torch.empty(shape, dtype=dtype, device=grad_out.device, memory_format=torch.channels_last), 0
+    else:
+        assert tuple(into.shape) == shape and into.dtype == dtype
+        out, acc = _channels_last_rows(into, "image_gather_rows_backward(into)"), 1
+    L.check(L.load().ts_image_gather_rows_backward(L.ptr(grad_out), c, 1 if dtype == torch.float16 else 0, L.ptr(plan["perm"]),
+                                                   L.ptr(plan["paddr"]), L.ptr(plan["run"]), n, L.ptr(out), out.numel(), acc,
+                                                   L.stream()), "ts_image_gather_rows_backward")
     return out
 
 

@@ -382,7 +382,7 @@ extern "C" int ts_conv_block_eval(const void *feat, int64_t n_feat_rows, int32_t
   void *conv_out = p;
   // the elementwise tail rides on pass 2 where the convolution ends in its list form (csrc/conv_pairs*.hip: one launch and one
   // round trip of the convolution output less; TASEG_EVAL_TAIL_IN_PASS2=0 keeps the separate pass)
-  static const bool tail_in_pass2 = !(getenv("TASEG_EVAL_TAIL_IN_PASS2") && atoi(getenv("TASEG_EVAL_TAIL_IN_PASS2")) == 0);
+  const bool tail_in_pass2 = ts_get_option(TS_OPT_EVAL_TAIL_SEPARATE) == 0;
   const TsGatherEpilogue tail = {mean, invstd, bn_weight, bn_bias, residual, relu ? 1 : 0};
   bool tail_done = false;
   TS_TRY(block_conv(feat, n_feat_rows, c_in, kernel, K, nbmaps, nboffs, n_pairs, gather_col, pos, n_out, c_out, half, conv_out, w16, o,

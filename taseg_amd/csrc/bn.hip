@@ -342,18 +342,12 @@ static inline int bn_rows_per_slice(int64_t n, int c) {
   return (int)rows;
 }
 
-// TASEG_DEBUG_BN_ABLATE (diagnostic, fp32 path).  Bits 0 / 1 (WRONG results, timing only): skip the forward statistics pass
+// TS_OPT_DEBUG_BN_ABLATE (diagnostic, fp32 path).  Bits 0 / 1 (WRONG results, timing only): skip the forward statistics pass
 // (bn_partial<0>) / the forward elementwise pass of the blocks without a residual.  Garbage activations also change what the
 // chip draws, so the CLEAN measurement is bits 2 / 3: run the same pass TWICE (same results) - the step's slow-down is what one such
 // pass costs in the step, launch gap included: the most "statistics in the epilogue of the pass that produces y" / "normalise where
 // the consumer gathers the row" could save.
-static int bn_debug_ablate() {
-  static const int v = [] {
-    const char *e = getenv("TASEG_DEBUG_BN_ABLATE");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
+static int bn_debug_ablate() { return (int)ts_get_option(TS_OPT_DEBUG_BN_ABLATE); }
 
 extern "C" size_t ts_bn_train_workspace_bytes(int32_t c) {
   // float partials [BN_MAX_SLICES][2][C] + float coefficients [2][C]

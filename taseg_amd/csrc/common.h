@@ -167,9 +167,13 @@ struct TsWgradPlan {
   int n_chunks;       // ceil(n_pairs / chunk)
   int64_t slots;      // n_chunks + K
 };
-extern int g_ts_wgrad_wgs;   // workgroups a weight-gradient launch aims for (default 512 = two resident rounds of 256 CUs; TASEG_WGRAD_WGS)
+// workgroups a weight-gradient launch aims for (default 512 = two resident rounds of 256 CUs; TS_OPT_WGRAD_WGS)
+static inline int ts_wgrad_wgs() {
+  const int64_t v = ts_get_option(TS_OPT_WGRAD_WGS);
+  return v ? (int)v : 512;
+}
 static inline TsWgradPlan ts_wgrad_plan(int64_t n_pairs, int tiles, int K, int step, int max_chunk) {
-  int64_t chunk = ts_cdiv(n_pairs * tiles, g_ts_wgrad_wgs);
+  int64_t chunk = ts_cdiv(n_pairs * tiles, ts_wgrad_wgs());
   chunk = std::min<int64_t>(max_chunk, std::max<int64_t>(128, (chunk + step - 1) / step * step));
   TsWgradPlan p;
   p.chunk = (int)chunk;

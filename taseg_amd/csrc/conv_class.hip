@@ -607,12 +607,10 @@ static int cg_check(const char *what, int K, int groups, int c_red, int c_out, i
 // gain from ~60k rows in half storage (stride-1 96 -> 96: 105 -> 89 us) and only on the largest maps in fp32 (178k rows: 233 -> 224
 // us; 84k rows: level; 30k rows: a third slower); inside the training step, with the staging stream's kernels beside it, the
 // nuScenes autocast step got 0.2 ms SLOWER with it (16.94 -> 17.17 ms, profiles/r04_ab_class_finish.txt).  So the block calls keep
-// pass 2 (thresholds 0 = never); TASEG_CLASS_FINISH_ROWS / TASEG_CLASS_FINISH_ROWS_HALF (rows from which the finish is taken) switch
+// pass 2 (thresholds 0 = never); TS_OPT_CLASS_FINISH_ROWS / TS_OPT_CLASS_FINISH_ROWS_HALF (rows from which the finish is taken) switch
 // it on for A/B runs, and ts_conv_class_conv is there for callers that want the convolution in one call.
 extern "C" int32_t ts_conv_class_finish_pays(int64_t n, int32_t half) {
-  static const int64_t rows32 = getenv("TASEG_CLASS_FINISH_ROWS") ? atoll(getenv("TASEG_CLASS_FINISH_ROWS")) : 0;
-  static const int64_t rows16 = getenv("TASEG_CLASS_FINISH_ROWS_HALF") ? atoll(getenv("TASEG_CLASS_FINISH_ROWS_HALF")) : 0;
-  const int64_t lim = half ? rows16 : rows32;
+  const int64_t lim = ts_get_option(half ? TS_OPT_CLASS_FINISH_ROWS_HALF : TS_OPT_CLASS_FINISH_ROWS);
   return lim > 0 && n >= lim;
 }
 

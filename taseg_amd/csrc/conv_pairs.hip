@@ -930,7 +930,7 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
   const bool vec = (c % 4 == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
   // default: live positions compacted in LDS first (gather_list_kernel); TASEG_GATHER_POSITIONS=1 in the environment
   // keeps the K-register form (A/B runs)
-  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  const bool k_registers = ts_get_option(TS_OPT_GATHER_POSITIONS) != 0;
   if (vec && K <= 32 && c >= 16 && c <= 1024 && !k_registers && g_ts_conv_impl != 1)
     return launch_gather_list(z, c, pos, K, n_rows, n_pairs, out, side, addend, stream);
   if (vec) {
@@ -951,7 +951,7 @@ int ts_conv_gather_sum_ex(const float *z, int32_t c, const int32_t *pos, int32_t
 
 int ts_conv_gather_sum_epi(const float *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs, float *out,
                            const TsGatherEpilogue &epi, ts_stream_t stream_) {
-  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  const bool k_registers = ts_get_option(TS_OPT_GATHER_POSITIONS) != 0;
   const bool vec = (c % 4 == 0) && ((((uintptr_t)z) | ((uintptr_t)out) | ((uintptr_t)epi.residual) | ((uintptr_t)epi.mean) |
                                      ((uintptr_t)epi.invstd) | ((uintptr_t)epi.w) | ((uintptr_t)epi.b)) & 15) == 0;
   if (!(vec && K > 0 && K <= 32 && c >= 16 && c <= 1024 && !k_registers && g_ts_conv_impl != 1 && n_rows > 0 && z && pos && out &&
@@ -1350,12 +1350,6 @@ static int launch_wgrad(const float *A, int CA, const float *B, int CB, const in
   return TS_OK;
 }
 
-static int wgrad_wgs_from_env() {
-  const char *e = getenv("TASEG_WGRAD_WGS");
-  const int v = e ? atoi(e) : 0;
-  return v >= 64 && v <= 8192 ? v : 512;
-}
-int g_ts_wgrad_wgs = wgrad_wgs_from_env();
 thread_local float *g_ts_wgrad_part = nullptr;
 thread_local TsWgradPlan g_ts_wgrad_plan = {0, 0, 0};
 

@@ -444,7 +444,7 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
              "ts_conv_gather_sum_f16: pointers must be 16-byte aligned");
   const _Float16 *zz = (const _Float16 *)z;
   // default: live positions compacted in LDS first; TASEG_GATHER_POSITIONS=1 keeps the K-register form (A/B runs)
-  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  const bool k_registers = ts_get_option(TS_OPT_GATHER_POSITIONS) != 0;
   if (K <= 32 && c >= 64 && c <= 2048 && !k_registers && g_ts_conv_impl != 1) {   // 32 channels: 64 rows per workgroup, the list build costs more than it saves
     const int rpw = 256 / (c >> 3);
     gather_list_h_kernel<8><<<(unsigned)ts_cdiv(n_rows, rpw), 256, 0, stream>>>(zz, c, pos, K, n_rows, (_Float16 *)out, side,
@@ -466,7 +466,7 @@ int ts_conv_gather_sum_f16_ex(const void *z, int32_t c, const int32_t *pos, int3
 
 int ts_conv_gather_sum_f16_epi(const void *z, int32_t c, const int32_t *pos, int32_t K, int64_t n_rows, int64_t n_pairs, void *out,
                                const TsGatherEpilogue &epi, ts_stream_t stream_) {
-  static const bool k_registers = getenv("TASEG_GATHER_POSITIONS") != nullptr;
+  const bool k_registers = ts_get_option(TS_OPT_GATHER_POSITIONS) != 0;
   if (!(K > 0 && K <= 32 && c >= 64 && c <= 2048 && (c & 7) == 0 && !k_registers && g_ts_conv_impl != 1 && n_rows > 0 && z && pos &&
         out && epi.mean && epi.invstd && epi.w && epi.b &&
         ((((uintptr_t)z) | ((uintptr_t)out) | ((uintptr_t)epi.residual)) & 15) == 0))

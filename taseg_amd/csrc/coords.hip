@@ -409,6 +409,7 @@ static int build_kmap_impl(const int32_t *in_coords, int64_t n_in, const int32_t
   const int half = K / 2;
   // (the flag sits in the last 256 bytes of what ts_build_kmap_workspace_bytes asks for, behind the scan's scratch)
   const size_t flag_at = ts_build_kmap_workspace_bytes(n_in, n_out, K) - 256;
+  TS_REQUIRE(!sym || ws_bytes >= flag_at + 256, TS_ERR_WORKSPACE_TOO_SMALL, "ts_build_kmap_sym: workspace too small for the duplicate flag");
   int *dup = sym ? (int *)((char *)ws + flag_at) : nullptr;
   const TsFillSeg extra[5] = {inverse[0], inverse[1], {(unsigned *)((char *)ws + used) + (n_cnt - 1), 4, 0u},
                               {nbr + (size_t)(half + 1) * n_out, (size_t)half * n_out * 4, 0xFFFFFFFFu}, {dup, 4, 0u}};

@@ -46,6 +46,7 @@ struct Api {
   decltype(&ts_devox_order) devox_order = nullptr;
   decltype(&ts_cat_cols) cat_cols = nullptr;
   decltype(&ts_copy_cols) copy_cols = nullptr;
+  decltype(&ts_get_option) get_option = nullptr;
 } api;
 
 void check(int rc, const char *what) {
@@ -511,6 +512,7 @@ void load_backend(const std::string &libpath) {
   TS_BIND(devox_order, "ts_devox_order");
   TS_BIND(cat_cols, "ts_cat_cols");
   TS_BIND(copy_cols, "ts_copy_cols");
+  TS_BIND(get_option, "ts_get_option");
 #undef TS_BIND
   api.handle = h;
 }
@@ -685,7 +687,7 @@ index_plan(const at::Tensor &coords_in, const at::Tensor &points_in, int64_t num
   py::gil_scoped_release nogil;
   at::NoGradGuard nograd;
   at::Tensor coords = coords_in.contiguous(), points = points_in.contiguous();
-  static const bool sym_probe = !(getenv("TASEG_KMAP_SYM") && atoi(getenv("TASEG_KMAP_SYM")) == 0);
+  const bool sym_probe = api.get_option(TS_OPT_KMAP_FULL_PROBE) == 0;
   std::vector<at::Tensor> cmaps;
   std::vector<Kmap> sub, down;
   cmaps.push_back(coords);

@@ -27,6 +27,7 @@ struct Layer {                            // one convolution + its BatchNorm / S
   at::Tensor planes32, half16;            // pre-split bf16 planes / kept IEEE-half copy of the weight (taseg_amd/planes.py), or undefined
   at::Tensor dest_w, dest_g, dest_b;      // gradient-bucket slots (parallel.GradBucketReducer), or undefined
   int64_t claimed = -1;                   // gradient epoch in which the slots were last handed out
+  bool claimed_direct = false;            // ... to a pass that delivers them itself (its parameters are off the autograd graph)
   at::Tensor invstd;                      // evaluation: 1 / sqrt(running_var + eps), in step with the buffer
   uint32_t invstd_version = 0;
   const void *invstd_src = nullptr;
@@ -48,6 +49,7 @@ struct Program {
   // reducer re-points p.grad and counts the bucket down.  183 AccumulateGrad nodes and 183 Python hooks per step (each a trip to
   // the interpreter lock from the engine's thread, beside a staging thread that also wants it) become 8 calls.
   std::function<void()> deliver;
+  std::function<void()> deliver_check;    // raises when a bucket the slots belong to is no longer open (before the first write to a slot)
 
   // ops: (kind, layer, src, dst, aux, transposed, relu); layers: (kernel, bn_w, bn_b, running_mean, running_var, nbt, momentum, eps)
   Program(int n_inputs_, int out_reg_, const std::vector<std::tuple<int, int, int, int, int, bool, bool>> &ops_,
@@ -116,20 +118,33 @@ struct Program {
       layers[i].half16 = h16[i].has_value() ? *h16[i] : at::Tensor();
     }
   }
-  void set_deliver(py::object fn) {
-    if (fn.is_none()) {
-      deliver = nullptr;
-      return;
-    }
+  static std::function<void()> hold_callable(py::object fn) {
+    if (fn.is_none()) return nullptr;
     // (the callable is kept in a shared holder whose deleter takes the interpreter lock)
     std::shared_ptr<py::object> hold(new py::object(std::move(fn)), [](py::object *o) {
       py::gil_scoped_acquire gil;
       delete o;
     });
-    deliver = [hold]() {
+    return [hold]() {
       py::gil_scoped_acquire gil;
       (*hold)();
     };
+  }
+  void set_deliver(py::object fn, py::object check) {
+    deliver = hold_callable(std::move(fn));
+    deliver_check = deliver ? hold_callable(std::move(check)) : nullptr;
+  }
+  // A pass of this epoch already took its parameters OFF the autograd graph (direct delivery).  A second pass before that one's
+  // backward - two views, a consistency loss, recompute with gradients - would put them back ON it: AccumulateGrad then fires after
+  // the second pass's contribution alone, the reducer's hooks count the buckets down and launch the all-reduce on partial gradients,
+  // and the first pass's node afterwards writes into slots that are in flight.  Refused where it starts.
+  void refuse_second_pass(int64_t grad_epoch) const {
+    for (const Layer &l : layers)
+      TORCH_CHECK(!(l.claimed == grad_epoch && l.claimed_direct),
+                  "taseg_amd stage program: a second forward pass with gradients through the same stage before the backward pass of the "
+                  "first (two views / consistency losses / recompute).  The first pass delivers its parameter gradients straight into "
+                  "the optimizer's buckets (exactly one forward + backward per optimizer step); for such loops set "
+                  "taseg_amd.options.options.direct_grads = False before building the model");
   }
   // may this pass deliver its gradients directly?  (every slot present, nothing accumulated, slots not yet handed out this epoch)
   bool direct_ok(int64_t grad_epoch) const {
@@ -149,6 +164,7 @@ struct Program {
       layers[i].dest_g = d[3 * i + 1].has_value() ? *d[3 * i + 1] : at::Tensor();
       layers[i].dest_b = d[3 * i + 2].has_value() ? *d[3 * i + 2] : at::Tensor();
       layers[i].claimed = -1;
+      layers[i].claimed_direct = false;
     }
   }
 };
@@ -386,7 +402,10 @@ class StageRun : public torch::autograd::Function<StageRun> {
       r.side_ok = !l.kernel.grad().defined();
       r.use_dest = fresh && l.dest_w.defined() && l.dest_g.defined() && l.dest_b.defined() && l.claimed != grad_epoch;
       TORCH_CHECK(!direct || r.use_dest, "stage run: direct delivery without the reducer's slots");
-      if (r.use_dest) l.claimed = grad_epoch;
+      if (r.use_dest) {
+        l.claimed = grad_epoch;
+        l.claimed_direct = direct;
+      }
       const at::Tensor &table = o.transposed ? m.pos_in : m.pos_out;
       const void *pl = (!half && l.planes32.defined()) ? l.planes32.data_ptr() : nullptr;
       TsConvBlockOpts bopts = {g.plan_f[i].get(), nullptr, pl, kept16 ? 1 : 0, nullptr, nullptr, nullptr, 0, 0, 0, l.natural ? 1 : 0};
@@ -433,6 +452,7 @@ class StageRun : public torch::autograd::Function<StageRun> {
     const auto &rows = st->reg_rows;
     const auto &ch = st->reg_ch;
     TORCH_CHECK(grads[0].defined(), "stage run: the stage's output received no gradient");
+    if (st->direct && p.deliver_check) p.deliver_check();      // the buckets must still be open BEFORE the first write to a slot
     at::Tensor g_out = grads[0].contiguous().to(dt);
     const int n_in = p.n_inputs;
     // which registers need a gradient: the inputs that require one; every block output is on a differentiable path (parameters)
@@ -645,6 +665,7 @@ inline at::Tensor run_inner(const std::vector<at::Tensor> &inputs, std::shared_p
   // (the node must still be recorded: with its parameters off the graph that takes an input that requires a gradient)
   bool wanted = false;
   for (const at::Tensor &x : inputs) wanted = wanted || x.requires_grad();
+  if (at::GradMode::is_enabled() && wanted) prog->refuse_second_pass(grad_epoch);
   const bool direct = at::GradMode::is_enabled() && wanted && prog->direct_ok(grad_epoch);
   const std::vector<at::Tensor> params = direct ? std::vector<at::Tensor>() : prog->parameters();
   return StageRun::apply(at::TensorList(inputs), at::TensorList(params), prog, geom, half, stream, comm, group_id, grad_epoch, direct)[0];

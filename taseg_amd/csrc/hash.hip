@@ -18,6 +18,20 @@ void ts_set_error(const char *fmt, ...) {
 extern "C" const char *ts_last_error(void) { return g_err; }
 extern "C" const char *ts_version(void) { return "taseg_hip 0.1.0 gfx950"; }
 
+// ---------------------------------------------------------------- tuning values (set by the host side's options object)
+static int64_t g_opt[TS_OPT_COUNT] = {0};
+
+extern "C" int ts_set_option(int32_t key, int64_t value) {
+  TS_REQUIRE(key >= 0 && key < TS_OPT_COUNT, TS_ERR_INVALID_ARGUMENT, "ts_set_option: unknown key %d", key);
+  if (key == TS_OPT_WGRAD_WGS)
+    TS_REQUIRE(value == 0 || (value >= 64 && value <= 8192), TS_ERR_INVALID_ARGUMENT, "ts_set_option: workgroup target %lld outside 64 .. 8192",
+               (long long)value);
+  g_opt[key] = value;
+  return TS_OK;
+}
+
+extern "C" int64_t ts_get_option(int32_t key) { return key >= 0 && key < TS_OPT_COUNT ? g_opt[key] : 0; }
+
 // ---------------------------------------------------------------- multi-buffer fill
 struct TsFillSegs {
   TsFillSeg s[TS_FILL_MAX];

@@ -20,6 +20,7 @@
 //     zero-filled T x C x H x W tensor, no second dense add.
 #include <cstring>
 
+#include <hip/hip_fp16.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
@@ -246,5 +247,147 @@ extern "C" int ts_image_gather_backward(const float *grad_out, int32_t C, int64_
   TS_REQUIRE(run, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_backward: null pointer");
   image_scatter_rows_kernel<<<(unsigned)ts_cdiv(n_pts, IG_PTS), 256, 0, stream>>>(grad_out, C, hw, perm, paddr, run, n_pts, grad_feat);
   TS_CHECK_LAUNCH("ts_image_gather_backward");
+  return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same gather on a CHANNELS-LAST stack ([T, hs, ws, C] in memory: the layout the reference itself indexes, unet2d.py:183-187
+// `permute(0, 2, 3, 1)`, and the one MIOpen's fp16 convolutions produce).  A pixel is ONE contiguous row of C * elem bytes at
+// byte offset paddr * C * elem, so the gather is a row copy: thread (point i of the raster order, piece j) moves one 16-byte piece
+// (8 / 4 / 2 where the row length asks for it); a 96-channel fp32 row is 24 lanes, a wave moves 2 2/3 rows.  Raster order keeps
+// neighbouring rows of the map in neighbouring lanes (LiDAR returns of a scan line are 2-3 pixels apart) and duplicates of a pixel
+// together; the output rows are whole 128-byte lines wherever C * elem is a multiple of 128.  No LDS, no transpose.
+// The adjoint: the thread group of a pixel's FIRST point sums the gradient rows of its run in index order (fp32 accumulate) and
+// read-modify-writes the pixel's row once - every row has one owner in the grid: no atomics, run-to-run identical.
+template <typename V>
+__global__ __launch_bounds__(256) void image_rows_gather_kernel(const char *__restrict__ feat, int pieces, const int *__restrict__ perm,
+                                                                const int *__restrict__ paddr, int64_t n_pts, char *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = e / pieces;
+  if (i >= n_pts) return;
+  const int j = (int)(e - i * pieces);
+  const int a = paddr[i];
+  V v;
+  memset(&v, 0, sizeof(V));            // a point outside its sample's frames (plan's err) reads as zeros
+  if (a >= 0) v = ((const V *)(feat + (size_t)a * pieces * sizeof(V)))[j];
+  ((V *)(out + (size_t)perm[i] * pieces * sizeof(V)))[j] = v;
+}
+
+template <typename T>
+struct RowAcc;
+template <>
+struct RowAcc<float> {
+  static __device__ __forceinline__ float load(const float *p) { return *p; }
+  static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
+};
+template <>
+struct RowAcc<__half> {
+  static __device__ __forceinline__ float load(const __half *p) { return __half2float(*p); }
+  static __device__ __forceinline__ void store(__half *p, float v) { *p = __float2half(v); }
+};
+
+// VE elements of type T per thread (VE * sizeof(T) = 16, 8, 4 or 2 bytes); `pieces` = C / VE threads per row
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void image_rows_scatter_kernel(const T *__restrict__ gout, int pieces, const int *__restrict__ perm,
+                                                                 const int *__restrict__ paddr, const int *__restrict__ run, int64_t n_pts,
+                                                                 T *__restrict__ gfeat) {
+  struct alignas(VE * sizeof(T)) Vec {
+    T x[VE];
+  };
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = e / pieces;
+  if (i >= n_pts) return;
+  const int len = run[i];
+  const int a = paddr[i];
+  if (len <= 0 || a < 0) return;
+  const int j = (int)(e - i * pieces);
+  const size_t row = (size_t)pieces * VE;
+  float acc[VE];
+#pragma unroll
+  for (int k = 0; k < VE; ++k) acc[k] = 0.f;
+  for (int q = 0; q < len; ++q) {
+    const Vec g = ((const Vec *)(gout + (size_t)perm[i + q] * row))[j];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) acc[k] += RowAcc<T>::load(&g.x[k]);
+  }
+  Vec *dst = (Vec *)(gfeat + (size_t)a * row) + j;
+  Vec d = *dst;
+#pragma unroll
+  for (int k = 0; k < VE; ++k) RowAcc<T>::store(&d.x[k], RowAcc<T>::load(&d.x[k]) + acc[k]);
+  *dst = d;
+}
+
+// largest piece of 16 / 8 / 4 / 2 / 1 bytes that divides the row and keeps every base pointer aligned
+static int image_piece_bytes(size_t row_bytes, const void *a, const void *b) {
+  for (int v = 16; v > 1; v >>= 1)
+    if (row_bytes % v == 0 && ((uintptr_t)a % v) == 0 && ((uintptr_t)b % v) == 0) return v;
+  return 1;
+}
+
+// out[n, C] (original point order; every row written) from feat [T, hs, ws, C] (channels-last memory), elements of `elem_bytes`
+// bytes (a pure move: any dtype)
+extern "C" int ts_image_gather_rows_forward(const void *feat, int32_t C, int32_t elem_bytes, const int32_t *perm, const int32_t *paddr,
+                                            int64_t n_pts, void *out, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(n_pts >= 0 && C > 0 && n_pts < (1LL << 31) && (elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8),
+             TS_ERR_INVALID_ARGUMENT, "ts_image_gather_rows_forward: bad sizes");
+  if (n_pts == 0) return TS_OK;
+  TS_REQUIRE(feat && out && perm && paddr, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_rows_forward: null pointer");
+  const size_t row = (size_t)C * elem_bytes;
+  const int v = image_piece_bytes(row, feat, out);
+  const int pieces = (int)(row / v);
+  const unsigned grid = (unsigned)ts_cdiv(n_pts * pieces, 256);
+  const char *f = (const char *)feat;
+  char *o = (char *)out;
+  switch (v) {
+    case 16: image_rows_gather_kernel<uint4><<<grid, 256, 0, stream>>>(f, pieces, perm, paddr, n_pts, o); break;
+    case 8: image_rows_gather_kernel<uint2><<<grid, 256, 0, stream>>>(f, pieces, perm, paddr, n_pts, o); break;
+    case 4: image_rows_gather_kernel<uint32_t><<<grid, 256, 0, stream>>>(f, pieces, perm, paddr, n_pts, o); break;
+    case 2: image_rows_gather_kernel<uint16_t><<<grid, 256, 0, stream>>>(f, pieces, perm, paddr, n_pts, o); break;
+    default: image_rows_gather_kernel<uint8_t><<<grid, 256, 0, stream>>>(f, pieces, perm, paddr, n_pts, o); break;
+  }
+  TS_CHECK_LAUNCH("ts_image_gather_rows_forward");
+  return TS_OK;
+}
+
+template <typename T>
+static int image_rows_scatter(const T *g, int C, const int32_t *perm, const int32_t *paddr, const int32_t *run, int64_t n_pts, T *gf,
+                              hipStream_t stream) {
+  const int v = image_piece_bytes((size_t)C * sizeof(T), g, gf);
+  TS_REQUIRE(v >= (int)sizeof(T), TS_ERR_INVALID_ARGUMENT, "ts_image_gather_rows_backward: pointers must be aligned to the element size");
+  const int ve = v / (int)sizeof(T);
+  const int pieces = C / ve;
+  const unsigned grid = (unsigned)ts_cdiv(n_pts * pieces, 256);
+  if constexpr (sizeof(T) == 2) {
+    if (ve == 8) {
+      image_rows_scatter_kernel<T, 8><<<grid, 256, 0, stream>>>(g, pieces, perm, paddr, run, n_pts, gf);
+      return TS_OK;
+    }
+  }
+  if (ve == 4)
+    image_rows_scatter_kernel<T, 4><<<grid, 256, 0, stream>>>(g, pieces, perm, paddr, run, n_pts, gf);
+  else if (ve == 2)
+    image_rows_scatter_kernel<T, 2><<<grid, 256, 0, stream>>>(g, pieces, perm, paddr, run, n_pts, gf);
+  else
+    image_rows_scatter_kernel<T, 1><<<grid, 256, 0, stream>>>(g, pieces, perm, paddr, run, n_pts, gf);
+  return TS_OK;
+}
+
+// grad_feat [T, hs, ws, C] (channels-last memory, n_feat elements) += adjoint(grad_out [n, C]); half != 0: IEEE-half rows and map
+// (fp32 accumulation over a pixel's run, one rounding into the map).  accumulate == 0: grad_feat is zero-filled first.
+extern "C" int ts_image_gather_rows_backward(const void *grad_out, int32_t C, int32_t half, const int32_t *perm, const int32_t *paddr,
+                                             const int32_t *run, int64_t n_pts, void *grad_feat, int64_t n_feat, int32_t accumulate,
+                                             ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(grad_feat && n_feat >= 0 && n_pts >= 0 && C > 0 && n_pts < (1LL << 31), TS_ERR_INVALID_ARGUMENT,
+             "ts_image_gather_rows_backward: bad arguments");
+  if (!accumulate) TS_CHECK_HIP(hipMemsetAsync(grad_feat, 0, (size_t)n_feat * (half ? 2 : 4), stream), "image gather memset");
+  if (n_pts == 0) return TS_OK;
+  TS_REQUIRE(grad_out && perm && paddr && run, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_rows_backward: null pointer");
+  if (half)
+    image_rows_scatter<__half>((const __half *)grad_out, C, perm, paddr, run, n_pts, (__half *)grad_feat, stream);
+  else
+    image_rows_scatter<float>((const float *)grad_out, C, perm, paddr, run, n_pts, (float *)grad_feat, stream);
+  TS_CHECK_LAUNCH("ts_image_gather_rows_backward");
   return TS_OK;
 }

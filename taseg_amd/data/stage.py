@@ -19,6 +19,7 @@ import torch
 
 from .. import backend as B
 from ..torchsparse import SparseTensor
+from ..options import options
 
 __all__ = ["fuse_multiscan", "voxelize_sample_ms", "voxelize_sample", "collate_batch", "build_multiscan_batch",
            "build_multiscan_batch_per_sample", "voxelize_batch_ms", "rows_index", "DevicePrefetcher"]
@@ -178,7 +179,7 @@ def build_multiscan_batch_per_sample(scans: List[Dict], voxel_size: float, steps
 
 import os as _os
 
-_BATCHED = _os.environ.get("TASEG_STAGE_BATCHED", "1") != "0"
+_BATCHED = options.stage_batched
 _rows_cache = {}
 
 

@@ -11,6 +11,7 @@ from typing import List
 
 import torch
 import torch.distributed as dist
+from .options import options
 
 __all__ = ["env_rank", "init_distributed", "shard_seeds", "wrap_ddp", "reduce_max", "reduce_confusion",
            "GradBucketReducer"]
@@ -29,6 +30,21 @@ def grad_epoch() -> int:
 def bump_grad_epoch():
     global _grad_epoch
     _grad_epoch += 1
+
+
+# parameter -> the reducer that owns its bucket slot.  Kept OUTSIDE the tensors: a weak reference in a Parameter's __dict__ would make
+# torch.save(model) / pickle fail (Parameter.__reduce_ex__ pickles __dict__).  id-keyed, checked against the live object on look-up.
+_reducer_of = {}
+
+
+def reducer_of(param):
+    """the live GradBucketReducer whose bucket holds `param`'s gradient slot, or None"""
+    ref = _reducer_of.get(id(param))
+    red = ref() if ref is not None else None
+    if red is None:
+        return None
+    slot = red._slot_of.get(id(param))
+    return red if slot is not None and red.buckets[slot[0]]["params"][slot[1]] is param else None
 
 
 def env_rank():
@@ -104,7 +120,7 @@ class GradBucketReducer:
         # also usable without a process group (one process): the buckets then only flatten the gradients
         live = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if live else 1
-        if live and process_group is None and self.world > 1 and os.environ.get("TASEG_DIST_BUCKETS_ON_DEFAULT_GROUP") != "1":
+        if live and process_group is None and self.world > 1 and not options.dist_buckets_on_default_group:
             process_group = dist.new_group(backend=dist.get_backend())
         self.group = process_group
         self._next = 0              # index of the next bucket to launch (launch order = index order on every rank)
@@ -153,7 +169,8 @@ class GradBucketReducer:
             # nothing for it (the convolution weights are 99 % of the gradient bytes)
             p._taseg_grad_dest = v
             # ... and producers that deliver a whole stage's gradients themselves (deliver below) find their way back here
-            p._taseg_reducer = weakref.ref(self)
+            # through reducer_of(p)
+            _reducer_of[id(p)] = weakref.ref(self)
             self._slot_of[id(p)] = (bucket_index, i)
         self.buckets.append({"params": list(params), "flat": flat, "flat_all": flat_all, "flags": flags, "views": views,
                              "offsets": offsets, "pending": len(params), "launched": False, "unused": []})
@@ -172,6 +189,15 @@ class GradBucketReducer:
                 self._launch(self.buckets[self._next])
                 self._next += 1
         return hook
+
+    def check_open(self, params):
+        """raises unless every bucket of `params` still waits for gradients (called by a direct producer BEFORE it writes into the
+        slots: a bucket whose all-reduce is in flight must not be written to)"""
+        for p in params:
+            bucket = self.buckets[self._slot_of[id(p)][0]]
+            if bucket["launched"] or bucket["pending"] <= 0:
+                raise RuntimeError("GradBucketReducer: a backward pass reached a bucket whose all-reduce was already launched - "
+                                   "exactly one backward pass per finish() / optimizer step is supported")
 
     def deliver(self, params):
         """Gradients of `params` have been written straight into their bucket slots by a producer that bypasses autograd's

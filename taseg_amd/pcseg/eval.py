@@ -11,6 +11,7 @@ import os
 from typing import Dict, Iterable, List, Sequence
 
 import numpy as np
+from taseg_amd.options import options
 
 __all__ = ["accumulate_votes", "vote_payload", "write_prediction", "remap_lut", "remap_labels", "fast_hist",
            "fast_hist_crop", "per_class_iu", "scan_confusions", "evaluate"]
@@ -111,7 +112,7 @@ def _staged(model, batches: Iterable[Dict], prefetch: bool):
     # order): beside a forward pass one index plan takes longer than the pass (bench.py --eval: 5.9-6.3 -> 5.4 ms fp32, 4.2-5.1 -> 3.5-3.8
     # ms under autocast).  TASEG_EVAL_STAGE_DEPTH=1: one.
     pf = DevicePrefetcher(lambda: next(it, done), lambda b: b if b is done else prepare(b), threaded=True,
-                          depth=int(os.environ.get("TASEG_EVAL_STAGE_DEPTH", "2")))
+                          depth=options.eval_stage_depth)
     try:
         while True:
             batch = pf.next()

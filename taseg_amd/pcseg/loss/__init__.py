@@ -9,10 +9,11 @@ import os
 import torch
 import torch.nn as nn
 from torch.nn import CrossEntropyLoss
+from taseg_amd.options import options
 
 from .lovasz import _NO_IGNORE, lovasz_softmax
 
-_FUSED = os.environ.get("TASEG_FUSED_LOSS", "1") != "0"
+_FUSED = options.fused_loss
 
 
 class _CeLovasz(torch.autograd.Function):

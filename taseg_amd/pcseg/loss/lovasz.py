@@ -8,10 +8,11 @@ once: ONE batched descending sort of the [P, C] error matrix instead of C sorts,
 import os
 
 import torch
+from taseg_amd.options import options
 
 __all__ = ["lovasz_softmax", "lovasz_softmax_flat"]
 
-_FUSED = os.environ.get("TASEG_FUSED_LOVASZ", "1") != "0"
+_FUSED = options.fused_lovasz
 _NO_IGNORE = -(1 << 62)          # a label value nothing takes
 
 

@@ -17,6 +17,7 @@ from taseg_amd.pcseg.loss import Losses
 from ...base_segmentors import BaseSegmentor
 from taseg_amd import backend as B
 from taseg_amd import _fast
+from taseg_amd.options import options
 from .utils import voxel_to_point, voxelize_index
 from . import stage_program as _SP
 
@@ -24,8 +25,8 @@ __all__ = ["MinkUNet", "unvoxelise_predictions"]
 
 import contextlib
 import os as _os
-_DEVOX_ATOMIC = _os.environ.get("TASEG_DEVOX_ATOMIC", "0") == "1"
-_DEVOX_CELLS = _os.environ.get("TASEG_DEVOX_CELLS", "1") != "0"     # stride-16 devoxelize backward: cell-reduced two-stage sum
+_DEVOX_ATOMIC = options.devox_atomic
+_DEVOX_CELLS = options.devox_cells     # stride-16 devoxelize backward: cell-reduced two-stage sum
 
 
 def _coarse_devox_plan(idx, w, n_vox):
@@ -449,7 +450,7 @@ class _PinnedRing:
 
 _pinned = _PinnedRing()
 # TASEG_EVAL_COPY_STREAM=0: the deferred tail's device -> host copies on the launch stream
-_COPY_STREAM = _os.environ.get("TASEG_EVAL_COPY_STREAM", "1") != "0"
+_COPY_STREAM = options.eval_copy_stream
 _copy_streams = {}
 
 
@@ -519,7 +520,7 @@ class PendingPredictions:
         return self._out
 
 
-_FUSED_TAIL = _os.environ.get("TASEG_FUSED_EVAL_TAIL", "1") != "0"
+_FUSED_TAIL = options.fused_eval_tail
 
 
 def _fused_tail(out, vox_batch, invs, all_labels, num_points, want_probs, num_points_ms, names, defer, n_scenes):

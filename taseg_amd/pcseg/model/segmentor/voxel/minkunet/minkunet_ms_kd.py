@@ -15,12 +15,13 @@ import torch
 from torch import nn
 
 from taseg_amd.torchsparse.nn import functional as spF
+from taseg_amd.options import options
 from .minkunet import LazyScalar, MinkUNetBackbone, unvoxelise_predictions
 
 __all__ = ["MinkUNetMsKd"]
 
 # TASEG_KD_LOSS_ON_DEVICE=0: the reference's literal per-sample loop (three host reads per sample) instead of _kd_loss_on_device
-_KD_ON_DEVICE = os.environ.get("TASEG_KD_LOSS_ON_DEVICE", "1") != "0"
+_KD_ON_DEVICE = options.kd_loss_on_device
 
 _PARTS = ("stem", "stage1", "stage2", "stage3", "stage4", "up1", "up2", "up3", "up4", "classifier", "dropout")
 

@@ -20,14 +20,15 @@ from taseg_amd import _fast
 from taseg_amd import backend as B
 from taseg_amd import parallel as _parallel
 from taseg_amd import planes as _planes
+from taseg_amd.options import options
 from taseg_amd.torchsparse.nn import functional as spF
 from taseg_amd.torchsparse.nn import modules as spM
 from taseg_amd.torchsparse.utils import make_ntuple
 
 __all__ = ["StagePrograms", "enabled", "programs_of", "forget", "compiled"]
 
-_ON = os.environ.get("TASEG_STAGE_PROGRAM", "1") != "0"
-_DIRECT_GRADS = os.environ.get("TASEG_DIRECT_GRADS", "1") != "0"
+_ON = options.stage_program
+_DIRECT_GRADS = options.direct_grads
 _ONES = (1, 1, 1)
 _BLOCK, _CAT = 0, 1
 
@@ -251,6 +252,11 @@ class StagePrograms:
     def _finish_compile(self):
         """what usable() reads: shape rules decided once, the hook dictionaries and (dictionary, key, tensor) slots of every module"""
         layers = [(c, b) for st in self.stages.values() for c, b in st.layers]
+        # run / run_unet take the statistics scope (SyncBatchNorm or not, process group) from the FIRST layer for all of them: a
+        # partially converted model, or layers on different process groups, keep the per-module path, which decides per layer
+        kinds = {(isinstance(b, nn.SyncBatchNorm), id(getattr(b, "process_group", None))) for _, b in layers}
+        if len(kinds) > 1:
+            raise _Unsupported("BatchNorm layers of mixed type / process group")
         shapes = [(c.kernel.shape[-2], c.kernel.shape[-1], c.kernel.dim()) for c, _ in layers]
         base = all(co <= 1024 and (dim == 3 or spF._dense_ok(ci, co)) for ci, co, dim in shapes)
         self.ok_f32 = base and all(co % 4 == 0 for _, co, _ in shapes)
@@ -301,14 +307,24 @@ class StagePrograms:
             st.dest_state = first
             # with a reducer behind the slots the stage delivers its gradients itself, once per backward pass (TASEG_DIRECT_GRADS=0:
             # through autograd's AccumulateGrad and the reducer's per-parameter hooks)
-            ref = getattr(st.convs[0].kernel, "_taseg_reducer", None)
-            reducer = ref() if ref is not None else None
-            if reducer is not None and _DIRECT_GRADS and all(d is not None for d in dests):
-                params = [p for conv, bn in st.layers for p in (conv.kernel, bn.weight, bn.bias)]
-                rref = ref
-                st.program.set_deliver(lambda: rref().deliver(params))
+            reducer = _parallel.reducer_of(st.convs[0].kernel)
+            params = [p for conv, bn in st.layers for p in (conv.kernel, bn.weight, bn.bias)]
+            # (direct delivery bypasses AccumulateGrad: tensor hooks a user put on a parameter would never fire - the reducer's own
+            # post-accumulate hook is the one expected there)
+            hooked = any(p._backward_hooks or len(p._post_accumulate_grad_hooks or ()) > 1 for p in params)
+            if reducer is not None and _DIRECT_GRADS and not hooked and all(d is not None for d in dests) \
+                    and all(_parallel.reducer_of(p) is reducer for p in params):
+                rref = weakref.ref(reducer)
+
+                def _live():
+                    red = rref()
+                    if red is None:
+                        raise RuntimeError("taseg_amd stage program: the GradBucketReducer / FlatSGD that owns this model's gradient slots "
+                                           "no longer exists; build a new one before the next backward pass")
+                    return red
+                st.program.set_deliver(lambda: _live().deliver(params), lambda: _live().check_open(params))
             else:
-                st.program.set_deliver(None)
+                st.program.set_deliver(None, None)
         return stream
 
     ORDER = ("stage1", "stage2", "stage3", "stage4", "up1", "up2", "up3", "up4")

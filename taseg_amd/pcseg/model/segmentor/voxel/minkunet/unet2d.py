@@ -1,23 +1,44 @@
 """UNet2D - the camera branch of TIAF (reference pcseg/model/segmentor/voxel/minkunet/unet2d.py).
 
-The dense 2-D convolutions / BatchNorm2d / pooling / PixelShuffle stay on PyTorch-ROCm (MIOpen / rocBLAS are the
-roofline for dense NCHW work - SURVEY.md section 2.1 row 4); module tree and parameter names are the reference's, so
+The dense 2-D convolutions / BatchNorm2d / pooling / PixelShuffle stay on PyTorch-ROCm (MIOpen / hipBLASLt are the
+roofline for dense work - SURVEY.md section 2.1 row 4); module tree and parameter names are the reference's, so
 its checkpoints load (`stem.0.conv1.weight`, `stage2.bn1.running_mean`, `up3.conv1.weight`, `classifier.0.bias`).
 
-What is rebuilt is the image -> point hand-over (unet2d.py:180-214): the reference materialises NHWC copies of five
-feature stacks (6.8 GB for the 96-channel full-resolution map of 36 frames) and fancy-indexes them per sample;
-`image_gather` reads the NCHW stacks in place: the FOV points are put in raster order of their pixels once per batch and scale
-(`ts_image_plan`), every map is gathered with lanes along the points of that order (`ts_image_gather_forward`), and the adjoint is
-a segmented sum over the same order added into the map's other gradient in place (`ts_image_gather_backward`: no atomics, no
-zero-filled stack).
+Memory format: `options.image_layout = "nhwc"` (default) keeps the whole branch in `torch.channels_last` - the layout MIOpen's
+fp16 / NHWC solvers want (under `torch.autocast`, the mode the reference always trains in: dist_train.sh:18 `--amp`) and the layout
+the reference itself indexes for the image -> point hand-over (unet2d.py:183-187: `permute(0, 2, 3, 1)` then row indexing);
+"nchw" is the plain contiguous format.
+
+What is rebuilt is that hand-over (unet2d.py:180-214): the reference materialises NHWC copies of five feature stacks and
+fancy-indexes them per sample; here the FOV points are put in raster order of their pixels once per batch and scale
+(`ts_image_plan`) and every map is gathered in place -
+  * channels-last maps: a pixel is one contiguous row, moved in 16-byte pieces (`ts_image_gather_rows_forward`, any dtype); the
+    adjoint sums the gradient rows of a pixel's points in index order and read-modify-writes the pixel's row once
+    (`ts_image_gather_rows_backward`, fp32 / fp16 maps);
+  * NCHW maps: lanes along the points of the raster order, one plane at a time, an LDS transpose into rows
+    (`ts_image_gather_forward` / `_backward`, fp32);
+both adjoints without atomics (run-to-run identical) and ADDED into the gradient the map already has from its dense consumer
+(no zero-filled T x C x H x W stack).
 """
 import torch
 from torch import nn
 from torch.autograd import Function
 
 from taseg_amd import backend as B
+from taseg_amd.options import options
 
-__all__ = ["UNet2D", "image_gather", "image_gather_through", "image_plan"]
+__all__ = ["UNet2D", "image_gather", "image_plan"]
+
+
+def _rows(feat):
+    """is this map's MEMORY [T, hs, ws, C] (torch.channels_last)?  (a one-channel contiguous map is both)"""
+    return feat.dim() == 4 and feat.is_contiguous(memory_format=torch.channels_last)
+
+
+def _gather(feat, plan):
+    if _rows(feat):
+        return B.image_gather_rows_forward(feat, plan)
+    return B.image_gather_forward(feat.contiguous().float(), plan)
 
 
 class _ImageGather(Function):
@@ -25,36 +46,48 @@ class _ImageGather(Function):
 
     @staticmethod
     def forward(ctx, feat, plan):
-        ctx.plan, ctx.channels = plan, feat.shape[1]
-        return B.image_gather_forward(feat, plan)
+        ctx.plan, ctx.channels, ctx.rows, ctx.dtype = plan, feat.shape[1], _rows(feat), feat.dtype
+        return _gather(feat, plan)
 
     @staticmethod
     def backward(ctx, grad_out):
-        return B.image_gather_backward(grad_out.contiguous().float(), ctx.plan, ctx.channels), None
+        if ctx.rows and ctx.dtype in (torch.float32, torch.float16):
+            return B.image_gather_rows_backward(grad_out, ctx.plan, ctx.channels, dtype=ctx.dtype), None
+        return B.image_gather_backward(grad_out.contiguous().float(), ctx.plan, ctx.channels).to(ctx.dtype), None
 
 
 class _ImageGatherThrough(Function):
     """(feat', rows) = (feat, rows of feat at the plan's pixels): the map leaves the node a second time, and whatever consumes
     THAT tensor (the next decoder stage, the classifier, the dense loss) sends its gradient back INTO the node, where the adjoint
     of the gather is added to it in place on the pixels that have points - no zero-filled T x C x H x W stack (1.9 GB for the
-    96-channel full-resolution map of a bs-2 TIAF batch), no second dense add by the autograd engine.  Use feat' downstream."""
+    96-channel full-resolution fp32 map of a bs-2 TIAF batch), no second dense add by the autograd engine.  Use feat' downstream.
+
+    PRIVATE to UNet2D.forward: adding into the incoming gradient is only sound when that tensor is a buffer nobody else reads -
+    a fresh result of the consumer's backward (Conv2d, PixelShuffle, the permute + reshape in front of the dense loss) or the sum
+    the engine formed for this output.  A consumer such as `feat' + other` hands the SAME tensor object to both of its inputs; do
+    not put one behind this node."""
 
     @staticmethod
     def forward(ctx, feat, plan):
-        ctx.plan, ctx.shape = plan, tuple(feat.shape)
-        return feat.view_as(feat), B.image_gather_forward(feat, plan)
+        ctx.plan, ctx.shape, ctx.rows, ctx.dtype = plan, tuple(feat.shape), _rows(feat), feat.dtype
+        return feat.view_as(feat), _gather(feat, plan)
 
     @staticmethod
     def backward(ctx, grad_feat, grad_rows):
         if grad_rows is None:
             return grad_feat, None
+        c = ctx.shape[1]
+        if ctx.rows and ctx.dtype in (torch.float32, torch.float16):
+            if grad_feat is None:
+                return B.image_gather_rows_backward(grad_rows, ctx.plan, c, dtype=ctx.dtype), None
+            # (a gradient in another format / dtype is first brought into the map's: a copy, and then not the engine's buffer)
+            into = grad_feat.to(ctx.dtype).contiguous(memory_format=torch.channels_last)
+            return B.image_gather_rows_backward(grad_rows, ctx.plan, c, dtype=ctx.dtype, into=into), None
         g = grad_rows.contiguous().float()
         if grad_feat is None:
-            return B.image_gather_backward(g, ctx.plan, ctx.shape[1]), None
-        # the incoming gradient is the engine's own buffer for this output (a fresh result of the consumer's backward, or the sum
-        # the engine formed): adding into it is what the engine would do with a second dense tensor
+            return B.image_gather_backward(g, ctx.plan, c).to(ctx.dtype), None
         into = grad_feat if (grad_feat.dtype == torch.float32 and grad_feat.is_contiguous()) else grad_feat.float().contiguous()
-        return B.image_gather_backward(g, ctx.plan, ctx.shape[1], into=into), None
+        return B.image_gather_backward(g, ctx.plan, c, into=into).to(ctx.dtype), None
 
 
 def image_plan(pix, pbatch, frame_end, frames, height, width, shift=0):
@@ -63,15 +96,16 @@ def image_plan(pix, pbatch, frame_end, frames, height, width, shift=0):
 
 
 def image_gather(feat, pix, pbatch, frame_end, height, width, shift=0, plan=None):
-    """Rows of `feat` [T, C, H >> shift, W >> shift] at the pixels the FOV points project to -> ([n, C], err)."""
+    """Rows of `feat` [T, C, H >> shift, W >> shift] at the pixels the FOV points project to -> ([n, C] of feat's dtype, err); a
+    channels-last map is read as rows in place, any other as NCHW planes (fp32)."""
     if plan is None:
         plan = image_plan(pix, pbatch, frame_end, feat.shape[0], height, width, shift)
-    return _ImageGather.apply(feat.contiguous().float(), plan), plan["err"]
+    return _ImageGather.apply(feat, plan), plan["err"]
 
 
-def image_gather_through(feat, plan):
+def _image_gather_through(feat, plan):
     """(feat', rows): see _ImageGatherThrough"""
-    return _ImageGatherThrough.apply(feat.contiguous().float(), plan)
+    return _ImageGatherThrough.apply(feat, plan)
 
 
 def _leaky():
@@ -172,9 +206,19 @@ class UNet2D(nn.Module):
         self.up3 = UpBlock(cs[6], cs[7], 0.2, mid_filters=cs[6] // 4 + cs[2])
         self.up4 = UpBlock(cs[7], cs[8], 0.2, drop_out=False, mid_filters=cs[7] // 4 + cs[1])
         self.classifier = nn.Sequential(nn.Conv2d(cs[8], num_class, kernel_size=1, stride=1))
+        self._layout = None
+
+    def _set_layout(self):
+        """parameters in the memory format of options.image_layout (once; the Parameter objects stay)"""
+        want = torch.channels_last if options.image_layout == "nhwc" else torch.contiguous_format
+        if self._layout is not want:
+            self.to(memory_format=want)
+            self._layout = want
+        return want
 
     def forward(self, data_dict):
         x = data_dict["image_input"]
+        x = x.contiguous(memory_format=self._set_layout())
         height, width = int(x.shape[2]), int(x.shape[3])
         x0 = self.stem(x)
         x1, s1 = self.stage1(x0)
@@ -192,16 +236,16 @@ class UNet2D(nn.Module):
         u1 = self.up1(x5, s4)
         u2 = self.up2(u1, s3)           # 1/4 scale, 128 channels
         # (the gathered maps go on THROUGH their gather nodes: the adjoint is added into the gradient they get from here on)
-        u2, feat4 = image_gather_through(u2, plan4)
+        u2, feat4 = _image_gather_through(u2, plan4)
         u3 = self.up3(u2, s2)
         u4 = self.up4(u3, s1)           # full scale, 96 channels
-        u4, feat0 = image_gather_through(u4, plan0)
+        u4, feat0 = _image_gather_through(u4, plan0)
         logits = self.classifier(u4)
-        logits, logits_fov = image_gather_through(logits, plan0)
+        logits, logits_fov = _image_gather_through(logits, plan0)
         data_dict["image_logits"] = logits
         err = plan0["err"]
         with torch.no_grad():
-            targets_fov, _ = image_gather(data_dict["semantic_map_ms"].float(), None, None, None, height, width, plan=plan0)
+            targets_fov, _ = image_gather(data_dict["semantic_map_ms"], None, None, None, height, width, plan=plan0)
             rgb_fov, _ = image_gather(x, None, None, None, height, width, plan=plan0)
         data_dict["image_logits_fov"] = logits_fov
         data_dict["image_targets_fov"] = targets_fov[:, 0].to(data_dict["semantic_map_ms"].dtype)

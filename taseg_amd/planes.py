@@ -17,10 +17,11 @@ import weakref
 import torch
 
 from . import _lib as L
+from .options import options
 
 __all__ = ["planes_for", "half_for", "invalidate", "eligible", "eligible_half", "hint", "stats"]
 
-_ENABLED = os.environ.get("TASEG_PRESPLIT", "1") != "0"
+_ENABLED = options.presplit
 _entries = {}          # id(weight) -> _Entry (bf16 planes of the fp32 kernels)
 _half_entries = {}     # id(weight) -> _Entry (IEEE-half copy for the half-storage kernels)
 _epoch = 0

@@ -1,11 +1,19 @@
-"""Library-owned RCCL communicators for SyncBatchNorm (csrc/rccl.hip).
+"""SyncBatchNorm's statistics all-reduces: which transport carries them (csrc/rccl.hip holds the direct ones).
 
-`direct_comm(group)` returns an opaque communicator handle over the ranks of a torch.distributed process group, or
-None when the direct path is unavailable (TASEG_RCCL_DIRECT=0, librccl.so not loadable, a failed self-test on any
-rank) - callers then fall back to `dist.all_reduce` on the group.  Creation is collective: every rank of the group
-reaches it at the same point (the first SyncBatchNorm forward of the first step).  The 128-byte RCCL id travels over
-the process group itself; before the communicator is trusted one all-reduce is checked against the group's own, and
-the ranks agree on the outcome, so either all of them use the direct path or none does.
+DEFAULT: torch.distributed - `c10d_sum` on the caller's process group, the collective the reference's nn.SyncBatchNorm issues
+(R/train.py:247-251, R/pcseg/model/segmentor/voxel/minkunet/minkunet.py:23-25).  It is the only transport that has c10d's
+per-communicator mutex, work tracking and watchdog around it, and the one every multi-process test of this tree runs.
+
+`direct_comm(group)` returns an opaque communicator handle for the two OPT-IN transports (None = the default), chosen with
+`options.rccl_direct` (environment: TASEG_RCCL_DIRECT):
+  "borrow" - the process group's OWN RCCL communicator (`ProcessGroupNCCL._comm_ptr()`, a private accessor: guarded by a torch
+             version check), the `ncclAllReduce` issued by this library on the current stream: 126 c10d dispatches per step saved
+             (~1 ms of host time on the one-rank line);
+  "create" - a communicator this module creates over the ranks of the group (the 128-byte RCCL id travels over the group).
+Both are collective to set up (every rank reaches the first SyncBatchNorm forward), self-test one all-reduce against the
+group's own and agree on the outcome over the group, so either all ranks use the direct path or none does.  Neither has run
+with more than one rank on real devices (tests/test_gpu_dist.py::test_two_ranks_rccl needs two GPUs): they stay opt-in until
+one has.
 """
 import ctypes
 import os
@@ -31,7 +39,7 @@ def _create(group):
     ok = True
     try:
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        L.check(lib.ts_rccl_load(path.encode() if os.path.exists(path) else None), "ts_rccl_load")
+        _load(lib, path if os.path.exists(path) else None)
     except Exception as e:  # noqa: BLE001 - any failure means "use the process group instead"
         warnings.warn(f"taseg_amd: direct RCCL path unavailable ({e}); SyncBatchNorm uses torch.distributed")
         ok = False
@@ -62,15 +70,32 @@ def _create(group):
     return comm
 
 
-def single_communicator() -> bool:
-    """TASEG_DIST_SINGLE_COMM (default 1): SyncBatchNorm's statistics all-reduces go through torch.distributed's default
-    process group (c10d, on the compute stream) like nn.SyncBatchNorm under DDP in the reference (R/train.py:247-251); the
-    gradient buckets always use a communicator of their own (parallel.GradBucketReducer), launched in bucket-index order.
-    By default the library issues them on that group's own communicator itself (`_borrow`: the same RCCL calls on the same
-    communicator and stream, without c10d's per-call dispatch).  TASEG_DIST_SINGLE_COMM=0 moves the statistics onto a communicator
-    CREATED by this module - not the default until it has run with more than one rank on real devices
-    (tests/test_gpu_dist.py::test_two_ranks_rccl needs two GPUs and has been skipped on every box so far)."""
-    return os.environ.get("TASEG_DIST_SINGLE_COMM", "1") != "0"
+# torch releases whose ProcessGroupNCCL._comm_ptr() has been checked to return the ncclComm_t of the current device
+_BORROW_TORCH = ("2.9", "2.10")
+
+
+def _torch_rccl_path():
+    """librccl.so of the running PyTorch if it is ALREADY mapped into this process (RTLD_NOLOAD), else None: a handle borrowed
+    from torch's RCCL must only ever be passed to that same RCCL image"""
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        ctypes.CDLL(path, mode=os.RTLD_NOW | os.RTLD_NOLOAD)
+    except OSError:
+        return None
+    return path
+
+
+_loaded_path = [None]
+
+
+def _load(lib, path):
+    """bind the library's RCCL entry points to `path` (None: the default search path); refuses a second, different image"""
+    if _loaded_path[0] is not None and _loaded_path[0] != (path or ""):
+        raise RuntimeError(f"RCCL already bound to '{_loaded_path[0]}', not '{path or ''}'")
+    L.check(lib.ts_rccl_load(path.encode() if path else None), "ts_rccl_load")
+    _loaded_path[0] = path or ""
 
 
 def _borrow(group):
@@ -88,6 +113,10 @@ def _borrow(group):
         backend = None
     if backend is None or not hasattr(backend, "_comm_ptr"):
         return None                                       # (a property of the group's type: the same answer on every rank)
+    if not torch.__version__.startswith(tuple(v + "." for v in _BORROW_TORCH)):
+        warnings.warn(f"taseg_amd: ProcessGroupNCCL._comm_ptr() is unchecked on torch {torch.__version__}; SyncBatchNorm goes "
+                      f"through torch.distributed")
+        return None                                       # (the same torch on every rank)
 
     def step(fn):
         """one rank-local step; afterwards the ranks agree whether ALL of them succeeded (every rank issues the same collectives
@@ -102,8 +131,11 @@ def _borrow(group):
         return _agree(ok, group, dev)
 
     def load():
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        L.check(lib.ts_rccl_load(path.encode() if os.path.exists(path) else None), "ts_rccl_load")
+        # only the RCCL image torch itself runs on: the handle is meaningless to any other
+        path = _torch_rccl_path()
+        if path is None:
+            raise RuntimeError("torch's own librccl.so is not mapped into this process")
+        _load(lib, path)
         return True
 
     if not step(load):
@@ -132,21 +164,33 @@ _borrowed = set()
 
 def direct_comm(group):
     """Communicator handle (ctypes.c_void_p) for `group`, resolved on first use (collectively: every rank reaches the first
-    SyncBatchNorm forward); None = go through torch.distributed (`c10d_sum`).
-      default (TASEG_DIST_SINGLE_COMM=1, TASEG_RCCL_DIRECT unset): the group's OWN communicator, called from the library (`_borrow`) -
-        the calls c10d would make, without its dispatch; where that is not available (gloo), torch.distributed;
-      TASEG_RCCL_DIRECT=0: always through torch.distributed;
-      TASEG_RCCL_DIRECT=1 or TASEG_DIST_SINGLE_COMM=0: a communicator created by this module (`_create`)."""
+    SyncBatchNorm forward); None = go through torch.distributed (`c10d_sum`), the default.  See the module docstring."""
     key = id(group)
     if key not in _comms:
-        want = os.environ.get("TASEG_RCCL_DIRECT")
-        if want == "0":
-            _comms[key] = None
-        elif want == "1" or not single_communicator():
+        from .options import options
+        want = options.rccl_direct
+        if want == "create":
             _comms[key] = _create(group)
-        else:
+        elif want == "borrow":
             _comms[key] = _borrow(group)
+        else:
+            _comms[key] = None
+        _groups[key] = group          # (keeps the group object alive, so that its id is not reused while the entry exists)
     return _comms[key]
+
+
+_groups = {}
+
+
+def forget(group):
+    """drop the entry of a process group that is being destroyed (a created communicator is destroyed, a borrowed one is the
+    group's own)"""
+    key = id(group)
+    comm = _comms.pop(key, None)
+    _groups.pop(key, None)
+    if comm is not None and comm.value and key not in _borrowed:
+        L.load().ts_rccl_comm_destroy(comm)
+    _borrowed.discard(key)
 
 
 def c10d_sum(buf, group):
@@ -180,4 +224,5 @@ def shutdown():
         if comm is not None and comm.value and key not in _borrowed:      # (a borrowed communicator belongs to its process group)
             lib.ts_rccl_comm_destroy(comm)
         del _comms[key]
+    _groups.clear()
     _borrowed.clear()

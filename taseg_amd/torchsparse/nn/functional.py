@@ -19,6 +19,7 @@ from torch.autograd import Function
 
 from ... import backend as B
 from ... import planes as _planes
+from ...options import options
 from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from .utils import get_kernel_offsets
@@ -373,17 +374,17 @@ def accept_class_plans(kmaps):
 # Class-sorted implicit GEMM (csrc/conv_class.hip) - where it beats pair GEMM + gather-sum (profiles/r03_class_gemm_layers.txt):
 # 1.4-1.65x on the 178k-voxel stride-1 maps and the 32 / 64-wide stride-2 layers, 1.1-1.3x on the 84k-voxel 96-wide ones,
 # 1.1x on 30k voxels x 64 channels, a loss on 30k x 128 and below.  TASEG_CLASS_GEMM=0 keeps every block on the two passes.
-_CLASS_GEMM = os.environ.get("TASEG_CLASS_GEMM", "1") != "0"
+_CLASS_GEMM = options.class_gemm
 _CLASS_MIN_ROWS = 16384          # <= 64 channels (module attributes: tests force them down to pin the class path at model level)
-_CLASS_MIN_ROWS_96 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_96", "48000"))
-_CLASS_MIN_ROWS_128 = int(os.environ.get("TASEG_CLASS_MIN_ROWS_128", "60000"))
+_CLASS_MIN_ROWS_96 = options.class_min_rows_96
+_CLASS_MIN_ROWS_128 = options.class_min_rows_128
 _CLASS_MAX_WORK = 1.6        # a class plan is used while its row-products stay under 1.6x the rulebook's pairs
-_CLASS_MIN_ROWS_HALF = int(os.environ.get("TASEG_CLASS_MIN_ROWS_HALF", "16384"))
+_CLASS_MIN_ROWS_HALF = options.class_min_rows_half
 # one-pass 2x2x2 strided / transposed convolutions on direct class plans (TASEG_DIRECT_CONV=0: pair GEMM + pass 2)
-_DIRECT_CONV = os.environ.get("TASEG_DIRECT_CONV", "1") != "0"
-_DIRECT_MIN_ROWS = int(os.environ.get("TASEG_DIRECT_MIN_ROWS", "0"))
+_DIRECT_CONV = options.direct_conv != "0"
+_DIRECT_MIN_ROWS = options.direct_min_rows
 _DIRECT_DOWN_MIN_ROWS = 8000        # smallest destination-row count any "down" plan is chosen at (direct_conv_pays)
-_DIRECT_FORCE = os.environ.get("TASEG_DIRECT_CONV") == "force"        # every fitting 2x2x2 product on its direct plan (tests, probes)
+_DIRECT_FORCE = options.direct_conv == "force"        # every fitting 2x2x2 product on its direct plan (tests, probes)
 
 
 def class_conv(x, w, plan, f16, wt=False):

@@ -11,14 +11,15 @@ from . import functional as F
 from ... import backend as _B
 from ... import _fast
 from ... import planes as _planes
+from ...options import options
 from .utils import fapply
 
 __all__ = ["Conv3d", "BatchNorm", "SyncBatchNorm", "ReLU", "LeakyReLU", "bn_act", "conv_bn_act"]
 
 
-_FUSED_BLOCK = os.environ.get("TASEG_FUSED_BLOCK", "1") != "0"
+_FUSED_BLOCK = options.fused_block
 # the 1x1x1 shortcut + its BatchNorm as one block call on the identity rulebook (_pointwise_bn_act); 0: GEMM node + BatchNorm node
-_POINTWISE_BLOCK = os.environ.get("TASEG_POINTWISE_BLOCK", "1") != "0"
+_POINTWISE_BLOCK = options.pointwise_block
 _DIL1 = (1, 1, 1)
 
 
@@ -92,7 +93,7 @@ def _sync_group(mod):
     import os
     import torch.distributed as dist
     if mod.training and dist.is_available() and dist.is_initialized() \
-            and (dist.get_world_size() > 1 or os.environ.get("TASEG_SYNCBN_SINGLE_RANK") == "1"):
+            and (dist.get_world_size() > 1 or options.syncbn_single_rank):
         return mod.process_group if mod.process_group is not None else dist.group.WORLD
     return None
 

@@ -129,7 +129,6 @@ def main():
     out = {}
     scan = make_scan(41 + rank)
     amp = os.environ.get("TASEG_WORKER_AMP") == "1"
-    # TASEG_DIST_SINGLE_COMM (default): buckets and SyncBatchNorm share the default group, as in bench.py
     group = dist.new_group(backend=backend)      # the buckets' own communicator, as bench.py passes it
     # TASEG_WORKER_LOCAL_BN=1: plain BatchNorm (per-rank statistics, bench.py --local-bn) instead of the configs' SyncBatchNorm
     out.update(pack("", *one_step(build(os.environ.get("TASEG_WORKER_LOCAL_BN") != "1"), [scan], group, amp=amp)))

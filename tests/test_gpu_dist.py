@@ -92,14 +92,14 @@ def _check_against_single(ranks, prefix="", amp=False):
     return worst
 
 
-@pytest.mark.parametrize("world,amp,single", [(2, False, "1"), (2, False, "0"), (4, False, "1"), (2, True, "1")])
-def test_ranks_share_one_device(tmp_path, world, amp, single):
-    """2 and 4 real rank processes on ONE card (gloo transport), fp32 and under autocast, with the step's collectives on one
-    communicator (the default, TASEG_DIST_SINGLE_COMM=1) and with a dedicated group for the gradient buckets"""
-    env = {"TASEG_RCCL_DIRECT": "0", "TASEG_DIST_SINGLE_COMM": single, "TASEG_WORKER_AMP": "1" if amp else "0"}
+@pytest.mark.parametrize("world,amp", [(2, False), (4, False), (2, True)])
+def test_ranks_share_one_device(tmp_path, world, amp):
+    """2 and 4 real rank processes on ONE card (gloo transport), fp32 and under autocast: SyncBatchNorm's statistics through
+    torch.distributed on the default group (the default transport), the gradient buckets on a group of their own"""
+    env = {"TASEG_WORKER_AMP": "1" if amp else "0"}
     ranks, _ = _run_ranks(world, "gloo", tmp_path, env)
     worst = _check_against_single(ranks, amp=amp)
-    print(f"{world} ranks (gloo, one device, {'AMP' if amp else 'fp32'}, single communicator {single}) vs one process on the "
+    print(f"{world} ranks (gloo, one device, {'AMP' if amp else 'fp32'}) vs one process on the "
           f"concatenated batch: worst relative gradient error {worst:.2e}")
 
 
@@ -107,7 +107,7 @@ def test_second_stream_under_the_bucket_reducer_gives_the_same_bits(tmp_path):
     """weight gradients on the second stream with N > 1 (per-rank BatchNorm statistics: a block that exchanges statistics keeps its
     weight gradient on its own stream): every bucket's all-reduce first joins the second stream (parallel.GradBucketReducer._launch) -
     logits, averaged gradients and running statistics bit-equal to the one-stream run"""
-    env = {"TASEG_RCCL_DIRECT": "0", "TASEG_WORKER_AMP": "0", "TASEG_WORKER_LOCAL_BN": "1"}
+    env = {"TASEG_WORKER_AMP": "0", "TASEG_WORKER_LOCAL_BN": "1"}
     (tmp_path / "one").mkdir()
     (tmp_path / "two").mkdir()
     one, _ = _run_ranks(2, "gloo", tmp_path / "one", env)
@@ -121,7 +121,7 @@ def test_second_stream_under_the_bucket_reducer_gives_the_same_bits(tmp_path):
 def test_flat_sgd_unused_parameter_rule_is_global(tmp_path):
     """A parameter with a gradient on rank 0 only: FlatSGD applies the averaged gradient on BOTH ranks (replicas stay
     bit-identical, DDP's find_unused_parameters rule); a parameter unused on every rank is left untouched (torch.optim.SGD)."""
-    ranks, _ = _run_ranks(2, "gloo", tmp_path, {"TASEG_RCCL_DIRECT": "0", "TASEG_WORKER_MODE": "unused"})
+    ranks, _ = _run_ranks(2, "gloo", tmp_path, {"TASEG_WORKER_MODE": "unused"})
     a, b = ranks
     assert set(a) == set(b)
     for k in a:
@@ -133,32 +133,31 @@ def test_flat_sgd_unused_parameter_rule_is_global(tmp_path):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two ROCm devices (RCCL refuses two ranks on one)")
 def test_two_ranks_rccl(tmp_path):
-    """the RCCL wire (needs two devices): first the DEFAULT arrangement - SyncBatchNorm's all-reduces on torch.distributed's
-    default group's own communicator, issued by the library (rccl._borrow; the "c10d/" half of every worker repeats the step
-    through torch.distributed's dispatcher), gradient buckets on a group of their own - then a communicator the library CREATES for
-    SyncBatchNorm (TASEG_DIST_SINGLE_COMM=0), each against ONE process on the concatenated batch"""
-    (tmp_path / "single").mkdir()
-    (tmp_path / "direct").mkdir()
-    ranks, _ = _run_ranks(2, "nccl", tmp_path / "single")
-    assert int(ranks[0]["direct_rccl"]) == 1 and int(ranks[0]["borrowed"]) == 1      # the process group's own communicator
+    """the RCCL wire (needs two devices), the DEFAULT arrangement: SyncBatchNorm's all-reduces through torch.distributed on the
+    default group, gradient buckets on a group of their own - against ONE process on the concatenated batch"""
+    ranks, outs = _run_ranks(2, "nccl", tmp_path)
+    assert int(ranks[0]["direct_rccl"]) == 0 and int(ranks[0]["borrowed"]) == 0      # torch.distributed is the default transport
     _check_against_single(ranks)
-    _check_against_single(ranks, "c10d/")
-    for got in ranks:                  # the same RCCL calls on the same communicator, issued from two places
-        for k in got:
-            if k.startswith("c10d/"):
-                assert np.allclose(got[k], got[k[5:]], rtol=1e-6, atol=1e-7), k
-    ranks, outs = _run_ranks(2, "nccl", tmp_path / "direct", {"TASEG_DIST_SINGLE_COMM": "0"})
-    assert int(ranks[0]["direct_rccl"]) == 1 and int(ranks[0]["borrowed"]) == 0, "the library-owned RCCL communicator was not created"
+    line = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    assert line, outs[0][1]
+    print("gradient all-reduce over RCCL:", line[-1])
+    assert json.loads(line[-1])["bus_GBps"] > 1.0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two ROCm devices (RCCL refuses two ranks on one)")
+@pytest.mark.parametrize("transport", ["borrow", "create"])
+def test_two_ranks_rccl_opt_in_transports(tmp_path, transport):
+    """the two OPT-IN transports of SyncBatchNorm's statistics (taseg_amd/rccl.py: the process group's own communicator called
+    from the library / a communicator the library creates), each against ONE process on the concatenated batch and against the
+    same step through torch.distributed (the "c10d/" half of every worker)"""
+    ranks, outs = _run_ranks(2, "nccl", tmp_path, {"TASEG_RCCL_DIRECT": transport})
+    assert int(ranks[0]["direct_rccl"]) == 1 and int(ranks[0]["borrowed"]) == (1 if transport == "borrow" else 0)
     _check_against_single(ranks)
     _check_against_single(ranks, "c10d/")
     for got in ranks:                  # both SyncBatchNorm transports run the same kernels around the same sums
         for k in got:
             if k.startswith("c10d/"):
                 assert np.allclose(got[k], got[k[5:]], rtol=1e-6, atol=1e-7), k
-    line = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
-    assert line, outs[0][1]
-    print("gradient all-reduce over RCCL:", line[-1])
-    assert json.loads(line[-1])["bus_GBps"] > 1.0
 
 
 def test_bench_gpus_flag():
@@ -178,7 +177,7 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     """`bench.py --gpus 2` starts its own two ranks and reports n_gpus 2 (gloo transport, both ranks on this card: a
     rehearsal of the launch + reducer + SyncBatchNorm path, not a performance number)"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(TASEG_BENCH_SHARE_DEVICE="1", TASEG_DIST_BACKEND="gloo", TASEG_RCCL_DIRECT="0")
+    env.update(TASEG_BENCH_SHARE_DEVICE="1", TASEG_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--points", "30000", "--no-cpu-baseline", "--no-kernel-events"], env=env, capture_output=True, text=True,
                        timeout=900)

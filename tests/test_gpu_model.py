@@ -305,7 +305,8 @@ def test_syncbn_collective_path_on_one_rank(tmp_path, mode):
     """The SyncBatchNorm / DDP code path that `bench.py --gpus N` executes, on a one-rank RCCL group: fused BN+act
     with the all-reduce between reduction and apply must equal the single-process path, and a DDP-wrapped training
     step must run (the multi-GPU scaling bench cannot be launched from the build box).  mode: the direct path on a communicator
-    the library creates (TASEG_RCCL_DIRECT=1) / on the process group's own communicator (the default, rccl._borrow)."""
+    the library creates (options.rccl_direct = "create") / on the process group's own communicator ("borrow"); both are opt-in,
+    the default goes through torch.distributed (third leg of the loop below)."""
     import os
     import subprocess
     import sys
@@ -313,7 +314,8 @@ def test_syncbn_collective_path_on_one_rank(tmp_path, mode):
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.environ["REPO"])
 import torch.distributed as dist
-os.environ["TASEG_SYNCBN_SINGLE_RANK"] = "1"
+from taseg_amd.options import options
+options.syncbn_single_rank = True
 dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
 torch.cuda.set_device(0)
 from taseg_amd.torchsparse.nn.batchnorm import batch_norm_act_train
@@ -375,10 +377,7 @@ dist.destroy_process_group()
 print("SYNC_OK")
 '''
     env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MODE=mode)
-    env.pop("TASEG_RCCL_DIRECT", None)
-    env.pop("TASEG_DIST_SINGLE_COMM", None)
-    if mode == "created":
-        env["TASEG_RCCL_DIRECT"] = "1"
+    env["TASEG_RCCL_DIRECT"] = "create" if mode == "created" else "borrow"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "SYNC_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 

@@ -271,6 +271,45 @@ def test_direct_gradient_delivery_counts_the_buckets_down_like_the_hooks():
     opt.reducer.finish()
 
 
+def test_a_second_forward_pass_before_the_backward_is_refused_under_direct_delivery(monkeypatch):
+    """two forward passes of one model with gradients and ONE backward (two views, a consistency loss) under FlatSGD: with direct
+    delivery the first pass has taken the parameters off the autograd graph, so the second is refused where it starts (it would
+    launch the buckets' all-reduce on partial gradients); with options.direct_grads off autograd sums both passes"""
+    from taseg_amd.optim import FlatSGD
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet import stage_program as SP
+    _set(True)
+    make, n = _scan_batch(seed=8)
+    model = _model(num_layer=[1] * 8).train()
+    opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=0.0, max_norm=10.0, bucket_mb=8.0)
+    opt.zero_grad()
+    ret, _, _ = model(make())
+    with pytest.raises(RuntimeError, match="second forward pass"):
+        model(make())
+    ret["loss"].backward()                   # the first pass is intact
+    opt.step()
+    torch.cuda.synchronize()
+    # the same loop through autograd's AccumulateGrad: both passes contribute
+    monkeypatch.setattr(SP, "_DIRECT_GRADS", False)
+    model2 = _model(num_layer=[1] * 8).train()
+    opt2 = FlatSGD(model2, lr=0.01, momentum=0.9, weight_decay=0.0, max_norm=10.0, bucket_mb=8.0)
+    opt2.zero_grad()
+    torch.manual_seed(3)
+    one, _, _ = model2(make())
+    one["loss"].backward()
+    g1 = {k: p.grad.detach().clone() for k, p in model2.named_parameters()}
+    opt2.reducer.finish()
+    opt2.zero_grad()
+    torch.manual_seed(3)
+    a, _, _ = model2(make())
+    torch.manual_seed(3)
+    b, _, _ = model2(make())
+    (a["loss"] + b["loss"]).backward()
+    torch.cuda.synchronize()
+    for k, p in model2.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[k], rtol=2e-3, atol=1e-5), k
+    opt2.reducer.finish()
+
+
 @pytest.mark.parametrize("amp", [False, True])
 def test_training_mode_pass_without_a_graph_runs_on_the_programs(amp):
     """train-mode BatchNorm under no_grad - the frozen teacher of MinkUNetMsKd (R/.../minkunet_ms_kd.py:533) - on the stage programs:

@@ -23,14 +23,20 @@ def _reference_gather(feat, pix, pbatch, frame_end, shift):
     return torch.cat(outs, 0)
 
 
-@pytest.mark.parametrize("shift,c", [(0, 96), (2, 128), (0, 1), (0, 20)])
-def test_image_gather_matches_indexing(shift, c):
+def _in_layout(t, layout):
+    """the same values in channels-last ("nhwc") or plain contiguous ("nchw") memory"""
+    return t.contiguous(memory_format=torch.channels_last) if layout == "nhwc" else t.contiguous()
+
+
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+@pytest.mark.parametrize("shift,c", [(0, 96), (2, 128), (0, 1), (0, 20), (0, 3)])
+def test_image_gather_matches_indexing(shift, c, layout):
     from taseg_amd import backend as B
     from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import image_gather
     g = torch.Generator().manual_seed(5)
     frames, H, W = [3, 2, 4], 24, 40
     frame_end = torch.tensor(np.cumsum(frames), dtype=torch.int32, device="cuda")
-    feat = torch.randn(sum(frames), c, H >> shift, W >> shift, generator=g).cuda().requires_grad_()
+    feat = _in_layout(torch.randn(sum(frames), c, H >> shift, W >> shift, generator=g).cuda(), layout).requires_grad_()
     n = 5000
     pbatch = torch.sort(torch.randint(0, 3, (n,), generator=g)).values.int().cuda()     # batch-sorted, as collated
     rows = torch.stack([torch.randint(0, frames[b] * H, (1,), generator=g) for b in pbatch.tolist()]).view(-1)
@@ -50,21 +56,46 @@ def test_image_gather_matches_indexing(shift, c):
     bad[0, 0] = frames[0] * H + 1
     plan = B.image_plan(bad, pbatch, frame_end, sum(frames), H, W, shift)
     assert int(plan["err"]) == 1
-    assert torch.equal(B.image_gather_forward(feat.detach(), plan)[1:], want.detach()[1:])       # the other rows are what they were
+    got = B.image_gather_rows_forward(feat.detach(), plan) if layout == "nhwc" else B.image_gather_forward(feat.detach(), plan)
+    assert torch.equal(got[1:], want.detach()[1:]) and not got[0].any()       # the other rows are what they were, the bad one zeros
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.uint8, torch.int64])
+def test_image_row_gather_moves_any_dtype(dtype):
+    """the channels-last gather is a pure move: half maps (autocast), byte images, integer label maps come out bit for bit"""
+    from taseg_amd import backend as B
+    g = torch.Generator().manual_seed(6)
+    frames, H, W, c = [2, 3], 16, 24, 5
+    T = sum(frames)
+    frame_end = torch.tensor(np.cumsum(frames), dtype=torch.int32, device="cuda")
+    base = torch.randint(0, 200, (T, c, H, W), generator=g)
+    feat = base.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    n = 3000
+    pbatch = torch.sort(torch.randint(0, 2, (n,), generator=g)).values.int().cuda()
+    rows = torch.stack([torch.randint(0, frames[b] * H, (1,), generator=g) for b in pbatch.tolist()]).view(-1)
+    pix = torch.stack([rows, torch.randint(0, W, (n,), generator=g)], 1).float().cuda()
+    plan = B.image_plan(pix, pbatch, frame_end, T, H, W, 0)
+    out = B.image_gather_rows_forward(feat, plan)
+    want = _reference_gather(feat, pix, pbatch, frame_end, 0)
+    assert out.dtype == dtype and torch.equal(out, want)
+    with pytest.raises(ValueError, match="channels_last"):
+        B.image_gather_rows_forward(feat.contiguous(), plan)
+
+
+@pytest.mark.parametrize("layout,dtype", [("nhwc", torch.float32), ("nhwc", torch.float16), ("nchw", torch.float32)])
 @pytest.mark.parametrize("shift,c", [(0, 96), (2, 128), (0, 20)])
-def test_image_gather_at_tiaf_size_through_path(shift, c):
-    """>= 20k FOV points on a camera-sized stack (minkunet_mk34_cr10_fsa_tiaf.yaml: 384 x 1280): the raster-order gather against
-    plain indexing and the oracle, and the adjoint ADDED into the map's other gradient in place (unet2d.image_gather_through)
-    against autograd's own sum of the two gradients - run-to-run identical (no atomics)."""
+def test_image_gather_at_tiaf_size_through_path(shift, c, layout, dtype):
+    """>= 20k FOV points on a camera-sized stack (minkunet_mk34_cr10_fsa_tiaf.yaml: 384 x 1280), channels-last rows (fp32 and the
+    fp16 maps of an autocast step) and NCHW planes: the raster-order gather against plain indexing and the oracle, and the adjoint
+    ADDED into the map's other gradient in place (unet2d._image_gather_through) against autograd's own sum of the two gradients -
+    run-to-run identical (no atomics)."""
     from oracle import ts_oracle as O
-    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import image_gather_through, image_plan
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import _image_gather_through as image_gather_through, image_plan
     g = torch.Generator().manual_seed(11)
     frames, H, W = [2, 1], 384, 1280
     T = sum(frames)
     frame_end = torch.tensor(np.cumsum(frames), dtype=torch.int32, device="cuda")
-    feat = torch.randn(T, c, H >> shift, W >> shift, generator=g).cuda().requires_grad_()
+    feat = _in_layout(torch.randn(T, c, H >> shift, W >> shift, generator=g).cuda().to(dtype), layout).requires_grad_()
     n = 60000
     pbatch = torch.sort(torch.randint(0, 2, (n,), generator=g)).values.int().cuda()
     # scan-line-like pixels: a few rows, neighbouring columns, several points per pixel
@@ -75,17 +106,22 @@ def test_image_gather_at_tiaf_size_through_path(shift, c):
     assert int(plan["err"]) == 0
     through, out = image_gather_through(feat, plan)
     want = _reference_gather(feat, pix, pbatch, frame_end, shift)
-    assert torch.equal(out, want)
-    assert np.array_equal(out.detach().cpu().numpy(), O.image_gather(feat.detach().cpu().numpy(), pix.cpu().numpy(),
-                                                                     pbatch.cpu().numpy(), frame_end.cpu().numpy(), shift))
-    w = torch.randn(n, c, generator=g).cuda()
-    dense = torch.randn(feat.shape, generator=g).cuda()
+    assert out.dtype == dtype and torch.equal(out, want)
+    assert np.array_equal(out.detach().float().cpu().numpy(), O.image_gather(feat.detach().float().cpu().numpy(), pix.cpu().numpy(),
+                                                                             pbatch.cpu().numpy(), frame_end.cpu().numpy(), shift))
+    w = torch.randn(n, c, generator=g).cuda().to(dtype)
+    dense = _in_layout(torch.randn(feat.shape, generator=g).cuda().to(dtype), layout)
     loss = (out * w).sum() + (through * dense).sum()             # the map's second consumer
     (g_ours,) = torch.autograd.grad(loss, feat, retain_graph=True)
     (g_again,) = torch.autograd.grad(loss, feat)
-    (g_ref,) = torch.autograd.grad((want * w).sum() + (feat * dense).sum(), feat)
     assert torch.equal(g_ours, g_again)                          # deterministic
-    assert float((g_ours - g_ref).abs().max()) <= 1e-5 * max(1.0, float(g_ref.abs().max()))
+    assert g_ours.dtype == dtype and g_ours.is_contiguous(memory_format=torch.channels_last if layout == "nhwc" else torch.contiguous_format)
+    # against a float64 evaluation of the same sum (fp16 maps: one rounding of the fp32 run sum into the map's gradient, where
+    # index_put(accumulate) in half - what the reference does under autocast - rounds after every point)
+    f64 = feat.detach().double().requires_grad_()
+    (g_ref,) = torch.autograd.grad((_reference_gather(f64, pix, pbatch, frame_end, shift) * w.double()).sum() + (f64 * dense.double()).sum(), f64)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert float((g_ours.double() - g_ref).abs().max()) <= tol * max(1.0, float(g_ref.abs().max()))
 
 
 def _tiaf_batch(g):

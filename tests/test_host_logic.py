@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: containers, kernel offsets, numpy quantize / collate against the
 oracle, state_dict layout against the reference's, the vectorised Lovasz loss against the per-class loop."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -355,7 +357,8 @@ def test_wgrad_stream_tuner_keeps_the_second_stream_only_on_a_clear_win(monkeypa
     state = {"on": False}
     monkeypatch.setattr(_fast, "module", lambda: object())
     monkeypatch.setattr(_fast, "wgrad_stream", lambda on: state.__setitem__("on", bool(on)) or bool(on))
-    monkeypatch.delenv("TASEG_WGRAD_STREAM", raising=False)
+    from taseg_amd.options import options
+    monkeypatch.setattr(options, "wgrad_stream", "auto")
 
     clock = {"t": 0.0}
     monkeypatch.setattr(time, "perf_counter", lambda: clock["t"])      # a clock that only the steps advance: no timing noise
@@ -374,7 +377,59 @@ def test_wgrad_stream_tuner_keeps_the_second_stream_only_on_a_clear_win(monkeypa
     assert run([4.0], [4.4]) is False                     # slower
     assert run([4.0, 4.0, 4.0], [3.6, 4.1, 3.6]) is True  # one lost round of three is allowed
     assert run([4.0, 4.0, 4.0], [3.6, 4.1, 4.1]) is False
-    monkeypatch.setenv("TASEG_WGRAD_STREAM", "1")
+    monkeypatch.setattr(options, "wgrad_stream", "1")
     assert _fast.tune_wgrad_stream(lambda: None, lambda: None) == (True, None, None)
-    monkeypatch.setenv("TASEG_WGRAD_STREAM", "0")
+    monkeypatch.setattr(options, "wgrad_stream", "0")
     assert _fast.tune_wgrad_stream(lambda: None, lambda: None) == (False, None, None)
+
+
+def test_options_object_is_typed_and_the_environment_only_overrides():
+    """taseg_amd.options: one typed object; TASEG_<FIELD> replaces a default when the module is imported (diagnostics), legacy
+    spellings are mapped, unknown fields / values are refused, overrides are scoped"""
+    from taseg_amd.options import Options
+    o = Options()
+    assert o.rccl_direct == "c10d" and o.class_gemm is True and o.class_min_rows_96 == 48000       # the defaults
+    taken = o.load_environment({"TASEG_RCCL_DIRECT": "1", "TASEG_CLASS_GEMM": "0", "TASEG_CLASS_MIN_ROWS_96": "123", "PATH": "x",
+                                "TASEG_BENCH_WATCHDOG_S": "5"})
+    assert set(taken) == {"rccl_direct", "class_gemm", "class_min_rows_96"}
+    assert o.rccl_direct == "create" and o.class_gemm is False and o.class_min_rows_96 == 123
+    with o.override(class_gemm=True, rccl_direct="borrow"):
+        assert o.class_gemm is True and o.rccl_direct == "borrow"
+    assert o.class_gemm is False and o.rccl_direct == "create"
+    with pytest.raises(AttributeError):
+        o.no_such_option = 1
+    with pytest.raises(ValueError):
+        o.rccl_direct = "carrier-pigeon"
+    with pytest.raises(TypeError):
+        o.class_min_rows_96 = "many" if False else 1.5
+    with pytest.warns(UserWarning, match="TASEG_CLAS_GEMM"):
+        Options().load_environment({"TASEG_CLAS_GEMM": "0"})                      # a typo is reported, not ignored
+    # nothing else under taseg_amd/ reads the environment for configuration
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "taseg_amd")
+    bad = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")) and f != "options.py":
+                text = open(os.path.join(d, f)).read()
+                if re.search(r"environ[.\w]*[\[(]\s*[\"']TASEG_|getenv\(\"TASEG_", text):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_a_model_with_a_reducer_still_pickles_and_finds_its_reducer():
+    """the parameter -> reducer mapping lives outside the tensors (a weak reference in Parameter.__dict__ made torch.save(model) fail)"""
+    import io
+    import pickle
+    from taseg_amd import parallel
+    lin = torch.nn.Linear(8, 4)
+    red = parallel.GradBucketReducer(lin)
+    assert parallel.reducer_of(lin.weight) is red and parallel.reducer_of(lin.bias) is red
+    pickle.dumps(lin)
+    torch.save(lin, io.BytesIO())
+    other = torch.nn.Linear(8, 4)
+    assert parallel.reducer_of(other.weight) is None
+    red.check_open([lin.weight])
+    red.buckets[0]["launched"] = True
+    with pytest.raises(RuntimeError, match="already launched"):
+        red.check_open([lin.weight])
