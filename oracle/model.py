@@ -203,7 +203,26 @@ class OracleMinkUNet:
         z3 = self.voxel_to_point(y4, zC, cache)
         self.debug.update(kmaps=x0.kmaps, cmaps=x0.cmaps, tri=cache)
         feat = torch.cat([z1, z2, z3], 1)
+        self.debug["point_features"] = feat
         return TF.linear(feat, self.p["classifier.0.weight"], self.p["classifier.0.bias"])
+
+    def unet3d(self, x0, zC):
+        """R/.../unet3d.py:297-316 - the FOV encoder of TIAF: stem + four down stages of one residual block each, point features
+        at strides 1 / 4 / 16 -> a linear classifier; returns (logits, x4, x2, x0) like the reference."""
+        cache = {}
+        x0 = self.bn(self.conv(x0, "stem.0", 3), "stem.1")
+        x0 = x0.like(self.act(x0.F))
+        x0 = self.bn(self.conv(x0, "stem.3", 3), "stem.4")
+        x0 = x0.like(self.act(x0.F))
+        z0 = self.voxel_to_point(x0, zC, cache)
+        x1 = self.stage(x0, "stage1", 1)
+        x2 = self.stage(x1, "stage2", 1)
+        z1 = self.voxel_to_point(x2, zC, cache)
+        x3 = self.stage(x2, "stage3", 1)
+        x4 = self.stage(x3, "stage4", 1)
+        z2 = self.voxel_to_point(x4, zC, cache)
+        out = TF.linear(torch.cat([z0, z1, z2], 1), self.p["classifier.0.weight"], self.p["classifier.0.bias"])
+        return out, x4, x2, x0
 
     def forward_minkunet(self, coords, feats):
         """R/.../minkunet.py:385-422 (with initial_voxelize)."""
@@ -254,3 +273,103 @@ def loss_ce_lovasz(logits, target, ignore=0, label_smoothing=0.1):
     """R/pcseg/loss/__init__.py:52-56,106-115: CE(ignore, label smoothing) + Lovasz-softmax, weights 1."""
     ce = TF.cross_entropy(logits, target, ignore_index=ignore, label_smoothing=label_smoothing)
     return ce + lovasz_softmax_ref(logits.softmax(1), target, ignore)
+
+
+class _Renamed:
+    """a state_dict seen through a renaming of its first name component: `prefix` in front (the sub-module `lidar_backbone.`),
+    `part_suffix` behind it (the teacher's `stem_gt`, `stage1_gt`, ... of MinkUNetMsKd, minkunet_ms_kd.py:231-380)"""
+
+    def __init__(self, params, prefix="", part_suffix=""):
+        self.params, self.prefix, self.suffix = params, prefix, part_suffix
+
+    def _k(self, name):
+        head, dot, rest = name.partition(".")
+        return f"{self.prefix}{head}{self.suffix}{dot}{rest}"
+
+    def __getitem__(self, name):
+        return self.params[self._k(name)]
+
+    def __contains__(self, name):
+        return self._k(name) in self.params
+
+
+def forward_minkunet_ms_mm(params, cfg, coords, feats, fov_coords, fov_feats, image_features_fov, image_logits_fov=None,
+                           training=True, backend="numpy", act=None):
+    """MinkUNetMsMm (TIAF) below the image branch - R/.../minkunet_ms_mm.py:456-516: the FOV encoder (UNet3D) on
+    [LiDAR attributes | gathered image features (| gathered image logits)], the MinkUNet of MinkUNetMs on the fused cloud, the FOV
+    encoder's stride-16 / 4 / 1 features trilinearly interpolated onto EVERY point of the fused cloud (`voxel_to_point_fov`,
+    utils.py:149-170: a point with no FOV voxel around it gets a zero row), and `classifier_fusion` (Linear, BatchNorm1d, ReLU,
+    Linear) on the rows whose stride-16 FOV feature is not all zero.  The dense 2-D branch stays outside: `image_features_fov`
+    [n_fov, 224] (and `image_logits_fov`) are INPUTS - tensors, so that gradients with respect to them can be compared too.
+    Dropouts are identities (the tests switch them off).  Returns dict(logits, fusion_logits, fov_logits, overlap)."""
+    in_dim = cfg["IN_FEATURE_DIM"]
+    use = cfg.get("INPUT_FEAT_LIDAR")
+    fov_feats = torch.as_tensor(fov_feats)
+    cols = []
+    if "lidar" in use:
+        cols.append(fov_feats[:, :in_dim - 1])
+    if "image" in use:
+        cols.append(image_features_fov)
+    if "logit" in use:
+        cols.append(image_logits_fov)
+    fc = np.asarray(fov_coords, dtype=np.int32)
+    enc = OracleMinkUNet(_Renamed(params, prefix="lidar_backbone."), cfg, backend=backend, training=training, act=act)
+    xf = _Sparse(torch.cat(cols, 1), fc, 1)
+    xf.cmaps[1] = fc
+    fov_logits, x4f, x2f, x0f = enc.unet3d(xf, fc.astype(np.float32))
+
+    main = OracleMinkUNet(params, cfg, backend=backend, training=training, act=act)
+    logits = main.forward_minkunet_ms(coords, torch.as_tensor(feats))
+    point_feats = main.debug["point_features"]
+    zC = np.asarray(coords, dtype=np.float32)
+    fov_point = []
+    for x in (x4f, x2f, x0f):
+        idx, w = O.trilinear_map(zC, x.C, x.s)
+        fov_point.append(_Devox.apply(x.F, idx, w))
+    overlap = fov_point[0].detach().sum(-1) != 0
+    fusion = torch.cat([point_feats] + fov_point, 1)[overlap]
+    h = TF.linear(fusion, params["classifier_fusion.0.weight"], params["classifier_fusion.0.bias"])
+    h = TF.batch_norm(h, params["classifier_fusion.1.running_mean"], params["classifier_fusion.1.running_var"],
+                      params["classifier_fusion.1.weight"], params["classifier_fusion.1.bias"], training, 0.1, 1e-5)
+    fusion_logits = TF.linear(torch.relu(h), params["classifier_fusion.3.weight"], params["classifier_fusion.3.bias"])
+    return dict(logits=logits, fusion_logits=fusion_logits, fov_logits=fov_logits, overlap=overlap)
+
+
+def loss_minkunet_ms_mm(out, labels, fov_targets, image_logits_fov, image_logits_dense, image_targets_dense, weights,
+                        ignore=0, label_smoothing=0.0):
+    """the five weighted losses of R/.../minkunet_ms_mm.py:518-528 (each CE + Lovasz) -> (loss, parts[5])"""
+    labels = torch.as_tensor(labels).long()
+    fov_targets = torch.as_tensor(fov_targets).long()
+    crit = lambda lg, t: loss_ce_lovasz(lg, t, ignore, label_smoothing)      # noqa: E731
+    parts = [crit(out["logits"], labels) * weights[0],
+             crit(out["fusion_logits"], labels[out["overlap"]]) * weights[1],
+             crit(image_logits_fov, fov_targets) * weights[2],
+             crit(image_logits_dense, torch.as_tensor(image_targets_dense).long()) * weights[3],
+             crit(out["fov_logits"], fov_targets) * weights[4]]
+    return sum(parts), parts
+
+
+def forward_minkunet_ms_kd(params, cfg, coords, feats, coords_gt, feats_gt, labels, training=True, backend="numpy",
+                           feat_kd_weight=10.0, label_smoothing=0.0, ignore=0):
+    """MinkUNetMsKd's training forward - R/.../minkunet_ms_kd.py:532-640: the frozen teacher (the `*_gt` parts, no graph; its
+    BatchNorm layers follow the module's mode) on the cloud fused with ground-truth masks, the student on the cloud fused with
+    pseudo-label masks, CE + Lovasz on the student's logits, and per sample the MSE between the student's and the teacher's point
+    features on the voxels present in both clouds (coordinate hash query), weighted FEAT_KD_WEIGHT / batch size - without the random
+    sub-sampling (MAX_VOXEL above every sample's common voxels: the deterministic case the reference's fixture uses).
+    Returns dict(loss, loss_seg, loss_feat_kd, logits, teacher_logits)."""
+    teacher = OracleMinkUNet(_Renamed(params, part_suffix="_gt"), cfg, backend=backend, training=training)
+    with torch.no_grad():
+        teacher_logits = teacher.forward_minkunet_ms(coords_gt, torch.as_tensor(feats_gt))
+        feat_t = teacher.debug["point_features"]
+    student = OracleMinkUNet(params, cfg, backend=backend, training=training)
+    logits = student.forward_minkunet_ms(coords, torch.as_tensor(feats))
+    feat_s = student.debug["point_features"]
+    loss_seg = loss_ce_lovasz(logits, torch.as_tensor(labels).long(), ignore, label_smoothing)
+    c, cg = np.asarray(coords, dtype=np.int32), np.asarray(coords_gt, dtype=np.int32)
+    s2t = O.sphashquery(O.sphash(c), O.sphash(cg))
+    batch_size = int(c[:, 3].max()) + 1
+    loss_kd = 0
+    for b in range(batch_size):
+        pick = np.nonzero((s2t >= 0) & (c[:, 3] == b))[0]
+        loss_kd = loss_kd + TF.mse_loss(feat_s[pick], feat_t[s2t[pick]]) * feat_kd_weight / batch_size
+    return dict(loss=loss_seg + loss_kd, loss_seg=loss_seg, loss_feat_kd=loss_kd, logits=logits, teacher_logits=teacher_logits)
