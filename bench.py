@@ -141,6 +141,9 @@ def parse():
     ap.add_argument("--eval", action="store_true",
                     help="evaluation pass instead of a training step: eval-mode forward on the index plan + un-voxelisation + "
                          "arg-max per point, as the segmentors' eval branch returns it (minkunet.py:435-455, R/train.py:452-540)")
+    ap.add_argument("--history", type=int, default=None,
+                    help="minkunet_ms: history scans fused per sample (default 4 = BASELINE configs[2]; the reference's FSA recipe, "
+                         "minkunet_mk34_cr10_fsa.yaml:14,34, is 16 at bs 6)")
     ap.add_argument("--image-layout", default=None, choices=["nhwc", "nchw"],
                     help="tiaf: memory format of UNet2D and form of the image gather (default: taseg_amd.options.image_layout = nhwc)")
     ap.add_argument("--no-secondary", action="store_true",
@@ -350,6 +353,29 @@ def tiaf_phase_table(model, net, opt, make_batch, amp, steps=3):
         out[name] = round(sum(vals) / len(vals), 3) if vals else None
     out["step (staged in line)"] = round(sum(m["start"].elapsed_time(m["optimizer_done"]) for m in marks_all) / len(marks_all), 3)
     return out
+
+
+def miopen_find_db():
+    """UNet2D's dense 2-D convolutions run on MIOpen (out of the hand-written scope).  On a machine that has never
+    run these shapes MIOpen first measures its solvers and compiles the chosen kernels: ~3 minutes before the first TIAF step, and a
+    line is only as good as the solvers that search ends with.  taseg_amd/data/miopen_gfx950/ holds what that search produced for the
+    shapes of the TIAF workload on this ROCm (MIOpen's user find-db, text, + its kernel cache): copied into a private directory that
+    MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR point at (MIOpen writes there), unless the caller has set either variable.  A
+    db of another MIOpen build / device is ignored by MIOpen itself (file names carry version, arch and CU count)."""
+    if os.environ.get("MIOPEN_USER_DB_PATH") or os.environ.get("MIOPEN_CUSTOM_CACHE_DIR") or os.environ.get("TASEG_BENCH_MIOPEN_DB") == "0":
+        return None
+    src = os.path.join(ROOT, "taseg_amd", "data", "miopen_gfx950")
+    if not os.path.isdir(src):
+        return None
+    import shutil
+    import tempfile
+    dst = tempfile.mkdtemp(prefix="taseg_miopen_")
+    for f in os.listdir(src):
+        if f.endswith((".txt", ".ukdb")):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = dst
+    return dst
 
 
 def make_nusc_samples(rank, batch, points, multiscan=15, step=1.0):
@@ -649,8 +675,10 @@ def launches_of(args):
     path = os.path.join(ROOT, "profiles", "launches.json")
     if not os.path.exists(path):
         return None
+    default_bs = {"nuscenes_ms": 4, "kd": 6}.get(args.workload, 2)
     key = ("eval " if getattr(args, "eval", False) else "") + args.workload + (" amp" if args.amp else "") + \
-        (" force-dist" if args.force_dist else "") + (f" bs{args.batch}" if args.batch not in (None, 2, 4) else "")
+        (" force-dist" if args.force_dist else "") + (f" bs{args.batch}" if args.batch not in (None, default_bs) else "") + \
+        (f" history{args.history}" if getattr(args, "history", None) else "")
     return json.load(open(path)).get(key)
 
 
@@ -699,7 +727,7 @@ def build_roofline(prof, amp, bracket_us):
     return roof
 
 
-def secondary_runs(steps=30, warmup=8):
+def secondary_runs(steps=30, warmup=8, only=None):
     """Short runs of the other BASELINE configurations (4-scan TFA, AMP, nuScenes shape + AMP) as CHILD processes after
     the headline measurement, so that the driver's default invocation observes them too.  Each entry is the child's
     own JSON line cut down to value / ms_per_step / dtype / config."""
@@ -708,7 +736,16 @@ def secondary_runs(steps=30, warmup=8):
     # (`--workload tiaf` is NOT among them: on a fresh box its first steps are MIOpen's search over the 2-D convolutions of UNet2D -
     # 3.5 minutes of a default invocation - and a line is only as good as the solvers that search ends with; run it by hand,
     # profiles/r05_bench_workloadtiaf.json holds the round's line)
-    for extra in (["--workload", "minkunet_ms"], ["--amp"], ["--workload", "nuscenes_ms", "--amp"], ["--eval"], ["--eval", "--amp"]):
+    # (the last three: the reference's own recipes - single-frame at bs 12 / GPU, minkunet_mk34_cr10.yaml:26; FSA with 16 history scans
+    # at bs 6 / GPU, minkunet_mk34_cr10_fsa.yaml:14,34, both under --amp as dist_train.sh:18 runs them - and the mask-distillation
+    # step, minkunet_mk34_cr10_fsa_kd.yaml; fewer, longer steps)
+    runs = [(["--workload", "minkunet_ms"], steps, warmup), (["--amp"], steps, warmup), (["--workload", "nuscenes_ms", "--amp"], steps, warmup),
+            (["--eval"], steps, warmup), (["--eval", "--amp"], steps, warmup),
+            (["--batch", "12", "--amp"], 15, 4), (["--workload", "minkunet_ms", "--history", "16", "--batch", "6", "--amp"], 12, 4),
+            (["--workload", "kd"], 12, 4)]
+    if only:
+        runs = [r for r in runs if " ".join(r[0]) in only]
+    for extra, steps, warmup in runs:
         note("secondary run: " + " ".join(extra))
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
                "--no-secondary"] + extra           # per-launch events on the first timed step: every entry has its roofline
@@ -905,8 +942,7 @@ def main():
     tiaf = args.workload == "tiaf"
     kd = args.workload == "kd"
     ms = args.workload in ("minkunet_ms", "nuscenes_ms", "tiaf", "kd")
-    if kd:
-        args.no_kernel_events = True      # (two networks in one step: the per-kernel table of the single-network lines does not apply)
+    # (kd: the per-launch events cover BOTH networks of the step - the frozen teacher's forward pass and the student's forward + backward)
     if args.batch is None:
         args.batch = 4 if nusc else 6 if kd else 2       # (kd yaml :44 BATCH_SIZE_PER_GPU 6)
     if args.points is None:
@@ -920,6 +956,9 @@ def main():
         from taseg_amd.data.synthetic import TIAF_CFG
         from taseg_amd.options import options as _opts
         extra_cfg = dict(TIAF_CFG)
+        miopen_find_db()
+        if os.environ.get("TASEG_BENCH_MIOPEN_FIND") == "1":       # MIOpen's measured solver search for UNet2D's convolutions (minutes
+            torch.backends.cudnn.benchmark = True                  # on a machine without a find-db for these shapes)
         if args.image_layout:
             _opts.image_layout = args.image_layout
     if kd:
@@ -989,7 +1028,7 @@ def main():
                 nvox_gt[0] = int(bd["lidar_ms_gt"].C.shape[0])
                 return bd
         else:
-            scans, npts = make_multiscans(rank, args.batch, args.points)
+            scans, npts = make_multiscans(rank, args.batch, args.points, history=args.history or 4)
 
             def make_batch():
                 bd = build_multiscan_batch(scans, voxel, FLEXIBLE_STEPS_KITTI)
@@ -1195,7 +1234,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 storage / f32 accumulate (torch.autocast)" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": f"{name} mk34 cr1.0 ("
-                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else 'TIAF: 16 fused history scans + 5 camera frames of 384 x 1280 per sample, UNet2D + UNet3D + fusion head, five losses' if tiaf else 'mask distillation: 16 history scans fused twice per sample, frozen teacher forward + student step, segmentation + feature MSE losses' if kd else '4-scan TFA multi-scan' if ms else 'single-frame'}), "
+                                   f"{'nuScenes FSA stage: sweeps selected at 1 m of driven distance up to 15 m + keyframes' if nusc else 'TIAF: 16 fused history scans + 5 camera frames of 384 x 1280 per sample, UNet2D + UNet3D + fusion head, five losses' if tiaf else 'mask distillation: 16 history scans fused twice per sample, frozen teacher forward + student step, segmentation + feature MSE losses' if kd else f'{args.history or 4}-scan TFA multi-scan' if ms else 'single-frame'}), "
                                    f"bs={args.batch}/GPU, voxel {voxel:g} m, {'AMP fp16' if args.amp else 'fp32'}, rulebook+fwd+loss+bwd+SGD step",
                        "points_per_step_per_gpu": npts, "voxels_per_step_per_gpu": nvox[0],
                        "parallelism": f"dp{world}",
@@ -1221,8 +1260,8 @@ def main():
             from taseg_amd.options import options as _opts
             line["config"]["fov_points_per_step_per_gpu"] = n_fov[0]
             line["config"]["image_layout"] = _opts.image_layout
-            gat = tiaf_gather_roofline(model, pf._current if pf is not None and pf._current is not None else make_batch(),
-                                       _opts.image_layout, torch.float16 if args.amp else torch.float32)
+            # (a FRESH batch: the forward pass of a step overwrites the FOV cloud's feature matrix, pixel columns included)
+            gat = tiaf_gather_roofline(model, make_batch(), _opts.image_layout, torch.float16 if args.amp else torch.float32)
             line["image_gather"] = gat
             # the line's roofline object: the hand-written kernel of this workload that moves the most bytes - the gather of the
             # 96-channel full-resolution map - forward and adjoint (HBM-bound: algorithmic bytes / event-bracketed launch time)

@@ -25,17 +25,27 @@
 
 #include "common.h"
 
-__device__ __forceinline__ bool image_pixel(const float *__restrict__ pix, const int *__restrict__ pbatch,
-                                            const int *__restrict__ frame_end, int64_t n, int n_batch, int T, int H,
-                                            int W, int shift, int &frame, int &r, int &c) {
+// pixel address (frame * hs + r) * ws + c of point n in the [T, hs, ws] stack, or `limit` when the point falls outside its
+// sample's frames.  Written without early exits and with ONE select at the end: with the key initialised to `limit` and
+// overwritten in a branch, hipcc (ROCm 7.2) kept the key in the register its integer division used as scratch, and an invalid
+// point left the kernel with row / H as its key (found in round 6: `err` was right, the address was not).
+__device__ __forceinline__ unsigned image_pixel_key(const float *__restrict__ pix, const int *__restrict__ pbatch,
+                                                    const int *__restrict__ frame_end, int64_t n, int n_batch, int T, int H, int W,
+                                                    int shift, unsigned limit) {
+  const int hs = H >> shift, ws = W >> shift;
   const int row = (int)pix[2 * n], col = (int)pix[2 * n + 1];   // `.long()` of a non-negative float: truncation
   const int b = pbatch[n];
-  if (b < 0 || b >= n_batch || row < 0 || col < 0) return false;
-  const int start = b > 0 ? frame_end[b - 1] : 0;
-  frame = start + row / H;
-  r = (row % H) >> shift;
-  c = col >> shift;
-  return frame < T && frame < frame_end[b] && c < (W >> shift);
+  const bool in_batch = b >= 0 && b < n_batch;
+  const int bc = in_batch ? b : 0;
+  const int start = bc > 0 ? frame_end[bc - 1] : 0;
+  const int end = frame_end[bc];
+  const int rowc = row < 0 ? 0 : row;
+  const int frame = start + rowc / H;
+  const int r = (rowc % H) >> shift;
+  const int c = (col < 0 ? 0 : col) >> shift;
+  const bool ok = in_batch && row >= 0 && col >= 0 && frame < T && frame < end && c < ws;
+  const unsigned key = (unsigned)((frame * hs + r) * ws + c);
+  return ok ? key : limit;
 }
 
 // key = pixel address in the [T, hs, ws] stack, `limit` (= T * hs * ws) for a point outside its sample's frames (sorts last)
@@ -43,15 +53,10 @@ __global__ __launch_bounds__(256) void image_key_kernel(const float *__restrict_
                                                         const int *__restrict__ frame_end, int64_t n_pts, int n_batch, int T, int H,
                                                         int W, int shift, unsigned limit, unsigned *__restrict__ keys,
                                                         int *__restrict__ idx, int *__restrict__ err) {
-  const int hs = H >> shift, ws = W >> shift;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pts) return;
-  int f, r, c;
-  unsigned key = limit;
-  if (image_pixel(pix, pbatch, frame_end, i, n_batch, T, H, W, shift, f, r, c))
-    key = (unsigned)((f * hs + r) * ws + c);
-  else
-    *err = 1;          // the reference would raise an IndexError
+  const unsigned key = image_pixel_key(pix, pbatch, frame_end, i, n_batch, T, H, W, shift, limit);
+  if (key >= limit) *err = 1;          // the reference would raise an IndexError
   keys[i] = key;
   idx[i] = (int)i;
 }
@@ -262,10 +267,11 @@ extern "C" int ts_image_gather_backward(const float *grad_out, int32_t C, int64_
 template <typename V>
 __global__ __launch_bounds__(256) void image_rows_gather_kernel(const char *__restrict__ feat, int pieces, const int *__restrict__ perm,
                                                                 const int *__restrict__ paddr, int64_t n_pts, char *__restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t i = e / pieces;
-  if (i >= n_pts) return;
-  const int j = (int)(e - i * pieces);
+  // (32-bit index arithmetic: the entry checks n_pts * pieces < 2^31)
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = e / (unsigned)pieces;
+  if (i >= (unsigned)n_pts) return;
+  const unsigned j = e - i * (unsigned)pieces;
   const int a = paddr[i];
   V v;
   memset(&v, 0, sizeof(V));            // a point outside its sample's frames (plan's err) reads as zeros
@@ -294,13 +300,13 @@ __global__ __launch_bounds__(256) void image_rows_scatter_kernel(const T *__rest
   struct alignas(VE * sizeof(T)) Vec {
     T x[VE];
   };
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t i = e / pieces;
-  if (i >= n_pts) return;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = e / (unsigned)pieces;
+  if (i >= (unsigned)n_pts) return;
   const int len = run[i];
   const int a = paddr[i];
   if (len <= 0 || a < 0) return;
-  const int j = (int)(e - i * pieces);
+  const unsigned j = e - i * (unsigned)pieces;
   const size_t row = (size_t)pieces * VE;
   float acc[VE];
 #pragma unroll
@@ -336,6 +342,7 @@ extern "C" int ts_image_gather_rows_forward(const void *feat, int32_t C, int32_t
   const size_t row = (size_t)C * elem_bytes;
   const int v = image_piece_bytes(row, feat, out);
   const int pieces = (int)(row / v);
+  TS_REQUIRE(n_pts * pieces < (1LL << 31), TS_ERR_UNSUPPORTED, "ts_image_gather_rows_forward: more than 2^31 row pieces");
   const unsigned grid = (unsigned)ts_cdiv(n_pts * pieces, 256);
   const char *f = (const char *)feat;
   char *o = (char *)out;
@@ -357,6 +364,7 @@ static int image_rows_scatter(const T *g, int C, const int32_t *perm, const int3
   TS_REQUIRE(v >= (int)sizeof(T), TS_ERR_INVALID_ARGUMENT, "ts_image_gather_rows_backward: pointers must be aligned to the element size");
   const int ve = v / (int)sizeof(T);
   const int pieces = C / ve;
+  TS_REQUIRE(n_pts * pieces < (1LL << 31), TS_ERR_UNSUPPORTED, "ts_image_gather_rows_backward: more than 2^31 row pieces");
   const unsigned grid = (unsigned)ts_cdiv(n_pts * pieces, 256);
   if constexpr (sizeof(T) == 2) {
     if (ve == 8) {
@@ -384,10 +392,9 @@ extern "C" int ts_image_gather_rows_backward(const void *grad_out, int32_t C, in
   if (!accumulate) TS_CHECK_HIP(hipMemsetAsync(grad_feat, 0, (size_t)n_feat * (half ? 2 : 4), stream), "image gather memset");
   if (n_pts == 0) return TS_OK;
   TS_REQUIRE(grad_out && perm && paddr && run, TS_ERR_INVALID_ARGUMENT, "ts_image_gather_rows_backward: null pointer");
-  if (half)
-    image_rows_scatter<__half>((const __half *)grad_out, C, perm, paddr, run, n_pts, (__half *)grad_feat, stream);
-  else
-    image_rows_scatter<float>((const float *)grad_out, C, perm, paddr, run, n_pts, (float *)grad_feat, stream);
+  const int rc = half ? image_rows_scatter<__half>((const __half *)grad_out, C, perm, paddr, run, n_pts, (__half *)grad_feat, stream)
+                      : image_rows_scatter<float>((const float *)grad_out, C, perm, paddr, run, n_pts, (float *)grad_feat, stream);
+  if (rc != TS_OK) return rc;
   TS_CHECK_LAUNCH("ts_image_gather_rows_backward");
   return TS_OK;
 }

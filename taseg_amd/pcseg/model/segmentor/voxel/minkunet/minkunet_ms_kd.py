@@ -71,7 +71,9 @@ class MinkUNetMsKd(MinkUNetBackbone):
         else:
             key = torch.where(cand, torch.rand(n, device=dev, dtype=torch.float64), torch.full((), 2.0, device=dev, dtype=torch.float64))
             order = torch.argsort(b.double() * 4.0 + key)                       # sample-major, candidates first, random among them
-        rows = torch.bincount(b, minlength=batch_size)[:batch_size]
+        # (rows per sample without torch.bincount: it reads the largest value back to size its result - a host wait for the whole
+        # forward pass of both networks in the middle of the step, 45 ms at bs 6)
+        rows = torch.zeros(batch_size, dtype=torch.int64, device=dev).index_add_(0, b.clamp(max=batch_size - 1), torch.ones_like(b))
         start = torch.cumsum(rows, 0) - rows
         rank = torch.empty(n, dtype=torch.int64, device=dev)
         rank[order] = torch.arange(n, device=dev) - start[b[order]]

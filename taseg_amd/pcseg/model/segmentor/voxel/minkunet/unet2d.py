@@ -216,16 +216,26 @@ class UNet2D(nn.Module):
             self._layout = want
         return want
 
-    def forward(self, data_dict):
-        x = data_dict["image_input"]
-        x = x.contiguous(memory_format=self._set_layout())
-        height, width = int(x.shape[2]), int(x.shape[3])
+    # the dense network in three pieces around the two maps the hand-over reads (unet2d.py:155-172); a test can stand in for them
+    def _encode(self, x):
         x0 = self.stem(x)
         x1, s1 = self.stage1(x0)
         x2, s2 = self.stage2(x1)
         x3, s3 = self.stage3(x2)
         x4, s4 = self.stage4(x3)
-        x5 = self.mid_stage(x4)
+        return self.mid_stage(x4), (s1, s2, s3, s4)
+
+    def _decode_u2(self, x5, skips):
+        return self.up2(self.up1(x5, skips[3]), skips[2])           # 1/4 scale, 128 channels
+
+    def _decode_u4(self, u2, skips):
+        return self.up4(self.up3(u2, skips[1]), skips[0])           # full scale, 96 channels
+
+    def forward(self, data_dict):
+        x = data_dict["image_input"]
+        x = x.contiguous(memory_format=self._set_layout())
+        height, width = int(x.shape[2]), int(x.shape[3])
+        x5, skips = self._encode(x)
         fov = data_dict["lidar_fov_ms"]
         pix = fov.F[:, -2:].float().contiguous()                      # (row in the sample's stacked frames, col)
         pbatch = fov.C[:, -1].int().contiguous()
@@ -233,12 +243,10 @@ class UNet2D(nn.Module):
         with torch.no_grad():       # the points in raster order, once per scale (csrc/image.hip)
             plan0 = image_plan(pix, pbatch, frame_end, x.shape[0], height, width, 0)
             plan4 = image_plan(pix, pbatch, frame_end, x.shape[0], height, width, 2)
-        u1 = self.up1(x5, s4)
-        u2 = self.up2(u1, s3)           # 1/4 scale, 128 channels
+        u2 = self._decode_u2(x5, skips)
         # (the gathered maps go on THROUGH their gather nodes: the adjoint is added into the gradient they get from here on)
         u2, feat4 = _image_gather_through(u2, plan4)
-        u3 = self.up3(u2, s2)
-        u4 = self.up4(u3, s1)           # full scale, 96 channels
+        u4 = self._decode_u4(u2, skips)
         u4, feat0 = _image_gather_through(u4, plan0)
         logits = self.classifier(u4)
         logits, logits_fov = _image_gather_through(logits, plan0)

@@ -13,7 +13,7 @@
 // i.e. +15 us per layer and direction instead of -10: a wave's 64 lanes read 64 different rows, so every load instruction touches
 // 64 cache lines of which 16 bytes each are used, and C / 4 = 32-64 workgroups occupy 32-64 of the 256 CUs - the texture path
 // of those few CUs serialises ~4 x N line requests per direction (9.2k rows: ~18 us) where the three launches stream the same
-// bytes coalesced over 200+ CUs.  Together with steps 9c / 10d / 10e / 11c of DESIGN.md section 3.1 this closes the list of
+// bytes coalesced over 200+ CUs.  Together with steps 9c / 10d / 10e / 11c of HISTORY.md section 3.1 this closes the list of
 // launch mergers for the BatchNorm chain that do not need a grid-wide synchronisation.  It also moved one mk34 gradient
 // (up1.0.net.0.kernel) from 4.7e-4 to 1.6e-3 of the float64 evaluation - another summation order in a chaotic train-mode chain.
 //
