@@ -733,16 +733,15 @@ def secondary_runs(steps=30, warmup=8, only=None):
     own JSON line cut down to value / ms_per_step / dtype / config."""
     import subprocess
     out = []
-    # (`--workload tiaf` is NOT among them: on a fresh box its first steps are MIOpen's search over the 2-D convolutions of UNet2D -
-    # 3.5 minutes of a default invocation - and a line is only as good as the solvers that search ends with; run it by hand,
-    # profiles/r05_bench_workloadtiaf.json holds the round's line)
     # (the last three: the reference's own recipes - single-frame at bs 12 / GPU, minkunet_mk34_cr10.yaml:26; FSA with 16 history scans
     # at bs 6 / GPU, minkunet_mk34_cr10_fsa.yaml:14,34, both under --amp as dist_train.sh:18 runs them - and the mask-distillation
     # step, minkunet_mk34_cr10_fsa_kd.yaml; fewer, longer steps)
     runs = [(["--workload", "minkunet_ms"], steps, warmup), (["--amp"], steps, warmup), (["--workload", "nuscenes_ms", "--amp"], steps, warmup),
             (["--eval"], steps, warmup), (["--eval", "--amp"], steps, warmup),
             (["--batch", "12", "--amp"], 15, 4), (["--workload", "minkunet_ms", "--history", "16", "--batch", "6", "--amp"], 12, 4),
-            (["--workload", "kd"], 12, 4)]
+            (["--workload", "kd"], 12, 4),
+            # TIAF in the reference's mode (UNet2D channels-last under autocast; MIOpen's find-db for its shapes ships with the tree)
+            (["--workload", "tiaf", "--amp"], 6, 3)]
     if only:
         runs = [r for r in runs if " ".join(r[0]) in only]
     for extra, steps, warmup in runs:
@@ -766,9 +765,11 @@ def secondary_runs(steps=30, warmup=8, only=None):
                 entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us", "avg_us_net", "hbm_frac_net", "mfma_frac_net",
                                                              "ms_per_step", "launches_per_step", "mfma_frac", "hbm_frac",
                                                              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
-                                                             "whole_step_lower_bound_ms", "small_layers")} if roof else None
+                                                             "whole_step_lower_bound_ms", "small_layers", "adjoint", "all_maps")} if roof else None
                 if rec.get("image_gather") is not None:
                     entry["image_gather"] = rec["image_gather"]
+                if rec.get("phases_ms") is not None:
+                    entry["phases_ms"] = rec["phases_ms"]
                 entry["conv_bytes_per_step"] = rec.get("conv_bytes_per_step")
                 entry["ideal_fused_bytes_per_step"] = rec.get("ideal_fused_bytes_per_step")
         except Exception as exc:      # a failed side run must not lose the headline line

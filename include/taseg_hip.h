@@ -421,6 +421,27 @@ int ts_image_gather_rows_backward(const void *grad_out, int32_t C, int32_t half,
                                   const int32_t *run, int64_t n_pts, void *grad_feat, int64_t n_feat, int32_t accumulate,
                                   ts_stream_t stream);
 
+/* AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad) of UNet2D's encoder blocks (R pcseg/model/segmentor/voxel/minkunet/
+ * unet2d.py:58-62: `nn.AvgPool2d(kernel_size=kernel_size, stride=2, padding=1)`, kernel_size (3, 3)) on a channels-last stack:
+ * x [T, H, W, C] -> y [T, Ho, Wo, C], Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1; fp32 accumulation, sum / 9.  half != 0: IEEE half.
+ * The backward writes every element of grad_x (a gather over the <= 4 windows that hold a pixel: no atomics). */
+int ts_avgpool3s2_rows_forward(const void *x, int32_t T, int32_t H, int32_t W, int32_t C, int32_t half, void *y, ts_stream_t stream);
+int ts_avgpool3s2_rows_backward(const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t C, int32_t half, void *grad_x,
+                                ts_stream_t stream);
+
+/* LeakyReLU -> BatchNorm2d (training) of UNet2D's blocks (unet2d.py:24-30,71,108: `bn(act(conv(x)))`, `nn.LeakyReLU()` slope 0.01) on
+ * a channels-last stack seen as rows [N = T*H*W, C]: partial sums -> finish (double) -> elementwise pass, per direction.
+ *   forward   out = (leaky(x) - mean) * invstd * weight + bias; mean / invstd [C] (statistics of the ACTIVATED values) kept for the
+ *             backward; running_mean / running_var (momentum, unbiased variance) and num_batches_tracked updated when not NULL
+ *   backward  grad_x with respect to the LeakyReLU's input, grad_weight / grad_bias [C] (may be NULL)
+ * half != 0: IEEE half rows (C % 8 == 0), else float (C % 4 == 0); C <= 1024; ws >= ts_bn_train_workspace_bytes(c). */
+int ts_leaky_bn_train_forward(const void *x, const float *weight, const float *bias, float *running_mean, float *running_var,
+                              int64_t *num_batches_tracked, int64_t n, int32_t c, float eps, float momentum, float slope, int32_t half,
+                              float *mean, float *invstd, void *out, void *ws, size_t ws_bytes, ts_stream_t stream);
+int ts_leaky_bn_train_backward(const void *grad_out, const void *x, const float *mean, const float *invstd, const float *weight,
+                               int64_t n, int32_t c, float slope, int32_t half, void *grad_x, float *grad_weight, float *grad_bias,
+                               void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* ---- fp16 storage / fp32 accumulation (the reference trains under AMP: conv.py:19 `custom_fwd(cast_inputs=half)`).
  * `void *` operands are IEEE half arrays.  Channel counts must be multiples of 32, K <= 63.
  *   ts_cast_weights_f16      w f32 [K, Ci, Co] -> w16 [K, Ci, Co] and / or w16t [K, Co, Ci] (either may be NULL)

@@ -84,6 +84,11 @@ SIGNATURES = {
     "ts_image_gather_backward": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "ts_image_gather_rows_forward": (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "ts_image_gather_rows_backward": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "ts_avgpool3s2_rows_forward": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_avgpool3s2_rows_backward": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_leaky_bn_train_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _i32, _vp, _vp, _vp,
+                                         _vp, _sz, _vp]),
+    "ts_leaky_bn_train_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_pair_gemm_f16_nat": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),

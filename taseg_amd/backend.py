@@ -20,7 +20,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward",
 ]
 
 
@@ -835,6 +835,37 @@ def image_gather_rows_backward(grad_out, plan, channels, dtype=None, into=None):
                                                    L.ptr(plan["paddr"]), L.ptr(plan["run"]), n, L.ptr(out), out.numel(), acc,
                                                    L.stream()), "ts_image_gather_rows_backward")
     return out
+
+
+def _pool_dtype(t, what):
+    if t.dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"{what}: float32 / float16 only, got {t.dtype}")
+    return 1 if t.dtype == torch.float16 else 0
+
+
+def avgpool3s2_rows_forward(x):
+    """AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad) of a channels-last [T, C, H, W] float32 / float16 stack ->
+    [T, C, Ho, Wo], channels-last (csrc/image.hip)."""
+    L.require_device(x)
+    half = _pool_dtype(x, "avgpool3s2_rows_forward")
+    x = _channels_last_rows(x, "avgpool3s2_rows_forward")
+    t, c, h, w = x.shape
+    y = torch.empty((t, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    L.check(L.load().ts_avgpool3s2_rows_forward(L.ptr(x), t, h, w, c, half, L.ptr(y), L.stream()), "ts_avgpool3s2_rows_forward")
+    return y
+
+
+def avgpool3s2_rows_backward(grad_y, in_shape):
+    """gradient of avgpool3s2_rows_forward with respect to its input of shape `in_shape` (channels-last, grad_y's dtype)"""
+    L.require_device(grad_y)
+    half = _pool_dtype(grad_y, "avgpool3s2_rows_backward")
+    t, c, h, w = (int(v) for v in in_shape)
+    if tuple(grad_y.shape) != (t, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1):
+        raise ValueError(f"avgpool3s2_rows_backward: gradient of shape {tuple(grad_y.shape)} for an input of {(t, c, h, w)}")
+    grad_y = grad_y.contiguous(memory_format=torch.channels_last)
+    gx = torch.empty((t, c, h, w), dtype=grad_y.dtype, device=grad_y.device, memory_format=torch.channels_last)
+    L.check(L.load().ts_avgpool3s2_rows_backward(L.ptr(grad_y), t, h, w, c, half, L.ptr(gx), L.stream()), "ts_avgpool3s2_rows_backward")
+    return gx
 
 
 def set_conv_impl(impl):

@@ -783,3 +783,206 @@ extern "C" int ts_bn_act_backward_f16(const void *grad_out, const uint8_t *mask,
   TS_CHECK_LAUNCH("ts_bn_act_backward_f16");
   return TS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// LeakyReLU -> BatchNorm (training) in one chain of passes, for the dense 2-D branch of TIAF (R/pcseg/model/segmentor/voxel/
+// minkunet/unet2d.py:24-30,71,108: every block computes `bn(act(conv(x)))` with `nn.LeakyReLU()`, slope 0.01).  A channels-last
+// feature stack [T, H, W, C] IS a row matrix [T*H*W, C], so the sliced statistics / double finish of the sparse BatchNorm above
+// serve it; what differs is the activation IN FRONT of the normalisation:
+//   forward   a = leaky(x);  out = (a - mean(a)) * invstd(a) * w + b             (x = the convolution's output, kept for backward)
+//   backward  gw = sum dy (a - mean) invstd,  gb = sum dy,  ga = (dy - mean(dy) - (a - mean) invstd^2 mean(dy (a - mean))) invstd w,
+//             gx = ga * (x > 0 ? 1 : slope)
+// Three launches per direction (partial sums -> finish -> elementwise), 2 reads + 1 write of N*C*s forward, 3 reads + 1 write
+// backward, where the library path of this PyTorch-ROCm takes a LeakyReLU pass, a layout copy and three MIOpen BatchNorm kernels
+// forward, and as many backward.  T = float (4 channels per thread) or _Float16 (8 per thread); statistics fp32 / double.
+template <typename T, int VE>
+struct alignas(VE * sizeof(T)) LbnVec {
+  T x[VE];
+};
+
+__device__ __forceinline__ float lbn_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// MODE 0: (a, a^2)   1: (dy, dy (a - mean))
+template <typename T, int VE, int MODE>
+__global__ __launch_bounds__(256) void lbn_partial_kernel(const T *__restrict__ X, const T *__restrict__ DY, const float *__restrict__ mean,
+                                                          float slope, int64_t n, int c, int rows_per_wg, float *__restrict__ part) {
+  using V = LbnVec<T, VE>;
+  __shared__ float red[2][256 * VE];
+  const int cq = c / VE, rpp = 256 / cq;
+  const int tid = threadIdx.x, ty = tid / cq, tx = tid - ty * cq;
+  const bool active = ty < rpp;
+  float s0[VE], s1[VE], mu[VE];
+#pragma unroll
+  for (int i = 0; i < VE; ++i) s0[i] = s1[i] = mu[i] = 0.f;
+  if (MODE != 0 && active) {
+#pragma unroll
+    for (int i = 0; i < VE; ++i) mu[i] = mean[VE * tx + i];
+  }
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_wg, r_end = min(n, r_beg + rows_per_wg);
+  if (active) {
+#pragma unroll 2
+    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
+      const V x = *(const V *)(X + r * c + VE * tx);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+          const float a = lbn_leaky((float)x.x[i], slope);
+          s0[i] += a;
+          s1[i] += a * a;
+        }
+      } else {
+        const V d = *(const V *)(DY + r * c + VE * tx);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+          const float dv = (float)d.x[i];
+          s0[i] += dv;
+          s1[i] += dv * (lbn_leaky((float)x.x[i], slope) - mu[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VE; ++i) {
+    red[0][tid * VE + i] = s0[i];
+    red[1][tid * VE + i] = s1[i];
+  }
+  __syncthreads();
+  float *out = part + (int64_t)blockIdx.x * 2 * c;
+  for (int ch = tid; ch < c; ch += 256) {
+    const int q = ch / VE, l = ch % VE;
+    float a = 0.f, b = 0.f;
+    for (int y = 0; y < rpp; ++y) {
+      a += red[0][(y * cq + q) * VE + l];
+      b += red[1][(y * cq + q) * VE + l];
+    }
+    out[ch] = a;
+    out[c + ch] = b;
+  }
+}
+
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void lbn_fwd_kernel(const LbnVec<T, VE> *__restrict__ X, const float *__restrict__ mean,
+                                                      const float *__restrict__ invstd, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float slope, int64_t total, int cq,
+                                                      LbnVec<T, VE> *__restrict__ OUT) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    const int q = (int)(e % cq) * VE;
+    const LbnVec<T, VE> x = X[e];
+    LbnVec<T, VE> y;
+#pragma unroll
+    for (int i = 0; i < VE; ++i)
+      y.x[i] = (T)((lbn_leaky((float)x.x[i], slope) - mean[q + i]) * invstd[q + i] * w[q + i] + b[q + i]);
+    OUT[e] = y;
+  }
+}
+
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void lbn_bwd_kernel(const LbnVec<T, VE> *__restrict__ GOUT, const LbnVec<T, VE> *__restrict__ X,
+                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                      const float *__restrict__ w, const float *__restrict__ coef, float slope,
+                                                      int64_t total, int c, LbnVec<T, VE> *__restrict__ GX) {
+  const int cq = c / VE;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; e < total; e += step) {
+    const int q = (int)(e % cq) * VE;
+    const LbnVec<T, VE> g = GOUT[e], x = X[e];
+    LbnVec<T, VE> gx;
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+      const float xv = (float)x.x[i];
+      const float ga = ((float)g.x[i] - coef[q + i] - (lbn_leaky(xv, slope) - mean[q + i]) * coef[c + q + i]) * invstd[q + i] * w[q + i];
+      gx.x[i] = (T)(xv > 0.f ? ga : ga * slope);
+    }
+    GX[e] = gx;
+  }
+}
+
+static int lbn_check(const char *what, int64_t n, int32_t c, int32_t half, size_t ws_bytes) {
+  const int ve = half ? 8 : 4;
+  TS_REQUIRE(n > 0 && c > 0 && c % ve == 0 && c / ve <= 256 && c <= 1024, TS_ERR_UNSUPPORTED,
+             "%s: need N > 0 and C a multiple of %d, <= 1024", what, ve);
+  TS_REQUIRE(ws_bytes >= ts_bn_train_workspace_bytes(c), TS_ERR_WORKSPACE_TOO_SMALL, "%s: workspace too small", what);
+  return TS_OK;
+}
+
+template <typename T, int VE>
+static inline int lbn_rows_per_slice(int64_t n, int c) {
+  const int rpp = 256 / (c / VE);
+  int64_t rows = std::max<int64_t>(ts_cdiv(n, BN_MAX_SLICES), 32);
+  return (int)(ts_cdiv(rows, rpp) * rpp);
+}
+
+template <typename T, int VE>
+static void lbn_forward_launch(const void *x, const float *weight, const float *bias, float *running_mean, float *running_var,
+                               int64_t *nbt, int64_t n, int c, float eps, float momentum, float slope, float *mean, float *invstd,
+                               void *out, float *part, hipStream_t stream) {
+  const int rows = lbn_rows_per_slice<T, VE>(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  lbn_partial_kernel<T, VE, 0><<<slices, 256, 0, stream>>>((const T *)x, nullptr, nullptr, slope, n, c, rows, part);
+  bn_fwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, eps, momentum, running_mean,
+                                                                           running_var, mean, invstd, nbt);
+  const int64_t total = n * (c / VE);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total, 256), 1 << 16);
+  lbn_fwd_kernel<T, VE><<<grid, 256, 0, stream>>>((const LbnVec<T, VE> *)x, mean, invstd, weight, bias, slope, total, c / VE,
+                                                  (LbnVec<T, VE> *)out);
+}
+
+template <typename T, int VE>
+static void lbn_backward_launch(const void *grad_out, const void *x, const float *mean, const float *invstd, const float *weight,
+                                int64_t n, int c, float slope, void *grad_x, float *grad_weight, float *grad_bias, float *part,
+                                hipStream_t stream) {
+  float *coef = part + (size_t)BN_MAX_SLICES * 2 * c;
+  const int rows = lbn_rows_per_slice<T, VE>(n, c);
+  const int slices = (int)ts_cdiv(n, rows);
+  lbn_partial_kernel<T, VE, 1><<<slices, 256, 0, stream>>>((const T *)x, (const T *)grad_out, mean, slope, n, c, rows, part);
+  bn_bwd_finish_kernel<<<(unsigned)ts_cdiv(c, BN_FIN_CH), 256, 0, stream>>>(part, slices, (double)n, c, invstd, coef, grad_weight,
+                                                                           grad_bias);
+  const int64_t total = n * (c / VE);
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total, 256), 1 << 16);
+  lbn_bwd_kernel<T, VE><<<grid, 256, 0, stream>>>((const LbnVec<T, VE> *)grad_out, (const LbnVec<T, VE> *)x, mean, invstd, weight,
+                                                  coef, slope, total, c, (LbnVec<T, VE> *)grad_x);
+}
+
+// out [N, C] = BatchNorm_train(LeakyReLU_slope(x [N, C])); mean / invstd [C] (of the activated values) are kept for the backward;
+// running statistics (may be NULL) and num_batches_tracked (may be NULL) updated as nn.BatchNorm2d does.  half != 0: IEEE half
+// rows.  ws >= ts_bn_train_workspace_bytes(c), every pointer 16-byte aligned.
+extern "C" int ts_leaky_bn_train_forward(const void *x, const float *weight, const float *bias, float *running_mean, float *running_var,
+                                         int64_t *num_batches_tracked, int64_t n, int32_t c, float eps, float momentum, float slope,
+                                         int32_t half, float *mean, float *invstd, void *out, void *ws, size_t ws_bytes,
+                                         ts_stream_t stream_) {
+  const int rc = lbn_check("ts_leaky_bn_train_forward", n, c, half, ws_bytes);
+  if (rc != TS_OK) return rc;
+  TS_REQUIRE(x && weight && bias && mean && invstd && out && ws, TS_ERR_INVALID_ARGUMENT, "ts_leaky_bn_train_forward: null pointer");
+  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT,
+             "ts_leaky_bn_train_forward: pointers must be 16-byte aligned");
+  if (half)
+    lbn_forward_launch<_Float16, 8>(x, weight, bias, running_mean, running_var, num_batches_tracked, n, c, eps, momentum, slope, mean,
+                                    invstd, out, (float *)ws, (hipStream_t)stream_);
+  else
+    lbn_forward_launch<float, 4>(x, weight, bias, running_mean, running_var, num_batches_tracked, n, c, eps, momentum, slope, mean,
+                                 invstd, out, (float *)ws, (hipStream_t)stream_);
+  TS_CHECK_LAUNCH("ts_leaky_bn_train_forward");
+  return TS_OK;
+}
+
+// grad_x [N, C] (with respect to the LeakyReLU's input), grad_weight / grad_bias [C] (may be NULL) from grad_out [N, C]
+extern "C" int ts_leaky_bn_train_backward(const void *grad_out, const void *x, const float *mean, const float *invstd,
+                                          const float *weight, int64_t n, int32_t c, float slope, int32_t half, void *grad_x,
+                                          float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  const int rc = lbn_check("ts_leaky_bn_train_backward", n, c, half, ws_bytes);
+  if (rc != TS_OK) return rc;
+  TS_REQUIRE(grad_out && x && mean && invstd && weight && grad_x && ws, TS_ERR_INVALID_ARGUMENT, "ts_leaky_bn_train_backward: null pointer");
+  TS_REQUIRE(bn_aligned(grad_out) && bn_aligned(x) && bn_aligned(grad_x) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT,
+             "ts_leaky_bn_train_backward: pointers must be 16-byte aligned");
+  if (half)
+    lbn_backward_launch<_Float16, 8>(grad_out, x, mean, invstd, weight, n, c, slope, grad_x, grad_weight, grad_bias, (float *)ws,
+                                     (hipStream_t)stream_);
+  else
+    lbn_backward_launch<float, 4>(grad_out, x, mean, invstd, weight, n, c, slope, grad_x, grad_weight, grad_bias, (float *)ws,
+                                  (hipStream_t)stream_);
+  TS_CHECK_LAUNCH("ts_leaky_bn_train_backward");
+  return TS_OK;
+}

@@ -398,3 +398,133 @@ extern "C" int ts_image_gather_rows_backward(const void *grad_out, int32_t C, in
   TS_CHECK_LAUNCH("ts_image_gather_rows_backward");
   return TS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad = True) of UNet2D's encoder (R/.../unet2d.py:58-62,72-77:
+// `nn.AvgPool2d(kernel_size=(3, 3), stride=2, padding=1)`) on a CHANNELS-LAST stack.  Hand-written because the library kernel this
+// PyTorch-ROCm dispatches to for channels-last gradients (`avg_pool2d_backward_out_cuda_frame_nhwc`) returns wrong values (found in
+// round 6 by the TIAF golden: relative error 1.0 against the NCHW form on the same input, fp32 and fp16), and because both passes
+// are plain row moves here: a thread owns one 16-byte piece of one output (forward) / input (backward) pixel row, sums the <= 9
+// (<= 4) contributing rows in fp32 in a fixed order and divides by 9 - no atomics, run-to-run identical.
+template <typename T, int VE>
+struct alignas(VE * sizeof(T)) PoolVec {
+  T x[VE];
+};
+
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const T *__restrict__ X, int H, int W, int Ho, int Wo, int pieces,
+                                                             unsigned total, T *__restrict__ Y) {
+  using V = PoolVec<T, VE>;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= total) return;
+  const unsigned j = e % (unsigned)pieces, px = e / (unsigned)pieces;
+  const unsigned wo = px % (unsigned)Wo, rest = px / (unsigned)Wo;
+  const unsigned ho = rest % (unsigned)Ho, t = rest / (unsigned)Ho;
+  float acc[VE];
+#pragma unroll
+  for (int k = 0; k < VE; ++k) acc[k] = 0.f;
+  const V *base = (const V *)X + (size_t)t * H * W * pieces + j;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int h = 2 * (int)ho + dy;
+    if (h < 0 || h >= H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int w = 2 * (int)wo + dx;
+      if (w < 0 || w >= W) continue;
+      const V v = base[((size_t)h * W + w) * pieces];
+#pragma unroll
+      for (int k = 0; k < VE; ++k) acc[k] += RowAcc<T>::load(&v.x[k]);
+    }
+  }
+  V out;
+#pragma unroll
+  for (int k = 0; k < VE; ++k) RowAcc<T>::store(&out.x[k], acc[k] / 9.f);
+  ((V *)Y)[(size_t)px * pieces + j] = out;
+}
+
+template <typename T, int VE>
+__global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const T *__restrict__ GY, int H, int W, int Ho, int Wo, int pieces,
+                                                             unsigned total, T *__restrict__ GX) {
+  using V = PoolVec<T, VE>;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= total) return;
+  const unsigned j = e % (unsigned)pieces, px = e / (unsigned)pieces;
+  const unsigned w = px % (unsigned)W, rest = px / (unsigned)W;
+  const unsigned h = rest % (unsigned)H, t = rest / (unsigned)H;
+  // output rows whose window (2 ho - 1 .. 2 ho + 1) holds h: h / 2 for an even h, (h - 1) / 2 and (h + 1) / 2 for an odd one
+  const int ho0 = (int)h / 2, ho1 = (h & 1) ? ho0 + 1 : ho0;
+  const int wo0 = (int)w / 2, wo1 = (w & 1) ? wo0 + 1 : wo0;
+  float acc[VE];
+#pragma unroll
+  for (int k = 0; k < VE; ++k) acc[k] = 0.f;
+  const V *base = (const V *)GY + (size_t)t * Ho * Wo * pieces + j;
+  for (int ho = ho0; ho <= ho1; ++ho) {
+    if (ho >= Ho) continue;
+    for (int wo = wo0; wo <= wo1; ++wo) {
+      if (wo >= Wo) continue;
+      const V v = base[((size_t)ho * Wo + wo) * pieces];
+#pragma unroll
+      for (int k = 0; k < VE; ++k) acc[k] += RowAcc<T>::load(&v.x[k]) / 9.f;
+    }
+  }
+  V out;
+#pragma unroll
+  for (int k = 0; k < VE; ++k) RowAcc<T>::store(&out.x[k], acc[k]);
+  ((V *)GX)[(size_t)px * pieces + j] = out;
+}
+
+template <typename T>
+static int avgpool3s2_launch(const char *what, bool backward, const T *in, int T_, int H, int W, int C, T *out, hipStream_t stream) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int v = image_piece_bytes((size_t)C * sizeof(T), in, out);
+  TS_REQUIRE(v >= (int)sizeof(T), TS_ERR_INVALID_ARGUMENT, "%s: pointers must be aligned to the element size", what);
+  const int ve = v / (int)sizeof(T), pieces = C / ve;
+  const int64_t total = (int64_t)T_ * (backward ? (int64_t)H * W : (int64_t)Ho * Wo) * pieces;
+  TS_REQUIRE(total < (1LL << 32), TS_ERR_UNSUPPORTED, "%s: more than 2^32 row pieces", what);
+  if (total == 0) return TS_OK;
+  const unsigned grid = (unsigned)ts_cdiv(total, 256);
+#define TS_POOL(VE_)                                                                                                          \
+  (backward ? avgpool3s2_bwd_kernel<T, VE_><<<grid, 256, 0, stream>>>(in, H, W, Ho, Wo, pieces, (unsigned)total, out)         \
+            : avgpool3s2_fwd_kernel<T, VE_><<<grid, 256, 0, stream>>>(in, H, W, Ho, Wo, pieces, (unsigned)total, out))
+  if constexpr (sizeof(T) == 2) {
+    if (ve == 8) {
+      TS_POOL(8);
+      return TS_OK;
+    }
+  }
+  if (ve == 4)
+    TS_POOL(4);
+  else if (ve == 2)
+    TS_POOL(2);
+  else
+    TS_POOL(1);
+#undef TS_POOL
+  return TS_OK;
+}
+
+// y [T, Ho, Wo, C] = AvgPool2d(3, stride 2, padding 1)(x [T, H, W, C]); Ho = (H - 1) / 2 + 1, Wo likewise; half != 0: IEEE half
+extern "C" int ts_avgpool3s2_rows_forward(const void *x, int32_t T, int32_t H, int32_t W, int32_t C, int32_t half, void *y,
+                                          ts_stream_t stream_) {
+  TS_REQUIRE(T >= 0 && H > 0 && W > 0 && C > 0, TS_ERR_INVALID_ARGUMENT, "ts_avgpool3s2_rows_forward: bad sizes");
+  if (T == 0) return TS_OK;
+  TS_REQUIRE(x && y, TS_ERR_INVALID_ARGUMENT, "ts_avgpool3s2_rows_forward: null pointer");
+  const int rc = half ? avgpool3s2_launch<__half>("ts_avgpool3s2_rows_forward", false, (const __half *)x, T, H, W, C, (__half *)y, (hipStream_t)stream_)
+                      : avgpool3s2_launch<float>("ts_avgpool3s2_rows_forward", false, (const float *)x, T, H, W, C, (float *)y, (hipStream_t)stream_);
+  if (rc != TS_OK) return rc;
+  TS_CHECK_LAUNCH("ts_avgpool3s2_rows_forward");
+  return TS_OK;
+}
+
+// grad_x [T, H, W, C] (every element written) from grad_y [T, Ho, Wo, C]
+extern "C" int ts_avgpool3s2_rows_backward(const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t C, int32_t half, void *grad_x,
+                                           ts_stream_t stream_) {
+  TS_REQUIRE(T >= 0 && H > 0 && W > 0 && C > 0, TS_ERR_INVALID_ARGUMENT, "ts_avgpool3s2_rows_backward: bad sizes");
+  if (T == 0) return TS_OK;
+  TS_REQUIRE(grad_y && grad_x, TS_ERR_INVALID_ARGUMENT, "ts_avgpool3s2_rows_backward: null pointer");
+  const int rc = half ? avgpool3s2_launch<__half>("ts_avgpool3s2_rows_backward", true, (const __half *)grad_y, T, H, W, C, (__half *)grad_x, (hipStream_t)stream_)
+                      : avgpool3s2_launch<float>("ts_avgpool3s2_rows_backward", true, (const float *)grad_y, T, H, W, C, (float *)grad_x, (hipStream_t)stream_);
+  if (rc != TS_OK) return rc;
+  TS_CHECK_LAUNCH("ts_avgpool3s2_rows_backward");
+  return TS_OK;
+}

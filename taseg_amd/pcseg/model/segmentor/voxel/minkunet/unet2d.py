@@ -108,6 +108,89 @@ def _image_gather_through(feat, plan):
     return _ImageGatherThrough.apply(feat, plan)
 
 
+class _AvgPool3s2Rows(Function):
+    """AvgPool2d(3, stride 2, padding 1) on a channels-last map through csrc/image.hip (forward and gradient)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.in_shape, ctx.dtype = tuple(x.shape), x.dtype
+        return B.avgpool3s2_rows_forward(x)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        return B.avgpool3s2_rows_backward(grad_y.to(ctx.dtype), ctx.in_shape)
+
+
+def _pool(module, x):
+    """the block's AvgPool2d.  A channels-last map on the device goes through the library's own kernels: the gradient kernel this
+    PyTorch-ROCm dispatches to for that format returns wrong values (see csrc/image.hip); everything else is the module itself."""
+    ks, st, pd = module.kernel_size, module.stride, module.padding
+    three = ks in (3, (3, 3)) and st in (2, (2, 2)) and pd in (1, (1, 1)) and module.count_include_pad and not module.ceil_mode \
+        and module.divisor_override is None
+    if three and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.float16) and not x.is_contiguous() \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        return _AvgPool3s2Rows.apply(x)
+    if x.is_cuda and x.requires_grad and not x.is_contiguous():
+        x = x.contiguous()                              # (any other channels-last pool: in the format whose gradient is right)
+    return module(x)
+
+
+class _LeakyBatchNormRows(Function):
+    """BatchNorm2d_train(LeakyReLU(x)) of a channels-last map as ONE node on the library's row kernels (csrc/bn.hip,
+    ts_leaky_bn_train_*): x - the convolution's output - is what is kept for the backward pass, the activated map never exists"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, slope):
+        t, c, h, w = x.shape
+        n = t * h * w
+        half = x.dtype == torch.float16
+        lib = B.L.load()
+        out = torch.empty_like(x, memory_format=torch.channels_last)
+        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws = B.L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+        B.L.check(lib.ts_leaky_bn_train_forward(B.L.ptr(x), B.L.ptr(weight), B.L.ptr(bias), B.L.ptr(running_mean), B.L.ptr(running_var),
+                                                B.L.ptr(nbt), n, c, float(eps), float(momentum), float(slope), 1 if half else 0,
+                                                B.L.ptr(stats[0]), B.L.ptr(stats[1]), B.L.ptr(out), B.L.ptr(ws), ws.numel(), B.L.stream()),
+                  "ts_leaky_bn_train_forward")
+        for buf in (running_mean, running_var, nbt):      # written through raw pointers: move their version counters
+            if buf is not None:
+                torch.autograd.graph.increment_version(buf)
+        ctx.save_for_backward(x, weight, stats)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, stats = ctx.saved_tensors
+        t, c, h, w = x.shape
+        lib = B.L.load()
+        grad_out = grad_out.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        grad_x = torch.empty_like(x, memory_format=torch.channels_last)
+        gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws = B.L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
+        B.L.check(lib.ts_leaky_bn_train_backward(B.L.ptr(grad_out), B.L.ptr(x), B.L.ptr(stats[0]), B.L.ptr(stats[1]), B.L.ptr(weight),
+                                                 t * h * w, c, ctx.slope, 1 if x.dtype == torch.float16 else 0, B.L.ptr(grad_x),
+                                                 B.L.ptr(gwb[0]), B.L.ptr(gwb[1]), B.L.ptr(ws), ws.numel(), B.L.stream()),
+                  "ts_leaky_bn_train_backward")
+        return grad_x, gwb[0].to(weight.dtype), gwb[1].to(weight.dtype), None, None, None, None, None, None
+
+
+def _act_bn(act, bn, x):
+    """bn(act(x)) of a block (unet2d.py:24-30,71,108).  Training-mode BatchNorm2d behind a LeakyReLU on a channels-last device map
+    goes through ONE fused node; anything else - evaluation mode, other layouts / dtypes, modules with hooks, options.image_fused_bn
+    off - is the two modules themselves."""
+    c = x.shape[1] if x.dim() == 4 else 0
+    if (options.image_fused_bn and bn.training and x.is_cuda and x.dim() == 4 and isinstance(act, nn.LeakyReLU) and type(bn) is nn.BatchNorm2d
+            and bn.affine and bn.track_running_stats and bn.momentum is not None and x.dtype in (torch.float32, torch.float16)
+            and c % (8 if x.dtype == torch.float16 else 4) == 0 and c <= 1024 and bn.weight.dtype == torch.float32
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and not (act._forward_hooks or act._forward_pre_hooks or act._backward_hooks or bn._forward_hooks or bn._forward_pre_hooks
+                     or bn._backward_hooks)):
+        return _LeakyBatchNormRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                                         bn.momentum, act.negative_slope)
+    return bn(act(x))
+
+
 def _leaky():
     return nn.LeakyReLU()
 
@@ -128,8 +211,8 @@ class ResContextBlock(nn.Module):
 
     def forward(self, x):
         skip = self.act1(self.conv1(x))
-        y = self.bn1(self.act2(self.conv2(skip)))
-        y = self.bn2(self.act3(self.conv3(y)))
+        y = _act_bn(self.act2, self.bn1, self.conv2(skip))
+        y = _act_bn(self.act3, self.bn2, self.conv3(y))
         return skip + y
 
 
@@ -150,11 +233,11 @@ class ResBlock(nn.Module):
             self.pool = nn.AvgPool2d(kernel_size=kernel_size, stride=2, padding=1)
 
     def forward(self, x):
-        res = self.act1(self.conv1(x)) + self.bn1(self.act2(self.conv2(x)))
+        res = self.act1(self.conv1(x)) + _act_bn(self.act2, self.bn1, self.conv2(x))
         out = self.dropout(res) if self.drop_out else res
         if not self.pooling:
             return out
-        out = self.pool(out)
+        out = _pool(self.pool, out)
         return (out, res) if self.return_skip else out
 
 
@@ -180,7 +263,7 @@ class UpBlock(nn.Module):
         cat = torch.cat((up, skip), dim=1)
         if self.drop_out:
             cat = self.dropout2(cat)
-        out = self.bn1(self.act1(self.conv1(cat)))
+        out = _act_bn(self.act1, self.bn1, self.conv1(cat))
         return self.dropout3(out) if self.drop_out else out
 
 

@@ -124,6 +124,79 @@ def test_image_gather_at_tiaf_size_through_path(shift, c, layout, dtype):
     assert float((g_ours.double() - g_ref).abs().max()) <= tol * max(1.0, float(g_ref.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 32, 24, 40), (2, 64, 17, 33), (1, 96, 5, 7), (2, 20, 8, 6)])
+def test_channels_last_average_pool_equals_the_contiguous_module(shape, dtype):
+    """UNet2D's AvgPool2d(3, stride 2, padding 1) on channels-last maps runs on the library's kernels (csrc/image.hip): forward and
+    gradient against torch's own module in the CONTIGUOUS format (whose gradient is right; the channels-last gradient kernel of this
+    PyTorch-ROCm is not - that is why the kernels exist), odd sizes included; deterministic"""
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import _pool
+    g = torch.Generator().manual_seed(4)
+    pool = torch.nn.AvgPool2d(kernel_size=(3, 3), stride=2, padding=1)
+    x = torch.randn(*shape, generator=g).cuda().to(dtype)
+    w = torch.randn(shape[0], shape[1], (shape[2] - 1) // 2 + 1, (shape[3] - 1) // 2 + 1, generator=g).cuda().to(dtype)
+    a = x.clone().requires_grad_()
+    want = pool(a)
+    (ga,) = torch.autograd.grad((want.float() * w.float()).sum(), a)
+    b = x.contiguous(memory_format=torch.channels_last).requires_grad_()
+    got = _pool(pool, b)
+    assert got.shape == want.shape and got.dtype == dtype and got.is_contiguous(memory_format=torch.channels_last)
+    (gb,) = torch.autograd.grad((got.float() * w.float()).sum(), b, retain_graph=True)
+    (gb2,) = torch.autograd.grad((got.float() * w.float()).sum(), b)
+    tol = 1e-6 if dtype == torch.float32 else 2e-3
+    assert float((got.float() - want.float()).abs().max()) <= tol * max(1.0, float(want.float().abs().max()))
+    assert float((gb.float() - ga.float()).abs().max()) <= tol * max(1.0, float(ga.float().abs().max()))
+    assert torch.equal(gb, gb2) and gb.is_contiguous(memory_format=torch.channels_last)
+    # a contiguous input keeps the module's own path
+    assert torch.equal(_pool(pool, x), pool(x))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 32, 24, 40), (2, 96, 17, 33), (1, 256, 5, 7), (4, 64, 48, 160)])
+def test_fused_leaky_relu_batch_norm_equals_the_two_modules(shape, dtype):
+    """UNet2D's `bn(act(conv(x)))` tail on a channels-last map as one node (csrc/bn.hip ts_leaky_bn_train_*) against nn.LeakyReLU +
+    nn.BatchNorm2d in training mode evaluated in float64: output, the three gradients, running statistics and the batch counter;
+    run-to-run identical"""
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import _act_bn
+    g = torch.Generator().manual_seed(7)
+    c = shape[1]
+    x = (torch.randn(*shape, generator=g) * 1.5 + 0.3).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(*shape, generator=g).cuda()
+    act = torch.nn.LeakyReLU()
+
+    def make_bn(dt):
+        bn = torch.nn.BatchNorm2d(c).cuda().to(dt).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g))
+            bn.running_mean.copy_(torch.randn(c, generator=g))
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        return bn
+    g.manual_seed(8)
+    ours = make_bn(torch.float32)
+    g.manual_seed(8)
+    ref = make_bn(torch.float64)
+    a = x.clone().requires_grad_()
+    out = _act_bn(act, ours, a)
+    assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last) and out.grad_fn.__class__.__name__.startswith("_LeakyBatchNormRows")
+    ga, gw, gb = torch.autograd.grad((out.float() * wt).sum(), (a, ours.weight, ours.bias), retain_graph=True)
+    ga2, gw2, gb2 = torch.autograd.grad((out.float() * wt).sum(), (a, ours.weight, ours.bias))
+    assert torch.equal(ga, ga2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    b = x.double().clone().requires_grad_()
+    want = ref(act(b))
+    gb_x, gb_w, gb_b = torch.autograd.grad((want * wt.double()).sum(), (b, ref.weight, ref.bias))
+    tol = 2e-5 if dtype == torch.float32 else 4e-3
+    rel = lambda p, q: float((p.double() - q).norm() / q.norm().clamp_min(1e-30))      # noqa: E731
+    assert float((out.double() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert rel(ga, gb_x) <= tol and rel(gw, gb_w) <= tol and rel(gb, gb_b) <= tol, (rel(ga, gb_x), rel(gw, gb_w), rel(gb, gb_b))
+    assert int(ours.num_batches_tracked) == 1
+    assert torch.allclose(ours.running_mean.double(), ref.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ours.running_var.double(), ref.running_var, rtol=1e-3 if dtype == torch.float16 else 1e-4, atol=1e-5)
+    # evaluation mode / a contiguous map / a hooked module: the modules themselves
+    ours.eval()
+    assert torch.equal(_act_bn(act, ours, x), ours(act(x)))
+
+
 def _tiaf_batch(g):
     from taseg_amd.torchsparse import SparseTensor
     dev = "cuda"

@@ -31,6 +31,14 @@ trace ms "minkunet_ms" sgd_decide_kernel 20 --workload minkunet_ms --steps 20 --
 export TASEG_WGRAD_STREAM=1
 trace default_side "minkunet second-stream" sgd_decide_kernel 20 --steps 20 --warmup 5
 unset TASEG_WGRAD_STREAM
+unset TASEG_WGRAD_STREAM
+# the reference's recipe batch sizes, mask distillation and TIAF (round 6)
+trace bs12_amp "minkunet amp bs12" sgd_decide_kernel 12 --batch 12 --amp --steps 12 --warmup 4
+trace fsa16_bs6_amp "minkunet_ms amp bs6 history16" sgd_decide_kernel 10 --workload minkunet_ms --history 16 --batch 6 --amp --steps 10 --warmup 3
+trace kd "kd" sgd_decide_kernel 10 --workload kd --steps 10 --warmup 3
+python bench.py --workload tiaf --amp --steps 2 --warmup 1 > /dev/null 2>&1      # (MIOpen's kernels of this process tree compiled before the trace)
+trace tiaf_amp "tiaf amp" sgd_decide_kernel 6 --workload tiaf --amp --steps 6 --warmup 2 --no-wgrad-tune
+python tools/tiaf_families.py $OUT/tiaf_amp_kernel_stats.csv 11 > $OUT/tiaf_amp_families.txt     # 2 + 6 timed + 3 phase-table steps in the trace
 trace eval "eval minkunet" "unvoxelise_kernel" 40 --eval --steps 40 --warmup 8
 trace evalamp "eval minkunet amp" "unvoxelise_kernel" 40 --eval --amp --steps 40 --warmup 8
 echo "  \"_source\": \"rocprofv3 --kernel-trace of the tree, kernels of all streams inside the timed steps (tools/stream_busy.py)\"" >> $OUT/launches.json
@@ -47,7 +55,7 @@ python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collectio
 cp profiles/traffic.json $OUT/traffic.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_amp $OUT/pmc_write_amp
 say "side lines"
-for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist" "--workload kd"; do
+for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist" "--workload kd" "--workload tiaf --amp" "--workload tiaf" "--batch 12 --amp" "--workload minkunet_ms --history 16 --batch 6 --amp"; do
   tag=$(echo $w | tr -d ' -'); say "bench $w"; python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary > $OUT/bench_$tag.json 2> /dev/null; done
 say "host phases"
 for w in "" "--amp"; do TASEG_BENCH_HOST_PHASES=1 python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes|second stream" | sed "s/^/[bench.py $w] /" >> $OUT/host_phases.txt; done
