@@ -39,13 +39,31 @@ extern "C" size_t ts_conv_block_wgrad_ws_bytes(int64_t n_pairs, int64_t n_out, i
   return blk_align((size_t)n_out * (size_t)std::max(c_in, c_out) * es) + blk_align(ts_wgrad_partial_bytes(n_pairs, c_in, c_out, K));
 }
 
+// `waiter` waits for everything enqueued on `other` so far.  The events come from a small ring that lives as long as the library:
+// until round 6 every call created an event, recorded it, made the waiter wait and DESTROYED it right away - legal by the API's
+// letter (resources are released when the wait has completed), but the one place where a missed wait would show is exactly where an
+// intermittent failure did: two rank processes on one card with the weight gradients on a second stream, where a gradient bucket's
+// all-reduce reads the slots right behind this join (tests/test_gpu_dist.py::test_second_stream_under_the_bucket_reducer...: once a
+// crashed rank, once gradients that were not the one-stream run's).  A wait on an event that still exists has no such question
+// mark; re-recording a ring entry while an older wait on it is pending is fine (a wait refers to the record at the time of the call).
 extern "C" int ts_stream_join(ts_stream_t waiter, ts_stream_t other) {
   if (waiter == other) return TS_OK;
-  hipEvent_t ev;
-  TS_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "ts_stream_join: event");
+  constexpr int RING = 64;
+  static hipEvent_t ring[RING];
+  static std::atomic<int> made{0};
+  static std::atomic<unsigned> next{0};
+  static std::mutex mu;
+  if (made.load(std::memory_order_acquire) == 0) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (made.load(std::memory_order_relaxed) == 0) {
+      for (int i = 0; i < RING; ++i) TS_CHECK_HIP(hipEventCreateWithFlags(&ring[i], hipEventDisableTiming), "ts_stream_join: event");
+      made.store(1, std::memory_order_release);
+    }
+  }
+  hipEvent_t ev = ring[next.fetch_add(1) % RING];
+  std::lock_guard<std::mutex> lock(mu);          // (record + wait of one entry as a pair: two host threads join streams here)
   TS_CHECK_HIP(hipEventRecord(ev, (hipStream_t)other), "ts_stream_join: record");
   TS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)waiter, ev, 0), "ts_stream_join: wait");
-  TS_CHECK_HIP(hipEventDestroy(ev), "ts_stream_join: destroy");      // released once the wait has completed
   return TS_OK;
 }
 

@@ -50,8 +50,10 @@ def _run_ranks(world, backend, out_dir, extra_env=None):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for rc, o, e in outs:
-        assert rc == 0, e[-3000:]
+    if any(rc != 0 for rc, _, _ in outs):
+        # every rank's tail: the rank that reports "connection closed by peer" is rarely the one that failed first
+        report = "\n".join(f"---- rank {r}: exit code {rc}\n{e[-2500:]}" for r, (rc, _, e) in enumerate(outs))
+        raise AssertionError(report)
     return [dict(np.load(os.path.join(out_dir, f"rank{r}.npz"))) for r in range(world)], outs
 
 
