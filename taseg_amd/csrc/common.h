@@ -167,10 +167,14 @@ struct TsWgradPlan {
   int n_chunks;       // ceil(n_pairs / chunk)
   int64_t slots;      // n_chunks + K
 };
-// workgroups a weight-gradient launch aims for (default 512 = two resident rounds of 256 CUs; TS_OPT_WGRAD_WGS)
+// workgroups a weight-gradient launch aims for (TS_OPT_WGRAD_WGS).  Default 256 = one workgroup per CU: against 512 (two resident
+// rounds, the default until round 6) the chunks of the strides-4 .. 16 layers are twice as long and their partial tiles - a third of
+// those launches' bytes - half as many; the largest layers sit at the chunk cap either way.  Measured on the whole step, two
+// interleaved runs each (profiles/r06_wgrad_wgs_ab.txt): fp32 15.11 / 15.05 -> 14.95 / 14.93 ms, autocast 9.45 / 9.50 -> 9.33 / 9.38.
+// One target for every mode: the target fixes the summation order, and the bits must not depend on the stream a gradient runs on.
 static inline int ts_wgrad_wgs() {
   const int64_t v = ts_get_option(TS_OPT_WGRAD_WGS);
-  return v ? (int)v : 512;
+  return v ? (int)v : 256;
 }
 static inline TsWgradPlan ts_wgrad_plan(int64_t n_pairs, int tiles, int K, int step, int max_chunk) {
   int64_t chunk = ts_cdiv(n_pairs * tiles, ts_wgrad_wgs());

@@ -17,6 +17,7 @@ trace() {   # tag, launches key, marker regex, steps, bench arguments...
   $RP -d $OUT/trace_$tag -- python3 bench.py "$@" --no-cpu-baseline --no-secondary > $OUT/bench_${tag}_under_rocprof.json 2> $OUT/trace_$tag.err
   python tools/kstats.py $OUT/trace_$tag $steps 45 > $OUT/kstats_$tag.txt
   python tools/stream_busy.py $OUT/trace_$tag $steps "$marker" > $OUT/busy_$tag.txt
+  python tools/fill_sources.py $OUT/trace_$tag $steps "$marker" > $OUT/fills_$tag.txt 2>&1 || true
   echo "  \"$key\": $(grep LAUNCHES_PER_STEP $OUT/busy_$tag.txt | cut -d' ' -f2)," >> $OUT/launches.json
   f=$(find $OUT/trace_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${tag}_kernel_stats.csv
   rm -rf $OUT/trace_$tag
