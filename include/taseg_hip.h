@@ -48,7 +48,7 @@ const char *ts_last_error(void);
 /* Tuning values of the library (process-wide; the host side's options object - taseg_amd/options.py - pushes its fields when it
  * loads the library; the library itself reads no environment variable).  0 is every key's default.
  *   TS_OPT_GATHER_POSITIONS        != 0: pass 2 with K position registers per lane instead of LDS lists
- *   TS_OPT_WGRAD_WGS               workgroup target of the weight gradient's chunking (64 .. 8192; 0 = 256)
+ *   TS_OPT_WGRAD_WGS               workgroup target of the weight gradient's chunking (64 .. 8192; 0 = 512)
  *   TS_OPT_EVAL_TAIL_SEPARATE      != 0: the evaluation block's BatchNorm tail as a launch of its own
  *   TS_OPT_CLASS_FINISH_ROWS[_HALF] rows from which a class plan's finish runs inside the product (0 = never)
  *   TS_OPT_DEBUG_BN_ABLATE         timing diagnostics of csrc/bn.hip (bit field)

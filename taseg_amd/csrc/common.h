@@ -167,14 +167,16 @@ struct TsWgradPlan {
   int n_chunks;       // ceil(n_pairs / chunk)
   int64_t slots;      // n_chunks + K
 };
-// workgroups a weight-gradient launch aims for (TS_OPT_WGRAD_WGS).  Default 256 = one workgroup per CU: against 512 (two resident
-// rounds, the default until round 6) the chunks of the strides-4 .. 16 layers are twice as long and their partial tiles - a third of
-// those launches' bytes - half as many; the largest layers sit at the chunk cap either way.  Measured on the whole step, two
-// interleaved runs each (profiles/r06_wgrad_wgs_ab.txt): fp32 15.11 / 15.05 -> 14.95 / 14.93 ms, autocast 9.45 / 9.50 -> 9.33 / 9.38.
-// One target for every mode: the target fixes the summation order, and the bits must not depend on the stream a gradient runs on.
+// workgroups a weight-gradient launch aims for (TS_OPT_WGRAD_WGS; default 512 = two resident rounds of 256 CUs).  Round 6 measured
+// 256 (chunks of the strides-4 .. 16 layers twice as long, half the partial tiles) on the whole step and per family
+// (profiles/r06_wgrad_wgs_ab.txt): the bs-2 steps gain 1 % (fp32 15.08 -> 14.94 ms, autocast 9.47 -> 9.36) because the gradient
+// then leaves more of the chip to the input gradient beside it on the second stream - but the family ALONE gets slower (3.51 ->
+// 3.94 ms per step, 0.45 -> 0.40 of HBM: fewer workgroups cost the mid-size layers more than the partial tiles they save) and the
+// large batches lose (mask distillation at bs 6: 97 -> 104 ms).  512 stays.  One target for every mode either way: the target fixes
+// the summation order, and the bits must not depend on the stream a gradient runs on.
 static inline int ts_wgrad_wgs() {
   const int64_t v = ts_get_option(TS_OPT_WGRAD_WGS);
-  return v ? (int)v : 256;
+  return v ? (int)v : 512;
 }
 static inline TsWgradPlan ts_wgrad_plan(int64_t n_pairs, int tiles, int K, int step, int max_chunk) {
   int64_t chunk = ts_cdiv(n_pairs * tiles, ts_wgrad_wgs());

@@ -84,13 +84,19 @@ def _backend():
 
 
 def test_bench_scan_train_step_vs_reference_cpu_kernels():
+    run_bench_scan_case(rank=0, batch=1)
+
+
+def run_bench_scan_case(rank, batch):
+    """the case of the test above for `batch` scans of bench.make_scans(rank, ...) - batch 1 in the suite; tools/bench_backward_bs2.py
+    runs the block-diagonal bs-2 batch of the timed step itself (two seeds; ~4 minutes of CPU oracle each)"""
     import bench
     from taseg_amd import _fast
     from taseg_amd import backend as B
     from taseg_amd.pcseg.model import build_network
     from taseg_amd.pcseg.model.segmentor.voxel.minkunet import stage_program as SP
     from taseg_amd.torchsparse import SparseTensor
-    coords, feats, labels, npts = bench.make_scans(0, 1, 120000, "minkunet")
+    coords, feats, labels, npts = bench.make_scans(rank, batch, 120000, "minkunet")
     cfg = make_model_cfg("MinkUNet", in_dim=4, cr=1.0)
     model = fill_parameters(build_network(cfg, 20), seed=7).cuda().train()
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}        # before the forward pass moves the statistics
@@ -112,7 +118,7 @@ def test_bench_scan_train_step_vs_reference_cpu_kernels():
     ours_logits = grabbed["logits"].float().cpu()
     ours_grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
     names = state["_learn"]
-    assert ours_logits.shape[0] > 80000 and len(names) == 191
+    assert ours_logits.shape[0] > 80000 * batch and len(names) == 191
     # what ran: class GEMM on 96- and 32-column tiles (stride 1 / 2 layers at production thresholds), direct plans (result rows
     # stored by the product itself), the weight gradient's ordered sum as a launch of its own on the second stream, stage programs
     cls = [r[3] for r in recs if r[0] == "class_gemm"]
@@ -133,9 +139,9 @@ def test_bench_scan_train_step_vs_reference_cpu_kernels():
         torch.set_num_threads(threads)
     t1 = time.time()
     o64 = _oracle_pass(cfg, state, c_np, f_cpu, l_cpu, "numpy", torch.float64)
-    print(f"bench scan: {npts} points -> {ours_logits.shape[0]} voxels; oracle passes {t1 - t0:.0f} s (reference kernels, fp32) + "
+    print(f"bench scan(s), seed rank {rank}, bs {batch}: {npts} points -> {ours_logits.shape[0]} voxels; oracle passes {t1 - t0:.0f} s (reference kernels, fp32) + "
           f"{time.time() - t1:.0f} s (float64); {len(cls)} class-GEMM launches, second stream {side}")
-    _compare("bench scan, train step", ours_logits, float(tb["loss"]), ours_grads, o32, o64, names)
+    _compare(f"bench scan(s) bs {batch}, train step", ours_logits, float(tb["loss"]), ours_grads, o32, o64, names)
 
 
 def test_forced_class_path_with_a_smooth_activation_meets_the_plain_gradient_bar(monkeypatch):
