@@ -54,7 +54,9 @@ def _compare(tag, ours_logits, ours_loss, ours_grads, o32, o64, names, forced_to
     d_ref = float((ours_logits.double() - l32.double()).abs().max())
     d_64 = float((ours_logits.double() - l64).abs().max())
     ref_64 = float((l32.double() - l64).abs().max())
-    assert d_ref <= LOGIT_TOL and d_64 <= LOGIT_TOL, (d_ref, d_64)
+    # against float64 the plain bar; against the reference's fp32 kernels the bar cannot be tighter than their own distance to
+    # float64 (bs 2, 178k voxels: 0.9e-3 .. 1.1e-3 of summation noise in the reference kernels themselves, ours 3e-5 .. 4e-5)
+    assert d_64 <= LOGIT_TOL and d_ref <= max(LOGIT_TOL, 2.0 * ref_64), (d_ref, d_64, ref_64)
     assert abs(ours_loss - loss32) <= 1e-3 and abs(ours_loss - loss64) <= 1e-3, (ours_loss, loss32, loss64)
     worst_norm, worst_t = (0.0, 0.0, ""), (0.0, 0.0, "")
     sampled = set(names[:: max(1, len(names) // 24)][:24])

@@ -1,11 +1,14 @@
 # Round profile set (run on the GPU box through gpurun): default bench line, rocprofv3 kernel traces of the default, --amp, nuScenes --amp and
 # evaluation runs (kernel statistics + per-queue busy time + launches per step), the two PMC passes behind profiles/traffic.json.
-#    bash tools/collect_profiles.sh <out dir under gpurun_out/>          (writes progress lines: a silent run is taken to be hung)
+#    bash tools/collect_profiles.sh <out dir under gpurun_out/> [main|side|all]   (writes progress lines: a silent run is taken to be hung;
+#    "main" = default line + traces + PMC passes, "side" = the other lines by hand + host phases: each fits one 20-minute gpurun call)
 set -e
 OUT=gpurun_out/${1:-prof}
+PART=${2:-all}
 mkdir -p $OUT
 export TMPDIR=/tmp
 say() { echo "[collect $(date +%H:%M:%S)] $*"; }
+if [ "$PART" != side ]; then
 say "default bench line"
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 RP="rocprofv3 --kernel-trace --stats --output-format csv"
@@ -55,6 +58,8 @@ unset TASEG_WGRAD_STREAM
 python profiles/parse_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $(find $OUT/pmc_fetch_amp -name "*counter_collection.csv") $(find $OUT/pmc_write_amp -name "*counter_collection.csv") > $OUT/traffic.txt
 cp profiles/traffic.json $OUT/traffic.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_amp $OUT/pmc_write_amp
+fi
+if [ "$PART" = main ]; then exit 0; fi
 say "side lines"
 for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist" "--workload kd" "--workload tiaf --amp" "--workload tiaf" "--batch 12 --amp" "--workload minkunet_ms --history 16 --batch 6 --amp"; do
   tag=$(echo $w | tr -d ' -'); say "bench $w"; python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary > $OUT/bench_$tag.json 2> /dev/null; done
