@@ -173,6 +173,14 @@ def make_scans(rank, batch, points, workload):
             torch.from_numpy(np.concatenate(labels)).to(dev), npts)
 
 
+def _parallel_scans(jobs):
+    """[(seed, synth_scan keyword arguments)] -> [(points, labels)] in order, on up to 8 host threads"""
+    from concurrent.futures import ThreadPoolExecutor
+    from taseg_amd.data.synthetic import synth_scan
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda job: synth_scan(job[0], **job[1]), jobs))
+
+
 def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label_map=None, pseudo_flip=0.0):
     """Raw resident scans for the "4-scan TFA" workload: per sample the
     current scan plus `history` earlier scans of the same scene seen from the ego poses
@@ -181,12 +189,16 @@ def make_multiscans(rank, batch, points, history=4, n_beams=64, n_az=2083, label
     from taseg_amd.data.synthetic import synth_pose, synth_scan
     dev = torch.device("cuda")
     scans, npts = [], 0
+    # (the synthetic scans are numpy work of ~1 s each - 102 of them for the FSA recipe at bs 6: generated on a few host threads, every
+    # scan from its own seed, so the clouds do not depend on the order they are made in)
+    made = _parallel_scans([(1000 * rank + 10 * b + t, dict(n_points=points, pose=synth_pose(history - t), scene_seed=1000 * rank + 10 * b,
+                                                            n_beams=n_beams, n_az=n_az)) for b in range(batch) for t in range(history + 1)])
     for b in range(batch):
         seed = 1000 * rank + 10 * b
         pts, labs, poses = [], [], []
         for t in range(history + 1):               # frame t: current = history, oldest = 0
             pose = synth_pose(history - t)
-            p, l = synth_scan(seed + t, n_points=points, pose=pose, scene_seed=seed, n_beams=n_beams, n_az=n_az)
+            p, l = made[b * (history + 1) + t]
             if label_map is not None:
                 l = np.asarray(label_map, dtype=l.dtype)[l]
             pts.append(torch.from_numpy(p).to(dev))
@@ -228,9 +240,9 @@ def make_tiaf_frames(rank, batch, points, n_beams=64, n_az=2083):
         seed = 1000 * rank + 100 * b
         rs = np.random.RandomState(seed)
         frames = {}
-        for d in deltas:
+        made = _parallel_scans([(seed - d, dict(n_points=points, pose=synth_pose(-d), scene_seed=seed, n_beams=n_beams, n_az=n_az)) for d in deltas])
+        for d, (p, l) in zip(deltas, made):
             pose = synth_pose(-d)
-            p, l = synth_scan(seed - d, n_points=points, pose=pose, scene_seed=seed, n_beams=n_beams, n_az=n_az)
             lab = torch.from_numpy(l.astype(np.int64)).to(dev)
             f = {"points": torch.from_numpy(p).to(dev), "labels": lab, "pseudo": lab, "pose": torch.from_numpy(pose).to(dev)}
             if d in with_img:

@@ -442,6 +442,26 @@ int ts_leaky_bn_train_backward(const void *grad_out, const void *x, const float 
                                int64_t n, int32_t c, float slope, int32_t half, void *grad_x, float *grad_weight, float *grad_bias,
                                void *ws, size_t ws_bytes, ts_stream_t stream);
 
+/* Dense 3 x 3 convolution, 32 -> 32 channels, stride 1, padding = dilation (1 or 2), on channels-last IEEE-half rows - the
+ * full-resolution layers of UNet2D (unet2d.py:10-31,41-60: `nn.Conv2d(32, 32, (3, 3), padding=1)` and `dilation=2, padding=2`).
+ *   ts_conv3x3c32_pack   the nn.Conv2d weight [co][ci][ky][kx] (half, any strides) -> the MFMA operand form the kernel keeps in
+ *                        registers (ts_conv3x3c32_packed_bytes() bytes); mode 0: forward, mode 1: data gradient (taps mirrored,
+ *                        channels swapped)
+ *   ts_conv3x3c32_rows   y [T, H, W, 32] = conv(x [T, H, W, 32]) + bias [32] (float, may be NULL); with a mode-1 pack and
+ *                        x = grad_y it returns grad_x.  fp32 accumulation, one rounding to half. */
+size_t ts_conv3x3c32_packed_bytes(void);
+int ts_conv3x3c32_pack(const void *weight, int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, int32_t mode, void *packed,
+                       ts_stream_t stream);
+int ts_conv3x3c32_rows(const void *x, const void *packed, const float *bias, int32_t T, int32_t H, int32_t W, int32_t dilation, void *y,
+                       ts_stream_t stream);
+/*   ts_conv3x3c32_wgrad  grad_weight [co][ci][ky][kx] (half, the element strides of the weight it belongs to) = sum over pixels of
+ *                        x[t, y + (ky - 1) D, x + (kx - 1) D, ci] grad_y[t, y, x, co]: partial [9][32][32] sums per workgroup (fp32, LDS
+ *                        transposing reads feed the MFMAs), then their sum in index order - no atomics, run-to-run identical.
+ *                        ws >= ts_conv3x3c32_wgrad_workspace_bytes(). */
+size_t ts_conv3x3c32_wgrad_workspace_bytes(void);
+int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t dilation, void *grad_weight,
+                        int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* ---- fp16 storage / fp32 accumulation (the reference trains under AMP: conv.py:19 `custom_fwd(cast_inputs=half)`).
  * `void *` operands are IEEE half arrays.  Channel counts must be multiples of 32, K <= 63.
  *   ts_cast_weights_f16      w f32 [K, Ci, Co] -> w16 [K, Ci, Co] and / or w16t [K, Co, Ci] (either may be NULL)

@@ -40,6 +40,20 @@ def module():
 
 
 _side = None
+_single_stream_only = None      # reason (str) while the second stream must stay off
+
+
+def require_single_stream(reason):
+    """From now on (until `reason` is None again) wgrad_stream(True) is refused and the second stream is off.  Set by
+    parallel.GradBucketReducer when gradients are averaged over MORE THAN ONE rank: a gradient bucket's all-reduce reads the slots
+    in the middle of the backward pass, right behind a join of the second stream, and that combination has failed intermittently in
+    every two-rank rehearsal it was given (round 5: a memory-access fault with SyncBatchNorm; round 6: a memory-access fault, a
+    crashed rank and gradients that were not the one-stream run's, tests/test_gpu_dist.py) without a cause found.  Until it has
+    been, N > 1 keeps every weight gradient on the stream of its backward pass."""
+    global _single_stream_only
+    _single_stream_only = reason
+    if reason is not None and _mod is not None:
+        _mod.set_wgrad_stream(0, 0, 0, 0)
 
 
 def wgrad_stream(on):
@@ -51,6 +65,8 @@ def wgrad_stream(on):
     if mod is None:
         return False
     import torch
+    if on and _single_stream_only is not None:
+        on = False
     if on and torch.cuda.is_available():
         if _side is None:
             _side = torch.cuda.Stream()
@@ -78,6 +94,8 @@ def tune_wgrad_stream(step, fence, rounds=3, steps=4):
     # setting: the second stream is rank-local, the sequence of collectives does not depend on it; the gradient buckets join the
     # second stream before their all-reduce, parallel.GradBucketReducer._launch)
     pinned = options.wgrad_stream
+    if _single_stream_only is not None:
+        return (wgrad_stream(False) if module() is not None else False), None, None
     if module() is None or pinned in ("0", "1"):
         return (wgrad_stream(pinned == "1") if module() is not None else False), None, None
     best = {False: float("inf"), True: float("inf")}

@@ -89,6 +89,11 @@ SIGNATURES = {
     "ts_leaky_bn_train_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _i32, _vp, _vp, _vp,
                                          _vp, _sz, _vp]),
     "ts_leaky_bn_train_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ts_conv3x3c32_packed_bytes": (_sz, []),
+    "ts_conv3x3c32_pack": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "ts_conv3x3c32_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_conv3x3c32_wgrad_workspace_bytes": (_sz, []),
+    "ts_conv3x3c32_wgrad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ts_conv_pair_gemm_f16": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "ts_conv_pair_gemm_f16_nat": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),

@@ -20,7 +20,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad",
 ]
 
 
@@ -866,6 +866,51 @@ def avgpool3s2_rows_backward(grad_y, in_shape):
     gx = torch.empty((t, c, h, w), dtype=grad_y.dtype, device=grad_y.device, memory_format=torch.channels_last)
     L.check(L.load().ts_avgpool3s2_rows_backward(L.ptr(grad_y), t, h, w, c, half, L.ptr(gx), L.stream()), "ts_avgpool3s2_rows_backward")
     return gx
+
+
+def conv3x3c32_pack(weight, mode):
+    """the packed MFMA operand of a Conv2d(32, 32, 3) weight (half, any strides): mode 0 forward, 1 data gradient"""
+    L.require_device(weight)
+    if weight.dtype != torch.float16 or tuple(weight.shape) != (32, 32, 3, 3):
+        raise ValueError(f"conv3x3c32_pack: a float16 [32, 32, 3, 3] weight, got {weight.dtype} {tuple(weight.shape)}")
+    lib = L.load()
+    packed = torch.empty(lib.ts_conv3x3c32_packed_bytes(), dtype=torch.uint8, device=weight.device)
+    s = weight.stride()
+    L.check(lib.ts_conv3x3c32_pack(L.ptr(weight), s[0], s[1], s[2], s[3], int(mode), L.ptr(packed), L.stream()), "ts_conv3x3c32_pack")
+    return packed
+
+
+def conv3x3c32_rows(x, packed, bias, dilation):
+    """Conv2d(32, 32, 3, stride 1, padding = dilation) of a channels-last float16 [T, 32, H, W] stack with a packed weight
+    (conv3x3c32_pack) and an optional float32 bias [32]; with the data-gradient pack and x = grad_y: grad_x."""
+    L.require_device(x, packed, bias)
+    x = _channels_last_rows(x, "conv3x3c32_rows")
+    t, c, h, w = x.shape
+    if c != 32 or x.dtype != torch.float16:
+        raise ValueError(f"conv3x3c32_rows: float16 with 32 channels, got {x.dtype} with {c}")
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    L.check(L.load().ts_conv3x3c32_rows(L.ptr(x), L.ptr(packed), L.ptr(bias), t, h, w, int(dilation), L.ptr(y), L.stream()),
+            "ts_conv3x3c32_rows")
+    return y
+
+
+def conv3x3c32_wgrad(x, grad_y, like_weight, dilation):
+    """weight gradient of Conv2d(32, 32, 3, stride 1, padding = dilation) from the channels-last float16 input x and output gradient
+    grad_y [T, 32, H, W]: a float16 tensor with like_weight's shape and strides (csrc/conv2d_rows.hip, deterministic)"""
+    L.require_device(x, grad_y)
+    x, grad_y = _channels_last_rows(x, "conv3x3c32_wgrad(x)"), _channels_last_rows(grad_y, "conv3x3c32_wgrad(grad_y)")
+    if x.shape != grad_y.shape or x.shape[1] != 32 or x.dtype != torch.float16 or grad_y.dtype != torch.float16:
+        raise ValueError("conv3x3c32_wgrad: two float16 [T, 32, H, W] stacks of one shape")
+    t, _, h, w = x.shape
+    gw = torch.empty_like(like_weight, dtype=torch.float16)          # (same strides as the weight)
+    s = gw.stride()
+    lib = L.load()
+    ws = L.workspace(lib.ts_conv3x3c32_wgrad_workspace_bytes(), x.device)
+    L.check(lib.ts_conv3x3c32_wgrad(L.ptr(x), L.ptr(grad_y), t, h, w, int(dilation), L.ptr(gw), s[0], s[1], s[2], s[3], L.ptr(ws), ws.numel(),
+                                    L.stream()), "ts_conv3x3c32_wgrad")
+    return gw
 
 
 def set_conv_impl(impl):

@@ -1,0 +1,314 @@
+// Dense 3 x 3 convolutions of TIAF's camera branch on channels-last half rows - the full-resolution layers of UNet2D
+// (R/pcseg/model/segmentor/voxel/minkunet/unet2d.py:10-31,41-60: `nn.Conv2d(32, 32, (3, 3), padding = 1)` and the dilated twin
+// `dilation = 2, padding = 2`; stem x 6, stage1 x 1: 4.9 M pixels each at bs 2).
+//
+// Why hand-written: MIOpen's best solver for this shape (its own find-db: ConvAsmImplicitGemmGTCDynamicFwdXdlopsNHWC) takes 0.60 ms
+// for the plain and 1.5 ms for the dilated layer; the layer moves 315 MB in and 315 MB out (0.08 ms at 8 TB/s) and needs 90 GFLOP
+// (0.04 ms of fp16 MFMA).  With 32 channels the whole weight (9 x 32 x 32 halfs = 18 KB) fits a wave's registers in MFMA operand
+// form, so the kernel is: weights -> 72 VGPRs once per wave, then per 32-pixel segment of an output row 18 x
+// `v_mfma_f32_32x32x16_f16` (M = output channel, N = pixel, K = 16 input channels: 2 per tap) whose B operands are 16-byte reads
+// of the input rows (lane = pixel, half = channel block) from a [pixel][channel] image of the tile's rows in LDS.
+// The four waves of a workgroup take four vertically adjacent segments and share the 4 + 2 D staged input rows; the result leaves
+// as 8-byte stores (4 consecutive output channels of a pixel per accumulator group).
+//   forward        Y[t, y, x, co] = bias[co] + sum_{ky, kx, ci} X[t, y + (ky - 1) D, x + (kx - 1) D, ci] W[co, ci, ky, kx]
+//   data gradient  dX = the same kernel over dY with the packed weights of mode 1 (taps mirrored, channels swapped), no bias
+// fp32 accumulation (the MFMA's), one rounding to half at the store - what MIOpen's fp16 solvers do.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+typedef _Float16 c2_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c2_h4 __attribute__((ext_vector_type(4)));
+typedef float c2_f16 __attribute__((ext_vector_type(16)));
+
+#define C2_C 32
+
+// weight [co][ci][ky][kx] with element strides (s_co, s_ci, s_ky, s_kx) -> packed[tap][kb][lane] (8 halfs per lane): the A operand of
+// v_mfma_f32_32x32x16_f16 for output row m = lane & 31 and reduction index k = 16 kb + 8 (lane >> 5) + j
+//   mode 0 (forward):        m = co, k = ci, tap = (ky, kx):          W[m][k][ky][kx]
+//   mode 1 (data gradient):  m = ci, k = co, tap = (ky, kx) mirrored: W[k][m][2 - ky][2 - kx]
+__global__ __launch_bounds__(64) void conv3x3c32_pack_kernel(const _Float16 *__restrict__ w, int64_t s_co, int64_t s_ci, int64_t s_ky,
+                                                             int64_t s_kx, int mode, c2_h8 *__restrict__ packed) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int tap = blockIdx.x / 2, kb = blockIdx.x % 2;
+  const int ky = tap / 3, kx = tap % 3;
+  c2_h8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * kb + 8 * h + j;
+    v[j] = mode == 0 ? w[r * s_co + k * s_ci + ky * s_ky + kx * s_kx] : w[k * s_co + r * s_ci + (2 - ky) * s_ky + (2 - kx) * s_kx];
+  }
+  packed[(size_t)blockIdx.x * 64 + lane] = v;
+}
+
+#define C2_PITCH 40            // halfs per staged pixel row (32 channels + 8: 16-byte multiple, 4 mod 8 dwords - the 16-byte fragment
+                               // reads of a 16-lane group then cover the 64 banks exactly once)
+
+// One tile = 4 output rows x 32 pixels.  The workgroup stages the 4 + 2 D input rows of the tile with their D-pixel halo in LDS
+// ([pixel][channel] rows, zeros where the image ends), wave w computes output row w: per tap two 16-byte LDS reads per lane (B
+// operand: lane = pixel, half = channel block) and two MFMAs against the weight fragments it holds in registers.  The NEXT tile's
+// rows are already on their way from HBM while the current one is multiplied (global loads into registers before the MFMAs, LDS
+// store after the barrier): the first form, which read its operands straight from global memory, ran at the latency of those
+// reads (0.32 ms per layer); the weight gradient below uses the same pipeline.
+template <int DIL>
+__global__ __launch_bounds__(256) void conv3x3c32_rows_kernel(const _Float16 *__restrict__ X, const c2_h8 *__restrict__ Wp,
+                                                              const float *__restrict__ bias, _Float16 *__restrict__ Y, int H, int W,
+                                                              int tiles_x, int tiles_y, int n_tiles) {
+  constexpr int XR = 4 + 2 * DIL, XW = 32 + 2 * DIL, N_X = XR * XW * 4, X_IT = (N_X + 255) / 256;
+  __shared__ __attribute__((aligned(16))) _Float16 xs[XR * XW * C2_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  c2_h8 wr[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    wr[tap][0] = Wp[(tap * 2 + 0) * 64 + lane];
+    wr[tap][1] = Wp[(tap * 2 + 1) * 64 + lane];
+  }
+  // accumulator register i of this lane belongs to output channel (i & 3) + 8 (i >> 2) + 4 h (column = pixel r)
+  c2_f16 init;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) init[i] = bias ? bias[(i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
+  const c2_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  c2_h8 nx[X_IT];
+  auto fetch = [&](int tile) {                                   // the tile's input rows -> registers (zeros outside the image)
+    const int xsi = tile % tiles_x, rest = tile / tiles_x;
+    const int y0 = (rest % tiles_y) * 4, x0 = xsi * 32;
+    const _Float16 *img = X + (size_t)(rest / tiles_y) * H * W * C2_C;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int e = tid + it * 256;
+      const int c8 = (e & 3) * 8, px = (e >> 2) % XW, row = (e >> 2) / XW;
+      const int yy = y0 - DIL + row, xx = x0 - DIL + px;
+      nx[it] = (e < N_X && yy >= 0 && yy < H && xx >= 0 && xx < W) ? *(const c2_h8 *)(img + ((size_t)yy * W + xx) * C2_C + c8) : zero;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();                                             // (the previous tile's fragments have been read)
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int e = tid + it * 256;
+      if (e < N_X) *(c2_h8 *)&xs[((e >> 2) / XW * XW + (e >> 2) % XW) * C2_PITCH + (e & 3) * 8] = nx[it];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) fetch(next);                             // in flight while this tile is multiplied
+    const int xsi = tile % tiles_x, rest = tile / tiles_x;
+    const int yb = rest % tiles_y, t = rest / tiles_y;
+    const int y = yb * 4 + wave, x = xsi * 32 + r;
+    c2_f16 acc = init;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const _Float16 *xrow = xs + ((wave + ky * DIL) * XW + r) * C2_PITCH + 8 * h;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const c2_h8 b0 = *(const c2_h8 *)(xrow + kx * DIL * C2_PITCH), b1 = *(const c2_h8 *)(xrow + kx * DIL * C2_PITCH + 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][1], b1, acc, 0, 0, 0);
+      }
+    }
+    if (y < H && x < W) {
+      _Float16 *o = Y + (((size_t)t * H + y) * W + x) * C2_C + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        c2_h4 v = {(_Float16)acc[4 * g], (_Float16)acc[4 * g + 1], (_Float16)acc[4 * g + 2], (_Float16)acc[4 * g + 3]};
+        *(c2_h4 *)(o + 8 * g) = v;
+      }
+    }
+  }
+}
+
+extern "C" size_t ts_conv3x3c32_packed_bytes(void) { return (size_t)9 * 2 * 64 * 16; }
+
+// weight: the nn.Conv2d parameter [32 co][32 ci][3][3] (IEEE half) with its element strides; mode 0 = forward operand, 1 = data
+// gradient operand; packed: ts_conv3x3c32_packed_bytes() bytes
+extern "C" int ts_conv3x3c32_pack(const void *weight, int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, int32_t mode, void *packed,
+                                  ts_stream_t stream) {
+  TS_REQUIRE(weight && packed && (mode == 0 || mode == 1), TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_pack: bad arguments");
+  TS_REQUIRE((((uintptr_t)packed) & 15) == 0, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_pack: packed must be 16-byte aligned");
+  conv3x3c32_pack_kernel<<<18, 64, 0, (hipStream_t)stream>>>((const _Float16 *)weight, s_co, s_ci, s_ky, s_kx, mode, (c2_h8 *)packed);
+  TS_CHECK_LAUNCH("ts_conv3x3c32_pack");
+  return TS_OK;
+}
+
+// y [T, H, W, 32] = conv3x3(x [T, H, W, 32], packed weights) (+ bias [32] float, may be NULL); stride 1, padding = dilation (1 or 2).
+// x and y channels-last IEEE half, 16-byte aligned, not overlapping.
+extern "C" int ts_conv3x3c32_rows(const void *x, const void *packed, const float *bias, int32_t T, int32_t H, int32_t W, int32_t dilation,
+                                  void *y, ts_stream_t stream) {
+  TS_REQUIRE(T >= 0 && H > 0 && W > 0 && (dilation == 1 || dilation == 2), TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_rows: bad sizes");
+  if (T == 0) return TS_OK;
+  TS_REQUIRE(x && packed && y && x != y, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_rows: null / aliased pointer");
+  TS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)packed)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv3x3c32_rows: pointers must be 16-byte aligned");
+  const int tiles_x = (int)ts_cdiv(W, 32), tiles_y = (int)ts_cdiv(H, 4);
+  const int64_t n_tiles = (int64_t)T * tiles_x * tiles_y;
+  TS_REQUIRE(n_tiles < (1LL << 31) && (int64_t)T * H * W * C2_C < (1LL << 40), TS_ERR_UNSUPPORTED, "ts_conv3x3c32_rows: stack too large");
+  // persistent workgroups: the 18 KB of packed weights are read once per wave, not once per tile
+  const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 256 * 8);
+  if (dilation == 1)
+    conv3x3c32_rows_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)x, (const c2_h8 *)packed, bias, (_Float16 *)y, H, W,
+                                                                     tiles_x, tiles_y, (int)n_tiles);
+  else
+    conv3x3c32_rows_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)x, (const c2_h8 *)packed, bias, (_Float16 *)y, H, W,
+                                                                     tiles_x, tiles_y, (int)n_tiles);
+  TS_CHECK_LAUNCH("ts_conv3x3c32_rows");
+  return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers:  dW[co, ci, ky, kx] = sum_{t, y, x} X[t, y + (ky - 1) D, x + (kx - 1) D, ci] dY[t, y, x, co].
+// Per tap a 32 x 32 product whose REDUCTION index is the pixel: both operands arrive pixel-major (channels-last rows), so a
+// workgroup stages the rows it needs as [pixel][channel] images in LDS (4 output rows x 32 pixels of dY, the 4 + 2 D input rows with
+// their D-pixel halo, zero where the image ends) and the MFMA fragments - 8 consecutive pixels of one channel per lane - come out of
+// gfx950's transposing LDS read (ds_read_b64_tr_b16), as in the sparse weight gradient (conv_pairs_h.hip).  Wave w of a workgroup owns
+// output row w of the tile and keeps all 9 x (32 x 32) sums in registers (144 accumulators) over the tiles of a persistent
+// workgroup; the four waves' sums meet in LDS once at the end, the workgroup writes ONE partial [9][32][32] and a second launch adds
+// the partials in index order: no atomics, run-to-run identical.  MIOpen's best solver for this shape: 0.95 ms; bytes: X and dY
+// once, 630 MB.
+#define CW_PITCH 40            // halfs per staged pixel row (32 channels + 8: 16-byte multiple, 4 mod 8 dwords)
+typedef __fp16 c2_hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float c2_f4 __attribute__((ext_vector_type(4)));
+
+template <int DIL>
+__global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *__restrict__ X, const _Float16 *__restrict__ DY, int H,
+                                                               int W, int tiles_x, int tiles_y, int n_tiles, float *__restrict__ part) {
+  constexpr int XR = 4 + 2 * DIL, XW = 32 + 2 * DIL;
+  constexpr int XS_HALFS = XR * XW * CW_PITCH, YS_HALFS = 4 * 32 * CW_PITCH;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[XS_HALFS + YS_HALFS];
+  _Float16 *xs = smem, *ys = smem + XS_HALFS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4, tq = r16 >> 2, tp = lane & 3;
+  const c2_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  // transposed fragment: pixels r0 .. r0 + 7 (rows of the image) of channel c0 + r16
+  auto frag = [&](const _Float16 *img, int r0, int c0) -> c2_h8 {
+    typedef c2_hv4 __attribute__((address_space(3))) * lds_hv4;
+    const c2_hv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + tq) * CW_PITCH + c0 + 4 * tp));
+    const c2_hv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + 4 + tq) * CW_PITCH + c0 + 4 * tp));
+    c2_h8 v;
+    v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+    v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+    return v;
+  };
+  c2_f4 acc[9][2][2];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t9][a][b] = (c2_f4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int N_X = XR * XW * 4, X_IT = (N_X + 255) / 256;
+  c2_h8 nx[X_IT], ny[2];
+  auto fetch = [&](int tile) {                                   // the tile's rows -> registers (zeros outside the image)
+    const int xsi = tile % tiles_x, rest = tile / tiles_x;
+    const int y0 = (rest % tiles_y) * 4, x0 = xsi * 32;
+    const _Float16 *ximg = X + (size_t)(rest / tiles_y) * H * W * C2_C, *yimg = DY + (size_t)(rest / tiles_y) * H * W * C2_C;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {                          // input rows y0 - D .. y0 + 3 + D, pixels x0 - D .. x0 + 31 + D
+      const int e = tid + it * 256;
+      const int c8 = (e & 3) * 8, px = (e >> 2) % XW, row = (e >> 2) / XW;
+      const int yy = y0 - DIL + row, xx = x0 - DIL + px;
+      nx[it] = (e < N_X && yy >= 0 && yy < H && xx >= 0 && xx < W) ? *(const c2_h8 *)(ximg + ((size_t)yy * W + xx) * C2_C + c8) : zero;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                             // output rows y0 .. y0 + 3, pixels x0 .. x0 + 31
+      const int e = tid + it * 256;
+      const int c8 = (e & 3) * 8, px = (e >> 2) & 31, row = e >> 7;
+      const int yy = y0 + row, xx = x0 + px;
+      ny[it] = (yy < H && xx < W) ? *(const c2_h8 *)(yimg + ((size_t)yy * W + xx) * C2_C + c8) : zero;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();                                       // (the previous tile's fragments have been read)
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int e = tid + it * 256;
+      if (e < N_X) *(c2_h8 *)&xs[((e >> 2) / XW * XW + (e >> 2) % XW) * CW_PITCH + (e & 3) * 8] = nx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + it * 256;
+      *(c2_h8 *)&ys[((e >> 7) * 32 + ((e >> 2) & 31)) * CW_PITCH + (e & 3) * 8] = ny[it];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) fetch(next);                       // in flight while this tile is multiplied
+    // (no lane-dependent control flow from here to the end of the tile: the transposing reads need every lane)
+    const _Float16 *yrow = ys + wave * 32 * CW_PITCH;
+    const c2_h8 b0 = frag(yrow, 8 * kg, 0), b1 = frag(yrow, 8 * kg, 16);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const _Float16 *xrow = xs + (wave + ky * DIL) * XW * CW_PITCH;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t9 = ky * 3 + kx;
+        const c2_h8 a0 = frag(xrow, 8 * kg + kx * DIL, 0), a1 = frag(xrow, 8 * kg + kx * DIL, 16);
+        acc[t9][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[t9][0][0], 0, 0, 0);
+        acc[t9][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc[t9][0][1], 0, 0, 0);
+        acc[t9][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc[t9][1][0], 0, 0, 0);
+        acc[t9][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[t9][1][1], 0, 0, 0);
+      }
+    }
+  }
+  // the four waves' sums, tap by tap through LDS (the staging images are free now), wave order 0 .. 3
+  __syncthreads();
+  float *red = (float *)smem;                              // 4 waves x [32][32] floats = 16 KB <= the two images together
+  static_assert(sizeof(_Float16) * (XS_HALFS + YS_HALFS) >= 4 * 1024 * sizeof(float) && (XS_HALFS % 8) == 0,
+                "LDS images too small for the reduction / second image misaligned");
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                          // accumulator register q: ci = 16 a + 4 kg + q, co = 16 b + r16
+          red[wave * 1024 + (16 * a + 4 * kg + q) * 32 + 16 * b + r16] = acc[t9][a][b][q];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256)
+      part[((size_t)blockIdx.x * 9 + t9) * 1024 + e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+    __syncthreads();
+  }
+}
+
+// dW[co][ci][ky][kx] (element strides given, IEEE half) = sum over the workgroups' partials [n_part][9][ci][co] in index order
+__global__ __launch_bounds__(256) void conv3x3c32_wgrad_reduce_kernel(const float *__restrict__ part, int n_part, _Float16 *__restrict__ dw,
+                                                                      int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx) {
+  const int e = blockIdx.x * 256 + threadIdx.x;            // (tap, ci, co)
+  if (e >= 9 * 1024) return;
+  float s = 0.f;
+  for (int p = 0; p < n_part; ++p) s += part[(size_t)p * 9 * 1024 + e];
+  const int t9 = e >> 10, ci = (e >> 5) & 31, co = e & 31;
+  dw[co * s_co + ci * s_ci + (t9 / 3) * s_ky + (t9 % 3) * s_kx] = (_Float16)s;
+}
+
+#define C2_WGRAD_WGS 512
+extern "C" size_t ts_conv3x3c32_wgrad_workspace_bytes(void) { return (size_t)C2_WGRAD_WGS * 9 * 1024 * sizeof(float); }
+
+// grad_weight [32 co][32 ci][3][3] (IEEE half, element strides given: the layout of the weight it belongs to) from x and grad_y
+// [T, H, W, 32] channels-last half; ws >= ts_conv3x3c32_wgrad_workspace_bytes()
+extern "C" int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t dilation, void *grad_weight,
+                                   int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(T > 0 && H > 0 && W > 0 && (dilation == 1 || dilation == 2), TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_wgrad: bad sizes");
+  TS_REQUIRE(x && grad_y && grad_weight && ws && ws_bytes >= ts_conv3x3c32_wgrad_workspace_bytes(), TS_ERR_INVALID_ARGUMENT,
+             "ts_conv3x3c32_wgrad: null pointer / workspace too small");
+  TS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)grad_y) | ((uintptr_t)ws)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv3x3c32_wgrad: pointers must be 16-byte aligned");
+  const int tiles_x = (int)ts_cdiv(W, 32), tiles_y = (int)ts_cdiv(H, 4);
+  const int64_t n_tiles = (int64_t)T * tiles_x * tiles_y;
+  TS_REQUIRE(n_tiles < (1LL << 31), TS_ERR_UNSUPPORTED, "ts_conv3x3c32_wgrad: stack too large");
+  const int grid = (int)std::min<int64_t>(n_tiles, C2_WGRAD_WGS);
+  if (dilation == 1)
+    conv3x3c32_wgrad_kernel<1><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
+                                                         (float *)ws);
+  else
+    conv3x3c32_wgrad_kernel<2><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
+                                                         (float *)ws);
+  conv3x3c32_wgrad_reduce_kernel<<<36, 256, 0, stream>>>((const float *)ws, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx);
+  TS_CHECK_LAUNCH("ts_conv3x3c32_wgrad");
+  return TS_OK;
+}

@@ -123,6 +123,9 @@ class GradBucketReducer:
         if live and process_group is None and self.world > 1 and not options.dist_buckets_on_default_group:
             process_group = dist.new_group(backend=dist.get_backend())
         self.group = process_group
+        if self.world > 1:          # (see _fast.require_single_stream: no weight gradients on a second stream under N > 1)
+            from . import _fast
+            _fast.require_single_stream("gradient buckets are averaged over %d ranks" % self.world)
         self._next = 0              # index of the next bucket to launch (launch order = index order on every rank)
         self._slot_of = {}          # id(parameter) -> (bucket index, position in the bucket)
         params = [p for p in model.parameters() if p.requires_grad]

@@ -191,6 +191,45 @@ def _act_bn(act, bn, x):
     return bn(act(x))
 
 
+class _Conv3x3C32Rows(Function):
+    """Conv2d(32, 32, 3, stride 1, padding = dilation) of a channels-last half map on csrc/conv2d_rows.hip: forward, data gradient
+    (the weight lives in a wave's registers as MFMA operands) and weight gradient (pixel-major rows through LDS transposing reads,
+    partial sums in a fixed order) on the library's kernels - tools/conv2d_probe.py has them against MIOpen's best solvers for
+    this shape; the bias gradient is one fp32-accumulated sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight16, bias, dilation):
+        y = B.conv3x3c32_rows(x, B.conv3x3c32_pack(weight16, 0), None if bias is None else bias.float(), dilation)
+        ctx.save_for_backward(x, weight16)
+        ctx.dilation, ctx.bias_dtype = int(dilation), None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, w = ctx.saved_tensors
+        d = ctx.dilation
+        grad_y = grad_y.to(torch.float16).contiguous(memory_format=torch.channels_last)
+        gx = B.conv3x3c32_rows(grad_y, B.conv3x3c32_pack(w, 1), None, d) if ctx.needs_input_grad[0] else None
+        gw = B.conv3x3c32_wgrad(x, grad_y, w, d) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            gb = grad_y.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+        return gx, gw, gb, None
+
+
+def _conv(conv, x):
+    """the block's Conv2d.  The 3 x 3, 32 -> 32 channel layers (plain and dilated: the seven full-resolution layers of the stem and
+    stage 1) of a channels-last half map - what autocast makes of them - go through the library's kernel; everything else is the
+    module itself."""
+    if (options.image_conv_rows and x.is_cuda and x.dim() == 4 and x.dtype == torch.float16 and type(conv) is nn.Conv2d
+            and conv.in_channels == 32 and conv.out_channels == 32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.groups == 1 and conv.padding == conv.dilation and conv.dilation in ((1, 1), (2, 2)) and conv.padding_mode == "zeros"
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks)):
+        return _Conv3x3C32Rows.apply(x, conv.weight.to(torch.float16), conv.bias, conv.dilation[0])
+    return conv(x)
+
+
 def _leaky():
     return nn.LeakyReLU()
 
@@ -211,8 +250,8 @@ class ResContextBlock(nn.Module):
 
     def forward(self, x):
         skip = self.act1(self.conv1(x))
-        y = _act_bn(self.act2, self.bn1, self.conv2(skip))
-        y = _act_bn(self.act3, self.bn2, self.conv3(y))
+        y = _act_bn(self.act2, self.bn1, _conv(self.conv2, skip))
+        y = _act_bn(self.act3, self.bn2, _conv(self.conv3, y))
         return skip + y
 
 
@@ -233,7 +272,7 @@ class ResBlock(nn.Module):
             self.pool = nn.AvgPool2d(kernel_size=kernel_size, stride=2, padding=1)
 
     def forward(self, x):
-        res = self.act1(self.conv1(x)) + _act_bn(self.act2, self.bn1, self.conv2(x))
+        res = self.act1(self.conv1(x)) + _act_bn(self.act2, self.bn1, _conv(self.conv2, x))
         out = self.dropout(res) if self.drop_out else res
         if not self.pooling:
             return out

@@ -59,9 +59,10 @@ def one_step(model, batches, process_group=None, amp=False):
     from taseg_amd.optim import FlatSGD
     from taseg_amd.torchsparse import SparseTensor
     opt = FlatSGD(model, lr=0.0, momentum=0.0, weight_decay=0.0, process_group=process_group)
-    if os.environ.get("TASEG_WORKER_SIDE") == "1":      # weight gradients on the second stream, joined before every bucket's all-reduce
-        from taseg_amd import _fast
-        assert _fast.wgrad_stream(True)
+    if os.environ.get("TASEG_WORKER_SIDE") == "1":      # asked for: weight gradients on the second stream.  Under N > 1 the request is
+        from taseg_amd import _fast                      # refused (taseg_amd._fast.require_single_stream), on one rank it is granted
+        granted = _fast.wgrad_stream(True)
+        assert granted == (opt.reducer.world == 1), (granted, opt.reducer.world)
     coords = torch.from_numpy(np.concatenate([b[0] for b in batches])).cuda()
     feats = torch.from_numpy(np.concatenate([b[1] for b in batches])).cuda()
     labels = torch.from_numpy(np.concatenate([b[2] for b in batches])).cuda()

@@ -105,10 +105,11 @@ def test_ranks_share_one_device(tmp_path, world, amp):
           f"concatenated batch: worst relative gradient error {worst:.2e}")
 
 
-def test_second_stream_under_the_bucket_reducer_gives_the_same_bits(tmp_path):
-    """weight gradients on the second stream with N > 1 (per-rank BatchNorm statistics: a block that exchanges statistics keeps its
-    weight gradient on its own stream): every bucket's all-reduce first joins the second stream (parallel.GradBucketReducer._launch) -
-    logits, averaged gradients and running statistics bit-equal to the one-stream run"""
+def test_second_stream_is_refused_under_more_than_one_rank(tmp_path):
+    """Under N > 1 the weight gradients stay on the stream of their backward pass: a request for the second stream is refused
+    (taseg_amd._fast.require_single_stream, set by GradBucketReducer when world > 1 - the workers assert it), and the step is the
+    one-stream step bit for bit.  (Rounds 5 and 6 ran the second stream under the gradient buckets in this two-rank rehearsal:
+    intermittent memory-access faults, a crashed rank, wrong gradients - no cause found, so the combination is off.)"""
     env = {"TASEG_WORKER_AMP": "0", "TASEG_WORKER_LOCAL_BN": "1"}
     (tmp_path / "one").mkdir()
     (tmp_path / "two").mkdir()

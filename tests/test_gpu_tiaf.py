@@ -197,6 +197,39 @@ def test_fused_leaky_relu_batch_norm_equals_the_two_modules(shape, dtype):
     assert torch.equal(_act_bn(act, ours, x), ours(act(x)))
 
 
+@pytest.mark.parametrize("dilation", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 32, 19, 45), (1, 32, 4, 32), (3, 32, 64, 96)])
+def test_conv3x3_c32_rows_equals_the_module(shape, dilation):
+    """UNet2D's 3 x 3, 32 -> 32 channel layers on channels-last half maps (csrc/conv2d_rows.hip, unet2d._conv) against nn.Conv2d
+    evaluated in float64 on the same half inputs: output, input gradient (ours), weight / bias gradients (vendor library behind the
+    same node); sizes that are no multiple of the 32-pixel segments / 4-row tiles; run-to-run identical"""
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import _conv
+    g = torch.Generator().manual_seed(13)
+    conv = torch.nn.Conv2d(32, 32, 3, padding=dilation, dilation=dilation).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(*shape, generator=g).cuda().half().contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = torch.randn(*shape, generator=g).cuda()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = _conv(conv, x)
+    assert y.dtype == torch.float16 and y.grad_fn.__class__.__name__.startswith("_Conv3x3C32Rows") and y.is_contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias), retain_graph=True)
+    gx2, _, _ = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
+    assert torch.equal(gx, gx2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
+    ref = torch.nn.Conv2d(32, 32, 3, padding=dilation, dilation=dilation).cuda().double()
+    with torch.no_grad():
+        ref.weight.copy_(conv.weight.half().double())          # the half weight autocast hands the kernel
+        ref.bias.copy_(conv.bias.double())
+    xd = x.detach().double().requires_grad_()
+    want = ref(xd)
+    wx, ww, wb = torch.autograd.grad((want * wt.double()).sum(), (xd, ref.weight, ref.bias))
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm().clamp_min(1e-30))      # noqa: E731
+    assert float((y.double() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))      # one rounding to half
+    assert rel(gx, wx) <= 2e-3 and rel(gw, ww) <= 5e-3 and rel(gb, wb) <= 5e-3, (rel(gx, wx), rel(gw, ww), rel(gb, wb))
+    # a float32 map / another shape of layer: the module itself
+    assert _conv(conv, x.detach().float()).grad_fn.__class__.__name__ == "ConvolutionBackward0"
+    other = torch.nn.Conv2d(32, 64, 3, padding=1).cuda().half().to(memory_format=torch.channels_last)
+    assert torch.equal(_conv(other, x.detach()), other(x.detach()))
+
+
 def _tiaf_batch(g):
     from taseg_amd.torchsparse import SparseTensor
     dev = "cuda"
@@ -271,6 +304,55 @@ def test_tiaf_model_vs_reference_golden(g_minkunet_ms_mm, training):
     assert sorted(names) == sorted(grads)
     norms = np.array([float(grads[n].norm()) for n in names])
     assert np.allclose(norms, g[f"{tag}_gradnorms"], rtol=5e-2 if training else 2e-3, atol=1e-6)
+
+
+def test_tiaf_model_under_autocast_takes_the_row_kernels_and_stays_close(g_minkunet_ms_mm):
+    """the mode the reference trains TIAF in (dist_train.sh:18 `--amp`): MinkUNetMsMm under torch.autocast on the golden's inputs - the
+    camera branch runs channels-last on the library's kernels (row gathers, average pooling, LeakyReLU + BatchNorm2d, the 3 x 3
+    32-channel convolutions), logits and the five losses stay within half-precision distance of the reference's fp32 run, the
+    step is run-to-run identical"""
+    import taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d as U
+    g = g_minkunet_ms_mm
+    seen = set()
+    real = {n: getattr(U, n) for n in ("_Conv3x3C32Rows", "_LeakyBatchNormRows", "_AvgPool3s2Rows", "_ImageGatherThrough")}
+
+    def run():
+        _, model = _build_mm()
+        model.train()
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+                m.eval()
+        grabbed = {}
+        hooks = [m.register_forward_hook(lambda mod, i, o, key=key: grabbed.__setitem__(key, o.detach().float().cpu().numpy()))
+                 for key, m in (("logits", model.classifier), ("fusion_logits", model.classifier_fusion),
+                                ("fov_logits", model.lidar_backbone.classifier), ("image_logits", model.image_backbone.classifier))]
+        bd = _tiaf_batch(g)
+        with torch.autocast("cuda", dtype=torch.float16):
+            ret, tb, _ = model(bd)
+        for h in hooks:
+            h.remove()
+        node, stack = ret["loss"].grad_fn, [ret["loss"].grad_fn]
+        while stack:                                   # which of the library's 2-D nodes are in the graph
+            node = stack.pop()
+            if node is None or id(node) in seen:
+                continue
+            seen.add(id(node))
+            seen.add(type(node).__name__)
+            stack.extend(fn for fn, _ in node.next_functions)
+        model.zero_grad()
+        ret["loss"].float().backward()
+        grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        return grabbed, np.array([float(tb[k]) for k in ("loss_lidar", "loss_fusion", "loss_image_s", "loss_image_d", "loss_image_lidar")]), grads
+
+    a, parts_a, grads_a = run()
+    for name in real:
+        assert any(isinstance(t, str) and t.startswith(name) for t in seen), f"{name} is not in the autocast graph"
+    for key in ("image_logits", "fov_logits", "logits", "fusion_logits"):
+        assert np.abs(a[key] - g[f"train_{key}"]).max() <= 5e-2, (key, float(np.abs(a[key] - g[f"train_{key}"]).max()))
+    assert np.abs(parts_a - g["train_loss_parts"]).max() <= 2e-2
+    b, parts_b, grads_b = run()
+    assert all(np.array_equal(a[k], b[k]) for k in a) and np.array_equal(parts_a, parts_b)
+    assert all(torch.equal(grads_a[n], grads_b[n]) for n in grads_a)
 
 
 def test_tiaf_fix_part_param():
