@@ -462,6 +462,29 @@ size_t ts_conv3x3c32_wgrad_workspace_bytes(void);
 int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t dilation, void *grad_weight,
                         int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, void *ws, size_t ws_bytes, ts_stream_t stream);
 
+/* The same convolution (stride 1, padding 1, no dilation) with the channel counts opened up - UpBlock.conv1 of the decoder
+ * (unet2d.py:81-115: 96 -> 96 channels at 1/2 scale, 56 -> 96 at full scale): input channels a multiple of 8 up to 96, output
+ * channels a multiple of 8.  A persistent workgroup owns one 32-channel output block, its 9 x C_in/16 weight fragments in registers.
+ *   ts_conv3x3_rows_packed_bytes(k, m)  bytes of the packed operand for k reduction channels (the channels of the call's input)
+ *                                       and m result channels; 0 = the kernel does not take the layer
+ *   ts_conv3x3_rows_pack                weight [c_out][c_in][3][3] (half, element strides) -> packed; mode 0 forward
+ *                                       (k, m) = (c_in, c_out), mode 1 data gradient (k, m) = (c_out, c_in)
+ *   ts_conv3x3_rows                     y [T, H, W, y_channels] = conv(x [T, H, W, x_channels]) + bias (float, may be NULL) */
+size_t ts_conv3x3_rows_packed_bytes(int32_t k_channels, int32_t m_channels);
+int ts_conv3x3_rows_pack(const void *weight, int32_t c_out, int32_t c_in, int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx,
+                         int32_t mode, void *packed, ts_stream_t stream);
+int ts_conv3x3_rows(const void *x, int32_t x_channels, const void *packed, const float *bias, int32_t T, int32_t H, int32_t W, void *y,
+                    int32_t y_channels, ts_stream_t stream);
+
+/* UpBlock's entry on channels-last rows (unet2d.py:98-108: PixelShuffle(2), Dropout2d, torch.cat((upA, skip), dim=1), Dropout2d) in one
+ * pass:  cat [T, 2h, 2w, C/4 + Cs] = concat(PixelShuffle(2)(x [T, h, w, C]), skip [T, 2h, 2w, Cs]) * scale [T, C/4 + Cs]
+ * (float, may be NULL: the two dropout masks folded into one factor per frame and channel).  half != 0: IEEE half (C a multiple of
+ * 32, Cs of 8), else float (16 / 4).  _backward is the adjoint: grad_x and grad_skip from grad_cat with the same scale. */
+int ts_shuffle_cat_rows_forward(const void *x, const void *skip, const float *scale, int32_t T, int32_t h, int32_t w, int32_t C, int32_t Cs,
+                                int32_t half, void *cat, ts_stream_t stream);
+int ts_shuffle_cat_rows_backward(const void *grad_cat, const float *scale, int32_t T, int32_t h, int32_t w, int32_t C, int32_t Cs,
+                                 int32_t half, void *grad_x, void *grad_skip, ts_stream_t stream);
+
 /* ---- fp16 storage / fp32 accumulation (the reference trains under AMP: conv.py:19 `custom_fwd(cast_inputs=half)`).
  * `void *` operands are IEEE half arrays.  Channel counts must be multiples of 32, K <= 63.
  *   ts_cast_weights_f16      w f32 [K, Ci, Co] -> w16 [K, Ci, Co] and / or w16t [K, Co, Ci] (either may be NULL)

@@ -92,6 +92,11 @@ SIGNATURES = {
     "ts_conv3x3c32_packed_bytes": (_sz, []),
     "ts_conv3x3c32_pack": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "ts_conv3x3c32_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_shuffle_cat_rows_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ts_shuffle_cat_rows_backward": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ts_conv3x3_rows_packed_bytes": (_sz, [_i32, _i32]),
+    "ts_conv3x3_rows_pack": (_i32, [_vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "ts_conv3x3_rows": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "ts_conv3x3c32_wgrad_workspace_bytes": (_sz, []),
     "ts_conv3x3c32_wgrad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ts_cast_weights_f16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

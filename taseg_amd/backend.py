@@ -20,7 +20,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad", "conv3x3_rows_takes", "conv3x3_rows_pack", "conv3x3_rows", "shuffle_cat_rows_takes", "shuffle_cat_rows_forward", "shuffle_cat_rows_backward",
 ]
 
 
@@ -893,6 +893,97 @@ def conv3x3c32_rows(x, packed, bias, dilation):
     y = torch.empty_like(x, memory_format=torch.channels_last)
     L.check(L.load().ts_conv3x3c32_rows(L.ptr(x), L.ptr(packed), L.ptr(bias), t, h, w, int(dilation), L.ptr(y), L.stream()),
             "ts_conv3x3c32_rows")
+    return y
+
+
+def shuffle_cat_rows_takes(x, skip):
+    """whether ts_shuffle_cat_rows_* takes this pair: channels-last float32 / float16 of one dtype, skip twice x's size, channel counts
+    multiples of the 16-byte piece"""
+    if (x.dim() != 4 or skip.dim() != 4 or x.dtype != skip.dtype or x.dtype not in (torch.float16, torch.float32) or not x.is_cuda
+            or tuple(skip.shape[2:]) != (2 * x.shape[2], 2 * x.shape[3]) or skip.shape[0] != x.shape[0]):
+        return False
+    ve = 8 if x.dtype == torch.float16 else 4
+    return (x.shape[1] % (4 * ve) == 0 and skip.shape[1] % ve == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and skip.is_contiguous(memory_format=torch.channels_last))
+
+
+def shuffle_cat_rows_forward(x, skip, scale=None):
+    """concat(PixelShuffle(2)(x), skip) along the channels, times an optional float32 factor [T, C/4 + Cs] per frame and channel;
+    channels-last in and out (csrc/shuffle_cat.hip)"""
+    L.require_device(x, skip, scale)
+    if not shuffle_cat_rows_takes(x, skip):
+        raise ValueError(f"shuffle_cat_rows_forward: unsupported pair {tuple(x.shape)} {x.dtype} / {tuple(skip.shape)} {skip.dtype}")
+    t, c, h, w = x.shape
+    cs = skip.shape[1]
+    if scale is not None:
+        scale = _f32(scale, "scale")
+        if scale.numel() != t * (c // 4 + cs):
+            raise ValueError("shuffle_cat_rows_forward: scale must be [T, C/4 + Cs]")
+    cat = torch.empty((t, c // 4 + cs, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    L.check(L.load().ts_shuffle_cat_rows_forward(L.ptr(x), L.ptr(skip), L.ptr(scale), t, h, w, c, cs, int(x.dtype == torch.float16), L.ptr(cat),
+                                                 L.stream()), "ts_shuffle_cat_rows_forward")
+    return cat
+
+
+def shuffle_cat_rows_backward(grad_cat, channels, scale=None):
+    """the adjoint of shuffle_cat_rows_forward for x of `channels` channels: (grad_x [T, C, h, w], grad_skip [T, Cs, 2h, 2w])"""
+    L.require_device(grad_cat, scale)
+    grad_cat = _channels_last_rows(grad_cat, "shuffle_cat_rows_backward")
+    t, cc, h2, w2 = grad_cat.shape
+    c = int(channels)
+    cs = cc - c // 4
+    gx = torch.empty((t, c, h2 // 2, w2 // 2), dtype=grad_cat.dtype, device=grad_cat.device, memory_format=torch.channels_last)
+    gs = torch.empty((t, max(cs, 0), h2, w2), dtype=grad_cat.dtype, device=grad_cat.device, memory_format=torch.channels_last)
+    if not shuffle_cat_rows_takes(gx, gs) or cs <= 0:
+        raise ValueError(f"shuffle_cat_rows_backward: unsupported gradient {tuple(grad_cat.shape)} {grad_cat.dtype} for {c} channels")
+    if scale is not None:
+        scale = _f32(scale, "scale")
+        if scale.numel() != t * cc:
+            raise ValueError("shuffle_cat_rows_backward: scale must be [T, C/4 + Cs]")
+    L.check(L.load().ts_shuffle_cat_rows_backward(L.ptr(grad_cat), L.ptr(scale), t, h2 // 2, w2 // 2, c, cs, int(grad_cat.dtype == torch.float16),
+                                                  L.ptr(gx), L.ptr(gs), L.stream()), "ts_shuffle_cat_rows_backward")
+    return gx, gs
+
+
+def conv3x3_rows_takes(c_in, c_out):
+    """whether csrc/conv2d_rows.hip's general kernel takes a Conv2d(c_in, c_out, 3, padding 1) forward AND backward"""
+    lib = L.load()
+    return bool(lib.ts_conv3x3_rows_packed_bytes(int(c_in), int(c_out))) and bool(lib.ts_conv3x3_rows_packed_bytes(int(c_out), int(c_in)))
+
+
+def conv3x3_rows_pack(weight, mode):
+    """the packed MFMA operand of a Conv2d(c_in, c_out, 3) weight (half, any strides): mode 0 forward, 1 data gradient"""
+    L.require_device(weight)
+    if weight.dtype != torch.float16 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError(f"conv3x3_rows_pack: a float16 [c_out, c_in, 3, 3] weight, got {weight.dtype} {tuple(weight.shape)}")
+    lib = L.load()
+    c_out, c_in = int(weight.shape[0]), int(weight.shape[1])
+    n = lib.ts_conv3x3_rows_packed_bytes(c_in, c_out) if int(mode) == 0 else lib.ts_conv3x3_rows_packed_bytes(c_out, c_in)
+    if n == 0:
+        raise ValueError(f"conv3x3_rows_pack: the kernel does not take {c_in} -> {c_out} channels (mode {mode})")
+    packed = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    s = weight.stride()
+    L.check(lib.ts_conv3x3_rows_pack(L.ptr(weight), c_out, c_in, s[0], s[1], s[2], s[3], int(mode), L.ptr(packed), L.stream()),
+            "ts_conv3x3_rows_pack")
+    return packed
+
+
+def conv3x3_rows(x, packed, bias, out_channels):
+    """Conv2d(C, out_channels, 3, stride 1, padding 1) of a channels-last float16 [T, C, H, W] stack with a packed weight
+    (conv3x3_rows_pack) and an optional float32 bias; with the data-gradient pack and x = grad_y: grad_x."""
+    L.require_device(x, packed, bias)
+    x = _channels_last_rows(x, "conv3x3_rows")
+    t, c, h, w = x.shape
+    lib = L.load()
+    if x.dtype != torch.float16 or packed.numel() != lib.ts_conv3x3_rows_packed_bytes(c, int(out_channels)) or packed.numel() == 0:
+        raise ValueError(f"conv3x3_rows: float16 rows and the packed operand of {c} -> {out_channels} channels")
+    if bias is not None:
+        bias = _f32(bias, "bias")
+        if bias.numel() != int(out_channels):
+            raise ValueError("conv3x3_rows: bias length")
+    y = torch.empty((t, int(out_channels), h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    L.check(lib.ts_conv3x3_rows(L.ptr(x), c, L.ptr(packed), L.ptr(bias), t, h, w, L.ptr(y), int(out_channels), L.stream()),
+            "ts_conv3x3_rows")
     return y
 
 

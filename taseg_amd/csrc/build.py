@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "stage.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_class.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip", "evaltail.hip", "conv2d_rows.hip"]
+SOURCES = ["hash.hip", "coords.hip", "pointops.hip", "conv.hip", "conv_pairs.hip", "bn.hip", "quantize.hip", "stage.hip", "image.hip", "conv_pairs_h.hip", "conv_pairs_s.hip", "conv_class.hip", "optim.hip", "rccl.hip", "block.hip", "loss.hip", "evaltail.hip", "conv2d_rows.hip", "shuffle_cat.hip"]
 # measured-and-shelved kernels (HISTORY.md section 3.1 step 11) live in tools/experiments/ and are NOT part of libtaseg_hip.so:
 # `python -m taseg_amd.csrc.build --experiments` builds them into tools/experiments/build/libtaseg_exp.so for the probes there
 EXP_DIR = os.path.join(ROOT, "tools", "experiments")

@@ -274,13 +274,30 @@ __global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *_
   }
 }
 
-// dW[co][ci][ky][kx] (element strides given, IEEE half) = sum over the workgroups' partials [n_part][9][ci][co] in index order
+// dW[co][ci][ky][kx] (element strides given, IEEE half) = sum over the workgroups' partials [n_part][9][ci][co] in index order.
+// A workgroup owns 64 consecutive elements; its four waves each add a quarter of the partials (8 loads in flight per lane) and the
+// four sums meet in LDS in wave order - a fixed order, run-to-run identical.  (The first form, one thread per element walking all
+// 512 partials, took 0.12 ms per layer: as long as half the weight gradient itself.)
 __global__ __launch_bounds__(256) void conv3x3c32_wgrad_reduce_kernel(const float *__restrict__ part, int n_part, _Float16 *__restrict__ dw,
                                                                       int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx) {
-  const int e = blockIdx.x * 256 + threadIdx.x;            // (tap, ci, co)
-  if (e >= 9 * 1024) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;                    // (tap, ci, co); 9 * 1024 = 144 * 64
+  const int per = (n_part + 3) / 4, p0 = q * per, p1 = min(n_part, p0 + per);
   float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += part[(size_t)p * 9 * 1024 + e];
+  int p = p0;
+  for (; p + 8 <= p1; p += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(p + j) * 9 * 1024 + e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; p < p1; ++p) s += part[(size_t)p * 9 * 1024 + e];
+  red[q][lane] = s;
+  __syncthreads();
+  if (q != 0) return;
+  s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   const int t9 = e >> 10, ci = (e >> 5) & 31, co = e & 31;
   dw[co * s_co + ci * s_ci + (t9 / 3) * s_ky + (t9 % 3) * s_kx] = (_Float16)s;
 }
@@ -308,7 +325,212 @@ extern "C" int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T,
   else
     conv3x3c32_wgrad_kernel<2><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
                                                          (float *)ws);
-  conv3x3c32_wgrad_reduce_kernel<<<36, 256, 0, stream>>>((const float *)ws, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx);
+  conv3x3c32_wgrad_reduce_kernel<<<144, 256, 0, stream>>>((const float *)ws, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx);
   TS_CHECK_LAUNCH("ts_conv3x3c32_wgrad");
   return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The decoder's wide layers: UpBlock.conv1 of up3 (96 -> 96 channels at 1/2 scale) and up4 (56 -> 96 at full scale)
+// (R/pcseg/model/segmentor/voxel/minkunet/unet2d.py:81-115; plain 3 x 3, stride 1, padding 1).  MIOpen's best solvers for the up4
+// shape take 4.4 ms forward and 1.5 ms for the data gradient (tools/unet2d_layers.py; the maps are 550 + 945 MB: 0.19 ms of HBM, 0.2 ms
+// of fp16 MFMA).  Same scheme as the 32-channel kernel above with the channel counts opened up:
+//   - C_in any multiple of 8 up to 96 (staged in LDS zero-padded to 16 KB channels: KB = 2, 4, 6 K-blocks per tap),
+//   - C_out any multiple of 8, in blocks of 32: a persistent workgroup owns ONE output block and keeps its 9 x KB weight fragments
+//     in registers (36 KB VGPRs of the 512 a wave of a 256-thread workgroup may hold); workgroups of the blocks of one tile are
+//     neighbours in the grid, so the input rows they all stage come out of L2 for all but the first,
+//   - a wave computes RPW vertically adjacent output rows of the 32-pixel segment: a B fragment (one input row, tap column, K block)
+//     read from LDS once feeds the up to RPW output rows it belongs to - at one row per wave the LDS reads (1 KB per MFMA) are as
+//     long as the MFMAs themselves.
+template <int KB, int RPW>
+__global__ __launch_bounds__(256) void conv3x3_rows_kernel(const _Float16 *__restrict__ X, int x_ch, const c2_h8 *__restrict__ Wp,
+                                                           const float *__restrict__ bias, _Float16 *__restrict__ Y, int y_ch, int H, int W,
+                                                           int tiles_x, int tiles_y, int n_tiles, int n_cob) {
+  constexpr int TR = 4 * RPW, XR = TR + 2, XW = 34, NCH = 2 * KB, PITCH = 16 * KB + 8;
+  constexpr int N_X = XR * XW * NCH, X_IT = (N_X + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) _Float16 xs_dyn[];
+  _Float16 *xs = xs_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // grid = groups of 8 n_cob workgroups: workgroup j of a group takes output block j / 8 of tile stream 8 group + j % 8 - the n_cob
+  // workgroups of one tile stream have the same index modulo 8, i.e. sit on the same XCD and share its L2
+  const int j = blockIdx.x % (8 * n_cob), cob = j >> 3, first = (blockIdx.x / (8 * n_cob)) * 8 + (j & 7), step = gridDim.x / n_cob;
+  const int x_chunks = x_ch >> 3;
+  c2_h8 wr[9][KB];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) wr[tap][kb] = Wp[((size_t)(cob * 9 + tap) * KB + kb) * 64 + lane];
+  // accumulator register i of this lane belongs to output channel 32 cob + (i & 3) + 8 (i >> 2) + 4 h (column = pixel r)
+  c2_f16 init;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int co = 32 * cob + (i & 3) + 8 * (i >> 2) + 4 * h;
+    init[i] = (bias && co < y_ch) ? bias[co] : 0.f;
+  }
+  const c2_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  c2_h8 nx[X_IT];
+  // (the offsets of a thread's pieces are recomputed per tile on purpose: kept in registers across tiles they push the prefetched
+  // rows out to AGPRs behind a wait per load - KB = 6 ran twice as long that way)
+  auto fetch = [&](int tile) {                                   // the tile's input rows -> registers (zeros outside the image / beyond C_in)
+    const int xsi = tile % tiles_x, rest = tile / tiles_x;
+    const int y0 = (rest % tiles_y) * TR, x0 = xsi * 32;
+    const _Float16 *img = X + (size_t)(rest / tiles_y) * H * W * x_ch;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int e = tid + it * 256;
+      const int ch = e % NCH, px = (e / NCH) % XW, row = (e / NCH) / XW;
+      const int yy = y0 - 1 + row, xx = x0 - 1 + px;
+      nx[it] = (e < N_X && ch < x_chunks && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                   ? *(const c2_h8 *)(img + ((size_t)yy * W + xx) * x_ch + 8 * ch) : zero;
+    }
+  };
+  // A tile's result is held back (rounded to half: 8 RPW registers) and stored while the NEXT tile is multiplied: stores count
+  // against the same counter as loads on this target, so the wait for the prefetched rows at the top of the loop would otherwise
+  // also wait for stores issued a moment before it - with one wave per SIMD nothing else runs meanwhile.
+  c2_h4 pend[RPW][4];
+  int pend_tile = -1;
+  auto flush = [&](int tile) {
+    const int xsi = tile % tiles_x, rest = tile / tiles_x;
+    const int yb = rest % tiles_y, t = rest / tiles_y;
+    const int x = xsi * 32 + r;
+#pragma unroll
+    for (int o = 0; o < RPW; ++o) {
+      const int y = yb * TR + wave * RPW + o;
+      if (y < H && x < W) {
+        _Float16 *op = Y + (((size_t)t * H + y) * W + x) * y_ch + 32 * cob + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (32 * cob + 4 * h + 8 * g < y_ch) *(c2_h4 *)(op + 8 * g) = pend[o][g];
+      }
+    }
+  };
+  int tile = first;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += step) {
+    __syncthreads();                                             // (the previous tile's fragments have been read)
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int e = tid + it * 256;
+      if (e < N_X) *(c2_h8 *)&xs[(e / NCH) * PITCH + (e % NCH) * 8] = nx[it];
+    }
+    __syncthreads();
+    const int next = tile + step;
+    if (next < n_tiles) fetch(next);                             // in flight while this tile is multiplied
+    if (pend_tile >= 0) flush(pend_tile);                        // the previous tile's result leaves while this one is multiplied
+    c2_f16 acc[RPW];
+#pragma unroll
+    for (int o = 0; o < RPW; ++o) acc[o] = init;
+#pragma unroll
+    for (int ir = 0; ir < RPW + 2; ++ir) {                       // input row wave * RPW + ir of the staged image
+      const _Float16 *xrow = xs + ((wave * RPW + ir) * XW + r) * PITCH + 8 * h;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const c2_h8 b = *(const c2_h8 *)(xrow + kx * PITCH + 16 * kb);
+#pragma unroll
+          for (int o = 0; o < RPW; ++o) {
+            const int ky = ir - o;                               // output row o takes this input row at tap row ky
+            if (ky >= 0 && ky < 3) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kb], b, acc[o], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < RPW; ++o)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pend[o][g] = (c2_h4){(_Float16)acc[o][4 * g], (_Float16)acc[o][4 * g + 1], (_Float16)acc[o][4 * g + 2], (_Float16)acc[o][4 * g + 3]};
+    pend_tile = tile;
+  }
+  if (pend_tile >= 0) flush(pend_tile);
+}
+
+// packed[cob][tap][kb][lane] for the kernel above: rows m = 32 cob + (lane & 31) < M, reduction k = 16 kb + 8 (lane >> 5) + j < K,
+// zero beyond;  mode 0: (M, K) = (C_out, C_in), W[m][k][ky][kx];  mode 1: (M, K) = (C_in, C_out), W[k][m][2 - ky][2 - kx]
+__global__ __launch_bounds__(64) void conv3x3_pack_kernel(const _Float16 *__restrict__ w, int64_t s_co, int64_t s_ci, int64_t s_ky,
+                                                          int64_t s_kx, int mode, int M, int K, int KB, c2_h8 *__restrict__ packed) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int kb = blockIdx.x % KB, tap = (blockIdx.x / KB) % 9, cob = blockIdx.x / (9 * KB);
+  const int ky = tap / 3, kx = tap % 3, m = 32 * cob + r;
+  c2_h8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * kb + 8 * h + j;
+    v[j] = (m < M && k < K) ? (mode == 0 ? w[m * s_co + k * s_ci + ky * s_ky + kx * s_kx] : w[k * s_co + m * s_ci + (2 - ky) * s_ky + (2 - kx) * s_kx])
+                            : (_Float16)0;
+  }
+  packed[(size_t)blockIdx.x * 64 + lane] = v;
+}
+
+static int c2_kb_of(int k_channels) { return k_channels <= 32 ? 2 : k_channels <= 64 ? 4 : 6; }
+
+// bytes of the packed operand of a layer with k_channels reduction channels (the input of the call: C_in forward, C_out for the data
+// gradient) and m_channels result channels; 0 if the kernel does not take the layer
+extern "C" size_t ts_conv3x3_rows_packed_bytes(int32_t k_channels, int32_t m_channels) {
+  if (k_channels < 8 || k_channels > 96 || (k_channels & 7) || m_channels < 8 || (m_channels & 7)) return 0;
+  return (size_t)ts_cdiv(m_channels, 32) * 9 * c2_kb_of(k_channels) * 64 * 16;
+}
+
+// weight: the nn.Conv2d parameter [c_out][c_in][3][3] (IEEE half) with its element strides; mode 0 = forward operand, 1 = data
+// gradient operand; packed: ts_conv3x3_rows_packed_bytes(mode 0: c_in, c_out; mode 1: c_out, c_in) bytes
+extern "C" int ts_conv3x3_rows_pack(const void *weight, int32_t c_out, int32_t c_in, int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx,
+                                    int32_t mode, void *packed, ts_stream_t stream) {
+  TS_REQUIRE(weight && packed && (mode == 0 || mode == 1), TS_ERR_INVALID_ARGUMENT, "ts_conv3x3_rows_pack: bad arguments");
+  const int M = mode == 0 ? c_out : c_in, K = mode == 0 ? c_in : c_out;
+  TS_REQUIRE(ts_conv3x3_rows_packed_bytes(K, M) != 0, TS_ERR_UNSUPPORTED,
+             "ts_conv3x3_rows_pack: reduction channels a multiple of 8 up to 96, result channels a multiple of 8");
+  TS_REQUIRE((((uintptr_t)packed) & 15) == 0, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3_rows_pack: packed must be 16-byte aligned");
+  const int KB = c2_kb_of(K), n_cob = (int)ts_cdiv(M, 32);
+  conv3x3_pack_kernel<<<n_cob * 9 * KB, 64, 0, (hipStream_t)stream>>>((const _Float16 *)weight, s_co, s_ci, s_ky, s_kx, mode, M, K, KB,
+                                                                      (c2_h8 *)packed);
+  TS_CHECK_LAUNCH("ts_conv3x3_rows_pack");
+  return TS_OK;
+}
+
+template <int KB, int RPW>
+static int conv3x3_rows_launch(const _Float16 *x, int x_ch, const c2_h8 *packed, const float *bias, int T, int H, int W, _Float16 *y, int y_ch,
+                               hipStream_t stream) {
+  constexpr int TR = 4 * RPW;
+  constexpr size_t lds = (size_t)(TR + 2) * 34 * (16 * KB + 8) * sizeof(_Float16);
+  static_assert(lds <= 160 * 1024, "staged rows exceed the LDS of a CU");
+  static bool attr_set = false;
+  auto kern = conv3x3_rows_kernel<KB, RPW>;
+  if (lds > 64 * 1024 && !attr_set) {
+    TS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    attr_set = true;
+  }
+  const int tiles_x = (int)ts_cdiv(W, 32), tiles_y = (int)ts_cdiv(H, TR), n_cob = (int)ts_cdiv(y_ch, 32);
+  const int64_t n_tiles = (int64_t)T * tiles_x * tiles_y;
+  TS_REQUIRE(n_tiles < (1LL << 31) && (int64_t)T * H * W * std::max(x_ch, y_ch) < (1LL << 40), TS_ERR_UNSUPPORTED,
+             "ts_conv3x3_rows: stack too large");
+  // persistent workgroups (the packed weights are read once per wave, not once per tile), the blocks of a tile side by side
+  // (2048 workgroups: 1024 and 512 measured 5 - 25 % slower at the up4 shape, one or two output rows per wave the same)
+  const unsigned groups = (unsigned)ts_cdiv(std::min<int64_t>(n_tiles, std::max(8, 2048 / n_cob)), 8);
+  kern<<<groups * 8 * n_cob, 256, lds, stream>>>(x, x_ch, packed, bias, y, y_ch, H, W, tiles_x, tiles_y, (int)n_tiles, n_cob);
+  TS_CHECK_LAUNCH("ts_conv3x3_rows");
+  return TS_OK;
+}
+
+// y [T, H, W, y_channels] = conv3x3(x [T, H, W, x_channels], packed weights) (+ bias [y_channels] float, may be NULL); stride 1,
+// padding 1.  x and y channels-last IEEE half, 16-byte aligned, not overlapping; with a mode-1 pack and x = grad_y: grad_x.
+extern "C" int ts_conv3x3_rows(const void *x, int32_t x_channels, const void *packed, const float *bias, int32_t T, int32_t H, int32_t W,
+                               void *y, int32_t y_channels, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(T >= 0 && H > 0 && W > 0, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3_rows: bad sizes");
+  TS_REQUIRE(ts_conv3x3_rows_packed_bytes(x_channels, y_channels) != 0, TS_ERR_UNSUPPORTED,
+             "ts_conv3x3_rows: input channels a multiple of 8 up to 96, output channels a multiple of 8");
+  if (T == 0) return TS_OK;
+  TS_REQUIRE(x && packed && y && x != y, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3_rows: null / aliased pointer");
+  TS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)packed)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv3x3_rows: pointers must be 16-byte aligned");
+  const _Float16 *xp = (const _Float16 *)x;
+  _Float16 *yp = (_Float16 *)y;
+  const c2_h8 *pp = (const c2_h8 *)packed;
+  switch (c2_kb_of(x_channels)) {
+    case 2: return conv3x3_rows_launch<2, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
+    case 4: return conv3x3_rows_launch<4, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
+    default: return conv3x3_rows_launch<6, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
+  }
 }

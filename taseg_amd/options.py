@@ -30,7 +30,8 @@ class Options:
     eval_stage_depth: int = 2          # batches staged ahead in the evaluation loops
     image_layout: str = "nhwc"         # UNet2D's memory format and the image gather's form: "nhwc" (channels_last rows) | "nchw" (planes)
     image_fused_bn: bool = True        # UNet2D: LeakyReLU + training BatchNorm2d of a channels-last map as one node on csrc/bn.hip
-    image_conv_rows: bool = True       # UNet2D: the 3x3, 32 -> 32 channel layers of a channels-last half map on csrc/conv2d_rows.hip
+    image_conv_rows: bool = True       # UNet2D: the 3x3 layers with up to 96 input channels of a channels-last half map on csrc/conv2d_rows.hip
+    image_shuffle_cat: bool = True     # UNet2D: UpBlock's PixelShuffle + Dropout2d + concat + Dropout2d as one pass (csrc/shuffle_cat.hip)
     # ---- rehearsals of the N > 1 path on one card (tests, bench.py --force-dist)
     syncbn_single_rank: bool = False   # SyncBatchNorm takes the collective path in a one-rank group
     dist_buckets_on_default_group: bool = False

@@ -217,6 +217,53 @@ class _Conv3x3C32Rows(Function):
         return gx, gw, gb, None
 
 
+class _ShuffleCatRows(Function):
+    """UpBlock's entry - PixelShuffle(2), Dropout2d, concat with the skip map, Dropout2d - of two channels-last maps as one pass over
+    the result (csrc/shuffle_cat.hip); `scale` [T, C/4 + Cs] float32 holds the two dropout masks folded together, or None.  The
+    adjoint hands back two CONTIGUOUS gradients (ATen's concat backward leaves strided slices every consumer first copies)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, scale):
+        ctx.channels, ctx.scale = x.shape[1], scale
+        return B.shuffle_cat_rows_forward(x, skip, scale)
+
+    @staticmethod
+    def backward(ctx, grad_cat):
+        grad_cat = grad_cat.contiguous(memory_format=torch.channels_last)
+        gx, gs = B.shuffle_cat_rows_backward(grad_cat, ctx.channels, ctx.scale)
+        return gx, gs, None
+
+
+class _Conv3x3Rows(Function):
+    """Conv2d(C_in <= 96, C_out, 3, stride 1, padding 1) of a channels-last half map - the decoder's wide layers (UpBlock.conv1 of up3:
+    96 -> 96 at 1/2 scale, up4: 56 -> 96 at full scale) - forward and data gradient on csrc/conv2d_rows.hip's general kernel (MIOpen's
+    best solvers for the up4 shape: 4.4 and 1.5 ms, tools/unet2d_layers.py); the weight gradient stays the vendor library's."""
+
+    @staticmethod
+    def forward(ctx, x, weight16, bias):
+        y = B.conv3x3_rows(x, B.conv3x3_rows_pack(weight16, 0), None if bias is None else bias.float(), weight16.shape[0])
+        ctx.save_for_backward(x, weight16)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, w = ctx.saved_tensors
+        grad_y = grad_y.to(torch.float16).contiguous(memory_format=torch.channels_last)
+        gx = B.conv3x3_rows(grad_y, B.conv3x3_rows_pack(w, 1), None, w.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(grad_y, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])[1]
+        gb = None
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            gb = grad_y.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+        return gx, gw, gb
+
+
+# layers the general kernel is measured faster on (tools/conv2d_probe.py): at least this many pixels per call
+_CONV_ROWS_MIN_PIXELS = 192 * 640
+
+
 def _conv(conv, x):
     """the block's Conv2d.  The 3 x 3, 32 -> 32 channel layers (plain and dilated: the seven full-resolution layers of the stem and
     stage 1) of a channels-last half map - what autocast makes of them - go through the library's kernel; everything else is the
@@ -227,6 +274,13 @@ def _conv(conv, x):
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
             and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks)):
         return _Conv3x3C32Rows.apply(x, conv.weight.to(torch.float16), conv.bias, conv.dilation[0])
+    if (options.image_conv_rows and x.is_cuda and x.dim() == 4 and x.dtype == torch.float16 and type(conv) is nn.Conv2d
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.padding_mode == "zeros" and x.shape[2] * x.shape[3] >= _CONV_ROWS_MIN_PIXELS
+            and (conv.in_channels, conv.out_channels) != (32, 32) and B.conv3x3_rows_takes(conv.in_channels, conv.out_channels)
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks)):
+        return _Conv3x3Rows.apply(x, conv.weight.to(torch.float16), conv.bias)
     return conv(x)
 
 
@@ -295,14 +349,28 @@ class UpBlock(nn.Module):
         self.dropout3 = nn.Dropout2d(p=dropout_rate)
         self.shuffle = nn.PixelShuffle(2)       # parameter-free (the reference builds it inside forward)
 
+    def _masks(self, x, skip):
+        """the two Dropout2d masks of forward() as one float32 factor [T, C/4 + Cs] (same distribution: a Bernoulli draw per frame and
+        channel of `upA` and of the concatenation, kept values scaled by 1 / (1 - p)), or None when nothing is dropped"""
+        if not (self.drop_out and (self.dropout1.training or self.dropout2.training)):      # (the modules' own flags, as in their forward)
+            return None
+        t, cq, cs = x.shape[0], x.shape[1] // 4, skip.shape[1]
+        ones = torch.ones((t, cq + cs, 1, 1), dtype=torch.float32, device=x.device)
+        m1 = nn.functional.dropout2d(ones[:, :cq], self.dropout1.p, self.dropout1.training)
+        m2 = nn.functional.dropout2d(ones, self.dropout2.p, self.dropout2.training)
+        return (torch.cat((m1, ones[:, cq:]), dim=1) * m2).reshape(t, cq + cs)
+
     def forward(self, x, skip):
-        up = self.shuffle(x)
-        if self.drop_out:
-            up = self.dropout1(up)
-        cat = torch.cat((up, skip), dim=1)
-        if self.drop_out:
-            cat = self.dropout2(cat)
-        out = _act_bn(self.act1, self.bn1, self.conv1(cat))
+        if options.image_shuffle_cat and B.shuffle_cat_rows_takes(x, skip):
+            cat = _ShuffleCatRows.apply(x, skip, self._masks(x, skip))
+        else:
+            up = self.shuffle(x)
+            if self.drop_out:
+                up = self.dropout1(up)
+            cat = torch.cat((up, skip), dim=1)
+            if self.drop_out:
+                cat = self.dropout2(cat)
+        out = _act_bn(self.act1, self.bn1, _conv(self.conv1, cat))
         return self.dropout3(out) if self.drop_out else out
 
 

@@ -230,6 +230,104 @@ def test_conv3x3_c32_rows_equals_the_module(shape, dilation):
     assert torch.equal(_conv(other, x.detach()), other(x.detach()))
 
 
+@pytest.mark.parametrize("shape,c_out", [((2, 56, 19, 45), 96), ((2, 96, 21, 37), 96), ((1, 32, 9, 33), 64), ((2, 64, 10, 70), 40),
+                                         ((1, 8, 8, 32), 8), ((3, 96, 64, 96), 56)])
+def test_conv3x3_rows_general_channels_equals_the_module(shape, c_out, monkeypatch):
+    """the decoder's wide 3 x 3 layers (UpBlock.conv1: 56 -> 96, 96 -> 96; csrc/conv2d_rows.hip's general kernel behind unet2d._conv)
+    against nn.Conv2d evaluated in float64 on the same half inputs: output and input gradient (ours), weight / bias gradients (the
+    vendor library's weight gradient behind the same node); channel counts that are no multiple of 16 / 32, ragged image sizes"""
+    from taseg_amd import backend as B
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet import unet2d
+    monkeypatch.setattr(unet2d, "_CONV_ROWS_MIN_PIXELS", 1)
+    g = torch.Generator().manual_seed(17)
+    c_in = shape[1]
+    conv = torch.nn.Conv2d(c_in, c_out, 3, padding=1).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(*shape, generator=g).cuda().half().contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = torch.randn(shape[0], c_out, *shape[2:], generator=g).cuda()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = unet2d._conv(conv, x)
+    assert y.dtype == torch.float16 and y.grad_fn.__class__.__name__.startswith("_Conv3x3Rows") and y.is_contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias), retain_graph=True)
+    gx2, _, _ = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
+    assert torch.equal(gx, gx2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
+    ref = torch.nn.Conv2d(c_in, c_out, 3, padding=1).cuda().double()
+    with torch.no_grad():
+        ref.weight.copy_(conv.weight.half().double())
+        ref.bias.copy_(conv.bias.double())
+    xd = x.detach().double().requires_grad_()
+    want = ref(xd)
+    wx, ww, wb = torch.autograd.grad((want * wt.double()).sum(), (xd, ref.weight, ref.bias))
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm().clamp_min(1e-30))      # noqa: E731
+    assert float((y.double() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))      # one rounding to half
+    assert rel(gx, wx) <= 2e-3 and rel(gw, ww) <= 5e-3 and rel(gb, wb) <= 5e-3, (rel(gx, wx), rel(gw, ww), rel(gb, wb))
+    # channel counts the kernel does not take: the module itself
+    odd = torch.nn.Conv2d(c_in, 20, 3, padding=1).cuda().half().to(memory_format=torch.channels_last)
+    assert unet2d._conv(odd, x.detach()).shape[1] == 20 and not B.conv3x3_rows_takes(c_in, 20) and not B.conv3x3_rows_takes(128, 96)
+    with pytest.raises(ValueError):
+        B.conv3x3_rows(x.detach(), torch.empty(16, dtype=torch.uint8, device="cuda"), None, c_out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape,cs", [((2, 96, 12, 20), 32), ((1, 128, 5, 7), 64), ((3, 256, 3, 4), 128), ((2, 32, 9, 33), 8)])
+def test_shuffle_cat_rows_equals_pixel_shuffle_and_cat(shape, cs, dtype):
+    """UpBlock's entry as one pass (csrc/shuffle_cat.hip behind unet2d._ShuffleCatRows) against nn.PixelShuffle + torch.cat on the same
+    channels-last maps: bit-equal without dropout factors (it is a permutation), one rounding apart with them; the adjoint against
+    autograd of the ATen ops; contiguous gradients"""
+    from taseg_amd import backend as B
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import _ShuffleCatRows
+    g = torch.Generator().manual_seed(23)
+    t, c, h, w = shape
+    x = torch.randn(*shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    skip = torch.randn(t, cs, 2 * h, 2 * w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = torch.randn(t, c // 4 + cs, 2 * h, 2 * w, generator=g).cuda().to(dtype)
+    assert B.shuffle_cat_rows_takes(x, skip)
+    want = torch.cat((torch.nn.functional.pixel_shuffle(x, 2), skip), dim=1)
+    got = _ShuffleCatRows.apply(x, skip, None)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    gx, gs = torch.autograd.grad(got, (x, skip), wt)
+    wx, ws = torch.autograd.grad(want, (x, skip), wt)
+    assert torch.equal(gx, wx) and torch.equal(gs, ws)
+    assert gx.is_contiguous(memory_format=torch.channels_last) and gs.is_contiguous(memory_format=torch.channels_last)
+    # with the dropout factors: (x * m1) * m2 in ATen, x * (m1 m2) here
+    m = torch.tensor([0.0, 1.25, 1.5625], device="cuda")[torch.randint(0, 3, (t, c // 4 + cs), generator=g).cuda()]
+    want = want * m[:, :, None, None].to(dtype)
+    got = _ShuffleCatRows.apply(x, skip, m)
+    tol = 2e-3 if dtype == torch.float16 else 1e-6
+    assert torch.allclose(got.float(), want.float(), rtol=tol, atol=0) and bool(((got == 0) == (want == 0)).all())
+    gx, gs = torch.autograd.grad(got, (x, skip), wt)
+    wx, ws = torch.autograd.grad(want, (x, skip), wt)
+    assert torch.allclose(gx.float(), wx.float(), rtol=tol, atol=0) and torch.allclose(gs.float(), ws.float(), rtol=tol, atol=0)
+    # pairs the kernel does not take
+    assert not B.shuffle_cat_rows_takes(x, skip.float() if dtype == torch.float16 else skip.half())
+    assert not B.shuffle_cat_rows_takes(x.detach().contiguous(), skip)
+    with pytest.raises(ValueError):
+        B.shuffle_cat_rows_forward(x.detach(), skip.detach()[:, :, :-1])
+
+
+def test_up_block_fused_entry_equals_the_modules_and_draws_dropout_masks():
+    """UpBlock with the fused entry against the module sequence of the reference (unet2d.py:98-115): equal in eval mode; in training the
+    folded mask takes the values {0, 1/(1-p), 1/(1-p)^2} (skip channels {0, 1/(1-p)}) at the modules' rates"""
+    from taseg_amd.options import options
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import UpBlock
+    torch.manual_seed(5)
+    blk = UpBlock(128, 96, 0.2, mid_filters=128 // 4 + 64).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(3, 128, 10, 14, device="cuda").contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(3, 64, 20, 28, device="cuda").contiguous(memory_format=torch.channels_last)
+    blk.eval()
+    with torch.no_grad():
+        got = blk(x, skip)
+        with options.override(image_shuffle_cat=False):
+            want = blk(x, skip)
+    assert torch.equal(got, want)
+    blk.train()
+    m = torch.cat([blk._masks(x.expand(3, -1, -1, -1), skip) for _ in range(200)])          # 600 frames x 96 channels
+    up, sk = m[:, :32], m[:, 32:]
+    assert set(up.unique().tolist()) <= {0.0, 1.25, 1.5625} and set(sk.unique().tolist()) <= {0.0, 1.25}
+    assert abs(float((up == 1.5625).float().mean()) - 0.64) < 0.02 and abs(float((sk == 1.25).float().mean()) - 0.8) < 0.02
+    y = blk(x, skip)
+    assert y.grad_fn is not None and torch.isfinite(y).all()
+
+
 def _tiaf_batch(g):
     from taseg_amd.torchsparse import SparseTensor
     dev = "cuda"

@@ -27,6 +27,8 @@ def timed(fn, n=10):
 
 def main():
     torch.manual_seed(0)
+    if "general" in sys.argv[1:]:
+        return general()
     for shape, dil in (((2, 32, 19, 45), 1), ((2, 32, 19, 45), 2), ((10, 32, 384, 1280), 1), ((10, 32, 384, 1280), 2)):
         conv = torch.nn.Conv2d(32, 32, 3, padding=dil, dilation=dil).cuda().half().to(memory_format=torch.channels_last)
         x = torch.randn(*shape, device="cuda").half().contiguous(memory_format=torch.channels_last).requires_grad_()
@@ -62,6 +64,34 @@ def main():
             rec["torch_wgrad_us"] = timed(lambda: torch.ops.aten.convolution_backward(gy, xd, conv.weight, None, [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [False, True, False]))
             byts = 2 * xd.numel() * 2
             rec["ours_fwd_hbm_frac"] = byts / rec["ours_fwd_us"] / 1e3 / 8000.0
+        print(json.dumps(rec), flush=True)
+    general()
+
+
+def general():
+    """the general kernel (C_in <= 96) at the decoder's shapes: time against the vendor library, values against it"""
+    import bench
+    bench.miopen_find_db()
+    for name, (t, ci, h, w), co in (("up4.conv1", (10, 56, 384, 1280), 96), ("up3.conv1", (10, 96, 192, 640), 96),
+                                    ("stage2.conv2", (10, 32, 192, 640), 64)):
+        conv = torch.nn.Conv2d(ci, co, 3, padding=1).cuda().half().to(memory_format=torch.channels_last)
+        x = torch.randn(t, ci, h, w, device="cuda").half().contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(t, co, h, w, device="cuda").half().contiguous(memory_format=torch.channels_last)
+        wd, bd = conv.weight.detach(), conv.bias.detach()
+        p0, p1 = B.conv3x3_rows_pack(wd, 0), B.conv3x3_rows_pack(wd, 1)
+        args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+        want = conv(x)
+        got = B.conv3x3_rows(x, p0, bd.float(), co)
+        gx_want = torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [True, False, False])[0]
+        gx = B.conv3x3_rows(gy, p1, None, ci)
+        rec = {"layer": name, "shape": [t, ci, h, w], "c_out": co,
+               "fwd_max_abs_diff_vs_torch": float((got.float() - want.float()).abs().max()), "fwd_scale": float(want.float().abs().max()),
+               "dgrad_max_abs_diff_vs_torch": float((gx.float() - gx_want.float()).abs().max()), "dgrad_scale": float(gx_want.float().abs().max()),
+               "ours_fwd_us": timed(lambda: B.conv3x3_rows(x, p0, bd.float(), co)), "torch_fwd_us": timed(lambda: conv(x)),
+               "ours_dgrad_us": timed(lambda: B.conv3x3_rows(gy, p1, None, ci)),
+               "torch_dgrad_us": timed(lambda: torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [True, False, False])),
+               "torch_wgrad_us": timed(lambda: torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [False, True, False]))}
+        rec["ours_fwd_hbm_frac"] = 2 * (x.numel() + gy.numel()) / rec["ours_fwd_us"] / 1e3 / 8000.0
         print(json.dumps(rec), flush=True)
 
 
