@@ -457,10 +457,12 @@ int ts_conv3x3c32_rows(const void *x, const void *packed, const float *bias, int
 /*   ts_conv3x3c32_wgrad  grad_weight [co][ci][ky][kx] (half, the element strides of the weight it belongs to) = sum over pixels of
  *                        x[t, y + (ky - 1) D, x + (kx - 1) D, ci] grad_y[t, y, x, co]: partial [9][32][32] sums per workgroup (fp32, LDS
  *                        transposing reads feed the MFMAs), then their sum in index order - no atomics, run-to-run identical.
+ *                        grad_bias [32] (float, may be NULL): the column sums of grad_y, in the same pass.
  *                        ws >= ts_conv3x3c32_wgrad_workspace_bytes(). */
 size_t ts_conv3x3c32_wgrad_workspace_bytes(void);
 int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t dilation, void *grad_weight,
-                        int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, void *ws, size_t ws_bytes, ts_stream_t stream);
+                        int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, float *grad_bias, void *ws, size_t ws_bytes,
+                        ts_stream_t stream);
 
 /* The same convolution (stride 1, padding 1, no dilation) with the channel counts opened up - UpBlock.conv1 of the decoder
  * (unet2d.py:81-115: 96 -> 96 channels at 1/2 scale, 56 -> 96 at full scale): input channels a multiple of 8 up to 96, output
@@ -475,6 +477,14 @@ int ts_conv3x3_rows_pack(const void *weight, int32_t c_out, int32_t c_in, int64_
                          int32_t mode, void *packed, ts_stream_t stream);
 int ts_conv3x3_rows(const void *x, int32_t x_channels, const void *packed, const float *bias, int32_t T, int32_t H, int32_t W, void *y,
                     int32_t y_channels, ts_stream_t stream);
+/*   ts_conv3x3_wgrad                    grad_weight [c_out][c_in][3][3] (half, the weight's element strides) and grad_bias [c_out]
+ *                                       (float, may be NULL) of the same layers (channel counts multiples of 8 up to 96) from x and
+ *                                       grad_y: the 9 x c_in x c_out fp32 sums in the registers of persistent workgroups (96 x 96 in two
+ *                                       passes over the input channels), partials added in a fixed order - run-to-run identical.
+ *                                       ws >= ts_conv3x3_wgrad_workspace_bytes(c_in, c_out) (0: layer not taken). */
+size_t ts_conv3x3_wgrad_workspace_bytes(int32_t c_in, int32_t c_out);
+int ts_conv3x3_wgrad(const void *x, int32_t c_in, const void *grad_y, int32_t c_out, int32_t T, int32_t H, int32_t W, void *grad_weight,
+                     int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
 
 /* UpBlock's entry on channels-last rows (unet2d.py:98-108: PixelShuffle(2), Dropout2d, torch.cat((upA, skip), dim=1), Dropout2d) in one
  * pass:  cat [T, 2h, 2w, C/4 + Cs] = concat(PixelShuffle(2)(x [T, h, w, C]), skip [T, 2h, 2w, Cs]) * scale [T, C/4 + Cs]

@@ -20,7 +20,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad", "conv3x3_rows_takes", "conv3x3_rows_pack", "conv3x3_rows", "shuffle_cat_rows_takes", "shuffle_cat_rows_forward", "shuffle_cat_rows_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad", "conv3x3_rows_takes", "conv3x3_rows_pack", "conv3x3_rows", "conv3x3_wgrad", "shuffle_cat_rows_takes", "shuffle_cat_rows_forward", "shuffle_cat_rows_backward",
 ]
 
 
@@ -948,7 +948,8 @@ def shuffle_cat_rows_backward(grad_cat, channels, scale=None):
 def conv3x3_rows_takes(c_in, c_out):
     """whether csrc/conv2d_rows.hip's general kernel takes a Conv2d(c_in, c_out, 3, padding 1) forward AND backward"""
     lib = L.load()
-    return bool(lib.ts_conv3x3_rows_packed_bytes(int(c_in), int(c_out))) and bool(lib.ts_conv3x3_rows_packed_bytes(int(c_out), int(c_in)))
+    return (bool(lib.ts_conv3x3_rows_packed_bytes(int(c_in), int(c_out))) and bool(lib.ts_conv3x3_rows_packed_bytes(int(c_out), int(c_in)))
+            and bool(lib.ts_conv3x3_wgrad_workspace_bytes(int(c_in), int(c_out))))
 
 
 def conv3x3_rows_pack(weight, mode):
@@ -987,21 +988,45 @@ def conv3x3_rows(x, packed, bias, out_channels):
     return y
 
 
-def conv3x3c32_wgrad(x, grad_y, like_weight, dilation):
+def conv3x3_wgrad(x, grad_y, like_weight, want_bias=True):
+    """(grad_weight, grad_bias) of Conv2d(C_in, C_out, 3, stride 1, padding 1) from the channels-last float16 input x [T, C_in, H, W]
+    and output gradient grad_y [T, C_out, H, W]: a float16 tensor with like_weight's shape and strides and a float32 [C_out] (None
+    unless want_bias) - csrc/conv2d_rows.hip, deterministic"""
+    L.require_device(x, grad_y)
+    x, grad_y = _channels_last_rows(x, "conv3x3_wgrad(x)"), _channels_last_rows(grad_y, "conv3x3_wgrad(grad_y)")
+    t, ci, h, w = x.shape
+    co = grad_y.shape[1]
+    lib = L.load()
+    need = lib.ts_conv3x3_wgrad_workspace_bytes(ci, co)
+    if (x.dtype != torch.float16 or grad_y.dtype != torch.float16 or tuple(grad_y.shape) != (t, co, h, w) or need == 0
+            or tuple(like_weight.shape) != (co, ci, 3, 3)):
+        raise ValueError(f"conv3x3_wgrad: float16 stacks {tuple(x.shape)} / {tuple(grad_y.shape)} and a weight like {tuple(like_weight.shape)}")
+    gw = torch.empty_like(like_weight, dtype=torch.float16)          # (same strides as the weight)
+    gb = torch.empty(co, dtype=torch.float32, device=x.device) if want_bias else None
+    s = gw.stride()
+    ws = L.workspace(need, x.device)
+    L.check(lib.ts_conv3x3_wgrad(L.ptr(x), ci, L.ptr(grad_y), co, t, h, w, L.ptr(gw), s[0], s[1], s[2], s[3], L.ptr(gb), L.ptr(ws), ws.numel(),
+                                 L.stream()), "ts_conv3x3_wgrad")
+    return gw, gb
+
+
+def conv3x3c32_wgrad(x, grad_y, like_weight, dilation, want_bias=False):
     """weight gradient of Conv2d(32, 32, 3, stride 1, padding = dilation) from the channels-last float16 input x and output gradient
-    grad_y [T, 32, H, W]: a float16 tensor with like_weight's shape and strides (csrc/conv2d_rows.hip, deterministic)"""
+    grad_y [T, 32, H, W]: a float16 tensor with like_weight's shape and strides (csrc/conv2d_rows.hip, deterministic); with want_bias
+    the pair (grad_weight, grad_bias float32 [32]) - the column sums of grad_y come out of the same pass"""
     L.require_device(x, grad_y)
     x, grad_y = _channels_last_rows(x, "conv3x3c32_wgrad(x)"), _channels_last_rows(grad_y, "conv3x3c32_wgrad(grad_y)")
     if x.shape != grad_y.shape or x.shape[1] != 32 or x.dtype != torch.float16 or grad_y.dtype != torch.float16:
         raise ValueError("conv3x3c32_wgrad: two float16 [T, 32, H, W] stacks of one shape")
     t, _, h, w = x.shape
     gw = torch.empty_like(like_weight, dtype=torch.float16)          # (same strides as the weight)
+    gb = torch.empty(32, dtype=torch.float32, device=x.device) if want_bias else None
     s = gw.stride()
     lib = L.load()
     ws = L.workspace(lib.ts_conv3x3c32_wgrad_workspace_bytes(), x.device)
-    L.check(lib.ts_conv3x3c32_wgrad(L.ptr(x), L.ptr(grad_y), t, h, w, int(dilation), L.ptr(gw), s[0], s[1], s[2], s[3], L.ptr(ws), ws.numel(),
-                                    L.stream()), "ts_conv3x3c32_wgrad")
-    return gw
+    L.check(lib.ts_conv3x3c32_wgrad(L.ptr(x), L.ptr(grad_y), t, h, w, int(dilation), L.ptr(gw), s[0], s[1], s[2], s[3], L.ptr(gb), L.ptr(ws),
+                                    ws.numel(), L.stream()), "ts_conv3x3c32_wgrad")
+    return (gw, gb) if want_bias else gw
 
 
 def set_conv_impl(impl):

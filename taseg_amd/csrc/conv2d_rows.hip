@@ -172,7 +172,8 @@ typedef float c2_f4 __attribute__((ext_vector_type(4)));
 
 template <int DIL>
 __global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *__restrict__ X, const _Float16 *__restrict__ DY, int H,
-                                                               int W, int tiles_x, int tiles_y, int n_tiles, float *__restrict__ part) {
+                                                               int W, int tiles_x, int tiles_y, int n_tiles, float *__restrict__ part,
+                                                               float *__restrict__ bias_part) {
   constexpr int XR = 4 + 2 * DIL, XW = 32 + 2 * DIL;
   constexpr int XS_HALFS = XR * XW * CW_PITCH, YS_HALFS = 4 * 32 * CW_PITCH;
   __shared__ __attribute__((aligned(16))) _Float16 smem[XS_HALFS + YS_HALFS];
@@ -197,6 +198,9 @@ __global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *_
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[t9][a][b] = (c2_f4){0.f, 0.f, 0.f, 0.f};
+  // the bias gradient (column sums of dY) rides along: one more product per co block, against a fragment of ones
+  const c2_h8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+  c2_f4 bacc[2] = {(c2_f4){0.f, 0.f, 0.f, 0.f}, (c2_f4){0.f, 0.f, 0.f, 0.f}};
 
   constexpr int N_X = XR * XW * 4, X_IT = (N_X + 255) / 256;
   c2_h8 nx[X_IT], ny[2];
@@ -239,6 +243,8 @@ __global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *_
     // (no lane-dependent control flow from here to the end of the tile: the transposing reads need every lane)
     const _Float16 *yrow = ys + wave * 32 * CW_PITCH;
     const c2_h8 b0 = frag(yrow, 8 * kg, 0), b1 = frag(yrow, 8 * kg, 16);
+    bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, b0, bacc[0], 0, 0, 0);
+    bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, b1, bacc[1], 0, 0, 0);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const _Float16 *xrow = xs + (wave + ky * DIL) * XW * CW_PITCH;
@@ -272,43 +278,60 @@ __global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *_
       part[((size_t)blockIdx.x * 9 + t9) * 1024 + e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
     __syncthreads();
   }
+  if (kg == 0) {                                           // (every row of the ones product holds the column sums: row 0)
+    red[wave * 32 + r16] = bacc[0][0];
+    red[wave * 32 + 16 + r16] = bacc[1][0];
+  }
+  __syncthreads();
+  if (tid < 32) bias_part[(size_t)blockIdx.x * 32 + tid] = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
 }
 
 // dW[co][ci][ky][kx] (element strides given, IEEE half) = sum over the workgroups' partials [n_part][9][ci][co] in index order.
 // A workgroup owns 64 consecutive elements; its four waves each add a quarter of the partials (8 loads in flight per lane) and the
 // four sums meet in LDS in wave order - a fixed order, run-to-run identical.  (The first form, one thread per element walking all
 // 512 partials, took 0.12 ms per layer: as long as half the weight gradient itself.)
-__global__ __launch_bounds__(256) void conv3x3c32_wgrad_reduce_kernel(const float *__restrict__ part, int n_part, _Float16 *__restrict__ dw,
-                                                                      int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx) {
+__global__ __launch_bounds__(256) void conv3x3c32_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias_part,
+                                                                      int n_part, _Float16 *__restrict__ dw, int64_t s_co, int64_t s_ci,
+                                                                      int64_t s_ky, int64_t s_kx, float *__restrict__ db) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;                    // (tap, ci, co); 9 * 1024 = 144 * 64
+  const int e = blockIdx.x * 64 + lane;                    // (tap, ci, co): 9 * 1024 = 144 * 64 elements, then the 32 of the bias
+  const bool is_w = e < 9 * 1024, live = e < 9 * 1024 + 32;
+  const float *src = is_w ? part + e : bias_part + (e - 9 * 1024);
+  const size_t pitch = is_w ? (size_t)9 * 1024 : (size_t)32;
   const int per = (n_part + 3) / 4, p0 = q * per, p1 = min(n_part, p0 + per);
   float s = 0.f;
-  int p = p0;
-  for (; p + 8 <= p1; p += 8) {
-    float v[8];
+  if (live) {
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+      float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(p + j) * 9 * 1024 + e];
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(p + j) * pitch];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; p < p1; ++p) s += src[(size_t)p * pitch];
   }
-  for (; p < p1; ++p) s += part[(size_t)p * 9 * 1024 + e];
   red[q][lane] = s;
   __syncthreads();
-  if (q != 0) return;
+  if (q != 0 || !live) return;
   s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-  const int t9 = e >> 10, ci = (e >> 5) & 31, co = e & 31;
-  dw[co * s_co + ci * s_ci + (t9 / 3) * s_ky + (t9 % 3) * s_kx] = (_Float16)s;
+  if (is_w) {
+    const int t9 = e >> 10, ci = (e >> 5) & 31, co = e & 31;
+    dw[co * s_co + ci * s_ci + (t9 / 3) * s_ky + (t9 % 3) * s_kx] = (_Float16)s;
+  } else if (db) {
+    db[e - 9 * 1024] = s;
+  }
 }
 
 #define C2_WGRAD_WGS 512
-extern "C" size_t ts_conv3x3c32_wgrad_workspace_bytes(void) { return (size_t)C2_WGRAD_WGS * 9 * 1024 * sizeof(float); }
+extern "C" size_t ts_conv3x3c32_wgrad_workspace_bytes(void) { return (size_t)C2_WGRAD_WGS * (9 * 1024 + 32) * sizeof(float); }
 
-// grad_weight [32 co][32 ci][3][3] (IEEE half, element strides given: the layout of the weight it belongs to) from x and grad_y
-// [T, H, W, 32] channels-last half; ws >= ts_conv3x3c32_wgrad_workspace_bytes()
+// grad_weight [32 co][32 ci][3][3] (IEEE half, element strides given: the layout of the weight it belongs to) and grad_bias [32]
+// (float, may be NULL) from x and grad_y [T, H, W, 32] channels-last half; ws >= ts_conv3x3c32_wgrad_workspace_bytes()
 extern "C" int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T, int32_t H, int32_t W, int32_t dilation, void *grad_weight,
-                                   int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, void *ws, size_t ws_bytes, ts_stream_t stream_) {
+                                   int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, float *grad_bias, void *ws, size_t ws_bytes,
+                                   ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(T > 0 && H > 0 && W > 0 && (dilation == 1 || dilation == 2), TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_wgrad: bad sizes");
   TS_REQUIRE(x && grad_y && grad_weight && ws && ws_bytes >= ts_conv3x3c32_wgrad_workspace_bytes(), TS_ERR_INVALID_ARGUMENT,
@@ -319,13 +342,14 @@ extern "C" int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T,
   const int64_t n_tiles = (int64_t)T * tiles_x * tiles_y;
   TS_REQUIRE(n_tiles < (1LL << 31), TS_ERR_UNSUPPORTED, "ts_conv3x3c32_wgrad: stack too large");
   const int grid = (int)std::min<int64_t>(n_tiles, C2_WGRAD_WGS);
+  float *part = (float *)ws, *bias_part = part + (size_t)C2_WGRAD_WGS * 9 * 1024;
   if (dilation == 1)
     conv3x3c32_wgrad_kernel<1><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
-                                                         (float *)ws);
+                                                         part, bias_part);
   else
     conv3x3c32_wgrad_kernel<2><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
-                                                         (float *)ws);
-  conv3x3c32_wgrad_reduce_kernel<<<144, 256, 0, stream>>>((const float *)ws, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx);
+                                                         part, bias_part);
+  conv3x3c32_wgrad_reduce_kernel<<<145, 256, 0, stream>>>(part, bias_part, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx, grad_bias);
   TS_CHECK_LAUNCH("ts_conv3x3c32_wgrad");
   return TS_OK;
 }
@@ -533,4 +557,228 @@ extern "C" int ts_conv3x3_rows(const void *x, int32_t x_channels, const void *pa
     case 4: return conv3x3_rows_launch<4, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
     default: return conv3x3_rows_launch<6, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight (and bias) gradient of the general layers:  dW[co, ci, ky, kx] = sum_{t, y, x} X[t, y + ky - 1, x + kx - 1, ci] dY[t, y, x, co],
+// db[co] = sum dY[t, y, x, co].  MIOpen's best solver: 2.4 ms at the up4 shape (56 -> 96 channels, full scale), 1.2 ms at up3's; ATen's
+// bias sum over the 96-channel map another 0.2 - 0.4 ms.  The 9 x C_in x C_out fp32 sums (83 k for 96 x 96) stay in REGISTERS for the
+// whole run of a persistent workgroup: its four waves split the (ci, co) plane 2 x 2, wave (a, b) owning NI x NO blocks of 16 x 16
+// (v_mfma_f32_16x16x32_f16, K = 32 pixels of a row: 36 NI NO accumulator registers, 324 for 96 x 96), and every wave walks all TR
+// rows of the staged tile.  Operands as in the 32-channel kernel: [pixel][channel] images of the tile's rows in LDS, fragments through
+// the transposing read.  The bias sums ride along as one more product against a fragment of ones.  Per workgroup one partial
+// [9][CIP][COP] (+ [COP]); a second launch adds the partials in a fixed order.
+template <int NI, int NO, int TR>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const _Float16 *__restrict__ X, int x_ch, int x_off, int x_chunks,
+                                                            const _Float16 *__restrict__ DY, int y_ch, int H, int W, int tiles_x, int tiles_y,
+                                                            int n_tiles, float *__restrict__ part, float *__restrict__ bias_part) {
+  constexpr int CIP = 32 * NI, COP = 32 * NO, PI = CIP + 8, PO = COP + 8, XR = TR + 2, XW = 34;
+  constexpr int XS_HALFS = XR * XW * PI;
+  constexpr int NCI = CIP / 8, NCO = COP / 8, N_X = XR * XW * NCI, N_Y = TR * 32 * NCO, X_IT = (N_X + 255) / 256, Y_IT = (N_Y + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) _Float16 wg_dyn[];
+  _Float16 *xs = wg_dyn, *ys = wg_dyn + XS_HALFS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wa = wave >> 1, wb = wave & 1;
+  const int r16 = lane & 15, kg = lane >> 4, tq = r16 >> 2, tp = lane & 3;
+  const int y_chunks = y_ch >> 3;                              // (x: channels x_off .. x_off + 8 x_chunks - 1 of the x_ch in a row)
+  const c2_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  const c2_h8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+  // transposed fragment: pixels r0 .. r0 + 7 (rows of the image, `pitch` halfs apart) of channel c0 + r16
+  auto frag = [&](const _Float16 *img, int pitch, int r0, int c0) -> c2_h8 {
+    typedef c2_hv4 __attribute__((address_space(3))) * lds_hv4;
+    const c2_hv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + tq) * pitch + c0 + 4 * tp));
+    const c2_hv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hv4)(img + (r0 + 4 + tq) * pitch + c0 + 4 * tp));
+    c2_h8 v;
+    v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+    v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+    return v;
+  };
+  c2_f4 acc[9][NI][NO], bacc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    bacc[o] = (c2_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[t9][i][o] = (c2_f4){0.f, 0.f, 0.f, 0.f};
+  }
+  c2_h8 nx[X_IT], ny[Y_IT];
+  auto fetch = [&](int tile) {                                   // the tile's rows -> registers (zeros outside the image / beyond the channels)
+    const int xsi = tile % tiles_x, rest = tile / tiles_x;
+    const int y0 = (rest % tiles_y) * TR, x0 = xsi * 32;
+    const _Float16 *ximg = X + (size_t)(rest / tiles_y) * H * W * x_ch + x_off, *yimg = DY + (size_t)(rest / tiles_y) * H * W * y_ch;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {                          // input rows y0 - 1 .. y0 + TR, pixels x0 - 1 .. x0 + 32
+      const int e = tid + it * 256;
+      const int ch = e % NCI, px = (e / NCI) % XW, row = (e / NCI) / XW;
+      const int yy = y0 - 1 + row, xx = x0 - 1 + px;
+      nx[it] = (e < N_X && ch < x_chunks && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                   ? *(const c2_h8 *)(ximg + ((size_t)yy * W + xx) * x_ch + 8 * ch) : zero;
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {                          // output rows y0 .. y0 + TR - 1, pixels x0 .. x0 + 31
+      const int e = tid + it * 256;
+      const int ch = e % NCO, px = (e / NCO) & 31, row = (e / NCO) >> 5;
+      const int yy = y0 + row, xx = x0 + px;
+      ny[it] = (e < N_Y && ch < y_chunks && yy < H && xx < W) ? *(const c2_h8 *)(yimg + ((size_t)yy * W + xx) * y_ch + 8 * ch) : zero;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();                                             // (the previous tile's fragments have been read)
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int e = tid + it * 256;
+      if (e < N_X) *(c2_h8 *)&xs[(e / NCI) * PI + (e % NCI) * 8] = nx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int e = tid + it * 256;
+      if (e < N_Y) *(c2_h8 *)&ys[(e / NCO) * PO + (e % NCO) * 8] = ny[it];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) fetch(next);                             // in flight while this tile is multiplied
+    // (no lane-dependent control flow from here to the end of the tile: the transposing reads need every lane)
+#pragma unroll
+    for (int row = 0; row < TR; ++row) {
+      const _Float16 *yrow = ys + row * 32 * PO;
+      c2_h8 b[NO];
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        b[o] = frag(yrow, PO, 8 * kg, (wb * NO + o) * 16);
+        bacc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, b[o], bacc[o], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const _Float16 *xrow = xs + (row + ky) * XW * PI;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const c2_h8 a = frag(xrow, PI, 8 * kg + kx, (wa * NI + i) * 16);
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+              acc[ky * 3 + kx][i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[o], acc[ky * 3 + kx][i][o], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // accumulator register q of block (i, o): ci = 16 (wa NI + i) + 4 kg + q, co = 16 (wb NO + o) + r16
+  float *mine = part + (size_t)blockIdx.x * 9 * CIP * COP;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mine[((size_t)t9 * CIP + 16 * (wa * NI + i) + 4 * kg + q) * COP + 16 * (wb * NO + o) + r16] = acc[t9][i][o][q];
+  if (wa == 0 && kg == 0)                                        // (every row of the ones product holds the column sums: row 0)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bias_part[(size_t)blockIdx.x * COP + 16 * (wb * NO + o) + r16] = bacc[o][0];
+}
+
+// dW[co][ci][ky][kx] (element strides given, IEEE half) and db[co] (float) = sums over the workgroups' partials in index order;
+// elements [0, 9 CIP COP): (tap, ci, co) of the weight, [9 CIP COP, 9 CIP COP + COP): the bias
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias_part, int n_part,
+                                                                   int CIP, int COP, int ci_off, int c_in, int c_out, _Float16 *__restrict__ dw, int64_t s_co,
+                                                                   int64_t s_ci, int64_t s_ky, int64_t s_kx, float *__restrict__ db) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int n_w = 9 * CIP * COP, e = blockIdx.x * 64 + lane;
+  const bool is_w = e < n_w, live = e < n_w + COP;
+  const float *src = is_w ? part + e : bias_part + (e - n_w);
+  const size_t pitch = is_w ? (size_t)n_w : (size_t)COP;
+  const int per = (n_part + 3) / 4, p0 = q * per, p1 = min(n_part, p0 + per);
+  float s = 0.f;
+  if (live) {
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(p + j) * pitch];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; p < p1; ++p) s += src[(size_t)p * pitch];
+  }
+  red[q][lane] = s;
+  __syncthreads();
+  if (q != 0 || !live) return;
+  s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (is_w) {
+    const int t9 = e / (CIP * COP), ci = (e / COP) % CIP, co = e % COP;
+    if (ci_off + ci < c_in && co < c_out) dw[co * s_co + (ci_off + ci) * s_ci + (t9 / 3) * s_ky + (t9 % 3) * s_kx] = (_Float16)s;
+  } else if (db && e - n_w < c_out) {
+    db[e - n_w] = s;
+  }
+}
+
+#define C2G_WGRAD_WGS 512
+static int c2_pad32(int c) { return (c + 31) / 32 * 32; }
+// input channels per pass: with 96 output channels 64 (216 accumulator registers per wave; 96 x 96 in one pass does not fit the
+// register file - the compiler spills 487 of them), else all
+static int c2g_pass_ci(int c_in, int c_out) { return (c2_pad32(c_in) / 32) * (c2_pad32(c_out) / 32) > 6 ? 64 : c2_pad32(c_in); }
+
+// 0 if the kernel does not take the layer (channel counts multiples of 8 up to 96)
+extern "C" size_t ts_conv3x3_wgrad_workspace_bytes(int32_t c_in, int32_t c_out) {
+  if (c_in < 8 || c_in > 96 || (c_in & 7) || c_out < 8 || c_out > 96 || (c_out & 7)) return 0;
+  return (size_t)C2G_WGRAD_WGS * ((size_t)9 * c2g_pass_ci(c_in, c_out) * c2_pad32(c_out) + c2_pad32(c_out)) * sizeof(float);
+}
+
+template <int NI, int NO, int TR>
+static int conv3x3_wgrad_launch(const _Float16 *x, int x_ch, int x_off, int x_chunks, const _Float16 *gy, int y_ch, int T, int H, int W,
+                                float *part, float *bias_part, int *n_part, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)(TR + 2) * 34 * (32 * NI + 8) + (size_t)TR * 32 * (32 * NO + 8)) * sizeof(_Float16);
+  static_assert(lds <= 160 * 1024, "staged rows exceed the LDS of a CU");
+  static bool attr_set = false;
+  auto kern = conv3x3_wgrad_kernel<NI, NO, TR>;
+  if (lds > 64 * 1024 && !attr_set) {
+    TS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    attr_set = true;
+  }
+  const int tiles_x = (int)ts_cdiv(W, 32), tiles_y = (int)ts_cdiv(H, TR);
+  const int64_t n_tiles = (int64_t)T * tiles_x * tiles_y;
+  TS_REQUIRE(n_tiles < (1LL << 31), TS_ERR_UNSUPPORTED, "ts_conv3x3_wgrad: stack too large");
+  const int grid = (int)std::min<int64_t>(n_tiles, C2G_WGRAD_WGS);
+  kern<<<grid, 256, lds, stream>>>(x, x_ch, x_off, x_chunks, gy, y_ch, H, W, tiles_x, tiles_y, (int)n_tiles, part, bias_part);
+  *n_part = grid;
+  return TS_OK;
+}
+
+// grad_weight [c_out][c_in][3][3] (IEEE half, element strides given) and grad_bias [c_out] (float, may be NULL) of a 3 x 3, stride 1,
+// padding 1 layer from x [T, H, W, c_in] and grad_y [T, H, W, c_out], channels-last half; ws >= ts_conv3x3_wgrad_workspace_bytes()
+extern "C" int ts_conv3x3_wgrad(const void *x, int32_t c_in, const void *grad_y, int32_t c_out, int32_t T, int32_t H, int32_t W,
+                                void *grad_weight, int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, float *grad_bias, void *ws,
+                                size_t ws_bytes, ts_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TS_REQUIRE(T > 0 && H > 0 && W > 0, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3_wgrad: bad sizes");
+  const size_t need = ts_conv3x3_wgrad_workspace_bytes(c_in, c_out);
+  TS_REQUIRE(need != 0, TS_ERR_UNSUPPORTED, "ts_conv3x3_wgrad: channel counts multiples of 8 up to 96");
+  TS_REQUIRE(x && grad_y && grad_weight && ws && ws_bytes >= need, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3_wgrad: null pointer / workspace too small");
+  TS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)grad_y) | ((uintptr_t)ws)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv3x3_wgrad: pointers must be 16-byte aligned");
+  const int pass_ci = c2g_pass_ci(c_in, c_out), COP = c2_pad32(c_out), NO = COP / 32;
+  const _Float16 *xp = (const _Float16 *)x, *gp = (const _Float16 *)grad_y;
+  for (int ci_off = 0; ci_off < c_in; ci_off += pass_ci) {       // (passes on one stream: the workspace is free again when the next starts)
+    const int ci_n = std::min(pass_ci, c_in - ci_off), CIP = c2_pad32(ci_n), NI = CIP / 32;
+    float *part = (float *)ws, *bias_part = part + (size_t)C2G_WGRAD_WGS * 9 * CIP * COP;
+    int n_part = 0, rc = TS_ERR_UNSUPPORTED;
+#define C2G_CASE(NI_, NO_, TR_) \
+    if (NI == NI_ && NO == NO_)   \
+      rc = conv3x3_wgrad_launch<NI_, NO_, TR_>(xp, c_in, ci_off, ci_n / 8, gp, c_out, T, H, W, part, bias_part, &n_part, stream);
+    C2G_CASE(1, 1, 8) C2G_CASE(1, 2, 8) C2G_CASE(1, 3, 8) C2G_CASE(2, 1, 8) C2G_CASE(2, 2, 8) C2G_CASE(2, 3, 4) C2G_CASE(3, 1, 8) C2G_CASE(3, 2, 4)
+#undef C2G_CASE
+    if (rc != TS_OK) return rc;
+    TS_CHECK_LAUNCH("ts_conv3x3_wgrad");
+    const int n_elems = 9 * CIP * COP + COP;
+    conv3x3_wgrad_reduce_kernel<<<(n_elems + 63) / 64, 256, 0, stream>>>(part, bias_part, n_part, CIP, COP, ci_off, c_in, c_out,
+                                                                         (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx,
+                                                                         ci_off == 0 ? grad_bias : nullptr);
+    TS_CHECK_LAUNCH("ts_conv3x3_wgrad (reduce)");
+  }
+  return TS_OK;
 }

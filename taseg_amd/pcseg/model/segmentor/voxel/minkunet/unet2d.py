@@ -195,7 +195,7 @@ class _Conv3x3C32Rows(Function):
     """Conv2d(32, 32, 3, stride 1, padding = dilation) of a channels-last half map on csrc/conv2d_rows.hip: forward, data gradient
     (the weight lives in a wave's registers as MFMA operands) and weight gradient (pixel-major rows through LDS transposing reads,
     partial sums in a fixed order) on the library's kernels - tools/conv2d_probe.py has them against MIOpen's best solvers for
-    this shape; the bias gradient is one fp32-accumulated sum."""
+    this shape; the bias gradient comes out of the weight gradient's pass (a product against ones)."""
 
     @staticmethod
     def forward(ctx, x, weight16, bias, dilation):
@@ -210,11 +210,12 @@ class _Conv3x3C32Rows(Function):
         d = ctx.dilation
         grad_y = grad_y.to(torch.float16).contiguous(memory_format=torch.channels_last)
         gx = B.conv3x3c32_rows(grad_y, B.conv3x3c32_pack(w, 1), None, d) if ctx.needs_input_grad[0] else None
-        gw = B.conv3x3c32_wgrad(x, grad_y, w, d) if ctx.needs_input_grad[1] else None
-        gb = None
-        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
-            gb = grad_y.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
-        return gx, gw, gb, None
+        gw = gb = None
+        want_bias = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_bias:
+            gw, gb = B.conv3x3c32_wgrad(x, grad_y, w, d, True)           # (the bias sums ride along in the same pass)
+            gb = gb.to(ctx.bias_dtype) if want_bias else None
+        return gx, gw if ctx.needs_input_grad[1] else None, gb, None
 
 
 class _ShuffleCatRows(Function):
@@ -237,7 +238,8 @@ class _ShuffleCatRows(Function):
 class _Conv3x3Rows(Function):
     """Conv2d(C_in <= 96, C_out, 3, stride 1, padding 1) of a channels-last half map - the decoder's wide layers (UpBlock.conv1 of up3:
     96 -> 96 at 1/2 scale, up4: 56 -> 96 at full scale) - forward and data gradient on csrc/conv2d_rows.hip's general kernel (MIOpen's
-    best solvers for the up4 shape: 4.4 and 1.5 ms, tools/unet2d_layers.py); the weight gradient stays the vendor library's."""
+    best solvers for the up4 shape: 4.4, 1.5 and 2.4 ms, tools/unet2d_layers.py) and weight + bias gradient on its companion (fp32 sums in
+    registers, partials added in a fixed order)."""
 
     @staticmethod
     def forward(ctx, x, weight16, bias):
@@ -251,13 +253,12 @@ class _Conv3x3Rows(Function):
         x, w = ctx.saved_tensors
         grad_y = grad_y.to(torch.float16).contiguous(memory_format=torch.channels_last)
         gx = B.conv3x3_rows(grad_y, B.conv3x3_rows_pack(w, 1), None, w.shape[1]) if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(grad_y, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])[1]
-        gb = None
-        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
-            gb = grad_y.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
-        return gx, gw, gb
+        gw = gb = None
+        want_bias = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_bias:
+            gw, gb = B.conv3x3_wgrad(x, grad_y, w, want_bias)            # (the bias sums ride along in the same pass)
+            gb = gb.to(ctx.bias_dtype) if want_bias else None
+        return gx, gw if ctx.needs_input_grad[1] else None, gb
 
 
 # layers the general kernel is measured faster on (tools/conv2d_probe.py): at least this many pixels per call

@@ -201,8 +201,7 @@ def test_fused_leaky_relu_batch_norm_equals_the_two_modules(shape, dtype):
 @pytest.mark.parametrize("shape", [(2, 32, 19, 45), (1, 32, 4, 32), (3, 32, 64, 96)])
 def test_conv3x3_c32_rows_equals_the_module(shape, dilation):
     """UNet2D's 3 x 3, 32 -> 32 channel layers on channels-last half maps (csrc/conv2d_rows.hip, unet2d._conv) against nn.Conv2d
-    evaluated in float64 on the same half inputs: output, input gradient (ours), weight / bias gradients (vendor library behind the
-    same node); sizes that are no multiple of the 32-pixel segments / 4-row tiles; run-to-run identical"""
+    evaluated in float64 on the same half inputs: output, input gradient, weight and bias gradient (all ours); sizes that are no multiple of the 32-pixel segments / 4-row tiles; run-to-run identical"""
     from taseg_amd.pcseg.model.segmentor.voxel.minkunet.unet2d import _conv
     g = torch.Generator().manual_seed(13)
     conv = torch.nn.Conv2d(32, 32, 3, padding=dilation, dilation=dilation).cuda().to(memory_format=torch.channels_last)
@@ -212,8 +211,8 @@ def test_conv3x3_c32_rows_equals_the_module(shape, dilation):
         y = _conv(conv, x)
     assert y.dtype == torch.float16 and y.grad_fn.__class__.__name__.startswith("_Conv3x3C32Rows") and y.is_contiguous(memory_format=torch.channels_last)
     gx, gw, gb = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias), retain_graph=True)
-    gx2, _, _ = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
-    assert torch.equal(gx, gx2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
+    gx2, gw2, gb2 = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
     ref = torch.nn.Conv2d(32, 32, 3, padding=dilation, dilation=dilation).cuda().double()
     with torch.no_grad():
         ref.weight.copy_(conv.weight.half().double())          # the half weight autocast hands the kernel
@@ -234,8 +233,9 @@ def test_conv3x3_c32_rows_equals_the_module(shape, dilation):
                                          ((1, 8, 8, 32), 8), ((3, 96, 64, 96), 56)])
 def test_conv3x3_rows_general_channels_equals_the_module(shape, c_out, monkeypatch):
     """the decoder's wide 3 x 3 layers (UpBlock.conv1: 56 -> 96, 96 -> 96; csrc/conv2d_rows.hip's general kernel behind unet2d._conv)
-    against nn.Conv2d evaluated in float64 on the same half inputs: output and input gradient (ours), weight / bias gradients (the
-    vendor library's weight gradient behind the same node); channel counts that are no multiple of 16 / 32, ragged image sizes"""
+    against nn.Conv2d evaluated in float64 on the same half inputs: output, input gradient, weight and bias gradient (all ours: the
+    9 x C_in x C_out sums in registers, 96 x 96 in two passes); channel counts that are no multiple of 16 / 32, ragged image sizes;
+    run-to-run identical"""
     from taseg_amd import backend as B
     from taseg_amd.pcseg.model.segmentor.voxel.minkunet import unet2d
     monkeypatch.setattr(unet2d, "_CONV_ROWS_MIN_PIXELS", 1)
@@ -248,8 +248,8 @@ def test_conv3x3_rows_general_channels_equals_the_module(shape, c_out, monkeypat
         y = unet2d._conv(conv, x)
     assert y.dtype == torch.float16 and y.grad_fn.__class__.__name__.startswith("_Conv3x3Rows") and y.is_contiguous(memory_format=torch.channels_last)
     gx, gw, gb = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias), retain_graph=True)
-    gx2, _, _ = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
-    assert torch.equal(gx, gx2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
+    gx2, gw2, gb2 = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
     ref = torch.nn.Conv2d(c_in, c_out, 3, padding=1).cuda().double()
     with torch.no_grad():
         ref.weight.copy_(conv.weight.half().double())

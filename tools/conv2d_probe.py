@@ -90,7 +90,13 @@ def general():
                "ours_fwd_us": timed(lambda: B.conv3x3_rows(x, p0, bd.float(), co)), "torch_fwd_us": timed(lambda: conv(x)),
                "ours_dgrad_us": timed(lambda: B.conv3x3_rows(gy, p1, None, ci)),
                "torch_dgrad_us": timed(lambda: torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [True, False, False])),
-               "torch_wgrad_us": timed(lambda: torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [False, True, False]))}
+               "torch_wgrad_us": timed(lambda: torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [False, True, False])),
+               "ours_wgrad_bias_us": timed(lambda: B.conv3x3_wgrad(x, gy, wd, True)),
+               "torch_bias_sum_us": timed(lambda: gy.sum(dim=(0, 2, 3), dtype=torch.float32))}
+        gw, gb = B.conv3x3_wgrad(x, gy, wd, True)
+        gw_want = torch.ops.aten.convolution_backward(gy, x, wd, None, *args, [False, True, False])[1]
+        rec["wgrad_rel_diff_vs_torch"] = float((gw.float() - gw_want.float()).norm() / gw_want.float().norm())
+        rec["bias_rel_diff_vs_torch"] = float((gb - gy.sum(dim=(0, 2, 3), dtype=torch.float32)).norm() / gb.norm())
         rec["ours_fwd_hbm_frac"] = 2 * (x.numel() + gy.numel()) / rec["ours_fwd_us"] / 1e3 / 8000.0
         print(json.dumps(rec), flush=True)
 
