@@ -464,6 +464,17 @@ int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T, int32_t H,
                         int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, float *grad_bias, void *ws, size_t ws_bytes,
                         ts_stream_t stream);
 
+/* The 1 x 1, 32 -> 32 channel layers in front of UNet2D's blocks with the LeakyReLU behind them (unet2d.py:10-12,41-43:
+ * `act1(conv1(x))`) on channels-last IEEE-half rows: y [n_pixels, 32] = LeakyReLU_slope(x W^T + bias) (leaky = 0: no activation;
+ * with a mode-1 pack that is the data gradient).  ts_conv1x1c32_wgrad: weight [co][ci] and bias gradient from x and the gradient g at
+ * the layer's output - the 3 x 3 weight gradient's pass, centre tap (same workspace). */
+size_t ts_conv1x1c32_packed_bytes(void);
+int ts_conv1x1c32_pack(const void *weight, int64_t s_co, int64_t s_ci, int32_t mode, void *packed, ts_stream_t stream);
+int ts_conv1x1c32_rows(const void *x, const void *packed, const float *bias, int64_t n_pixels, int32_t leaky, float slope, void *y,
+                       ts_stream_t stream);
+int ts_conv1x1c32_wgrad(const void *x, const void *g, int32_t T, int32_t H, int32_t W, void *grad_weight, int64_t s_co, int64_t s_ci,
+                        float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream);
+
 /* The same convolution (stride 1, padding 1, no dilation) with the channel counts opened up - UpBlock.conv1 of the decoder
  * (unet2d.py:81-115: 96 -> 96 channels at 1/2 scale, 56 -> 96 at full scale): input channels a multiple of 8 up to 96, output
  * channels a multiple of 8.  A persistent workgroup owns one 32-channel output block, its 9 x C_in/16 weight fragments in registers.

@@ -97,6 +97,10 @@ SIGNATURES = {
     "ts_conv3x3_rows_packed_bytes": (_sz, [_i32, _i32]),
     "ts_conv3x3_rows_pack": (_i32, [_vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "ts_conv3x3_rows": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "ts_conv1x1c32_packed_bytes": (_sz, []),
+    "ts_conv1x1c32_pack": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "ts_conv1x1c32_rows": (_i32, [_vp, _vp, _vp, _i64, _i32, _c.c_float, _vp, _vp]),
+    "ts_conv1x1c32_wgrad": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "ts_conv3x3_wgrad_workspace_bytes": (_sz, [_i32, _i32]),
     "ts_conv3x3_wgrad": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "ts_conv3x3c32_wgrad_workspace_bytes": (_sz, []),

@@ -20,7 +20,7 @@ __all__ = [
     "devoxelize_backward_csr",
     "convolution_forward_cuda", "convolution_backward_cuda",
     "downsample", "unique_i64", "build_kmap", "trilinear_map", "conv_nbr", "conv_wgrad", "conv_class_plan", "conv_class_gemm", "conv_class_gemm_f16", "conv_class_conv", "conv_class_conv_f16", "class_finish_pays",
-    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad", "conv3x3_rows_takes", "conv3x3_rows_pack", "conv3x3_rows", "conv3x3_wgrad", "shuffle_cat_rows_takes", "shuffle_cat_rows_forward", "shuffle_cat_rows_backward",
+    "fuse_scan", "fuse_scans", "fuse_sweeps", "project_fov", "voxel_coords", "sparse_quantize", "set_conv_impl", "image_gather_forward", "image_gather_backward", "image_gather_rows_forward", "image_gather_rows_backward", "avgpool3s2_rows_forward", "avgpool3s2_rows_backward", "conv3x3c32_pack", "conv3x3c32_rows", "conv3x3c32_wgrad", "conv3x3_rows_takes", "conv3x3_rows_pack", "conv3x3_rows", "conv3x3_wgrad", "conv1x1c32_pack", "conv1x1c32_rows", "conv1x1c32_wgrad", "shuffle_cat_rows_takes", "shuffle_cat_rows_forward", "shuffle_cat_rows_backward",
 ]
 
 
@@ -986,6 +986,50 @@ def conv3x3_rows(x, packed, bias, out_channels):
     L.check(lib.ts_conv3x3_rows(L.ptr(x), c, L.ptr(packed), L.ptr(bias), t, h, w, L.ptr(y), int(out_channels), L.stream()),
             "ts_conv3x3_rows")
     return y
+
+
+def conv1x1c32_pack(weight, mode):
+    """the packed MFMA operand of a Conv2d(32, 32, 1) weight (half, any strides): mode 0 forward, 1 data gradient"""
+    L.require_device(weight)
+    if weight.dtype != torch.float16 or tuple(weight.shape) != (32, 32, 1, 1):
+        raise ValueError(f"conv1x1c32_pack: a float16 [32, 32, 1, 1] weight, got {weight.dtype} {tuple(weight.shape)}")
+    lib = L.load()
+    packed = torch.empty(lib.ts_conv1x1c32_packed_bytes(), dtype=torch.uint8, device=weight.device)
+    L.check(lib.ts_conv1x1c32_pack(L.ptr(weight), weight.stride(0), weight.stride(1), int(mode), L.ptr(packed), L.stream()), "ts_conv1x1c32_pack")
+    return packed
+
+
+def conv1x1c32_rows(x, packed, bias, slope=None):
+    """Conv2d(32, 32, 1) of a channels-last float16 [T, 32, H, W] stack with a packed weight and an optional float32 bias, followed by
+    LeakyReLU(slope) unless slope is None; with the data-gradient pack: grad_x (csrc/conv2d_rows.hip)"""
+    L.require_device(x, packed, bias)
+    x = _channels_last_rows(x, "conv1x1c32_rows")
+    t, c, h, w = x.shape
+    if c != 32 or x.dtype != torch.float16:
+        raise ValueError(f"conv1x1c32_rows: float16 with 32 channels, got {x.dtype} with {c}")
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    L.check(L.load().ts_conv1x1c32_rows(L.ptr(x), L.ptr(packed), L.ptr(bias), t * h * w, int(slope is not None), float(slope or 0.0), L.ptr(y),
+                                        L.stream()), "ts_conv1x1c32_rows")
+    return y
+
+
+def conv1x1c32_wgrad(x, g, like_weight):
+    """(grad_weight float16 like like_weight [32, 32, 1, 1], grad_bias float32 [32]) of Conv2d(32, 32, 1) from the channels-last float16
+    input x and the gradient g at the layer's output"""
+    L.require_device(x, g)
+    x, g = _channels_last_rows(x, "conv1x1c32_wgrad(x)"), _channels_last_rows(g, "conv1x1c32_wgrad(g)")
+    if x.shape != g.shape or x.shape[1] != 32 or x.dtype != torch.float16 or g.dtype != torch.float16 or tuple(like_weight.shape) != (32, 32, 1, 1):
+        raise ValueError("conv1x1c32_wgrad: two float16 [T, 32, H, W] stacks of one shape and a [32, 32, 1, 1] weight")
+    t, _, h, w = x.shape
+    gw = torch.empty_like(like_weight, dtype=torch.float16)
+    gb = torch.empty(32, dtype=torch.float32, device=x.device)
+    lib = L.load()
+    ws = L.workspace(lib.ts_conv3x3c32_wgrad_workspace_bytes(), x.device)
+    L.check(lib.ts_conv1x1c32_wgrad(L.ptr(x), L.ptr(g), t, h, w, L.ptr(gw), gw.stride(0), gw.stride(1), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream()),
+            "ts_conv1x1c32_wgrad")
+    return gw, gb
 
 
 def conv3x3_wgrad(x, grad_y, like_weight, want_bias=True):

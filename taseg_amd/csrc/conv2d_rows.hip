@@ -292,11 +292,11 @@ __global__ __launch_bounds__(256) void conv3x3c32_wgrad_kernel(const _Float16 *_
 // 512 partials, took 0.12 ms per layer: as long as half the weight gradient itself.)
 __global__ __launch_bounds__(256) void conv3x3c32_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias_part,
                                                                       int n_part, _Float16 *__restrict__ dw, int64_t s_co, int64_t s_ci,
-                                                                      int64_t s_ky, int64_t s_kx, float *__restrict__ db) {
+                                                                      int64_t s_ky, int64_t s_kx, float *__restrict__ db, int center_only) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;                    // (tap, ci, co): 9 * 1024 = 144 * 64 elements, then the 32 of the bias
-  const bool is_w = e < 9 * 1024, live = e < 9 * 1024 + 32;
+  const bool is_w = e < 9 * 1024, live = e < 9 * 1024 + 32 && !(center_only && is_w && (e >> 10) != 4);   // (uniform per workgroup)
   const float *src = is_w ? part + e : bias_part + (e - 9 * 1024);
   const size_t pitch = is_w ? (size_t)9 * 1024 : (size_t)32;
   const int per = (n_part + 3) / 4, p0 = q * per, p1 = min(n_part, p0 + per);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void conv3x3c32_wgrad_reduce_kernel(const floa
   s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   if (is_w) {
     const int t9 = e >> 10, ci = (e >> 5) & 31, co = e & 31;
-    dw[co * s_co + ci * s_ci + (t9 / 3) * s_ky + (t9 % 3) * s_kx] = (_Float16)s;
+    dw[co * s_co + ci * s_ci + (center_only ? 0 : (t9 / 3) * s_ky + (t9 % 3) * s_kx)] = (_Float16)s;
   } else if (db) {
     db[e - 9 * 1024] = s;
   }
@@ -333,7 +333,8 @@ extern "C" int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T,
                                    int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx, float *grad_bias, void *ws, size_t ws_bytes,
                                    ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TS_REQUIRE(T > 0 && H > 0 && W > 0 && (dilation == 1 || dilation == 2), TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_wgrad: bad sizes");
+  // (dilation 0: the 1 x 1 layer of ts_conv1x1c32_wgrad below - the same pass, only the centre tap is written)
+  TS_REQUIRE(T > 0 && H > 0 && W > 0 && dilation >= 0 && dilation <= 2, TS_ERR_INVALID_ARGUMENT, "ts_conv3x3c32_wgrad: bad sizes");
   TS_REQUIRE(x && grad_y && grad_weight && ws && ws_bytes >= ts_conv3x3c32_wgrad_workspace_bytes(), TS_ERR_INVALID_ARGUMENT,
              "ts_conv3x3c32_wgrad: null pointer / workspace too small");
   TS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)grad_y) | ((uintptr_t)ws)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
@@ -343,15 +344,106 @@ extern "C" int ts_conv3x3c32_wgrad(const void *x, const void *grad_y, int32_t T,
   TS_REQUIRE(n_tiles < (1LL << 31), TS_ERR_UNSUPPORTED, "ts_conv3x3c32_wgrad: stack too large");
   const int grid = (int)std::min<int64_t>(n_tiles, C2_WGRAD_WGS);
   float *part = (float *)ws, *bias_part = part + (size_t)C2_WGRAD_WGS * 9 * 1024;
-  if (dilation == 1)
+  if (dilation <= 1)
     conv3x3c32_wgrad_kernel<1><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
                                                          part, bias_part);
   else
     conv3x3c32_wgrad_kernel<2><<<grid, 256, 0, stream>>>((const _Float16 *)x, (const _Float16 *)grad_y, H, W, tiles_x, tiles_y, (int)n_tiles,
                                                          part, bias_part);
-  conv3x3c32_wgrad_reduce_kernel<<<145, 256, 0, stream>>>(part, bias_part, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx, grad_bias);
+  conv3x3c32_wgrad_reduce_kernel<<<145, 256, 0, stream>>>(part, bias_part, grid, (_Float16 *)grad_weight, s_co, s_ci, s_ky, s_kx, grad_bias,
+                                                          dilation == 0);
   TS_CHECK_LAUNCH("ts_conv3x3c32_wgrad");
   return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 1 x 1, 32 -> 32 channel layers in front of the blocks (ResContextBlock.conv1 of stem[1], stem[2], ResBlock.conv1 of stage 1:
+// unet2d.py:10-12,41-43 - `act1(conv1(x))`, a LeakyReLU straight behind the layer): a [pixels, 32] x [32, 32] product, bias and
+// activation in the epilogue.  No LDS: a lane's two 16-byte loads ARE the B operand (lane = pixel, half = channel block), a wave keeps
+// four 32-pixel segments in flight.  630 MB per layer at full scale; MIOpen + ATen's LeakyReLU take 0.31 + 0.07 ms.
+// With a mode-1 pack (channels swapped) and no activation the same kernel is the data gradient.
+template <bool LEAKY>
+__global__ __launch_bounds__(256) void conv1x1c32_kernel(const _Float16 *__restrict__ X, const c2_h8 *__restrict__ Wp,
+                                                         const float *__restrict__ bias, float slope, _Float16 *__restrict__ Y, int64_t n_px) {
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const c2_h8 w0 = Wp[lane], w1 = Wp[64 + lane];
+  c2_f16 init;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) init[i] = bias ? bias[(i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
+  const c2_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t n_seg = (n_px + 31) / 32, waves = (int64_t)gridDim.x * 4;
+  for (int64_t s0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * UNR; s0 < n_seg; s0 += waves * UNR) {
+    c2_h8 b[UNR][2];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t px = (s0 + u) * 32 + r;
+      const bool ok = px < n_px;
+      const c2_h8 *p = (const c2_h8 *)(X + (ok ? px : 0) * C2_C + 8 * h);
+      b[u][0] = ok ? p[0] : zero;
+      b[u][1] = ok ? p[2] : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      c2_f16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b[u][0], init, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b[u][1], acc, 0, 0, 0);
+      const int64_t px = (s0 + u) * 32 + r;
+      if (px < n_px) {
+        _Float16 *o = Y + px * C2_C + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          c2_h4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const _Float16 y = (_Float16)acc[4 * g + k];         // (rounded first: LeakyReLU acts on the half value, as the module pair does)
+            v[k] = LEAKY ? (y > (_Float16)0 ? y : (_Float16)((float)y * slope)) : y;
+          }
+          *(c2_h4 *)(o + 8 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+// packed operand of a [32 co][32 ci] weight (element strides given): 2 x 64 x 16 bytes; mode 0 forward, 1 data gradient
+extern "C" size_t ts_conv1x1c32_packed_bytes(void) { return (size_t)2 * 64 * 16; }
+
+extern "C" int ts_conv1x1c32_pack(const void *weight, int64_t s_co, int64_t s_ci, int32_t mode, void *packed, ts_stream_t stream) {
+  TS_REQUIRE(weight && packed && (mode == 0 || mode == 1), TS_ERR_INVALID_ARGUMENT, "ts_conv1x1c32_pack: bad arguments");
+  TS_REQUIRE((((uintptr_t)packed) & 15) == 0, TS_ERR_INVALID_ARGUMENT, "ts_conv1x1c32_pack: packed must be 16-byte aligned");
+  // (the 3 x 3 pack with tap strides 0: blocks 0 and 1 are tap (0, 0) = the weight itself)
+  conv3x3c32_pack_kernel<<<2, 64, 0, (hipStream_t)stream>>>((const _Float16 *)weight, s_co, s_ci, 0, 0, mode, (c2_h8 *)packed);
+  TS_CHECK_LAUNCH("ts_conv1x1c32_pack");
+  return TS_OK;
+}
+
+// y [n_pixels, 32] = x [n_pixels, 32] W^T + bias [32] (float, may be NULL), then LeakyReLU(slope) if leaky != 0; IEEE-half rows
+// (a channels-last stack is its [T H W, 32] rows), 16-byte aligned, not overlapping
+extern "C" int ts_conv1x1c32_rows(const void *x, const void *packed, const float *bias, int64_t n_pixels, int32_t leaky, float slope, void *y,
+                                  ts_stream_t stream) {
+  TS_REQUIRE(n_pixels >= 0 && n_pixels < (1LL << 40), TS_ERR_INVALID_ARGUMENT, "ts_conv1x1c32_rows: bad sizes");
+  if (n_pixels == 0) return TS_OK;
+  TS_REQUIRE(x && packed && y && x != y, TS_ERR_INVALID_ARGUMENT, "ts_conv1x1c32_rows: null / aliased pointer");
+  TS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)packed)) & 15) == 0, TS_ERR_INVALID_ARGUMENT,
+             "ts_conv1x1c32_rows: pointers must be 16-byte aligned");
+  const int64_t n_seg = (n_pixels + 31) / 32;
+  const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(n_seg, 16), 256 * 16);
+  if (leaky)
+    conv1x1c32_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)x, (const c2_h8 *)packed, bias, slope, (_Float16 *)y, n_pixels);
+  else
+    conv1x1c32_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)x, (const c2_h8 *)packed, bias, slope, (_Float16 *)y, n_pixels);
+  TS_CHECK_LAUNCH("ts_conv1x1c32_rows");
+  return TS_OK;
+}
+
+// grad_weight [32 co][32 ci] (IEEE half, element strides given) and grad_bias [32] (float, may be NULL) of the 1 x 1 layer from x and
+// g = the gradient at the layer's output (behind the activation's own backward), [T, H, W, 32] rows: the 3 x 3 weight gradient's pass
+// (its centre tap), workspace as there
+extern "C" int ts_conv3x3c32_wgrad(const void *, const void *, int32_t, int32_t, int32_t, int32_t, void *, int64_t, int64_t, int64_t, int64_t,
+                                   float *, void *, size_t, ts_stream_t);
+extern "C" int ts_conv1x1c32_wgrad(const void *x, const void *g, int32_t T, int32_t H, int32_t W, void *grad_weight, int64_t s_co, int64_t s_ci,
+                                   float *grad_bias, void *ws, size_t ws_bytes, ts_stream_t stream) {
+  return ts_conv3x3c32_wgrad(x, g, T, H, W, 0, grad_weight, s_co, s_ci, 0, 0, grad_bias, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

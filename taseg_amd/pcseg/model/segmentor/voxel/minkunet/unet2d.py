@@ -261,6 +261,46 @@ class _Conv3x3Rows(Function):
         return gx, gw if ctx.needs_input_grad[1] else None, gb
 
 
+class _Conv1x1C32Act(Function):
+    """LeakyReLU(Conv2d(32, 32, 1)) of a channels-last half map as one node (csrc/conv2d_rows.hip: the activation in the product's
+    epilogue; backward: ATen's LeakyReLU gradient from the saved OUTPUT, then data gradient on the same kernel and weight + bias
+    gradient on the 3 x 3 layers' pass)."""
+
+    @staticmethod
+    def forward(ctx, x, weight16, bias, slope):
+        y = B.conv1x1c32_rows(x, B.conv1x1c32_pack(weight16, 0), None if bias is None else bias.float(), slope)
+        ctx.save_for_backward(x, weight16, y)
+        ctx.slope, ctx.bias_dtype = float(slope), None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, w, y = ctx.saved_tensors
+        grad_y = grad_y.to(torch.float16).contiguous(memory_format=torch.channels_last)
+        g = torch.ops.aten.leaky_relu_backward(grad_y, y, ctx.slope, True)           # (slope > 0: the output's sign is the input's)
+        gx = B.conv1x1c32_rows(g, B.conv1x1c32_pack(w, 1), None, None) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        want_bias = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_bias:
+            gw, gb = B.conv1x1c32_wgrad(x, g, w)
+            gb = gb.to(ctx.bias_dtype) if want_bias else None
+        return gx, gw if ctx.needs_input_grad[1] else None, gb, None
+
+
+def _conv_act(conv, act, x):
+    """act(conv(x)) at the head of a block: the 1 x 1, 32 -> 32 channel layers of a channels-last half map with their LeakyReLU as one
+    node; everything else the two modules"""
+    if (options.image_conv_rows and x.is_cuda and x.dim() == 4 and x.dtype == torch.float16 and type(conv) is nn.Conv2d
+            and type(act) is nn.LeakyReLU and not act.inplace and act.negative_slope > 0
+            and conv.in_channels == 32 and conv.out_channels == 32 and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.groups == 1 and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and x.shape[2] * x.shape[3] >= _CONV_ROWS_MIN_PIXELS
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and not (conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks or act._forward_hooks or act._forward_pre_hooks)):
+        return _Conv1x1C32Act.apply(x, conv.weight.to(torch.float16), conv.bias, act.negative_slope)
+    return act(conv(x))
+
+
 # layers the general kernel is measured faster on (tools/conv2d_probe.py): at least this many pixels per call
 _CONV_ROWS_MIN_PIXELS = 192 * 640
 
@@ -304,7 +344,7 @@ class ResContextBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(out_filters)
 
     def forward(self, x):
-        skip = self.act1(self.conv1(x))
+        skip = _conv_act(self.conv1, self.act1, x)
         y = _act_bn(self.act2, self.bn1, _conv(self.conv2, skip))
         y = _act_bn(self.act3, self.bn2, _conv(self.conv3, y))
         return skip + y
@@ -327,7 +367,7 @@ class ResBlock(nn.Module):
             self.pool = nn.AvgPool2d(kernel_size=kernel_size, stride=2, padding=1)
 
     def forward(self, x):
-        res = self.act1(self.conv1(x)) + _act_bn(self.act2, self.bn1, _conv(self.conv2, x))
+        res = _conv_act(self.conv1, self.act1, x) + _act_bn(self.act2, self.bn1, _conv(self.conv2, x))
         out = self.dropout(res) if self.drop_out else res
         if not self.pooling:
             return out

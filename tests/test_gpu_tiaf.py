@@ -267,6 +267,41 @@ def test_conv3x3_rows_general_channels_equals_the_module(shape, c_out, monkeypat
         B.conv3x3_rows(x.detach(), torch.empty(16, dtype=torch.uint8, device="cuda"), None, c_out)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 19, 45), (1, 32, 3, 5), (3, 32, 64, 96)])
+def test_conv1x1_c32_with_leaky_relu_equals_the_two_modules(shape, monkeypatch):
+    """LeakyReLU(Conv2d(32, 32, 1)) as one node (unet2d._conv_act on csrc/conv2d_rows.hip) against the two modules evaluated in float64
+    on the same half inputs (the activation applied to the HALF-rounded layer output, as the module pair does under autocast): output,
+    input, weight and bias gradient; pixel counts that are no multiple of the 32-pixel segments; run-to-run identical"""
+    from taseg_amd.pcseg.model.segmentor.voxel.minkunet import unet2d
+    monkeypatch.setattr(unet2d, "_CONV_ROWS_MIN_PIXELS", 1)
+    g = torch.Generator().manual_seed(29)
+    conv = torch.nn.Conv2d(32, 32, 1).cuda().to(memory_format=torch.channels_last)
+    act = torch.nn.LeakyReLU()
+    x = torch.randn(*shape, generator=g).cuda().half().contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = torch.randn(*shape, generator=g).cuda()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = unet2d._conv_act(conv, act, x)
+    assert y.dtype == torch.float16 and y.grad_fn.__class__.__name__.startswith("_Conv1x1C32Act") and y.is_contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias), retain_graph=True)
+    gx2, gw2, gb2 = torch.autograd.grad((y.float() * wt).sum(), (x, conv.weight, conv.bias))
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2) and gw.dtype == torch.float32 and gb.dtype == torch.float32
+    ref = torch.nn.Conv2d(32, 32, 1).cuda().double()
+    with torch.no_grad():
+        ref.weight.copy_(conv.weight.half().double())
+        ref.bias.copy_(conv.bias.double())
+    xd = x.detach().double().requires_grad_()
+    want = act(ref(xd))
+    wx, ww, wb = torch.autograd.grad((want * wt.double()).sum(), (xd, ref.weight, ref.bias))
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm().clamp_min(1e-30))      # noqa: E731
+    assert float((y.detach().double() - want.detach()).abs().max()) <= 2e-3 * max(1.0, float(want.detach().abs().max()))
+    # (an output that rounds to the other side of zero flips a slope: a handful of elements of the input gradient at most)
+    assert rel(gx, wx) <= 5e-3 and rel(gw, ww) <= 5e-3 and rel(gb, wb) <= 5e-3, (rel(gx, wx), rel(gw, ww), rel(gb, wb))
+    # other layers / float32 maps: the two modules
+    assert unet2d._conv_act(conv, act, x.detach().float()).grad_fn.__class__.__name__ == "LeakyReluBackward0"
+    wide = torch.nn.Conv2d(32, 64, 1).cuda().half().to(memory_format=torch.channels_last)
+    assert torch.equal(unet2d._conv_act(wide, act, x.detach()), act(wide(x.detach())))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("shape,cs", [((2, 96, 12, 20), 32), ((1, 128, 5, 7), 64), ((3, 256, 3, 4), 128), ((2, 32, 9, 33), 8)])
 def test_shuffle_cat_rows_equals_pixel_shuffle_and_cat(shape, cs, dtype):
