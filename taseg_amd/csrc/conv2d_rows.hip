@@ -9,7 +9,7 @@
 // `v_mfma_f32_32x32x16_f16` (M = output channel, N = pixel, K = 16 input channels: 2 per tap) whose B operands are 16-byte reads
 // of the input rows (lane = pixel, half = channel block) from a [pixel][channel] image of the tile's rows in LDS.
 // The four waves of a workgroup take four vertically adjacent segments and share the 4 + 2 D staged input rows; the result leaves
-// as 8-byte stores (4 consecutive output channels of a pixel per accumulator group).
+// as 16-byte stores (the two lanes of a pixel trade accumulator groups first: c2_pair_up).
 //   forward        Y[t, y, x, co] = bias[co] + sum_{ky, kx, ci} X[t, y + (ky - 1) D, x + (kx - 1) D, ci] W[co, ci, ky, kx]
 //   data gradient  dX = the same kernel over dY with the packed weights of mode 1 (taps mirrored, channels swapped), no bias
 // fp32 accumulation (the MFMA's), one rounding to half at the store - what MIOpen's fp16 solvers do.
@@ -22,6 +22,27 @@ typedef _Float16 c2_h4 __attribute__((ext_vector_type(4)));
 typedef float c2_f16 __attribute__((ext_vector_type(16)));
 
 #define C2_C 32
+
+// Result layout of v_mfma_f32_32x32x16: lane (pixel r, half h) holds, per group g = 0 .. 3, the channels 8 g + 4 h .. + 3 of its pixel -
+// stored as they come that is four 8-byte pieces per lane, and 8-byte stores of 64 lanes to 32 rows are what such a kernel then spends
+// its time issuing.  One v_permlane32_swap per dword (gfx950) trades pieces between the two lanes of a pixel: the h = 0 lane ends up
+// with channels 0 .. 15, the h = 1 lane with 16 .. 31, each as two 16-byte pieces side by side (p0: channels 16 h .. + 7, p1: + 8).
+// Every lane of the wave must be active.
+__device__ inline void c2_pair_up(const float (&a)[16], c2_h8 &p0, c2_h8 &p1) {
+  union { c2_h4 v; unsigned d[2]; } g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g[k].v = (c2_h4){(_Float16)a[4 * k], (_Float16)a[4 * k + 1], (_Float16)a[4 * k + 2], (_Float16)a[4 * k + 3]};
+  union { c2_h8 v; unsigned d[4]; } q0, q1;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    // swap(x, y): x' = {lower lanes: x, upper lanes: y of the lower lanes}, y' = {lower lanes: x of the upper lanes, upper lanes: y}
+    const auto s02 = __builtin_amdgcn_permlane32_swap(g[0].d[d], g[2].d[d], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(g[1].d[d], g[3].d[d], false, false);
+    q0.d[d] = s02[0]; q0.d[2 + d] = s02[1];
+    q1.d[d] = s13[0]; q1.d[2 + d] = s13[1];
+  }
+  p0 = q0.v; p1 = q1.v;
+}
 
 // weight [co][ci][ky][kx] with element strides (s_co, s_ci, s_ky, s_kx) -> packed[tap][kb][lane] (8 halfs per lane): the A operand of
 // v_mfma_f32_32x32x16_f16 for output row m = lane & 31 and reduction index k = 16 kb + 8 (lane >> 5) + j
@@ -108,13 +129,15 @@ __global__ __launch_bounds__(256) void conv3x3c32_rows_kernel(const _Float16 *__
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][1], b1, acc, 0, 0, 0);
       }
     }
-    if (y < H && x < W) {
-      _Float16 *o = Y + (((size_t)t * H + y) * W + x) * C2_C + 4 * h;
+    float af[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        c2_h4 v = {(_Float16)acc[4 * g], (_Float16)acc[4 * g + 1], (_Float16)acc[4 * g + 2], (_Float16)acc[4 * g + 3]};
-        *(c2_h4 *)(o + 8 * g) = v;
-      }
+    for (int i = 0; i < 16; ++i) af[i] = acc[i];
+    c2_h8 p0, p1;
+    c2_pair_up(af, p0, p1);                                      // (all lanes: before the bounds check)
+    if (y < H && x < W) {
+      _Float16 *o = Y + (((size_t)t * H + y) * W + x) * C2_C + 16 * h;
+      *(c2_h8 *)o = p0;
+      *(c2_h8 *)(o + 8) = p1;
     }
   }
 }
@@ -388,18 +411,18 @@ __global__ __launch_bounds__(256) void conv1x1c32_kernel(const _Float16 *__restr
       c2_f16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b[u][0], init, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b[u][1], acc, 0, 0, 0);
       const int64_t px = (s0 + u) * 32 + r;
+      float af[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const _Float16 y = (_Float16)acc[i];                     // (rounded first: LeakyReLU acts on the half value, as the module pair does)
+        af[i] = LEAKY ? (float)(y > (_Float16)0 ? y : (_Float16)((float)y * slope)) : (float)y;
+      }
+      c2_h8 p0, p1;
+      c2_pair_up(af, p0, p1);                                    // (all lanes: before the bounds check)
       if (px < n_px) {
-        _Float16 *o = Y + px * C2_C + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          c2_h4 v;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const _Float16 y = (_Float16)acc[4 * g + k];         // (rounded first: LeakyReLU acts on the half value, as the module pair does)
-            v[k] = LEAKY ? (y > (_Float16)0 ? y : (_Float16)((float)y * slope)) : y;
-          }
-          *(c2_h4 *)(o + 8 * g) = v;
-        }
+        _Float16 *o = Y + px * C2_C + 16 * h;
+        *(c2_h8 *)o = p0;
+        *(c2_h8 *)(o + 8) = p1;
       }
     }
   }
@@ -452,31 +475,36 @@ extern "C" int ts_conv1x1c32_wgrad(const void *x, const void *g, int32_t T, int3
 // shape take 4.4 ms forward and 1.5 ms for the data gradient (tools/unet2d_layers.py; the maps are 550 + 945 MB: 0.19 ms of HBM, 0.2 ms
 // of fp16 MFMA).  Same scheme as the 32-channel kernel above with the channel counts opened up:
 //   - C_in any multiple of 8 up to 96 (staged in LDS zero-padded to 16 KB channels: KB = 2, 4, 6 K-blocks per tap),
-//   - C_out any multiple of 8, in blocks of 32: a persistent workgroup owns ONE output block and keeps its 9 x KB weight fragments
-//     in registers (36 KB VGPRs of the 512 a wave of a 256-thread workgroup may hold); workgroups of the blocks of one tile are
-//     neighbours in the grid, so the input rows they all stage come out of L2 for all but the first,
-//   - a wave computes RPW vertically adjacent output rows of the 32-pixel segment: a B fragment (one input row, tap column, K block)
-//     read from LDS once feeds the up to RPW output rows it belongs to - at one row per wave the LDS reads (1 KB per MFMA) are as
-//     long as the MFMAs themselves.
-template <int KB, int RPW>
-__global__ __launch_bounds__(256) void conv3x3_rows_kernel(const _Float16 *__restrict__ X, int x_ch, const c2_h8 *__restrict__ Wp,
-                                                           const float *__restrict__ bias, _Float16 *__restrict__ Y, int y_ch, int H, int W,
-                                                           int tiles_x, int tiles_y, int n_tiles, int n_cob) {
-  constexpr int TR = 4 * RPW, XR = TR + 2, XW = 34, NCH = 2 * KB, PITCH = 16 * KB + 8;
-  constexpr int N_X = XR * XW * NCH, X_IT = (N_X + 255) / 256;
+//   - C_out any multiple of 8, in blocks of 32.  A WAVE owns one output block and keeps its 9 x KB weight fragments in registers
+//     (36 KB VGPRs of the 512 a lone wave of a SIMD may hold); the NCOB waves of the blocks share ONE staged tile of input rows, so
+//     the input is read from HBM and written to LDS once, not once per block (the first form - a workgroup per block - ran at the
+//     bytes it kept in flight: 1.0 ms forward at the up4 shape), and RG such wave groups split the tile's rows,
+//   - a wave walks its rows two at a time: a B fragment (one input row, tap column, K block) read from LDS once feeds both output
+//     rows it belongs to - at one row per pass the LDS reads (1 KB per MFMA) are as long as the MFMAs themselves,
+//   - the rows of the next tile are on their way while a tile is multiplied, and the last row pair's result leaves during the next
+//     tile (stores count against the same counter as loads here: a store just before the loop's wait would be waited for).
+template <int KB, int NCOB, int RG, int TR>
+__global__ __launch_bounds__(64 * NCOB * RG) void conv3x3_rows_kernel(const _Float16 *__restrict__ X, int x_ch, const c2_h8 *__restrict__ Wp,
+                                                                      const float *__restrict__ bias, _Float16 *__restrict__ Y, int y_ch,
+                                                                      int H, int W, int tiles_x, int tiles_y, int n_tiles, int n_cob,
+                                                                      int n_groups) {
+  constexpr int NT = 64 * NCOB * RG, RPWV = TR / RG, NP = RPWV / 2;
+  static_assert(TR % RG == 0 && RPWV % 2 == 0, "rows per wave must be even");
+  constexpr int XR = TR + 2, XW = 34, NCH = 2 * KB, PITCH = 16 * KB + 8;
+  constexpr int N_X = XR * XW * NCH, X_IT = (N_X + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) _Float16 xs_dyn[];
   _Float16 *xs = xs_dyn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  // grid = groups of 8 n_cob workgroups: workgroup j of a group takes output block j / 8 of tile stream 8 group + j % 8 - the n_cob
-  // workgroups of one tile stream have the same index modulo 8, i.e. sit on the same XCD and share its L2
-  const int j = blockIdx.x % (8 * n_cob), cob = j >> 3, first = (blockIdx.x / (8 * n_cob)) * 8 + (j & 7), step = gridDim.x / n_cob;
+  const int group = blockIdx.x % n_groups, first = blockIdx.x / n_groups, step = gridDim.x / n_groups;
+  const int cob = group * NCOB + wave % NCOB, row0 = (wave / NCOB) * RPWV;    // this wave's output block and first row in the tile
+  const bool live = cob < n_cob;                                              // (wave-uniform; idle waves still stage and wait)
   const int x_chunks = x_ch >> 3;
   c2_h8 wr[9][KB];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) wr[tap][kb] = Wp[((size_t)(cob * 9 + tap) * KB + kb) * 64 + lane];
+    for (int kb = 0; kb < KB; ++kb) wr[tap][kb] = Wp[((size_t)((live ? cob : 0) * 9 + tap) * KB + kb) * 64 + lane];
   // accumulator register i of this lane belongs to output channel 32 cob + (i & 3) + 8 (i >> 2) + 4 h (column = pixel r)
   c2_f16 init;
 #pragma unroll
@@ -494,30 +522,27 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const _Float16 *__res
     const _Float16 *img = X + (size_t)(rest / tiles_y) * H * W * x_ch;
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
-      const int e = tid + it * 256;
+      const int e = tid + it * NT;
       const int ch = e % NCH, px = (e / NCH) % XW, row = (e / NCH) / XW;
       const int yy = y0 - 1 + row, xx = x0 - 1 + px;
       nx[it] = (e < N_X && ch < x_chunks && yy >= 0 && yy < H && xx >= 0 && xx < W)
                    ? *(const c2_h8 *)(img + ((size_t)yy * W + xx) * x_ch + 8 * ch) : zero;
     }
   };
-  // A tile's result is held back (rounded to half: 8 RPW registers) and stored while the NEXT tile is multiplied: stores count
-  // against the same counter as loads on this target, so the wait for the prefetched rows at the top of the loop would otherwise
-  // also wait for stores issued a moment before it - with one wave per SIMD nothing else runs meanwhile.
-  c2_h4 pend[RPW][4];
+  c2_h8 pend[2][2];
   int pend_tile = -1;
-  auto flush = [&](int tile) {
+  auto store = [&](int tile, int rows_at, const c2_h8 (&v)[2][2]) {      // two output rows of this wave's block (c2_pair_up's pieces)
     const int xsi = tile % tiles_x, rest = tile / tiles_x;
     const int yb = rest % tiles_y, t = rest / tiles_y;
     const int x = xsi * 32 + r;
 #pragma unroll
-    for (int o = 0; o < RPW; ++o) {
-      const int y = yb * TR + wave * RPW + o;
-      if (y < H && x < W) {
-        _Float16 *op = Y + (((size_t)t * H + y) * W + x) * y_ch + 32 * cob + 4 * h;
+    for (int o = 0; o < 2; ++o) {
+      const int y = yb * TR + rows_at + o;
+      if (live && y < H && x < W) {
+        _Float16 *op = Y + (((size_t)t * H + y) * W + x) * y_ch + 32 * cob + 16 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if (32 * cob + 4 * h + 8 * g < y_ch) *(c2_h4 *)(op + 8 * g) = pend[o][g];
+        for (int k = 0; k < 2; ++k)
+          if (32 * cob + 16 * h + 8 * k < y_ch) *(c2_h8 *)(op + 8 * k) = v[o][k];
       }
     }
   };
@@ -527,40 +552,52 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const _Float16 *__res
     __syncthreads();                                             // (the previous tile's fragments have been read)
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
-      const int e = tid + it * 256;
+      const int e = tid + it * NT;
       if (e < N_X) *(c2_h8 *)&xs[(e / NCH) * PITCH + (e % NCH) * 8] = nx[it];
     }
     __syncthreads();
     const int next = tile + step;
     if (next < n_tiles) fetch(next);                             // in flight while this tile is multiplied
-    if (pend_tile >= 0) flush(pend_tile);                        // the previous tile's result leaves while this one is multiplied
-    c2_f16 acc[RPW];
+    if (pend_tile >= 0) store(pend_tile, row0 + 2 * (NP - 1), pend);
 #pragma unroll
-    for (int o = 0; o < RPW; ++o) acc[o] = init;
+    for (int p = 0; p < NP; ++p) {
+      c2_f16 acc[2] = {init, init};
 #pragma unroll
-    for (int ir = 0; ir < RPW + 2; ++ir) {                       // input row wave * RPW + ir of the staged image
-      const _Float16 *xrow = xs + ((wave * RPW + ir) * XW + r) * PITCH + 8 * h;
+      for (int ir = 0; ir < 4; ++ir) {                           // input row row0 + 2 p + ir of the staged image
+        const _Float16 *xrow = xs + ((row0 + 2 * p + ir) * XW + r) * PITCH + 8 * h;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
+        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const c2_h8 b = *(const c2_h8 *)(xrow + kx * PITCH + 16 * kb);
+          for (int kb = 0; kb < KB; ++kb) {
+            const c2_h8 b = *(const c2_h8 *)(xrow + kx * PITCH + 16 * kb);
 #pragma unroll
-          for (int o = 0; o < RPW; ++o) {
-            const int ky = ir - o;                               // output row o takes this input row at tap row ky
-            if (ky >= 0 && ky < 3) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kb], b, acc[o], 0, 0, 0);
+            for (int o = 0; o < 2; ++o) {
+              const int ky = ir - o;                             // output row o takes this input row at tap row ky
+              if (ky >= 0 && ky < 3) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kb], b, acc[o], 0, 0, 0);
+            }
           }
         }
       }
+      c2_h8 out[2][2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        float af[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) af[i] = acc[o][i];
+        c2_pair_up(af, out[o][0], out[o][1]);                    // (all lanes: the bounds check is in store)
+      }
+      if (p + 1 < NP) {
+        store(tile, row0 + 2 * p, out);
+      } else {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) pend[o][k] = out[o][k];
+      }
     }
-#pragma unroll
-    for (int o = 0; o < RPW; ++o)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        pend[o][g] = (c2_h4){(_Float16)acc[o][4 * g], (_Float16)acc[o][4 * g + 1], (_Float16)acc[o][4 * g + 2], (_Float16)acc[o][4 * g + 3]};
     pend_tile = tile;
   }
-  if (pend_tile >= 0) flush(pend_tile);
+  if (pend_tile >= 0) store(pend_tile, row0 + 2 * (NP - 1), pend);
 }
 
 // packed[cob][tap][kb][lane] for the kernel above: rows m = 32 cob + (lane & 31) < M, reduction k = 16 kb + 8 (lane >> 5) + j < K,
@@ -605,28 +642,41 @@ extern "C" int ts_conv3x3_rows_pack(const void *weight, int32_t c_out, int32_t c
   return TS_OK;
 }
 
-template <int KB, int RPW>
+template <int KB, int NCOB, int RG, int TR>
 static int conv3x3_rows_launch(const _Float16 *x, int x_ch, const c2_h8 *packed, const float *bias, int T, int H, int W, _Float16 *y, int y_ch,
                                hipStream_t stream) {
-  constexpr int TR = 4 * RPW;
   constexpr size_t lds = (size_t)(TR + 2) * 34 * (16 * KB + 8) * sizeof(_Float16);
   static_assert(lds <= 160 * 1024, "staged rows exceed the LDS of a CU");
   static bool attr_set = false;
-  auto kern = conv3x3_rows_kernel<KB, RPW>;
+  auto kern = conv3x3_rows_kernel<KB, NCOB, RG, TR>;
   if (lds > 64 * 1024 && !attr_set) {
     TS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
     attr_set = true;
   }
   const int tiles_x = (int)ts_cdiv(W, 32), tiles_y = (int)ts_cdiv(H, TR), n_cob = (int)ts_cdiv(y_ch, 32);
+  const int n_groups = (int)ts_cdiv(n_cob, NCOB);                // (more than NCOB output blocks: workgroups side by side per tile)
   const int64_t n_tiles = (int64_t)T * tiles_x * tiles_y;
   TS_REQUIRE(n_tiles < (1LL << 31) && (int64_t)T * H * W * std::max(x_ch, y_ch) < (1LL << 40), TS_ERR_UNSUPPORTED,
              "ts_conv3x3_rows: stack too large");
-  // persistent workgroups (the packed weights are read once per wave, not once per tile), the blocks of a tile side by side
-  // (2048 workgroups: 1024 and 512 measured 5 - 25 % slower at the up4 shape, one or two output rows per wave the same)
-  const unsigned groups = (unsigned)ts_cdiv(std::min<int64_t>(n_tiles, std::max(8, 2048 / n_cob)), 8);
-  kern<<<groups * 8 * n_cob, 256, lds, stream>>>(x, x_ch, packed, bias, y, y_ch, H, W, tiles_x, tiles_y, (int)n_tiles, n_cob);
+  // persistent workgroups: the packed weights are read once per wave, not once per tile
+  const unsigned per_group = (unsigned)std::min<int64_t>(n_tiles, 1024);
+  kern<<<per_group * n_groups, 64 * NCOB * RG, lds, stream>>>(x, x_ch, packed, bias, y, y_ch, H, W, tiles_x, tiles_y, (int)n_tiles, n_cob,
+                                                              n_groups);
   TS_CHECK_LAUNCH("ts_conv3x3_rows");
   return TS_OK;
+}
+
+template <int KB>
+static int conv3x3_rows_by_blocks(const _Float16 *x, int x_ch, const c2_h8 *packed, const float *bias, int T, int H, int W, _Float16 *y, int y_ch,
+                                  hipStream_t stream) {
+  // waves = output blocks x row groups: 1 x 4, 2 x 2, 3 x 1, 4 x 1 (more blocks: several workgroups per tile)
+  constexpr int TR = KB == 6 ? 4 : 8;
+  switch ((int)ts_cdiv(y_ch, 32)) {
+    case 1: return conv3x3_rows_launch<KB, 1, 4, 8>(x, x_ch, packed, bias, T, H, W, y, y_ch, stream);
+    case 2: return conv3x3_rows_launch<KB, 2, 2, TR>(x, x_ch, packed, bias, T, H, W, y, y_ch, stream);
+    case 3: return conv3x3_rows_launch<KB, 3, 1, TR>(x, x_ch, packed, bias, T, H, W, y, y_ch, stream);
+    default: return conv3x3_rows_launch<KB, 4, 1, TR>(x, x_ch, packed, bias, T, H, W, y, y_ch, stream);
+  }
 }
 
 // y [T, H, W, y_channels] = conv3x3(x [T, H, W, x_channels], packed weights) (+ bias [y_channels] float, may be NULL); stride 1,
@@ -645,9 +695,9 @@ extern "C" int ts_conv3x3_rows(const void *x, int32_t x_channels, const void *pa
   _Float16 *yp = (_Float16 *)y;
   const c2_h8 *pp = (const c2_h8 *)packed;
   switch (c2_kb_of(x_channels)) {
-    case 2: return conv3x3_rows_launch<2, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
-    case 4: return conv3x3_rows_launch<4, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
-    default: return conv3x3_rows_launch<6, 2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
+    case 2: return conv3x3_rows_by_blocks<2>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
+    case 4: return conv3x3_rows_by_blocks<4>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
+    default: return conv3x3_rows_by_blocks<6>(xp, x_channels, pp, bias, T, H, W, yp, y_channels, stream);
   }
 }
 

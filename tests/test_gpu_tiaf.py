@@ -267,6 +267,19 @@ def test_conv3x3_rows_general_channels_equals_the_module(shape, c_out, monkeypat
         B.conv3x3_rows(x.detach(), torch.empty(16, dtype=torch.uint8, device="cuda"), None, c_out)
 
 
+def test_conv3x3_rows_with_more_output_blocks_than_a_workgroup_holds():
+    """160 output channels = 5 blocks of 32: two workgroups per tile, the second with one live wave (backend call: unet2d._conv does not
+    route such layers - their weight gradient is not built)"""
+    from taseg_amd import backend as B
+    g = torch.Generator().manual_seed(31)
+    conv = torch.nn.Conv2d(32, 160, 3, padding=1).cuda().half().to(memory_format=torch.channels_last)
+    x = torch.randn(2, 32, 11, 37, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    got = B.conv3x3_rows(x, B.conv3x3_rows_pack(conv.weight.detach(), 0), conv.bias.detach().float(), 160)
+    want = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), padding=1)
+    assert float((got.double() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))
+    assert not B.conv3x3_rows_takes(32, 160)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 19, 45), (1, 32, 3, 5), (3, 32, 64, 96)])
 def test_conv1x1_c32_with_leaky_relu_equals_the_two_modules(shape, monkeypatch):
     """LeakyReLU(Conv2d(32, 32, 1)) as one node (unet2d._conv_act on csrc/conv2d_rows.hip) against the two modules evaluated in float64

@@ -8,7 +8,10 @@ import re
 import sys
 
 FAMILIES = [
-    ("UNet2D convolutions (MIOpen / hipBLASLt / CK)", r"igemm_|^Cijk_|Custom_Cijk|miopenSp3|grouped_conv|naive_conv|batched_transpose|SubTensorOp|gemm_"),
+    ("UNet2D convolutions (ours: csrc/conv2d_rows.hip - 3x3 up to 96 input channels, 1x1 + LeakyReLU, weight + bias gradients)", r"conv3x3|conv1x1"),
+    ("UNet2D LeakyReLU + BatchNorm2d as one node (ours: csrc/bn.hip lbn_*)", r"lbn_"),
+    ("UNet2D PixelShuffle + dropout + concat (ours: csrc/shuffle_cat.hip)", r"shuffle_cat"),
+    ("UNet2D convolutions left on the vendor libraries (MIOpen / hipBLASLt / CK)", r"igemm_|^Cijk_|Custom_Cijk|miopenSp3|grouped_conv|naive_conv|batched_transpose|SubTensorOp|gemm_"),
     ("UNet2D BatchNorm2d (MIOpen / ATen)", r"MIOpenBatchNorm|batch_norm_"),
     ("UNet2D elementwise (ATen: LeakyReLU, add, cat, copies, bias-gradient sums, dropout)", r"at::native::|at_cuda_detail"),
     ("UNet2D average pooling (ours, channels-last)", r"avgpool3s2"),
