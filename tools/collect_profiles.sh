@@ -63,6 +63,12 @@ if [ "$PART" = main ]; then exit 0; fi
 say "side lines"
 for w in "--eval" "--eval --amp" "--workload minkunet_ms" "--amp" "--workload nuscenes_ms --amp" "--workload nuscenes_ms" "--batch 8" "--batch 8 --amp" "--force-dist" "--workload kd" "--workload tiaf --amp" "--workload tiaf" "--batch 12 --amp" "--workload minkunet_ms --history 16 --batch 6 --amp"; do
   tag=$(echo $w | tr -d ' -'); say "bench $w"; python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary > $OUT/bench_$tag.json 2> /dev/null; done
+say "2-D convolution kernels: probe, per-layer table, SQ counters"
+python tools/conv2d_probe.py > $OUT/conv2d_probe.txt 2> /dev/null
+python tools/unet2d_layers.py > $OUT/unet2d_layers.txt 2> /dev/null || true
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_conv2d -o p -- python3 tools/conv2d_probe.py general > /dev/null 2> $OUT/pmc_conv2d.err
+python tools/pmc_conv2d.py $(find $OUT/pmc_conv2d -name "*counter_collection.csv" | head -1) > $OUT/conv3x3_rows_pmc.txt
+rm -rf $OUT/pmc_conv2d
 say "host phases"
 for w in "" "--amp"; do TASEG_BENCH_HOST_PHASES=1 python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes|second stream" | sed "s/^/[bench.py $w] /" >> $OUT/host_phases.txt; done
 for t in 0 1; do TASEG_STAGE_THREAD=$t TASEG_BENCH_HOST_PHASES=1 python bench.py --amp --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes" | sed "s/^/[bench.py --amp, TASEG_STAGE_THREAD=$t] /" >> $OUT/host_phases.txt; done

@@ -44,7 +44,7 @@ def main():
     from taseg_amd.options import options
     with torch.no_grad(), options.override(image_conv_rows=False):
         s = net._encode(x)
-        net._decode_u4(net._decode_u2(*s), s[1])
+        net.classifier(net._decode_u4(net._decode_u2(*s), s[1]))
     for h in hs:
         h.remove()
     del s
