@@ -298,12 +298,13 @@ def tiaf_gather_roofline(model, bd, layout="nhwc", dtype=torch.float32):
     return out
 
 
-def tiaf_phase_table(model, net, opt, make_batch, amp, steps=3):
+def tiaf_phase_table(model, net, opt, make_batch, amp, steps=5):
     """Where a TIAF step's DEVICE time goes, by branch: `steps` further steps after the timed region, staged in line (no
     prefetcher), with HIP events at the branch boundaries - forward hooks around UNet2D (with its gathers) and UNet3D, a tensor hook
     on the gathered image features (their gradient is complete when the sparse branches' backward is: what follows is the gather
     adjoints + UNet2D's backward; the dense image loss's own backward runs first and is counted with the sparse part).
-    Milliseconds per step, averages."""
+    Milliseconds per step, the MEDIAN over the steps (a step of this in-line form now and then carries an allocator growth or a host
+    hiccup inside one phase: with three steps and means one of them moved a phase by 10 ms)."""
     marks_all = []
     cur = {}
 
@@ -361,9 +362,10 @@ def tiaf_phase_table(model, net, opt, make_batch, amp, steps=3):
              ("optimizer (clip + SGD)", "backward_done", "optimizer_done"))
     out = {}
     for name, a, b in spans:
-        vals = [m[a].elapsed_time(m[b]) for m in marks_all if a in m and b in m]
-        out[name] = round(sum(vals) / len(vals), 3) if vals else None
-    out["step (staged in line)"] = round(sum(m["start"].elapsed_time(m["optimizer_done"]) for m in marks_all) / len(marks_all), 3)
+        vals = sorted(m[a].elapsed_time(m[b]) for m in marks_all if a in m and b in m)
+        out[name] = round(vals[len(vals) // 2], 3) if vals else None
+    whole = sorted(m["start"].elapsed_time(m["optimizer_done"]) for m in marks_all)
+    out["step (staged in line)"] = round(whole[len(whole) // 2], 3)
     return out
 
 

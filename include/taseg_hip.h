@@ -431,13 +431,14 @@ int ts_avgpool3s2_rows_backward(const void *grad_y, int32_t T, int32_t H, int32_
 
 /* LeakyReLU -> BatchNorm2d (training) of UNet2D's blocks (unet2d.py:24-30,71,108: `bn(act(conv(x)))`, `nn.LeakyReLU()` slope 0.01) on
  * a channels-last stack seen as rows [N = T*H*W, C]: partial sums -> finish (double) -> elementwise pass, per direction.
- *   forward   out = (leaky(x) - mean) * invstd * weight + bias; mean / invstd [C] (statistics of the ACTIVATED values) kept for the
- *             backward; running_mean / running_var (momentum, unbiased variance) and num_batches_tracked updated when not NULL
+ *   forward   out = (leaky(x) - mean) * invstd * weight + bias (+ residual [N, C], may be NULL: the block's `skip + y`, unet2d.py:31,64);
+ *             mean / invstd [C] (statistics of the ACTIVATED values) kept for the backward; running_mean / running_var (momentum,
+ *             unbiased variance) and num_batches_tracked updated when not NULL
  *   backward  grad_x with respect to the LeakyReLU's input, grad_weight / grad_bias [C] (may be NULL)
  * half != 0: IEEE half rows (C % 8 == 0), else float (C % 4 == 0); C <= 1024; ws >= ts_bn_train_workspace_bytes(c). */
 int ts_leaky_bn_train_forward(const void *x, const float *weight, const float *bias, float *running_mean, float *running_var,
                               int64_t *num_batches_tracked, int64_t n, int32_t c, float eps, float momentum, float slope, int32_t half,
-                              float *mean, float *invstd, void *out, void *ws, size_t ws_bytes, ts_stream_t stream);
+                              float *mean, float *invstd, const void *residual, void *out, void *ws, size_t ws_bytes, ts_stream_t stream);
 int ts_leaky_bn_train_backward(const void *grad_out, const void *x, const float *mean, const float *invstd, const float *weight,
                                int64_t n, int32_t c, float slope, int32_t half, void *grad_x, float *grad_weight, float *grad_bias,
                                void *ws, size_t ws_bytes, ts_stream_t stream);
@@ -738,7 +739,9 @@ void ts_set_conv_impl(int32_t impl);
  *   ts_lovasz_errors  errors[c, p] = |(labels[p] == c) - probas[p, c]| where labels[p] != ignore, else 0 (class-major [C, P])
  *   caller            errors_sorted, perm = sort(errors, dim 1, descending)            (perm int64, as torch.sort returns it)
  *   ts_lovasz_grad    loss[0] = mean over the classes present of dot(errors_sorted_c, lovasz_grad(fg_sorted_c));
- *                     grad_probas[p, c] = d loss / d probas[p, c] (every element written; rows with the ignored label 0)
+ *                     grad_probas[p, c] = d loss / d probas[p, c] (every element written; rows with the ignored label 0), stored
+ *                     [P, C], or [C, P] when class_major != 0 (what ts_ce_lovasz_backward reads: the scatter through perm then
+ *                     stays inside one class's 4 P bytes at a time)
  * probas [P, C] float32 row-major, labels [P] int64 (`ignore` = a value no label takes when nothing is ignored),
  * C <= 64.  ws >= ts_lovasz_workspace_bytes(P, C).  Rows with the ignored label keep their place with zero error and
  * zero foreground (same value as dropping them, no host read of their number). */
@@ -746,7 +749,8 @@ int ts_lovasz_errors(const float *probas, const int64_t *labels, int64_t ignore,
                      float *errors, ts_stream_t stream);
 size_t ts_lovasz_workspace_bytes(int64_t n_points, int32_t n_classes);
 int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, const int64_t *labels, int64_t ignore, int64_t n_points,
-                   int32_t n_classes, float *loss, float *grad_probas, void *ws, size_t ws_bytes, ts_stream_t stream);
+                   int32_t n_classes, float *loss, float *grad_probas, int32_t class_major, void *ws, size_t ws_bytes,
+                   ts_stream_t stream);
 
 /* The segmentors' training loss, CE + Lovasz (R/pcseg/loss/__init__.py:40-44, 118-133: nn.CrossEntropyLoss(ignore_index,
  * label_smoothing) + lovasz_softmax(softmax(logits), ignore)), around the one sort:
@@ -755,8 +759,8 @@ int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, const int64_
  *   ts_ce_lovasz_finish    out4 = { w_ce ce + w_lov lovasz, ce, lovasz, rows that count }; ce = (1 - eps) nll / n + eps smooth / (n C)
  *                          (torch's label-smoothed mean over the rows whose label is not ignored); lovasz = ts_lovasz_grad's
  *                          loss scalar (device pointer) or NULL
- *   ts_ce_lovasz_backward  grad_logits [P, C] from probas, labels, grad_probas (= ts_lovasz_grad's, or NULL) and the
- *                          upstream gradient scalar (device pointer) */
+ *   ts_ce_lovasz_backward  grad_logits [P, C] from probas, labels, grad_probas (= ts_lovasz_grad's in CLASS-MAJOR form [C, P], or
+ *                          NULL) and the upstream gradient scalar (device pointer) */
 int ts_softmax_ce_forward(const float *logits, const int64_t *labels, int64_t ignore, int64_t n_points, int32_t n_classes,
                           float *probas, float *errors, double *partials, ts_stream_t stream);
 int ts_ce_lovasz_finish(const double *partials, int64_t n_points, int32_t n_classes, float smoothing, float w_ce, float w_lov,

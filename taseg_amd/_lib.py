@@ -87,7 +87,7 @@ SIGNATURES = {
     "ts_avgpool3s2_rows_forward": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ts_avgpool3s2_rows_backward": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ts_leaky_bn_train_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _i32, _vp, _vp, _vp,
-                                         _vp, _sz, _vp]),
+                                         _vp, _vp, _sz, _vp]),
     "ts_leaky_bn_train_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _c.c_float, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ts_conv3x3c32_packed_bytes": (_sz, []),
     "ts_conv3x3c32_pack": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
@@ -157,7 +157,7 @@ SIGNATURES = {
     "ts_ce_lovasz_backward": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _vp, _vp]),
     "ts_lovasz_errors": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "ts_lovasz_workspace_bytes": (_sz, [_i64, _i32]),
-    "ts_lovasz_grad": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ts_lovasz_grad": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "ts_conv_split_planes": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ts_conv_split_planes_batch": (_i32, [_vp, _i32, _vp]),
     "ts_cast_weights_f16_batch": (_i32, [_vp, _i32, _vp]),

@@ -945,8 +945,18 @@ def shuffle_cat_rows_backward(grad_cat, channels, scale=None):
     return gx, gs
 
 
+_conv3x3_takes = {}
+
+
 def conv3x3_rows_takes(c_in, c_out):
     """whether csrc/conv2d_rows.hip's general kernel takes a Conv2d(c_in, c_out, 3, padding 1) forward AND backward"""
+    key = (int(c_in), int(c_out))
+    if key not in _conv3x3_takes:
+        _conv3x3_takes[key] = _conv3x3_rows_takes(*key)
+    return _conv3x3_takes[key]
+
+
+def _conv3x3_rows_takes(c_in, c_out):
     lib = L.load()
     return (bool(lib.ts_conv3x3_rows_packed_bytes(int(c_in), int(c_out))) and bool(lib.ts_conv3x3_rows_packed_bytes(int(c_out), int(c_in)))
             and bool(lib.ts_conv3x3_wgrad_workspace_bytes(int(c_in), int(c_out))))

@@ -864,7 +864,7 @@ template <typename T, int VE>
 __global__ __launch_bounds__(256) void lbn_fwd_kernel(const LbnVec<T, VE> *__restrict__ X, const float *__restrict__ mean,
                                                       const float *__restrict__ invstd, const float *__restrict__ w,
                                                       const float *__restrict__ b, float slope, int64_t total, int cq,
-                                                      LbnVec<T, VE> *__restrict__ OUT) {
+                                                      const LbnVec<T, VE> *__restrict__ RES, LbnVec<T, VE> *__restrict__ OUT) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (; e < total; e += step) {
@@ -874,6 +874,11 @@ __global__ __launch_bounds__(256) void lbn_fwd_kernel(const LbnVec<T, VE> *__res
 #pragma unroll
     for (int i = 0; i < VE; ++i)
       y.x[i] = (T)((lbn_leaky((float)x.x[i], slope) - mean[q + i]) * invstd[q + i] * w[q + i] + b[q + i]);
+    if (RES) {                                             // the block's residual sum: added to the ROUNDED result, as the module pair does
+      const LbnVec<T, VE> r = RES[e];
+#pragma unroll
+      for (int i = 0; i < VE; ++i) y.x[i] = (T)((float)y.x[i] + (float)r.x[i]);
+    }
     OUT[e] = y;
   }
 }
@@ -918,7 +923,7 @@ static inline int lbn_rows_per_slice(int64_t n, int c) {
 template <typename T, int VE>
 static void lbn_forward_launch(const void *x, const float *weight, const float *bias, float *running_mean, float *running_var,
                                int64_t *nbt, int64_t n, int c, float eps, float momentum, float slope, float *mean, float *invstd,
-                               void *out, float *part, hipStream_t stream) {
+                               const void *residual, void *out, float *part, hipStream_t stream) {
   const int rows = lbn_rows_per_slice<T, VE>(n, c);
   const int slices = (int)ts_cdiv(n, rows);
   lbn_partial_kernel<T, VE, 0><<<slices, 256, 0, stream>>>((const T *)x, nullptr, nullptr, slope, n, c, rows, part);
@@ -927,7 +932,7 @@ static void lbn_forward_launch(const void *x, const float *weight, const float *
   const int64_t total = n * (c / VE);
   const unsigned grid = (unsigned)std::min<int64_t>(ts_cdiv(total, 256), 1 << 16);
   lbn_fwd_kernel<T, VE><<<grid, 256, 0, stream>>>((const LbnVec<T, VE> *)x, mean, invstd, weight, bias, slope, total, c / VE,
-                                                  (LbnVec<T, VE> *)out);
+                                                  (const LbnVec<T, VE> *)residual, (LbnVec<T, VE> *)out);
 }
 
 template <typename T, int VE>
@@ -946,24 +951,25 @@ static void lbn_backward_launch(const void *grad_out, const void *x, const float
                                                   coef, slope, total, c, (LbnVec<T, VE> *)grad_x);
 }
 
-// out [N, C] = BatchNorm_train(LeakyReLU_slope(x [N, C])); mean / invstd [C] (of the activated values) are kept for the backward;
-// running statistics (may be NULL) and num_batches_tracked (may be NULL) updated as nn.BatchNorm2d does.  half != 0: IEEE half
-// rows.  ws >= ts_bn_train_workspace_bytes(c), every pointer 16-byte aligned.
+// out [N, C] = BatchNorm_train(LeakyReLU_slope(x [N, C])) (+ residual [N, C], may be NULL: the block's `skip + y`, added to the rounded
+// result); mean / invstd [C] (of the activated values) are kept for the backward; running statistics (may be NULL) and
+// num_batches_tracked (may be NULL) updated as nn.BatchNorm2d does.  half != 0: IEEE half rows.
+// ws >= ts_bn_train_workspace_bytes(c), every pointer 16-byte aligned.
 extern "C" int ts_leaky_bn_train_forward(const void *x, const float *weight, const float *bias, float *running_mean, float *running_var,
                                          int64_t *num_batches_tracked, int64_t n, int32_t c, float eps, float momentum, float slope,
-                                         int32_t half, float *mean, float *invstd, void *out, void *ws, size_t ws_bytes,
-                                         ts_stream_t stream_) {
+                                         int32_t half, float *mean, float *invstd, const void *residual, void *out, void *ws,
+                                         size_t ws_bytes, ts_stream_t stream_) {
   const int rc = lbn_check("ts_leaky_bn_train_forward", n, c, half, ws_bytes);
   if (rc != TS_OK) return rc;
   TS_REQUIRE(x && weight && bias && mean && invstd && out && ws, TS_ERR_INVALID_ARGUMENT, "ts_leaky_bn_train_forward: null pointer");
-  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && bn_aligned(ws), TS_ERR_INVALID_ARGUMENT,
+  TS_REQUIRE(bn_aligned(x) && bn_aligned(out) && bn_aligned(ws) && bn_aligned(residual), TS_ERR_INVALID_ARGUMENT,
              "ts_leaky_bn_train_forward: pointers must be 16-byte aligned");
   if (half)
     lbn_forward_launch<_Float16, 8>(x, weight, bias, running_mean, running_var, num_batches_tracked, n, c, eps, momentum, slope, mean,
-                                    invstd, out, (float *)ws, (hipStream_t)stream_);
+                                    invstd, residual, out, (float *)ws, (hipStream_t)stream_);
   else
     lbn_forward_launch<float, 4>(x, weight, bias, running_mean, running_var, num_batches_tracked, n, c, eps, momentum, slope, mean,
-                                 invstd, out, (float *)ws, (hipStream_t)stream_);
+                                 invstd, residual, out, (float *)ws, (hipStream_t)stream_);
   TS_CHECK_LAUNCH("ts_leaky_bn_train_forward");
   return TS_OK;
 }

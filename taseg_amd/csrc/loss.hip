@@ -45,10 +45,24 @@ __device__ __forceinline__ int lv_fg(const int64_t *__restrict__ labels, int64_t
   const int64_t lab = labels[src];
   return (lab != ignore && lab == c) ? 1 : 0;
 }
+// Large clouds (the dense image loss of TIAF: 4.9 M rows x 20 classes): the label of every element of every class row is looked up
+// through the sort permutation - 98 M random reads.  From the int64 labels (39 MB) they miss L2; a byte table (4.9 MB: 255 = ignored /
+// no class) stays in it.  Built once per call in the workspace.
+__device__ __forceinline__ int lv_fg(const uint8_t *__restrict__ labels, int64_t, int64_t src, int c) { return labels[src] == c ? 1 : 0; }
+
+__global__ __launch_bounds__(256) void lovasz_pack_labels_kernel(const int64_t *__restrict__ labels, int64_t ignore, int64_t P,
+                                                                 uint8_t *__restrict__ lab8) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int64_t lab = labels[p];
+  lab8[p] = (lab != ignore && lab >= 0 && lab < 255) ? (uint8_t)lab : (uint8_t)255;
+}
+#define LV_BYTE_LABELS_FROM (1 << 20)   // points from which the byte table is used (below, the int64 labels fit L2 themselves)
 
 // foreground count of every tile of every class
+template <typename LabT>
 __global__ __launch_bounds__(256) void lovasz_tile_count_kernel(const int64_t *__restrict__ perm,
-                                                                const int64_t *__restrict__ labels, int64_t ignore,
+                                                                const LabT *__restrict__ labels, int64_t ignore,
                                                                 int64_t P, int tiles, int *__restrict__ tile_fg) {
   __shared__ int red[4];
   const int c = blockIdx.y, t = blockIdx.x;
@@ -100,12 +114,13 @@ __device__ __forceinline__ float lv_present(const float *__restrict__ gts, int C
 }
 
 // tile-local scan + Lovasz gradient + partial dot product + gradient scatter
+template <typename LabT>
 __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restrict__ errors_sorted,
                                                           const int64_t *__restrict__ perm,
-                                                          const int64_t *__restrict__ labels, int64_t ignore, int64_t P,
+                                                          const LabT *__restrict__ labels, int64_t ignore, int64_t P,
                                                           int C, int tiles, const int *__restrict__ tile_base,
                                                           const float *__restrict__ gts,
-                                                          float *__restrict__ tile_loss, float *__restrict__ dprob) {
+                                                          float *__restrict__ tile_loss, float *__restrict__ dprob, int class_major) {
   __shared__ int wsum[4];
   __shared__ float wred[4];
   const int c = blockIdx.y, t = blockIdx.x;
@@ -150,7 +165,10 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restric
       const float gr = j_i - j_p;
       part += es[u] * gr;
       const float sign = es[u] > 0.f ? (fg[u] ? -1.f : 1.f) : 0.f;
-      dprob[src[u] * C + c] = sign * gr * scale;
+      // the scatter through the sort permutation: 4-byte writes at random rows.  Row-major [P, C] they are spread over the whole
+      // array (393 MB for TIAF's dense image loss: each a read-modify-write of a 64-byte sector in HBM, 3.1 ms); class-major
+      // [C, P] the class in flight writes one 4 P-byte slab, which the memory-side cache holds
+      dprob[class_major ? (int64_t)c * P + src[u] : src[u] * C + c] = sign * gr * scale;
     }
   }
 #pragma unroll
@@ -188,13 +206,14 @@ __global__ __launch_bounds__(1024) void lovasz_finish_kernel(const float *__rest
 
 extern "C" size_t ts_lovasz_workspace_bytes(int64_t n_points, int32_t n_classes) {
   const size_t tiles = (size_t)ts_cdiv(std::max<int64_t>(n_points, 1), LV_TILE);
-  return ts_align_up(tiles * n_classes * 4, 256) * 2 + ts_align_up((size_t)n_classes * 4 + 4, 256);
+  return ts_align_up(tiles * n_classes * 4, 256) * 2 + ts_align_up((size_t)n_classes * 4 + 4, 256) +
+         (n_points >= LV_BYTE_LABELS_FROM ? ts_align_up((size_t)n_points, 256) : 0);
 }
 
-// errors_sorted / perm [C, P] = sort(errors, descending) of ts_lovasz_errors' output; loss [1]; grad_probas [P, C]
-// (every element written).  ws >= ts_lovasz_workspace_bytes.
+// errors_sorted / perm [C, P] = sort(errors, descending) of ts_lovasz_errors' output; loss [1]; grad_probas [P, C], or [C, P] with
+// class_major != 0 (every element written).  ws >= ts_lovasz_workspace_bytes.
 extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, const int64_t *labels, int64_t ignore,
-                              int64_t n_points, int32_t n_classes, float *loss, float *grad_probas, void *ws,
+                              int64_t n_points, int32_t n_classes, float *loss, float *grad_probas, int32_t class_major, void *ws,
                               size_t ws_bytes, ts_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TS_REQUIRE(n_points > 0 && n_classes > 0 && n_classes <= 64, TS_ERR_INVALID_ARGUMENT,
@@ -210,11 +229,21 @@ extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, c
   float *tile_loss = (float *)p;
   p += ts_align_up((size_t)tiles * n_classes * 4, 256);
   float *gts = (float *)p;
+  p += ts_align_up((size_t)n_classes * 4 + 4, 256);
   dim3 grid((unsigned)tiles, (unsigned)n_classes);
-  lovasz_tile_count_kernel<<<grid, 256, 0, stream>>>(perm, labels, ignore, n_points, tiles, tile_fg);
-  lovasz_tile_scan_kernel<<<n_classes, 256, 0, stream>>>(tile_fg, tiles, gts);
-  lovasz_grad_kernel<<<grid, 256, 0, stream>>>(errors_sorted, perm, labels, ignore, n_points, n_classes, tiles, tile_fg,
-                                               gts, tile_loss, grad_probas);
+  if (n_points >= LV_BYTE_LABELS_FROM) {
+    uint8_t *lab8 = (uint8_t *)p;
+    lovasz_pack_labels_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, stream>>>(labels, ignore, n_points, lab8);
+    lovasz_tile_count_kernel<uint8_t><<<grid, 256, 0, stream>>>(perm, lab8, ignore, n_points, tiles, tile_fg);
+    lovasz_tile_scan_kernel<<<n_classes, 256, 0, stream>>>(tile_fg, tiles, gts);
+    lovasz_grad_kernel<uint8_t><<<grid, 256, 0, stream>>>(errors_sorted, perm, lab8, ignore, n_points, n_classes, tiles, tile_fg, gts,
+                                                          tile_loss, grad_probas, class_major);
+  } else {
+    lovasz_tile_count_kernel<int64_t><<<grid, 256, 0, stream>>>(perm, labels, ignore, n_points, tiles, tile_fg);
+    lovasz_tile_scan_kernel<<<n_classes, 256, 0, stream>>>(tile_fg, tiles, gts);
+    lovasz_grad_kernel<int64_t><<<grid, 256, 0, stream>>>(errors_sorted, perm, labels, ignore, n_points, n_classes, tiles, tile_fg, gts,
+                                                          tile_loss, grad_probas, class_major);
+  }
   lovasz_finish_kernel<<<1, 1024, 0, stream>>>(tile_loss, gts, n_classes, tiles, loss);
   TS_CHECK_LAUNCH("ts_lovasz_grad");
   return TS_OK;
@@ -231,27 +260,51 @@ extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, c
 // C <= 32; one thread per row.
 #define CE_MAXC 32
 
+// A workgroup's 256 rows are one contiguous piece of a [P, C] array: it moves between HBM and LDS as whole 256-byte wave rows
+// (lane = consecutive float) and a thread reads / writes ITS row in LDS (pitch C | 1: odd, no bank conflicts).  One thread per row
+// straight from global memory - lanes 4 C bytes apart - ran at 0.8 TB/s on the dense image loss of TIAF (4.9 M rows).
+// CT: the class count at compile time (0: any count up to 32 at run time).
+#define CE_ROWS 256
+template <int CT>
+__device__ __forceinline__ void ce_rows_in(const float *__restrict__ g, int n, int C, float *__restrict__ tile) {
+  const int Cc = CT ? CT : C, pitch = Cc | 1;
+  for (int i = threadIdx.x; i < n; i += CE_ROWS) tile[(i / Cc) * pitch + i % Cc] = g[i];
+}
+template <int CT>
+__device__ __forceinline__ void ce_rows_out(const float *__restrict__ tile, int n, int C, float *__restrict__ g) {
+  const int Cc = CT ? CT : C, pitch = Cc | 1;
+  for (int i = threadIdx.x; i < n; i += CE_ROWS) g[i] = tile[(i / Cc) * pitch + i % Cc];
+}
+
+template <int CT>
 __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float *__restrict__ logits,
                                                              const int64_t *__restrict__ labels, int64_t ignore,
-                                                             int64_t P, int C, float *__restrict__ probas,
+                                                             int64_t P, int C_, float *__restrict__ probas,
                                                              float *__restrict__ err, double *__restrict__ part) {
+  __shared__ float tile[CE_ROWS * (CE_MAXC + 1)];
   __shared__ double red[3][4];
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int C = CT ? CT : C_, pitch = C | 1;
+  const int64_t row0 = (int64_t)blockIdx.x * CE_ROWS;
+  const int rows = (int)min((int64_t)CE_ROWS, P - row0);
+  ce_rows_in<CT>(logits + row0 * C, rows * C, C, tile);
+  __syncthreads();
+  const int64_t p = row0 + threadIdx.x;
+  float *mine = tile + threadIdx.x * pitch;
   double nll = 0.0, smooth = 0.0, cnt = 0.0;
   if (p < P) {
-    float v[CE_MAXC];
+    float v[CE_MAXC], raw[CE_MAXC];
     float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CE_MAXC; ++c)
       if (c < C) {
-        v[c] = logits[p * C + c];
-        mx = fmaxf(mx, v[c]);
+        raw[c] = mine[c];
+        mx = fmaxf(mx, raw[c]);
       }
     float se = 0.f;
 #pragma unroll
     for (int c = 0; c < CE_MAXC; ++c)
       if (c < C) {
-        v[c] = expf(v[c] - mx);
+        v[c] = expf(raw[c] - mx);
         se += v[c];
       }
     const float lse = logf(se), inv = 1.f / se;
@@ -261,11 +314,11 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float *__rest
 #pragma unroll
     for (int c = 0; c < CE_MAXC; ++c)
       if (c < C) {
-        const float lp = (logits[p * C + c] - mx) - lse;
+        const float lp = (raw[c] - mx) - lse;
         sum_logp += lp;
         if (lab == c) picked = lp;
         const float pr = v[c] * inv;
-        probas[p * C + c] = pr;
+        mine[c] = pr;                                      // (this thread's row: leaves with the workgroup below)
         const float fg = (valid && lab == c) ? 1.f : 0.f;
         err[(int64_t)c * P + p] = valid ? fabsf(fg - pr) : 0.f;
       }
@@ -278,6 +331,8 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float *__rest
       cnt = 1.0;
     }
   }
+  __syncthreads();
+  ce_rows_out<CT>(tile, rows * C, C, probas + row0 * C);
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     nll += __shfl_down(nll, d, 64);
@@ -300,8 +355,15 @@ extern "C" int ts_softmax_ce_forward(const float *logits, const int64_t *labels,
   TS_REQUIRE(n_points > 0 && n_classes > 0 && n_classes <= CE_MAXC, TS_ERR_INVALID_ARGUMENT,
              "ts_softmax_ce_forward: need points and 1 .. 32 classes");
   TS_REQUIRE(logits && labels && probas && errors && partials, TS_ERR_INVALID_ARGUMENT, "ts_softmax_ce_forward: null pointer");
-  softmax_ce_fwd_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, (hipStream_t)stream>>>(logits, labels, ignore, n_points,
-                                                                                           n_classes, probas, errors, partials);
+  const unsigned grid = (unsigned)ts_cdiv(n_points, CE_ROWS);
+#define CE_FWD(CT_) softmax_ce_fwd_kernel<CT_><<<grid, 256, 0, (hipStream_t)stream>>>(logits, labels, ignore, n_points, n_classes, probas, errors, partials)
+  switch (n_classes) {            // (the class counts of the reference's configurations at compile time: divisions by a constant)
+    case 20: CE_FWD(20); break;
+    case 19: CE_FWD(19); break;
+    case 17: CE_FWD(17); break;
+    default: CE_FWD(0);
+  }
+#undef CE_FWD
   TS_CHECK_LAUNCH("ts_softmax_ce_forward");
   return TS_OK;
 }
@@ -347,38 +409,53 @@ extern "C" int ts_ce_lovasz_finish(const double *partials, int64_t n_points, int
   return TS_OK;
 }
 
+template <int CT>
 __global__ __launch_bounds__(256) void ce_lovasz_bwd_kernel(const float *__restrict__ probas,
                                                             const int64_t *__restrict__ labels, int64_t ignore,
                                                             const float *__restrict__ dprob, const float *__restrict__ out4,
-                                                            const float *__restrict__ grad_out, int64_t P, int C,
+                                                            const float *__restrict__ grad_out, int64_t P, int C_,
                                                             float smoothing, float w_ce, float w_lov,
                                                             float *__restrict__ dlogits) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  const float go = *grad_out;
-  const float n = out4[3];
-  const int64_t lab = labels[p];
-  const float kce = (lab != ignore) ? go * w_ce / n : 0.f;
+  __shared__ float tile[CE_ROWS * (CE_MAXC + 1)];
+  const int C = CT ? CT : C_, pitch = C | 1;
+  const int64_t row0 = (int64_t)blockIdx.x * CE_ROWS;
+  const int rows = (int)min((int64_t)CE_ROWS, P - row0);
+  const int64_t p = row0 + threadIdx.x;
+  float *mine = tile + threadIdx.x * pitch;
   float pr[CE_MAXC], dp[CE_MAXC];
-  float dot = 0.f;
+  // probas in and the result out through the LDS image (see softmax_ce_fwd_kernel)
+  ce_rows_in<CT>(probas + row0 * C, rows * C, C, tile);
+  __syncthreads();
 #pragma unroll
   for (int c = 0; c < CE_MAXC; ++c)
+    if (c < C) pr[c] = p < P ? mine[c] : 0.f;
+  __syncthreads();
+  float dot = 0.f;                                         // d lovasz / d probas: CLASS-major [C, P] (ts_lovasz_grad with class_major):
+#pragma unroll                                             // lane = consecutive row, a coalesced read per class
+  for (int c = 0; c < CE_MAXC; ++c)
     if (c < C) {
-      pr[c] = probas[p * C + c];
-      dp[c] = dprob ? dprob[p * C + c] : 0.f;
+      dp[c] = (dprob && p < P) ? dprob[(int64_t)c * P + p] : 0.f;
       dot += pr[c] * dp[c];
     }
-  const float klov = go * w_lov, invc = 1.f / (float)C;
+  if (p < P) {
+    const float go = *grad_out;
+    const float n = out4[3];
+    const int64_t lab = labels[p];
+    const float kce = (lab != ignore) ? go * w_ce / n : 0.f;
+    const float klov = go * w_lov, invc = 1.f / (float)C;
 #pragma unroll
-  for (int c = 0; c < CE_MAXC; ++c)
-    if (c < C) {
-      const float onehot = lab == c ? 1.f : 0.f;
-      const float ce = (1.f - smoothing) * (pr[c] - onehot) + smoothing * (pr[c] - invc);
-      // a label outside [0, C) that is not the ignore index poisons the row's gradient like it poisons the forward loss (the
-      // reference device-asserts, R/pcseg/loss/__init__.py:40-44 -> F.cross_entropy): the optimizer must not step on it
-      const bool bad = lab != ignore && (lab < 0 || lab >= C);
-      dlogits[p * C + c] = bad ? __builtin_nanf("") : kce * ce + klov * pr[c] * (dp[c] - dot);
-    }
+    for (int c = 0; c < CE_MAXC; ++c)
+      if (c < C) {
+        const float onehot = lab == c ? 1.f : 0.f;
+        const float ce = (1.f - smoothing) * (pr[c] - onehot) + smoothing * (pr[c] - invc);
+        // a label outside [0, C) that is not the ignore index poisons the row's gradient like it poisons the forward loss (the
+        // reference device-asserts, R/pcseg/loss/__init__.py:40-44 -> F.cross_entropy): the optimizer must not step on it
+        const bool bad = lab != ignore && (lab < 0 || lab >= C);
+        mine[c] = bad ? __builtin_nanf("") : kce * ce + klov * pr[c] * (dp[c] - dot);
+      }
+  }
+  __syncthreads();
+  ce_rows_out<CT>(tile, rows * C, C, dlogits + row0 * C);
 }
 
 extern "C" int ts_ce_lovasz_backward(const float *probas, const int64_t *labels, int64_t ignore, const float *grad_probas,
@@ -387,8 +464,15 @@ extern "C" int ts_ce_lovasz_backward(const float *probas, const int64_t *labels,
   TS_REQUIRE(n_points > 0 && n_classes > 0 && n_classes <= CE_MAXC, TS_ERR_INVALID_ARGUMENT,
              "ts_ce_lovasz_backward: need points and 1 .. 32 classes");
   TS_REQUIRE(probas && labels && out4 && grad_out && grad_logits, TS_ERR_INVALID_ARGUMENT, "ts_ce_lovasz_backward: null pointer");
-  ce_lovasz_bwd_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, (hipStream_t)stream>>>(
-      probas, labels, ignore, grad_probas, out4, grad_out, n_points, n_classes, smoothing, w_ce, w_lov, grad_logits);
+  const unsigned grid = (unsigned)ts_cdiv(n_points, CE_ROWS);
+#define CE_BWD(CT_) ce_lovasz_bwd_kernel<CT_><<<grid, 256, 0, (hipStream_t)stream>>>(probas, labels, ignore, grad_probas, out4, grad_out, n_points, n_classes, smoothing, w_ce, w_lov, grad_logits)
+  switch (n_classes) {
+    case 20: CE_BWD(20); break;
+    case 19: CE_BWD(19); break;
+    case 17: CE_BWD(17); break;
+    default: CE_BWD(0);
+  }
+#undef CE_BWD
   TS_CHECK_LAUNCH("ts_ce_lovasz_backward");
   return TS_OK;
 }

@@ -38,9 +38,9 @@ class _CeLovasz(torch.autograd.Function):
                                           L.stream()), "ts_softmax_ce_forward")
         es, perm = torch.sort(err, dim=1, descending=True)
         lov = torch.empty(1, dtype=torch.float32, device=dev)
-        dprob = torch.empty((p, c), dtype=torch.float32, device=dev)
+        dprob = torch.empty((c, p), dtype=torch.float32, device=dev)          # class-major: what the backward kernel reads
         ws = L.workspace(lib.ts_lovasz_workspace_bytes(p, c), dev)
-        L.check(lib.ts_lovasz_grad(L.ptr(es), L.ptr(perm), L.ptr(lab), ign, p, c, L.ptr(lov), L.ptr(dprob), L.ptr(ws),
+        L.check(lib.ts_lovasz_grad(L.ptr(es), L.ptr(perm), L.ptr(lab), ign, p, c, L.ptr(lov), L.ptr(dprob), 1, L.ptr(ws),
                                    ws.numel(), L.stream()), "ts_lovasz_grad")
         out4 = torch.empty(4, dtype=torch.float32, device=dev)
         L.check(lib.ts_ce_lovasz_finish(L.ptr(partials), p, c, float(smoothing), float(w_ce), float(w_lov), L.ptr(lov),

@@ -35,7 +35,7 @@ class _LovaszPresent(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=prob.device)
         dprob = torch.empty((p, c), dtype=torch.float32, device=prob.device)
         ws = L.workspace(lib.ts_lovasz_workspace_bytes(p, c), prob.device)
-        L.check(lib.ts_lovasz_grad(L.ptr(es), L.ptr(perm), L.ptr(lab), ign, p, c, L.ptr(loss), L.ptr(dprob), L.ptr(ws),
+        L.check(lib.ts_lovasz_grad(L.ptr(es), L.ptr(perm), L.ptr(lab), ign, p, c, L.ptr(loss), L.ptr(dprob), 0, L.ptr(ws),
                                    ws.numel(), L.stream()), "ts_lovasz_grad")
         ctx.save_for_backward(dprob)
         ctx.in_dtype = probas.dtype

@@ -140,7 +140,7 @@ class _LeakyBatchNormRows(Function):
     ts_leaky_bn_train_*): x - the convolution's output - is what is kept for the backward pass, the activated map never exists"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, eps, momentum, slope, residual=None):
         t, c, h, w = x.shape
         n = t * h * w
         half = x.dtype == torch.float16
@@ -150,13 +150,13 @@ class _LeakyBatchNormRows(Function):
         ws = B.L.workspace(lib.ts_bn_train_workspace_bytes(c), x.device)
         B.L.check(lib.ts_leaky_bn_train_forward(B.L.ptr(x), B.L.ptr(weight), B.L.ptr(bias), B.L.ptr(running_mean), B.L.ptr(running_var),
                                                 B.L.ptr(nbt), n, c, float(eps), float(momentum), float(slope), 1 if half else 0,
-                                                B.L.ptr(stats[0]), B.L.ptr(stats[1]), B.L.ptr(out), B.L.ptr(ws), ws.numel(), B.L.stream()),
-                  "ts_leaky_bn_train_forward")
+                                                B.L.ptr(stats[0]), B.L.ptr(stats[1]), B.L.ptr(residual), B.L.ptr(out), B.L.ptr(ws), ws.numel(),
+                                                B.L.stream()), "ts_leaky_bn_train_forward")
         for buf in (running_mean, running_var, nbt):      # written through raw pointers: move their version counters
             if buf is not None:
                 torch.autograd.graph.increment_version(buf)
         ctx.save_for_backward(x, weight, stats)
-        ctx.slope = float(slope)
+        ctx.slope, ctx.with_residual = float(slope), residual is not None
         return out
 
     @staticmethod
@@ -172,13 +172,16 @@ class _LeakyBatchNormRows(Function):
                                                  t * h * w, c, ctx.slope, 1 if x.dtype == torch.float16 else 0, B.L.ptr(grad_x),
                                                  B.L.ptr(gwb[0]), B.L.ptr(gwb[1]), B.L.ptr(ws), ws.numel(), B.L.stream()),
                   "ts_leaky_bn_train_backward")
-        return grad_x, gwb[0].to(weight.dtype), gwb[1].to(weight.dtype), None, None, None, None, None, None
+        # (the residual's gradient is the node's own incoming gradient: the sum's other branch)
+        return (grad_x, gwb[0].to(weight.dtype), gwb[1].to(weight.dtype), None, None, None, None, None, None,
+                grad_out if ctx.with_residual else None)
 
 
-def _act_bn(act, bn, x):
-    """bn(act(x)) of a block (unet2d.py:24-30,71,108).  Training-mode BatchNorm2d behind a LeakyReLU on a channels-last device map
-    goes through ONE fused node; anything else - evaluation mode, other layouts / dtypes, modules with hooks, options.image_fused_bn
-    off - is the two modules themselves."""
+def _act_bn(act, bn, x, residual=None):
+    """bn(act(x)) of a block (unet2d.py:24-30,71,108), plus the block's residual sum (`skip + y`, unet2d.py:31,64) when given.
+    Training-mode BatchNorm2d behind a LeakyReLU on a channels-last device map goes through ONE fused node - the residual added in its
+    elementwise pass; anything else - evaluation mode, other layouts / dtypes, modules with hooks, options.image_fused_bn off - is the
+    modules themselves."""
     c = x.shape[1] if x.dim() == 4 else 0
     if (options.image_fused_bn and bn.training and x.is_cuda and x.dim() == 4 and isinstance(act, nn.LeakyReLU) and type(bn) is nn.BatchNorm2d
             and bn.affine and bn.track_running_stats and bn.momentum is not None and x.dtype in (torch.float32, torch.float16)
@@ -186,9 +189,13 @@ def _act_bn(act, bn, x):
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
             and not (act._forward_hooks or act._forward_pre_hooks or act._backward_hooks or bn._forward_hooks or bn._forward_pre_hooks
                      or bn._backward_hooks)):
+        if residual is not None and not (residual.shape == x.shape and residual.dtype == x.dtype
+                                         and residual.is_contiguous(memory_format=torch.channels_last)):
+            return residual + _act_bn(act, bn, x)
         return _LeakyBatchNormRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                                         bn.momentum, act.negative_slope)
-    return bn(act(x))
+                                         bn.momentum, act.negative_slope, residual)
+    y = bn(act(x))
+    return y if residual is None else residual + y
 
 
 class _Conv3x3C32Rows(Function):
@@ -346,8 +353,7 @@ class ResContextBlock(nn.Module):
     def forward(self, x):
         skip = _conv_act(self.conv1, self.act1, x)
         y = _act_bn(self.act2, self.bn1, _conv(self.conv2, skip))
-        y = _act_bn(self.act3, self.bn2, _conv(self.conv3, y))
-        return skip + y
+        return _act_bn(self.act3, self.bn2, _conv(self.conv3, y), residual=skip)
 
 
 class ResBlock(nn.Module):
@@ -367,7 +373,7 @@ class ResBlock(nn.Module):
             self.pool = nn.AvgPool2d(kernel_size=kernel_size, stride=2, padding=1)
 
     def forward(self, x):
-        res = _conv_act(self.conv1, self.act1, x) + _act_bn(self.act2, self.bn1, _conv(self.conv2, x))
+        res = _act_bn(self.act2, self.bn1, _conv(self.conv2, x), residual=_conv_act(self.conv1, self.act1, x))
         out = self.dropout(res) if self.drop_out else res
         if not self.pooling:
             return out

@@ -1017,11 +1017,12 @@ def test_devoxelize_backward_cell_reduced(B, F, stride, c):
     close(B.devoxelize_backward_csr(g[:, 32:].contiguous(), w, plan, m), ref, 2e-5)
 
 
-@pytest.mark.parametrize("p,c,ignore", [(70001, 20, 0), (4099, 17, 0), (1000, 20, None), (50000, 5, 3)])
+@pytest.mark.parametrize("p,c,ignore", [(70001, 20, 0), (4099, 17, 0), (1000, 20, None), (50000, 5, 3), (1200003, 20, 0)])
 def test_lovasz_kernels_match_the_tensor_form_and_the_oracle(p, c, ignore):
     """csrc/loss.hip (ts_lovasz_errors -> sort -> ts_lovasz_grad) against taseg_amd.pcseg.loss.lovasz.lovasz_softmax_flat
     (torch ops) and the oracle's per-class loop (the reference's lovasz_losses.py restated): value and gradient, classes that
-    do not occur, ignored rows, a tile boundary inside the rows."""
+    do not occur, ignored rows, a tile boundary inside the rows; 1.2 M rows: the byte label table of the large calls (the dense image
+    loss of TIAF)."""
     from oracle import model as OM
     from taseg_amd.pcseg.loss import lovasz as LV
     rs = np.random.RandomState(p + c)

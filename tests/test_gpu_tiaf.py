@@ -192,9 +192,20 @@ def test_fused_leaky_relu_batch_norm_equals_the_two_modules(shape, dtype):
     assert int(ours.num_batches_tracked) == 1
     assert torch.allclose(ours.running_mean.double(), ref.running_mean, rtol=1e-4, atol=1e-5)
     assert torch.allclose(ours.running_var.double(), ref.running_var, rtol=1e-3 if dtype == torch.float16 else 1e-4, atol=1e-5)
+    # the block's residual sum in the same pass (unet2d.py:31,64): bit-equal to adding it to the node's own result, its gradient the
+    # node's incoming gradient
+    r = torch.randn(*shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    before = ours.running_mean.clone()
+    with_res = _act_bn(act, ours, a, residual=r)
+    with torch.no_grad():
+        ours.running_mean.copy_(before)
+    assert with_res.grad_fn.__class__.__name__.startswith("_LeakyBatchNormRows") and torch.equal(with_res, out + r)
+    gr, ga3 = torch.autograd.grad((with_res.float() * wt).sum(), (r, a))
+    assert torch.equal(gr, wt.to(dtype)) and torch.equal(ga3, ga)
+    assert _act_bn(act, ours, a, residual=r.detach().float() if dtype == torch.float16 else r.detach().half()).grad_fn.__class__.__name__ == "AddBackward0"
     # evaluation mode / a contiguous map / a hooked module: the modules themselves
     ours.eval()
-    assert torch.equal(_act_bn(act, ours, x), ours(act(x)))
+    assert torch.equal(_act_bn(act, ours, x), ours(act(x))) and torch.equal(_act_bn(act, ours, x, residual=r.detach()), r.detach() + ours(act(x)))
 
 
 @pytest.mark.parametrize("dilation", [1, 2])

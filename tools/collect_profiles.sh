@@ -42,7 +42,7 @@ trace fsa16_bs6_amp "minkunet_ms amp bs6 history16" sgd_decide_kernel 10 --workl
 trace kd "kd" sgd_decide_kernel 10 --workload kd --steps 10 --warmup 3
 python bench.py --workload tiaf --amp --steps 2 --warmup 1 > /dev/null 2>&1      # (MIOpen's kernels of this process tree compiled before the trace)
 trace tiaf_amp "tiaf amp" sgd_decide_kernel 6 --workload tiaf --amp --steps 6 --warmup 2 --no-wgrad-tune
-python tools/tiaf_families.py $OUT/tiaf_amp_kernel_stats.csv 11 > $OUT/tiaf_amp_families.txt     # 2 + 6 timed + 3 phase-table steps in the trace
+python tools/tiaf_families.py $OUT/tiaf_amp_kernel_stats.csv 13 > $OUT/tiaf_amp_families.txt     # 2 + 6 timed + 5 phase-table steps in the trace
 trace eval "eval minkunet" "unvoxelise_kernel" 40 --eval --steps 40 --warmup 8
 trace evalamp "eval minkunet amp" "unvoxelise_kernel" 40 --eval --amp --steps 40 --warmup 8
 echo "  \"_source\": \"rocprofv3 --kernel-trace of the tree, kernels of all streams inside the timed steps (tools/stream_busy.py)\"" >> $OUT/launches.json
