@@ -14,7 +14,8 @@
 // is fixed (tile by tile), so the value is run-to-run deterministic.
 #include "common.h"
 
-#define LV_TILE 1024          // elements per workgroup (256 threads x 4)
+#define LV_TILE 1024          // elements per workgroup (256 threads x 4); LV_BIG x as many in the calls with the byte label table
+#define LV_BIG_PER 2      // elements per thread in the large calls
 
 __global__ __launch_bounds__(256) void lovasz_errors_kernel(const float *__restrict__ probas,
                                                             const int64_t *__restrict__ labels, int64_t ignore,
@@ -60,16 +61,16 @@ __global__ __launch_bounds__(256) void lovasz_pack_labels_kernel(const int64_t *
 #define LV_BYTE_LABELS_FROM (1 << 20)   // points from which the byte table is used (below, the int64 labels fit L2 themselves)
 
 // foreground count of every tile of every class
-template <typename LabT>
+template <typename LabT, int PER>
 __global__ __launch_bounds__(256) void lovasz_tile_count_kernel(const int64_t *__restrict__ perm,
                                                                 const LabT *__restrict__ labels, int64_t ignore,
                                                                 int64_t P, int tiles, int *__restrict__ tile_fg) {
   __shared__ int red[4];
   const int c = blockIdx.y, t = blockIdx.x;
-  const int64_t base = (int64_t)t * LV_TILE + threadIdx.x * 4;
+  const int64_t base = (int64_t)t * (256 * PER) + threadIdx.x * PER;
   int cnt = 0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < PER; ++u)
     if (base + u < P) cnt += lv_fg(labels, ignore, perm[(int64_t)c * P + base + u], c);
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
@@ -114,7 +115,7 @@ __device__ __forceinline__ float lv_present(const float *__restrict__ gts, int C
 }
 
 // tile-local scan + Lovasz gradient + partial dot product + gradient scatter
-template <typename LabT>
+template <typename LabT, int PER>
 __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restrict__ errors_sorted,
                                                           const int64_t *__restrict__ perm,
                                                           const LabT *__restrict__ labels, int64_t ignore, int64_t P,
@@ -124,13 +125,13 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restric
   __shared__ int wsum[4];
   __shared__ float wred[4];
   const int c = blockIdx.y, t = blockIdx.x;
-  const int64_t i0 = (int64_t)t * LV_TILE + threadIdx.x * 4;
-  int64_t src[4];
-  int fg[4];
-  float es[4];
+  const int64_t i0 = (int64_t)t * (256 * PER) + threadIdx.x * PER;
+  int64_t src[PER];
+  int fg[PER];
+  float es[PER];
   int mine = 0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < PER; ++u) {
     const bool in = i0 + u < P;
     src[u] = in ? perm[(int64_t)c * P + i0 + u] : 0;
     fg[u] = in ? lv_fg(labels, ignore, src[u], c) : 0;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float *__restric
   const float scale = (g > 0.f && np > 0.f) ? 1.f / np : 0.f;     // present_c / #present
   float part = 0.f;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < PER; ++u) {
     if (i0 + u < P) {
       const float rank = (float)(i0 + u + 1);
       const float cum_prev = (float)cum;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(1024) void lovasz_finish_kernel(const float *__rest
 }
 
 extern "C" size_t ts_lovasz_workspace_bytes(int64_t n_points, int32_t n_classes) {
-  const size_t tiles = (size_t)ts_cdiv(std::max<int64_t>(n_points, 1), LV_TILE);
+  const size_t tiles = (size_t)ts_cdiv(std::max<int64_t>(n_points, 1), 256 * LV_BIG_PER < LV_TILE ? 256 * LV_BIG_PER : LV_TILE);
   return ts_align_up(tiles * n_classes * 4, 256) * 2 + ts_align_up((size_t)n_classes * 4 + 4, 256) +
          (n_points >= LV_BYTE_LABELS_FROM ? ts_align_up((size_t)n_points, 256) : 0);
 }
@@ -222,7 +223,8 @@ extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, c
              "ts_lovasz_grad: null pointer");
   TS_REQUIRE(ws_bytes >= ts_lovasz_workspace_bytes(n_points, n_classes), TS_ERR_INVALID_ARGUMENT,
              "ts_lovasz_grad: workspace too small");
-  const int tiles = (int)ts_cdiv(n_points, LV_TILE);
+  const bool big = n_points >= LV_BYTE_LABELS_FROM;
+  const int tiles = (int)ts_cdiv(n_points, big ? 256 * LV_BIG_PER : LV_TILE);
   char *p = (char *)ws;
   int *tile_fg = (int *)p;
   p += ts_align_up((size_t)tiles * n_classes * 4, 256);
@@ -231,17 +233,17 @@ extern "C" int ts_lovasz_grad(const float *errors_sorted, const int64_t *perm, c
   float *gts = (float *)p;
   p += ts_align_up((size_t)n_classes * 4 + 4, 256);
   dim3 grid((unsigned)tiles, (unsigned)n_classes);
-  if (n_points >= LV_BYTE_LABELS_FROM) {
+  if (big) {
     uint8_t *lab8 = (uint8_t *)p;
     lovasz_pack_labels_kernel<<<(unsigned)ts_cdiv(n_points, 256), 256, 0, stream>>>(labels, ignore, n_points, lab8);
-    lovasz_tile_count_kernel<uint8_t><<<grid, 256, 0, stream>>>(perm, lab8, ignore, n_points, tiles, tile_fg);
+    lovasz_tile_count_kernel<uint8_t, LV_BIG_PER><<<grid, 256, 0, stream>>>(perm, lab8, ignore, n_points, tiles, tile_fg);
     lovasz_tile_scan_kernel<<<n_classes, 256, 0, stream>>>(tile_fg, tiles, gts);
-    lovasz_grad_kernel<uint8_t><<<grid, 256, 0, stream>>>(errors_sorted, perm, lab8, ignore, n_points, n_classes, tiles, tile_fg, gts,
+    lovasz_grad_kernel<uint8_t, LV_BIG_PER><<<grid, 256, 0, stream>>>(errors_sorted, perm, lab8, ignore, n_points, n_classes, tiles, tile_fg, gts,
                                                           tile_loss, grad_probas, class_major);
   } else {
-    lovasz_tile_count_kernel<int64_t><<<grid, 256, 0, stream>>>(perm, labels, ignore, n_points, tiles, tile_fg);
+    lovasz_tile_count_kernel<int64_t, 4><<<grid, 256, 0, stream>>>(perm, labels, ignore, n_points, tiles, tile_fg);
     lovasz_tile_scan_kernel<<<n_classes, 256, 0, stream>>>(tile_fg, tiles, gts);
-    lovasz_grad_kernel<int64_t><<<grid, 256, 0, stream>>>(errors_sorted, perm, labels, ignore, n_points, n_classes, tiles, tile_fg, gts,
+    lovasz_grad_kernel<int64_t, 4><<<grid, 256, 0, stream>>>(errors_sorted, perm, labels, ignore, n_points, n_classes, tiles, tile_fg, gts,
                                                           tile_loss, grad_probas, class_major);
   }
   lovasz_finish_kernel<<<1, 1024, 0, stream>>>(tile_loss, gts, n_classes, tiles, loss);
