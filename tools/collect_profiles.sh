@@ -69,6 +69,11 @@ python tools/unet2d_layers.py > $OUT/unet2d_layers.txt 2> /dev/null || true
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_conv2d -o p -- python3 tools/conv2d_probe.py general > /dev/null 2> $OUT/pmc_conv2d.err
 python tools/pmc_conv2d.py $(find $OUT/pmc_conv2d -name "*counter_collection.csv" | head -1) > $OUT/conv3x3_rows_pmc.txt
 rm -rf $OUT/pmc_conv2d
+say "dense-loss probe"
+python tools/loss_probe.py > $OUT/loss_probe.txt 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_loss -- python3 tools/loss_probe.py > /dev/null 2> $OUT/trace_loss.err
+python tools/kstats.py $OUT/trace_loss 7 12 >> $OUT/loss_probe.txt
+rm -rf $OUT/trace_loss
 say "host phases"
 for w in "" "--amp"; do TASEG_BENCH_HOST_PHASES=1 python bench.py --steps 30 --warmup 5 $w --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes|second stream" | sed "s/^/[bench.py $w] /" >> $OUT/host_phases.txt; done
 for t in 0 1; do TASEG_STAGE_THREAD=$t TASEG_BENCH_HOST_PHASES=1 python bench.py --amp --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 > /dev/null | grep -E "host issue|native nodes" | sed "s/^/[bench.py --amp, TASEG_STAGE_THREAD=$t] /" >> $OUT/host_phases.txt; done
