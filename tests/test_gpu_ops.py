@@ -1054,7 +1054,7 @@ def test_lovasz_kernels_match_the_tensor_form_and_the_oracle(p, c, ignore):
         assert float(zero) == 0.0 and float(z.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("p,c,smoothing,half", [(70001, 20, 0.0, False), (4099, 17, 0.1, False), (30000, 20, 0.05, True)])
+@pytest.mark.parametrize("p,c,smoothing,half", [(70001, 20, 0.0, False), (4099, 17, 0.1, False), (30000, 20, 0.05, True), (1100003, 20, 0.0, False)])
 def test_fused_ce_lovasz_loss_matches_the_tensor_form_and_the_oracle(monkeypatch, p, c, smoothing, half):
     """pcseg.loss.Losses on the csrc/loss.hip kernels (softmax + CE + Lovasz errors in one pass, one backward kernel) against
     the same module on tensor ops and against the oracle's CE + Lovasz: value and gradient w.r.t. the logits."""
@@ -1076,7 +1076,10 @@ def test_fused_ce_lovasz_loss_matches_the_tensor_form_and_the_oracle(monkeypatch
     (want * 3.0).backward()
     tol = 2e-3 if half else 3e-6
     assert abs(float(got) - float(want)) <= tol * max(1.0, abs(float(want)))
-    assert float((a.grad.float() - b.grad.float()).abs().max()) <= (2e-3 if half else 1e-4) * float(b.grad.float().abs().max()) + 1e-9
+    # (a million rows: gradients of 1e-6, and equal errors whose order a stable and an unstable sort settle differently - either order is
+    # a valid subgradient, the elements of a tie trade their values)
+    floor = 1e-9 if p < 1000000 else 5e-9
+    assert float((a.grad.float() - b.grad.float()).abs().max()) <= (2e-3 if half else 1e-4) * float(b.grad.float().abs().max()) + floor
     if not half:
         ref = OM.loss_ce_lovasz(logits.cpu(), labels.cpu(), label_smoothing=smoothing)      # weights 1 / 1
         monkeypatch.setattr(LS, "_FUSED", True)
