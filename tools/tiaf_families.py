@@ -11,7 +11,7 @@ FAMILIES = [
     ("UNet2D convolutions (ours: csrc/conv2d_rows.hip - 3x3 up to 96 input channels, 1x1 + LeakyReLU, weight + bias gradients)", r"conv3x3|conv1x1"),
     ("UNet2D LeakyReLU + BatchNorm2d as one node (ours: csrc/bn.hip lbn_*)", r"lbn_"),
     ("UNet2D PixelShuffle + dropout + concat (ours: csrc/shuffle_cat.hip)", r"shuffle_cat"),
-    ("vendor libraries (MIOpen / hipBLASLt / CK): UNet2D layers at 1/4 scale and below, input layer, classifier; the fusion head's GEMMs", r"igemm_|^Cijk_|Custom_Cijk|miopenSp3|grouped_conv|naive_conv|batched_transpose|SubTensorOp|gemm_"),
+    ("vendor libraries (MIOpen / hipBLASLt / CK): UNet2D layers at 1/4 scale and below, input layer, classifier; the fusion head's GEMMs", r"igemm_|^Cijk_|Custom_Cijk|miopenSp3|grouped_conv|naive_conv|batched_transpose|SubTensorOp"),
     ("UNet2D BatchNorm2d (MIOpen / ATen)", r"MIOpenBatchNorm|batch_norm_"),
     ("ATen kernels of the whole step (residual adds, gradient accumulation, LeakyReLU of the wide layers, casts, concatenations, index glue)", r"at::native::|at_cuda_detail"),
     ("UNet2D average pooling (ours, channels-last)", r"avgpool3s2"),
