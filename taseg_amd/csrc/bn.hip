@@ -820,9 +820,7 @@ __global__ __launch_bounds__(256) void lbn_partial_kernel(const T *__restrict__ 
   }
   const int64_t r_beg = (int64_t)blockIdx.x * rows_per_wg, r_end = min(n, r_beg + rows_per_wg);
   if (active) {
-#pragma unroll 2
-    for (int64_t r = r_beg + ty; r < r_end; r += rpp) {
-      const V x = *(const V *)(X + r * c + VE * tx);
+    auto add = [&](const V &x, const V &d) {
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
@@ -831,7 +829,6 @@ __global__ __launch_bounds__(256) void lbn_partial_kernel(const T *__restrict__ 
           s1[i] += a * a;
         }
       } else {
-        const V d = *(const V *)(DY + r * c + VE * tx);
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
           const float dv = (float)d.x[i];
@@ -839,6 +836,27 @@ __global__ __launch_bounds__(256) void lbn_partial_kernel(const T *__restrict__ 
           s1[i] += dv * (lbn_leaky((float)x.x[i], slope) - mu[i]);
         }
       }
+    };
+    // 8 rows per trip, their loads issued together (the sums still in row order): a workgroup walks ~10 k rows of a full-resolution
+    // map with one 16-byte load per thread and row - at one or two in flight per thread the 512 workgroups ran at 2.9 TB/s, the
+    // latency of their loads
+    constexpr int U = 8;
+    int64_t r = r_beg + ty;
+    for (; r + (int64_t)(U - 1) * rpp < r_end; r += (int64_t)U * rpp) {
+      V x[U], d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        x[u] = *(const V *)(X + (r + (int64_t)u * rpp) * c + VE * tx);
+        if (MODE != 0) d[u] = *(const V *)(DY + (r + (int64_t)u * rpp) * c + VE * tx);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) add(x[u], d[u]);
+    }
+    for (; r < r_end; r += rpp) {
+      const V x = *(const V *)(X + r * c + VE * tx);
+      V d = x;
+      if (MODE != 0) d = *(const V *)(DY + r * c + VE * tx);
+      add(x, d);
     }
   }
 #pragma unroll
