@@ -562,21 +562,32 @@ __global__ __launch_bounds__(64 * NCOB * RG) void conv3x3_rows_kernel(const _Flo
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       c2_f16 acc[2] = {init, init};
+      // The 12 (input row, tap column) groups of a row pair, software-pipelined by hand: group g + 1's KB fragments are requested
+      // before group g's MFMAs (left to itself the compiler keeps ONE LDS read ahead of each MFMA, and with one wave on the SIMD the
+      // rest of the read's latency is a stall per MFMA: forward at the up4 shape 0.84 -> 0.71 ms with whole rows requested at once,
+      // -> this form)
+      const _Float16 *xbase = xs + ((row0 + 2 * p) * XW + r) * PITCH + 8 * h;
+      c2_h8 bf[2][KB];
 #pragma unroll
-      for (int ir = 0; ir < 4; ++ir) {                           // input row row0 + 2 p + ir of the staged image
-        const _Float16 *xrow = xs + ((row0 + 2 * p + ir) * XW + r) * PITCH + 8 * h;
+      for (int kb = 0; kb < KB; ++kb) bf[0][kb] = *(const c2_h8 *)(xbase + 16 * kb);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+      for (int g = 0; g < 12; ++g) {
+        const int ir = g / 3, kx = g % 3;                        // input row row0 + 2 p + ir of the staged image, tap column kx
+        if (g + 1 < 12) {
+          const int ir1 = (g + 1) / 3, kx1 = (g + 1) % 3;
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb) {
-            const c2_h8 b = *(const c2_h8 *)(xrow + kx * PITCH + 16 * kb);
+          for (int kb = 0; kb < KB; ++kb) bf[(g + 1) & 1][kb] = *(const c2_h8 *)(xbase + (ir1 * XW + kx1) * PITCH + 16 * kb);
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // (the scheduler would sink each read back to its MFMA)
 #pragma unroll
-            for (int o = 0; o < 2; ++o) {
-              const int ky = ir - o;                             // output row o takes this input row at tap row ky
-              if (ky >= 0 && ky < 3) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kb], b, acc[o], 0, 0, 0);
-            }
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            const int ky = ir - o;                               // output row o takes this input row at tap row ky
+            if (ky >= 0 && ky < 3) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kb], bf[g & 1][kb], acc[o], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       c2_h8 out[2][2];
 #pragma unroll
@@ -798,8 +809,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const _Float16 *__re
         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const c2_h8 a = frag(xrow, PI, 8 * kg + kx, (wa * NI + i) * 16);
-#pragma unroll
+            const c2_h8 a = frag(xrow, PI, 8 * kg + kx, (wa * NI + i) * 16);     // (requesting a tap row's fragments ahead of their
+#pragma unroll                                                                   // MFMAs, as the forward kernel does: no gain here)
             for (int o = 0; o < NO; ++o)
               acc[ky * 3 + kx][i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[o], acc[ky * 3 + kx][i][o], 0, 0, 0);
           }
